@@ -1,0 +1,102 @@
+"""Synthetic scene pieces used by tests, smoke() and bench.py (no dataset exists offline).
+
+* analytic sphere-union-torus triangle mesh,
+* surface points / normals / view directions on it,
+* pinhole rays of an 800x800 TensoSDF-synthetic style camera (dataset/database.py:545-559
+  conventions: camera on a sphere of radius 2 looking at the origin).
+"""
+import math
+
+import numpy as np
+
+
+def uv_sphere(radius=0.5, n_lat=16, n_lon=32, center=(0.0, 0.0, 0.0)):
+    verts = [(0.0, 0.0, radius)]
+    for i in range(1, n_lat):
+        th = math.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * math.pi * j / n_lon
+            verts.append((radius * math.sin(th) * math.cos(ph), radius * math.sin(th) * math.sin(ph),
+                          radius * math.cos(th)))
+    verts.append((0.0, 0.0, -radius))
+    faces = []
+    for j in range(n_lon):
+        faces.append((0, 1 + j, 1 + (j + 1) % n_lon))
+    for i in range(n_lat - 2):
+        r0, r1 = 1 + i * n_lon, 1 + (i + 1) * n_lon
+        for j in range(n_lon):
+            a, b = r0 + j, r0 + (j + 1) % n_lon
+            c, d = r1 + j, r1 + (j + 1) % n_lon
+            faces.append((a, c, d))
+            faces.append((a, d, b))
+    last = len(verts) - 1
+    r0 = 1 + (n_lat - 2) * n_lon
+    for j in range(n_lon):
+        faces.append((last, r0 + (j + 1) % n_lon, r0 + j))
+    v = np.asarray(verts, np.float32) + np.asarray(center, np.float32)
+    return v, np.asarray(faces, np.int32)
+
+
+def torus(R=0.75, r=0.12, n_major=48, n_minor=16, center=(0.0, 0.0, 0.0)):
+    verts, faces = [], []
+    for i in range(n_major):
+        u = 2 * math.pi * i / n_major
+        for j in range(n_minor):
+            w = 2 * math.pi * j / n_minor
+            verts.append(((R + r * math.cos(w)) * math.cos(u), (R + r * math.cos(w)) * math.sin(u), r * math.sin(w)))
+    for i in range(n_major):
+        for j in range(n_minor):
+            a = i * n_minor + j
+            b = ((i + 1) % n_major) * n_minor + j
+            c = ((i + 1) % n_major) * n_minor + (j + 1) % n_minor
+            d = i * n_minor + (j + 1) % n_minor
+            faces.append((a, b, c))
+            faces.append((a, c, d))
+    v = np.asarray(verts, np.float32) + np.asarray(center, np.float32)
+    return v, np.asarray(faces, np.int32)
+
+
+def sphere_torus_mesh(n_lat=16, n_lon=32, n_major=48, n_minor=16):
+    """-> vertices [V,3] f32, triangles [T,3] i32 (outward-facing winding)."""
+    v0, f0 = uv_sphere(0.5, n_lat, n_lon)
+    v1, f1 = torus(0.75, 0.12, n_major, n_minor)
+    return np.concatenate([v0, v1], 0), np.concatenate([f0, f1 + len(v0)], 0)
+
+
+def sphere_surface_points(n, seed=6, radius=0.5, cam_dist=2.0, n_cams=8):
+    """Points on the sphere with analytic normals and view dirs toward one of `n_cams`
+    cameras for which the point is front-facing. -> pts, normals, view_dirs  (f32 [n,3])."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = d * radius
+    k = np.arange(n_cams)
+    cams = np.stack([np.cos(2 * np.pi * k / n_cams) * math.cos(0.5), np.sin(2 * np.pi * k / n_cams) * math.cos(0.5),
+                     np.full(n_cams, math.sin(0.5))], -1) * cam_dist
+    score = d @ cams.T
+    pick = np.argmax(score + rng.uniform(0, 0.3, size=score.shape), axis=-1)
+    view = cams[pick] - pts
+    view /= np.linalg.norm(view, axis=-1, keepdims=True)
+    return pts.astype(np.float32), d.astype(np.float32), view.astype(np.float32)
+
+
+def pinhole_rays(n, seed=2, h=800, w=800, focal=1111.1, cam_dist=2.0, az=0.7, el=0.5):
+    """n random pixels of an h x w pinhole looking at the origin.
+    -> rays_o, rays_d (unit), radiis [n,1], rays_cos [n,1]  (shapeRenderer.py:479-486,510 style)."""
+    rng = np.random.default_rng(seed)
+    idx = rng.permutation(h * w)[:n]
+    py, px = (idx // w).astype(np.float64), (idx % w).astype(np.float64)
+    c = np.array([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)]) * cam_dist
+    fwd = -c / np.linalg.norm(c)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    dx = (px + 0.5 - w / 2) / focal
+    dy = (py + 0.5 - h / 2) / focal
+    dirs = fwd[None] + dx[:, None] * right[None] - dy[:, None] * up[None]
+    nrm = np.linalg.norm(dirs, axis=-1, keepdims=True)
+    cos = 1.0 / nrm
+    dirs = dirs / nrm
+    radii = np.full((n, 1), 1.0 / (focal * math.sqrt(math.pi)))  # sqrt(pixel area / pi)
+    o = np.broadcast_to(c, dirs.shape)
+    return o.astype(np.float32).copy(), dirs.astype(np.float32), radii.astype(np.float32), cos.astype(np.float32)

@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """npz fixture: arrays as torch tensors, `sd/...` entries collected into .sd."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.sd, self.grad, self.out, self.a = {}, {}, {}, {}
+        for k in z.files:
+            t = torch.from_numpy(z[k])
+            if k.startswith("sd/"):
+                self.sd[k[3:]] = t
+            elif k.startswith("grad/"):
+                self.grad[k[5:]] = t
+            elif k.startswith("out/"):
+                self.out[k[4:]] = t
+            else:
+                self.a[k] = t
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return load
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|, 1) -- the 'relative fp32' measure used throughout."""
+    a, b = a.double(), b.double()
+    return float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) if a.numel() else 0.0
+
+
+AABB = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])

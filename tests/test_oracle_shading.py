@@ -1,0 +1,51 @@
+"""Oracle MC-shading restatement vs golden vectors produced by the imported reference
+(MCShadingNetwork.forward, eval, step=None: one pass with the fixed samplers, one with the flows)."""
+import pytest
+import torch
+
+from conftest import AABB, rel_err
+from oracle import shading as osh
+
+
+def _tracer(g):
+    tri = g["verts"][g["faces"].long()]
+    return osh.MeshTracer(tri)
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_shade_fixed_and_flow(golden, tag):
+    g = golden("shading_" + tag)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    tr = _tracer(g)
+    unit = float(g["unit_size"])
+    fixed = osh.shade(g.sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s,
+                      n_fixed_diffuse=n_fd, n_fixed_specular=n_fs, use_flow=False)
+    assert rel_err(fixed["metallic"], g.out["metallic"]) < 1e-6
+    assert rel_err(fixed["roughness"], g.out["roughness"]) < 1e-6
+    assert rel_err(fixed["albedo"], g.out["albedo"]) < 1e-6
+    assert rel_err(fixed["colors"], g["colors"]) < 2e-5
+    assert rel_err(fixed["visibility"], g.out["visibility"]) < 1e-6
+    assert rel_err(fixed["indirect_light"], g.out["indirect_light"]) < 2e-5
+    assert rel_err(fixed["diffuse_light"], g.out["diffuse_light"]) < 2e-5
+    assert rel_err(fixed["specular_light"], g.out["specular_light"]) < 2e-5
+    flow = osh.shade(g.sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s,
+                     n_fixed_diffuse=n_fd, n_fixed_specular=n_fs, use_flow=True)
+    assert rel_err(flow["colors"], g.out["rgb_pr_nis"]) < 5e-5
+    assert rel_err(flow["visibility"], g.out["visibility_nis"]) < 1e-6
+    assert rel_err(flow["indirect_light"], g.out["indirect_light_nis"]) < 5e-5
+    assert rel_err(flow["diffuse_light"], g.out["diffuse_light_nis"]) < 5e-5
+    assert rel_err(torch.clamp(osh.linear_to_srgb(flow["diffuse_lin"]), 0, 1), g.out["diffuse_color_nis"]) < 5e-5
+    assert rel_err(torch.clamp(osh.linear_to_srgb(flow["specular_lin"]), 0, 1), g.out["specular_color_nis"]) < 5e-5
+
+
+def test_env_and_lights(golden):
+    g = golden("shading_small")
+    got = osh.env_direct_light(g.sd["outer_light.base"], g["env_dirs"])
+    assert rel_err(got, g["env_direct"]) < 1e-6
+    tr = _tracer(g)
+    pts = g["pts"].repeat_interleave(4, 0)
+    lights, hit, inters = osh.get_lights(g.sd, tr, float(g["unit_size"]), pts, g["env_dirs"])
+    assert torch.equal(hit, g["gl_hit"].bool())
+    assert 0.02 < hit.float().mean() < 0.98          # both branches exercised
+    assert rel_err(lights, g["gl_lights"]) < 1e-5
+    assert rel_err(inters, g["gl_inters"]) < 1e-6

@@ -1,0 +1,231 @@
+"""Generate golden fixtures under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Build-container only (needs /root/reference).  It imports the reference's own classes
+through tools/ref_shim.py (stub modules for absent third-party packages, cuda->cpu
+rewriting) and records seeded inputs, the reference `state_dict`s and the reference outputs
+as small .npz files.  Nothing of the reference's source is stored -- only numbers.
+
+The third-party ops the reference calls (dr.texture, segment_coo, nerfacc scan, BVH) are
+served by the oracle's restatements (see oracle/__init__.py: parity unpinned there).
+
+    python tools/gen_golden.py            # regenerate everything
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+AABB = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, sd=None, **arrays):
+    flat = {k: _np(v) for k, v in arrays.items() if v is not None}
+    if sd is not None:
+        for k, v in sd.items():
+            flat["sd/" + k] = _np(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(flat)} arrays")
+
+
+def perturb_(params, scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in params:
+            p.add_(scale * torch.randn(p.shape, generator=g))
+
+
+def gen_tensosdf():
+    from network.fields import TensoSDF
+    for tag, R, nlev in (("r32_l1", 32, 1), ("r32_l3", 32, 3), ("r24x32x40_l3", (24, 32, 40), 3)):
+        torch.manual_seed(6033)
+        gs = torch.tensor([R] * 3 if isinstance(R, int) else list(R))
+        net = TensoSDF(gs, AABB, device="cpu", sdf_n_comp=36, sdf_dim=256, app_dim=128,
+                       init_n_levels=nlev, sdf_multires=0)
+        perturb_(list(net.sdf_plane) + list(net.sdf_line), 0.05, 1)
+        net.eval()
+        g = torch.Generator().manual_seed(11)
+        pts = torch.rand(384, 3, generator=g) * 2.4 - 1.2          # incl. out-of-aabb
+        pts[:8] = torch.tensor([[-1., -1, -1], [1, 1, 1], [0, 0, 0], [1, -1, 0.5], [-1.0001, 0.3, 1.0001],
+                                [0.999, 0.999, -0.999], [0.5, 0.5, 0.5], [-0.25, 0.75, 0]])
+        level = torch.rand(384, 1, generator=g) * 4 - 1            # U(-1,3): exercises both clamps
+        level[8:16, 0] = torch.tensor([0.0, 1.0, 2.0, 0.5, 1.5, 2.5, -0.5, 3.5])
+        with torch.no_grad():
+            out_none = net(pts, None)
+            out_lvl = net(pts, level)
+            sdf = out_lvl[..., :1]
+            grad, nh = net.gradient(pts, level, training=True, sdf=sdf)
+            grad0, _ = net.gradient(pts, None, training=False)
+        # backward golden: d(sum(out*w))/d(params)
+        w = torch.randn(out_lvl.shape, generator=g)
+        net.zero_grad()
+        (net(pts, level) * w).sum().backward()
+        grads = {"grad/" + k: p.grad for k, p in net.named_parameters()}
+        save(f"tensosdf_{tag}", sd=net.state_dict(), pts=pts, level=level, out_none=out_none, out_lvl=out_lvl,
+             grad_lvl=grad, normal_hessian=nh, grad_none=grad0, grid_size=gs, n_levels=np.int32(nlev),
+             units=net.units, bwd_w=w, **grads)
+
+
+def gen_pwquad():
+    from network.flow import ElementWisePWQuadraticTransform
+    t = ElementWisePWQuadraticTransform()
+    g = torch.Generator().manual_seed(21)
+    M = 2048
+    wv = torch.randn(M, 1, 21, generator=g) * 1.5
+    y = torch.rand(M, 1, generator=g)
+    # edge cases: y -> 0/1, equal v, tiny / huge w
+    y[:8, 0] = torch.tensor([1e-6, 1 - 1e-6, 0.5, 1e-3, 0.999, 0.25, 0.75, 0.1])
+    wv[8:16, 0, :11] = 0.3
+    wv[16:24, 0, 11:] = torch.tensor([-12.0, 0, 0, 0, 0, 0, 0, 0, 0, 6.0])
+    wv[24:32] = 0.0
+    x, lj = t.flow(y, wv, True)
+    # bins: recompute with the same public function outputs by calling on detached clones is not
+    # possible (bins are internal) -> bins are checked through the oracle (tests) only.
+    out, lji = t.flow_inv(y, wv, True)
+    save("pwquad", wv=wv[:, 0], y=y[:, 0], inv_x=x[:, 0], inv_logj=lj[:, 0], fwd_out=out[:, 0], fwd_logj=lji[:, 0])
+
+
+def make_flow(R=32, seed=4):
+    from network.flow import TensoFlow
+    torch.manual_seed(seed)
+    net = TensoFlow(2, AABB, device="cpu", gridSize=[R, R, R])
+    perturb_(list(net.nis_plane) + list(net.nis_line), 0.1, 3)
+    # make the coupling nets non-trivial but tame
+    perturb_([p for n, p in net.flows.named_parameters() if "weight" in n], 0.05, 5)
+    net.eval()
+    return net
+
+
+def gen_flow():
+    net = make_flow()
+    g = torch.Generator().manual_seed(31)
+    pn = 48
+    pts = torch.rand(pn, 3, generator=g) * 1.6 - 0.8
+    va = torch.rand(pn, 2, generator=g)
+    rough = torch.rand(pn, 1, generator=g)
+    arrays = dict(pts=pts, view_angles=va, roughness=rough)
+    with torch.no_grad():
+        arrays["cond_feat"] = net.tenso_feature(pts)
+        for sn in (8, 32, 128):
+            lat, lat_logj = net.latent_prior((pn, sn))
+            ang, logj = net.sample(pts, va, rough, sn, return_jacobian=True)
+            z, logq = net(pts, va, rough, ang, return_jacobian=True)
+            arrays.update({f"latent_{sn}": lat[0], f"latent_logj_{sn}": lat_logj[0], f"angles_{sn}": ang,
+                           f"logj_{sn}": logj, f"z_{sn}": z, f"logq_{sn}": logq})
+        # arbitrary x (not produced by the flow) + rays_id gather form
+        x = torch.rand(pn, 16, 2, generator=g)
+        z, logq = net(pts, va, rough, x, return_jacobian=True)
+        rid = torch.sort(torch.randint(0, pn, (300,), generator=g)).values
+        xr = torch.rand(300, 2, generator=g)
+        zr, logqr = net(pts, va, rough, xr, return_jacobian=True, rays_id=rid)
+        arrays.update(x_rand=x, z_rand=z, logq_rand=logq, rays_id=rid, x_rid=xr, z_rid=zr, logq_rid=logqr)
+    # backward golden of the NIS-style loss  -(w * logq).mean()
+    w = torch.rand(pn, 16, 1, generator=g)
+    net.zero_grad()
+    z, logq = net(pts, va, rough, x, return_jacobian=True)
+    (-(w * logq).mean()).backward()
+    grads = {"grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    save("tensoflow_r32", sd=net.state_dict(), bwd_w=w, **arrays, **grads)
+
+
+def gen_encodings():
+    from utils.network_utils import get_embedder
+    from utils.ref_utils import generate_ide_fn
+    from utils.raw_utils import linear_to_srgb
+    g = torch.Generator().manual_seed(41)
+    x3 = torch.randn(64, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+    lin = torch.cat([torch.rand(60, generator=g) * 2, torch.tensor([0.0, 0.0031308, 1e-9, 5.0])])
+    arr = dict(x3=x3, dirs=d, lin=lin, srgb=linear_to_srgb(lin))
+    for nf in (3, 6, 8):
+        e, _ = get_embedder(nf, 3)
+        arr[f"posenc{nf}"] = e(x3)
+    ide = generate_ide_fn(5)
+    arr["ide5"] = ide(d, 0)
+    arr["ide5_rough"] = ide(d, torch.rand(64, 1, generator=g))
+    save("encodings", **arr)
+
+
+def small_mesh():
+    from tensoflow_amd.synth import sphere_torus_mesh
+    return sphere_torus_mesh(n_lat=8, n_lon=12, n_major=16, n_minor=8)
+
+
+def gen_shading():
+    """MCShadingNetwork.forward (eval, step=None => fixed-sampler pass + flow-sampler pass)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, o + 2 * unit * d, d)
+    for tag, cfg, pn in (
+        ("small", dict(diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+                       nis_specular_sample_num=8), 48),
+        ("default", dict(), 6),
+    ):
+        torch.manual_seed(4)
+        cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+                   gridSize=[R, R, R], light_reso=16, **cfg)
+        net = MCShadingNetwork(cfg, trace, AABB)
+        # small material planes (the 512^2 default would make a 113 MB fixture)
+        g = torch.Generator().manual_seed(3)
+        net.mat_plane = torch.nn.ParameterList(
+            [torch.nn.Parameter(0.3 * torch.randn(1, 36, R, R, generator=g)) for _ in range(3)])
+        net.mat_line = torch.nn.ParameterList(
+            [torch.nn.Parameter(0.5 + 0.3 * torch.randn(1, 36, R, 1, generator=g)) for _ in range(3)])
+        for fl in (net.flow_diffuse, net.flow_specular, net.flow_diffuse_copy, net.flow_specular_copy):
+            perturb_(list(fl.nis_plane) + list(fl.nis_line), 0.1, 3)
+            perturb_([p for n, p in fl.flows.named_parameters() if "weight" in n], 0.05, 5)
+        with torch.no_grad():
+            net.outer_light.base.add_(0.5 * torch.randn(net.outer_light.base.shape, generator=g))
+        net.eval()
+        pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=6)]
+        # un-normalised inputs: forward() normalises them itself
+        view_in, nrm_in = view * 1.7, nrm * 0.6
+        with torch.no_grad():
+            colors, outputs = net(pts, view_in, nrm_in, None, None, False)
+            dirs = torch.nn.functional.normalize(torch.randn(pn * 4, 3, generator=g), dim=-1)
+            direct = net.outer_light.direct_light(dirs)
+            lights, _, inters, lnrm, hit = net.get_lights(pts.repeat_interleave(4, 0)[:, None], dirs[:, None], None)
+        keep = ("albedo", "roughness", "metallic", "diffuse_light", "specular_light", "diffuse_color",
+                "specular_color", "visibility", "indirect_light", "rgb_pr_nis", "diffuse_color_nis",
+                "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis",
+                "specular_light_nis")
+        arr = {"out/" + k: outputs[k] for k in keep}
+        save(f"shading_{tag}", sd=net.state_dict(), pts=pts, view_in=view_in, normals_in=nrm_in, colors=colors,
+             verts=verts, faces=faces, unit_size=np.float32(unit), env_dirs=dirs, env_direct=direct,
+             gl_lights=lights[:, 0], gl_hit=hit[:, 0], gl_inters=inters[:, 0],
+             sn=np.array([cfg["diffuse_sample_num"] if "diffuse_sample_num" in cfg else 512,
+                          cfg.get("specular_sample_num", 256), cfg.get("nis_diffuse_sample_num", 64),
+                          cfg.get("nis_specular_sample_num", 32)], np.int32), **arr)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march"]
+    with ref_shim.reference():
+        for w in which:
+            globals()["gen_" + w]()
+
+
+if __name__ == "__main__":
+    main()
