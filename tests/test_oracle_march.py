@@ -1,0 +1,53 @@
+"""Oracle ray-march restatement vs golden vectors produced by the imported reference
+(ShapeRenderer.sample_ray / compute_sdf_alpha / render_core / ShapeShadingNetwork.forward)."""
+import torch
+
+from conftest import AABB, rel_err
+from oracle import march as om
+
+GS = torch.tensor([32, 32, 32])
+
+
+def _env(g):
+    return dict(diffuse=g["env_diffuse"], specular=[g["env_spec0"], g["env_spec1"], g["env_spec2"]])
+
+
+def test_sample_ray_indices_bit_exact(golden):
+    g = golden("march_r32")
+    t0, t1, ridx = om.sample_ray(g.sd, g["rays_o"], g["dirs"], g["near"], g["far"], g["radiis"], g["rays_cos"],
+                                 AABB, GS, 3, float(g["base_radii"]))
+    assert torch.equal(ridx, g["ray_indices"])                 # int64, bit-exact
+    assert rel_err(t0, g["t_starts"]) < 1e-6 and rel_err(t1, g["t_ends"]) < 1e-6
+
+
+def test_sdf_alpha(golden):
+    g = golden("march_r32")
+    ridx = g["ray_indices"]
+    dists = g["t_ends"] - g["t_starts"]
+    for ca in (0.0, 0.5, 1.0):
+        alpha, grad, feat, inv_s, sdf, nh = om.sdf_alpha(g.sd, g["sample_pts"], g["sample_levels"], dists,
+                                                         g["dirs"][ridx], ca, AABB, GS, 3)
+        assert rel_err(alpha, g[f"alpha_{ca}"]) < 1e-5
+    assert rel_err(grad, g["sa_grad"]) < 1e-5 and rel_err(feat, g["sa_feat"]) < 1e-5
+    assert rel_err(sdf, g["sa_sdf"]) < 1e-6 and rel_err(nh, g["sa_hess"]) < 1e-4
+    assert rel_err(inv_s, g["sa_inv_s"]) < 1e-6
+
+
+def test_shape_shading(golden):
+    g = golden("march_r32")
+    ridx = g["ray_indices"]
+    nrm = torch.nn.functional.normalize(g["sa_grad"], dim=-1)
+    col, occ, rough, refl = om.shape_shade(g.sd, _env(g), g["fg_lut"], g["sample_pts"], nrm, -g["dirs"][ridx], g["sa_feat"])
+    assert rel_err(col, g["shade_color"]) < 2e-5
+    assert rel_err(occ, g["shade_occ_prob"]) < 1e-5
+    assert rel_err(rough, g["shade_roughness"]) < 1e-6
+    assert rel_err(refl, g["shade_reflective"]) < 1e-6
+
+
+def test_render_core(golden):
+    g = golden("march_r32")
+    out = om.render_core(g.sd, _env(g), g["fg_lut"], g["rays_o"], g["dirs"], g["radiis"], g["rays_cos"],
+                         g["t_starts"], g["t_ends"], g["ray_indices"], AABB, GS, 3, float(g["base_radii"]), 0.5)
+    for k in ("ray_rgb", "acc", "normal", "gradient_error", "std", "loss_sparse"):
+        assert rel_err(out[k], g["rc/" + k]) < 2e-5, k
+    assert rel_err(out["loss_hessian"], g["rc/loss_hessian"]) < 1e-4

@@ -219,6 +219,65 @@ def gen_shading():
                           cfg.get("nis_specular_sample_num", 32)], np.int32), **arr)
 
 
+def gen_march():
+    """ShapeRenderer.sample_ray / compute_sdf_alpha / render_core (shapeRenderer.py:871,995,1105)."""
+    from network.shapeRenderer import ShapeRenderer
+    from tensoflow_amd.synth import pinhole_rays
+    R = 32
+    cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
+               isBGWhite=True, has_radiance_field=False, clip_sample_variance=False, apply_occ_loss=True,
+               occ_loss_step=10000, device="cpu", database_name="tensoSDF/compressor", nerfDataType=True,
+               apply_gaussian_loss=False, inv_s_init=0.3)
+    torch.manual_seed(6033)
+    r = ShapeRenderer(cfg, training=False)
+    net = r.sdf_network
+    perturb_(list(net.sdf_plane) + list(net.sdf_line), 0.02, 1)
+    g = torch.Generator().manual_seed(7)
+    cn = r.color_network
+    perturb_([p for n, p in cn.named_parameters() if "original1" in n], 0.05, 9)
+    # injected pre-filtered environment (EnvLight.build_mips needs the CUDA renderutils plugin)
+    spec = [0.5 * torch.randn(6, s, s, 3, generator=g) - 0.7 for s in (16, 8, 4)]
+    diff = 0.5 * torch.randn(6, 4, 4, 3, generator=g) - 0.7
+    cn.envlight.specular, cn.envlight.diffuse = spec, diff
+    u = torch.linspace(0, 1, 32)
+    lut = torch.stack(torch.meshgrid(u, u, indexing="ij"), -1)
+    cn.FG_LUT = torch.stack([0.9 * (1 - lut[..., 1]) * lut[..., 0] + 0.05, 0.1 * (1 - lut[..., 0]) ** 2], -1)[None].contiguous()
+    r.eval()
+    rn = 96
+    o, d, radii, cos = [torch.from_numpy(a) for a in pinhole_rays(rn, seed=2)]
+    near, far = r.near_far_from_sphere(o, d)
+    arr = dict(rays_o=o, dirs=d, radiis=radii, rays_cos=cos, near=near, far=far)
+    with torch.no_grad():
+        t0, t1, ridx = r.sample_ray(o, d, near, far, 0, radiis=radii, rays_cos=cos)
+    arr.update(t_starts=t0, t_ends=t1, ray_indices=ridx)
+    mid = (t0 + t1) * 0.5
+    pts = o[ridx] + d[ridx] * mid[:, None]
+    lv = torch.log2(r.compute_ball_radii(mid[:, None], radii[ridx], cos[ridx]) / r.base_radii)
+    arr.update(sample_pts=pts, sample_levels=lv)
+    with torch.no_grad():
+        for ca in (0.0, 0.5, 1.0):
+            alpha, grad, feat, inv_s, sdf, hess = r.compute_sdf_alpha(pts, lv, t1 - t0, d[ridx], ca, 100, True)
+            arr.update({f"alpha_{ca}": alpha})
+        arr.update(sa_grad=grad, sa_feat=feat, sa_inv_s=inv_s, sa_sdf=sdf, sa_hess=hess)
+        hp = torch.zeros(rn, 3, 4)
+        out = r.render_core(o, d, d, radii, cos, t0, t1, ridx, hp, cos_anneal_ratio=0.5, step=100, is_train=True)
+        for k in ("ray_rgb", "acc", "normal", "gradient_error", "std", "loss_sparse", "loss_hessian", "loss_tv_sdf"):
+            arr["rc/" + k] = out[k]
+        col, _, occ = cn(pts, torch.nn.functional.normalize(grad, dim=-1), -d[ridx], feat, hp[ridx], step=100)
+        arr.update(shade_color=col, shade_occ_prob=occ["occ_prob"], shade_roughness=occ["roughness"],
+                   shade_reflective=occ["reflective"])
+    # backward of the rendered colour / acc wrt every parameter that receives a gradient
+    w = torch.rand(rn, 3, generator=g)
+    r.zero_grad()
+    out = r.render_core(o, d, d, radii, cos, t0, t1, ridx, hp, cos_anneal_ratio=0.5, step=100, is_train=True)
+    ((out["ray_rgb"] * w).sum() + out["acc"].sum() + 0.1 * out["gradient_error"].mean()).backward()
+    grads = {"grad/" + k: p.grad for k, p in r.named_parameters() if p.grad is not None and "envlight" not in k}
+    sd = {k: v for k, v in r.state_dict().items() if "FG_LUT" not in k and "envlight.base" not in k and "gaussian" not in k
+          and "outer_light" not in k}
+    save("march_r32", sd=sd, bwd_w=w, fg_lut=cn.FG_LUT, env_diffuse=diff, env_spec0=spec[0], env_spec1=spec[1],
+         env_spec2=spec[2], step_size=r.stepSize, base_radii=r.base_radii, **arr, **grads)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march"]
