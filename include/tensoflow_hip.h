@@ -1,0 +1,230 @@
+/*
+ * tensoflow_hip.h -- C ABI of libtensoflow_hip.so (MI355X / gfx950).
+ *
+ * The reference (fudan-zvg/tensoflow) has no FFI for its hot path: it is PyTorch modules
+ * calling third-party CUDA extensions.  Its only native-boundary pattern is
+ * network/renderutils/ops.py:391-425 (autograd.Function -> pybind op of a JIT extension).
+ * This header is the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md).
+ * Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory (inputs, outputs, workspaces); nothing is retained;
+ *   - work is enqueued on `stream` (a hipStream_t) and returns without synchronising;
+ *   - return 0 on success, negative TfStatus otherwise; message via tf_last_error()
+ *     (thread-local); no C++ exception crosses the boundary;
+ *   - all floating point is fp32, indices int64 (torch.long) unless stated.
+ */
+#ifndef TENSOFLOW_HIP_H
+#define TENSOFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tf_stream_t; /* hipStream_t */
+
+typedef enum TfStatus {
+  TF_OK = 0,
+  TF_EINVAL = -1, /* null pointer / bad flag */
+  TF_ESHAPE = -2, /* sizes inconsistent with what the kernel and its grid assume */
+  TF_EHIP = -3    /* a HIP runtime call failed */
+} TfStatus;
+
+int tf_version(void);
+const char* tf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * VM-decomposed tensorial field (3 planes + 3 lines, C components each).
+ * Replaces the 6 x dr.texture(...) + permute/contiguous + per-call mip rebuild of
+ * network/fields.py:262-291 (TensoSDF), :776-806 (material field), network/flow.py:709-738.
+ *
+ * Packed pyramid layout in HBM (floats), built once per optimizer step by tf_vm_pack_fwd:
+ *   for i in 0..2: for l in 0..n_levels-1:  plane_i level l  as [H>>l][W>>l][C]   (channel-last,
+ *   one texel = C*4 contiguous bytes), then for i: for l: line_i level l as [L>>l][C].
+ * Plane i is addressed with u = xyz[mat_mode[i][0]] along W and v = xyz[mat_mode[i][1]] along H
+ * (mat_mode = {0,1},{0,2},{1,2}); line i with xyz[vec_mode[i]] (vec_mode = 2,1,0).
+ * Sizes > 1 must be divisible by 2^(n_levels-1).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfVmDesc {
+  int32_t C;        /* components per plane/line (36 sdf/material, 12 flow) */
+  int32_t n_levels; /* mip levels incl. level 0 (1..4) */
+  int32_t ph[3];    /* plane heights at level 0 (v axis) */
+  int32_t pw[3];    /* plane widths  at level 0 (u axis) */
+  int32_t ll[3];    /* line lengths  at level 0 */
+} TfVmDesc;
+
+size_t tf_vm_packed_floats(const TfVmDesc* d);
+
+/* planes[i]: [C,H,W] (the reference's nn.Parameter [1,C,H,W]); lines[i]: [C,L] ([1,C,L,1]). */
+int tf_vm_pack_fwd(const TfVmDesc* d, const float* const planes[3], const float* const lines[3],
+                   float* packed, tf_stream_t stream);
+/* adjoint of tf_vm_pack_fwd: folds the pyramid gradient back to [C,H,W] / [C,L] (overwrites). */
+int tf_vm_pack_bwd(const TfVmDesc* d, const float* gpacked, float* const gplanes[3],
+                   float* const glines[3], tf_stream_t stream);
+
+/* feat[n, i*C + c] = plane_i(c) * line_i(c) at xyz[n]; level may be NULL (== 0).
+ * aabb_host: 6 floats (min xyz, max xyz), contraction of utils/network_utils.py:90-91. */
+int tf_vm_gather_fwd(const TfVmDesc* d, const float* packed, const float* xyz, const float* level,
+                     const float* aabb_host, int64_t n, float* feat, tf_stream_t stream);
+/* gpacked += d feat / d packed (float atomics; zero it first). */
+int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const float* xyz, const float* level,
+                     const float* aabb_host, int64_t n, const float* gfeat, float* gpacked,
+                     tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TensoSDF decoder: cat[feat(3C), xyz(3)] -> Linear(3C+3, Hd) -> Softplus(beta=100) ->
+ * Linear(Hd, 1+A)   (network/fields.py:78-81, :293-299).  Weights in torch layout.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfSdfMlp {
+  const float* w1; /* [Hd, 3C+3] */
+  const float* b1; /* [Hd] */
+  const float* w2; /* [1+A, Hd] */
+  const float* b2; /* [1+A] */
+  int32_t hidden;  /* Hd (256) */
+  int32_t app_dim; /* A (128) */
+} TfSdfMlp;
+
+/* Device scratch (floats) the two SDF entry points need for fragment-ordered weights. */
+size_t tf_sdf_workspace_floats(void);
+
+/* TensoSDF.forward (fields.py:262-299), returned split the way every caller slices it
+ * (fields.py:148-152): sdf [n] = out[:,0], feat [n,A] = out[:,1:] (feat may be NULL: sdf only).
+ * This build instantiates C = 36, Hd = 256, A = 128 (configs/shape/syn/compressor.yaml:64-66). */
+int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* xyz,
+                   const float* level, const float* aabb_host, int64_t n, float* sdf, float* feat,
+                   float* workspace, size_t workspace_floats, tf_stream_t stream);
+
+/* ShapeRenderer.compute_sdf_alpha (shapeRenderer.py:995-1025) = forward + 6-tap central
+ * differences (fields.py:227-260) + NeuS alpha.  units_host[3] = aabbSize/(R-1).
+ * Outputs: alpha[n], grad[n,3], feat[n,A] (may be NULL), sdf[n], nhess[n] (normal_hessian; may be NULL). */
+int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
+                     const float* level, const float* dists, const float* dirs, const float* aabb_host,
+                     const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha,
+                     float* grad, float* feat, float* sdf, float* nhess, float* workspace,
+                     size_t workspace_floats, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Packed-ray compositing: nerfacc.render_weight_from_alpha + accumulate_along_rays
+ * (call sites network/shapeRenderer.py:1166-1206).  ray_indices sorted ascending.
+ *   weights[i] = alpha[i] * prod_{j<i, same ray}(1-alpha[j]);  acc[r] = sum w;  out[r,:] = sum w*values
+ * ------------------------------------------------------------------------------------------ */
+int tf_composite_fwd(const float* alpha, const int64_t* ray_indices, const float* values, int64_t n,
+                     int64_t n_rays, int32_t k, float* weights, float* acc, float* out,
+                     tf_stream_t stream);
+/* gradients wrt alpha and values given g_acc[n_rays], g_out[n_rays,k] (either may be NULL). */
+int tf_composite_bwd(const float* alpha, const int64_t* ray_indices, const float* values,
+                     const float* weights, const float* g_acc, const float* g_out, int64_t n,
+                     int64_t n_rays, int32_t k, float* g_alpha, float* g_values, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TensoFlow coupling flow ('pwquad', 2 blocks, n_bins = 10): network/flow.py:314-525, :549-641,
+ * :766-855.  Net k (flows.k.nn.{1,3,5,7}): Linear 44->64->64->64->21, LeakyReLU(0.01), input
+ * Reshift(2,-1).  cond [pn,37] = [nis feature 16 | embed3(view_angles) 14 | 0 x 7].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfCouplingNet {
+  const float* w[4]; /* [64,44] [64,64] [64,64] [21,64] */
+  const float* b[4];
+} TfCouplingNet;
+
+/* Device scratch (floats) both flow entry points need: fragment-ordered weights + the per-point
+ * hoisted layer-1 vectors [2,pn,64]. */
+size_t tf_flow_workspace_floats(int64_t pn);
+
+/* TensoFlow.sample(..., return_jacobian=True) given the condition vectors.
+ * latent [sn,2] = SphereSampler set (flow.py:62-76); jitter [pn,sn] or NULL (training azimuth noise).
+ * Outputs angles [pn,sn,2], logj [pn,sn]; bins [pn,sn,2] int32 or NULL (spline bin per block). */
+int tf_flow_sample_fwd(const TfCouplingNet nets[2], const float* cond, const float* latent,
+                       const float* jitter, int64_t pn, int32_t sn, float* angles, float* logj,
+                       int32_t* bins, float* workspace, size_t workspace_floats, tf_stream_t stream);
+
+/* TensoFlow.forward(..., return_jacobian=True): x [m,2]; row r uses cond[rays_id[r]] or, when
+ * rays_id is NULL, cond[r / sn].  Outputs z [m,2], logq [m]; bins [m,2] int32 or NULL. */
+int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float* x,
+                     const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, float* z, float* logq,
+                     int32_t* bins, float* workspace, size_t workspace_floats, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Environment light: EnvLight.direct_light (network/light.py:125-162) = exp(bilinear cube lookup
+ * of the log-radiance cubemap base [6,R,R,3]) with seam-crossing taps.
+ * ------------------------------------------------------------------------------------------ */
+int tf_cube_lookup_fwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                       float* out, tf_stream_t stream);
+/* g_base += d out/d base (atomics; zero first); out = forward result (needed when apply_exp). */
+int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                       const float* g_out, float* g_base, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * First-hit ray/mesh intersection: raytracing.RayTracer.trace (raytracing/raytracer.py:19-54) +
+ * MaterialRenderer.trace post-processing (network/materialRenderer.py:253-263).
+ * The BVH is built on the host (tf_bvh_build_host) and uploaded by the caller.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfBvhNode { /* 32 bytes */
+  float lo[3];
+  int32_t left;  /* inner: index of left child (right = left+1); leaf: first triangle */
+  float hi[3];
+  int32_t count; /* 0 = inner node, >0 = leaf with `count` triangles */
+} TfBvhNode;
+
+/* verts_host [nv,3], faces_host [nf,3] -> nodes_host (capacity 2*nf), tris_host [nf,9] reordered
+ * triangle soup (a,b,c); returns number of nodes (>0) or a negative TfStatus. */
+int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const int32_t* faces_host, int64_t nf,
+                          TfBvhNode* nodes_host, float* tris_host);
+
+/* o,d [m,3] -> pos [m,3] (= origin + depth*d), nrm [m,3] (= normalize(-face_normal), 0 on a miss),
+ * depth [m] (10.0 on a miss), hit [m] uint8 (depth < 10); pos/nrm/hit may be NULL.
+ * origin = (o + d*origin_offset0) + origin_offset1*d, the two roundings of the reference's
+ * `p + 1e-5 d` (fields.py:955) followed by `o + 2*unit_size*d` (materialRenderer.py:223); pass 0,0 for
+ * a plain trace. */
+int tf_bvh_trace(const TfBvhNode* nodes, const float* tris, int64_t n_nodes, const float* o, const float* d,
+                 float origin_offset0, float origin_offset1, int64_t m, float* pos, float* nrm, float* depth,
+                 uint8_t* hit, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic small MLP on rows (weight-norm already folded by the caller): used for the inner-light
+ * net of MCShadingNetwork.get_inner_lights (network/fields.py:905-911: pos_enc8 + IDE5 -> 123 ->
+ * 256 -> 256 -> 256 -> 3, exp(min(x, exp_max))).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfMlp4 {
+  const float* w[4]; /* [256,123] [256,256] [256,256] [3,256] */
+  const float* b[4];
+} TfMlp4;
+size_t tf_inner_light_workspace_floats(void);
+/* pts/view/nrm [m,3] (hit position, direction back along the ray = -d, surface normal) -> out [m,3]. */
+int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm,
+                       int64_t m, float exp_max, float* out, float* workspace, size_t workspace_floats,
+                       tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Monte-Carlo shading integral, MCShadingNetwork.shade_mixed (network/fields.py:1075-1235),
+ * eval path with the flow samplers active (use_half_* = True, human lights off).
+ *
+ * tf_shade_dirs: per point builds the tangent frame (fields.py:812-822), turns the flow samples
+ *   (half-vector angles in [0,1]^2 + logq) and the fixed cosine set (fields.py:824-856) into
+ *   outgoing directions, pdfs and per-direction BRDF weights.  Slot layout per point, T = sd+nf+ss:
+ *     [0,sd) flow diffuse | [sd,sd+nf) fixed diffuse | [sd+nf,T) flow specular.
+ *   dirs [pn,T,3]; wgt [pn,T,3] = (BRDF weight / max(pdf,1e-6)) / count  (0 for masked specular);
+ *   spec_mask [pn,ss] uint8 = dot(dir, n) > 0 (fields.py:1209).
+ * tf_shade_reduce: colors [pn,3] = linear_to_srgb(sum_t wgt*light) (fields.py:1230-1231) plus the
+ *   linear diffuse / specular sums.
+ * ------------------------------------------------------------------------------------------ */
+int tf_view_angles(const float* normals, const float* view, int64_t pn, float* view_angles,
+                   tf_stream_t stream);
+/* fixed_d [nf,2] = (azimuth/2pi, 1-2*elevation/pi) of the Fibonacci set (fields.py:734-737);
+ * az_jitter [pn] in [0,1) = the training-mode random azimuth (fields.py:837-838) or NULL. */
+int tf_shade_dirs(const float* normals, const float* view, const float* metallic, const float* roughness,
+                  const float* albedo, const float* ang_d, const float* logq_d, int32_t sd,
+                  const float* fixed_d, const float* az_jitter, int32_t nf, const float* ang_s,
+                  const float* logq_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
+                  tf_stream_t stream);
+/* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
+int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
+                    float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSOFLOW_HIP_H */

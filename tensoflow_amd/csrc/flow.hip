@@ -1,0 +1,354 @@
+// TensoFlow coupling flow ('pwquad'): fused sampler and density kernels.
+// Replaces TensoFlow.flow / flow_inv + Block.flow / flow_inv + ElementWisePWQuadraticTransform
+// (network/flow.py:314-525, :549-641, :766-799, :801-855) -- ~30 tiny PyTorch kernels per block and
+// a [pn*sn, 44] activation round trip per layer in the reference -- by ONE launch:
+//   * rows (point, sample) sit on MFMA columns; the two 44-64-64-64-21 nets run as fp32 MFMA
+//     (mfma_mlp.h) with all fragment-ordered weights resident in LDS (86 KB per workgroup);
+//   * the 37 per-point condition inputs of layer 1 are hoisted into a per-point vector
+//     P[pn,64] (one small pre-pass), so layer 1 costs 8 instead of 44 k-steps per sample;
+//   * the spline (normalisation, bin search, quadratic solve / evaluation, log-det) is evaluated
+//     in registers in the order of operations of the reference so bin indices agree.
+// Bound: fp32 MFMA (157 TF/s); HBM traffic is 16-20 B per sample.
+#include "mfma_mlp.h"
+#include "tf_common.h"
+
+#define FLOW_NB 10
+static constexpr float kEps32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+static constexpr float kHalfPi = 1.5707963267948966f;
+
+// ------------------------------------------------------------------------------- spline
+struct PwTables {
+  float w[FLOW_NB], wss[FLOW_NB + 1], v[FLOW_NB + 1], vw[FLOW_NB + 1];
+};
+
+template <bool CLAMP_W>
+__device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
+  // wv[0..10] = v_tilde, wv[11..20] = w_tilde   (flow.py:337-350 / :420-434)
+  float wsum[FLOW_NB];
+  float run = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    float e = expf(wv[11 + i]);
+    if (CLAMP_W) e = fmaxf(e, 1e-6f);
+    T.w[i] = e;
+    run += e;
+    wsum[i] = run;
+  }
+  const float wn = run;
+  T.wss[0] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    float wi = T.w[i] / wn;
+    if (CLAMP_W) wi = fmaxf(wi, 1e-6f);
+    T.w[i] = wi;
+    T.wss[i + 1] = wsum[i] / wn;
+  }
+  float ev[FLOW_NB + 1];
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) ev[i] = expf(wv[i]);
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) den += (ev[i] + ev[i + 1]) / 2.f * T.w[i];
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) T.v[i] = fmaxf(ev[i] / den, 1e-6f);
+  T.vw[0] = 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    acc += (T.v[i] + T.v[i + 1]) / 2.f * T.w[i];
+    T.vw[i + 1] = acc;
+  }
+}
+
+#define PW_PICK(arr, n, idx, dst)            \
+  {                                          \
+    dst = arr[0];                            \
+    _Pragma("unroll") for (int q_ = 1; q_ < (n); ++q_) dst = (idx == q_) ? arr[q_] : dst; \
+  }
+
+// sampling direction (inverse spline), flow.py:415-525
+__device__ __forceinline__ void pw_inverse(float y, const float (&wv)[32], float& x, float& logj, int& bin) {
+  PwTables T;
+  pw_tables<false>(wv, T);
+  // arg-max trick of flow.py:443-457, emulated exactly (first occurrence of the maximum of
+  // [eps, finder*(vw+1)]), so ties from rounding pick the same bin as the reference.
+  int cnt = 0;
+  {
+    float best = kEps32;
+#pragma unroll
+    for (int i = 0; i <= FLOW_NB; ++i) {
+      float val = (T.vw[i] > y) ? 0.f : T.vw[i] + 1.f;
+      if (val > best) { best = val; cnt = i + 1; }
+    }
+  }
+  int e = min(max(cnt - 1, 0), FLOW_NB - 1);
+  float ve, ve1, we, vwe, wsse;
+  PW_PICK(T.v, FLOW_NB + 1, e, ve)
+  {
+    int e1 = e + 1;
+    PW_PICK(T.v, FLOW_NB + 1, e1, ve1)
+  }
+  PW_PICK(T.w, FLOW_NB, e, we)
+  PW_PICK(T.vw, FLOW_NB + 1, e, vwe)
+  PW_PICK(T.wss, FLOW_NB + 1, e, wsse)
+  float a = (ve1 - ve) * we;
+  float b = ve * we;
+  float c = vwe - y;
+  a = fabsf(a) < kEps32 ? kEps32 : a;
+  float d = fmaxf(b * b - 2.f * a * c, 0.f);
+  float sq = sqrtf(d);
+  float s1 = (-b - sq) / a, s2 = (-b + sq) / a;
+  float sol = (s1 >= 0.f && s1 < 1.f) ? s1 : s2;
+  sol = fminf(fmaxf(sol, kEps32), 1.f - kEps32);
+  x = fminf(fmaxf(we * sol + wsse, kEps32), 1.f - kEps32);
+  logj = -logf(ve + sol * (ve1 - ve));  // torch.lerp(start,end,w) = start + w*(end-start) for w < 0.5 ...
+  if (sol >= 0.5f) logj = -logf(ve1 - (ve1 - ve) * (1.f - sol));  // ... and end - (end-start)*(1-w) otherwise
+  bin = e;
+}
+
+// density direction (forward spline), flow.py:332-413
+__device__ __forceinline__ void pw_forward(float xin, const float (&wv)[32], float& out, float& logj, int& bin) {
+  PwTables T;
+  pw_tables<true>(wv, T);
+  int cnt = 0;   // flow.py:355-366: argmax of [eps, finder*wsum], first occurrence
+  {
+    float best = kEps32;
+#pragma unroll
+    for (int i = 1; i <= FLOW_NB; ++i) {
+      float val = (T.wss[i] > xin) ? 0.f : T.wss[i];
+      if (val > best) { best = val; cnt = i; }
+    }
+  }
+  int m = min(max(cnt, 0), FLOW_NB - 1);
+  float vm, vm1, wm, vwm, wssm;
+  PW_PICK(T.v, FLOW_NB + 1, m, vm)
+  {
+    int m1 = m + 1;
+    PW_PICK(T.v, FLOW_NB + 1, m1, vm1)
+  }
+  PW_PICK(T.w, FLOW_NB, m, wm)
+  PW_PICK(T.vw, FLOW_NB + 1, m, vwm)
+  PW_PICK(T.wss, FLOW_NB + 1, m, wssm)
+  float al = fminf(fmaxf((xin - wssm) / wm, 0.f), 1.f);
+  float o = (al * al) / 2.f * ((vm1 - vm) * wm) + al * vm * wm + vwm;
+  out = fminf(fmaxf(o, kEps32), 1.f - kEps32);
+  float lerp = al < 0.5f ? vm + al * (vm1 - vm) : vm1 - (vm1 - vm) * (1.f - al);
+  logj = logf(lerp);
+  bin = m;
+}
+
+// ------------------------------------------------------------------------------- kernel
+// LDS image per block net (floats): L1s [2][4][64] | L2 [2][32][64] | L3 [2][32][64] | L4 [1][32][64]
+//                                   | b2 [64] | b3 [64] | b4 [32]   (biases in accumulator order)
+static constexpr int kL1 = 0, kL2 = kL1 + 2 * 4 * 64, kL3 = kL2 + 2 * 32 * 64, kL4 = kL3 + 2 * 32 * 64,
+                     kB2 = kL4 + 32 * 64, kB3 = kB2 + 64, kB4 = kB3 + 64, kNetFloats = kB4 + 32;
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
+
+// net eval for one tile: y_keep per lane (this lane's row), P row pointer -> wv[32] (all 21+pad outputs of the row)
+__device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS*/, const float* __restrict__ Prow,
+                                             float y_keep, int lane, float (&wv)[32]) {
+  const int h = lane >> 5;
+  // layer-1 sample part: embed3(y) (7 values, Reshift 2x-1), k = rho(j,h), j = 0..3
+  float emb[8];
+  emb[0] = y_keep;
+  emb[1] = sinf(y_keep); emb[2] = cosf(y_keep);
+  emb[3] = sinf(y_keep * 2.f); emb[4] = cosf(y_keep * 2.f);
+  emb[5] = sinf(y_keep * 4.f); emb[6] = cosf(y_keep * 4.f);
+  emb[7] = 0.5f;  // padded input: 2*0.5-1 = 0 (its weight column is zero anyway)
+  f32x16 in1[1];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) in1[0][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) in1[0][j] = (h ? emb[4 + j] : emb[j]) * 2.f - 1.f;
+  f32x16 a[2], b[2];
+  // init accumulators with the hoisted per-point part (already includes b1)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[t][j] = Prow[32 * t + tf_rho(j, h)];
+  tf_layer<4, 2, 1>(net + kL1 + lane, in1, a);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      a[t][j] = leaky(a[t][j]);
+      b[t][j] = net[kB2 + (t * 16 + j) * 2 + h];
+    }
+  tf_layer<32, 2, 2>(net + kL2 + lane, a, b);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      b[t][j] = leaky(b[t][j]);
+      a[t][j] = net[kB3 + (t * 16 + j) * 2 + h];
+    }
+  tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
+  f32x16 o[1];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[t][j] = leaky(a[t][j]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o[0][j] = net[kB4 + j * 2 + h];
+  tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
+  // gather the row's 32 outputs: own 16 (rows rho(j,h)) + partner's 16 (rows rho(j,1-h))
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float mine = o[0][j];
+    float other = __shfl_xor(mine, 32);
+    int r0 = (j & 3) + 8 * (j >> 2);
+    wv[r0] = h ? other : mine;
+    wv[r0 + 4] = h ? mine : other;
+  }
+}
+
+template <bool SAMPLE>
+__global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
+                                                   const float* __restrict__ P /*[2][pn][64]*/,
+                                                   const float* __restrict__ latent, const float* __restrict__ jitter,
+                                                   const float* __restrict__ xin, const long long* __restrict__ rays_id,
+                                                   long long m, int sn, long long pn, float* __restrict__ out_xy,
+                                                   float* __restrict__ out_lj, int* __restrict__ bins) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < 2 * kNetFloats; i += blockDim.x) lds[i] = netfrag[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const long long n_tiles = (m + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * waves_per_block + wave; tile < n_tiles;
+       tile += (long long)gridDim.x * waves_per_block) {
+    asm volatile("" ::: "memory");  // keep the LDS weight fragments out of registers across tiles (LICM)
+    long long row = tile * 32 + (lane & 31);
+    const bool valid = row < m;
+    if (!valid) row = m - 1;
+    long long pt;
+    float x0, x1, lj;
+    if (SAMPLE) {
+      pt = row / sn;
+      int s = (int)(row % sn);
+      x0 = latent[2 * s];
+      x1 = latent[2 * s + 1];
+      if (jitter) { x0 = x0 + jitter[row]; x0 = x0 - floorf(x0); }   // (x + u) % 1
+      x0 = fminf(fmaxf(x0, 1e-6f), 1.f - 1e-6f);
+      x1 = fminf(fmaxf(x1, 1e-6f), 1.f - 1e-6f);
+      lj = -logf(cosf(x1 * kHalfPi));
+    } else {
+      pt = rays_id ? rays_id[row] : row / sn;
+      x0 = fminf(fmaxf(xin[2 * row], 1e-6f), 1.f - 1e-6f);
+      x1 = fminf(fmaxf(xin[2 * row + 1], 1e-6f), 1.f - 1e-6f);
+      lj = 0.f;
+    }
+    float wv[32];
+    int bin0, bin1;
+    float t, l;
+    if (SAMPLE) {
+      coupling_net(lds, P + pt * 64, x0, lane, wv);                      // block 0 keeps x0, moves x1
+      pw_inverse(x1, wv, t, l, bin0); x1 = t; lj += l;
+      coupling_net(lds + kNetFloats, P + (pn + pt) * 64, x1, lane, wv);  // block 1 keeps x1, moves x0
+      pw_inverse(x0, wv, t, l, bin1); x0 = t; lj += l;
+    } else {
+      coupling_net(lds + kNetFloats, P + (pn + pt) * 64, x1, lane, wv);
+      pw_forward(x0, wv, t, l, bin1); x0 = t; lj += l;
+      coupling_net(lds, P + pt * 64, x0, lane, wv);
+      pw_forward(x1, wv, t, l, bin0); x1 = t; lj += l;
+      lj += logf(cosf(x1 * kHalfPi));   // + latent_prior.log_prob(z)
+    }
+    if (valid && lane < 32) {
+      reinterpret_cast<float2*>(out_xy)[row] = make_float2(x0, x1);
+      out_lj[row] = lj;
+      if (bins) reinterpret_cast<int2*>(bins)[row] = make_int2(bin0, bin1);
+    }
+  }
+}
+
+// per-point hoisted layer-1 part: P[b][pt][u] = b1[u] + sum_k W1[u][7+k] * (2*cond[pt][k] - 1)
+__global__ void __launch_bounds__(256) flow_point_part_kernel(const float* __restrict__ w1a, const float* __restrict__ b1a,
+                                                              const float* __restrict__ w1b, const float* __restrict__ b1b,
+                                                              const float* __restrict__ cond, long long pn,
+                                                              float* __restrict__ P) {
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * pn * 64) return;
+  int u = (int)(e & 63);
+  long long pt = (e >> 6) % pn;
+  int blk = (int)((e >> 6) / pn);
+  const float* w = (blk ? w1b : w1a) + u * 44 + 7;
+  float acc = (blk ? b1b : b1a)[u];
+  const float* c = cond + pt * 37;
+#pragma unroll
+  for (int k = 0; k < 37; ++k) acc += w[k] * (c[k] * 2.f - 1.f);
+  P[e] = acc;
+}
+
+static int pack_nets(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
+  for (int b = 0; b < 2; ++b) {
+    float* base = netfrag + (size_t)b * kNetFloats;
+    for (int l = 0; l < 4; ++l)
+      TF_REQUIRE(nets[b].w[l] && nets[b].b[l], TF_EINVAL, "tf_flow: null weight pointer (block %d layer %d)", b, l);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
+    tf_pack_wfrag_kernel<<<tf_blocks(32 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + kB2);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + kB3);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + kB4);
+  }
+  return TF_OK;
+}
+
+extern "C" size_t tf_flow_workspace_floats(int64_t pn) { return (size_t)2 * kNetFloats + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0); }
+
+template <bool SAMPLE>
+static int flow_launch(const TfCouplingNet nets[2], const float* cond, const float* latent, const float* jitter,
+                       const float* x, const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, float* out_xy,
+                       float* out_lj, int32_t* bins, float* workspace, size_t workspace_floats, hipStream_t stream,
+                       const char* who) {
+  TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(nets && cond && out_xy && out_lj && workspace, TF_EINVAL, "%s: null pointer", who);
+  TF_REQUIRE(pn > 0, TF_ESHAPE, "%s: pn == 0 with m > 0", who);
+  TF_REQUIRE(workspace_floats >= tf_flow_workspace_floats(pn), TF_ESHAPE, "%s: workspace too small (%zu < %zu floats)", who,
+             workspace_floats, tf_flow_workspace_floats(pn));
+  if (SAMPLE) {
+    TF_REQUIRE(latent, TF_EINVAL, "%s: latent is null", who);
+    TF_REQUIRE(m == pn * (int64_t)sn, TF_ESHAPE, "%s: m != pn*sn", who);
+  } else {
+    TF_REQUIRE(x, TF_EINVAL, "%s: x is null", who);
+    TF_REQUIRE(rays_id || m == pn * (int64_t)sn, TF_ESHAPE, "%s: without rays_id m must equal pn*sn", who);
+  }
+  float* netfrag = workspace;
+  float* P = workspace + 2 * kNetFloats;
+  if (int rc = pack_nets(nets, netfrag, stream)) return rc;
+  flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
+                                                                         nets[1].b[0], cond, pn, P);
+  const size_t lds = (size_t)2 * kNetFloats * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)flow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const long long tiles = (m + 31) / 32;
+  const int waves_per_block = 8;
+  long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
+  if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles
+  flow_kernel<SAMPLE><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+      netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+
+extern "C" int tf_flow_sample_fwd(const TfCouplingNet nets[2], const float* cond, const float* latent, const float* jitter,
+                                  int64_t pn, int32_t sn, float* angles, float* logj, int32_t* bins, float* workspace,
+                                  size_t workspace_floats, tf_stream_t stream) {
+  return flow_launch<true>(nets, cond, latent, jitter, nullptr, nullptr, pn * (int64_t)sn, sn, pn, angles, logj, bins,
+                           workspace, workspace_floats, (hipStream_t)stream, "tf_flow_sample_fwd");
+}
+
+extern "C" int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id,
+                                int64_t m, int32_t sn, int64_t pn, float* z, float* logq, int32_t* bins, float* workspace,
+                                size_t workspace_floats, tf_stream_t stream) {
+  return flow_launch<false>(nets, cond, nullptr, nullptr, x, rays_id, m, sn, pn, z, logq, bins, workspace,
+                            workspace_floats, (hipStream_t)stream, "tf_flow_logq_fwd");
+}

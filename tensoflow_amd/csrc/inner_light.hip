@@ -1,0 +1,179 @@
+// Indirect ("inner") light network of the rendering integral:
+// MCShadingNetwork.get_inner_lights (network/fields.py:905-911) =
+//   cat[pos_enc8(p) (51), IDE5(reflect(view, n), kappa_inv = 0) (72)] -> 123-256-256-256-3 (ReLU),
+//   out = exp(min(x, exp_max))            (make_predictor_4layer, network/other_field.py:86-119)
+// evaluated for every secondary ray that hits geometry (327 kflop per ray: the largest flop term of the
+// integral).  One wave per 32 rays, fp32 MFMA, activations in accumulator registers between layers
+// (mfma_mlp.h); the 688 KB of fragment-ordered weights stream from L2 (256 coalesced bytes per MFMA).
+// Weight-norm is folded by the caller (effective W = g * v / |v|).
+#include <cmath>
+
+#include "mfma_mlp.h"
+#include "tf_common.h"
+
+// fragment workspace layout (floats)
+static constexpr int kI1 = 0;                       // [8][64][64]   123 -> 256 (K padded to 128)
+static constexpr int kI2 = kI1 + 8 * 64 * 64;       // [8][128][64]
+static constexpr int kI3 = kI2 + 8 * 128 * 64;      // [8][128][64]
+static constexpr int kI4 = kI3 + 8 * 128 * 64;      // [1][128][64]  256 -> 3
+static constexpr int kIB1 = kI4 + 128 * 64;         // biases, accumulator order
+static constexpr int kIB2 = kIB1 + 256;
+static constexpr int kIB3 = kIB2 + 256;
+static constexpr int kIB4 = kIB3 + 256;
+static constexpr int kIdeMat = kIB4 + 32;           // [17][36] IDE polynomial coefficients
+static constexpr int kInnerWsFloats = kIdeMat + 17 * 36;
+
+extern "C" size_t tf_inner_light_workspace_floats(void) { return kInnerWsFloats; }
+
+// ---- IDE tables (Ref-NeRF eq. 6-8; utils/ref_utils.py:8-78): (l, m) for l = 1,2,4,8,16, m = 0..l
+static void ide_tables_host(float* mat /*[17][36]*/) {
+  auto fact = [](int n) { double r = 1; for (int i = 2; i <= n; ++i) r *= i; return r; };
+  int col = 0;
+  for (int i = 0; i < 17 * 36; ++i) mat[i] = 0.f;
+  for (int d = 0; d < 5; ++d) {
+    const int l = 1 << d;
+    for (int m = 0; m <= l; ++m, ++col) {
+      for (int k = 0; k <= l - m; ++k) {
+        const double a = 0.5 * (l + k + m - 1.0);
+        double gb = 1.0;
+        for (int j = 0; j < l; ++j) gb *= (a - j);
+        gb /= fact(l);
+        const double leg = std::pow(-1.0, m) * std::pow(2.0, l) * fact(l) / fact(k) / fact(l - k - m) * gb;
+        const double sph = std::sqrt((2.0 * l + 1.0) * fact(l - m) / (4.0 * M_PI * fact(l + m))) * leg;
+        mat[k * 36 + col] = (float)sph;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+
+template <int KSTEPS, int TIN>
+__device__ __forceinline__ void hidden_layer(const float* __restrict__ wf, const float* __restrict__ bias, int h,
+                                             const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
+  tf_layer_sb<KSTEPS, 8, TIN, 8>(wf, in, out);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
+}
+
+__global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws, const float* __restrict__ pts,
+                                                          const float* __restrict__ view, const float* __restrict__ nrm,
+                                                          long long m, float exp_max, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const long long n_tiles = (m + 31) / 32;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (long long tile = wave_id; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    long long row = tile * 32 + (lane & 31);
+    const bool valid = row < m;
+    if (!valid) row = m - 1;
+    // ---- encodings (each lane computes all 123 and keeps the half its MFMA operand slots need)
+    float enc[128];
+    const float p[3] = {pts[3 * row], pts[3 * row + 1], pts[3 * row + 2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) enc[k] = p[k];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float a = p[k] * (float)(1 << f);
+        enc[3 + 6 * f + k] = sinf(a);
+        enc[3 + 6 * f + 3 + k] = cosf(a);
+      }
+    float n[3] = {nrm[3 * row], nrm[3 * row + 1], nrm[3 * row + 2]};
+    float v[3] = {view[3 * row], view[3 * row + 1], view[3 * row + 2]};
+    float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+    inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+    const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+    const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+    {
+      // IDE: sph[i] = (rx + i ry)^m_i * sum_k mat[k][i] rz^k ; output = [Re(36) | Im(36)]
+      float zp[17];
+      zp[0] = 1.f;
+#pragma unroll
+      for (int k = 1; k < 17; ++k) zp[k] = zp[k - 1] * rz;
+      float cre[17], cim[17];
+      cre[0] = 1.f; cim[0] = 0.f;
+#pragma unroll
+      for (int k = 1; k < 17; ++k) {
+        cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
+        cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
+      }
+      const float* mat = ws + kIdeMat;
+      int col = 0;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const int l = 1 << d;
+#pragma unroll
+        for (int mm = 0; mm <= l; ++mm, ++col) {
+          float poly = 0.f;
+#pragma unroll
+          for (int k = 0; k <= l - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+          enc[51 + col] = cre[mm] * poly;
+          enc[51 + 36 + col] = cim[mm] * poly;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 123; k < 128; ++k) enc[k] = 0.f;
+    f32x16 a[8], b[8];
+    {
+      f32x16 in1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k0 = 32 * t + (j & 3) + 8 * (j >> 2);
+          in1[t][j] = h ? enc[k0 + 4] : enc[k0];
+        }
+      hidden_layer<64, 4>(ws + kI1 + lane, ws + kIB1, h, in1, a);
+    }
+    hidden_layer<128, 8>(ws + kI2 + lane, ws + kIB2, h, a, b);
+    hidden_layer<128, 8>(ws + kI3 + lane, ws + kIB3, h, b, a);
+    f32x16 o[1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
+    tf_layer_sb<128, 1, 8, 16>(ws + kI4 + lane, a, o);
+    if (valid && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[3 * row + c] = expf(fminf(o[0][c], exp_max));
+    }
+  }
+}
+
+extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
+                                  float exp_max, float* out, float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(m >= 0, TF_ESHAPE, "tf_inner_light_fwd: m < 0");
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "tf_inner_light_fwd: null pointer");
+  TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_fwd: workspace too small (%zu < %d floats)",
+             workspace_floats, kInnerWsFloats);
+  for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "tf_inner_light_fwd: null weight pointer (layer %d)", l);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3);
+  tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[3], 3, 1, workspace + kIB4);
+  static float ide_host[17 * 36];
+  static bool ide_ready = false;
+  if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
+  hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_fwd: hipMemcpyAsync failed: %s", hipGetErrorString(e));
+  long long tiles = (m + 31) / 32;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  inner_light_kernel<<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
+  TF_LAUNCH_CHECK("tf_inner_light_fwd");
+  return TF_OK;
+}

@@ -1,0 +1,141 @@
+// Environment light lookup: EnvLight.direct_light (network/light.py:125-162) =
+// exp(dr.texture(base[None], dirs, filter_mode='linear', boundary_mode='cube')).
+// The cube map (6*R*R*3 floats, 1.2 MB at R=128) is L2-resident; one lane per direction,
+// 4 taps x 3 channels; taps that leave the face are re-projected onto the neighbouring face,
+// the tap that falls off a cube corner is dropped and the other three renormalised
+// (same rule as oracle/texture.py:cube_bilinear).
+#include "tf_common.h"
+
+struct CubeTaps {
+  int idx[4];   // flat texel index (face*R + y)*R + x
+  float w[4];
+};
+
+__device__ __forceinline__ void cube_face_uv(float dx, float dy, float dz, int& face, float& x, float& y) {
+  const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+  if (az > fmaxf(ax, ay)) {
+    const float m = 1.f / az;
+    face = dz < 0.f ? 5 : 4;
+    x = (dz < 0.f ? -dx : dx) * m;
+    y = -dy * m;
+  } else if (ay > ax) {
+    const float m = 1.f / ay;
+    face = dy < 0.f ? 3 : 2;
+    x = dx * m;
+    y = (dy < 0.f ? -dz : dz) * m;
+  } else {
+    const float m = 1.f / ax;
+    face = dx < 0.f ? 1 : 0;
+    x = (dx < 0.f ? dz : -dz) * m;
+    y = -dy * m;
+  }
+}
+
+__device__ __forceinline__ void cube_face_dir(int face, float x, float y, float& dx, float& dy, float& dz) {
+  switch (face) {
+    case 0: dx = 1.f; dy = -y; dz = -x; break;
+    case 1: dx = -1.f; dy = -y; dz = x; break;
+    case 2: dx = x; dy = 1.f; dz = y; break;
+    case 3: dx = x; dy = -1.f; dz = -y; break;
+    case 4: dx = x; dy = -y; dz = 1.f; break;
+    default: dx = -x; dy = -y; dz = -1.f; break;
+  }
+}
+
+__device__ __forceinline__ void cube_taps(float dx, float dy, float dz, int R, CubeTaps& T) {
+  int face;
+  float x, y;
+  cube_face_uv(dx, dy, dz, face, x, y);
+  const float u = (x * 0.5f + 0.5f) * (float)R - 0.5f;
+  const float v = (y * 0.5f + 0.5f) * (float)R - 0.5f;
+  const float fu0 = floorf(u), fv0 = floorf(v);
+  const float fu = u - fu0, fv = v - fv0;
+  const int iu0 = (int)fu0, iv0 = (int)fv0;
+  float wsum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int du = t & 1, dv = t >> 1;
+    const int iu = iu0 + du, iv = iv0 + dv;
+    float w = (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
+    const bool ou = iu < 0 || iu > R - 1, ov = iv < 0 || iv > R - 1;
+    int f2 = face, ju = iu, jv = iv;
+    if (ou || ov) {
+      const float tx = ((float)iu + 0.5f) / (float)R * 2.f - 1.f;
+      const float ty = ((float)iv + 0.5f) / (float)R * 2.f - 1.f;
+      float ex, ey, ez, x2, y2;
+      cube_face_dir(face, tx, ty, ex, ey, ez);
+      cube_face_uv(ex, ey, ez, f2, x2, y2);
+      ju = min(max((int)floorf((x2 * 0.5f + 0.5f) * (float)R), 0), R - 1);
+      jv = min(max((int)floorf((y2 * 0.5f + 0.5f) * (float)R), 0), R - 1);
+      if (ou && ov) w = 0.f;
+    }
+    T.idx[t] = (f2 * R + jv) * R + ju;
+    T.w[t] = w;
+    wsum += w;
+  }
+  const float inv = 1.f / wsum;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) T.w[t] *= inv;
+}
+
+__global__ void __launch_bounds__(256) cube_lookup_fwd_kernel(const float* __restrict__ base, int R,
+                                                              const float* __restrict__ dirs, long long m, int apply_exp,
+                                                              float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  CubeTaps T;
+  cube_taps(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], R, T);
+  float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float* p = base + 3LL * T.idx[t];
+    r += T.w[t] * p[0]; g += T.w[t] * p[1]; b += T.w[t] * p[2];
+  }
+  if (apply_exp) { r = expf(r); g = expf(g); b = expf(b); }
+  out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
+}
+
+__global__ void __launch_bounds__(256) cube_lookup_bwd_kernel(const float* __restrict__ base, int R,
+                                                              const float* __restrict__ dirs, long long m, int apply_exp,
+                                                              const float* __restrict__ g_out, float* __restrict__ g_base) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  CubeTaps T;
+  cube_taps(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], R, T);
+  float gr = g_out[3 * i], gg = g_out[3 * i + 1], gb = g_out[3 * i + 2];
+  if (apply_exp) {
+    float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float* p = base + 3LL * T.idx[t];
+      r += T.w[t] * p[0]; g += T.w[t] * p[1]; b += T.w[t] * p[2];
+    }
+    gr *= expf(r); gg *= expf(g); gb *= expf(b);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (T.w[t] == 0.f) continue;
+    float* p = g_base + 3LL * T.idx[t];
+    atomicAdd(p, T.w[t] * gr); atomicAdd(p + 1, T.w[t] * gg); atomicAdd(p + 2, T.w[t] * gb);
+  }
+}
+
+extern "C" int tf_cube_lookup_fwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                                  float* out, tf_stream_t stream) {
+  TF_REQUIRE(m >= 0 && res > 0, TF_ESHAPE, "tf_cube_lookup_fwd: m < 0 or res <= 0");
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(base && dirs && out, TF_EINVAL, "tf_cube_lookup_fwd: null pointer");
+  cube_lookup_fwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, out);
+  TF_LAUNCH_CHECK("tf_cube_lookup_fwd");
+  return TF_OK;
+}
+
+extern "C" int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                                  const float* g_out, float* g_base, tf_stream_t stream) {
+  TF_REQUIRE(m >= 0 && res > 0, TF_ESHAPE, "tf_cube_lookup_bwd: m < 0 or res <= 0");
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(base && dirs && g_out && g_base, TF_EINVAL, "tf_cube_lookup_bwd: null pointer");
+  cube_lookup_bwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, g_out, g_base);
+  TF_LAUNCH_CHECK("tf_cube_lookup_bwd");
+  return TF_OK;
+}

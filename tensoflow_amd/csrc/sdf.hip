@@ -1,0 +1,297 @@
+// Fused TensoSDF evaluation for the ray-march: VM gather -> feature assembly -> 111-256-129 decoder
+// -> 6-tap central differences -> NeuS alpha, one launch.
+// Replaces TensoSDF.forward x7 (network/fields.py:262-299, :227-260) + compute_sdf_alpha
+// (network/shapeRenderer.py:995-1025): in the reference every one of the 7 evaluations is 6 dr.texture
+// launches (each preceded by a full-plane permute().contiguous() copy and a mip rebuild), a [N,111]
+// concat and two GEMMs that compute all 129 outputs and throw 128 away for the FD taps.
+//
+// Mapping (wave64, one wave per SIMD, 4 waves per workgroup, persistent workgroups):
+//   * a wave owns 32 samples; sample r sits on MFMA column r; lane (r, h = lane>>5) gathers the 16-byte
+//     channel chunks q with q%2 == h of the 27 plane*line chunks (+ the xyz chunk), which is exactly the
+//     fp32-MFMA B-operand layout (mfma_mlp.h), so features never leave registers;
+//   * W1 (fragment order, 112 KB) lives in LDS for the whole kernel; hidden activations stay in the
+//     accumulator registers; the 6 FD taps only need the sdf row of W2 (a 256-long dot product, VALU +
+//     one cross-lane add); the centre tap runs the 256x128 appearance GEMM with W2 streamed from L2 in
+//     fragment order (coalesced 256 B per MFMA);
+//   * the field (51 MB at R=300 incl. mips) is served from L2 / Infinity Cache after first touch.
+// Algorithmic gather traffic: 7 x (3 planes x 4 texels + 3 lines x 2 texels) x C x 4 B = 18 144 B per live
+// sample and mip level (C = 36); flops: 122 880 + 6 x 57 344 = 466 944 per sample (fp32 MFMA).
+#include "mfma_mlp.h"
+#include "tf_common.h"
+
+#define SDF_C 36
+#define SDF_HID 256
+#define SDF_APP 128
+#define SDF_KSTEPS 56  // (108 features + xyz + pad) / 2
+
+// workspace layout (floats)
+static constexpr int kW1f = 0;                                   // [8][56][64]
+static constexpr int kB1a = kW1f + 8 * SDF_KSTEPS * 64;          // [8][16][2]
+static constexpr int kW2r0 = kB1a + 256;                         // sdf row of W2, accumulator order [8][16][2]
+static constexpr int kB2a = kW2r0 + 256;                         // b2[1:], accumulator order [4][16][2]
+static constexpr int kLdsFloats = kB2a + 128;                    // everything above is copied to LDS
+static constexpr int kW2f = kLdsFloats;                          // [4][128][64]  (global only)
+static constexpr int kSdfWsFloats = kW2f + 4 * 128 * 64;
+
+extern "C" size_t tf_sdf_workspace_floats(void) { return kSdfWsFloats; }
+
+struct SdfArgs {
+  VmGeom g;
+  const float* packed;
+  const float* ws;      // packed weights (see layout above)
+  const float* b2;      // [1+A] (device); b2[0] = sdf bias
+  const float* pts;     // [n,3]
+  const float* level;   // [n] or null
+  long long n;
+  // mode 0/1 outputs
+  float* sdf;           // [n]
+  float* feat;          // [n,A] or null
+  // mode 2 (alpha)
+  const float* dists;
+  const float* dirs;
+  float units[3];
+  float inv_s, cos_anneal;
+  float* alpha;
+  float* grad;
+  float* nhess;
+};
+
+__device__ __forceinline__ float4 f4_lerp(float4 a, float4 b, float t) {
+  const float s = 1.f - t;
+  return make_float4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+}
+
+// plane*line product for channel chunk q (plane i = q/9, channels 4*(q%9)..+3) at contracted point p
+__device__ __forceinline__ float4 gather_chunk(const VmGeom& g, const float* __restrict__ packed, const float (&p)[3],
+                                               int l0, int l1, float fl, int q) {
+  const int i = q / (SDF_C / 4), j = q % (SDF_C / 4);
+  const float u = i == 2 ? p[1] : p[0], v = i == 0 ? p[1] : p[2], w = i == 0 ? p[2] : (i == 1 ? p[1] : p[0]);
+#define SEL3(a) (i == 0 ? (a)[0] : (i == 1 ? (a)[1] : (a)[2]))
+#define SEL34(a, l) (l == 0 ? SEL3_L(a, 0) : (l == 1 ? SEL3_L(a, 1) : (l == 2 ? SEL3_L(a, 2) : SEL3_L(a, 3))))
+#define SEL3_L(a, l) (i == 0 ? (a)[0][l] : (i == 1 ? (a)[1][l] : (a)[2][l]))
+  const int ph = SEL3(g.ph), pw = SEL3(g.pw), ll = SEL3(g.ll);
+  float4 pv = make_float4(0, 0, 0, 0), lv = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int li = 0; li < 2; ++li) {
+    if (li == 1 && fl == 0.f) break;
+    const int l = li ? l1 : l0;
+    const float wl = li ? fl : 1.f - fl;
+    const int H = vm_dim(ph, l), W = vm_dim(pw, l), L = vm_dim(ll, l);
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    axis_taps(u, W, x0, x1, fx);
+    axis_taps(v, H, y0, y1, fy);
+    axis_taps(w, L, z0, z1, fz);
+    const float* pb = packed + SEL34(g.poff, l) + 4 * j;
+    const float* lb = packed + SEL34(g.loff, l) + 4 * j;
+    const float4 t00 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x0) * SDF_C);
+    const float4 t10 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x1) * SDF_C);
+    const float4 t01 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x0) * SDF_C);
+    const float4 t11 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x1) * SDF_C);
+    const float4 s0 = *reinterpret_cast<const float4*>(lb + (long long)z0 * SDF_C);
+    const float4 s1 = *reinterpret_cast<const float4*>(lb + (long long)z1 * SDF_C);
+    const float4 pl = f4_lerp(f4_lerp(t00, t10, fx), f4_lerp(t01, t11, fx), fy);
+    const float4 ln = f4_lerp(s0, s1, fz);
+    pv.x += wl * pl.x; pv.y += wl * pl.y; pv.z += wl * pl.z; pv.w += wl * pl.w;
+    lv.x += wl * ln.x; lv.y += wl * ln.y; lv.z += wl * ln.z; lv.w += wl * ln.w;
+  }
+  return make_float4(pv.x * lv.x, pv.y * lv.y, pv.z * lv.z, pv.w * lv.w);
+}
+
+// hidden layer for this lane's sample at world position x: fills acc[8] (post-softplus) and returns the sdf
+__device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* __restrict__ lds, const float (&x)[3], int l0,
+                                            int l1, float fl, int lane, f32x16 (&acc)[8]) {
+  const int h = lane >> 5;
+  float p[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = (x[k] - A.g.aabb_lo[k]) / A.g.aabb_size[k];
+  asm volatile("" ::: "memory");  // W1 fragments are re-read from LDS per tap (no CSE across the 7 taps)
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = lds[kB1a + (t * 16 + j) * 2 + h];
+  // layer 1 in 4 K-groups of 4 chunks: gather -> blend -> 16 k-steps x 8 unit tiles of MFMA.  The scheduling
+  // barriers bound how many gather results are live at once (each group: <= 48 x 16-byte loads).
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x16 fin;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float4 f = make_float4(0, 0, 0, 0);
+      if (!(t == 3 && jj >= 2)) {
+        const int q = 8 * t + 2 * jj + h;  // chunk index: 0..26 plane*line, 27 = (x,y,z,0)
+        if (t == 3 && jj == 1) {
+          // q = 26 + h : h==0 -> last feature chunk, h==1 -> xyz chunk (raw, un-contracted: fields.py:265,298)
+          const float4 g26 = gather_chunk(A.g, A.packed, p, l0, l1, fl, 26);
+          f = h ? make_float4(x[0], x[1], x[2], 0.f) : g26;
+        } else {
+          f = gather_chunk(A.g, A.packed, p, l0, l1, fl, q);
+        }
+      }
+      fin[4 * jj + 0] = f.x; fin[4 * jj + 1] = f.y; fin[4 * jj + 2] = f.z; fin[4 * jj + 3] = f.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int nj = t == 3 ? 8 : 16;
+#pragma unroll
+    for (int j = 0; j < nj; ++j)
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt)
+        acc[tt] = tf_mfma(lds[kW1f + (tt * SDF_KSTEPS + 16 * t + j) * 64 + lane], fin[j], acc[tt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      acc[t][j] = softplus100(acc[t][j]);
+      part += acc[t][j] * lds[kW2r0 + (t * 16 + j) * 2 + h];
+    }
+  part += __shfl_xor(part, 32);
+  return part + A.b2[0];
+}
+
+template <int MODE>  // 0: sdf + feat, 1: sdf only, 2: alpha (7 taps)
+__global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long long n_tiles = (A.n + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    asm volatile("" ::: "memory");  // do not hoist LDS weight fragments across tiles
+    long long row = tile * 32 + (lane & 31);
+    const bool valid = row < A.n;
+    if (!valid) row = A.n - 1;
+    float x[3] = {A.pts[3 * row], A.pts[3 * row + 1], A.pts[3 * row + 2]};
+    int l0, l1;
+    float fl;
+    mip_select(A.level ? A.level[row] : 0.f, A.g.n_levels, l0, l1, fl);
+    f32x16 acc[8];
+    const float s_c = sdf_hidden(A, lds, x, l0, l1, fl, lane, acc);
+    if (MODE != 1 && A.feat) {
+      // appearance features: [128 x 256] * H^T, W2 fragments streamed from L2
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        f32x16 o;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = lds[kB2a + (t * 16 + j) * 2 + h];
+        const float* __restrict__ wf = A.ws + kW2f + (long long)t * 128 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 128; ++s) o = tf_mfma(wf[s * 64], acc[s >> 4][s & 15], o);
+        if (valid) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            float4 v4 = make_float4(o[4 * jj], o[4 * jj + 1], o[4 * jj + 2], o[4 * jj + 3]);
+            *reinterpret_cast<float4*>(A.feat + row * SDF_APP + 32 * t + 8 * jj + 4 * h) = v4;
+          }
+        }
+      }
+    }
+    if (MODE != 2) {
+      if (valid && h == 0) A.sdf[row] = s_c;
+      continue;
+    }
+    // ---- 6 finite-difference taps (fields.py:234-256)
+    float sp[3], sn[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      float xt[3] = {x[0], x[1], x[2]};
+      xt[ax] = x[ax] + A.units[ax];
+      sp[ax] = sdf_hidden(A, lds, xt, l0, l1, fl, lane, acc);
+      xt[ax] = x[ax] - A.units[ax];
+      sn[ax] = sdf_hidden(A, lds, xt, l0, l1, fl, lane, acc);
+    }
+    if (valid && h == 0) {
+      float g[3], hs[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        g[ax] = (sp[ax] - sn[ax]) / (2.f * A.units[ax]);
+        hs[ax] = (sp[ax] + sn[ax] - 2.f * s_c) / (A.units[ax] * A.units[ax]);
+      }
+      const float d0 = A.dirs[3 * row], d1 = A.dirs[3 * row + 1], d2 = A.dirs[3 * row + 2];
+      const float true_cos = d0 * g[0] + d1 * g[1] + d2 * g[2];
+      const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.f) * (1.f - A.cos_anneal) + fmaxf(-true_cos, 0.f) * A.cos_anneal);
+      const float dist = A.dists[row];
+      const float pc = sigmoidf_((s_c - iter_cos * dist * 0.5f) * A.inv_s);
+      const float nc = sigmoidf_((s_c + iter_cos * dist * 0.5f) * A.inv_s);
+      A.alpha[row] = fminf(fmaxf((pc - nc + 1e-5f) / (pc + 1e-5f), 0.f), 1.f);
+      A.grad[3 * row] = g[0]; A.grad[3 * row + 1] = g[1]; A.grad[3 * row + 2] = g[2];
+      A.sdf[row] = s_c;
+      if (A.nhess) A.nhess[row] = (g[0] * hs[0] + g[1] * hs[1] + g[2] * hs[2]) / (g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + 1e-5f);
+    }
+  }
+}
+
+static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb_host, float* workspace,
+                       size_t workspace_floats, SdfArgs* A, hipStream_t stream, const char* who) {
+  TF_REQUIRE(d && mlp && aabb_host && workspace, TF_EINVAL, "%s: null pointer", who);
+  TF_REQUIRE(d->C == SDF_C && mlp->hidden == SDF_HID && mlp->app_dim == SDF_APP, TF_ESHAPE,
+             "%s: this build instantiates C=%d hidden=%d app_dim=%d (got %d/%d/%d)", who, SDF_C, SDF_HID, SDF_APP, d->C,
+             mlp->hidden, mlp->app_dim);
+  int rc = vm_geom_init(d, aabb_host, &A->g);
+  TF_REQUIRE(rc != -1, TF_EINVAL, "%s: bad TfVmDesc", who);
+  TF_REQUIRE(rc != -2, TF_ESHAPE, "%s: plane/line sizes > 1 must be divisible by 2^(n_levels-1)", who);
+  TF_REQUIRE(workspace_floats >= (size_t)kSdfWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
+             workspace_floats, kSdfWsFloats);
+  TF_REQUIRE(mlp->w1 && mlp->b1 && mlp->w2 && mlp->b2, TF_EINVAL, "%s: null weight pointer", who);
+  const int K = 3 * SDF_C + 3;
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * SDF_KSTEPS * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS,
+                                                                                workspace + kW1f);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b1, SDF_HID, 8, workspace + kB1a);
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
+  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
+  tf_pack_wfrag_kernel<<<tf_blocks(4 * 128 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4,
+                                                                         128, workspace + kW2f);
+  A->ws = workspace;
+  return TF_OK;
+}
+
+template <int MODE>
+static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
+  A.b2 = b2_dev;
+  const size_t lds = (size_t)kLdsFloats * sizeof(float);
+  static bool attr_set[3] = {false, false, false};
+  if (!attr_set[MODE]) {
+    hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
+    attr_set[MODE] = true;
+  }
+  long long tiles = (A.n + 31) / 32;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 256) blocks = 256;  // one 117 KB-LDS workgroup per CU; waves loop over tiles
+  sdf_kernel<MODE><<<(unsigned)blocks, 256, lds, stream>>>(A);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+
+extern "C" int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* xyz,
+                              const float* level, const float* aabb_host, int64_t n, float* sdf, float* feat,
+                              float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_forward: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(packed && xyz && sdf, TF_EINVAL, "tf_sdf_forward: null pointer");
+  SdfArgs A = {};
+  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, stream, "tf_sdf_forward")) return rc;
+  A.packed = packed; A.pts = xyz; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
+  return feat ? sdf_launch<0>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1>(A, mlp->b2, stream, "tf_sdf_forward");
+}
+
+extern "C" int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
+                                const float* level, const float* dists, const float* dirs, const float* aabb_host,
+                                const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha, float* grad,
+                                float* feat, float* sdf, float* nhess, float* workspace, size_t workspace_floats,
+                                tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_alpha_fwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(packed && pts && dists && dirs && units_host && alpha && grad && sdf, TF_EINVAL, "tf_sdf_alpha_fwd: null pointer");
+  SdfArgs A = {};
+  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, stream, "tf_sdf_alpha_fwd")) return rc;
+  A.packed = packed; A.pts = pts; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
+  A.dists = dists; A.dirs = dirs; A.inv_s = inv_s; A.cos_anneal = cos_anneal;
+  for (int k = 0; k < 3; ++k) A.units[k] = units_host[k];
+  A.alpha = alpha; A.grad = grad; A.nhess = nhess;
+  return sdf_launch<2>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
+}

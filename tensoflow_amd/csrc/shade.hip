@@ -1,0 +1,214 @@
+// Monte-Carlo shading integral of MCShadingNetwork.shade_mixed (network/fields.py:1075-1235):
+// direction construction from the flow samples + the fixed cosine set, pdfs, GGX/Schlick BRDF
+// weights, and the final reduction + sRGB.  Elementwise over pn*T slots; HBM-bound
+// (reads 12 B of flow output per slot, writes 24 B of direction + weight).
+#include "tf_common.h"
+
+static constexpr float kPi = 3.14159265358979323846f;
+static constexpr float kTwoPi = 6.28318530717958647692f;
+static constexpr float kHalfPi_ = 1.57079632679489661923f;
+static constexpr float kEPS = 1e-6f;
+
+struct Frame {
+  float n[3], x[3], y[3];
+};
+
+__device__ __forceinline__ void normalize3(float* v) {  // F.normalize(dim=-1), eps 1e-12
+  float inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+// get_orthogonal_directions + cross (fields.py:812-822, :829)
+__device__ __forceinline__ void make_frame(const float* nin, Frame& F) {
+  F.n[0] = nin[0]; F.n[1] = nin[1]; F.n[2] = nin[2];
+  normalize3(F.n);
+  const float o0[3] = {F.n[1], -F.n[0], 0.f};
+  const float o1[3] = {-F.n[2], 0.f, F.n[0]};
+  const float l0 = sqrtf(o0[0] * o0[0] + o0[1] * o0[1]), l1 = sqrtf(o1[0] * o1[0] + o1[2] * o1[2]);
+  const bool use0 = l0 > l1;
+  F.x[0] = use0 ? o0[0] : o1[0]; F.x[1] = use0 ? o0[1] : o1[1]; F.x[2] = use0 ? o0[2] : o1[2];
+  normalize3(F.x);
+  F.y[0] = F.n[1] * F.x[2] - F.n[2] * F.x[1];
+  F.y[1] = F.n[2] * F.x[0] - F.n[0] * F.x[2];
+  F.y[2] = F.n[0] * F.x[1] - F.n[1] * F.x[0];
+}
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float sat(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// direction_to_angle(normals, view)/(2pi, pi/2)  (fields.py:1035-1048, :1077-1079)
+__global__ void __launch_bounds__(256) view_angles_kernel(const float* __restrict__ normals, const float* __restrict__ view,
+                                                          long long pn, float* __restrict__ va) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pn) return;
+  Frame F;
+  make_frame(normals + 3 * i, F);
+  float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
+  normalize3(v);
+  const float cx = dot3(F.x, v), cy = dot3(F.y, v);
+  const float cz = fminf(fmaxf(dot3(F.n, v), -1.f + kEPS), 1.f - kEPS);
+  const float phi = fmodf(atan2f(cy, cx) + kTwoPi, kTwoPi);
+  va[2 * i] = phi / kTwoPi;
+  va[2 * i + 1] = acosf(cz) / kHalfPi_;
+}
+
+__device__ __forceinline__ float ggx_d(float NoH, float a) {
+  const float a2 = a * a;
+  const float den = NoH * NoH * (a2 - 1.f) + 1.f;
+  return a2 / fmaxf(kPi * den * den, kEPS);
+}
+__device__ __forceinline__ float schlick_g1(float c, float a) {
+  const float k = a / 2.f;
+  return c / (c * (1.f - k) + k + 1e-5f);
+}
+
+__global__ void __launch_bounds__(256) shade_dirs_kernel(
+    const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
+    const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
+    const float* __restrict__ logq_d, int sd, const float* __restrict__ fixed_d, const float* __restrict__ az_jitter, int nf,
+    const float* __restrict__ ang_s, const float* __restrict__ logq_s, int ss, long long pn, float* __restrict__ dirs,
+    float* __restrict__ wgt, unsigned char* __restrict__ spec_mask) {
+  const int T = sd + nf + ss;
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= pn * T) return;
+  const long long pt = e / T;
+  const int slot = (int)(e % T);
+  Frame F;
+  make_frame(normals + 3 * pt, F);
+  float v[3] = {view[3 * pt], view[3 * pt + 1], view[3 * pt + 2]};
+  normalize3(v);
+  const float met = metallic[pt], rough = roughness[pt];
+  const float alb[3] = {albedo[3 * pt], albedo[3 * pt + 1], albedo[3 * pt + 2]};
+  float dir[3], pdf;
+  const bool is_spec = slot >= sd + nf;
+  if (slot < sd || is_spec) {
+    // flow sample = half-vector angles in [0,1]^2 (fields.py:1085-1108 / :1164-1188)
+    const long long r = is_spec ? pt * ss + (slot - sd - nf) : pt * sd + slot;
+    const float* ang = is_spec ? ang_s : ang_d;
+    const float lq = (is_spec ? logq_s : logq_d)[r];
+    const float phi = ang[2 * r] * kTwoPi, theta = ang[2 * r + 1] * kHalfPi_;
+    const float st = sinf(theta), ct = cosf(theta);
+    const float cxh = st * cosf(phi), cyh = st * sinf(phi);
+    float H[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) H[k] = cxh * F.x[k] + cyh * F.y[k] + ct * F.n[k];
+    const float HoV = sat(dot3(v, H));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dir[k] = HoV * H[k] * 2.f - v[k];
+    pdf = expf(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(4.f * kPi * kPi * HoV * st, kEPS);
+  } else {
+    // fixed cosine set (fields.py:824-847)
+    const int s = slot - sd;
+    float az = fixed_d[2 * s] * kPi * 2.f;
+    const float el = fixed_d[2 * s + 1];
+    if (az_jitter) az = fmodf(az + az_jitter[pt] * kPi * 2.f, kTwoPi);
+    const float el_sqrt = sqrtf(el + 1e-7f);
+    const float cz = sqrtf(1.f - el + 1e-7f);
+    const float cx = el_sqrt * cosf(az), cy = el_sqrt * sinf(az);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dir[k] = cx * F.x[k] + cy * F.y[k] + cz * F.n[k];
+    pdf = sat(dot3(dir, F.n)) / kPi * (cosf((1.f - el) * kPi / 2.f) * kPi / 2.f);
+  }
+  float w[3];
+  if (!is_spec) {
+    const float kd = 1.f - met;
+    const float c = sat(dot3(dir, F.n)) / kPi;
+    const float inv = 1.f / fmaxf(pdf, kEPS) / (float)(sd + nf);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] = alb[k] * kd * c * inv;
+  } else {
+    const bool keep = dot3(dir, F.n) > 0.f;
+    spec_mask[pt * ss + (slot - sd - nf)] = keep ? 1 : 0;
+    float Hs[3] = {v[0] + dir[0], v[1] + dir[1], v[2] + dir[2]};
+    normalize3(Hs);
+    const float HoV = sat(dot3(Hs, v));
+    const float f5 = powf(sat(1.f - HoV), 5.f);
+    const float NoV = sat(dot3(F.n, v)), NoL = sat(dot3(F.n, dir)), NoH = sat(dot3(F.n, Hs));
+    const float geo = schlick_g1(NoV, rough) * schlick_g1(NoL, rough);
+    const float D = ggx_d(NoH, rough);
+    const float inv = 1.f / fmaxf(4.f * NoV, kEPS) / fmaxf(pdf, kEPS) / (float)ss;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float F0 = 0.04f * (1.f - met) + met * alb[k];
+      const float fres = F0 + (1.f - F0) * f5;
+      w[k] = keep ? D * fres * geo * inv : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { dirs[3 * e + k] = dir[k]; wgt[3 * e + k] = w[k]; }
+}
+
+__device__ __forceinline__ float srgb(float x) {  // utils/raw_utils.py:4-11
+  const float eps = 1.1920928955078125e-07f;
+  const float s0 = 12.92f * x;
+  const float s1 = (211.f * powf(fmaxf(x, eps), 5.f / 12.f) - 11.f) / 200.f;
+  return x <= 0.0031308f ? s0 : s1;
+}
+
+// one wave per point
+__global__ void __launch_bounds__(256) shade_reduce_kernel(const float* __restrict__ wgt, const float* __restrict__ lights,
+                                                           long long pn, int n_diff, int ss, float* __restrict__ colors,
+                                                           float* __restrict__ diffuse_lin, float* __restrict__ specular_lin) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= pn) return;
+  const int T = n_diff + ss;
+  float d[3] = {0, 0, 0}, s[3] = {0, 0, 0};
+  for (int t = lane; t < T; t += 64) {
+    const long long e = (pt * T + t) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float c = wgt[e + k] * lights[e + k];
+      if (t < n_diff) d[k] += c; else s[k] += c;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d[k] += __shfl_xor(d[k], o); s[k] += __shfl_xor(s[k], o); }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      colors[3 * pt + k] = srgb(d[k] + s[k]);
+      if (diffuse_lin) diffuse_lin[3 * pt + k] = d[k];
+      if (specular_lin) specular_lin[3 * pt + k] = s[k];
+    }
+  }
+}
+
+extern "C" int tf_view_angles(const float* normals, const float* view, int64_t pn, float* view_angles, tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0, TF_ESHAPE, "tf_view_angles: pn < 0");
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(normals && view && view_angles, TF_EINVAL, "tf_view_angles: null pointer");
+  view_angles_kernel<<<tf_blocks(pn, 256), 256, 0, (hipStream_t)stream>>>(normals, view, pn, view_angles);
+  TF_LAUNCH_CHECK("tf_view_angles");
+  return TF_OK;
+}
+
+extern "C" int tf_shade_dirs(const float* normals, const float* view, const float* metallic, const float* roughness,
+                             const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
+                             const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
+                             int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs: negative size");
+  if (pn == 0 || sd + nf + ss == 0) return TF_OK;
+  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "tf_shade_dirs: null pointer");
+  TF_REQUIRE((sd == 0 || (ang_d && logq_d)) && (nf == 0 || fixed_d) && (ss == 0 || (ang_s && logq_s && spec_mask)),
+             TF_EINVAL, "tf_shade_dirs: null sample pointer for a non-empty sample set");
+  long long work = (long long)pn * (sd + nf + ss);
+  shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
+                                                                          logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, ss,
+                                                                          pn, dirs, wgt, spec_mask);
+  TF_LAUNCH_CHECK("tf_shade_dirs");
+  return TF_OK;
+}
+
+extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
+                               float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_reduce: negative size");
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(wgt && lights && colors, TF_EINVAL, "tf_shade_reduce: null pointer");
+  shade_reduce_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, lights, pn, n_diffuse, ss, colors, diffuse_lin,
+                                                                        specular_lin);
+  TF_LAUNCH_CHECK("tf_shade_reduce");
+  return TF_OK;
+}

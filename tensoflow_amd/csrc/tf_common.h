@@ -1,0 +1,118 @@
+// Shared host/device helpers for libtensoflow_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/tensoflow_hip.h"
+
+// ---------------------------------------------------------------- host-side error plumbing
+void tf_set_error(const char* fmt, ...);
+
+#define TF_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      tf_set_error(__VA_ARGS__);     \
+      return code;                   \
+    }                                \
+  } while (0)
+
+#define TF_LAUNCH_CHECK(name)                                                    \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      tf_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+      return TF_EHIP;                                                            \
+    }                                                                            \
+  } while (0)
+
+static inline unsigned tf_blocks(int64_t n, int per_block) {
+  return (unsigned)((n + per_block - 1) / per_block);
+}
+
+// ---------------------------------------------------------------- packed VM pyramid geometry
+struct VmGeom {
+  int C, n_levels;
+  int ph[3], pw[3], ll[3];
+  // float offsets of plane i level l / line i level l inside the packed buffer
+  long long poff[3][4];
+  long long loff[3][4];
+  long long total;
+  float aabb_lo[3], aabb_inv[3];  // contraction: (x - lo) * inv  -- see note in vm_field.hip
+  float aabb_size[3];
+};
+
+static inline int vm_geom_init(const TfVmDesc* d, const float* aabb_host, VmGeom* g) {
+  if (!d) return -1;
+  if (d->C <= 0 || d->C % 4 != 0 || d->n_levels < 1 || d->n_levels > 4) return -1;
+  g->C = d->C;
+  g->n_levels = d->n_levels;
+  long long off = 0;
+  const int m = (1 << (d->n_levels - 1)) - 1;
+  for (int i = 0; i < 3; ++i) {
+    g->ph[i] = d->ph[i]; g->pw[i] = d->pw[i]; g->ll[i] = d->ll[i];
+    if (d->ph[i] < 1 || d->pw[i] < 1 || d->ll[i] < 1) return -1;
+    if ((d->ph[i] > 1 && (d->ph[i] & m)) || (d->pw[i] > 1 && (d->pw[i] & m)) || (d->ll[i] > 1 && (d->ll[i] & m)))
+      return -2;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int l = 0; l < 4; ++l) {
+      g->poff[i][l] = off;
+      if (l < d->n_levels) {
+        int h = d->ph[i] >> l, w = d->pw[i] >> l;
+        h = h < 1 ? 1 : h; w = w < 1 ? 1 : w;
+        off += (long long)h * w * d->C;
+      }
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int l = 0; l < 4; ++l) {
+      g->loff[i][l] = off;
+      if (l < d->n_levels) {
+        int n = d->ll[i] >> l;
+        n = n < 1 ? 1 : n;
+        off += (long long)n * d->C;
+      }
+    }
+  g->total = off;
+  for (int k = 0; k < 3; ++k) {
+    if (aabb_host) {
+      g->aabb_lo[k] = aabb_host[k];
+      g->aabb_size[k] = aabb_host[3 + k] - aabb_host[k];
+      g->aabb_inv[k] = 1.0f / g->aabb_size[k];
+    } else {
+      g->aabb_lo[k] = 0.f; g->aabb_size[k] = 1.f; g->aabb_inv[k] = 1.f;
+    }
+  }
+  return 0;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int vm_dim(int n, int l) { int v = n >> l; return v < 1 ? 1 : v; }
+
+// Bilinear tap set on one axis of size n (texel-centre addressing, clamp): i0, i1, frac.
+__device__ __forceinline__ void axis_taps(float t01, int n, int& i0, int& i1, float& f) {
+  float u = t01 * (float)n - 0.5f;
+  float fl = floorf(u);
+  f = u - fl;
+  int i = (int)fl;
+  i0 = min(max(i, 0), n - 1);
+  i1 = min(max(i + 1, 0), n - 1);
+}
+
+// Mip selection of dr.texture with mip_level_bias only: level clamped to [0, n_levels-1].
+__device__ __forceinline__ void mip_select(float level, int n_levels, int& l0, int& l1, float& f) {
+  float lv = fminf(fmaxf(level, 0.f), (float)(n_levels - 1));
+  float fl = floorf(lv);
+  l0 = (int)fl;
+  f = lv - fl;
+  l1 = min(l0 + 1, n_levels - 1);
+  if (l1 == l0) f = 0.f;
+}
+
+__device__ __forceinline__ float softplus100(float x) {
+  // torch.nn.Softplus(beta=100, threshold=20)
+  float bx = 100.f * x;
+  return bx > 20.f ? x : log1pf(expf(bx)) * 0.01f;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+#endif

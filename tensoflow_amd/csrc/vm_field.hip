@@ -1,0 +1,244 @@
+// VM-decomposed tensorial field: pyramid pack / unpack and the feature gather.
+// Replaces dr.texture x6 + permute().contiguous() + per-call mip rebuild of
+// network/fields.py:262-291, :776-806 and network/flow.py:709-738 (see include/tensoflow_hip.h).
+//
+// Data layout: channel-last packed pyramid (one texel = C*4 contiguous bytes), built once per
+// optimizer step.  Gather: one lane per (point, 16-byte channel chunk): the 3*C/4 lanes of a point
+// read each touched texel as one contiguous C*4-byte segment.
+#include "tf_common.h"
+
+// ------------------------------------------------------------------------------------ pack fwd
+// level 0: [C,H,W] -> [H,W,C].  One thread per pixel per pass over channels; transposed through LDS
+// so both the global read (along W) and the global write (along C) are coalesced.
+__global__ void __launch_bounds__(256) vm_pack_level0_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int C, long long npix) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [256][C+1]
+  const long long p0 = (long long)blockIdx.x * 256;
+  const int t = threadIdx.x;
+  const int stride = C + 1;
+  if (p0 + t < npix)
+    for (int c = 0; c < C; ++c) tile[t * stride + c] = src[(long long)c * npix + p0 + t];
+  __syncthreads();
+  const long long nvalid = min((long long)256, npix - p0);
+  for (long long e = t; e < nvalid * C; e += 256) {
+    int pix = (int)(e / C), c = (int)(e % C);
+    dst[p0 * C + e] = tile[pix * stride + c];
+  }
+}
+
+// level l from level l-1 (channel-last): 2x2 box (2x1 when one axis has size 1).
+__global__ void __launch_bounds__(256) vm_pack_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int hs, int ws, int hd, int wd) {
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)hd * wd * C;
+  if (e >= total) return;
+  int c = (int)(e % C);
+  long long pix = e / C;
+  int x = (int)(pix % wd), y = (int)(pix / wd);
+  int sy = hs > 1 ? 2 : 1, sx = ws > 1 ? 2 : 1;
+  float acc = 0.f;
+  // same association as the oracle: average over H first, then over W
+  if (sy == 2 && sx == 2) {
+    float a = 0.5f * (src[((long long)(2 * y) * ws + 2 * x) * C + c] + src[((long long)(2 * y + 1) * ws + 2 * x) * C + c]);
+    float b = 0.5f * (src[((long long)(2 * y) * ws + 2 * x + 1) * C + c] + src[((long long)(2 * y + 1) * ws + 2 * x + 1) * C + c]);
+    acc = 0.5f * (a + b);
+  } else if (sy == 2) {
+    acc = 0.5f * (src[((long long)(2 * y) * ws + x) * C + c] + src[((long long)(2 * y + 1) * ws + x) * C + c]);
+  } else if (sx == 2) {
+    acc = 0.5f * (src[((long long)y * ws + 2 * x) * C + c] + src[((long long)y * ws + 2 * x + 1) * C + c]);
+  } else {
+    acc = src[((long long)y * ws + x) * C + c];
+  }
+  dst[e] = acc;
+}
+
+// ------------------------------------------------------------------------------------ pack bwd
+// g[c,h,w] = sum_l  gp_l[h>>l, w>>l, c] / (box area at level l).  One thread per pixel, LDS transpose.
+__global__ void __launch_bounds__(256) vm_unpack_kernel(const float* __restrict__ gp, float* __restrict__ dst, int C,
+                                                        int H, int W, int n_levels, long long off0, long long off1,
+                                                        long long off2, long long off3) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [256][C+1]
+  const long long npix = (long long)H * W;
+  const long long p0 = (long long)blockIdx.x * 256;
+  const int t = threadIdx.x;
+  const int stride = C + 1;
+  const long long offs[4] = {off0, off1, off2, off3};
+  const long long nvalid = min((long long)256, npix - p0);
+  for (long long e = t; e < nvalid * C; e += 256) {
+    int pix = (int)(e / C), c = (int)(e % C);
+    long long p = p0 + pix;
+    int y = (int)(p / W), x = (int)(p % W);
+    float acc = 0.f, scale = 1.f;
+    int h = H, w = W;
+    for (int l = 0; l < n_levels; ++l) {
+      int yl = H > 1 ? (y >> l) : 0, xl = W > 1 ? (x >> l) : 0;
+      acc += scale * gp[offs[l] + ((long long)yl * w + xl) * C + c];
+      if (h > 1) { h >>= 1; scale *= 0.5f; }
+      if (w > 1) { w >>= 1; scale *= 0.5f; }
+    }
+    tile[pix * stride + c] = acc;
+  }
+  __syncthreads();
+  if (p0 + t < npix)
+    for (int c = 0; c < C; ++c) dst[(long long)c * npix + p0 + t] = tile[t * stride + c];
+}
+
+// ------------------------------------------------------------------------------------ gather
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float t) {
+  const float s = 1.f - t;
+  return make_float4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) vm_gather_kernel(VmGeom g, const float* __restrict__ packed,
+                                                        const float* __restrict__ xyz, const float* __restrict__ level,
+                                                        long long n, const float* __restrict__ gfeat,
+                                                        float* __restrict__ out) {
+  // one lane per (point, float4 chunk); chunks per point = 3*C/4
+  const int cpp = 3 * g.C / 4;
+  const int cpl = g.C / 4;
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * cpp) return;
+  long long pt = e / cpp;
+  int q = (int)(e % cpp);
+  int i = q / cpl, j = q % cpl;
+  float p[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = (xyz[pt * 3 + k] - g.aabb_lo[k]) / g.aabb_size[k];
+  const int m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2, vm = 2 - i;
+  float u = p[m0], v = p[m1], wv = p[vm];
+  int l0, l1;
+  float fl;
+  mip_select(level ? level[pt] : 0.f, g.n_levels, l0, l1, fl);
+  float4 pv = make_float4(0, 0, 0, 0), lv = make_float4(0, 0, 0, 0);
+  float4 gsum = make_float4(0, 0, 0, 0);
+  if (BWD) gsum = reinterpret_cast<const float4*>(gfeat)[e];
+  // two passes in BWD: first recompute pv, lv; then scatter.  FWD: single pass.
+  for (int pass = 0; pass < (BWD ? 2 : 1); ++pass) {
+    for (int li = 0; li < 2; ++li) {
+      int l = li ? l1 : l0;
+      float wl = li ? fl : 1.f - fl;
+      if (li && fl == 0.f) break;
+      int H = vm_dim(g.ph[i], l), W = vm_dim(g.pw[i], l), L = vm_dim(g.ll[i], l);
+      int x0, x1, y0, y1, z0, z1;
+      float fx, fy, fz;
+      axis_taps(u, W, x0, x1, fx);
+      axis_taps(v, H, y0, y1, fy);
+      axis_taps(wv, L, z0, z1, fz);
+      const long long pb = g.poff[i][l], lb = g.loff[i][l];
+      const long long a00 = pb + ((long long)y0 * W + x0) * g.C + 4 * j, a10 = pb + ((long long)y0 * W + x1) * g.C + 4 * j;
+      const long long a01 = pb + ((long long)y1 * W + x0) * g.C + 4 * j, a11 = pb + ((long long)y1 * W + x1) * g.C + 4 * j;
+      const long long b0 = lb + (long long)z0 * g.C + 4 * j, b1 = lb + (long long)z1 * g.C + 4 * j;
+      if (pass == 0) {
+        float4 t00 = *reinterpret_cast<const float4*>(packed + a00), t10 = *reinterpret_cast<const float4*>(packed + a10);
+        float4 t01 = *reinterpret_cast<const float4*>(packed + a01), t11 = *reinterpret_cast<const float4*>(packed + a11);
+        float4 s0 = *reinterpret_cast<const float4*>(packed + b0), s1 = *reinterpret_cast<const float4*>(packed + b1);
+        float4 top = lerp4(t00, t10, fx), bot = lerp4(t01, t11, fx);
+        float4 pl = lerp4(top, bot, fy), ln = lerp4(s0, s1, fz);
+        pv.x += wl * pl.x; pv.y += wl * pl.y; pv.z += wl * pl.z; pv.w += wl * pl.w;
+        lv.x += wl * ln.x; lv.y += wl * ln.y; lv.z += wl * ln.z; lv.w += wl * ln.w;
+      } else {
+        // d feat = gsum;  d plane-sample = gsum * lv ; d line-sample = gsum * pv
+        float4 gp_ = make_float4(gsum.x * lv.x * wl, gsum.y * lv.y * wl, gsum.z * lv.z * wl, gsum.w * lv.w * wl);
+        float4 gl_ = make_float4(gsum.x * pv.x * wl, gsum.y * pv.y * wl, gsum.z * pv.z * wl, gsum.w * pv.w * wl);
+#define ATOM4(addr, G, wt_) atomicAdd(out + (addr), G.x * (wt_)); atomicAdd(out + (addr) + 1, G.y * (wt_)); atomicAdd(out + (addr) + 2, G.z * (wt_)); atomicAdd(out + (addr) + 3, G.w * (wt_));
+        ATOM4(a00, gp_, (1.f - fx) * (1.f - fy)) ATOM4(a10, gp_, fx * (1.f - fy))
+        ATOM4(a01, gp_, (1.f - fx) * fy) ATOM4(a11, gp_, fx * fy)
+        ATOM4(b0, gl_, 1.f - fz) ATOM4(b1, gl_, fz)
+      }
+    }
+  }
+  if (!BWD) {
+    float4 f = make_float4(pv.x * lv.x, pv.y * lv.y, pv.z * lv.z, pv.w * lv.w);
+    reinterpret_cast<float4*>(out)[e] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" size_t tf_vm_packed_floats(const TfVmDesc* d) {
+  VmGeom g;
+  if (vm_geom_init(d, nullptr, &g) != 0) return 0;
+  return (size_t)g.total;
+}
+
+static int check_geom(const TfVmDesc* d, const float* aabb, VmGeom* g, const char* who) {
+  int rc = vm_geom_init(d, aabb, g);
+  TF_REQUIRE(rc != -1, TF_EINVAL, "%s: bad TfVmDesc (C must be a positive multiple of 4, 1<=n_levels<=4, sizes>=1)", who);
+  TF_REQUIRE(rc != -2, TF_ESHAPE, "%s: plane/line sizes > 1 must be divisible by 2^(n_levels-1)", who);
+  return 0;
+}
+
+extern "C" int tf_vm_pack_fwd(const TfVmDesc* d, const float* const planes[3], const float* const lines[3],
+                              float* packed, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VmGeom g;
+  if (int rc = check_geom(d, nullptr, &g, "tf_vm_pack_fwd")) return rc;
+  TF_REQUIRE(planes && lines && packed, TF_EINVAL, "tf_vm_pack_fwd: null pointer");
+  const size_t lds = 256 * (g.C + 1) * sizeof(float);
+  for (int i = 0; i < 3; ++i) {
+    TF_REQUIRE(planes[i] && lines[i], TF_EINVAL, "tf_vm_pack_fwd: null plane/line %d", i);
+    long long npix = (long long)g.ph[i] * g.pw[i];
+    vm_pack_level0_kernel<<<tf_blocks(npix, 256), 256, lds, stream>>>(planes[i], packed + g.poff[i][0], g.C, npix);
+    vm_pack_level0_kernel<<<tf_blocks(g.ll[i], 256), 256, lds, stream>>>(lines[i], packed + g.loff[i][0], g.C, g.ll[i]);
+    for (int l = 1; l < g.n_levels; ++l) {
+      int hs = g.ph[i] >> (l - 1), ws = g.pw[i] >> (l - 1), hd = g.ph[i] >> l, wd = g.pw[i] >> l;
+      hs = hs < 1 ? 1 : hs; ws = ws < 1 ? 1 : ws; hd = hd < 1 ? 1 : hd; wd = wd < 1 ? 1 : wd;
+      vm_pack_down_kernel<<<tf_blocks((long long)hd * wd * g.C, 256), 256, 0, stream>>>(
+          packed + g.poff[i][l - 1], packed + g.poff[i][l], g.C, hs, ws, hd, wd);
+      int ls = g.ll[i] >> (l - 1), ld = g.ll[i] >> l;
+      ls = ls < 1 ? 1 : ls; ld = ld < 1 ? 1 : ld;
+      vm_pack_down_kernel<<<tf_blocks((long long)ld * g.C, 256), 256, 0, stream>>>(
+          packed + g.loff[i][l - 1], packed + g.loff[i][l], g.C, ls, 1, ld, 1);
+    }
+  }
+  TF_LAUNCH_CHECK("tf_vm_pack_fwd");
+  return TF_OK;
+}
+
+extern "C" int tf_vm_pack_bwd(const TfVmDesc* d, const float* gpacked, float* const gplanes[3], float* const glines[3],
+                              tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VmGeom g;
+  if (int rc = check_geom(d, nullptr, &g, "tf_vm_pack_bwd")) return rc;
+  TF_REQUIRE(gpacked && gplanes && glines, TF_EINVAL, "tf_vm_pack_bwd: null pointer");
+  const size_t lds = 256 * (g.C + 1) * sizeof(float);
+  for (int i = 0; i < 3; ++i) {
+    TF_REQUIRE(gplanes[i] && glines[i], TF_EINVAL, "tf_vm_pack_bwd: null plane/line %d", i);
+    long long npix = (long long)g.ph[i] * g.pw[i];
+    vm_unpack_kernel<<<tf_blocks(npix, 256), 256, lds, stream>>>(gpacked, gplanes[i], g.C, g.ph[i], g.pw[i], g.n_levels,
+                                                                g.poff[i][0], g.poff[i][1], g.poff[i][2], g.poff[i][3]);
+    vm_unpack_kernel<<<tf_blocks(g.ll[i], 256), 256, lds, stream>>>(gpacked, glines[i], g.C, g.ll[i], 1, g.n_levels,
+                                                                   g.loff[i][0], g.loff[i][1], g.loff[i][2], g.loff[i][3]);
+  }
+  TF_LAUNCH_CHECK("tf_vm_pack_bwd");
+  return TF_OK;
+}
+
+extern "C" int tf_vm_gather_fwd(const TfVmDesc* d, const float* packed, const float* xyz, const float* level,
+                                const float* aabb_host, int64_t n, float* feat, tf_stream_t stream) {
+  VmGeom g;
+  TF_REQUIRE(aabb_host, TF_EINVAL, "tf_vm_gather_fwd: aabb_host is null");
+  if (int rc = check_geom(d, aabb_host, &g, "tf_vm_gather_fwd")) return rc;
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_vm_gather_fwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(packed && xyz && feat, TF_EINVAL, "tf_vm_gather_fwd: null pointer");
+  long long work = (long long)n * (3 * g.C / 4);
+  vm_gather_kernel<false><<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, nullptr, feat);
+  TF_LAUNCH_CHECK("tf_vm_gather_fwd");
+  return TF_OK;
+}
+
+extern "C" int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const float* xyz, const float* level,
+                                const float* aabb_host, int64_t n, const float* gfeat, float* gpacked,
+                                tf_stream_t stream) {
+  VmGeom g;
+  TF_REQUIRE(aabb_host, TF_EINVAL, "tf_vm_gather_bwd: aabb_host is null");
+  if (int rc = check_geom(d, aabb_host, &g, "tf_vm_gather_bwd")) return rc;
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_vm_gather_bwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(packed && xyz && gfeat && gpacked, TF_EINVAL, "tf_vm_gather_bwd: null pointer");
+  long long work = (long long)n * (3 * g.C / 4);
+  vm_gather_kernel<true><<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked);
+  TF_LAUNCH_CHECK("tf_vm_gather_bwd");
+  return TF_OK;
+}

@@ -1,0 +1,352 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point).
+
+PyTorch is plumbing here: it owns device memory and the stream; every op below validates
+its operands on the host (device, dtype, contiguity, shapes) BEFORE the kernel is launched,
+then enqueues on the current HIP stream.  No op has a PyTorch fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (tensoflow_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _aabb6(aabb):
+    a = torch.as_tensor(aabb, dtype=torch.float32).reshape(-1).cpu().tolist()
+    return (C.c_float * 6)(*a)
+
+
+def _f(t):
+    return t.contiguous().float()
+
+
+# ------------------------------------------------------------------------------ VM field
+class VmPacked:
+    """Channel-last packed mip pyramid of a VM field (built by tf_vm_pack_fwd)."""
+
+    def __init__(self, planes, lines, n_levels):
+        self.lib = L.load()
+        C_ = planes[0].shape[1]
+        d = L.TfVmDesc()
+        d.C, d.n_levels = C_, n_levels
+        for i in range(3):
+            assert planes[i].shape[0] == 1 and lines[i].shape[0] == 1 and lines[i].shape[3] == 1
+            assert planes[i].shape[1] == C_ and lines[i].shape[1] == C_
+            d.ph[i], d.pw[i], d.ll[i] = planes[i].shape[2], planes[i].shape[3], lines[i].shape[2]
+        self.desc = d
+        n = self.lib.tf_vm_packed_floats(C.byref(d))
+        if n == 0:
+            raise RuntimeError("tf_vm_packed_floats: invalid field geometry (C % 4, n_levels, divisibility)")
+        self.n_floats = n
+        self.C = C_
+        self.n_levels = n_levels
+        self.data = torch.empty(n, dtype=torch.float32, device=planes[0].device)
+        self.repack(planes, lines)
+
+    def repack(self, planes, lines):
+        pl = [_f(p.detach()) for p in planes]
+        ln = [_f(l.detach()) for l in lines]
+        pa = (C.c_void_p * 3)(*[p.data_ptr() for p in pl])
+        la = (C.c_void_p * 3)(*[l.data_ptr() for l in ln])
+        L.check(self.lib.tf_vm_pack_fwd(C.byref(self.desc), C.byref(pa), C.byref(la), _p(self.data), _stream()),
+                "tf_vm_pack_fwd")
+
+    def unpack_grad(self, gpacked, planes, lines):
+        gp = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in planes]
+        gl = [torch.empty_like(l, memory_format=torch.contiguous_format) for l in lines]
+        pa = (C.c_void_p * 3)(*[p.data_ptr() for p in gp])
+        la = (C.c_void_p * 3)(*[l.data_ptr() for l in gl])
+        L.check(self.lib.tf_vm_pack_bwd(C.byref(self.desc), _p(gpacked), C.byref(pa), C.byref(la), _stream()),
+                "tf_vm_pack_bwd")
+        return gp, gl
+
+
+def vm_gather(packed: VmPacked, xyz, level, aabb):
+    xyz = _f(xyz)
+    n = xyz.shape[0]
+    feat = torch.empty(n, 3 * packed.C, dtype=torch.float32, device=xyz.device)
+    lv = None if level is None else _f(level.reshape(-1))
+    L.check(packed.lib.tf_vm_gather_fwd(C.byref(packed.desc), _p(packed.data), _p(xyz), _p(lv), C.byref(_aabb6(aabb)), n,
+                                        _p(feat), _stream()), "tf_vm_gather_fwd")
+    return feat
+
+
+def vm_gather_bwd(packed: VmPacked, xyz, level, aabb, gfeat):
+    xyz = _f(xyz)
+    gfeat = _f(gfeat)
+    gpacked = torch.zeros_like(packed.data)
+    lv = None if level is None else _f(level.reshape(-1))
+    L.check(packed.lib.tf_vm_gather_bwd(C.byref(packed.desc), _p(packed.data), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
+                                        xyz.shape[0], _p(gfeat), _p(gpacked), _stream()), "tf_vm_gather_bwd")
+    return gpacked
+
+
+# ------------------------------------------------------------------------------ SDF decoder
+def _sdf_mlp(w1, b1, w2, b2):
+    m = L.TfSdfMlp()
+    keep = [_f(w1), _f(b1), _f(w2), _f(b2)]
+    m.w1, m.b1, m.w2, m.b2 = [t.data_ptr() for t in keep]
+    m.hidden, m.app_dim = w1.shape[0], w2.shape[0] - 1
+    return m, keep
+
+
+_ws_cache = {}
+
+
+def _workspace(key, n_floats, device):
+    t = _ws_cache.get((key, str(device)))
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+        _ws_cache[(key, str(device))] = t
+    return t
+
+
+def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=True):
+    """TensoSDF.forward -> (sdf [n], feat [n,A] or None)."""
+    lib = packed.lib
+    xyz = _f(xyz)
+    n = xyz.shape[0]
+    mlp, keep = _sdf_mlp(w1, b1, w2, b2)
+    sdf = torch.empty(n, dtype=torch.float32, device=xyz.device)
+    feat = torch.empty(n, w2.shape[0] - 1, dtype=torch.float32, device=xyz.device) if want_feat else None
+    ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), xyz.device)
+    lv = None if level is None else _f(level.reshape(-1))
+    L.check(lib.tf_sdf_forward(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
+                               n, _p(sdf), _p(feat), _p(ws), ws.numel(), _stream()), "tf_sdf_forward")
+    return sdf, feat
+
+
+def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, units, inv_s, cos_anneal,
+              want_feat=True, want_hess=True):
+    """ShapeRenderer.compute_sdf_alpha -> alpha, grad, feat, sdf, normal_hessian."""
+    lib = packed.lib
+    pts, dists, dirs = _f(pts), _f(dists.reshape(-1)), _f(dirs)
+    n = pts.shape[0]
+    dev = pts.device
+    mlp, keep = _sdf_mlp(w1, b1, w2, b2)
+    alpha = torch.empty(n, dtype=torch.float32, device=dev)
+    grad = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    feat = torch.empty(n, w2.shape[0] - 1, dtype=torch.float32, device=dev) if want_feat else None
+    nh = torch.empty(n, dtype=torch.float32, device=dev) if want_hess else None
+    ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), dev)
+    lv = None if level is None else _f(level.reshape(-1))
+    un = (C.c_float * 3)(*[float(u) for u in units])
+    L.check(lib.tf_sdf_alpha_fwd(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
+                                 C.byref(_aabb6(aabb)), C.byref(un), float(inv_s), float(cos_anneal), n, _p(alpha), _p(grad),
+                                 _p(feat), _p(sdf), _p(nh), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
+    return alpha, grad, feat, sdf, nh
+
+
+# ------------------------------------------------------------------------------ compositing
+def composite(alpha, ray_indices, values, n_rays):
+    lib = L.load()
+    alpha = _f(alpha)
+    n = alpha.shape[0]
+    k = 0 if values is None else values.shape[1]
+    values = None if values is None else _f(values)
+    dev = alpha.device
+    w = torch.empty(n, dtype=torch.float32, device=dev)
+    acc = torch.empty(n_rays, dtype=torch.float32, device=dev)
+    out = torch.empty(n_rays, k, dtype=torch.float32, device=dev)
+    L.check(lib.tf_composite_fwd(_p(alpha), _p(ray_indices, torch.int64), _p(values), n, n_rays, k, _p(w), _p(acc), _p(out),
+                                 _stream()), "tf_composite_fwd")
+    return w, acc, out
+
+
+def composite_bwd(alpha, ray_indices, values, weights, g_acc, g_out, n_rays):
+    lib = L.load()
+    n = alpha.shape[0]
+    k = 0 if values is None else values.shape[1]
+    g_alpha = torch.empty_like(alpha)
+    g_values = None if values is None else torch.empty_like(values)
+    L.check(lib.tf_composite_bwd(_p(alpha), _p(ray_indices, torch.int64), _p(values), _p(weights),
+                                 _p(None if g_acc is None else _f(g_acc)), _p(None if g_out is None else _f(g_out)), n, n_rays,
+                                 k, _p(g_alpha), _p(g_values), _stream()), "tf_composite_bwd")
+    return g_alpha, g_values
+
+
+# ------------------------------------------------------------------------------ flow
+def _coupling_nets(weights):
+    """weights: list of 2 lists of 4 (W, b) pairs."""
+    nets = (L.TfCouplingNet * 2)()
+    keep = []
+    for b in range(2):
+        for l in range(4):
+            W, bias = _f(weights[b][l][0]), _f(weights[b][l][1])
+            keep += [W, bias]
+            nets[b].w[l] = W.data_ptr()
+            nets[b].b[l] = bias.data_ptr()
+    expect = [(64, 44), (64, 64), (64, 64), (21, 64)]
+    for b in range(2):
+        for l in range(4):
+            if tuple(weights[b][l][0].shape) != expect[l]:
+                raise RuntimeError(f"coupling net {b} layer {l}: weight shape {tuple(weights[b][l][0].shape)} != {expect[l]}")
+    return nets, keep
+
+
+def flow_sample(weights, cond, latent, jitter=None, want_bins=False):
+    """-> angles [pn,sn,2], logj [pn,sn,1] (, bins [pn,sn,2] int32)."""
+    lib = L.load()
+    cond, latent = _f(cond), _f(latent)
+    pn, sn = cond.shape[0], latent.shape[0]
+    if cond.shape[1] != 37:
+        raise RuntimeError("cond must be [pn,37]")
+    dev = cond.device
+    nets, keep = _coupling_nets(weights)
+    ang = torch.empty(pn, sn, 2, dtype=torch.float32, device=dev)
+    lj = torch.empty(pn, sn, 1, dtype=torch.float32, device=dev)
+    bins = torch.empty(pn, sn, 2, dtype=torch.int32, device=dev) if want_bins else None
+    ws = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev)
+    jit = None if jitter is None else _f(jitter.reshape(pn, sn))
+    L.check(lib.tf_flow_sample_fwd(C.byref(nets), _p(cond), _p(latent), _p(jit), pn, sn, _p(ang), _p(lj), _p(bins, torch.int32),
+                                   _p(ws), ws.numel(), _stream()), "tf_flow_sample_fwd")
+    return (ang, lj, bins) if want_bins else (ang, lj)
+
+
+def flow_logq(weights, cond, x, rays_id=None, want_bins=False):
+    """x [pn,sn,2] (rays_id None) or [m,2] with rays_id [m] int64 -> z (same shape), logq [...,1]."""
+    lib = L.load()
+    cond, x = _f(cond), _f(x)
+    pn = cond.shape[0]
+    dev = cond.device
+    shape = x.shape[:-1]
+    m = int(np.prod(shape)) if len(shape) else 1
+    sn = x.shape[1] if rays_id is None else 1
+    nets, keep = _coupling_nets(weights)
+    z = torch.empty_like(x)
+    lq = torch.empty(*shape, 1, dtype=torch.float32, device=dev)
+    bins = torch.empty(*shape, 2, dtype=torch.int32, device=dev) if want_bins else None
+    ws = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev)
+    rid = None if rays_id is None else rays_id.contiguous()
+    L.check(lib.tf_flow_logq_fwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(z), _p(lq),
+                                 _p(bins, torch.int32), _p(ws), ws.numel(), _stream()), "tf_flow_logq_fwd")
+    return (z, lq, bins) if want_bins else (z, lq)
+
+
+# ------------------------------------------------------------------------------ light / mesh / shading
+def cube_lookup(base, dirs, apply_exp=True):
+    lib = L.load()
+    base, dirs = _f(base), _f(dirs.reshape(-1, 3))
+    assert base.dim() == 4 and base.shape[0] == 6 and base.shape[1] == base.shape[2] and base.shape[3] == 3
+    out = torch.empty_like(dirs)
+    L.check(lib.tf_cube_lookup_fwd(_p(base), base.shape[1], _p(dirs), dirs.shape[0], int(apply_exp), _p(out), _stream()),
+            "tf_cube_lookup_fwd")
+    return out
+
+
+def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
+    lib = L.load()
+    base, dirs, g_out = _f(base), _f(dirs.reshape(-1, 3)), _f(g_out.reshape(-1, 3))
+    g_base = torch.zeros_like(base)
+    L.check(lib.tf_cube_lookup_bwd(_p(base), base.shape[1], _p(dirs), dirs.shape[0], int(apply_exp), _p(g_out), _p(g_base),
+                                   _stream()), "tf_cube_lookup_bwd")
+    return g_base
+
+
+class Bvh:
+    """Host-built BVH uploaded to the device (replaces raytracing.RayTracer, raytracing/raytracer.py:7-17)."""
+
+    def __init__(self, vertices, triangles, device="cuda"):
+        self.lib = L.load()
+        v = np.ascontiguousarray(np.asarray(vertices, dtype=np.float32))
+        f = np.ascontiguousarray(np.asarray(triangles, dtype=np.int32))
+        if f.shape[0] <= 8:
+            raise AssertionError("BVH needs at least 8 triangles.")       # raytracer.py:15
+        nodes = np.zeros((2 * f.shape[0], 8), dtype=np.float32)
+        tris = np.zeros((f.shape[0], 9), dtype=np.float32)
+        n = self.lib.tf_bvh_build_host(v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], nodes.ctypes.data, tris.ctypes.data)
+        if n <= 0:
+            L.check(int(n), "tf_bvh_build_host")
+        self.n_nodes = int(n)
+        self.nodes = torch.from_numpy(nodes[:n].copy()).to(device)
+        self.tris = torch.from_numpy(tris).to(device)
+
+    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True):
+        o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
+        m = o.shape[0]
+        dev = o.device
+        pos = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_pos else None
+        nrm = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_nrm else None
+        depth = torch.empty(m, dtype=torch.float32, device=dev)
+        hit = torch.empty(m, dtype=torch.uint8, device=dev)
+        L.check(self.lib.tf_bvh_trace(_p(self.nodes), _p(self.tris), self.n_nodes, _p(o), _p(d), float(off0), float(off1), m,
+                                      _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8), _stream()), "tf_bvh_trace")
+        return pos, nrm, depth, hit.bool()
+
+
+def inner_light(weights, pts, view, nrm, exp_max=5.0):
+    """weights: 4 (W_eff, b) pairs, 123-256-256-256-3."""
+    lib = L.load()
+    pts, view, nrm = _f(pts), _f(view), _f(nrm)
+    net = L.TfMlp4()
+    keep = []
+    expect = [(256, 123), (256, 256), (256, 256), (3, 256)]
+    for l in range(4):
+        W, b = _f(weights[l][0]), _f(weights[l][1])
+        if tuple(W.shape) != expect[l]:
+            raise RuntimeError(f"inner light layer {l}: weight shape {tuple(W.shape)} != {expect[l]}")
+        keep += [W, b]
+        net.w[l], net.b[l] = W.data_ptr(), b.data_ptr()
+    out = torch.empty_like(pts)
+    ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pts.device)
+    L.check(lib.tf_inner_light_fwd(C.byref(net), _p(pts), _p(view), _p(nrm), pts.shape[0], float(exp_max), _p(out), _p(ws),
+                                   ws.numel(), _stream()), "tf_inner_light_fwd")
+    return out
+
+
+def view_angles(normals, view):
+    lib = L.load()
+    normals, view = _f(normals), _f(view)
+    va = torch.empty(normals.shape[0], 2, dtype=torch.float32, device=normals.device)
+    L.check(lib.tf_view_angles(_p(normals), _p(view), normals.shape[0], _p(va), _stream()), "tf_view_angles")
+    return va
+
+
+def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None):
+    lib = L.load()
+    pn = normals.shape[0]
+    sd = 0 if ang_d is None else ang_d.shape[1]
+    nf = 0 if fixed_d is None else fixed_d.shape[0]
+    ss = 0 if ang_s is None else ang_s.shape[1]
+    T = sd + nf + ss
+    dev = normals.device
+    dirs = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
+    wgt = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
+    mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
+    g = lambda t: None if t is None else _f(t)
+    L.check(lib.tf_shade_dirs(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                              _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
+                              _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(g(ang_s)),
+                              _p(g(None if logq_s is None else logq_s.reshape(pn, ss))), ss, pn, _p(dirs), _p(wgt),
+                              _p(mask, torch.uint8), _stream()), "tf_shade_dirs")
+    return dirs, wgt, mask.bool()
+
+
+def shade_reduce(wgt, lights, n_diffuse, ss):
+    lib = L.load()
+    pn = wgt.shape[0]
+    dev = wgt.device
+    colors = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    dl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    sl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    L.check(lib.tf_shade_reduce(_p(_f(wgt)), _p(_f(lights)), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl), _stream()),
+            "tf_shade_reduce")
+    return colors, dl, sl

@@ -1,0 +1,144 @@
+"""Host-side composition of the flow-sampled rendering integral on the MI355X.
+
+Mirrors MCShadingNetwork.forward -> shade_mixed (network/fields.py:1453-1473, :1075-1235) and
+MCShadingNetwork.get_lights (:951-975) with every per-sample stage on the HIP kernels of
+libtensoflow_hip.so (flow sampling, direction/pdf/BRDF construction, BVH visibility, cube-map
+lookup, inner-light MLP, reduction).  Only the per-POINT tiny MLPs (material predictors
+108-128-{1,1,3}, flow feature net 57-64-16) are plain library GEMMs through torch.
+
+Parameters are taken from a reference-layout state_dict (same keys as MCShadingNetwork).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def posenc(x, n_freq):
+    out = [x]
+    for k in range(n_freq):
+        out += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
+    return torch.cat(out, -1)
+
+
+def wn_weight(sd, prefix):
+    k0 = prefix + ".parametrizations.weight.original0"
+    if k0 in sd:
+        v = sd[prefix + ".parametrizations.weight.original1"]
+        return sd[k0] * v / v.norm(dim=1, keepdim=True)
+    return sd[prefix + ".weight"]
+
+
+def fibonacci_samples(n):
+    """MCShadingNetwork fixed direction set (fields.py:734-737 via utils/base_utils.py:869-882) -> [n,2]."""
+    g = (np.sqrt(5) - 1.0) / 2.0
+    num_points = int(n // (1 - 0.5))
+    k = np.arange(num_points - n, num_points, dtype=np.float64)
+    az = (2 * np.pi * k * g) % (2 * np.pi)
+    el = np.arcsin(2.0 * k / num_points - 1.0)
+    return torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32))
+
+
+def sphere_latent(sn):
+    """SphereSampler.set_angle (flow.py:62-76) -> [sn,2]."""
+    num_points = int(sn // (1 - (1 + 90) / 180))
+    g = (np.sqrt(5) - 1.0) / 2.0
+    k = np.arange(num_points - sn, num_points, dtype=np.float64)
+    phi = (2 * np.pi * k * g) % (2 * np.pi)
+    th = np.arcsin(2.0 * k / num_points - 1.0)
+    phi = torch.tensor(phi, dtype=torch.float32) / (2 * np.pi)
+    th = torch.tensor(th, dtype=torch.float32) / (0.5 * np.pi)
+    return torch.stack([phi, th], -1)
+
+
+class FlowParams:
+    """One TensoFlow (nis planes/lines + nis_mat + 2 coupling nets) resident on the device."""
+
+    def __init__(self, sd, prefix, device, n_levels=3):
+        g = lambda k: sd[prefix + k].to(device).float().contiguous()
+        self.planes = [g(f"nis_plane.{i}") for i in range(3)]
+        self.lines = [g(f"nis_line.{i}") for i in range(3)]
+        self.packed = ops.VmPacked(self.planes, self.lines, n_levels)
+        self.mat = [(g("nis_mat.0.weight"), g("nis_mat.0.bias")), (g("nis_mat.2.weight"), g("nis_mat.2.bias"))]
+        self.nets = [[(g(f"flows.{b}.nn.{l}.weight"), g(f"flows.{b}.nn.{l}.bias")) for l in (1, 3, 5, 7)] for b in range(2)]
+
+    def condition(self, pts, view_angles, aabb):
+        """[pn,37] = [feature 16 | embed3(view_angles) 14 | 7 zeros] (flow.py:803-815, :836-848)."""
+        feat = ops.vm_gather(self.packed, pts, None, aabb)
+        h = torch.cat([feat, posenc(pts, 3)], -1)
+        h = F.softplus(F.linear(h, *self.mat[0]), beta=100)
+        h = F.linear(h, *self.mat[1])
+        return torch.cat([h, posenc(view_angles, 3), torch.zeros(pts.shape[0], 7, device=pts.device)], -1).contiguous()
+
+
+class MCShader:
+    """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
+
+    def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
+                 exp_max=5.0, flow_suffix="_copy"):
+        self.device = device
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
+        self.unit = float(unit_size)
+        self.exp_max = exp_max
+        g = lambda k: sd[k].to(device).float().contiguous()
+        self.mat_planes = [g(f"mat_plane.{i}") for i in range(3)]
+        self.mat_lines = [g(f"mat_line.{i}") for i in range(3)]
+        self.mat_packed = ops.VmPacked(self.mat_planes, self.mat_lines, 3)
+        sdd = {k: v.to(device).float() for k, v in sd.items() if v.is_floating_point() and ("predictor" in k or "inner_light" in k)}
+        self.pred = {name: [(wn_weight(sdd, f"{name}_predictor.{i}").contiguous(), sdd[f"{name}_predictor.{i}.bias"]) for i in (0, 2)]
+                     for name in ("metallic", "roughness", "albedo")}
+        self.inner = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
+        self.env = g("outer_light.base")
+        self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device)
+        self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device)
+        self.bvh = ops.Bvh(vertices, triangles, device)
+        self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
+        self._latent = {}
+
+    def latent(self, sn):
+        if sn not in self._latent:
+            self._latent[sn] = sphere_latent(sn).to(self.device)
+        return self._latent[sn]
+
+    def predict_materials(self, pts):
+        feat = ops.vm_gather(self.mat_packed, pts, None, self.aabb)
+        out = {}
+        for name, layers in self.pred.items():
+            out[name] = torch.sigmoid(F.linear(F.relu(F.linear(feat, *layers[0])), *layers[1]))
+        rough = out["roughness"] * (1.0 - 0.04 ** 2) + 0.04 ** 2
+        return out["metallic"], rough, out["albedo"]
+
+    def lights(self, pts_rep, dirs):
+        """get_lights (fields.py:951-975): pts_rep, dirs [M,3] -> lights [M,3], hit [M] bool."""
+        inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit)
+        lights = ops.cube_lookup(self.env, dirs, apply_exp=True)
+        idx = torch.nonzero(hit, as_tuple=False)[:, 0]
+        if idx.numel() > 0:
+            inner = ops.inner_light(self.inner, inters[idx], -dirs[idx], nrm[idx], self.exp_max)
+            lights.index_copy_(0, idx, inner)
+        lights = lights * (depth > 1e-5).float()[:, None]
+        return lights, hit, inters
+
+    @torch.no_grad()
+    def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None):
+        """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)"""
+        pts = pts.to(self.device).float().contiguous()
+        pn = pts.shape[0]
+        metallic, rough, albedo = self.predict_materials(pts)
+        va = ops.view_angles(normals, view_dirs)
+        ang_d, lq_d = ops.flow_sample(self.flow_d.nets, self.flow_d.condition(pts, va, self.aabb), self.latent(sn_diffuse), jitter_d)
+        ang_s, lq_s = ops.flow_sample(self.flow_s.nets, self.flow_s.condition(pts, va, self.aabb), self.latent(sn_specular), jitter_s)
+        dirs, wgt, smask = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
+        T = dirs.shape[1]
+        pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
+        lights, hit, inters = self.lights(pts_rep, dirs.reshape(-1, 3))
+        n_diff = sn_diffuse + self.fixed_d.shape[0]
+        colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
+        rid = torch.arange(pn, device=self.device)[:, None].expand(pn, sn_specular)[smask]
+        return dict(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
+                    specular_mask=smask, specular_rays_id=rid, hit=hit.reshape(pn, T), view_angles=va,
+                    diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
+                    lights=lights.reshape(pn, T, 3))

@@ -1,0 +1,94 @@
+"""CPU checks of the drop-in boundary: the shared library builds, loads, and exports every symbol
+include/tensoflow_hip.h declares; the ctypes table mirrors the header; host-side argument
+validation fails loudly without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tensoflow_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return L.load()
+
+
+def _declared():
+    txt = open(os.path.join(REPO, "include", "tensoflow_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", txt)) - {"tf_stream_t"})
+
+
+def test_exports_every_declared_symbol(lib):
+    from tensoflow_amd import lib as L
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(L.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.tf_version() >= 100
+
+
+def test_packed_floats_and_validation(lib):
+    from tensoflow_amd import lib as L
+    d = L.TfVmDesc()
+    d.C, d.n_levels = 36, 3
+    for i in range(3):
+        d.ph[i] = d.pw[i] = d.ll[i] = 300
+    n = lib.tf_vm_packed_floats(C.byref(d))
+    expect = 3 * 36 * (300 * 300 + 150 * 150 + 75 * 75) + 3 * 36 * (300 + 150 + 75)
+    assert n == expect
+    d.ph[0] = 302                         # not divisible by 4 -> invalid geometry
+    assert lib.tf_vm_packed_floats(C.byref(d)) == 0
+    # null-pointer / shape errors are reported through the return code + tf_last_error, before any launch
+    aabb = (C.c_float * 6)(-1, -1, -1, 1, 1, 1)
+    rc = lib.tf_vm_gather_fwd(C.byref(d), None, None, None, C.byref(aabb), 5, None, None)
+    assert rc == -2 and b"divisible" in lib.tf_last_error()
+    d.ph[0] = 300
+    rc = lib.tf_vm_gather_fwd(C.byref(d), None, None, None, C.byref(aabb), 5, None, None)
+    assert rc == -1 and b"null" in lib.tf_last_error()
+    assert lib.tf_vm_gather_fwd(C.byref(d), None, None, None, C.byref(aabb), 0, None, None) == 0   # empty input is fine
+    assert lib.tf_composite_fwd(None, None, None, 0, 0, 0, None, None, None, None) == 0
+    assert lib.tf_flow_workspace_floats(10) > 2 * 64 * 10
+    assert lib.tf_sdf_workspace_floats() > 8 * 56 * 64
+
+
+def test_bvh_build_host(lib):
+    from tensoflow_amd.synth import sphere_torus_mesh
+    v, f = sphere_torus_mesh(8, 12, 16, 8)
+    nodes = np.zeros((2 * len(f), 8), np.float32)
+    tris = np.zeros((len(f), 9), np.float32)
+    n = lib.tf_bvh_build_host(v.ctypes.data, len(v), f.ctypes.data, len(f), nodes.ctypes.data, tris.ctypes.data)
+    assert 0 < n <= 2 * len(f)
+    nd = nodes[:n]
+    cnt = nd[:, 7].view(np.int32)
+    left = nd[:, 3].view(np.int32)
+    leaves = cnt > 0
+    assert cnt[leaves].sum() == len(f) and cnt.max() <= 4          # every triangle in exactly one leaf
+    # every triangle lies inside its leaf box, every child box inside the root box
+    for i in np.nonzero(leaves)[0]:
+        t = tris[left[i]:left[i] + cnt[i]].reshape(-1, 3)
+        assert (t >= nd[i, 0:3] - 1e-6).all() and (t <= nd[i, 4:7] + 1e-6).all()
+    assert (nd[:, 0:3] >= nd[0, 0:3] - 1e-6).all() and (nd[:, 4:7] <= nd[0, 4:7] + 1e-6).all()
+    # the reordered soup is a permutation of the input triangles
+    a = np.sort(v[f].reshape(len(f), 9).round(6).view([("", np.float32)] * 9), axis=0)
+    b = np.sort(tris.round(6).view([("", np.float32)] * 9), axis=0)
+    assert (a == b).all()
+    bad = f.copy(); bad[0, 0] = 10 ** 6
+    assert lib.tf_bvh_build_host(v.ctypes.data, len(v), bad.ctypes.data, len(f), nodes.ctypes.data, tris.ctypes.data) == -2
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    from tensoflow_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.cube_lookup(torch.zeros(6, 4, 4, 3), torch.zeros(5, 3))

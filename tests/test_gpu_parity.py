@@ -1,0 +1,266 @@
+"""GPU parity: HIP kernels (through the C ABI, tensoflow_amd.ops) vs the CPU oracle and the golden
+vectors generated from the imported reference.  Tolerance: 1e-4 relative fp32 (north_star);
+integer / boolean outputs bit-exact.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import AABB, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test collected but no GPU is visible")
+    return torch.device("cuda:0")
+
+
+def _planes(sd, pfx, dev):
+    return [sd[f"{pfx}plane.{i}"].to(dev) for i in range(3)], [sd[f"{pfx}line.{i}"].to(dev) for i in range(3)]
+
+
+# ------------------------------------------------------------------------------- VM field
+@pytest.mark.parametrize("tag", ["r32_l1", "r32_l3", "r24x32x40_l3"])
+def test_vm_gather_matches_oracle(golden, dev, tag):
+    from oracle import vm_field as ovm
+    from tensoflow_amd import ops
+    g = golden("tensosdf_" + tag)
+    nl = int(g["n_levels"])
+    planes, lines = _planes(g.sd, "sdf_", dev)
+    packed = ops.VmPacked(planes, lines, nl)
+    for level in (None, g["level"]):
+        feat = ops.vm_gather(packed, g["pts"].to(dev), None if level is None else level.to(dev), AABB)
+        pf, lf = ovm.vm_gather([p.cpu() for p in planes], [l.cpu() for l in lines],
+                               ovm.contraction(g["pts"], AABB), None if level is None else level[:, 0], nl)
+        assert rel_err(feat.cpu(), pf * lf) < TOL
+
+
+def test_vm_pack_roundtrip_and_backward(golden, dev):
+    """pack -> gather -> backward through (gather_bwd, pack_bwd) == autograd of the oracle."""
+    from oracle import vm_field as ovm
+    from tensoflow_amd import ops
+    g = golden("tensosdf_r32_l3")
+    planes, lines = _planes(g.sd, "sdf_", dev)
+    packed = ops.VmPacked(planes, lines, 3)
+    pts, level = g["pts"], g["level"]
+    gen = torch.Generator().manual_seed(0)
+    gfeat = torch.randn(pts.shape[0], 108, generator=gen)
+    gp = ops.vm_gather_bwd(packed, pts.to(dev), level.to(dev), AABB, gfeat.to(dev))
+    gplanes, glines = packed.unpack_grad(gp, planes, lines)
+    pl = [p.cpu().clone().requires_grad_(True) for p in planes]
+    ln = [l.cpu().clone().requires_grad_(True) for l in lines]
+    pf, lf = ovm.vm_gather(pl, ln, ovm.contraction(pts, AABB), level[:, 0], 3)
+    ((pf * lf) * gfeat).sum().backward()
+    for i in range(3):
+        assert rel_err(gplanes[i].cpu(), pl[i].grad) < TOL
+        assert rel_err(glines[i].cpu(), ln[i].grad) < TOL
+
+
+# ------------------------------------------------------------------------------- SDF
+@pytest.mark.parametrize("tag", ["r32_l1", "r32_l3", "r24x32x40_l3"])
+def test_sdf_forward_golden(golden, dev, tag):
+    from tensoflow_amd import ops
+    g = golden("tensosdf_" + tag)
+    nl = int(g["n_levels"])
+    planes, lines = _planes(g.sd, "sdf_", dev)
+    packed = ops.VmPacked(planes, lines, nl)
+    W = [g.sd[k].to(dev) for k in ("sdf_mat.0.weight", "sdf_mat.0.bias", "sdf_mat.2.weight", "sdf_mat.2.bias")]
+    for level, ref in ((None, g["out_none"]), (g["level"], g["out_lvl"])):
+        sdf, feat = ops.sdf_forward(packed, *W, g["pts"].to(dev), None if level is None else level.to(dev), AABB)
+        assert rel_err(sdf.cpu(), ref[:, 0]) < TOL
+        assert rel_err(feat.cpu(), ref[:, 1:]) < TOL
+        sdf_only, none = ops.sdf_forward(packed, *W, g["pts"].to(dev), None if level is None else level.to(dev), AABB,
+                                         want_feat=False)
+        assert none is None and torch.equal(sdf_only, sdf)
+
+
+def test_sdf_alpha_golden(golden, dev):
+    from tensoflow_amd import ops
+    g = golden("march_r32")
+    planes, lines = _planes(g.sd, "sdf_network.sdf_", dev)
+    packed = ops.VmPacked(planes, lines, 3)
+    W = [g.sd["sdf_network." + k].to(dev) for k in ("sdf_mat.0.weight", "sdf_mat.0.bias", "sdf_mat.2.weight", "sdf_mat.2.bias")]
+    ridx = g["ray_indices"]
+    dists = g["t_ends"] - g["t_starts"]
+    units = (AABB[1] - AABB[0]) / (torch.tensor([32.0, 32.0, 32.0]) - 1)
+    inv_s = float(torch.exp(g.sd["deviation_network.variance"] * 10.0))
+    for ca in (0.0, 0.5, 1.0):
+        alpha, grad, feat, sdf, nh = ops.sdf_alpha(packed, *W, g["sample_pts"].to(dev), g["sample_levels"].to(dev),
+                                                   dists.to(dev), g["dirs"][ridx].to(dev), AABB, units, inv_s, ca)
+        assert rel_err(alpha.cpu(), g[f"alpha_{ca}"]) < TOL
+    assert rel_err(grad.cpu(), g["sa_grad"]) < TOL
+    assert rel_err(feat.cpu(), g["sa_feat"]) < TOL
+    assert rel_err(sdf.cpu(), g["sa_sdf"]) < TOL
+    # second differences divide rounding noise by eps^2 = 4e-3: same looser bound as the oracle-vs-reference test
+    assert rel_err(nh.cpu(), g["sa_hess"]) < 2e-3
+
+
+# ------------------------------------------------------------------------------- compositing
+def test_composite_matches_oracle(dev):
+    from oracle import segments as oseg
+    from tensoflow_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n_rays = 257
+    counts = torch.randint(0, 200, (n_rays,), generator=gen)
+    counts[5] = 0
+    counts[17] = 300                       # > 4 wave chunks
+    ridx = torch.repeat_interleave(torch.arange(n_rays), counts)
+    n = ridx.shape[0]
+    alpha = torch.rand(n, generator=gen) ** 3
+    alpha[::97] = 1.0
+    alpha[1::89] = 0.0
+    vals = torch.randn(n, 3, generator=gen)
+    w, acc, out = ops.composite(alpha.to(dev), ridx.to(dev), vals.to(dev), n_rays)
+    w_ref, _ = oseg.render_weight_from_alpha_seq(alpha, ridx)
+    assert rel_err(w.cpu(), w_ref) < 1e-5
+    assert rel_err(acc.cpu(), oseg.accumulate_along_rays(w_ref, None, ridx, n_rays)[:, 0]) < 1e-5
+    assert rel_err(out.cpu(), oseg.accumulate_along_rays(w_ref, vals, ridx, n_rays)) < 1e-5
+    # empty input
+    w0, acc0, out0 = ops.composite(alpha[:0].to(dev), ridx[:0].to(dev), vals[:0].to(dev), 4)
+    assert acc0.abs().sum() == 0 and out0.abs().sum() == 0
+    # backward vs autograd through the oracle scan
+    a = alpha.clone().clamp(max=0.98).requires_grad_(True)
+    v = vals.clone().requires_grad_(True)
+    wr, _ = oseg.render_weight_from_alpha(a, ray_indices=ridx, n_rays=n_rays)
+    g_acc = torch.randn(n_rays, generator=gen)
+    g_out = torch.randn(n_rays, 3, generator=gen)
+    (oseg.accumulate_along_rays(wr, None, ridx, n_rays)[:, 0] * g_acc).sum().backward(retain_graph=True)
+    (oseg.accumulate_along_rays(wr, v, ridx, n_rays) * g_out).sum().backward()
+    ad = a.detach().to(dev)
+    w2, _, _ = ops.composite(ad, ridx.to(dev), vals.to(dev), n_rays)
+    ga, gv = ops.composite_bwd(ad, ridx.to(dev), vals.to(dev), w2, g_acc.to(dev), g_out.to(dev), n_rays)
+    assert rel_err(ga.cpu(), a.grad) < 1e-4
+    assert rel_err(gv.cpu(), v.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------- flow
+def _flow_weights(sd, pfx, dev):
+    return [[(sd[f"{pfx}flows.{b}.nn.{l}.weight"].to(dev), sd[f"{pfx}flows.{b}.nn.{l}.bias"].to(dev)) for l in (1, 3, 5, 7)]
+            for b in range(2)]
+
+
+def test_flow_sample_and_logq_golden(golden, dev):
+    from oracle import flow as oflow
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import sphere_latent
+    g = golden("tensoflow_r32")
+    cond = oflow.flow_condition(g.sd, g["pts"], g["view_angles"], g["roughness"], AABB).to(dev)
+    Wt = _flow_weights(g.sd, "", dev)
+    for sn in (8, 32, 128):
+        assert rel_err(sphere_latent(sn), g[f"latent_{sn}"]) < 1e-7
+        ang, logj, bins = ops.flow_sample(Wt, cond, sphere_latent(sn).to(dev), want_bins=True)
+        assert rel_err(ang.cpu(), g[f"angles_{sn}"]) < TOL
+        assert rel_err(logj.cpu(), g[f"logj_{sn}"]) < TOL
+        _, _, b0, b1 = oflow.flow_sample(g.sd, g["pts"], g["view_angles"], g["roughness"], sn, AABB, return_bins=True)
+        assert torch.equal(bins[..., 0].cpu().long(), b0) and torch.equal(bins[..., 1].cpu().long(), b1)   # bit-exact
+        z, logq, zb = ops.flow_logq(Wt, cond, g[f"angles_{sn}"].to(dev), want_bins=True)
+        assert rel_err(z.cpu(), g[f"z_{sn}"]) < TOL
+        assert rel_err(logq.cpu(), g[f"logq_{sn}"]) < TOL
+        _, _, b0, b1 = oflow.flow_logq(g.sd, g["pts"], g["view_angles"], g["roughness"], g[f"angles_{sn}"], AABB, return_bins=True)
+        assert torch.equal(zb[..., 0].cpu().long(), b0) and torch.equal(zb[..., 1].cpu().long(), b1)
+    z, logq = ops.flow_logq(Wt, cond, g["x_rand"].to(dev))
+    assert rel_err(z.cpu(), g["z_rand"]) < TOL and rel_err(logq.cpu(), g["logq_rand"]) < TOL
+    z, logq = ops.flow_logq(Wt, cond, g["x_rid"].to(dev), rays_id=g["rays_id"].to(dev))
+    assert rel_err(z.cpu(), g["z_rid"]) < TOL and rel_err(logq.cpu(), g["logq_rid"]) < TOL
+
+
+def test_flow_roundtrip_full_size(dev, golden):
+    """size-independent property at BASELINE size (128 samples, 4096 points): logq(sample) == -logj."""
+    from oracle import flow as oflow
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import sphere_latent
+    g = golden("tensoflow_r32")
+    gen = torch.Generator().manual_seed(5)
+    pn = 4096
+    pts = torch.rand(pn, 3, generator=gen) * 1.6 - 0.8
+    va, rough = torch.rand(pn, 2, generator=gen), torch.rand(pn, 1, generator=gen)
+    cond = oflow.flow_condition(g.sd, pts, va, rough, AABB).to(dev)
+    Wt = _flow_weights(g.sd, "", dev)
+    jit = torch.rand(pn, 128, generator=gen).to(dev)
+    ang, logj = ops.flow_sample(Wt, cond, sphere_latent(128).to(dev), jitter=jit)
+    assert torch.isfinite(ang).all() and ang.min() > 0 and ang.max() < 1
+    z, logq = ops.flow_logq(Wt, cond, ang)
+    assert float(torch.quantile((logq + logj).abs().flatten()[:1_000_000], 0.999)) < 1e-3
+
+
+# ------------------------------------------------------------------------------- light, mesh, shading
+def test_cube_lookup_golden(golden, dev):
+    from oracle import texture as otex
+    from tensoflow_amd import ops
+    g = golden("shading_small")
+    base = g.sd["outer_light.base"]
+    got = ops.cube_lookup(base.to(dev), g["env_dirs"].to(dev))
+    assert rel_err(got.cpu(), g["env_direct"]) < TOL
+    gen = torch.Generator().manual_seed(2)
+    # directions hugging edges and corners of the cube
+    d = torch.randn(20000, 3, generator=gen)
+    d[:5000] = torch.sign(d[:5000]) * (1 + 0.02 * torch.randn(5000, 3, generator=gen))
+    got = ops.cube_lookup(base.to(dev), d.to(dev), apply_exp=False)
+    assert rel_err(got.cpu(), otex.cube_bilinear(base, d)) < TOL
+    gout = torch.randn(20000, 3, generator=gen)
+    b = base.clone().requires_grad_(True)
+    (torch.exp(otex.cube_bilinear(b, d)) * gout).sum().backward()
+    gb = ops.cube_lookup_bwd(base.to(dev), d.to(dev), gout.to(dev), apply_exp=True)
+    assert rel_err(gb.cpu(), b.grad) < TOL
+
+
+def test_bvh_trace_matches_brute_force(golden, dev):
+    from oracle import shading as osh
+    from tensoflow_amd import ops
+    from tensoflow_amd.synth import sphere_torus_mesh
+    verts, faces = sphere_torus_mesh(n_lat=24, n_lon=48, n_major=64, n_minor=24)
+    bvh = ops.Bvh(verts, faces, dev)
+    tr = osh.MeshTracer(torch.from_numpy(verts)[torch.from_numpy(faces).long()])
+    gen = torch.Generator().manual_seed(9)
+    o = torch.randn(6000, 3, generator=gen) * 0.6
+    d = torch.nn.functional.normalize(torch.randn(6000, 3, generator=gen), dim=-1)
+    pos, nrm, depth, hit = bvh.trace(o.to(dev), d.to(dev))
+    rpos, rnrm, rdepth, rhit = tr(o, d)
+    assert torch.equal(hit.cpu(), rhit)                     # boolean, bit-exact
+    assert 0.2 < rhit.float().mean() < 0.98
+    assert rel_err(depth.cpu(), rdepth[:, 0]) < 1e-5
+    assert rel_err(pos.cpu(), rpos) < 1e-5
+    # normal of either adjacent face is acceptable on shared edges: compare where depths are not tied
+    assert float((nrm.cpu() - rnrm).norm(dim=-1).gt(1e-4).float().mean()) < 2e-3
+
+
+def test_inner_light_matches_oracle(golden, dev):
+    from oracle import shading as osh
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import wn_weight
+    g = golden("shading_small")
+    gen = torch.Generator().manual_seed(4)
+    m = 1000                                    # not a multiple of 32: exercises the ragged last tile
+    pts = torch.rand(m, 3, generator=gen) * 2 - 1
+    view = torch.randn(m, 3, generator=gen)
+    nrm = torch.randn(m, 3, generator=gen)
+    ref = osh.inner_light(g.sd, pts, view, nrm)
+    W = [(wn_weight(g.sd, f"inner_light.{i}").to(dev), g.sd[f"inner_light.{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
+    got = ops.inner_light(W, pts.to(dev), view.to(dev), nrm.to(dev))
+    assert rel_err(got.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_shade_golden(golden, dev, tag):
+    """Whole integral (flow samplers active) vs the reference's `*_nis` outputs."""
+    from tensoflow_amd.shading import MCShader
+    g = golden("shading_" + tag)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    sh = MCShader(g.sd, g["verts"].numpy(), g["faces"].numpy(), AABB, float(g["unit_size"]), device=dev, n_fixed_diffuse=n_fd)
+    out = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
+    assert rel_err(out["metallic"].cpu(), g.out["metallic"]) < TOL
+    assert rel_err(out["roughness"].cpu(), g.out["roughness"]) < TOL
+    assert rel_err(out["albedo"].cpu(), g.out["albedo"]) < TOL
+    assert rel_err(out["colors"].cpu(), g.out["rgb_pr_nis"]) < TOL      # per-pixel, 1e-4
+    # integer / boolean outputs against the oracle, bit-exact
+    from oracle import shading as osh
+    tr = osh.MeshTracer(g["verts"][g["faces"].long()])
+    ref = osh.shade(g.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s,
+                    n_fixed_diffuse=n_fd, n_fixed_specular=n_fs, use_flow=True)
+    assert torch.equal(out["specular_mask"].cpu(), ref["specular_mask"])
+    assert torch.equal(out["specular_rays_id"].cpu(), ref["specular_rays_id"])
+    nd = sn_d + n_fd
+    assert torch.equal(out["hit"][:, :nd].cpu(), ref["diffuse_hit"])
