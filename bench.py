@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Headline benchmark: shaded surface points/s at 128 flow samples (BASELINE.json metric).
+
+One "step" = one eval pass of the flow-sampled rendering integral (MCShadingNetwork.forward ->
+shade_mixed with the flow samplers active, network/fields.py:1453-1473,1075-1235) over one batch of
+synthetic surface points resident in HBM: per point 128 flow samples for the diffuse lobe + the 512
+fixed cosine directions the reference always appends + 128 flow samples for the specular lobe = 768
+secondary rays (BVH visibility, cube-map light on a miss, inner-light MLP on a hit).
+Workload = BASELINE.json configs[2] ("compressor material stage, 128 flow direction samples/point,
+1xMI355X") at the reference's field sizes (R = 512, C = 36 / 12), random-init weights, analytic
+sphere+torus mesh (no dataset / checkpoint exists offline).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  Points are sharded across ranks with no data-path collective
+(weak scaling: fixed points per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_HIT_RAY = 326_656        # inner-light MLP 123-256-256-256-3
+FLOP_PER_FLOW_SAMPLE = 2 * 24_704  # two coupling blocks 44-64-64-64-21 (reference-faithful count)
+MARCH_BYTES_PER_SAMPLE = 18_144   # 7 evals x 18 texels x 36 ch x 4 B, one mip level
+MARCH_FLOP_PER_SAMPLE = 466_944
+
+
+def build_scene(device, seed, mesh_res):
+    from tensoflow_amd.shading import MCShader
+    from tensoflow_amd.synth import random_mc_state, sphere_torus_mesh
+    sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
+    verts, faces = sphere_torus_mesh(*mesh_res)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    unit = 2.0 / 511
+    sh = MCShader(sd, verts, faces, aabb, unit, device=device, n_fixed_diffuse=512)
+    return sh, sd, verts, faces, aabb, unit
+
+
+def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
+    """Oracle (CPU PyTorch restatement of the reference path) on a bounded sample of the same workload."""
+    from oracle import shading as osh
+    from tensoflow_amd.synth import sphere_surface_points, sphere_torus_mesh
+    torch.set_num_threads(os.cpu_count())
+    # the oracle traces by brute force: use the same analytic scene at 3 264 triangles so the sample
+    # stays within budget (the reference's BVH is a CUDA extension; there is no CPU path for it)
+    verts, faces = sphere_torus_mesh(24, 48, 32, 16)
+    tr = osh.MeshTracer(torch.from_numpy(verts)[torch.from_numpy(faces).long()])
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(n_points, seed=77)]
+    t0 = time.time()
+    done = 0
+    chunk = 16
+    while done < n_points and time.time() - t0 < budget_s:
+        sl = slice(done, min(done + chunk, n_points))
+        with torch.no_grad():
+            osh.shade(sd, tr, unit, aabb, pts[sl], view[sl], nrm[sl], sn, sn, n_fixed_diffuse=512, use_flow=True)
+        done = sl.stop
+    dt = time.time() - t0
+    return dict(value=done / dt, unit="points/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{done} surface points x 768 secondary rays, oracle/shading.py on {torch.get_num_threads()} "
+                       f"threads, brute-force visibility over a {len(faces)}-triangle version of the same scene, {dt:.1f} s")
+
+
+def march_probe(device, steps):
+    """Secondary figure (BASELINE config 2): fused sdf-alpha kernel, live march samples/s and algorithmic gather GB/s."""
+    from tensoflow_amd import ops
+    from tensoflow_amd.synth import pinhole_rays, random_sdf_state
+    R = 300
+    sd = {k: v.to(device) for k, v in random_sdf_state(seed=1, R=R).items()}
+    packed = ops.VmPacked([sd[f"sdf_plane.{i}"] for i in range(3)], [sd[f"sdf_line.{i}"] for i in range(3)], 3)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    n_rays, n_steps = 16384, 64
+    o, d, radii, cos = [torch.from_numpy(a).to(device) for a in pinhole_rays(n_rays, seed=2)]
+    t = torch.linspace(1.0, 3.0, n_steps, device=device)[None, :].expand(n_rays, n_steps)
+    pts = (o[:, None] + d[:, None] * t[..., None]).reshape(-1, 3)
+    inside = (pts.abs() < 1).all(-1)
+    pts = pts[inside].contiguous()
+    dirs = d[:, None].expand(n_rays, n_steps, 3).reshape(-1, 3)[inside].contiguous()
+    n = pts.shape[0]
+    level = torch.zeros(n, device=device)             # one mip level touched: 18 144 B / sample
+    dists = torch.full((n,), 2.0 / n_steps, device=device)
+    units = [2.0 / (R - 1)] * 3
+    W = [sd["sdf_mat.0.weight"], sd["sdf_mat.0.bias"], sd["sdf_mat.2.weight"], sd["sdf_mat.2.bias"]]
+    run = lambda: ops.sdf_alpha(packed, *W, pts, level, dists, dirs, aabb, units, 20.0, 1.0)
+    run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(steps):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / steps
+    sps = n / (ms * 1e-3)
+    return dict(live_samples=n, ms_per_launch=ms, samples_per_s=sps,
+                algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9, hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS,
+                tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12, mfma_f32_frac=sps * MARCH_FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                workload="TensoSDF R=300 C=36 3 mips, fused 7-tap sdf+FD+alpha, level=0")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=16384, help="surface points per GPU per step")
+    ap.add_argument("--flow-samples", type=int, default=128)
+    ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-march", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product kernels)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from tensoflow_amd.shading import StageTimer
+    from tensoflow_amd.synth import sphere_surface_points
+    mesh_res = tuple(int(v) for v in args.mesh.split(","))
+    sh, sd, verts, faces, aabb, unit = build_scene(device, 4, mesh_res)
+    S = args.flow_samples
+    pn = args.points
+    # every rank shades its own shard of the point stream (weak scaling), inputs resident in HBM
+    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=6 + 1000 * rank)]
+
+    def step():
+        return sh.shade(pts, view, nrm, S, S)
+
+    for _ in range(args.warmup):
+        step()
+    timer = StageTimer()
+    sh.timer = timer
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    sh.timer = type(sh.timer)() if False else sh.timer
+    value = world * pn * args.steps / dt
+
+    if rank == 0:
+        summ = timer.summary()
+        stages = {k: dict(ms_per_step=v[0] / args.steps, launches=v[1]) for k, v in summ.items()}
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+        hits = timer.units.get("inner_light", 0)
+        hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
+        if dom == "inner_light":
+            n_launch = summ[dom][1]
+            ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
+            roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
+                        per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} flop")
+        elif dom == "flow_sample":
+            n_launch = summ[dom][1]
+            samples = timer.units.get("flow_sample", 0)
+            ach = samples * FLOP_PER_FLOW_SAMPLE / (summ[dom][0] * 1e-3) / 1e12
+            roof = dict(kernel="flow_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
+                        per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches)")
+        else:
+            # BVH traversal / elementwise stages: byte-bound; algorithmic bytes = rays x (24 B in + 29 B out)
+            rays = pn * (2 * S + 512) * args.steps
+            ach = rays * 53 / (summ[dom][0] * 1e-3) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
+                        traffic=None, avg_launch_ms=summ[dom][0] / summ[dom][1],
+                        per_launch=f"{rays // args.steps} rays x 53 B of ray in/out (BVH node traffic is data-dependent, not algorithmic)")
+        line = {
+            "metric": "shaded surface points/s @128 flow samples", "value": value, "unit": "points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
+                                   f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
+                       "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",
+                       "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "parallelism": f"points sharded x{world}, no collective"},
+            "roofline": roof,
+            "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        }
+        if world == 1 and not args.no_march:
+            sh.timer = type("N", (), {"stage": lambda s, n: __import__("contextlib").nullcontext(), "add_units": lambda s, n, k: None})()
+            line["march"] = march_probe(device, max(2, args.steps))
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, aabb, unit, 4096, S)
+        print(json.dumps(line))
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,7 +163,7 @@ extern "C" int tf_composite_fwd(const float* alpha, const int64_t* ray_indices, 
                                 int64_t n_rays, int32_t k, float* weights, float* acc, float* out, tf_stream_t stream) {
   TF_REQUIRE(n >= 0 && n_rays >= 0 && k >= 0, TF_ESHAPE, "tf_composite_fwd: negative size");
   if (n_rays == 0) return TF_OK;
-  TF_REQUIRE(acc && (k == 0 || (values && out)) && (n == 0 || (alpha && ray_indices && weights)), TF_EINVAL,
+  TF_REQUIRE(acc && (k == 0 || out) && (n == 0 || (alpha && ray_indices && weights && (k == 0 || values))), TF_EINVAL,
              "tf_composite_fwd: null pointer");
 #define CALL(KK) launch_fwd<KK>(alpha, (const long long*)ray_indices, values, n, n_rays, weights, acc, out, (hipStream_t)stream)
   DISPATCH_K(k, CALL)

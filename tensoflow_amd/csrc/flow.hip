@@ -17,6 +17,10 @@ static constexpr float kEps32 = 1.1920928955078125e-07f;  // torch.finfo(float32
 static constexpr float kHalfPi = 1.5707963267948966f;
 
 // ------------------------------------------------------------------------------- spline
+// The reference evaluates the spline with separate fp32 multiplies and adds (PyTorch eager); its closed-form
+// root (-b +- sqrt(b^2 - 2ac)) / a is ill-conditioned for nearly flat bins, so fused multiply-adds here would
+// change the rounding sequence and move samples by up to ~1e-4.  Contraction is therefore off for the spline.
+#pragma clang fp contract(off)
 struct PwTables {
   float w[FLOW_NB], wss[FLOW_NB + 1], v[FLOW_NB + 1], vw[FLOW_NB + 1];
 };

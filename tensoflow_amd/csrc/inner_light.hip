@@ -49,13 +49,14 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
 template <int KSTEPS, int TIN>
-__device__ __forceinline__ void hidden_layer(const float* __restrict__ wf, const float* __restrict__ bias, int h,
+__device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, const float* __restrict__ bias,
+                                             float* __restrict__ lds, int tid, int lane, int h,
                                              const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_sb<KSTEPS, 8, TIN, 8>(wf, in, out);
+  tf_layer_stream<KSTEPS, 8, TIN, 8>(wslab, lds, tid, lane, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -65,10 +66,11 @@ __device__ __forceinline__ void hidden_layer(const float* __restrict__ wf, const
 __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws, const float* __restrict__ pts,
                                                           const float* __restrict__ view, const float* __restrict__ nrm,
                                                           long long m, float exp_max, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, h = lane >> 5;
-  const long long n_tiles = (m + 31) / 32;
-  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (long long tile = wave_id; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 4096];
+  const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
+  const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
+  for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+    const long long tile = tg * 4 + (threadIdx.x >> 6);
     long long row = tile * 32 + (lane & 31);
     const bool valid = row < m;
     if (!valid) row = m - 1;
@@ -133,14 +135,14 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           const int k0 = 32 * t + (j & 3) + 8 * (j >> 2);
           in1[t][j] = h ? enc[k0 + 4] : enc[k0];
         }
-      hidden_layer<64, 4>(ws + kI1 + lane, ws + kIB1, h, in1, a);
+      hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
-    hidden_layer<128, 8>(ws + kI2 + lane, ws + kIB2, h, a, b);
-    hidden_layer<128, 8>(ws + kI3 + lane, ws + kIB3, h, b, a);
+    hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
+    hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
-    tf_layer_sb<128, 1, 8, 16>(ws + kI4 + lane, a, o);
+    tf_layer_stream<128, 1, 8, 64>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) out[3 * row + c] = expf(fminf(o[0][c], exp_max));
@@ -157,10 +159,10 @@ extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const flo
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_fwd: workspace too small (%zu < %d floats)",
              workspace_floats, kInnerWsFloats);
   for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "tf_inner_light_fwd: null weight pointer (layer %d)", l);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3);
-  tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
+  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3, 1);
+  tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
@@ -170,8 +172,7 @@ extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const flo
   if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
   hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
   TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_fwd: hipMemcpyAsync failed: %s", hipGetErrorString(e));
-  long long tiles = (m + 31) / 32;
-  long long blocks = (tiles + 3) / 4;
+  long long blocks = (m + 127) / 128;
   if (blocks > 1024) blocks = 1024;
   inner_light_kernel<<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
   TF_LAUNCH_CHECK("tf_inner_light_fwd");

@@ -30,13 +30,19 @@ __device__ __forceinline__ f32x16 tf_mfma(float a, float b, f32x16 c) {
 // Pack W [nout, ld] (columns col0 .. col0+kin-1 used) into fragment order; zero padded.
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                             int kin, int tout_tiles, int ksteps,
-                                                            float* __restrict__ dst) {
+                                                            float* __restrict__ dst, int s_major = 0) {
   int e = blockIdx.x * 256 + threadIdx.x;
   int total = tout_tiles * ksteps * 64;
   if (e >= total) return;
   int lane = e & 63;
-  int s = (e >> 6) % ksteps;
-  int tout = (e >> 6) / ksteps;
+  int s, tout;
+  if (s_major) {  // [s][tout][lane]: one k-group of all unit tiles is contiguous (LDS-staged streaming)
+    tout = (e >> 6) % tout_tiles;
+    s = (e >> 6) / tout_tiles;
+  } else {        // [tout][s][lane]
+    s = (e >> 6) % ksteps;
+    tout = (e >> 6) / ksteps;
+  }
   int row = 32 * tout + (lane & 31);
   int k = tf_kmap(s, lane >> 5);
   dst[e] = (row < nout && k < kin) ? W[(long long)row * ld + col0 + k] : 0.f;
@@ -77,5 +83,44 @@ __device__ __forceinline__ void tf_layer_sb(const float* __restrict__ wf, const 
       for (int t = 0; t < TOUT; ++t) out[t] = tf_mfma(wf[(t * KSTEPS + s) * 64], b, out[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Dense layer with the weights STREAMED through LDS by the whole 256-thread workgroup:
+// wslab is s-major fragment order [KSTEPS][TOUT][64]; it is consumed in groups of SL k-steps
+// (SL*TOUT*64 == 4096 floats = 16 KB), double buffered in `lds` (2 x 4096 floats).  Each thread moves
+// 4 float4 per group global->register while the previous group's MFMAs run, then register->LDS.
+// All four waves must call this with the same trip counts (it contains workgroup barriers).
+template <int KSTEPS, int TOUT, int TIN, int SL>
+__device__ __forceinline__ void tf_layer_stream(const float* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
+                                                const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+  static_assert(SL * TOUT * 64 == 4096, "one group must be 16 KB");
+  static_assert(KSTEPS % SL == 0, "KSTEPS must be a multiple of the group size");
+  constexpr int G = KSTEPS / SL;
+  float4 st[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st[i] = reinterpret_cast<const float4*>(wslab)[tid + 256 * i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(lds)[tid + 256 * i] = st[i];
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[i] = reinterpret_cast<const float4*>(wslab + (g + 1) * 4096)[tid + 256 * i];
+    }
+    const float* buf = lds + (g & 1) * 4096 + lane;
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int s = g * SL + sl;
+      const float b = in[s >> 4][s & 15];
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) out[t] = tf_mfma(buf[(sl * TOUT + t) * 64], b, out[t]);
+    }
+    if (g + 1 < G) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(lds + ((g + 1) & 1) * 4096)[tid + 256 * i] = st[i];
+    }
+    __syncthreads();
   }
 }

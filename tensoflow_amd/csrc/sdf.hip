@@ -157,8 +157,9 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
   for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-  const long long n_tiles = (A.n + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+  const long long n_groups = (A.n + 127) / 128;  // the 4 waves advance in lockstep (W2 streaming uses workgroup barriers)
+  for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+    const long long tile = tg * 4 + wave;
     asm volatile("" ::: "memory");  // do not hoist LDS weight fragments across tiles
     long long row = tile * 32 + (lane & 31);
     const bool valid = row < A.n;
@@ -171,21 +172,20 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
     const float s_c = sdf_hidden(A, lds, x, l0, l1, fl, lane, acc);
     if (MODE != 1 && A.feat) {
       // appearance features: [128 x 256] * H^T, W2 fragments streamed from L2
-#pragma unroll 1
-      for (int t = 0; t < 4; ++t) {
-        f32x16 o;
+      f32x16 o[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) o[j] = lds[kB2a + (t * 16 + j) * 2 + h];
-        const float* __restrict__ wf = A.ws + kW2f + (long long)t * 128 * 64 + lane;
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int s = 0; s < 128; ++s) o = tf_mfma(wf[s * 64], acc[s >> 4][s & 15], o);
-        if (valid) {
+        for (int j = 0; j < 16; ++j) o[t][j] = lds[kB2a + (t * 16 + j) * 2 + h];
+      tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kLdsFloats, threadIdx.x, lane, acc, o);
+      if (valid) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            float4 v4 = make_float4(o[4 * jj], o[4 * jj + 1], o[4 * jj + 2], o[4 * jj + 3]);
+            float4 v4 = make_float4(o[t][4 * jj], o[t][4 * jj + 1], o[t][4 * jj + 2], o[t][4 * jj + 3]);
             *reinterpret_cast<float4*>(A.feat + row * SDF_APP + 32 * t + 8 * jj + 4 * h) = v4;
           }
-        }
       }
     }
     if (MODE != 2) {
@@ -242,7 +242,7 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
   tf_pack_wfrag_kernel<<<tf_blocks(4 * 128 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4,
-                                                                         128, workspace + kW2f);
+                                                                         128, workspace + kW2f, 1);
   A->ws = workspace;
   return TF_OK;
 }
@@ -250,16 +250,15 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
 template <int MODE>
 static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
   A.b2 = b2_dev;
-  const size_t lds = (size_t)kLdsFloats * sizeof(float);
+  const size_t lds = (size_t)(kLdsFloats + 2 * 4096) * sizeof(float);  // weights + W2 streaming double buffer
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[MODE]) {
     hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
     attr_set[MODE] = true;
   }
-  long long tiles = (A.n + 31) / 32;
-  long long blocks = (tiles + 3) / 4;
-  if (blocks > 256) blocks = 256;  // one 117 KB-LDS workgroup per CU; waves loop over tiles
+  long long blocks = (A.n + 127) / 128;
+  if (blocks > 256) blocks = 256;  // one 150 KB-LDS workgroup per CU; waves loop over tile groups
   sdf_kernel<MODE><<<(unsigned)blocks, 256, lds, stream>>>(A);
   TF_LAUNCH_CHECK(who);
   return TF_OK;

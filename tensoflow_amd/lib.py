@@ -74,6 +74,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The HIP runtime must be the one PyTorch-ROCm already loaded (its bundled libamdhip64): streams and
+    # device pointers are only meaningful inside one runtime instance, so import torch FIRST.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

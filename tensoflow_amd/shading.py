@@ -54,6 +54,52 @@ def sphere_latent(sn):
     return torch.stack([phi, th], -1)
 
 
+class StageTimer:
+    """HIP-event stage timing on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.events = {}
+        self.units = {}
+
+    class _Ctx:
+        def __init__(self, owner, name):
+            self.o, self.name = owner, name
+
+        def __enter__(self):
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+        def __exit__(self, *a):
+            self.e.record()
+            self.o.events.setdefault(self.name, []).append((self.s, self.e))
+
+    def stage(self, name):
+        return StageTimer._Ctx(self, name)
+
+    def add_units(self, name, n):
+        self.units[name] = self.units.get(name, 0) + int(n)
+
+    def summary(self):
+        """-> {stage: (total_ms, launches)} (call after torch.cuda.synchronize())."""
+        return {k: (sum(s.elapsed_time(e) for s, e in v), len(v)) for k, v in self.events.items()}
+
+
+class _NoTimer:
+    class _C:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *a):
+            return False
+
+    def stage(self, name):
+        return _NoTimer._C()
+
+    def add_units(self, name, n):
+        pass
+
+
 class FlowParams:
     """One TensoFlow (nis planes/lines + nis_mat + 2 coupling nets) resident on the device."""
 
@@ -97,6 +143,7 @@ class MCShader:
         self.bvh = ops.Bvh(vertices, triangles, device)
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
         self._latent = {}
+        self.timer = _NoTimer()
 
     def latent(self, sn):
         if sn not in self._latent:
@@ -113,13 +160,22 @@ class MCShader:
 
     def lights(self, pts_rep, dirs):
         """get_lights (fields.py:951-975): pts_rep, dirs [M,3] -> lights [M,3], hit [M] bool."""
-        inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit)
-        lights = ops.cube_lookup(self.env, dirs, apply_exp=True)
-        idx = torch.nonzero(hit, as_tuple=False)[:, 0]
+        T = self.timer
+        with T.stage("bvh_trace"):
+            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit)
+        with T.stage("cube_lookup"):
+            lights = ops.cube_lookup(self.env, dirs, apply_exp=True)
+        with T.stage("hit_compaction"):
+            idx = torch.nonzero(hit, as_tuple=False)[:, 0]
+            hp, hv, hn = inters[idx], -dirs[idx], nrm[idx]
         if idx.numel() > 0:
-            inner = ops.inner_light(self.inner, inters[idx], -dirs[idx], nrm[idx], self.exp_max)
-            lights.index_copy_(0, idx, inner)
-        lights = lights * (depth > 1e-5).float()[:, None]
+            with T.stage("inner_light"):
+                inner = ops.inner_light(self.inner, hp, hv, hn, self.exp_max)
+            T.add_units("inner_light", idx.numel())
+            with T.stage("light_merge"):
+                lights.index_copy_(0, idx, inner)
+        with T.stage("light_merge"):
+            lights = lights * (depth > 1e-5).float()[:, None]
         return lights, hit, inters
 
     @torch.no_grad()
@@ -127,16 +183,26 @@ class MCShader:
         """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)"""
         pts = pts.to(self.device).float().contiguous()
         pn = pts.shape[0]
-        metallic, rough, albedo = self.predict_materials(pts)
-        va = ops.view_angles(normals, view_dirs)
-        ang_d, lq_d = ops.flow_sample(self.flow_d.nets, self.flow_d.condition(pts, va, self.aabb), self.latent(sn_diffuse), jitter_d)
-        ang_s, lq_s = ops.flow_sample(self.flow_s.nets, self.flow_s.condition(pts, va, self.aabb), self.latent(sn_specular), jitter_s)
-        dirs, wgt, smask = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
+        tm = self.timer
+        with tm.stage("materials"):
+            metallic, rough, albedo = self.predict_materials(pts)
+            va = ops.view_angles(normals, view_dirs)
+        with tm.stage("flow_condition"):
+            cond_d = self.flow_d.condition(pts, va, self.aabb)
+            cond_s = self.flow_s.condition(pts, va, self.aabb)
+        with tm.stage("flow_sample"):
+            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d)
+            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s)
+        tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
+        with tm.stage("shade_dirs"):
+            dirs, wgt, smask = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
         T = dirs.shape[1]
-        pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
+        with tm.stage("light_merge"):
+            pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
         lights, hit, inters = self.lights(pts_rep, dirs.reshape(-1, 3))
         n_diff = sn_diffuse + self.fixed_d.shape[0]
-        colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
+        with tm.stage("shade_reduce"):
+            colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
         rid = torch.arange(pn, device=self.device)[:, None].expand(pn, sn_specular)[smask]
         return dict(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                     specular_mask=smask, specular_rays_id=rid, hit=hit.reshape(pn, T), view_angles=va,

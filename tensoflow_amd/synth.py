@@ -100,3 +100,79 @@ def pinhole_rays(n, seed=2, h=800, w=800, focal=1111.1, cam_dist=2.0, az=0.7, el
     radii = np.full((n, 1), 1.0 / (focal * math.sqrt(math.pi)))  # sqrt(pixel area / pi)
     o = np.broadcast_to(c, dirs.shape)
     return o.astype(np.float32).copy(), dirs.astype(np.float32), radii.astype(np.float32), cos.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- synthetic parameters
+def _wn_linear(gen, fan_in, fan_out, sd, prefix, bias_fill=None):
+    """nn.utils.parametrizations.weight_norm(nn.Linear) state: original0 = g [out,1], original1 = v [out,in]."""
+    import torch
+    bound = 1.0 / math.sqrt(fan_in)
+    v = (torch.rand(fan_out, fan_in, generator=gen) * 2 - 1) * bound
+    sd[prefix + ".parametrizations.weight.original1"] = v
+    sd[prefix + ".parametrizations.weight.original0"] = v.norm(dim=1, keepdim=True)
+    b = (torch.rand(fan_out, generator=gen) * 2 - 1) * bound
+    if bias_fill is not None:
+        b = torch.full((fan_out,), float(bias_fill))
+    sd[prefix + ".bias"] = b
+
+
+def _linear(gen, fan_in, fan_out, sd, prefix):
+    import torch
+    bound = 1.0 / math.sqrt(fan_in)
+    sd[prefix + ".weight"] = (torch.rand(fan_out, fan_in, generator=gen) * 2 - 1) * bound
+    sd[prefix + ".bias"] = (torch.rand(fan_out, generator=gen) * 2 - 1) * bound
+
+
+def random_flow_state(sd, prefix, gen, R=512, C=12):
+    """TensoFlow state_dict entries (network/flow.py:683-698, :755-764 shapes and init scales, plus the
+    plane / net perturbation SURVEY.md 8(d) config 3 prescribes so the flow is non-trivial)."""
+    import torch
+    for i in range(3):
+        sd[f"{prefix}nis_plane.{i}"] = 1e-4 * (2 * torch.rand(1, C, R, R, generator=gen) - 1) + 0.1 * torch.randn(1, C, R, R, generator=gen)
+        sd[f"{prefix}nis_line.{i}"] = torch.full((1, C, R, 1), 1.0 / (C * 3)) + 0.1 * torch.randn(1, C, R, 1, generator=gen)
+    _linear(gen, 3 * C + 21, 64, sd, prefix + "nis_mat.0")
+    _linear(gen, 64, 16, sd, prefix + "nis_mat.2")
+    for b in range(2):
+        dims = [(44, 64), (64, 64), (64, 64), (64, 21)]
+        for l, (fi, fo) in zip((1, 3, 5, 7), dims):
+            _linear(gen, fi, fo, sd, f"{prefix}flows.{b}.nn.{l}")
+
+
+def random_mc_state(seed=4, R=512, flow_R=512, env_res=128):
+    """Random-init MCShadingNetwork parameters in the reference's state_dict layout
+    (network/fields.py:668-760; configs/mat/syn/compressor.yaml:15-21)."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i in range(3):
+        sd[f"mat_plane.{i}"] = 1e-4 * (2 * torch.rand(1, 36, R, R, generator=gen) - 1) + 0.1 * torch.randn(1, 36, R, R, generator=gen)
+        sd[f"mat_line.{i}"] = torch.full((1, 36, R, 1), 1.0 / 108) + 0.1 * torch.randn(1, 36, R, 1, generator=gen)
+    for name, out in (("metallic", 1), ("roughness", 1), ("albedo", 3)):
+        _wn_linear(gen, 108, 128, sd, f"{name}_predictor.0")
+        _wn_linear(gen, 128, out, sd, f"{name}_predictor.2")
+    dims = [(123, 256), (256, 256), (256, 256), (256, 3)]
+    for l, (fi, fo) in zip((0, 2, 4, 6), dims):
+        _wn_linear(gen, fi, fo, sd, f"inner_light.{l}", bias_fill=math.log(0.5) if l == 6 else None)
+    sd["outer_light.base"] = math.log(0.5) + 0.5 * torch.randn(6, env_res, env_res, 3, generator=gen)
+    for name in ("flow_diffuse_copy.", "flow_specular_copy."):
+        random_flow_state(sd, name, gen, R=flow_R)
+    return sd
+
+
+def random_sdf_state(seed=1, R=300, C=36, hidden=256, app=128):
+    """TensoSDF parameters in the reference layout (network/fields.py:78-131): circle init of radius 0.2
+    plus 0.02*N(0,1) on the planes."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    lin = torch.linspace(-1, 1, R)
+    xx, yy = torch.meshgrid(lin, lin, indexing="ij")
+    circ = (torch.sqrt(xx ** 2 + yy ** 2) - 0.2)[None, None].expand(1, C, R, R)
+    for i in range(3):
+        sd[f"sdf_plane.{i}"] = (circ + 0.02 * torch.randn(1, C, R, R, generator=gen)).contiguous()
+        sd[f"sdf_line.{i}"] = torch.full((1, C, R, 1), 1.0 / (C * 3))
+    sd["sdf_mat.0.weight"] = torch.randn(hidden, 3 * C + 3, generator=gen) * (math.sqrt(2) / math.sqrt(hidden))
+    sd["sdf_mat.0.bias"] = torch.zeros(hidden)
+    sd["sdf_mat.2.weight"] = math.sqrt(math.pi) / math.sqrt(hidden) + 1e-4 * torch.randn(1 + app, hidden, generator=gen)
+    sd["sdf_mat.2.bias"] = torch.full((1 + app,), -0.2)
+    return sd
