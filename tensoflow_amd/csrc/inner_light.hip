@@ -63,13 +63,17 @@ __device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, co
     for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
 }
 
-__global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws, const float* __restrict__ pts,
+__global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts,
                                                           const float* __restrict__ view, const float* __restrict__ nrm,
                                                           long long m, float exp_max, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 4096];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+    // opaque per-iteration copy of the workspace base: biases / IDE table / slab addresses are loop-invariant and
+    // would otherwise be hoisted out of the tile loop, spilled, and reloaded behind s_waitcnt vmcnt(0)
+    const float* ws = ws_arg;
+    asm volatile("" : "+s"(ws));
     const long long tile = tg * 4 + (threadIdx.x >> 6);
     long long row = tile * 32 + (lane & 31);
     const bool valid = row < m;

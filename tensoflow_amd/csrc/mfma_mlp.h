@@ -91,35 +91,58 @@ __device__ __forceinline__ void tf_layer_sb(const float* __restrict__ wf, const 
 // (SL*TOUT*64 == 4096 floats = 16 KB), double buffered in `lds` (2 x 4096 floats).  Each thread moves
 // 4 float4 per group global->register while the previous group's MFMAs run, then register->LDS.
 // All four waves must call this with the same trip counts (it contains workgroup barriers).
+typedef const __attribute__((address_space(1))) void* tf_gptr_t;
+typedef __attribute__((address_space(3))) void* tf_lptr_t;
+
+// One 16 KB weight slab global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, asynchronous):
+// each of the 4 waves moves 4 pieces of 1 KB (lane l supplies the source address of its 16 bytes).
+__device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*1024 + lane*4 */, float* __restrict__ lbuf,
+                                            int wave) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
+}
+
 template <int KSTEPS, int TOUT, int TIN, int SL>
 __device__ __forceinline__ void tf_layer_stream(const float* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
   static_assert(SL * TOUT * 64 == 4096, "one group must be 16 KB");
   static_assert(KSTEPS % SL == 0, "KSTEPS must be a multiple of the group size");
   constexpr int G = KSTEPS / SL;
-  float4 st[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) st[i] = reinterpret_cast<const float4*>(wslab)[tid + 256 * i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(lds)[tid + 256 * i] = st[i];
-  __syncthreads();
+  const int wave = tid >> 6;
+  // ONE running per-thread source pointer, advanced by 16 KB per slab and made opaque each step: otherwise the
+  // compiler materialises every slab address as its own loop-invariant 64-bit VGPR pair, hoists them out of the
+  // tile loop and spills them (each reload then serialises the DMAs behind an s_waitcnt vmcnt(0)).
+  const float* gp = wslab + wave * 1024 + lane * 4;
+  asm volatile("" : "+v"(gp));
+  tf_slab_dma(gp, lds, wave);
+  __syncthreads();   // (the compiler drains vmcnt before the barrier: slab 0 has landed for every wave)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    // slab g+1 streams into the other buffer while slab g feeds the MFMAs
     if (g + 1 < G) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) st[i] = reinterpret_cast<const float4*>(wslab + (g + 1) * 4096)[tid + 256 * i];
+      gp += 4096;
+      asm volatile("" : "+v"(gp));
+      tf_slab_dma(gp, lds + ((g + 1) & 1) * 4096, wave);
     }
     const float* buf = lds + (g & 1) * 4096 + lane;
+    // A operands are read from LDS one k-step AHEAD of the MFMAs that consume them (register double buffer),
+    // so the LDS latency hides under the previous step's MFMAs instead of stalling every issue.
+    float a_cur[TOUT], a_nxt[TOUT];
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) a_cur[t] = buf[t * 64];
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       const int s = g * SL + sl;
       const float b = in[s >> 4][s & 15];
+      if (sl + 1 < SL) {
 #pragma unroll
-      for (int t = 0; t < TOUT; ++t) out[t] = tf_mfma(buf[(sl * TOUT + t) * 64], b, out[t]);
-    }
-    if (g + 1 < G) {
+        for (int t = 0; t < TOUT; ++t) a_nxt[t] = buf[((sl + 1) * TOUT + t) * 64];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(lds + ((g + 1) & 1) * 4096)[tid + 256 * i] = st[i];
+      for (int t = 0; t < TOUT; ++t) out[t] = tf_mfma(a_cur[t], b, out[t]);
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) a_cur[t] = a_nxt[t];
     }
     __syncthreads();
   }

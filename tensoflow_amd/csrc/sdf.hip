@@ -30,6 +30,9 @@ static constexpr int kB1a = kW1f + 8 * SDF_KSTEPS * 64;          // [8][16][2]
 static constexpr int kW2r0 = kB1a + 256;                         // sdf row of W2, accumulator order [8][16][2]
 static constexpr int kB2a = kW2r0 + 256;                         // b2[1:], accumulator order [4][16][2]
 static constexpr int kLdsFloats = kB2a + 128;                    // everything above is copied to LDS
+static constexpr int kStream = kLdsFloats;                       // 2 x 4096 floats: W2 streaming double buffer
+static constexpr int kGeo = kStream + 2 * 4096;                  // 12 x 8 ints: per (plane, level) geometry
+static constexpr int kLdsTotal = kGeo + 96;
 static constexpr int kW2f = kLdsFloats;                          // [4][128][64]  (global only)
 static constexpr int kSdfWsFloats = kW2f + 4 * 128 * 64;
 
@@ -61,47 +64,68 @@ __device__ __forceinline__ float4 f4_lerp(float4 a, float4 b, float t) {
   return make_float4(a.x * s + b.x * t, a.y * s + b.y * t, a.z * s + b.z * t, a.w * s + b.w * t);
 }
 
-// plane*line product for channel chunk q (plane i = q/9, channels 4*(q%9)..+3) at contracted point p
-__device__ __forceinline__ float4 gather_chunk(const VmGeom& g, const float* __restrict__ packed, const float (&p)[3],
-                                               int l0, int l1, float fl, int q) {
+// ---- gather, split into an asynchronous "issue the 6 texel loads of one mip level" half and a "blend" half so
+// that the loads of the NEXT feature group fly while the MFMAs of the current one execute.
+struct ChunkRaw {
+  float4 t00, t10, t01, t11, s0, s1;
+  float fx, fy, fz;
+};
+
+// Per (plane, level) geometry lives in LDS as 8 ints {H, W, L, plane offset, line offset, -, -, -}: the plane index
+// of a chunk differs between the two lane halves and the level differs per lane, so the lookup is a per-lane LDS
+// read instead of select chains over kernel arguments.
+__device__ __forceinline__ void load_chunk(const int* __restrict__ geo, const float* __restrict__ packed, const float (&p)[3],
+                                           int l, int q, ChunkRaw& r) {
   const int i = q / (SDF_C / 4), j = q % (SDF_C / 4);
   const float u = i == 2 ? p[1] : p[0], v = i == 0 ? p[1] : p[2], w = i == 0 ? p[2] : (i == 1 ? p[1] : p[0]);
-#define SEL3(a) (i == 0 ? (a)[0] : (i == 1 ? (a)[1] : (a)[2]))
-#define SEL34(a, l) (l == 0 ? SEL3_L(a, 0) : (l == 1 ? SEL3_L(a, 1) : (l == 2 ? SEL3_L(a, 2) : SEL3_L(a, 3))))
-#define SEL3_L(a, l) (i == 0 ? (a)[0][l] : (i == 1 ? (a)[1][l] : (a)[2][l]))
-  const int ph = SEL3(g.ph), pw = SEL3(g.pw), ll = SEL3(g.ll);
+  const int4 ga = *reinterpret_cast<const int4*>(geo + (i * 4 + l) * 8);
+  const int loff = geo[(i * 4 + l) * 8 + 4];
+  const int H = ga.x, W = ga.y, L = ga.z;
+  int x0, x1, y0, y1, z0, z1;
+  axis_taps(u, W, x0, x1, r.fx);
+  axis_taps(v, H, y0, y1, r.fy);
+  axis_taps(w, L, z0, z1, r.fz);
+  const float* pb = packed + (unsigned)(ga.w + 4 * j);
+  const float* lb = packed + (unsigned)(loff + 4 * j);
+  r.t00 = *reinterpret_cast<const float4*>(pb + (unsigned)((y0 * W + x0) * SDF_C));
+  r.t10 = *reinterpret_cast<const float4*>(pb + (unsigned)((y0 * W + x1) * SDF_C));
+  r.t01 = *reinterpret_cast<const float4*>(pb + (unsigned)((y1 * W + x0) * SDF_C));
+  r.t11 = *reinterpret_cast<const float4*>(pb + (unsigned)((y1 * W + x1) * SDF_C));
+  r.s0 = *reinterpret_cast<const float4*>(lb + (unsigned)(z0 * SDF_C));
+  r.s1 = *reinterpret_cast<const float4*>(lb + (unsigned)(z1 * SDF_C));
+}
+
+template <int NL>
+__device__ __forceinline__ float4 blend_chunk(const ChunkRaw (&r)[NL], float fl) {
   float4 pv = make_float4(0, 0, 0, 0), lv = make_float4(0, 0, 0, 0);
 #pragma unroll
-  for (int li = 0; li < 2; ++li) {
-    if (li == 1 && fl == 0.f) break;
-    const int l = li ? l1 : l0;
-    const float wl = li ? fl : 1.f - fl;
-    const int H = vm_dim(ph, l), W = vm_dim(pw, l), L = vm_dim(ll, l);
-    int x0, x1, y0, y1, z0, z1;
-    float fx, fy, fz;
-    axis_taps(u, W, x0, x1, fx);
-    axis_taps(v, H, y0, y1, fy);
-    axis_taps(w, L, z0, z1, fz);
-    const float* pb = packed + SEL34(g.poff, l) + 4 * j;
-    const float* lb = packed + SEL34(g.loff, l) + 4 * j;
-    const float4 t00 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x0) * SDF_C);
-    const float4 t10 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x1) * SDF_C);
-    const float4 t01 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x0) * SDF_C);
-    const float4 t11 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x1) * SDF_C);
-    const float4 s0 = *reinterpret_cast<const float4*>(lb + (long long)z0 * SDF_C);
-    const float4 s1 = *reinterpret_cast<const float4*>(lb + (long long)z1 * SDF_C);
-    const float4 pl = f4_lerp(f4_lerp(t00, t10, fx), f4_lerp(t01, t11, fx), fy);
-    const float4 ln = f4_lerp(s0, s1, fz);
+  for (int li = 0; li < NL; ++li) {
+    const float wl = NL == 1 ? 1.f : (li ? fl : 1.f - fl);
+    const float4 pl = f4_lerp(f4_lerp(r[li].t00, r[li].t10, r[li].fx), f4_lerp(r[li].t01, r[li].t11, r[li].fx), r[li].fy);
+    const float4 ln = f4_lerp(r[li].s0, r[li].s1, r[li].fz);
     pv.x += wl * pl.x; pv.y += wl * pl.y; pv.z += wl * pl.z; pv.w += wl * pl.w;
     lv.x += wl * ln.x; lv.y += wl * ln.y; lv.z += wl * ln.z; lv.w += wl * ln.w;
   }
   return make_float4(pv.x * lv.x, pv.y * lv.y, pv.z * lv.z, pv.w * lv.w);
 }
 
-// hidden layer for this lane's sample at world position x: fills acc[8] (post-softplus) and returns the sdf
-__device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* __restrict__ lds, const float (&x)[3], int l0,
-                                            int l1, float fl, int lane, f32x16 (&acc)[8]) {
+// hidden layer for this lane's sample at world position x: fills acc[8] (post-softplus) and returns the sdf.
+// NL = number of mip levels fetched (1 when no lane of the wave has a fractional LOD, else 2).
+// Layer 1 runs as 7 feature groups of 2 chunks (8 k-steps x 8 unit tiles = 64 MFMAs each): while group g's MFMAs
+// execute, the 12*NL texel loads of group g+1 are already in flight.
+template <int NL>
+__device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
+                                               int l1, float fl, int lane, f32x16 (&acc)[8]) {
+  // Make the LDS base opaque per call: every LDS operand of this function (W1 fragments, biases, the sdf row of
+  // W2: ~700 values per lane) is loop-invariant across tiles and taps, and the compiler otherwise hoists them all
+  // out of the tile loop, spills them, and reloads each one from scratch behind an s_waitcnt vmcnt(0).
+  {
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    lds += opaque;
+  }
   const int h = lane >> 5;
+  const int* geo = reinterpret_cast<const int*>(lds + kGeo);
   float p[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) p[k] = (x[k] - A.g.aabb_lo[k]) / A.g.aabb_size[k];
@@ -110,33 +134,43 @@ __device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* __res
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = lds[kB1a + (t * 16 + j) * 2 + h];
-  // layer 1 in 4 K-groups of 4 chunks: gather -> blend -> 16 k-steps x 8 unit tiles of MFMA.  The scheduling
-  // barriers bound how many gather results are live at once (each group: <= 48 x 16-byte loads).
+  ChunkRaw raw[2][NL];
+  auto issue = [&](int g) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    f32x16 fin;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      float4 f = make_float4(0, 0, 0, 0);
-      if (!(t == 3 && jj >= 2)) {
-        const int q = 8 * t + 2 * jj + h;  // chunk index: 0..26 plane*line, 27 = (x,y,z,0)
-        if (t == 3 && jj == 1) {
-          // q = 26 + h : h==0 -> last feature chunk, h==1 -> xyz chunk (raw, un-contracted: fields.py:265,298)
-          const float4 g26 = gather_chunk(A.g, A.packed, p, l0, l1, fl, 26);
-          f = h ? make_float4(x[0], x[1], x[2], 0.f) : g26;
-        } else {
-          f = gather_chunk(A.g, A.packed, p, l0, l1, fl, q);
-        }
-      }
-      fin[4 * jj + 0] = f.x; fin[4 * jj + 1] = f.y; fin[4 * jj + 2] = f.z; fin[4 * jj + 3] = f.w;
+    for (int c = 0; c < 2; ++c) {
+      int q = 4 * g + 2 * c + h;        // this lane's chunks of group g: q = 2*(2g+c) + h
+      if (q > 26) q = 26;               // lane half 1 of the last group carries (x,y,z,0) instead: dummy fetch
+      load_chunk(geo, A.packed, p, l0, q, raw[c][0]);
+      if (NL == 2) load_chunk(geo, A.packed, p, l1, q, raw[c][NL - 1]);
     }
+  };
+  issue(0);
+#pragma unroll
+  for (int g = 0; g < 7; ++g) {
+    float f8[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float4 f = blend_chunk<NL>(raw[c], fl);
+      if (g == 6 && c == 1) f = h ? make_float4(x[0], x[1], x[2], 0.f) : f;   // raw xyz (fields.py:265,298)
+      f8[4 * c + 0] = f.x; f8[4 * c + 1] = f.y; f8[4 * c + 2] = f.z; f8[4 * c + 3] = f.w;
+    }
+    if (g + 1 < 7) issue(g + 1);
     __builtin_amdgcn_sched_barrier(0);
-    const int nj = t == 3 ? 8 : 16;
+    const float* wf = lds + kW1f + (8 * g) * 64 + lane;
+    float a_cur[8], a_nxt[8];
 #pragma unroll
-    for (int j = 0; j < nj; ++j)
+    for (int tt = 0; tt < 8; ++tt) a_cur[tt] = wf[tt * SDF_KSTEPS * 64];
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt)
-        acc[tt] = tf_mfma(lds[kW1f + (tt * SDF_KSTEPS + 16 * t + j) * 64 + lane], fin[j], acc[tt]);
+    for (int j = 0; j < 8; ++j) {
+      if (j + 1 < 8) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) a_nxt[tt] = wf[(tt * SDF_KSTEPS + j + 1) * 64];
+      }
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) acc[tt] = tf_mfma(a_cur[tt], f8[j], acc[tt]);
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) a_cur[tt] = a_nxt[tt];
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   float part = 0.f;
@@ -151,10 +185,28 @@ __device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* __res
   return part + A.b2[0];
 }
 
+__device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
+                                            int l1, float fl, int lane, f32x16 (&acc)[8]) {
+  // wave-uniform choice: one mip level is enough when no lane has a fractional LOD
+  if (__any(fl != 0.f)) return sdf_hidden_nl<2>(A, lds, x, l0, l1, fl, lane, acc);
+  return sdf_hidden_nl<1>(A, lds, x, l0, l1, fl, lane, acc);
+}
+
 template <int MODE>  // 0: sdf + feat, 1: sdf only, 2: alpha (7 taps)
 __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
+  if (threadIdx.x == 0) {
+    int* geo = reinterpret_cast<int*>(lds + kGeo);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        int* e = geo + (i * 4 + l) * 8;
+        e[0] = vm_dim(A.g.ph[i], l); e[1] = vm_dim(A.g.pw[i], l); e[2] = vm_dim(A.g.ll[i], l);
+        e[3] = (int)A.g.poff[i][l]; e[4] = (int)A.g.loff[i][l]; e[5] = e[6] = e[7] = 0;
+      }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const long long n_groups = (A.n + 127) / 128;  // the 4 waves advance in lockstep (W2 streaming uses workgroup barriers)
@@ -177,7 +229,7 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[t][j] = lds[kB2a + (t * 16 + j) * 2 + h];
-      tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kLdsFloats, threadIdx.x, lane, acc, o);
+      tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kStream, threadIdx.x, lane, acc, o);
       if (valid) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -232,6 +284,7 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   int rc = vm_geom_init(d, aabb_host, &A->g);
   TF_REQUIRE(rc != -1, TF_EINVAL, "%s: bad TfVmDesc", who);
   TF_REQUIRE(rc != -2, TF_ESHAPE, "%s: plane/line sizes > 1 must be divisible by 2^(n_levels-1)", who);
+  TF_REQUIRE(A->g.total < (1LL << 31), TF_ESHAPE, "%s: packed field exceeds 2^31 floats", who);
   TF_REQUIRE(workspace_floats >= (size_t)kSdfWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kSdfWsFloats);
   TF_REQUIRE(mlp->w1 && mlp->b1 && mlp->w2 && mlp->b2, TF_EINVAL, "%s: null weight pointer", who);
@@ -250,7 +303,7 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
 template <int MODE>
 static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
   A.b2 = b2_dev;
-  const size_t lds = (size_t)(kLdsFloats + 2 * 4096) * sizeof(float);  // weights + W2 streaming double buffer
+  const size_t lds = (size_t)kLdsTotal * sizeof(float);  // weights + W2 streaming double buffer + geometry table
   static bool attr_set[3] = {false, false, false};
   if (!attr_set[MODE]) {
     hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -110,9 +110,15 @@ __device__ __forceinline__ void mip_select(float level, int n_levels, int& l0, i
 }
 
 __device__ __forceinline__ float softplus100(float x) {
-  // torch.nn.Softplus(beta=100, threshold=20)
-  float bx = 100.f * x;
-  return bx > 20.f ? x : log1pf(expf(bx)) * 0.01f;
+  // torch.nn.Softplus(beta=100, threshold=20): log1p(exp(100 x)) / 100.
+  // Hardware exp2/log2 (1 ulp) + the classic log1p correction  log1p(t) = log(u) * t / (u - 1), u = fl(1 + t),
+  // which cancels the rounding of 1 + t; relative error ~3e-7 (the libm log1pf/expf pair costs ~100 VALU ops per
+  // activation, x 128 activations per lane per field evaluation -- it dominated the kernel).
+  const float bx = 100.f * x;
+  const float t = __expf(bx);
+  const float u = 1.f + t;
+  const float l = (u == 1.f) ? t : __logf(u) * __fdividef(t, u - 1.f);
+  return bx > 20.f ? x : l * 0.01f;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 #endif
