@@ -51,7 +51,7 @@ def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
     """Oracle (CPU PyTorch restatement of the reference path) on a bounded sample of the same workload."""
     from oracle import shading as osh
     from tensoflow_amd.synth import sphere_surface_points, sphere_torus_mesh
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(64, os.cpu_count()))   # beyond ~64 threads the small ops of this path slow down
     # the oracle traces by brute force: use the same analytic scene at 3 264 triangles so the sample
     # stays within budget (the reference's BVH is a CUDA extension; there is no CPU path for it)
     verts, faces = sphere_torus_mesh(24, 48, 32, 16)
@@ -59,7 +59,7 @@ def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
     pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(n_points, seed=77)]
     t0 = time.time()
     done = 0
-    chunk = 16
+    chunk = 128            # the reference shades 2048 points per step; per-call mip builds amortise over the chunk
     while done < n_points and time.time() - t0 < budget_s:
         sl = slice(done, min(done + chunk, n_points))
         with torch.no_grad():
