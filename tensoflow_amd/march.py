@@ -1,0 +1,144 @@
+"""Host-side composition of the NeuS-style ray-march on the MI355X.
+
+Mirrors ShapeRenderer.near_far_from_sphere (network/shapeRenderer.py:676-684), compute_ball_radii (:966-970),
+sample_ray + upsample + cat_z_vals (:820-932, with utils/network_utils.py:117-147 sample_pdf) and the train branch
+of render_core (:1105-1277).  All field evaluations (64 + 3x16 per ray in the sampler, 7 per live sample in
+render_core) and the compositing scan run in libtensoflow_hip.so (tf_sdf_forward, tf_sdf_alpha_fwd,
+tf_composite_fwd); the sampler's per-ray bookkeeping (sort / searchsorted / cumprod over <= 128 entries) is
+device-resident torch ops on the same stream -- no host round trip.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def near_far_from_sphere(o, d, radius=1.0):
+    a = (d ** 2).sum(-1, keepdim=True)
+    b = 2.0 * (o * d).sum(-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    return (mid - radius).clamp(min=1e-3), mid + radius
+
+
+def ball_radii(t, radii, cos):
+    inv = 1.0 / cos
+    tmp = (inv * inv - 1).sqrt() - radii
+    return t * radii * cos / (tmp * tmp + 1.0).sqrt()
+
+
+class SdfField:
+    """TensoSDF parameters resident on the device + packed pyramid (rebuilt by `refresh()` after an optimizer step)."""
+
+    def __init__(self, sd, aabb, grid_size, n_levels, device="cuda", prefix="sdf_network."):
+        g = lambda k: sd[prefix + k].to(device).float().contiguous()
+        self.planes = [g(f"sdf_plane.{i}") for i in range(3)]
+        self.lines = [g(f"sdf_line.{i}") for i in range(3)]
+        self.W = [g("sdf_mat.0.weight"), g("sdf_mat.0.bias"), g("sdf_mat.2.weight"), g("sdf_mat.2.bias")]
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).cpu()
+        self.aabb_dev = self.aabb.to(device)
+        self.grid_size = torch.as_tensor(grid_size, dtype=torch.float32)
+        self.units = ((self.aabb[1] - self.aabb[0]) / (self.grid_size - 1)).tolist()
+        self.n_levels = n_levels
+        self.device = device
+        self.packed = ops.VmPacked(self.planes, self.lines, n_levels)
+
+    def refresh(self):
+        self.packed.repack(self.planes, self.lines)
+
+    def sdf(self, pts, level=None):
+        return ops.sdf_forward(self.packed, *self.W, pts, level, self.aabb, want_feat=False)[0]
+
+    def forward(self, pts, level=None):
+        return ops.sdf_forward(self.packed, *self.W, pts, level, self.aabb, want_feat=True)
+
+    def sdf_alpha(self, pts, level, dists, dirs, inv_s, cos_anneal, want_feat=True, want_hess=True):
+        return ops.sdf_alpha(self.packed, *self.W, pts, level, dists, dirs, self.aabb, self.units, inv_s, cos_anneal,
+                             want_feat=want_feat, want_hess=want_hess)
+
+
+def _sample_pdf_det(bins, weights, n):
+    weights = weights + 1e-5
+    pdf = weights / weights.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    u = torch.linspace(0.5 / n, 1.0 - 0.5 / n, steps=n, device=bins.device).expand(list(cdf.shape[:-1]) + [n]).contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    b0, b1 = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    den = c1 - c0
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    return b0 + (u - c0) / den * (b1 - b0)
+
+
+def _upsample(o, d, z, sdf, n_imp, inv_s):
+    pts = o[:, None] + d[:, None] * z[..., None]
+    rad = pts.norm(dim=-1)
+    inside = (rad[:, :-1] < 1.0) | (rad[:, 1:] < 1.0)
+    ps, ns = sdf[:, :-1], sdf[:, 1:]
+    pz, nz = z[:, :-1], z[:, 1:]
+    mid = (ps + ns) * 0.5
+    cos = (ns - ps) / (nz - pz + 1e-5)
+    prev = torch.cat([torch.zeros(z.shape[0], 1, device=z.device), cos[:, :-1]], -1)
+    cos = torch.minimum(prev, cos).clip(-1e3, 0.0) * inside
+    dist = nz - pz
+    pc = torch.sigmoid((mid - cos * dist * 0.5) * inv_s)
+    nc = torch.sigmoid((mid + cos * dist * 0.5) * inv_s)
+    alpha = (pc - nc + 1e-5) / (pc + 1e-5)
+    w = alpha * torch.cumprod(torch.cat([torch.ones(z.shape[0], 1, device=z.device), 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
+    return _sample_pdf_det(z, w, n_imp)
+
+
+@torch.no_grad()
+def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n_samples=64, n_importance=64, up_steps=4):
+    """ShapeRenderer.sample_ray with perturb=0, clip_sample_variance=False -> packed t_starts, t_ends, ray_indices (int64)."""
+    rn = o.shape[0]
+    dev = o.device
+    aabb = field.aabb_dev
+    vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+    ra, rb = (aabb[1] - o) / vec, (aabb[0] - o) / vec
+    tmin = torch.minimum(ra, rb).amax(-1).clamp(min=near[:, 0], max=far[:, 0])[:, None]
+    tmax = torch.maximum(ra, rb).amin(-1).clamp(min=near[:, 0], max=far[:, 0])[:, None]
+    t = tmin + (tmax - tmin) * torch.linspace(0.0, 1.0, n_samples, device=dev)[None]
+    pts = o[:, None] + d[:, None] * t[..., None]
+    lv = torch.log2(ball_radii(t[..., None], radiis[:, None], rays_cos[:, None]) / base_radii)
+    sdf = field.sdf(pts.reshape(-1, 3), lv.reshape(-1)).reshape(rn, n_samples)
+    for i in range(up_steps):
+        inv_s = torch.ones(rn, t.shape[1] - 1, device=dev) * 64 * 2 ** i
+        new_t = _upsample(o, d, t, sdf, n_importance // up_steps, inv_s)
+        t_all, index = torch.sort(torch.cat([t, new_t], -1), -1)
+        if i + 1 < up_steps:
+            npts = o[:, None] + d[:, None] * new_t[..., None]
+            nlv = torch.log2(ball_radii(new_t[..., None], radiis[:, None], rays_cos[:, None]) / base_radii)
+            nsdf = field.sdf(npts.reshape(-1, 3), nlv.reshape(-1)).reshape(rn, -1)
+            sdf = torch.gather(torch.cat([sdf, nsdf], -1), -1, index)
+        t = t_all
+    dists = t[:, 1:] - t[:, :-1]
+    dists = torch.cat([dists, dists[:, -1:]], -1)
+    mid = t + dists * 0.5
+    ridx = torch.arange(rn, device=dev)[:, None].expand(rn, t.shape[1])
+    p = o[:, None] + d[:, None] * mid[..., None]
+    inner = ~((aabb[0] > p) | (p > aabb[1])).any(-1)
+    return t[inner], (t + dists)[inner], ridx[inner]
+
+
+@torch.no_grad()
+def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radii, inv_s, cos_anneal, shade_fn=None):
+    """Train-branch forward of ShapeRenderer.render_core with a white background.
+    shade_fn(points, normals, view_dirs, feat) -> color [N,3] (split-sum shading); None -> white (geometry-only march)."""
+    rn = o.shape[0]
+    mid = (t0 + t1) * 0.5
+    dists = t1 - t0
+    ro, rd = o[ridx], d[ridx]
+    pts = ro + rd * mid[:, None]
+    lv = torch.log2(ball_radii(mid[:, None], radiis[ridx], rays_cos[ridx]) / base_radii)[:, 0]
+    alpha, grad, feat, sdf, nh = field.sdf_alpha(pts, lv, dists, rd, inv_s, cos_anneal)
+    color = shade_fn(pts, F.normalize(grad, dim=-1), -rd, feat) if shade_fn is not None else torch.ones_like(pts)
+    vals = torch.cat([color, grad], -1).contiguous()
+    w, acc, out = ops.composite(alpha, ridx, vals, rn)
+    acc = acc[:, None]
+    rgb = out[:, :3] + (1 - acc)
+    nrm = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * torch.tensor([0.0, 0.0, 1.0], device=o.device), dim=-1)
+    return dict(ray_rgb=rgb, acc=acc, normal=nrm, gradient_error=(grad.norm(dim=-1) - 1.0) ** 2, alpha=alpha, weights=w,
+                sdf=sdf, grad=grad, feat=feat, normal_hessian=nh, points=pts, levels=lv,
+                loss_sparse=torch.exp(-20.0 * sdf.abs()).mean(), loss_hessian=nh.abs().mean())
