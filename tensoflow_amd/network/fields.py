@@ -1,0 +1,124 @@
+"""TensoSDF and MCShadingNetwork (reference: network/fields.py:20-317, :618-1595), forward direction, on the HIP kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..shading import MCShader
+from .flow import TensoFlow, _check_no_grad
+from .light import EnvLight
+
+
+class TensoSDF(nn.Module):
+    def __init__(self, gridSize, aabb, device="cuda", sdf_n_comp=36, sdf_dim=256, app_dim=128, init_n_levels=3, sdf_multires=0):
+        super().__init__()
+        if sdf_multires != 0:
+            raise NotImplementedError("the fused decoder instantiates sdf_multires=0 (configs/shape/*: default)")
+        self.sdf_n_comp, self.sdf_dim, self.app_dim, self.device = sdf_n_comp, sdf_dim, app_dim, device
+        self.matMode, self.vecMode, self.nplane, self.init_radius = [[0, 1], [0, 2], [1, 2]], [2, 1, 0], 3, 0.2
+        self.update_gridSize_aabb(torch.as_tensor(gridSize), aabb, init_n_levels)
+        planes, lines = [], []
+        for i in range(3):
+            ps, ls = self.gridSize[self.matMode[i]], self.gridSize[self.vecMode[i]]
+            x, y = torch.meshgrid(torch.linspace(-1, 1, int(ps[0])), torch.linspace(-1, 1, int(ps[1])), indexing="ij")
+            init = (torch.sqrt(x ** 2 + y ** 2) - self.init_radius)[None, None].expand(1, sdf_n_comp, -1, -1)
+            planes.append(nn.Parameter(init.clone()))
+            lines.append(nn.Parameter(torch.ones(1, sdf_n_comp, int(ls), 1) * (1.0 / (sdf_n_comp * 3))))
+        self.sdf_plane, self.sdf_line = nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
+        self.sdf_mat = nn.Sequential(nn.Linear(3 * sdf_n_comp + 3, sdf_dim), nn.Softplus(beta=100), nn.Linear(sdf_dim, 1 + app_dim)).to(device)
+        nn.init.constant_(self.sdf_mat[0].bias, 0.0)
+        nn.init.normal_(self.sdf_mat[0].weight, 0.0, np.sqrt(2) / np.sqrt(sdf_dim))
+        nn.init.constant_(self.sdf_mat[-1].bias, -self.init_radius)
+        nn.init.normal_(self.sdf_mat[-1].weight, mean=np.sqrt(np.pi) / np.sqrt(sdf_dim), std=0.0001)
+        self._packed, self._packed_version = None, None
+
+    def update_gridSize_aabb(self, gridSize, aabb, n_levels):
+        self.gridSize, self.aabb = gridSize, aabb
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.n_levels = n_levels
+
+    def _field(self):
+        ver = tuple(p._version for p in list(self.sdf_plane) + list(self.sdf_line)) + (self.n_levels,)
+        if self._packed is None or ver != self._packed_version:
+            self._packed = ops.VmPacked(list(self.sdf_plane), list(self.sdf_line), self.n_levels)
+            self._packed_version = ver
+        return self._packed
+
+    def _w(self):
+        return [self.sdf_mat[0].weight, self.sdf_mat[0].bias, self.sdf_mat[2].weight, self.sdf_mat[2].bias]
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        return [{"params": self.sdf_line, "lr": lr_init_spatialxyz}, {"params": self.sdf_plane, "lr": lr_init_spatialxyz},
+                {"params": self.sdf_mat.parameters(), "lr": lr_init_network}]
+
+    def forward(self, xyz_sampled, level_vol):
+        """fields.py:262-299 -> [N, 1+app_dim]."""
+        _check_no_grad(self, "TensoSDF.forward")
+        sdf, feat = ops.sdf_forward(self._field(), *self._w(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb)
+        return torch.cat([sdf[:, None], feat], -1)
+
+    def sdf(self, xyz_sampled, level_vol=None):
+        _check_no_grad(self, "TensoSDF.sdf")
+        return ops.sdf_forward(self._field(), *self._w(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb, want_feat=False)[0][:, None]
+
+    def sdf_hidden_appearance(self, xyz_sampled, level_vol):
+        return self.forward(xyz_sampled, level_vol)[..., 1:]
+
+    def gradient(self, x, level_vol, training=False, sdf=None):
+        """fields.py:227-260 -> (gradients [N,3], normal_hessian [N] or None); one fused launch instead of 6 forwards."""
+        _check_no_grad(self, "TensoSDF.gradient")
+        if x.shape[0] == 0:
+            return (torch.zeros(0, 3, device=x.device), torch.zeros(0, 3, device=x.device) if training else None)
+        z = torch.zeros(x.shape[0], device=x.device)
+        _, grad, _, _, nh = ops.sdf_alpha(self._field(), *self._w(), x, level_vol, z, torch.zeros_like(x), self.aabb,
+                                          [float(u) for u in self.units], 1.0, 0.0, want_feat=False, want_hess=training)
+        return grad, (nh if training else None)
+
+
+class MCShadingNetwork(nn.Module):
+    """Eval-mode material-stage shader with the reference's parameter names (fields.py:668-760).
+    `ray_tracer` is the (vertices, triangles) pair the reference hands to raytracing.RayTracer (materialRenderer.py:147-149)."""
+    default_cfg = {"diffuse_sample_num": 512, "specular_sample_num": 256, "outer_light_version": "envlight", "light_exp_max": 5.0,
+                   "inner_light_exp_max": 5.0, "human_lights": False, "gridSize": [512, 512, 512], "nis_diffuse_sample_num": 64,
+                   "nis_specular_sample_num": 32, "light_reso": 128, "mat_grid": 512}
+
+    def __init__(self, cfg, ray_tracer, aabb, unit_size):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if self.cfg["outer_light_version"] != "envlight" or self.cfg["human_lights"]:
+            raise NotImplementedError("round 1 covers outer_light_version='envlight', human_lights=False (configs/mat/syn/*.yaml)")
+        self.aabb, self.unit_size, self.ray_tracer = aabb, float(unit_size), ray_tracer
+        R, C = self.cfg["mat_grid"], 36
+        self.mat_plane = nn.ParameterList([nn.Parameter(1e-4 * (2 * torch.rand(1, C, R, R) - 1)) for _ in range(3)]).cuda()
+        self.mat_line = nn.ParameterList([nn.Parameter(torch.ones(1, C, R, 1) / (C * 3)) for _ in range(3)]).cuda()
+        wn = nn.utils.parametrizations.weight_norm
+        mk2 = lambda o: nn.Sequential(wn(nn.Linear(108, 128)), nn.ReLU(), wn(nn.Linear(128, o)), nn.Sigmoid()).cuda()
+        self.metallic_predictor, self.roughness_predictor, self.albedo_predictor = mk2(1), mk2(1), mk2(3)
+        self.inner_light = nn.Sequential(wn(nn.Linear(123, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
+                                         nn.ReLU(), wn(nn.Linear(256, 3)), nn.Identity()).cuda()
+        nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))
+        self.outer_light = EnvLight(trainable=True, max_res=self.cfg["light_reso"])
+        mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda")
+        self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
+        self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
+        self._shader = None
+
+    def shader(self):
+        """(Re)build the device-side evaluator from the current parameters (repacks the pyramids, folds weight-norm,
+        uploads the BVH the first time).  Call again after an optimizer step / load_state_dict."""
+        v, f = self.ray_tracer
+        sd = {k: t.detach() for k, t in self.state_dict().items()}
+        self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
+                                exp_max=self.cfg["inner_light_exp_max"])
+        return self._shader
+
+    @torch.no_grad()
+    def forward(self, pts, view_dirs, normals, human_poses=None, step=None, is_train=False):
+        """fields.py:1453-1473, eval with the flow samplers: -> (colors [pn,3], outputs dict)."""
+        sh = self._shader if self._shader is not None else self.shader()
+        out = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"])
+        outputs = {"albedo": out["albedo"], "roughness": out["roughness"], "metallic": out["metallic"],
+                   "normal": (F.normalize(normals, dim=-1) + 1) / 2, "specular_rays_id": out["specular_rays_id"]}
+        return out["colors"], outputs

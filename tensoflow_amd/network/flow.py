@@ -1,0 +1,116 @@
+"""TensoFlow (reference: network/flow.py:643-855) on the MI355X kernels."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..shading import posenc, sphere_latent
+
+
+class Reshift(nn.Module):
+    """network/flow.py:146-164 (kept only so that `flows.k.nn.0.{scale,offset}` exist in the state_dict)."""
+
+    def __init__(self, scale=2.0, offset=-1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.scalar_tensor(scale), requires_grad=False)
+        self.offset = nn.Parameter(torch.scalar_tensor(offset), requires_grad=False)
+
+    def forward(self, x):
+        return x * self.scale + self.offset
+
+
+class Block(nn.Module):
+    """Coupling block container (network/flow.py:549-598): nn = [Reshift, Linear, LeakyReLU, ... , Linear]."""
+
+    def __init__(self, d, mask, feature_dim, multires=3, d_hidden=64, n_hidden=3, n_bins=21):
+        super().__init__()
+        self.d, self.mask = d, mask
+        d_in = sum(mask) * (1 + 2 * multires)
+        layers = [Reshift()]
+        last = d_in + feature_dim
+        for _ in range(n_hidden):
+            layers += [nn.Linear(last, d_hidden), nn.LeakyReLU()]
+            last = d_hidden
+        layers.append(nn.Linear(last, (d - sum(mask)) * n_bins))
+        self.nn = nn.Sequential(*layers)
+
+
+def _check_no_grad(module, what):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise RuntimeError(f"{what}: the fused HIP forward has no backward yet (round 1) -- call it under torch.no_grad() "
+                           "or freeze the module (the reference's `*_copy` flows are frozen the same way, fields.py:1054-1065)")
+
+
+class TensoFlow(nn.Module):
+    def __init__(self, d, aabb, device="cuda", gridSize=[512, 512, 512], nis_n_comp=12, nis_dim=64, nis_feature_dim=16,
+                 nis_multires=3, refl_multires=3, roughness_multires=3, angle_multires=3, flow="pwquad", n_bins=10,
+                 disable_tensorial=False, disable_reflected=False):
+        super().__init__()
+        if flow != "pwquad" or d != 2 or n_bins != 10 or nis_dim != 64 or nis_feature_dim != 16 or \
+                (nis_multires, refl_multires, roughness_multires, angle_multires) != (3, 3, 3, 3):
+            raise NotImplementedError("the HIP kernels instantiate the reference default: d=2, 'pwquad', 10 bins, 64/16 dims")
+        self.nis_n_comp, self.nis_dim, self.nis_feature_dim = nis_n_comp, nis_dim, nis_feature_dim
+        self.device = device
+        self.matMode, self.vecMode = [[0, 1], [0, 2], [1, 2]], [2, 1, 0]
+        self.gridSize = torch.tensor(gridSize)
+        self.aabb = aabb
+        self.n_levels = 3
+        planes, lines = [], []
+        for i in range(3):
+            ps = self.gridSize[self.matMode[i]]
+            ls = self.gridSize[self.vecMode[i]]
+            planes.append(nn.Parameter(1e-4 * (2 * torch.rand(1, nis_n_comp, int(ps[0]), int(ps[1])) - 1)))
+            lines.append(nn.Parameter(torch.ones(1, nis_n_comp, int(ls), 1) * (1.0 / (nis_n_comp * 3))))
+        self.nis_plane = nn.ParameterList(planes).to(device)
+        self.nis_line = nn.ParameterList(lines).to(device)
+        self.nis_mat = nn.Sequential(nn.Linear(3 * nis_n_comp + 21, nis_dim), nn.Softplus(beta=100),
+                                     nn.Linear(nis_dim, nis_feature_dim)).to(device)
+        self.refl_input_ch, self.roughness_input_ch = 14, 7
+        feature_dim = nis_feature_dim + self.refl_input_ch + self.roughness_input_ch
+        self.flows = nn.ModuleList([Block(d, [(i + off) % 2 == 0 for i in range(d)], feature_dim, n_bins=2 * n_bins + 1)
+                                    for off in range(2)]).to(device)
+        self.disable_tensorial, self.disable_reflected = disable_tensorial, disable_reflected
+        self._packed = None
+        self._packed_version = None
+
+    # ---- parameter plumbing
+    def _field(self):
+        ver = tuple(p._version for p in list(self.nis_plane) + list(self.nis_line))
+        if self._packed is None or ver != self._packed_version:
+            self._packed = ops.VmPacked(list(self.nis_plane), list(self.nis_line), self.n_levels)
+            self._packed_version = ver
+        return self._packed
+
+    def _nets(self):
+        return [[(blk.nn[l].weight, blk.nn[l].bias) for l in (1, 3, 5, 7)] for blk in self.flows]
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.01, lr_init_network=0.001):
+        return [{"params": self.nis_line, "lr": lr_init_spatialxyz}, {"params": self.nis_plane, "lr": lr_init_spatialxyz},
+                {"params": self.nis_mat.parameters(), "lr": lr_init_network}, {"params": self.flows.parameters(), "lr": lr_init_network}]
+
+    def tenso_feature(self, xyz_sampled, level_vol=None):
+        feat = ops.vm_gather(self._field(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb)
+        return self.nis_mat(torch.cat([feat, posenc(xyz_sampled, 3)], -1))
+
+    def _condition(self, pts, reflections):
+        feature = self.tenso_feature(pts)
+        if self.disable_tensorial:
+            feature = torch.zeros_like(feature)
+        refl = posenc(reflections, 3)
+        if self.disable_reflected:
+            refl = torch.zeros_like(refl)
+        return torch.cat([feature, refl, torch.zeros(pts.shape[0], 7, device=pts.device)], -1).contiguous()
+
+    # ---- reference API
+    def sample(self, pts, reflections, roughness, n_samples, return_jacobian=False):
+        """flow.py:833-855 -> angles [pn,sn,2] (, logj [pn,sn,1])."""
+        _check_no_grad(self, "TensoFlow.sample")
+        jitter = torch.rand(pts.shape[0], n_samples, device=pts.device) if self.training else None   # flow.py:86-87
+        ang, logj = ops.flow_sample(self._nets(), self._condition(pts, reflections), sphere_latent(n_samples).to(pts.device), jitter)
+        return (ang, logj) if return_jacobian else ang
+
+    def forward(self, pts, reflections, roughness, x, return_jacobian=False, rays_id=None):
+        """flow.py:801-831 -> z (, logqx)."""
+        _check_no_grad(self, "TensoFlow.forward")
+        z, logq = ops.flow_logq(self._nets(), self._condition(pts, reflections), x, rays_id=rays_id)
+        return (z, logq) if return_jacobian else z

@@ -86,3 +86,56 @@ def test_march_full_size_properties(dev):
     _, _, a = ops.composite(out["alpha"], ridx, v, 4096)
     _, _, b = ops.composite(out["alpha"], ridx, 2 * v, 4096)
     assert rel_err((2 * a).cpu(), b.cpu()) < 1e-6
+
+
+# ------------------------------------------------------------------------------- drop-in modules
+def test_module_tensosdf(golden, dev):
+    from tensoflow_amd.network.fields import TensoSDF
+    g = golden("tensosdf_r32_l3")
+    m = TensoSDF(torch.tensor([32, 32, 32]), AABB, device=dev, init_n_levels=3)
+    m.load_state_dict({k: v for k, v in g.sd.items() if "gaussian" not in k})
+    with torch.no_grad():
+        out = m(g["pts"].to(dev), g["level"].to(dev))
+        assert rel_err(out.cpu(), g["out_lvl"]) < TOL
+        assert rel_err(m.sdf(g["pts"].to(dev)).cpu(), g["out_none"][:, :1]) < TOL
+        grad, nh = m.gradient(g["pts"].to(dev), g["level"].to(dev), training=True, sdf=out[:, :1])
+        assert rel_err(grad.cpu(), g["grad_lvl"]) < TOL and rel_err(nh.cpu(), g["normal_hessian"]) < 2e-3
+        grad0, none = m.gradient(g["pts"].to(dev), None, training=False)
+        assert none is None and rel_err(grad0.cpu(), g["grad_none"]) < TOL
+        # parameters changed in place -> the packed pyramid is rebuilt
+        m.sdf_plane[0].mul_(0.5)
+        assert not torch.allclose(m(g["pts"].to(dev), g["level"].to(dev)), out)
+
+
+def test_module_tensoflow(golden, dev):
+    from tensoflow_amd.network.flow import TensoFlow
+    g = golden("tensoflow_r32")
+    m = TensoFlow(2, AABB, device=dev, gridSize=[32, 32, 32])
+    m.load_state_dict(g.sd)
+    m.eval()
+    c = lambda k: g[k].to(dev)
+    with torch.no_grad():
+        assert rel_err(m.tenso_feature(c("pts")).cpu(), g["cond_feat"]) < TOL
+        ang, logj = m.sample(c("pts"), c("view_angles"), c("roughness"), 32, return_jacobian=True)
+        assert float(torch.quantile((ang.cpu() - g["angles_32"]).abs().flatten(), 0.999)) < TOL
+        z, logq = m(c("pts"), c("view_angles"), c("roughness"), c("x_rid"), return_jacobian=True, rays_id=c("rays_id"))
+        assert rel_err(z.cpu(), g["z_rid"]) < TOL and rel_err(logq.cpu(), g["logq_rid"]) < TOL
+
+
+def test_module_mcshading(golden, dev):
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    g = golden("shading_small")
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, nis_diffuse_sample_num=sn_d,
+               nis_specular_sample_num=sn_s)
+    m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
+    missing, unexpected = m.load_state_dict(g.sd, strict=False)
+    assert not missing, missing                                  # every parameter of the mirror exists in the reference checkpoint
+    m.shader()
+    colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
+    assert rel_err(colors.cpu(), g.out["rgb_pr_nis"]) < TOL
+    assert rel_err(outputs["albedo"].cpu(), g.out["albedo"]) < TOL
+    env = m.outer_light.direct_light(g["env_dirs"].to(dev)[None, None])
+    assert env.shape == (1, 1, g["env_dirs"].shape[0], 3) and rel_err(env[0, 0].detach().cpu(), g["env_direct"]) < TOL
+    env.sum().backward()                                          # cube lookup has a HIP backward
+    assert m.outer_light.base.grad is not None and float(m.outer_light.base.grad.abs().sum()) > 0
