@@ -29,6 +29,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense f16/bf16 MFMA peak (the f16x3 split runs on these instructions)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_HIT_RAY = 326_656        # inner-light MLP 123-256-256-256-3
 FLOP_PER_FLOW_SAMPLE = 2 * 24_704  # two coupling blocks 44-64-64-64-21 (reference-faithful count)
@@ -116,6 +117,8 @@ def main():
     ap.add_argument("--points", type=int, default=16384, help="surface points per GPU per step")
     ap.add_argument("--flow-samples", type=int, default=128)
     ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
+    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
+                    help="matrix-core arithmetic of the 256-wide decoder: f16x3 split (fp32-accurate) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march", action="store_true")
     args = ap.parse_args()
@@ -136,6 +139,8 @@ def main():
     from tensoflow_amd.synth import sphere_surface_points
     mesh_res = tuple(int(v) for v in args.mesh.split(","))
     sh, sd, verts, faces, aabb, unit = build_scene(device, 4, mesh_res)
+    from tensoflow_amd import ops as _ops
+    sh.precision = _ops.PREC_F16X3 if args.precision == "f16x3" else _ops.PREC_F32
     S = args.flow_samples
     pn = args.points
     # every rank shades its own shard of the point stream (weak scaling), inputs resident in HBM
@@ -174,9 +179,11 @@ def main():
         if dom == "inner_light":
             n_launch = summ[dom][1]
             ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
-            roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
-                        per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} flop")
+            peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+            roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
+                        frac=ach / peak, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
+                        per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
+                                   f"({args.precision} MFMA: {'3 f16 MFMAs per fp32 product term, peak = dense f16' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
         elif dom == "flow_sample":
             n_launch = summ[dom][1]
             samples = timer.units.get("flow_sample", 0)
@@ -194,7 +201,7 @@ def main():
         line = {
             "metric": "shaded surface points/s @128 flow samples", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (f16x3 split on the f16 MFMA for the 256-wide decoder)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
                                    f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",

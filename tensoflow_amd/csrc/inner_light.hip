@@ -21,7 +21,12 @@ static constexpr int kIB2 = kIB1 + 256;
 static constexpr int kIB3 = kIB2 + 256;
 static constexpr int kIB4 = kIB3 + 256;
 static constexpr int kIdeMat = kIB4 + 32;           // [17][36] IDE polynomial coefficients
-static constexpr int kInnerWsFloats = kIdeMat + 17 * 36;
+// f16x3 fragments (hi|lo halves), offsets in FLOAT units (each k-step16 of 8 unit tiles = 4096 floats)
+static constexpr int kH1 = ((kIdeMat + 17 * 36 + 1023) / 1024) * 1024;   // 123 -> 256: 8 k-steps16
+static constexpr int kH2 = kH1 + 8 * 4096;          // 256 -> 256: 16 k-steps16
+static constexpr int kH3 = kH2 + 16 * 4096;
+static constexpr int kH4 = kH3 + 16 * 4096;         // 256 -> 3: 16 k-steps16 x 1 tile = 2 slabs
+static constexpr int kInnerWsFloats = kH4 + 2 * 4096;
 
 extern "C" size_t tf_inner_light_workspace_floats(void) { return kInnerWsFloats; }
 
@@ -48,6 +53,21 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
+template <int K16, int TIN>
+__device__ __forceinline__ void hidden_layer_h3(const float* __restrict__ wslab, const float* __restrict__ bias,
+                                                float* __restrict__ lds, int tid, int lane, int h,
+                                                const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
+  tf_layer_stream_h3<K16, 8, TIN, 1, 3>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, out);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
+}
+
 template <int KSTEPS, int TIN>
 __device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, const float* __restrict__ bias,
                                              float* __restrict__ lds, int tid, int lane, int h,
@@ -56,17 +76,18 @@ __device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, co
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_stream<KSTEPS, 8, TIN, 8>(wslab, lds, tid, lane, in, out);
+  tf_layer_stream<KSTEPS, 8, TIN, 8, 3>(wslab, lds, tid, lane, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
 }
 
+template <bool H3>
 __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts,
                                                           const float* __restrict__ view, const float* __restrict__ nrm,
                                                           long long m, float exp_max, float* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 4096];
+  __shared__ __attribute__((aligned(16))) float lds[3 * 4096];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
@@ -139,14 +160,21 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           const int k0 = 32 * t + (j & 3) + 8 * (j >> 2);
           in1[t][j] = h ? enc[k0 + 4] : enc[k0];
         }
-      hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
+      if (H3) hidden_layer_h3<8, 4>(ws + kH1, ws + kIB1, lds, tid, lane, h, in1, a);
+      else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
-    hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
-    hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
+    if (H3) {
+      hidden_layer_h3<16, 8>(ws + kH2, ws + kIB2, lds, tid, lane, h, a, b);
+      hidden_layer_h3<16, 8>(ws + kH3, ws + kIB3, lds, tid, lane, h, b, a);
+    } else {
+      hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
+      hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
+    }
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
-    tf_layer_stream<128, 1, 8, 64>(ws + kI4, lds, tid, lane, a, o);
+    if (H3) tf_layer_stream_h3<16, 1, 8, 8, 3>(reinterpret_cast<const _Float16*>(ws + kH4), lds, tid, lane, a, o);
+    else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) out[3 * row + c] = expf(fminf(o[0][c], exp_max));
@@ -155,18 +183,28 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
 }
 
 extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
-                                  float exp_max, float* out, float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+                                  float exp_max, int32_t precision, float* out, float* workspace, size_t workspace_floats,
+                                  tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(m >= 0, TF_ESHAPE, "tf_inner_light_fwd: m < 0");
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_inner_light_fwd: unknown precision %d", precision);
   if (m == 0) return TF_OK;
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "tf_inner_light_fwd: null pointer");
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_fwd: workspace too small (%zu < %d floats)",
              workspace_floats, kInnerWsFloats);
   for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "tf_inner_light_fwd: null weight pointer (layer %d)", l);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3, 1);
-  tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
+  if (precision == TF_PREC_F32) {
+    tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
+  } else {
+    _Float16* hw = reinterpret_cast<_Float16*>(workspace);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
+  }
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
@@ -178,7 +216,8 @@ extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const flo
   TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_fwd: hipMemcpyAsync failed: %s", hipGetErrorString(e));
   long long blocks = (m + 127) / 128;
   if (blocks > 1024) blocks = 1024;
-  inner_light_kernel<<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
+  if (precision == TF_PREC_F32) inner_light_kernel<false><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
+  else inner_light_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
   TF_LAUNCH_CHECK("tf_inner_light_fwd");
   return TF_OK;
 }

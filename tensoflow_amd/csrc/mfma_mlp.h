@@ -103,12 +103,26 @@ __device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*
     __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
 }
 
-template <int KSTEPS, int TOUT, int TIN, int SL>
+template <int N>
+__device__ __forceinline__ void tf_wait_vmcnt_barrier() {
+  // counted wait (the N youngest vector-memory ops may stay in flight) + raw barrier: a __syncthreads() would make
+  // the compiler drain vmcnt(0), i.e. also wait for the slab that was only just requested.
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// NBUF = 2: slab g+1 streams while slab g computes (32 KB LDS).  NBUF = 3: slabs g+1 and g+2 are in flight
+// (48 KB LDS) -- one slab of MFMAs (~2 us) does not always cover an L2 round trip under load.
+template <int KSTEPS, int TOUT, int TIN, int SL, int NBUF = 2>
 __device__ __forceinline__ void tf_layer_stream(const float* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
   static_assert(SL * TOUT * 64 == 4096, "one group must be 16 KB");
   static_assert(KSTEPS % SL == 0, "KSTEPS must be a multiple of the group size");
+  static_assert(NBUF == 2 || NBUF == 3, "double or triple buffering");
   constexpr int G = KSTEPS / SL;
+  constexpr int AHEAD = NBUF - 1;
   const int wave = tid >> 6;
   // ONE running per-thread source pointer, advanced by 16 KB per slab and made opaque each step: otherwise the
   // compiler materialises every slab address as its own loop-invariant 64-bit VGPR pair, hoists them out of the
@@ -116,16 +130,22 @@ __device__ __forceinline__ void tf_layer_stream(const float* __restrict__ wslab,
   const float* gp = wslab + wave * 1024 + lane * 4;
   asm volatile("" : "+v"(gp));
   tf_slab_dma(gp, lds, wave);
-  __syncthreads();   // (the compiler drains vmcnt before the barrier: slab 0 has landed for every wave)
+  if (AHEAD == 2 && G > 1) {
+    gp += 4096;
+    asm volatile("" : "+v"(gp));
+    tf_slab_dma(gp, lds + 4096, wave);
+    tf_wait_vmcnt_barrier<4>();
+  } else {
+    tf_wait_vmcnt_barrier<0>();
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    // slab g+1 streams into the other buffer while slab g feeds the MFMAs
-    if (g + 1 < G) {
+    if (g + AHEAD < G) {
       gp += 4096;
       asm volatile("" : "+v"(gp));
-      tf_slab_dma(gp, lds + ((g + 1) & 1) * 4096, wave);
+      tf_slab_dma(gp, lds + ((g + AHEAD) % NBUF) * 4096, wave);
     }
-    const float* buf = lds + (g & 1) * 4096 + lane;
+    const float* buf = lds + (g % NBUF) * 4096 + lane;
     // A operands are read from LDS one k-step AHEAD of the MFMAs that consume them (register double buffer),
     // so the LDS latency hides under the previous step's MFMAs instead of stalling every issue.
     float a_cur[TOUT], a_nxt[TOUT];
@@ -144,6 +164,109 @@ __device__ __forceinline__ void tf_layer_stream(const float* __restrict__ wslab,
 #pragma unroll
       for (int t = 0; t < TOUT; ++t) a_cur[t] = a_nxt[t];
     }
-    __syncthreads();
+    // next slab must have landed for every wave; the one after it (NBUF = 3) may still be in flight
+    if (AHEAD == 2 && g + 2 < G) tf_wait_vmcnt_barrier<4>();
+    else tf_wait_vmcnt_barrier<0>();
+  }
+}
+
+// =====================================================================================================
+// f16x3 path: fp32-accurate products on the f16 matrix cores (16x the fp32 MFMA rate per instruction).
+// Every operand is split  x = hi + lo  with hi = f16(x), lo = f16(x - hi)  (22 significant bits, abs floor
+// ~3e-8 from f16 subnormals) and the product is accumulated in fp32 as  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi
+// (the dropped a_lo*b_lo term is ~2^-22 relative): 3 x v_mfma_f32_32x32x16_f16 replace 8 x
+// v_mfma_f32_32x32x2_f32, i.e. 5.3x fewer matrix-core cycles at fp32-level accuracy.
+//
+// v_mfma_f32_32x32x16_f16: lane l supplies A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31], e = 0..7;
+// the accumulator layout is the fp32 one, so k-step s16 = 2*t + u of the next layer takes element e of lane half h
+// from accumulator register 8u + e of unit tile t, i.e. unit  32t + (e&3) + 8*(2u + (e>>2)) + 4h.
+// Weight slabs (global, then LDS): [s16][tout][hi|lo][lane][8 halves]  (16 bytes per lane, conflict-free b128 reads).
+typedef _Float16 tf_h8 __attribute__((ext_vector_type(8)));
+
+__host__ __device__ __forceinline__ int tf_kmap16(int s16, int h, int e) {
+  return 32 * (s16 >> 1) + (e & 3) + 8 * (2 * (s16 & 1) + (e >> 2)) + 4 * h;
+}
+
+__device__ __forceinline__ f32x16 tf_mfma_h(tf_h8 a, tf_h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+static __global__ void __launch_bounds__(256) tf_pack_wfrag_h3_kernel(const float* __restrict__ W, int nout, int ld, int col0,
+                                                               int kin, int tout_tiles, int ksteps16,
+                                                               _Float16* __restrict__ dst) {
+  int e_ = blockIdx.x * 256 + threadIdx.x;          // one thread per (s16, tout, lane)
+  int total = tout_tiles * ksteps16 * 64;
+  if (e_ >= total) return;
+  int lane = e_ & 63;
+  int tout = (e_ >> 6) % tout_tiles;
+  int s16 = (e_ >> 6) / tout_tiles;
+  int row = 32 * tout + (lane & 31);
+  _Float16* base = dst + ((long long)(s16 * tout_tiles + tout) * 2) * 64 * 8;   // [hi|lo][lane][8]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int k = tf_kmap16(s16, lane >> 5, e);
+    float w = (row < nout && k < kin) ? W[(long long)row * ld + col0 + k] : 0.f;
+    _Float16 hi = (_Float16)w;
+    _Float16 lo = (_Float16)(w - (float)hi);
+    base[lane * 8 + e] = hi;
+    base[64 * 8 + lane * 8 + e] = lo;
+  }
+}
+
+// Dense layer, f16x3, weights streamed through LDS in 16 KB slabs of SL16 k-steps (SL16*TOUT*2 KB == 16 KB).
+template <int K16, int TOUT, int TIN, int SL16, int NBUF = 3>
+__device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
+                                                   const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+  static_assert(SL16 * TOUT * 2048 == 16384, "one slab must be 16 KB");
+  static_assert(K16 % SL16 == 0, "K16 must be a multiple of the slab size");
+  constexpr int G = K16 / SL16;
+  constexpr int AHEAD = NBUF - 1;
+  const int wave = tid >> 6;
+  const float* gp = reinterpret_cast<const float*>(wslab) + wave * 1024 + lane * 4;
+  asm volatile("" : "+v"(gp));
+  tf_slab_dma(gp, lds, wave);
+  if (AHEAD == 2 && G > 1) {
+    gp += 4096;
+    asm volatile("" : "+v"(gp));
+    tf_slab_dma(gp, lds + 4096, wave);
+    tf_wait_vmcnt_barrier<4>();
+  } else {
+    tf_wait_vmcnt_barrier<0>();
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g + AHEAD < G) {
+      gp += 4096;
+      asm volatile("" : "+v"(gp));
+      tf_slab_dma(gp, lds + ((g + AHEAD) % NBUF) * 4096, wave);
+    }
+    const tf_h8* buf = reinterpret_cast<const tf_h8*>(lds + (g % NBUF) * 4096) + lane;   // 16-byte units
+#pragma unroll
+    for (int sl = 0; sl < SL16; ++sl) {
+      const int s16 = g * SL16 + sl;
+      tf_h8 b_hi, b_lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = in[s16 >> 1][8 * (s16 & 1) + e];
+        const _Float16 h = (_Float16)x;
+        b_hi[e] = h;
+        b_lo[e] = (_Float16)(x - (float)h);
+      }
+      tf_h8 a_hi = buf[(sl * TOUT) * 128], a_lo = buf[(sl * TOUT) * 128 + 64];
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) {
+        tf_h8 n_hi = a_hi, n_lo = a_lo;
+        if (t + 1 < TOUT) {   // next tile's fragments are requested before this tile's MFMAs
+          n_hi = buf[(sl * TOUT + t + 1) * 128];
+          n_lo = buf[(sl * TOUT + t + 1) * 128 + 64];
+        }
+        out[t] = tf_mfma_h(a_hi, b_hi, out[t]);
+        out[t] = tf_mfma_h(a_hi, b_lo, out[t]);
+        out[t] = tf_mfma_h(a_lo, b_hi, out[t]);
+        a_hi = n_hi; a_lo = n_lo;
+      }
+    }
+    if (AHEAD == 2 && g + 2 < G) tf_wait_vmcnt_barrier<4>();
+    else tf_wait_vmcnt_barrier<0>();
   }
 }

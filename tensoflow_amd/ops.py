@@ -292,8 +292,11 @@ class Bvh:
         return pos, nrm, depth, hit.bool()
 
 
-def inner_light(weights, pts, view, nrm, exp_max=5.0):
-    """weights: 4 (W_eff, b) pairs, 123-256-256-256-3."""
+PREC_F32, PREC_F16X3 = 0, 1
+
+
+def inner_light(weights, pts, view, nrm, exp_max=5.0, precision=PREC_F16X3):
+    """weights: 4 (W_eff, b) pairs, 123-256-256-256-3.  precision: PREC_F32 (exact fp32 MFMA) or PREC_F16X3."""
     lib = L.load()
     pts, view, nrm = _f(pts), _f(view), _f(nrm)
     net = L.TfMlp4()
@@ -307,8 +310,8 @@ def inner_light(weights, pts, view, nrm, exp_max=5.0):
         net.w[l], net.b[l] = W.data_ptr(), b.data_ptr()
     out = torch.empty_like(pts)
     ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pts.device)
-    L.check(lib.tf_inner_light_fwd(C.byref(net), _p(pts), _p(view), _p(nrm), pts.shape[0], float(exp_max), _p(out), _p(ws),
-                                   ws.numel(), _stream()), "tf_inner_light_fwd")
+    L.check(lib.tf_inner_light_fwd(C.byref(net), _p(pts), _p(view), _p(nrm), pts.shape[0], float(exp_max), int(precision), _p(out),
+                                   _p(ws), ws.numel(), _stream()), "tf_inner_light_fwd")
     return out
 
 

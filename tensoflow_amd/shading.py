@@ -124,8 +124,9 @@ class MCShader:
     """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
-                 exp_max=5.0, flow_suffix="_copy"):
+                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3):
         self.device = device
+        self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
         self.unit = float(unit_size)
         self.exp_max = exp_max
@@ -170,7 +171,7 @@ class MCShader:
             hp, hv, hn = inters[idx], -dirs[idx], nrm[idx]
         if idx.numel() > 0:
             with T.stage("inner_light"):
-                inner = ops.inner_light(self.inner, hp, hv, hn, self.exp_max)
+                inner = ops.inner_light(self.inner, hp, hv, hn, self.exp_max, precision=self.precision)
             T.add_units("inner_light", idx.numel())
             with T.stage("light_merge"):
                 lights.index_copy_(0, idx, inner)

@@ -245,8 +245,11 @@ def test_inner_light_matches_oracle(golden, dev):
     nrm = torch.randn(m, 3, generator=gen)
     ref = osh.inner_light(g.sd, pts, view, nrm)
     W = [(wn_weight(g.sd, f"inner_light.{i}").to(dev), g.sd[f"inner_light.{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
-    got = ops.inner_light(W, pts.to(dev), view.to(dev), nrm.to(dev))
-    assert rel_err(got.cpu(), ref) < TOL
+    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+        got = ops.inner_light(W, pts.to(dev), view.to(dev), nrm.to(dev), precision=prec)
+        err = rel_err(got.cpu(), ref)
+        print(f"inner_light precision={prec}: max rel err {err:.2e}")
+        assert err < TOL
 
 
 @pytest.mark.parametrize("tag", ["small", "default"])

@@ -49,8 +49,9 @@ elif which == "inner":
     m = 3_000_000
     pts = torch.rand(m, 3, device=dev) * 2 - 1
     v = torch.randn(m, 3, device=dev); nr = torch.randn(m, 3, device=dev)
-    ms = timeit(lambda: ops.inner_light(W, pts, v, nr))
-    print(f"inner_light m={m}: {ms:.2f} ms  {m*326656/ms*1e-9:.1f} TF/s")
+    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+        ms = timeit(lambda: ops.inner_light(W, pts, v, nr, precision=prec))
+        print(f"inner_light m={m} precision={prec}: {ms:.2f} ms  {m*326656/ms*1e-9:.1f} TF/s (algorithmic)")
 elif which == "bvh":
     verts, faces = sphere_torus_mesh(224, 448, 256, 128)
     bvh = ops.Bvh(verts, faces, dev)
