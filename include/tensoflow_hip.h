@@ -34,6 +34,11 @@ typedef enum TfStatus {
   TF_EHIP = -3    /* a HIP runtime call failed */
 } TfStatus;
 
+/* Matrix-core arithmetic of the decoders.  TF_PREC_F32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain.
+ * TF_PREC_F16X3: every operand split x = hi + lo in f16 and a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
+ * fp32 on v_mfma_f32_32x32x16_f16 (22 significant bits per operand; 5.3x fewer matrix-core cycles). */
+typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1 } TfPrecision;
+
 int tf_version(void);
 const char* tf_last_error(void);
 
@@ -139,13 +144,15 @@ size_t tf_flow_workspace_floats(int64_t pn);
  * Outputs angles [pn,sn,2], logj [pn,sn]; bins [pn,sn,2] int32 or NULL (spline bin per block). */
 int tf_flow_sample_fwd(const TfCouplingNet nets[2], const float* cond, const float* latent,
                        const float* jitter, int64_t pn, int32_t sn, float* angles, float* logj,
-                       int32_t* bins, float* workspace, size_t workspace_floats, tf_stream_t stream);
+                       int32_t* bins, int32_t precision /* TfPrecision */, float* workspace,
+                       size_t workspace_floats, tf_stream_t stream);
 
 /* TensoFlow.forward(..., return_jacobian=True): x [m,2]; row r uses cond[rays_id[r]] or, when
  * rays_id is NULL, cond[r / sn].  Outputs z [m,2], logq [m]; bins [m,2] int32 or NULL. */
 int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float* x,
                      const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, float* z, float* logq,
-                     int32_t* bins, float* workspace, size_t workspace_floats, tf_stream_t stream);
+                     int32_t* bins, int32_t precision /* TfPrecision */, float* workspace,
+                     size_t workspace_floats, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Environment light: EnvLight.direct_light (network/light.py:125-162) = exp(bilinear cube lookup
@@ -179,9 +186,11 @@ int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const int32_t* fa
  * origin = (o + d*origin_offset0) + origin_offset1*d, the two roundings of the reference's
  * `p + 1e-5 d` (fields.py:955) followed by `o + 2*unit_size*d` (materialRenderer.py:223); pass 0,0 for
  * a plain trace. */
+/* live [m] uint8 or NULL: rays with live == 0 are not traversed and reported as misses (rays whose weight in the
+ * integral is exactly zero -- below-horizon samples, fields.py:1156,1209 -- per-wavefront live-sample culling). */
 int tf_bvh_trace(const TfBvhNode* nodes, const float* tris, int64_t n_nodes, const float* o, const float* d,
-                 float origin_offset0, float origin_offset1, int64_t m, float* pos, float* nrm, float* depth,
-                 uint8_t* hit, tf_stream_t stream);
+                 float origin_offset0, float origin_offset1, const uint8_t* live, int64_t m, float* pos,
+                 float* nrm, float* depth, uint8_t* hit, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic small MLP on rows (weight-norm already folded by the caller): used for the inner-light
@@ -193,10 +202,6 @@ typedef struct TfMlp4 {
   const float* b[4];
 } TfMlp4;
 size_t tf_inner_light_workspace_floats(void);
-/* Matrix-core arithmetic of the decoders.  TF_PREC_F32: v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain.
- * TF_PREC_F16X3: every operand split x = hi + lo in f16 and a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
- * fp32 on v_mfma_f32_32x32x16_f16 (22 significant bits per operand; 5.3x fewer matrix-core cycles). */
-typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1 } TfPrecision;
 /* pts/view/nrm [m,3] (hit position, direction back along the ray = -d, surface normal) -> out [m,3]. */
 int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm,
                        int64_t m, float exp_max, int32_t precision, float* out, float* workspace,
@@ -223,7 +228,7 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                   const float* albedo, const float* ang_d, const float* logq_d, int32_t sd,
                   const float* fixed_d, const float* az_jitter, int32_t nf, const float* ang_s,
                   const float* logq_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
-                  tf_stream_t stream);
+                  uint8_t* live /* [pn,T] = any(wgt != 0), may be NULL */, tf_stream_t stream);
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);

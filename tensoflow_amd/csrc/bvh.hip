@@ -138,7 +138,8 @@ __device__ __forceinline__ bool box_hit(const TfBvhNode& nd, float ox, float oy,
 
 __global__ void __launch_bounds__(256) bvh_trace_kernel(const TfBvhNode* __restrict__ nodes, const float* __restrict__ tris,
                                                         const float* __restrict__ o, const float* __restrict__ d,
-                                                        float off0, float off1, long long m, float* __restrict__ pos,
+                                                        float off0, float off1, const unsigned char* __restrict__ live,
+                                                        long long m, float* __restrict__ pos,
                                                         float* __restrict__ nrm, float* __restrict__ depth,
                                                         unsigned char* __restrict__ hit) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(256) bvh_trace_kernel(const TfBvhNode* __restr
   int cur = 0;
   float tn;
   if (!box_hit(nodes[0], ox, oy, oz, ix, iy, iz, best, tn)) cur = -1;
+  if (live && !live[i]) cur = -1;   // ray carries zero weight in the integral: reported as a miss, never traversed
   while (cur >= 0) {
     const TfBvhNode nd = nodes[cur];
     if (nd.count > 0) {
@@ -214,13 +216,13 @@ __global__ void __launch_bounds__(256) bvh_trace_kernel(const TfBvhNode* __restr
 }
 
 extern "C" int tf_bvh_trace(const TfBvhNode* nodes, const float* tris, int64_t n_nodes, const float* o, const float* d,
-                            float origin_offset0, float origin_offset1, int64_t m, float* pos, float* nrm, float* depth,
-                            uint8_t* hit, tf_stream_t stream) {
+                            float origin_offset0, float origin_offset1, const uint8_t* live, int64_t m, float* pos,
+                            float* nrm, float* depth, uint8_t* hit, tf_stream_t stream) {
   TF_REQUIRE(m >= 0 && n_nodes > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
   if (m == 0) return TF_OK;
   TF_REQUIRE(nodes && tris && o && d && depth, TF_EINVAL, "tf_bvh_trace: null pointer");
-  bvh_trace_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(nodes, tris, o, d, origin_offset0, origin_offset1, m,
-                                                                      pos, nrm, depth, hit);
+  bvh_trace_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(nodes, tris, o, d, origin_offset0, origin_offset1, live,
+                                                                      m, pos, nrm, depth, hit);
   TF_LAUNCH_CHECK("tf_bvh_trace");
   return TF_OK;
 }

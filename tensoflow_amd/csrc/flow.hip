@@ -147,12 +147,21 @@ __device__ __forceinline__ void pw_forward(float xin, const float (&wv)[32], flo
 static constexpr int kL1 = 0, kL2 = kL1 + 2 * 4 * 64, kL3 = kL2 + 2 * 32 * 64, kL4 = kL3 + 2 * 32 * 64,
                      kB2 = kL4 + 32 * 64, kB3 = kB2 + 64, kB4 = kB3 + 64, kNetFloats = kB4 + 32;
 
+// f16x3 image (offsets in floats; one (s16, tout) fragment pair = 512 floats = 2 KB):
+//   L1s [1][2] | L2 [4][2] | L3 [4][2] | L4 [4][1] | b2 | b3 | b4
+static constexpr int hL1 = 0, hL2 = hL1 + 2 * 512, hL3 = hL2 + 8 * 512, hL4 = hL3 + 8 * 512, hB2 = hL4 + 4 * 512,
+                     hB3 = hB2 + 64, hB4 = hB3 + 64, hNetFloats = hB4 + 32;
+static_assert(hNetFloats <= kNetFloats + 512, "workspace sizing assumes the f16x3 image is not much larger");
+
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
 
 // net eval for one tile: y_keep per lane (this lane's row), P row pointer -> wv[32] (all 21+pad outputs of the row)
+template <bool H3>
 __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS*/, const float* __restrict__ Prow,
                                              float y_keep, int lane, float (&wv)[32]) {
   const int h = lane >> 5;
+  constexpr int B2 = H3 ? hB2 : kB2, B3 = H3 ? hB3 : kB3, B4 = H3 ? hB4 : kB4;
+  const tf_h8* nh = reinterpret_cast<const tf_h8*>(net) + lane;
   // layer-1 sample part: embed3(y) (7 values, Reshift 2x-1), k = rho(j,h), j = 0..3
   float emb[8];
   emb[0] = y_keep;
@@ -165,37 +174,42 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
   for (int j = 0; j < 16; ++j) in1[0][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) in1[0][j] = (h ? emb[4 + j] : emb[j]) * 2.f - 1.f;
+  // (f16x3: k-step 0 takes registers 0..7; 4..7 stay 0 -> inputs 8..15 are padding)
   f32x16 a[2], b[2];
   // init accumulators with the hoisted per-point part (already includes b1)
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[t][j] = Prow[32 * t + tf_rho(j, h)];
-  tf_layer<4, 2, 1>(net + kL1 + lane, in1, a);
+  if (H3) tf_layer_h3<1, 2, 1>(nh + hL1 / 4, in1, a);
+  else tf_layer<4, 2, 1>(net + kL1 + lane, in1, a);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       a[t][j] = leaky(a[t][j]);
-      b[t][j] = net[kB2 + (t * 16 + j) * 2 + h];
+      b[t][j] = net[B2 + (t * 16 + j) * 2 + h];
     }
-  tf_layer<32, 2, 2>(net + kL2 + lane, a, b);
+  if (H3) tf_layer_h3<4, 2, 2>(nh + hL2 / 4, a, b);
+  else tf_layer<32, 2, 2>(net + kL2 + lane, a, b);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       b[t][j] = leaky(b[t][j]);
-      a[t][j] = net[kB3 + (t * 16 + j) * 2 + h];
+      a[t][j] = net[B3 + (t * 16 + j) * 2 + h];
     }
-  tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
+  if (H3) tf_layer_h3<4, 2, 2>(nh + hL3 / 4, b, a);
+  else tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
   f32x16 o[1];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[t][j] = leaky(a[t][j]);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) o[0][j] = net[kB4 + j * 2 + h];
-  tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
+  for (int j = 0; j < 16; ++j) o[0][j] = net[B4 + j * 2 + h];
+  if (H3) tf_layer_h3<4, 1, 2>(nh + hL4 / 4, a, o);
+  else tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
   // gather the row's 32 outputs: own 16 (rows rho(j,h)) + partner's 16 (rows rho(j,1-h))
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -207,7 +221,7 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
   }
 }
 
-template <bool SAMPLE>
+template <bool SAMPLE, bool H3>
 __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
                                                    const float* __restrict__ P /*[2][pn][64]*/,
                                                    const float* __restrict__ latent, const float* __restrict__ jitter,
@@ -215,7 +229,8 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
                                                    long long m, int sn, long long pn, float* __restrict__ out_xy,
                                                    float* __restrict__ out_lj, int* __restrict__ bins) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < 2 * kNetFloats; i += blockDim.x) lds[i] = netfrag[i];
+  constexpr int NF = H3 ? hNetFloats : kNetFloats;
+  for (int i = threadIdx.x; i < 2 * NF; i += blockDim.x) lds[i] = netfrag[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -248,14 +263,14 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
     int bin0, bin1;
     float t, l;
     if (SAMPLE) {
-      coupling_net(lds, P + pt * 64, x0, lane, wv);                      // block 0 keeps x0, moves x1
+      coupling_net<H3>(lds, P + pt * 64, x0, lane, wv);                  // block 0 keeps x0, moves x1
       pw_inverse(x1, wv, t, l, bin0); x1 = t; lj += l;
-      coupling_net(lds + kNetFloats, P + (pn + pt) * 64, x1, lane, wv);  // block 1 keeps x1, moves x0
+      coupling_net<H3>(lds + NF, P + (pn + pt) * 64, x1, lane, wv);     // block 1 keeps x1, moves x0
       pw_inverse(x0, wv, t, l, bin1); x0 = t; lj += l;
     } else {
-      coupling_net(lds + kNetFloats, P + (pn + pt) * 64, x1, lane, wv);
+      coupling_net<H3>(lds + NF, P + (pn + pt) * 64, x1, lane, wv);
       pw_forward(x0, wv, t, l, bin1); x0 = t; lj += l;
-      coupling_net(lds, P + pt * 64, x0, lane, wv);
+      coupling_net<H3>(lds, P + pt * 64, x0, lane, wv);
       pw_forward(x1, wv, t, l, bin0); x1 = t; lj += l;
       lj += logf(cosf(x1 * kHalfPi));   // + latent_prior.log_prob(z)
     }
@@ -285,6 +300,23 @@ __global__ void __launch_bounds__(256) flow_point_part_kernel(const float* __res
   P[e] = acc;
 }
 
+static int pack_nets_h3(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
+  for (int b = 0; b < 2; ++b) {
+    float* base = netfrag + (size_t)b * hNetFloats;
+    for (int l = 0; l < 4; ++l)
+      TF_REQUIRE(nets[b].w[l] && nets[b].b[l], TF_EINVAL, "tf_flow: null weight pointer (block %d layer %d)", b, l);
+    _Float16* hb = reinterpret_cast<_Float16*>(base);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 1 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 1, hb + 2 * (size_t)hL1);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL2);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL3);
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 4, hb + 2 * (size_t)hL4);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + hB2);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + hB3);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + hB4);
+  }
+  return TF_OK;
+}
+
 static int pack_nets(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
   for (int b = 0; b < 2; ++b) {
     float* base = netfrag + (size_t)b * kNetFloats;
@@ -301,13 +333,15 @@ static int pack_nets(const TfCouplingNet nets[2], float* netfrag, hipStream_t st
   return TF_OK;
 }
 
-extern "C" size_t tf_flow_workspace_floats(int64_t pn) { return (size_t)2 * kNetFloats + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0); }
+static constexpr int kWsNet = 2 * (hNetFloats > kNetFloats ? hNetFloats : kNetFloats);
+extern "C" size_t tf_flow_workspace_floats(int64_t pn) { return (size_t)kWsNet + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0); }
 
 template <bool SAMPLE>
 static int flow_launch(const TfCouplingNet nets[2], const float* cond, const float* latent, const float* jitter,
                        const float* x, const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, float* out_xy,
-                       float* out_lj, int32_t* bins, float* workspace, size_t workspace_floats, hipStream_t stream,
-                       const char* who) {
+                       float* out_lj, int32_t* bins, int32_t precision, float* workspace, size_t workspace_floats,
+                       hipStream_t stream, const char* who) {
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
   TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
   if (m == 0) return TF_OK;
   TF_REQUIRE(nets && cond && out_xy && out_lj && workspace, TF_EINVAL, "%s: null pointer", who);
@@ -322,37 +356,44 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
     TF_REQUIRE(rays_id || m == pn * (int64_t)sn, TF_ESHAPE, "%s: without rays_id m must equal pn*sn", who);
   }
   float* netfrag = workspace;
-  float* P = workspace + 2 * kNetFloats;
-  if (int rc = pack_nets(nets, netfrag, stream)) return rc;
+  float* P = workspace + kWsNet;
+  const bool h3 = precision == TF_PREC_F16X3;
+  if (int rc = h3 ? pack_nets_h3(nets, netfrag, stream) : pack_nets(nets, netfrag, stream)) return rc;
   flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
                                                                          nets[1].b[0], cond, pn, P);
-  const size_t lds = (size_t)2 * kNetFloats * sizeof(float);
+  const size_t lds = (size_t)kWsNet * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)flow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)flow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const long long tiles = (m + 31) / 32;
   const int waves_per_block = 8;
   long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles
-  flow_kernel<SAMPLE><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
-      netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
+  if (h3)
+    flow_kernel<SAMPLE, true><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+        netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
+  else
+    flow_kernel<SAMPLE, false><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+        netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
 
 extern "C" int tf_flow_sample_fwd(const TfCouplingNet nets[2], const float* cond, const float* latent, const float* jitter,
-                                  int64_t pn, int32_t sn, float* angles, float* logj, int32_t* bins, float* workspace,
-                                  size_t workspace_floats, tf_stream_t stream) {
+                                  int64_t pn, int32_t sn, float* angles, float* logj, int32_t* bins, int32_t precision,
+                                  float* workspace, size_t workspace_floats, tf_stream_t stream) {
   return flow_launch<true>(nets, cond, latent, jitter, nullptr, nullptr, pn * (int64_t)sn, sn, pn, angles, logj, bins,
-                           workspace, workspace_floats, (hipStream_t)stream, "tf_flow_sample_fwd");
+                           precision, workspace, workspace_floats, (hipStream_t)stream, "tf_flow_sample_fwd");
 }
 
 extern "C" int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id,
-                                int64_t m, int32_t sn, int64_t pn, float* z, float* logq, int32_t* bins, float* workspace,
-                                size_t workspace_floats, tf_stream_t stream) {
-  return flow_launch<false>(nets, cond, nullptr, nullptr, x, rays_id, m, sn, pn, z, logq, bins, workspace,
+                                int64_t m, int32_t sn, int64_t pn, float* z, float* logq, int32_t* bins, int32_t precision,
+                                float* workspace, size_t workspace_floats, tf_stream_t stream) {
+  return flow_launch<false>(nets, cond, nullptr, nullptr, x, rays_id, m, sn, pn, z, logq, bins, precision, workspace,
                             workspace_floats, (hipStream_t)stream, "tf_flow_logq_fwd");
 }

@@ -270,3 +270,27 @@ __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ 
     else tf_wait_vmcnt_barrier<0>();
   }
 }
+
+// Dense layer, f16x3, fragment weights resident in LDS ([s16][tout][hi|lo][lane][8 halves]).
+template <int K16, int TOUT, int TIN>
+__device__ __forceinline__ void tf_layer_h3(const tf_h8* __restrict__ wf /* + lane */, const f32x16 (&in)[TIN],
+                                            f32x16 (&out)[TOUT]) {
+#pragma unroll
+  for (int s16 = 0; s16 < K16; ++s16) {
+    tf_h8 b_hi, b_lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = in[s16 >> 1][8 * (s16 & 1) + e];
+      const _Float16 h = (_Float16)x;
+      b_hi[e] = h;
+      b_lo[e] = (_Float16)(x - (float)h);
+    }
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) {
+      const tf_h8 a_hi = wf[(s16 * TOUT + t) * 128], a_lo = wf[(s16 * TOUT + t) * 128 + 64];
+      out[t] = tf_mfma_h(a_hi, b_hi, out[t]);
+      out[t] = tf_mfma_h(a_hi, b_lo, out[t]);
+      out[t] = tf_mfma_h(a_lo, b_hi, out[t]);
+    }
+  }
+}

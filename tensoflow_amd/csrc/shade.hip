@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
     const float* __restrict__ logq_d, int sd, const float* __restrict__ fixed_d, const float* __restrict__ az_jitter, int nf,
     const float* __restrict__ ang_s, const float* __restrict__ logq_s, int ss, long long pn, float* __restrict__ dirs,
-    float* __restrict__ wgt, unsigned char* __restrict__ spec_mask) {
+    float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live) {
   const int T = sd + nf + ss;
   long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= pn * T) return;
@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) { dirs[3 * e + k] = dir[k]; wgt[3 * e + k] = w[k]; }
+  if (live) live[e] = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f) ? 1 : 0;
 }
 
 __device__ __forceinline__ float srgb(float x) {  // utils/raw_utils.py:4-11
@@ -188,7 +189,7 @@ extern "C" int tf_view_angles(const float* normals, const float* view, int64_t p
 extern "C" int tf_shade_dirs(const float* normals, const float* view, const float* metallic, const float* roughness,
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
-                             int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, tf_stream_t stream) {
+                             int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, tf_stream_t stream) {
   TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs: negative size");
   if (pn == 0 || sd + nf + ss == 0) return TF_OK;
   TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "tf_shade_dirs: null pointer");
@@ -197,7 +198,7 @@ extern "C" int tf_shade_dirs(const float* normals, const float* view, const floa
   long long work = (long long)pn * (sd + nf + ss);
   shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
                                                                           logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, ss,
-                                                                          pn, dirs, wgt, spec_mask);
+                                                                          pn, dirs, wgt, spec_mask, live);
   TF_LAUNCH_CHECK("tf_shade_dirs");
   return TF_OK;
 }

@@ -202,7 +202,7 @@ def _coupling_nets(weights):
     return nets, keep
 
 
-def flow_sample(weights, cond, latent, jitter=None, want_bins=False):
+def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1):
     """-> angles [pn,sn,2], logj [pn,sn,1] (, bins [pn,sn,2] int32)."""
     lib = L.load()
     cond, latent = _f(cond), _f(latent)
@@ -217,11 +217,11 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False):
     ws = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev)
     jit = None if jitter is None else _f(jitter.reshape(pn, sn))
     L.check(lib.tf_flow_sample_fwd(C.byref(nets), _p(cond), _p(latent), _p(jit), pn, sn, _p(ang), _p(lj), _p(bins, torch.int32),
-                                   _p(ws), ws.numel(), _stream()), "tf_flow_sample_fwd")
+                                   int(precision), _p(ws), ws.numel(), _stream()), "tf_flow_sample_fwd")
     return (ang, lj, bins) if want_bins else (ang, lj)
 
 
-def flow_logq(weights, cond, x, rays_id=None, want_bins=False):
+def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
     """x [pn,sn,2] (rays_id None) or [m,2] with rays_id [m] int64 -> z (same shape), logq [...,1]."""
     lib = L.load()
     cond, x = _f(cond), _f(x)
@@ -237,7 +237,7 @@ def flow_logq(weights, cond, x, rays_id=None, want_bins=False):
     ws = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev)
     rid = None if rays_id is None else rays_id.contiguous()
     L.check(lib.tf_flow_logq_fwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(z), _p(lq),
-                                 _p(bins, torch.int32), _p(ws), ws.numel(), _stream()), "tf_flow_logq_fwd")
+                                 _p(bins, torch.int32), int(precision), _p(ws), ws.numel(), _stream()), "tf_flow_logq_fwd")
     return (z, lq, bins) if want_bins else (z, lq)
 
 
@@ -279,7 +279,7 @@ class Bvh:
         self.nodes = torch.from_numpy(nodes[:n].copy()).to(device)
         self.tris = torch.from_numpy(tris).to(device)
 
-    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True):
+    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None):
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = o.shape[0]
         dev = o.device
@@ -287,8 +287,10 @@ class Bvh:
         nrm = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_nrm else None
         depth = torch.empty(m, dtype=torch.float32, device=dev)
         hit = torch.empty(m, dtype=torch.uint8, device=dev)
-        L.check(self.lib.tf_bvh_trace(_p(self.nodes), _p(self.tris), self.n_nodes, _p(o), _p(d), float(off0), float(off1), m,
-                                      _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8), _stream()), "tf_bvh_trace")
+        lv = None if live is None else live.reshape(-1).contiguous()
+        L.check(self.lib.tf_bvh_trace(_p(self.nodes), _p(self.tris), self.n_nodes, _p(o), _p(d), float(off0), float(off1),
+                                      _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8), _stream()),
+                "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()
 
 
@@ -334,13 +336,14 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     dirs = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
     wgt = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
     mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
+    live = torch.empty(pn, T, dtype=torch.uint8, device=dev)
     g = lambda t: None if t is None else _f(t)
     L.check(lib.tf_shade_dirs(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
                               _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
                               _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(g(ang_s)),
                               _p(g(None if logq_s is None else logq_s.reshape(pn, ss))), ss, pn, _p(dirs), _p(wgt),
-                              _p(mask, torch.uint8), _stream()), "tf_shade_dirs")
-    return dirs, wgt, mask.bool()
+                              _p(mask, torch.uint8), _p(live, torch.uint8), _stream()), "tf_shade_dirs")
+    return dirs, wgt, mask.bool(), live
 
 
 def shade_reduce(wgt, lights, n_diffuse, ss):

@@ -127,6 +127,7 @@ class MCShader:
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
+        self.cull_dead_rays = True      # skip BVH + inner light for rays whose weight is exactly 0 (result unchanged)
         self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
         self.unit = float(unit_size)
         self.exp_max = exp_max
@@ -159,11 +160,12 @@ class MCShader:
         rough = out["roughness"] * (1.0 - 0.04 ** 2) + 0.04 ** 2
         return out["metallic"], rough, out["albedo"]
 
-    def lights(self, pts_rep, dirs):
-        """get_lights (fields.py:951-975): pts_rep, dirs [M,3] -> lights [M,3], hit [M] bool."""
+    def lights(self, pts_rep, dirs, live=None):
+        """get_lights (fields.py:951-975): pts_rep, dirs [M,3] -> lights [M,3], hit [M] bool.
+        live [M] uint8 (optional): rays whose weight in the integral is exactly zero are neither traced nor shaded."""
         T = self.timer
         with T.stage("bvh_trace"):
-            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit)
+            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live)
         with T.stage("cube_lookup"):
             lights = ops.cube_lookup(self.env, dirs, apply_exp=True)
         with T.stage("hit_compaction"):
@@ -192,20 +194,20 @@ class MCShader:
             cond_d = self.flow_d.condition(pts, va, self.aabb)
             cond_s = self.flow_s.condition(pts, va, self.aabb)
         with tm.stage("flow_sample"):
-            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d)
-            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s)
+            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d, precision=self.precision)
+            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision)
         tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         with tm.stage("shade_dirs"):
-            dirs, wgt, smask = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
+            dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
         T = dirs.shape[1]
         with tm.stage("light_merge"):
             pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
-        lights, hit, inters = self.lights(pts_rep, dirs.reshape(-1, 3))
+        lights, hit, inters = self.lights(pts_rep, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
             colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
         rid = torch.arange(pn, device=self.device)[:, None].expand(pn, sn_specular)[smask]
         return dict(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
-                    specular_mask=smask, specular_rays_id=rid, hit=hit.reshape(pn, T), view_angles=va,
+                    specular_mask=smask, specular_rays_id=rid, hit=hit.reshape(pn, T), live=live, view_angles=va,
                     diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
                     lights=lights.reshape(pn, T, 3))

@@ -142,7 +142,8 @@ def _flow_weights(sd, pfx, dev):
             for b in range(2)]
 
 
-def test_flow_sample_and_logq_golden(golden, dev):
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f16x3"])
+def test_flow_sample_and_logq_golden(golden, dev, prec):
     from oracle import flow as oflow
     from tensoflow_amd import ops
     from tensoflow_amd.shading import sphere_latent
@@ -151,7 +152,7 @@ def test_flow_sample_and_logq_golden(golden, dev):
     Wt = _flow_weights(g.sd, "", dev)
     for sn in (8, 32, 128):
         assert rel_err(sphere_latent(sn).clamp(1e-6, 1 - 1e-6), g[f"latent_{sn}"]) < 1e-7
-        ang, logj, bins = ops.flow_sample(Wt, cond, sphere_latent(sn).to(dev), want_bins=True)
+        ang, logj, bins = ops.flow_sample(Wt, cond, sphere_latent(sn).to(dev), want_bins=True, precision=prec)
         # The reference's closed-form spline root (flow.py:479-493) loses digits when the quadratic
         # coefficient a = (v[e+1]-v[e])*w[e] is tiny: |d sol| ~ eps*b/|a|.  A ~1e-6 difference in the MLP
         # output (MKL vs MFMA summation order) can therefore move an isolated sample by > 1e-4 in the
@@ -162,14 +163,14 @@ def test_flow_sample_and_logq_golden(golden, dev):
         assert float(torch.quantile(el, 0.999)) < TOL and float(el.max()) < 2e-3
         _, _, b0, b1 = oflow.flow_sample(g.sd, g["pts"], g["view_angles"], g["roughness"], sn, AABB, return_bins=True)
         assert torch.equal(bins[..., 0].cpu().long(), b0) and torch.equal(bins[..., 1].cpu().long(), b1)   # bit-exact
-        z, logq, zb = ops.flow_logq(Wt, cond, g[f"angles_{sn}"].to(dev), want_bins=True)
+        z, logq, zb = ops.flow_logq(Wt, cond, g[f"angles_{sn}"].to(dev), want_bins=True, precision=prec)
         assert rel_err(z.cpu(), g[f"z_{sn}"]) < TOL
         assert rel_err(logq.cpu(), g[f"logq_{sn}"]) < TOL
         _, _, b0, b1 = oflow.flow_logq(g.sd, g["pts"], g["view_angles"], g["roughness"], g[f"angles_{sn}"], AABB, return_bins=True)
         assert torch.equal(zb[..., 0].cpu().long(), b0) and torch.equal(zb[..., 1].cpu().long(), b1)
-    z, logq = ops.flow_logq(Wt, cond, g["x_rand"].to(dev))
+    z, logq = ops.flow_logq(Wt, cond, g["x_rand"].to(dev), precision=prec)
     assert rel_err(z.cpu(), g["z_rand"]) < TOL and rel_err(logq.cpu(), g["logq_rand"]) < TOL
-    z, logq = ops.flow_logq(Wt, cond, g["x_rid"].to(dev), rays_id=g["rays_id"].to(dev))
+    z, logq = ops.flow_logq(Wt, cond, g["x_rid"].to(dev), rays_id=g["rays_id"].to(dev), precision=prec)
     assert rel_err(z.cpu(), g["z_rid"]) < TOL and rel_err(logq.cpu(), g["logq_rid"]) < TOL
 
 
@@ -272,4 +273,10 @@ def test_shade_golden(golden, dev, tag):
     assert torch.equal(out["specular_mask"].cpu(), ref["specular_mask"])
     assert torch.equal(out["specular_rays_id"].cpu(), ref["specular_rays_id"])
     nd = sn_d + n_fd
-    assert torch.equal(out["hit"][:, :nd].cpu(), ref["diffuse_hit"])
+    live = out["live"].bool().cpu()
+    assert torch.equal(out["hit"][:, :nd].cpu(), ref["diffuse_hit"] & live[:, :nd])     # dead rays are never traced
+    assert 0.5 < float(live.float().mean()) < 1.0
+    sh.cull_dead_rays = False                                                         # reference-faithful: trace everything
+    out2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
+    assert torch.equal(out2["hit"][:, :nd].cpu(), ref["diffuse_hit"])
+    assert torch.equal(out2["colors"], out["colors"])                                 # culling changes nothing, bit for bit
