@@ -153,6 +153,7 @@ def main():
         step()
     timer = StageTimer()
     sh.timer = timer
+    sh.hit_total = None
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -174,7 +175,7 @@ def main():
         summ = timer.summary()
         stages = {k: dict(ms_per_step=v[0] / args.steps, launches=v[1]) for k, v in summ.items()}
         dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
-        hits = timer.units.get("inner_light", 0)
+        hits = int(sh.hit_total.item()) if sh.hit_total is not None else 0
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
         if dom == "inner_light":
             n_launch = summ[dom][1]

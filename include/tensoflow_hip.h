@@ -158,8 +158,9 @@ int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float
  * Environment light: EnvLight.direct_light (network/light.py:125-162) = exp(bilinear cube lookup
  * of the log-radiance cubemap base [6,R,R,3]) with seam-crossing taps.
  * ------------------------------------------------------------------------------------------ */
+/* depth [m] or NULL: out is zeroed where !(depth > near_eps) (the near mask of get_lights, fields.py:973-974). */
 int tf_cube_lookup_fwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
-                       float* out, tf_stream_t stream);
+                       const float* depth, float near_eps, float* out, tf_stream_t stream);
 /* g_base += d out/d base (atomics; zero first); out = forward result (needed when apply_exp). */
 int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
                        const float* g_out, float* g_base, tf_stream_t stream);
@@ -206,6 +207,17 @@ size_t tf_inner_light_workspace_floats(void);
 int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm,
                        int64_t m, float exp_max, int32_t precision, float* out, float* workspace,
                        size_t workspace_floats, tf_stream_t stream);
+
+/* Device-side form used inside get_lights (fields.py:970-974): rows are the rays listed in idx[0 .. *count_dev)
+ * (built by tf_compact_mask from the hit flags; at most `capacity` rows), view = -dirs[i], and the result is
+ * scattered: lights[i] = light * (depth[i] > near_eps).  No host synchronisation between trace and shading. */
+int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, const float* dirs, const float* nrm,
+                               const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
+                               float near_eps, float exp_max, int32_t precision, float* lights, float* workspace,
+                               size_t workspace_floats, tf_stream_t stream);
+/* idx[0 .. *count) = indices i with mask[i] != 0 (unordered); *count is zeroed by the call (replaces the boolean-mask
+ * indexing of fields.py:962-971). */
+int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Monte-Carlo shading integral, MCShadingNetwork.shade_mixed (network/fields.py:1075-1235),

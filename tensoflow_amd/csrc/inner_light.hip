@@ -83,10 +83,19 @@ __device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, co
     for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
 }
 
+// Dense mode (idx == nullptr): row r reads pts/view/nrm[r] and writes out[r].
+// Indexed mode: row r stands for ray i = idx[r], r < *count_dev (device-side count: no host sync between the BVH
+// trace and this kernel); view = -view[i] (the ray direction is passed), out[i] = light * (depth[i] > near_eps).
 template <bool H3>
 __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts,
                                                           const float* __restrict__ view, const float* __restrict__ nrm,
-                                                          long long m, float exp_max, float* __restrict__ out) {
+                                                          long long m_arg, const long long* __restrict__ idx,
+                                                          const long long* __restrict__ count_dev,
+                                                          const float* __restrict__ depth, float near_eps, float exp_max,
+                                                          float* __restrict__ out) {
+  long long m = m_arg;
+  if (count_dev) m = min(m_arg, *count_dev);
+  if (m <= 0) return;
   __shared__ __attribute__((aligned(16))) float lds[3 * 4096];
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
@@ -99,9 +108,11 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     long long row = tile * 32 + (lane & 31);
     const bool valid = row < m;
     if (!valid) row = m - 1;
+    const long long src = idx ? idx[row] : row;
+    const float vsign = idx ? -1.f : 1.f;
     // ---- encodings (each lane computes all 123 and keeps the half its MFMA operand slots need)
     float enc[128];
-    const float p[3] = {pts[3 * row], pts[3 * row + 1], pts[3 * row + 2]};
+    const float p[3] = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
 #pragma unroll
     for (int k = 0; k < 3; ++k) enc[k] = p[k];
 #pragma unroll
@@ -112,8 +123,8 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
         enc[3 + 6 * f + k] = sinf(a);
         enc[3 + 6 * f + 3 + k] = cosf(a);
       }
-    float n[3] = {nrm[3 * row], nrm[3 * row + 1], nrm[3 * row + 2]};
-    float v[3] = {view[3 * row], view[3 * row + 1], view[3 * row + 2]};
+    float n[3] = {nrm[3 * src], nrm[3 * src + 1], nrm[3 * src + 2]};
+    float v[3] = {vsign * view[3 * src], vsign * view[3 * src + 1], vsign * view[3 * src + 2]};
     float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
     n[0] *= inv; n[1] *= inv; n[2] *= inv;
     inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
@@ -176,23 +187,24 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     if (H3) tf_layer_stream_h3<16, 1, 8, 8, 3>(reinterpret_cast<const _Float16*>(ws + kH4), lds, tid, lane, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
+      const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) out[3 * row + c] = expf(fminf(o[0][c], exp_max));
+      for (int c = 0; c < 3; ++c) out[3 * src + c] = expf(fminf(o[0][c], exp_max)) * near;
     }
   }
 }
 
-extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
-                                  float exp_max, int32_t precision, float* out, float* workspace, size_t workspace_floats,
-                                  tf_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  TF_REQUIRE(m >= 0, TF_ESHAPE, "tf_inner_light_fwd: m < 0");
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_inner_light_fwd: unknown precision %d", precision);
+static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
+                              const int64_t* idx, const int64_t* count_dev, const float* depth, float near_eps, float exp_max,
+                              int32_t precision, float* out, float* workspace, size_t workspace_floats, hipStream_t stream,
+                              const char* who) {
+  TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
-  TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "tf_inner_light_fwd: null pointer");
-  TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_fwd: workspace too small (%zu < %d floats)",
+  TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
+  TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kInnerWsFloats);
-  for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "tf_inner_light_fwd: null weight pointer (layer %d)", l);
+  for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "%s: null weight pointer (layer %d)", who, l);
   if (precision == TF_PREC_F32) {
     tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
     tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
@@ -213,11 +225,77 @@ extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const flo
   static bool ide_ready = false;
   if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
   hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
-  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_fwd: hipMemcpyAsync failed: %s", hipGetErrorString(e));
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   long long blocks = (m + 127) / 128;
   if (blocks > 1024) blocks = 1024;
-  if (precision == TF_PREC_F32) inner_light_kernel<false><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
-  else inner_light_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, exp_max, out);
-  TF_LAUNCH_CHECK("tf_inner_light_fwd");
+  if (precision == TF_PREC_F32)
+    inner_light_kernel<false><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
+                                                                   (const long long*)count_dev, depth, near_eps, exp_max, out);
+  else
+    inner_light_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
+                                                                  (const long long*)count_dev, depth, near_eps, exp_max, out);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+
+extern "C" int tf_inner_light_fwd(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
+                                  float exp_max, int32_t precision, float* out, float* workspace, size_t workspace_floats,
+                                  tf_stream_t stream) {
+  return inner_light_launch(net, pts, view, nrm, m, nullptr, nullptr, nullptr, 0.f, exp_max, precision, out, workspace,
+                            workspace_floats, (hipStream_t)stream, "tf_inner_light_fwd");
+}
+
+extern "C" int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, const float* dirs, const float* nrm,
+                                          const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
+                                          float near_eps, float exp_max, int32_t precision, float* lights, float* workspace,
+                                          size_t workspace_floats, tf_stream_t stream) {
+  TF_REQUIRE(capacity == 0 || (idx && count_dev), TF_EINVAL, "tf_inner_light_indexed_fwd: idx / count_dev is null");
+  return inner_light_launch(net, pos, dirs, nrm, capacity, idx, count_dev, depth, near_eps, exp_max, precision, lights, workspace,
+                            workspace_floats, (hipStream_t)stream, "tf_inner_light_indexed_fwd");
+}
+
+// ---------------------------------------------------------------- stream compaction of a byte mask (hit rays)
+#define COMPACT_ITEMS 8192   // elements per workgroup: one global atomic per 8192 rays instead of one per wave
+__global__ void __launch_bounds__(256) compact_mask_kernel(const unsigned char* __restrict__ mask, long long m,
+                                                           long long* __restrict__ idx, unsigned long long* __restrict__ count) {
+  __shared__ unsigned int s_cnt, s_off;
+  __shared__ unsigned long long s_base;
+  const int lane = threadIdx.x & 63;
+  const long long first = (long long)blockIdx.x * COMPACT_ITEMS;
+  if (threadIdx.x == 0) { s_cnt = 0; s_off = 0; }
+  __syncthreads();
+  unsigned int mine = 0;
+  for (int k = 0; k < COMPACT_ITEMS / 256; ++k) {
+    const long long i = first + k * 256 + threadIdx.x;
+    mine += (i < m && mask[i] != 0) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(count, (unsigned long long)s_cnt) : 0ULL;
+  __syncthreads();
+  const unsigned long long base = s_base;
+  for (int k = 0; k < COMPACT_ITEMS / 256; ++k) {
+    const long long i = first + k * 256 + threadIdx.x;
+    const bool on = i < m && mask[i] != 0;
+    const unsigned long long b = __ballot(on);
+    unsigned int wbase = 0;
+    if (lane == 0 && b) wbase = atomicAdd(&s_off, (unsigned int)__popcll(b));
+    wbase = __shfl(wbase, 0);
+    if (on) idx[base + wbase + __popcll(b & ((1ULL << lane) - 1ULL))] = i;
+  }
+}
+
+extern "C" int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(m >= 0, TF_ESHAPE, "tf_compact_mask: m < 0");
+  TF_REQUIRE(count, TF_EINVAL, "tf_compact_mask: count is null");
+  hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t), stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_compact_mask: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(mask && idx, TF_EINVAL, "tf_compact_mask: null pointer");
+  compact_mask_kernel<<<tf_blocks(m, COMPACT_ITEMS), 256, 0, stream>>>(mask, m, (long long*)idx, (unsigned long long*)count);
+  TF_LAUNCH_CHECK("tf_compact_mask");
   return TF_OK;
 }

@@ -80,6 +80,7 @@ __device__ __forceinline__ void cube_taps(float dx, float dy, float dz, int R, C
 
 __global__ void __launch_bounds__(256) cube_lookup_fwd_kernel(const float* __restrict__ base, int R,
                                                               const float* __restrict__ dirs, long long m, int apply_exp,
+                                                              const float* __restrict__ depth, float near_eps,
                                                               float* __restrict__ out) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(256) cube_lookup_fwd_kernel(const float* __res
     r += T.w[t] * p[0]; g += T.w[t] * p[1]; b += T.w[t] * p[2];
   }
   if (apply_exp) { r = expf(r); g = expf(g); b = expf(b); }
+  if (depth && !(depth[i] > near_eps)) { r = 0.f; g = 0.f; b = 0.f; }   // fields.py:973-974 near mask
   out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
 }
 
@@ -121,11 +123,11 @@ __global__ void __launch_bounds__(256) cube_lookup_bwd_kernel(const float* __res
 }
 
 extern "C" int tf_cube_lookup_fwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
-                                  float* out, tf_stream_t stream) {
+                                  const float* depth, float near_eps, float* out, tf_stream_t stream) {
   TF_REQUIRE(m >= 0 && res > 0, TF_ESHAPE, "tf_cube_lookup_fwd: m < 0 or res <= 0");
   if (m == 0) return TF_OK;
   TF_REQUIRE(base && dirs && out, TF_EINVAL, "tf_cube_lookup_fwd: null pointer");
-  cube_lookup_fwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, out);
+  cube_lookup_fwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, depth, near_eps, out);
   TF_LAUNCH_CHECK("tf_cube_lookup_fwd");
   return TF_OK;
 }

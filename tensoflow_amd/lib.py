@@ -55,12 +55,14 @@ SIGNATURES = {
     "tf_flow_workspace_floats": (sz, [i64]),
     "tf_flow_sample_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, c_f, c_f, c_f, i32, c_f, sz, c_f]),
     "tf_flow_logq_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, c_f, c_f, i32, c_f, sz, c_f]),
-    "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f]),
+    "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
     "tf_bvh_build_host": (i64, [C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p]),
     "tf_bvh_trace": (C.c_int, [c_f, c_f, i64, c_f, c_f, f32, f32, c_f, i64, c_f, c_f, c_f, c_f, c_f]),
     "tf_inner_light_workspace_floats": (sz, []),
     "tf_inner_light_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, i64, f32, i32, c_f, c_f, sz, c_f]),
+    "tf_inner_light_indexed_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, c_f, c_f, i64, c_f, f32, f32, i32, c_f, c_f, sz, c_f]),
+    "tf_compact_mask": (C.c_int, [c_f, i64, c_f, c_f, c_f]),
     "tf_view_angles": (C.c_int, [c_f, c_f, i64, c_f, c_f]),
     "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_reduce": (C.c_int, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),

@@ -242,14 +242,50 @@ def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
 
 
 # ------------------------------------------------------------------------------ light / mesh / shading
-def cube_lookup(base, dirs, apply_exp=True):
+def cube_lookup(base, dirs, apply_exp=True, depth=None, near_eps=0.0):
     lib = L.load()
     base, dirs = _f(base), _f(dirs.reshape(-1, 3))
     assert base.dim() == 4 and base.shape[0] == 6 and base.shape[1] == base.shape[2] and base.shape[3] == 3
     out = torch.empty_like(dirs)
-    L.check(lib.tf_cube_lookup_fwd(_p(base), base.shape[1], _p(dirs), dirs.shape[0], int(apply_exp), _p(out), _stream()),
+    L.check(lib.tf_cube_lookup_fwd(_p(base), base.shape[1], _p(dirs), dirs.shape[0], int(apply_exp),
+                                   _p(None if depth is None else _f(depth.reshape(-1))), float(near_eps), _p(out), _stream()),
             "tf_cube_lookup_fwd")
     return out
+
+
+def compact_mask(mask_u8):
+    """-> idx [m] int64 (first *count entries valid, unordered), count [1] int64 -- both on the device, no sync."""
+    lib = L.load()
+    m = mask_u8.numel()
+    idx = torch.empty(m, dtype=torch.int64, device=mask_u8.device)
+    count = torch.empty(1, dtype=torch.int64, device=mask_u8.device)
+    L.check(lib.tf_compact_mask(_p(mask_u8.reshape(-1).contiguous(), torch.uint8), m, _p(idx, torch.int64), _p(count, torch.int64),
+                                _stream()), "tf_compact_mask")
+    return idx, count
+
+
+def _mlp4(weights):
+    net = L.TfMlp4()
+    keep = []
+    expect = [(256, 123), (256, 256), (256, 256), (3, 256)]
+    for l in range(4):
+        W, b = _f(weights[l][0]), _f(weights[l][1])
+        if tuple(W.shape) != expect[l]:
+            raise RuntimeError(f"inner light layer {l}: weight shape {tuple(W.shape)} != {expect[l]}")
+        keep += [W, b]
+        net.w[l], net.b[l] = W.data_ptr(), b.data_ptr()
+    return net, keep
+
+
+def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=5.0, precision=1):
+    """In place: lights[i] = inner_light(pos[i], -dirs[i], nrm[i]) * (depth[i] > near_eps) for i in idx[:count]."""
+    lib = L.load()
+    net, keep = _mlp4(weights)
+    ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pos.device)
+    L.check(lib.tf_inner_light_indexed_fwd(C.byref(net), _p(pos), _p(dirs), _p(nrm), _p(idx, torch.int64), _p(count, torch.int64),
+                                           idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision), _p(lights),
+                                           _p(ws), ws.numel(), _stream()), "tf_inner_light_indexed_fwd")
+    return lights
 
 
 def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):

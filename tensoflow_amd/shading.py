@@ -146,6 +146,7 @@ class MCShader:
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
         self._latent = {}
         self.timer = _NoTimer()
+        self.hit_total = None
 
     def latent(self, sn):
         if sn not in self._latent:
@@ -167,18 +168,14 @@ class MCShader:
         with T.stage("bvh_trace"):
             inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live)
         with T.stage("cube_lookup"):
-            lights = ops.cube_lookup(self.env, dirs, apply_exp=True)
+            # miss branch + near mask of get_lights in one pass (every ray; hit rays are overwritten below)
+            lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)
         with T.stage("hit_compaction"):
-            idx = torch.nonzero(hit, as_tuple=False)[:, 0]
-            hp, hv, hn = inters[idx], -dirs[idx], nrm[idx]
-        if idx.numel() > 0:
-            with T.stage("inner_light"):
-                inner = ops.inner_light(self.inner, hp, hv, hn, self.exp_max, precision=self.precision)
-            T.add_units("inner_light", idx.numel())
-            with T.stage("light_merge"):
-                lights.index_copy_(0, idx, inner)
-        with T.stage("light_merge"):
-            lights = lights * (depth > 1e-5).float()[:, None]
+            idx, count = ops.compact_mask(hit.view(torch.uint8))
+        with T.stage("inner_light"):
+            ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5,
+                                    exp_max=self.exp_max, precision=self.precision)
+        self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return lights, hit, inters
 
     @torch.no_grad()
