@@ -125,7 +125,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product kernels)")
     torch.cuda.set_device(local_rank)
@@ -133,7 +133,11 @@ def main():
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("TENSOFLOW_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for 1-GPU dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from tensoflow_amd.shading import StageTimer
     from tensoflow_amd.synth import sphere_surface_points
@@ -165,7 +169,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([dt], device=device)
+        tt = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     sh.timer = type(sh.timer)() if False else sh.timer
