@@ -188,10 +188,12 @@ int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const int32_t* fa
  * `p + 1e-5 d` (fields.py:955) followed by `o + 2*unit_size*d` (materialRenderer.py:223); pass 0,0 for
  * a plain trace. */
 /* live [m] uint8 or NULL: rays with live == 0 are not traversed and reported as misses (rays whose weight in the
- * integral is exactly zero -- below-horizon samples, fields.py:1156,1209 -- per-wavefront live-sample culling). */
+ * integral is exactly zero -- below-horizon samples, fields.py:1156,1209 -- per-wavefront live-sample culling).
+ * work_counter: 8 bytes of device scratch (zeroed by the call) that switches on the persistent kernel with dynamic
+ * ray fetch (lanes pull new rays as their wave-mates finish); NULL = one statically assigned ray per lane. */
 int tf_bvh_trace(const TfBvhNode* nodes, const float* tris, int64_t n_nodes, const float* o, const float* d,
                  float origin_offset0, float origin_offset1, const uint8_t* live, int64_t m, float* pos,
-                 float* nrm, float* depth, uint8_t* hit, tf_stream_t stream);
+                 float* nrm, float* depth, uint8_t* hit, int64_t* work_counter, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic small MLP on rows (weight-norm already folded by the caller): used for the inner-light

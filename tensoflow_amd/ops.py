@@ -315,7 +315,7 @@ class Bvh:
         self.nodes = torch.from_numpy(nodes[:n].copy()).to(device)
         self.tris = torch.from_numpy(tris).to(device)
 
-    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None):
+    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True):
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = o.shape[0]
         dev = o.device
@@ -324,9 +324,10 @@ class Bvh:
         depth = torch.empty(m, dtype=torch.float32, device=dev)
         hit = torch.empty(m, dtype=torch.uint8, device=dev)
         lv = None if live is None else live.reshape(-1).contiguous()
+        ctr = torch.empty(1, dtype=torch.int64, device=dev) if dynamic else None
         L.check(self.lib.tf_bvh_trace(_p(self.nodes), _p(self.tris), self.n_nodes, _p(o), _p(d), float(off0), float(off1),
-                                      _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8), _stream()),
-                "tf_bvh_trace")
+                                      _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
+                                      _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()
 
 

@@ -224,7 +224,10 @@ def test_bvh_trace_matches_brute_force(golden, dev):
     gen = torch.Generator().manual_seed(9)
     o = torch.randn(6000, 3, generator=gen) * 0.6
     d = torch.nn.functional.normalize(torch.randn(6000, 3, generator=gen), dim=-1)
-    pos, nrm, depth, hit = bvh.trace(o.to(dev), d.to(dev))
+    pos, nrm, depth, hit = bvh.trace(o.to(dev), d.to(dev), dynamic=True)
+    pos2, nrm2, depth2, hit2 = bvh.trace(o.to(dev), d.to(dev), dynamic=False)
+    # same algorithm, different instruction selection (FMA contraction): flags identical, values to the last bits
+    assert torch.equal(hit, hit2) and rel_err(depth, depth2) < 1e-6 and rel_err(pos, pos2) < 1e-6
     rpos, rnrm, rdepth, rhit = tr(o, d)
     assert torch.equal(hit.cpu(), rhit)                     # boolean, bit-exact
     assert 0.2 < rhit.float().mean() < 0.98

@@ -61,5 +61,7 @@ elif which == "bvh":
     T = 768
     d = torch.nn.functional.normalize(torch.randn(pn, T, 3, device=dev) + nrm[:, None], dim=-1).reshape(-1, 3)
     o = pts[:, None].expand(pn, T, 3).reshape(-1, 3).contiguous()
-    ms = timeit(lambda: bvh.trace(o, d, 1e-5, 2 * 2 / 511))
-    print(f"bvh_trace {o.shape[0]} rays, {len(faces)} tris: {ms:.2f} ms  {o.shape[0]/ms*1e-6:.2f} Grays/s")
+    d = torch.where(((d.view(pn, T, 3) * nrm[:, None]).sum(-1, keepdim=True) < 0), -d.view(pn, T, 3), d.view(pn, T, 3)).reshape(-1, 3).contiguous()
+    for dyn in (False, True):
+        ms = timeit(lambda: bvh.trace(o, d, 1e-5, 2 * 2 / 511, dynamic=dyn))
+        print(f"bvh_trace dynamic={dyn} {o.shape[0]} rays, {len(faces)} tris: {ms:.2f} ms  {o.shape[0]/ms*1e-6:.2f} Grays/s")
