@@ -139,3 +139,37 @@ def test_module_mcshading(golden, dev):
     assert env.shape == (1, 1, g["env_dirs"].shape[0], 3) and rel_err(env[0, 0].detach().cpu(), g["env_direct"]) < TOL
     env.sum().backward()                                          # cube lookup has a HIP backward
     assert m.outer_light.base.grad is not None and float(m.outer_light.base.grad.abs().sum()) > 0
+
+
+def test_trace_sdf_with_mesh(golden, dev):
+    from tensoflow_amd import ops, surface
+    from tensoflow_amd.march import SdfField
+    g = golden("refine_r32")
+    f = SdfField(g.sd, AABB, [32, 32, 32], 3, device=dev)
+    bvh = ops.Bvh(g["verts"].numpy(), g["faces"].numpy(), dev)
+    inters, normals, depth, hit = surface.trace_sdf_with_mesh(bvh, f, g["rays_o"].to(dev), g["rays_d"].to(dev), float(g["inv_s"]),
+                                                             float(g["unit_size"]))
+    assert torch.equal(hit.cpu(), g["hit"].bool())
+    assert rel_err(depth.cpu(), g["depth"]) < TOL and rel_err(inters.cpu(), g["inters"]) < TOL
+    assert rel_err(normals.cpu(), g["normals"]) < 5e-4      # FD normal of a normalised difference of ~1e-3-sized sdf values
+
+
+def test_render_frame_small(golden, dev):
+    """Full-frame pipeline (BVH -> SDF refinement -> flow-sampled shading) on a 48x48 crop: finite, white background,
+    and identical to shading the refined surface points directly."""
+    from tensoflow_amd import surface
+    from tensoflow_amd.march import SdfField
+    from tensoflow_amd.shading import MCShader
+    from tensoflow_amd.synth import pinhole_rays
+    gs, gr = golden("shading_small"), golden("refine_r32")
+    f = SdfField(gr.sd, AABB, [32, 32, 32], 3, device=dev)
+    sh = MCShader(gs.sd, gr["verts"].numpy(), gr["faces"].numpy(), AABB, float(gr["unit_size"]), device=dev, n_fixed_diffuse=32)
+    o, d, _, _ = [torch.from_numpy(a).to(dev) for a in pinhole_rays(48 * 48, seed=5, focal=2400.0)]
+    out = surface.render_frame(sh, f, o, d, float(gr["inv_s"]), float(gr["unit_size"]), 16, 8, chunk=1000)
+    assert torch.isfinite(out["color"]).all()
+    assert 0.05 < float(out["hit"].float().mean()) < 0.95
+    assert torch.equal(out["color"][~out["hit"]], torch.ones_like(out["color"][~out["hit"]]))
+    inters, nrm, depth, hit = surface.trace_sdf_with_mesh(sh.bvh, f, o, d, float(gr["inv_s"]), float(gr["unit_size"]))
+    idx = torch.nonzero(hit[:, 0])[:, 0]
+    direct = sh.shade(inters[idx], -d[idx], nrm[idx], 16, 8)["colors"]
+    assert rel_err(out["color"][idx].cpu(), direct.cpu()) < 1e-6

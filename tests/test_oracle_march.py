@@ -51,3 +51,15 @@ def test_render_core(golden):
     for k in ("ray_rgb", "acc", "normal", "gradient_error", "std", "loss_sparse"):
         assert rel_err(out[k], g["rc/" + k]) < 2e-5, k
     assert rel_err(out["loss_hessian"], g["rc/loss_hessian"]) < 1e-4
+
+
+def test_refine_hits(golden):
+    """SDF refinement of mesh hits vs MaterialRenderer.trace_sdf_with_mesh run on the imported reference."""
+    from oracle import refine, shading as osh
+    g = golden("refine_r32")
+    tr = osh.MeshTracer(g["verts"][g["faces"].long()])
+    inters, normals, depth, hit = refine.refine_hits(g.sd, tr, g["rays_o"], g["rays_d"], AABB, GS, 3, float(g["inv_s"]),
+                                                     float(g["unit_size"]))
+    assert torch.equal(hit, g["hit"].bool()) and 0.05 < hit.float().mean() < 0.95
+    assert rel_err(depth, g["depth"]) < 1e-5 and rel_err(inters, g["inters"]) < 1e-5
+    assert rel_err(normals, g["normals"]) < 1e-4

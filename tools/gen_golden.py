@@ -278,9 +278,37 @@ def gen_march():
          env_spec2=spec[2], step_size=r.stepSize, base_radii=r.base_radii, **arr, **grads)
 
 
+def gen_refine():
+    """MaterialRenderer.trace_sdf_with_mesh (materialRenderer.py:316-343) on a sphere mesh + a TensoSDF of the same sphere."""
+    from network.fields import TensoSDF
+    from network.materialRenderer import MaterialRenderer
+    from network.other_field import SingleVarianceNetwork
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import pinhole_rays, uv_sphere
+    R = 32
+    torch.manual_seed(6033)
+    gs = torch.tensor([R, R, R])
+    net = TensoSDF(gs, AABB, device="cpu", sdf_n_comp=36, sdf_dim=256, app_dim=128, init_n_levels=3, sdf_multires=0)
+    perturb_(list(net.sdf_plane) + list(net.sdf_line), 0.01, 1)
+    net.eval()
+    dev_net = SingleVarianceNetwork(init_val=0.3, activation="exp")
+    verts, faces = uv_sphere(0.2, 12, 24)                    # the circle-initialised SDF has its zero set near r = 0.2
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True, radius=torch.tensor(1.0),
+                                 unit_size=torch.tensor(2.0 / (R - 1)), sdf_network=net, deviation_net=dev_net,
+                                 sdf_inter_fun=lambda x: net.sdf(x, None))
+    for name in ("trace", "near_far_from_sphere", "get_intersection_around_mesh"):
+        setattr(host, name, types.MethodType(getattr(MaterialRenderer, name), host))
+    o, d, _, _ = [torch.from_numpy(a) for a in pinhole_rays(512, seed=3, focal=2400.0)]
+    with torch.no_grad():
+        inters, normals, depth, hit = MaterialRenderer.trace_sdf_with_mesh(host, o, d, 32, 9)
+    save("refine_r32", sd={"sdf_network." + k: v for k, v in net.state_dict().items() if "gaussian" not in k},
+         rays_o=o, rays_d=d, verts=verts, faces=faces, inters=inters, normals=normals, depth=depth, hit=hit,
+         inv_s=dev_net(torch.zeros(1, 3))[0, 0], unit_size=np.float32(2.0 / (R - 1)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march"]
+    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine"]
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
