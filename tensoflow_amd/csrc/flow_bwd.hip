@@ -1,0 +1,481 @@
+// Backward of tf_flow_logq_fwd: gradient of sum_r g_logq[r] * logq[r] with respect to the 16 tensors of the two coupling
+// nets and to the per-point condition vectors.  This is the training direction of TensoFlow (the NIS loss,
+// network/fields.py:1257-1333 -> TensoFlow.forward, network/flow.py:801-831); the reference gets it from autograd through
+// ~200 tiny kernels.  One launch here, per 32-row tile and wave:
+//   1. forward recompute (fp32 MFMA, weights in LDS) keeping the three hidden activations of each net in registers;
+//   2. closed-form reverse pass through the two piecewise-quadratic splines and the prior term;
+//   3. delta propagation W^T * delta on the MFMA (transposed fragments streamed from L2);
+//   4. weight gradients delta * h^T on the MFMA: both tiles are transposed through a per-wave LDS scratch so that the
+//      32 rows of the tile become the MFMA k dimension; the resulting 32x32 blocks are added to global memory with
+//      float atomics shaped as two 128-byte segments per wave instruction;
+//   5. bias / per-point (hoisted layer-1) gradients reduced over the tile's rows in LDS, one atomic per unit.
+#include "mfma_mlp.h"
+#include "tf_common.h"
+
+#define FLOW_NB 10
+static constexpr float kEps32 = 1.1920928955078125e-07f;
+static constexpr float kHalfPi = 1.5707963267948966f;
+
+// forward fragment image per net (same as flow.hip, fp32): L1s [2][4][64] | L2 [2][32][64] | L3 | L4 [1][32][64] | b2 | b3 | b4
+static constexpr int kL1 = 0, kL2 = kL1 + 2 * 4 * 64, kL3 = kL2 + 2 * 32 * 64, kL4 = kL3 + 2 * 32 * 64, kB2 = kL4 + 32 * 64,
+                     kB3 = kB2 + 64, kB4 = kB3 + 64, kNetFloats = kB4 + 32;
+// transposed fragments per net (global): T4 = W4^T [64 x 21->32], T3, T2 = W^T [64 x 64], T1 = W1s^T [8->32 x 64]
+static constexpr int kT4 = 0, kT3 = kT4 + 2 * 16 * 64, kT2 = kT3 + 2 * 32 * 64, kT1 = kT2 + 2 * 32 * 64, kTNet = kT1 + 1 * 32 * 64;
+static constexpr int kBwdWs = 2 * kNetFloats + 2 * kTNet;   // + P [2][pn][64]
+static constexpr int kTileLds = 64 * 33;                     // one transposed [64 units][32 rows (+1 pad)] tile
+
+extern "C" size_t tf_flow_bwd_workspace_floats(int64_t pn) { return (size_t)kBwdWs + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0); }
+
+struct FlowGrads {
+  float* w[2][4];
+  float* b[2][4];
+  float* gP;   // [2][pn][64]
+};
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
+__device__ __forceinline__ float dleaky(float h) { return h > 0.f ? 1.f : 0.01f; }   // sign(h) == sign(pre-activation)
+
+#pragma clang fp contract(off)
+struct PwT {
+  float e[FLOW_NB], w[FLOW_NB], wn[FLOW_NB], wss[FLOW_NB + 1], C[FLOW_NB + 1], S;
+  float ev[FLOW_NB + 1], vn[FLOW_NB + 1], v[FLOW_NB + 1], vw[FLOW_NB + 1], den;
+};
+
+__device__ __forceinline__ void pw_tables_fwd(const float (&wv)[32], PwT& T) {
+  float run = 0.f;
+  T.C[0] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    T.e[i] = fmaxf(expf(wv[11 + i]), 1e-6f);
+    run += T.e[i];
+    T.C[i + 1] = run;
+  }
+  T.S = run;
+  T.wss[0] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    T.wn[i] = T.e[i] / T.S;
+    T.w[i] = fmaxf(T.wn[i], 1e-6f);
+    T.wss[i + 1] = T.C[i + 1] / T.S;
+  }
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) T.ev[i] = expf(wv[i]);
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) den += (T.ev[i] + T.ev[i + 1]) / 2.f * T.w[i];
+  T.den = den;
+  T.vw[0] = 0.f;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) { T.vn[i] = T.ev[i] / den; T.v[i] = fmaxf(T.vn[i], 1e-6f); }
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) { acc += (T.v[i] + T.v[i + 1]) / 2.f * T.w[i]; T.vw[i + 1] = acc; }
+}
+
+#define PICK(arr, n, idx, dst) { dst = arr[0]; _Pragma("unroll") for (int q_ = 1; q_ < (n); ++q_) dst = (idx == q_) ? arr[q_] : dst; }
+
+// forward spline (density direction) + its reverse pass: returns out, logj; given upstream (g_out, g_logj) adds d/d wv.
+__device__ __forceinline__ void pw_forward_fb(float xin, const float (&wv)[32], float& out, float& logj) {
+  PwT T;
+  pw_tables_fwd(wv, T);
+  int cnt = 0;
+  {
+    float best = kEps32;
+#pragma unroll
+    for (int i = 1; i <= FLOW_NB; ++i) { float val = (T.wss[i] > xin) ? 0.f : T.wss[i]; if (val > best) { best = val; cnt = i; } }
+  }
+  const int m = min(max(cnt, 0), FLOW_NB - 1), m1 = m + 1;
+  float vm, vm1, wm, vwm, wssm;
+  PICK(T.v, FLOW_NB + 1, m, vm) PICK(T.v, FLOW_NB + 1, m1, vm1) PICK(T.w, FLOW_NB, m, wm) PICK(T.vw, FLOW_NB + 1, m, vwm)
+  PICK(T.wss, FLOW_NB + 1, m, wssm)
+  const float al = fminf(fmaxf((xin - wssm) / wm, 0.f), 1.f);
+  const float o = (al * al) / 2.f * ((vm1 - vm) * wm) + al * vm * wm + vwm;
+  out = fminf(fmaxf(o, kEps32), 1.f - kEps32);
+  const float lerp = al < 0.5f ? vm + al * (vm1 - vm) : vm1 - (vm1 - vm) * (1.f - al);
+  logj = logf(lerp);
+}
+
+__device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32], float g_out, float g_logj, float (&g_wv)[32]) {
+  PwT T;
+  pw_tables_fwd(wv, T);
+  int cnt = 0;
+  {
+    float best = kEps32;
+#pragma unroll
+    for (int i = 1; i <= FLOW_NB; ++i) { float val = (T.wss[i] > xin) ? 0.f : T.wss[i]; if (val > best) { best = val; cnt = i; } }
+  }
+  const int m = min(max(cnt, 0), FLOW_NB - 1), m1 = m + 1;
+  float vm, vm1, wm, vwm, wssm;
+  PICK(T.v, FLOW_NB + 1, m, vm) PICK(T.v, FLOW_NB + 1, m1, vm1) PICK(T.w, FLOW_NB, m, wm) PICK(T.vw, FLOW_NB + 1, m, vwm)
+  PICK(T.wss, FLOW_NB + 1, m, wssm)
+  const float araw = (xin - wssm) / wm;
+  const float al = fminf(fmaxf(araw, 0.f), 1.f);
+  const float dv = vm1 - vm;
+  const float o = (al * al) / 2.f * (dv * wm) + al * vm * wm + vwm;
+  const float go = (o >= kEps32 && o <= 1.f - kEps32) ? g_out : 0.f;   // clamp(eps, 1-eps) passes gradient inside only
+  const float lerp = vm + al * dv;
+  const float g_lerp = g_logj / lerp;
+  float g_vm = g_lerp * (1.f - al) + go * al * wm - go * (al * al) / 2.f * wm;
+  float g_vm1 = g_lerp * al + go * (al * al) / 2.f * wm;
+  float g_al = g_lerp * dv + go * (al * dv * wm + vm * wm);
+  float g_wm = go * ((al * al) / 2.f * dv + al * vm);
+  const float g_vwm = go;
+  if (!(araw >= 0.f && araw <= 1.f)) g_al = 0.f;
+  const float g_wssm = -g_al / wm;
+  g_wm += -g_al * araw / wm;
+  // scatter the picked gradients back into per-index arrays
+  float g_v[FLOW_NB + 1], g_w[FLOW_NB];
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) g_v[i] = (i == m ? g_vm : 0.f) + (i == m1 ? g_vm1 : 0.f);
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) g_w[i] = (i == m ? g_wm : 0.f);
+  // vw[m] = sum_{i<m} (v_i + v_{i+1})/2 * w_i
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    const float on = i < m ? g_vwm : 0.f;
+    g_v[i] += on * T.w[i] / 2.f;
+    g_v[i + 1] += on * T.w[i] / 2.f;
+    g_w[i] += on * (T.v[i] + T.v[i + 1]) / 2.f;
+  }
+  // v = max(ev/den, 1e-6)
+  float g_ev[FLOW_NB + 1];
+  float g_den = 0.f;
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) {
+    const float g_vn = T.vn[i] > 1e-6f ? g_v[i] : 0.f;
+    g_ev[i] = g_vn / T.den;
+    g_den -= g_vn * T.vn[i] / T.den;
+  }
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    g_ev[i] += g_den * T.w[i] / 2.f;
+    g_ev[i + 1] += g_den * T.w[i] / 2.f;
+    g_w[i] += g_den * (T.ev[i] + T.ev[i + 1]) / 2.f;
+  }
+#pragma unroll
+  for (int i = 0; i <= FLOW_NB; ++i) g_wv[i] += g_ev[i] * T.ev[i];
+  // w = max(e/S, 1e-6); wss[k] = C[k]/S
+  float g_e[FLOW_NB];
+  float g_S = 0.f;
+  float Cm;
+  PICK(T.C, FLOW_NB + 1, m, Cm)
+  const float g_Cm = g_wssm / T.S;
+  g_S -= g_wssm * Cm / (T.S * T.S);
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    const float g_wn = T.wn[i] > 1e-6f ? g_w[i] : 0.f;
+    g_e[i] = g_wn / T.S + (i < m ? g_Cm : 0.f);
+    g_S -= g_wn * T.e[i] / (T.S * T.S);
+  }
+#pragma unroll
+  for (int i = 0; i < FLOW_NB; ++i) {
+    const float ge = g_e[i] + g_S;
+    g_wv[11 + i] += (T.e[i] > 1e-6f) ? ge * T.e[i] : 0.f;
+  }
+}
+#pragma clang fp contract(fast)
+
+// forward net keeping the hidden activations; P-row + sample embed -> wv[32]
+__device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, const float* __restrict__ Prow, const float (&in8)[8],
+                                             int lane, f32x16 (&in1)[1], f32x16 (&h1)[2], f32x16 (&h2)[2], f32x16 (&h3)[2],
+                                             float (&wv)[32]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) in1[0][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) in1[0][j] = h ? in8[4 + j] : in8[j];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h1[t][j] = Prow[32 * t + tf_rho(j, h)];
+  tf_layer<4, 2, 1>(net + kL1 + lane, in1, h1);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { h1[t][j] = leaky(h1[t][j]); h2[t][j] = net[kB2 + (t * 16 + j) * 2 + h]; }
+  tf_layer<32, 2, 2>(net + kL2 + lane, h1, h2);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { h2[t][j] = leaky(h2[t][j]); h3[t][j] = net[kB3 + (t * 16 + j) * 2 + h]; }
+  tf_layer<32, 2, 2>(net + kL3 + lane, h2, h3);
+  f32x16 o[1];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h3[t][j] = leaky(h3[t][j]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) o[0][j] = net[kB4 + j * 2 + h];
+  tf_layer<32, 1, 2>(net + kL4 + lane, h3, o);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float mine = o[0][j], other = __shfl_xor(mine, 32);
+    const int r0 = (j & 3) + 8 * (j >> 2);
+    wv[r0] = h ? other : mine;
+    wv[r0 + 4] = h ? mine : other;
+  }
+}
+
+// tile (accumulator layout, TT unit tiles) -> LDS [unit][row] with a 33-float row stride
+template <int TT>
+__device__ __forceinline__ void tile_to_lds(const f32x16 (&x)[TT], float* __restrict__ l, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < TT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) l[(32 * t + tf_rho(j, h)) * 33 + r] = x[t][j];
+}
+
+// g_W[out, col0 + in] += delta * hin^T over the 32 rows of the tile; tiles come from the LDS transposes.
+template <int TO, int TI>
+__device__ __forceinline__ void accum_dw(const float* __restrict__ ld_, const float* __restrict__ lh_, float* __restrict__ gW, int ld,
+                                         int nout, int nin, int lane) {
+  const int i = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int to = 0; to < TO; ++to)
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      f32x16 acc;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        acc = tf_mfma(ld_[(32 * to + i) * 33 + 2 * s + kh], lh_[(32 * ti + i) * 33 + 2 * s + kh], acc);
+      const int col = 32 * ti + i;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = 32 * to + tf_rho(j, kh);
+        if (row < nout && col < nin) atomicAdd(gW + (long long)row * ld + col, acc[j]);
+      }
+    }
+}
+
+// sum over the tile's 32 rows of an LDS [unit][row] tile: lanes 0..31 take unit 32*t + lane
+__device__ __forceinline__ float row_sum(const float* __restrict__ l, int unit) {
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) s += l[unit * 33 + r];
+  return s;
+}
+
+// backward through one net given delta4 (accumulator layout, 21 valid units); returns g of the 8 sample inputs (in8 order)
+__device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f32x16 (&in1)[1], const f32x16 (&h1)[2],
+                                        const f32x16 (&h2)[2], const f32x16 (&h3)[2], const float (&g_wv)[32],
+                                        float* __restrict__ lds_d, float* __restrict__ lds_h, float* const (&gW)[4],
+                                        float* const (&gB)[4], float* __restrict__ gP_pt, bool uniform_pt, int lane, float (&g_in8)[8]) {
+  const int h = lane >> 5, i = lane & 31;
+  f32x16 d4[1], d3[2], d2[2], d1[2], d0[1];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { const int r0 = (j & 3) + 8 * (j >> 2); d4[0][j] = h ? g_wv[r0 + 4] : g_wv[r0]; }
+  // ---- layer 4: dW4 = d4 * h3^T, db4, d3 = (W4^T d4) * lrelu'(h3)
+  tile_to_lds<1>(d4, lds_d, lane);
+  tile_to_lds<2>(h3, lds_h, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  accum_dw<1, 2>(lds_d, lds_h, gW[3], 64, 21, 64, lane);
+  if (lane < 21) atomicAdd(gB[3] + lane, row_sum(lds_d, lane));
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d3[t][j] = 0.f;
+  tf_layer_sb<16, 2, 1, 16>(tfrag + kT4 + lane, d4, d3);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d3[t][j] *= dleaky(h3[t][j]);
+  // ---- layer 3
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  tile_to_lds<2>(d3, lds_d, lane);
+  tile_to_lds<2>(h2, lds_h, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  accum_dw<2, 2>(lds_d, lds_h, gW[2], 64, 64, 64, lane);
+  if (lane < 32) { atomicAdd(gB[2] + lane, row_sum(lds_d, lane)); atomicAdd(gB[2] + 32 + lane, row_sum(lds_d, 32 + lane)); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d2[t][j] = 0.f;
+  tf_layer_sb<32, 2, 2, 16>(tfrag + kT3 + lane, d3, d2);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d2[t][j] *= dleaky(h2[t][j]);
+  // ---- layer 2
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  tile_to_lds<2>(d2, lds_d, lane);
+  tile_to_lds<2>(h1, lds_h, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  accum_dw<2, 2>(lds_d, lds_h, gW[1], 64, 64, 64, lane);
+  if (lane < 32) { atomicAdd(gB[1] + lane, row_sum(lds_d, lane)); atomicAdd(gB[1] + 32 + lane, row_sum(lds_d, 32 + lane)); }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d1[t][j] = 0.f;
+  tf_layer_sb<32, 2, 2, 16>(tfrag + kT2 + lane, d2, d1);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d1[t][j] *= dleaky(h1[t][j]);
+  // ---- layer 1 (sample part 64 x 8) + hoisted per-point part
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  tile_to_lds<2>(d1, lds_d, lane);
+  tile_to_lds<1>(in1, lds_h, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  accum_dw<2, 1>(lds_d, lds_h, gW[0], 44, 64, 7, lane);
+  if (uniform_pt) {
+    if (lane < 32) { atomicAdd(gP_pt + lane, row_sum(lds_d, lane)); atomicAdd(gP_pt + 32 + lane, row_sum(lds_d, 32 + lane)); }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) atomicAdd(gP_pt + 32 * t + tf_rho(j, h), d1[t][j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d0[0][j] = 0.f;
+  tf_layer_sb<32, 1, 2, 16>(tfrag + kT1 + lane, d1, d0);
+  // d0 rows 0..7 = gradient of the 8 sample inputs; row rho(j,h): collect both halves
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float mine = d0[0][j], other = __shfl_xor(mine, 32);
+    g_in8[j] = h ? other : mine;
+    g_in8[4 + j] = h ? mine : other;
+  }
+  (void)i;
+}
+
+__device__ __forceinline__ void embed8(float y, float (&in8)[8]) {
+  in8[0] = y * 2.f - 1.f;
+  in8[1] = sinf(y) * 2.f - 1.f; in8[2] = cosf(y) * 2.f - 1.f;
+  in8[3] = sinf(y * 2.f) * 2.f - 1.f; in8[4] = cosf(y * 2.f) * 2.f - 1.f;
+  in8[5] = sinf(y * 4.f) * 2.f - 1.f; in8[6] = cosf(y * 4.f) * 2.f - 1.f;
+  in8[7] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restrict__ ws_arg, const float* __restrict__ P,
+                                                            const float* __restrict__ xin, const long long* __restrict__ rays_id,
+                                                            long long m, int sn, long long pn, const float* __restrict__ g_logq,
+                                                            FlowGrads G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < 2 * kNetFloats; i += 256) lds[i] = ws_arg[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* lds_d = lds + 2 * kNetFloats + wave * 2 * kTileLds;
+  float* lds_h = lds_d + kTileLds;
+  const long long n_tiles = (m + 31) / 32;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+    const float* ws = ws_arg;
+    asm volatile("" : "+s"(ws));                 // keep the transposed-fragment addresses out of LICM's reach
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const float* net_lds = lds + opaque;         // ... and the LDS weight operands
+    long long row = tile * 32 + (lane & 31);
+    const bool valid = row < m;
+    if (!valid) row = m - 1;
+    const long long pt = rays_id ? rays_id[row] : row / sn;
+    const float x0 = fminf(fmaxf(xin[2 * row], 1e-6f), 1.f - 1e-6f);
+    const float x1 = fminf(fmaxf(xin[2 * row + 1], 1e-6f), 1.f - 1e-6f);
+    const float g = valid ? g_logq[row] : 0.f;
+    const long long pt0 = __shfl(pt, 0);
+    const bool uniform_pt = __all(pt == pt0) != 0;
+    // ---- forward recompute
+    float in8a[8], in8b[8], wv1[32], wv0[32];
+    f32x16 in1a[1], a1[2], a2[2], a3[2];
+    embed8(x1, in8a);
+    net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);   // net 1 keeps x1, moves x0
+    float z0, lj1;
+    pw_forward_fb(x0, wv1, z0, lj1);
+    f32x16 in1b[1], b1[2], b2[2], b3[2];
+    embed8(z0, in8b);
+    net_fwd_keep(net_lds, P + pt * 64, in8b, lane, in1b, b1, b2, b3, wv0);                        // net 0 keeps z0, moves x1
+    float z1, lj0;
+    pw_forward_fb(x1, wv0, z1, lj0);
+    // ---- reverse
+    const float g_z1 = g * (-tanf(z1 * kHalfPi) * kHalfPi);
+    float g_wv0[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) g_wv0[k] = 0.f;
+    pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);
+    float g_in8[8];
+    float* const gW0[4] = {G.w[0][0], G.w[0][1], G.w[0][2], G.w[0][3]};
+    float* const gB0[4] = {G.b[0][0], G.b[0][1], G.b[0][2], G.b[0][3]};
+    net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, gW0, gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
+    // d(2*emb(z0) - 1)/dz0
+    const float g_z0 = 2.f * (g_in8[0] + g_in8[1] * cosf(z0) - g_in8[2] * sinf(z0) + 2.f * g_in8[3] * cosf(2.f * z0) -
+                              2.f * g_in8[4] * sinf(2.f * z0) + 4.f * g_in8[5] * cosf(4.f * z0) - 4.f * g_in8[6] * sinf(4.f * z0));
+    float g_wv1[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
+    pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
+    float* const gW1[4] = {G.w[1][0], G.w[1][1], G.w[1][2], G.w[1][3]};
+    float* const gB1[4] = {G.b[1][0], G.b[1][1], G.b[1][2], G.b[1][3]};
+    net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, gW1, gB1, G.gP + (pn + pt) * 64, uniform_pt, lane,
+            g_in8);
+  }
+}
+
+// shared with flow.hip
+__global__ void __launch_bounds__(256) flow_point_part_kernel2(const float* __restrict__ w1a, const float* __restrict__ b1a,
+                                                               const float* __restrict__ w1b, const float* __restrict__ b1b,
+                                                               const float* __restrict__ cond, long long pn, float* __restrict__ P) {
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * pn * 64) return;
+  int u = (int)(e & 63);
+  long long pt = (e >> 6) % pn;
+  int blk = (int)((e >> 6) / pn);
+  const float* w = (blk ? w1b : w1a) + u * 44 + 7;
+  float acc = (blk ? b1b : b1a)[u];
+  const float* c = cond + pt * 37;
+#pragma unroll
+  for (int k = 0; k < 37; ++k) acc += w[k] * (c[k] * 2.f - 1.f);
+  P[e] = acc;
+}
+
+extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id, int64_t m,
+                                int32_t sn, int64_t pn, const float* g_logq, const TfCouplingNetGrad gnets[2], float* g_point,
+                                float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const char* who = "tf_flow_logq_bwd";
+  TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(nets && gnets && cond && x && g_logq && g_point && workspace, TF_EINVAL, "%s: null pointer", who);
+  TF_REQUIRE(pn > 0 && (rays_id || m == pn * (int64_t)sn), TF_ESHAPE, "%s: without rays_id m must equal pn*sn", who);
+  TF_REQUIRE(workspace_floats >= tf_flow_bwd_workspace_floats(pn), TF_ESHAPE, "%s: workspace too small", who);
+  FlowGrads G;
+  for (int b = 0; b < 2; ++b)
+    for (int l = 0; l < 4; ++l) {
+      TF_REQUIRE(nets[b].w[l] && nets[b].b[l] && gnets[b].w[l] && gnets[b].b[l], TF_EINVAL, "%s: null weight / gradient pointer", who);
+      G.w[b][l] = gnets[b].w[l];
+      G.b[b][l] = gnets[b].b[l];
+    }
+  G.gP = g_point;
+  for (int b = 0; b < 2; ++b) {
+    float* base = workspace + (size_t)b * kNetFloats;
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
+    tf_pack_wfrag_kernel<<<tf_blocks(32 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + kB2);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + kB3);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + kB4);
+    float* tb = workspace + 2 * kNetFloats + (size_t)b * kTNet;
+    // transposed fragments: logical matrix = W^T  (rows = layer inputs, cols = layer outputs)
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 16 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 64, 64, 0, 21, 2, 16, tb + kT4, 0, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, tb + kT3, 0, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, tb + kT2, 0, 1);
+    tf_pack_wfrag_kernel<<<tf_blocks(1 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 7, 44, 0, 64, 1, 32, tb + kT1, 0, 1);
+  }
+  float* P = workspace + kBwdWs;
+  flow_point_part_kernel2<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0], nets[1].b[0],
+                                                                          cond, pn, P);
+  const size_t lds = (size_t)(2 * kNetFloats + 4 * 2 * kTileLds) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)flow_logq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long long tiles = (m + 31) / 32;
+  long long blocks = (tiles + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}

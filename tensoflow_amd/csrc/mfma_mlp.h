@@ -30,7 +30,9 @@ __device__ __forceinline__ f32x16 tf_mfma(float a, float b, f32x16 c) {
 // Pack W [nout, ld] (columns col0 .. col0+kin-1 used) into fragment order; zero padded.
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                             int kin, int tout_tiles, int ksteps,
-                                                            float* __restrict__ dst, int s_major = 0) {
+                                                            float* __restrict__ dst, int s_major = 0,
+                                                            int transpose = 0) {
+  // transpose = 1 packs W^T: logical row r / column k read W[k*ld + col0 + r]  (nout = logical rows, kin = logical cols)
   int e = blockIdx.x * 256 + threadIdx.x;
   int total = tout_tiles * ksteps * 64;
   if (e >= total) return;
@@ -45,7 +47,8 @@ static __global__ void __launch_bounds__(256) tf_pack_wfrag_kernel(const float* 
   }
   int row = 32 * tout + (lane & 31);
   int k = tf_kmap(s, lane >> 5);
-  dst[e] = (row < nout && k < kin) ? W[(long long)row * ld + col0 + k] : 0.f;
+  if (transpose) dst[e] = (row < nout && k < kin) ? W[(long long)k * ld + col0 + row] : 0.f;
+  else dst[e] = (row < nout && k < kin) ? W[(long long)row * ld + col0 + k] : 0.f;
 }
 
 // Pack a bias vector [n] into accumulator order: dst[(tout*16 + reg)*2 + h] = b[32*tout + rho(reg,h)].

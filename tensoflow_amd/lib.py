@@ -26,6 +26,10 @@ class TfCouplingNet(C.Structure):
     _fields_ = [("w", c_f * 4), ("b", c_f * 4)]
 
 
+class TfCouplingNetGrad(C.Structure):
+    _fields_ = [("w", c_f * 4), ("b", c_f * 4)]
+
+
 class TfMlp4(C.Structure):
     _fields_ = [("w", c_f * 4), ("b", c_f * 4)]
 
@@ -55,6 +59,8 @@ SIGNATURES = {
     "tf_flow_workspace_floats": (sz, [i64]),
     "tf_flow_sample_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, c_f, c_f, c_f, i32, c_f, sz, c_f]),
     "tf_flow_logq_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, c_f, c_f, i32, c_f, sz, c_f]),
+    "tf_flow_bwd_workspace_floats": (sz, [i64]),
+    "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, sz, c_f]),
     "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
     "tf_bvh_build_host": (i64, [C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p]),

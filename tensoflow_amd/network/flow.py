@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..autograd import FlowLogqFn, VmGatherFn
 from ..shading import posenc, sphere_latent
 
 
@@ -89,7 +90,11 @@ class TensoFlow(nn.Module):
                 {"params": self.nis_mat.parameters(), "lr": lr_init_network}, {"params": self.flows.parameters(), "lr": lr_init_network}]
 
     def tenso_feature(self, xyz_sampled, level_vol=None):
-        feat = ops.vm_gather(self._field(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in list(self.nis_plane) + list(self.nis_line)):
+            feat = VmGatherFn.apply(xyz_sampled.reshape(-1, 3).contiguous(), level_vol, self.aabb, self.n_levels,
+                                    *self.nis_plane, *self.nis_line)
+        else:
+            feat = ops.vm_gather(self._field(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb)
         return self.nis_mat(torch.cat([feat, posenc(xyz_sampled, 3)], -1))
 
     def _condition(self, pts, reflections):
@@ -110,7 +115,16 @@ class TensoFlow(nn.Module):
         return (ang, logj) if return_jacobian else ang
 
     def forward(self, pts, reflections, roughness, x, return_jacobian=False, rays_id=None):
-        """flow.py:801-831 -> z (, logqx)."""
-        _check_no_grad(self, "TensoFlow.forward")
-        z, logq = ops.flow_logq(self._nets(), self._condition(pts, reflections), x, rays_id=rays_id)
+        """flow.py:801-831 -> z (, logqx).  Differentiable wrt every parameter of the flow (the NIS loss path):
+        forward and backward are fused HIP kernels (autograd.FlowLogqFn / VmGatherFn); the 57-64-16 feature net is a
+        per-point library GEMM under plain autograd."""
+        cond = self._condition(pts, reflections)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            wb = []
+            for blk in self.flows:
+                for l in (1, 3, 5, 7):
+                    wb += [blk.nn[l].weight, blk.nn[l].bias]
+            z, logq = FlowLogqFn.apply(cond, x.clamp(1e-6, 1 - 1e-6).contiguous(), rays_id, *wb)
+        else:
+            z, logq = ops.flow_logq(self._nets(), cond, x, rays_id=rays_id)
         return (z, logq) if return_jacobian else z

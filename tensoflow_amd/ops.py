@@ -241,6 +241,38 @@ def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
     return (z, lq, bins) if want_bins else (z, lq)
 
 
+def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None):
+    """Backward of flow_logq wrt the 16 net tensors and cond.
+    -> (grads: 2 lists of 4 (gW, gb) pairs in torch layout, g_cond [pn,37])."""
+    lib = L.load()
+    cond, x, g_logq = _f(cond), _f(x), _f(g_logq.reshape(-1))
+    pn = cond.shape[0]
+    dev = cond.device
+    shape = x.shape[:-1]
+    m = int(np.prod(shape)) if len(shape) else 1
+    sn = x.shape[1] if rays_id is None else 1
+    nets, keep = _coupling_nets(weights)
+    gnets = (L.TfCouplingNetGrad * 2)()
+    grads = [[(torch.zeros_like(_f(W)), torch.zeros_like(_f(b))) for (W, b) in weights[k]] for k in range(2)]
+    for k in range(2):
+        for l in range(4):
+            gnets[k].w[l], gnets[k].b[l] = grads[k][l][0].data_ptr(), grads[k][l][1].data_ptr()
+    g_point = torch.zeros(2, pn, 64, dtype=torch.float32, device=dev)
+    ws = _workspace("flow_bwd", lib.tf_flow_bwd_workspace_floats(pn), dev)
+    rid = None if rays_id is None else rays_id.contiguous()
+    L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
+                                 _p(g_point), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
+    # fold the hoisted per-point part (three small library GEMMs per net)
+    c = cond * 2.0 - 1.0
+    g_cond = torch.zeros_like(cond)
+    for k in range(2):
+        gW1, gb1 = grads[k][0]
+        gW1[:, 7:] += g_point[k].t() @ c
+        gb1 += g_point[k].sum(0)
+        g_cond += 2.0 * (g_point[k] @ _f(weights[k][0][0])[:, 7:])
+    return grads, g_cond
+
+
 # ------------------------------------------------------------------------------ light / mesh / shading
 def cube_lookup(base, dirs, apply_exp=True, depth=None, near_eps=0.0):
     lib = L.load()

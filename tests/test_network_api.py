@@ -35,4 +35,4 @@ def test_fused_forward_refuses_autograd():
     from tensoflow_amd.network.flow import TensoFlow
     m = TensoFlow(2, AABB, device="cpu", gridSize=[8, 8, 8])
     with pytest.raises(RuntimeError, match="no backward yet"):
-        m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)
+        m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)   # sampling is a frozen-copy op
