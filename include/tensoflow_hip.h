@@ -231,6 +231,12 @@ int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, const float*
                                const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
                                float near_eps, float exp_max, int32_t precision, float* lights, float* workspace,
                                size_t workspace_floats, tf_stream_t stream);
+/* Input encoding of the inner-light net alone: X [capacity,123] = cat[pos_enc8(pos[i]), IDE5(reflect(-dirs[i], nrm[i]))] for
+ * i = idx[r] (r < *count_dev), or i = r when idx is NULL (then view = dirs).  Used by the training backward, whose
+ * weight-gradient products are plain library GEMMs on X. */
+int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm, const int64_t* idx,
+                          const int64_t* count_dev, int64_t capacity, float* X, float* workspace,
+                          size_t workspace_floats, tf_stream_t stream);
 /* idx[0 .. *count) = indices i with mask[i] != 0 (unordered); *count is zeroed by the call (replaces the boolean-mask
  * indexing of fields.py:962-971). */
 int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
@@ -256,7 +262,16 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                   const float* albedo, const float* ang_d, const float* logq_d, int32_t sd,
                   const float* fixed_d, const float* az_jitter, int32_t nf, const float* ang_s,
                   const float* logq_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
-                  uint8_t* live /* [pn,T] = any(wgt != 0), may be NULL */, tf_stream_t stream);
+                  uint8_t* live /* [pn,T] = any(wgt != 0), may be NULL */,
+                  float* flow_logjac /* [pn, sd+ss] = log max(4 pi^2 HoV sin(theta), 1e-6) of the flow slots (NIS loss,
+                                        fields.py:1275,1312), may be NULL */,
+                  tf_stream_t stream);
+/* Backward of the BRDF weights wrt the per-point materials (training): g_wgt [pn,T,3] ->
+ * g_albedo [pn,3], g_metallic [pn], g_roughness [pn] (overwritten).  dirs / wgt are tf_shade_dirs' outputs. */
+int tf_shade_dirs_bwd(const float* normals, const float* view, const float* metallic, const float* roughness,
+                      const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd,
+                      int32_t nf, int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness,
+                      tf_stream_t stream);
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);

@@ -254,6 +254,73 @@ extern "C" int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, c
                             workspace_floats, (hipStream_t)stream, "tf_inner_light_indexed_fwd");
 }
 
+// ---------------------------------------------------------------- input encoding only (training: the weight-gradient
+// GEMMs [rows x 256]^T [rows x 256] are plain library GEMMs on this [rows,123] matrix)
+__global__ void __launch_bounds__(256) inner_light_encode_kernel(const float* __restrict__ mat, const float* __restrict__ pts,
+                                                                 const float* __restrict__ view, const float* __restrict__ nrm,
+                                                                 long long m_arg, const long long* __restrict__ idx,
+                                                                 const long long* __restrict__ count_dev, float* __restrict__ X) {
+  long long m = m_arg;
+  if (count_dev) m = min(m_arg, *count_dev);
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= m) return;
+  const long long src = idx ? idx[row] : row;
+  const float vsign = idx ? -1.f : 1.f;
+  float* x = X + row * 123;
+  const float p[3] = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+  for (int k = 0; k < 3; ++k) x[k] = p[k];
+  for (int f = 0; f < 8; ++f)
+    for (int k = 0; k < 3; ++k) {
+      const float a = p[k] * (float)(1 << f);
+      x[3 + 6 * f + k] = sinf(a);
+      x[3 + 6 * f + 3 + k] = cosf(a);
+    }
+  float n[3] = {nrm[3 * src], nrm[3 * src + 1], nrm[3 * src + 2]};
+  float v[3] = {vsign * view[3 * src], vsign * view[3 * src + 1], vsign * view[3 * src + 2]};
+  float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+  n[0] *= inv; n[1] *= inv; n[2] *= inv;
+  inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+  const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+  float zp[17], cre[17], cim[17];
+  zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
+  for (int k = 1; k < 17; ++k) {
+    zp[k] = zp[k - 1] * rz;
+    cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
+    cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
+  }
+  int col = 0;
+  for (int d = 0; d < 5; ++d) {
+    const int l = 1 << d;
+    for (int mm = 0; mm <= l; ++mm, ++col) {
+      float poly = 0.f;
+      for (int k = 0; k <= l - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+      x[51 + col] = cre[mm] * poly;
+      x[51 + 36 + col] = cim[mm] * poly;
+    }
+  }
+}
+
+extern "C" int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm, const int64_t* idx,
+                                     const int64_t* count_dev, int64_t capacity, float* X, float* workspace, size_t workspace_floats,
+                                     tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(capacity >= 0, TF_ESHAPE, "tf_inner_light_encode: capacity < 0");
+  if (capacity == 0) return TF_OK;
+  TF_REQUIRE(pos && dirs && nrm && X && workspace, TF_EINVAL, "tf_inner_light_encode: null pointer");
+  TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_encode: workspace too small");
+  static float ide_host[17 * 36];
+  static bool ide_ready = false;
+  if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
+  hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_encode: hipMemcpyAsync failed: %s", hipGetErrorString(e));
+  inner_light_encode_kernel<<<tf_blocks(capacity, 256), 256, 0, stream>>>(workspace + kIdeMat, pos, dirs, nrm, capacity,
+                                                                         (const long long*)idx, (const long long*)count_dev, X);
+  TF_LAUNCH_CHECK("tf_inner_light_encode");
+  return TF_OK;
+}
+
 // ---------------------------------------------------------------- stream compaction of a byte mask (hit rays)
 #define COMPACT_ITEMS 8192   // elements per workgroup: one global atomic per 8192 rays instead of one per wave
 __global__ void __launch_bounds__(256) compact_mask_kernel(const unsigned char* __restrict__ mask, long long m,

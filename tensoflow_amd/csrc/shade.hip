@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
     const float* __restrict__ logq_d, int sd, const float* __restrict__ fixed_d, const float* __restrict__ az_jitter, int nf,
     const float* __restrict__ ang_s, const float* __restrict__ logq_s, int ss, long long pn, float* __restrict__ dirs,
-    float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live) {
+    float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live,
+    float* __restrict__ flow_logjac) {
   const int T = sd + nf + ss;
   long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= pn * T) return;
@@ -96,6 +97,8 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) dir[k] = HoV * H[k] * 2.f - v[k];
     pdf = expf(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(4.f * kPi * kPi * HoV * st, kEPS);
+    // log of the (angles -> outgoing direction) Jacobian used by the NIS loss (fields.py:1275, :1312)
+    if (flow_logjac) flow_logjac[pt * (sd + ss) + (is_spec ? sd + (slot - sd - nf) : slot)] = logf(fmaxf(4.f * kPi * kPi * HoV * st, kEPS));
   } else {
     // fixed cosine set (fields.py:824-847)
     const int s = slot - sd;
@@ -137,6 +140,77 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
 #pragma unroll
   for (int k = 0; k < 3; ++k) { dirs[3 * e + k] = dir[k]; wgt[3 * e + k] = w[k]; }
   if (live) live[e] = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f) ? 1 : 0;
+}
+
+// Backward of the BRDF weights wrt the per-point materials: given g_wgt [pn,T,3] accumulates
+//   g_albedo [pn,3], g_metallic [pn], g_roughness [pn]   (directions and pdfs do not depend on trainable parameters:
+//   the sampling flows are frozen copies, fields.py:1054-1065).  One wave per point, slots strided over lanes.
+__global__ void __launch_bounds__(256) shade_dirs_bwd_kernel(
+    const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
+    const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ dirs,
+    const float* __restrict__ wgt, const float* __restrict__ g_wgt, int sd, int nf, int ss, long long pn,
+    float* __restrict__ g_albedo, float* __restrict__ g_metallic, float* __restrict__ g_roughness) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= pn) return;
+  const int T = sd + nf + ss;
+  Frame F;
+  make_frame(normals + 3 * pt, F);
+  float v[3] = {view[3 * pt], view[3 * pt + 1], view[3 * pt + 2]};
+  normalize3(v);
+  const float met = metallic[pt], a = roughness[pt];
+  const float alb[3] = {albedo[3 * pt], albedo[3 * pt + 1], albedo[3 * pt + 2]};
+  float ga[3] = {0, 0, 0}, gm = 0.f, gr = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const long long e = pt * T + t;
+    const float gw[3] = {g_wgt[3 * e], g_wgt[3 * e + 1], g_wgt[3 * e + 2]};
+    const float w[3] = {wgt[3 * e], wgt[3 * e + 1], wgt[3 * e + 2]};
+    if (t < sd + nf) {
+      // w_k = alb_k * (1 - met) * C   ->  C = w_k / (alb_k (1-met)); use the stored weight to avoid recomputing pdfs
+      const float kd = 1.f - met;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float C = (alb[k] * kd != 0.f) ? w[k] / (alb[k] * kd) : 0.f;
+        ga[k] += gw[k] * kd * C;
+        gm -= gw[k] * alb[k] * C;
+      }
+    } else {
+      if (w[0] == 0.f && w[1] == 0.f && w[2] == 0.f) continue;          // masked (below horizon)
+      const float dir[3] = {dirs[3 * e], dirs[3 * e + 1], dirs[3 * e + 2]};
+      float Hs[3] = {v[0] + dir[0], v[1] + dir[1], v[2] + dir[2]};
+      normalize3(Hs);
+      const float HoV = sat(dot3(Hs, v));
+      const float f5 = powf(sat(1.f - HoV), 5.f);
+      const float NoV = sat(dot3(F.n, v)), NoL = sat(dot3(F.n, dir)), NoH = sat(dot3(F.n, Hs));
+      // D(a), G(a) and their logarithmic derivatives
+      const float a2 = a * a, q = NoH * NoH * (a2 - 1.f) + 1.f;
+      const float dlogD = (kPi * q * q > kEPS) ? (2.f / a) * (1.f - 2.f * a2 * NoH * NoH / q) : 2.f / a;
+      const float k_ = a / 2.f;
+      const float denV = NoV * (1.f - k_) + k_ + 1e-5f, denL = NoL * (1.f - k_) + k_ + 1e-5f;
+      const float dlogG = -(1.f - NoV) / (2.f * denV) - (1.f - NoL) / (2.f * denL);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float F0 = 0.04f * (1.f - met) + met * alb[k];
+        const float fres = F0 + (1.f - F0) * f5;
+        // w_k = D * fres_k * G * inv  ->  d w_k / d a = w_k (dlogD + dlogG);  d w_k / d F0 = w_k (1 - f5) / fres_k
+        gr += gw[k] * w[k] * (dlogD + dlogG);
+        const float dwdF0 = fres != 0.f ? w[k] * (1.f - f5) / fres : 0.f;
+        gm += gw[k] * dwdF0 * (alb[k] - 0.04f);
+        ga[k] += gw[k] * dwdF0 * met;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gm += __shfl_xor(gm, o); gr += __shfl_xor(gr, o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ga[k] += __shfl_xor(ga[k], o);
+  }
+  if (lane == 0) {
+    g_metallic[pt] = gm; g_roughness[pt] = gr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_albedo[3 * pt + k] = ga[k];
+  }
 }
 
 __device__ __forceinline__ float srgb(float x) {  // utils/raw_utils.py:4-11
@@ -189,7 +263,8 @@ extern "C" int tf_view_angles(const float* normals, const float* view, int64_t p
 extern "C" int tf_shade_dirs(const float* normals, const float* view, const float* metallic, const float* roughness,
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
-                             int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, tf_stream_t stream) {
+                             int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
+                             tf_stream_t stream) {
   TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs: negative size");
   if (pn == 0 || sd + nf + ss == 0) return TF_OK;
   TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "tf_shade_dirs: null pointer");
@@ -198,7 +273,7 @@ extern "C" int tf_shade_dirs(const float* normals, const float* view, const floa
   long long work = (long long)pn * (sd + nf + ss);
   shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
                                                                           logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, ss,
-                                                                          pn, dirs, wgt, spec_mask, live);
+                                                                          pn, dirs, wgt, spec_mask, live, flow_logjac);
   TF_LAUNCH_CHECK("tf_shade_dirs");
   return TF_OK;
 }
@@ -211,5 +286,18 @@ extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn
   shade_reduce_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, lights, pn, n_diffuse, ss, colors, diffuse_lin,
                                                                         specular_lin);
   TF_LAUNCH_CHECK("tf_shade_reduce");
+  return TF_OK;
+}
+
+extern "C" int tf_shade_dirs_bwd(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                 const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd, int32_t nf,
+                                 int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness, tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs_bwd: negative size");
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt && g_wgt && g_albedo && g_metallic && g_roughness,
+             TF_EINVAL, "tf_shade_dirs_bwd: null pointer");
+  shade_dirs_bwd_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, dirs, wgt,
+                                                                          g_wgt, sd, nf, ss, pn, g_albedo, g_metallic, g_roughness);
+  TF_LAUNCH_CHECK("tf_shade_dirs_bwd");
   return TF_OK;
 }

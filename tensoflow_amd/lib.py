@@ -70,7 +70,9 @@ SIGNATURES = {
     "tf_inner_light_indexed_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, c_f, c_f, i64, c_f, f32, f32, i32, c_f, c_f, sz, c_f]),
     "tf_compact_mask": (C.c_int, [c_f, i64, c_f, c_f, c_f]),
     "tf_view_angles": (C.c_int, [c_f, c_f, i64, c_f, c_f]),
-    "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
+    "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "tf_shade_dirs_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, c_f]),
+    "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, c_f, sz, c_f]),
     "tf_shade_reduce": (C.c_int, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),
 }
 

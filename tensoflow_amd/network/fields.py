@@ -5,7 +5,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..shading import MCShader
+from ..autograd import LightsFn, ShadeWeightsFn, VmGatherFn
+from ..shading import MCShader, fibonacci_samples, sphere_latent
 from .flow import TensoFlow, _check_no_grad
 from .light import EnvLight
 
@@ -114,9 +115,72 @@ class MCShadingNetwork(nn.Module):
                                 exp_max=self.cfg["inner_light_exp_max"])
         return self._shader
 
-    @torch.no_grad()
+    def _linear_to_srgb(self, lin):
+        eps = torch.finfo(torch.float32).eps
+        return torch.where(lin <= 0.0031308, 323 / 25 * lin, (211 * lin.clamp(min=eps) ** (5 / 12) - 11) / 200)
+
+    def forward_train(self, pts, view_dirs, normals, step=None, is_train=True):
+        """Differentiable forward of shade_mixed with the flow samplers (fields.py:1075-1335): every per-sample stage runs in
+        the HIP kernels through autograd Functions whose backward is HIP as well (VM gather, BRDF weights, cube map, flow
+        log-density) or a library GEMM (inner-light weight gradients); the per-point material MLPs are torch modules."""
+        dev = pts.device
+        pn = pts.shape[0]
+        sd, ss = self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"]
+        feat = VmGatherFn.apply(pts.contiguous(), None, self.aabb, 3, *self.mat_plane, *self.mat_line)
+        metallic = self.metallic_predictor(feat)
+        roughness = self.roughness_predictor(feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2
+        albedo = self.albedo_predictor(feat)
+        if not hasattr(self, "_bvh"):
+            self._bvh = ops.Bvh(self.ray_tracer[0], self.ray_tracer[1], dev)
+            self._fixed = fibonacci_samples(self.cfg["diffuse_sample_num"]).to(dev)
+        with torch.no_grad():
+            va = ops.view_angles(normals, view_dirs)
+            jit = (lambda n: torch.rand(pn, n, device=dev)) if (is_train and self.training) else (lambda n: None)
+            ang_d, lq_d = self.flow_diffuse_copy._sample_nograd(pts, va, sd, jit(sd))
+            ang_s, lq_s = self.flow_specular_copy._sample_nograd(pts, va, ss, jit(ss))
+            az_jit = torch.rand(pn, device=dev) if (is_train and self.training) else None
+        wgt, dirs, smask, live, logjac = ShadeWeightsFn.apply(metallic, roughness, albedo, normals.contiguous(), view_dirs.contiguous(),
+                                                              ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit)
+        T = dirs.shape[1]
+        nd = sd + self._fixed.shape[0]
+        pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3).contiguous()
+        inner_wb = []
+        for i in (0, 2, 4, 6):
+            inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)
+        lights, hit = LightsFn.apply(self.outer_light.base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
+                                     self.cfg["inner_light_exp_max"], ops.PREC_F32, *inner_wb)
+        lights = lights.view(pn, T, 3)
+        contrib = wgt * lights
+        diffuse_lin, specular_lin = contrib[:, :nd].sum(1), contrib[:, nd:].sum(1)
+        colors = self._linear_to_srgb(diffuse_lin + specular_lin)
+        outputs = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (F.normalize(normals, dim=-1) + 1) / 2,
+                   "diffuse_light": torch.clamp(self._linear_to_srgb(lights[:, :nd].mean(1)), 0, 1), "specular_mask": smask}
+        zero = torch.zeros((), device=dev)
+        outputs["loss_nis_diffuse"] = outputs["loss_nis_specular"] = zero
+        if step is not None and step >= self.cfg.get("nis_loss_iter_diffuse", 500):
+            # loss = -mean(fx * logq / p) with fx / p = wgt * count * lights on the flow slots (fields.py:1271-1284)
+            x = ang_d.clamp(1e-6, 1 - 1e-6)
+            _, logq = self.flow_diffuse(pts, va, roughness.detach(), x, return_jacobian=True)
+            logqx = logq[..., 0] - logjac[:, :sd]
+            outputs["loss_nis_diffuse"] = -(contrib[:, :sd] * float(nd) * logqx[..., None]).mean()
+        if step is not None and step >= self.cfg.get("nis_loss_iter_specular", 500):
+            rid = torch.arange(pn, device=dev)[:, None].expand(pn, ss)[smask]
+            x = ang_s[smask].clamp(1e-6, 1 - 1e-6).contiguous()
+            _, logq = self.flow_specular(pts, va, roughness.detach(), x, return_jacobian=True, rays_id=rid)
+            logqx = logq[:, 0] - logjac[:, sd:][smask]
+            outputs["loss_nis_specular"] = -(contrib[:, nd:][smask] * float(ss) * logqx[:, None]).mean()
+        outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
+        return colors, outputs
+
     def forward(self, pts, view_dirs, normals, human_poses=None, step=None, is_train=False):
-        """fields.py:1453-1473, eval with the flow samplers: -> (colors [pn,3], outputs dict)."""
+        """fields.py:1453-1473 with the flow samplers active: -> (colors [pn,3], outputs dict).
+        With autograd enabled (training) the differentiable composition is used; otherwise the fused inference path."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train)
+        return self._forward_eval(pts, view_dirs, normals)
+
+    @torch.no_grad()
+    def _forward_eval(self, pts, view_dirs, normals):
         sh = self._shader if self._shader is not None else self.shader()
         out = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"])
         outputs = {"albedo": out["albedo"], "roughness": out["roughness"], "metallic": out["metallic"],

@@ -106,6 +106,12 @@ class TensoFlow(nn.Module):
             refl = torch.zeros_like(refl)
         return torch.cat([feature, refl, torch.zeros(pts.shape[0], 7, device=pts.device)], -1).contiguous()
 
+    @torch.no_grad()
+    def _sample_nograd(self, pts, view_angles, n_samples, jitter=None):
+        """sample() for a frozen copy (fields.py:1054-1065): angles [pn,sn,2], logq [pn,sn,1]."""
+        cond = self._condition(pts, view_angles)
+        return ops.flow_sample(self._nets(), cond, sphere_latent(n_samples).to(pts.device), jitter, precision=ops.PREC_F32)
+
     # ---- reference API
     def sample(self, pts, reflections, roughness, n_samples, return_jacobian=False):
         """flow.py:833-855 -> angles [pn,sn,2] (, logj [pn,sn,1])."""

@@ -394,7 +394,7 @@ def view_angles(normals, view):
     return va
 
 
-def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None):
+def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False):
     lib = L.load()
     pn = normals.shape[0]
     sd = 0 if ang_d is None else ang_d.shape[1]
@@ -406,13 +406,40 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     wgt = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
     mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
     live = torch.empty(pn, T, dtype=torch.uint8, device=dev)
+    logjac = torch.empty(pn, sd + ss, dtype=torch.float32, device=dev) if want_logjac else None
     g = lambda t: None if t is None else _f(t)
     L.check(lib.tf_shade_dirs(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
                               _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
                               _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(g(ang_s)),
                               _p(g(None if logq_s is None else logq_s.reshape(pn, ss))), ss, pn, _p(dirs), _p(wgt),
-                              _p(mask, torch.uint8), _p(live, torch.uint8), _stream()), "tf_shade_dirs")
+                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _stream()), "tf_shade_dirs")
+    if want_logjac:
+        return dirs, wgt, mask.bool(), live, logjac
     return dirs, wgt, mask.bool(), live
+
+
+def shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss):
+    lib = L.load()
+    pn = normals.shape[0]
+    dev = normals.device
+    g_alb = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    g_met = torch.empty(pn, dtype=torch.float32, device=dev)
+    g_rough = torch.empty(pn, dtype=torch.float32, device=dev)
+    L.check(lib.tf_shade_dirs_bwd(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                                  _p(_f(albedo)), _p(_f(dirs)), _p(_f(wgt)), _p(_f(g_wgt)), sd, nf, ss, pn, _p(g_alb), _p(g_met),
+                                  _p(g_rough), _stream()), "tf_shade_dirs_bwd")
+    return g_alb, g_met, g_rough
+
+
+def inner_light_encode(pos, dirs, nrm, idx=None, count=None):
+    """-> X [capacity,123] (rows >= *count are undefined)."""
+    lib = L.load()
+    cap = pos.shape[0] if idx is None else idx.numel()
+    X = torch.empty(cap, 123, dtype=torch.float32, device=pos.device)
+    ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pos.device)
+    L.check(lib.tf_inner_light_encode(_p(_f(pos)), _p(_f(dirs)), _p(_f(nrm)), _p(idx, torch.int64), _p(count, torch.int64), cap, _p(X),
+                                      _p(ws), ws.numel(), _stream()), "tf_inner_light_encode")
+    return X
 
 
 def shade_reduce(wgt, lights, n_diffuse, ss):

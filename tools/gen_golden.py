@@ -306,9 +306,52 @@ def gen_refine():
          inv_s=dev_net(torch.zeros(1, 3))[0, 0], unit_size=np.float32(2.0 / (R - 1)))
 
 
+def gen_shading_grad():
+    """Training-direction golden: MCShadingNetwork.forward(step=600) with the flow samplers active (use_flow_*_copy), loss =
+    sum(colors*w) + loss_nis; gradients of every trainable tensor from the reference's autograd."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, o + 2 * unit * d, d)
+    torch.manual_seed(4)
+    cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+               nis_specular_sample_num=8)
+    net = MCShadingNetwork(cfg, trace, AABB)
+    g = torch.Generator().manual_seed(3)
+    net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(0.3 * torch.randn(1, 36, R, R, generator=g)) for _ in range(3)])
+    net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(0.5 + 0.3 * torch.randn(1, 36, R, 1, generator=g)) for _ in range(3)])
+    for fl in (net.flow_diffuse, net.flow_specular, net.flow_diffuse_copy, net.flow_specular_copy):
+        perturb_(list(fl.nis_plane) + list(fl.nis_line), 0.1, 3)
+        perturb_([p for n, p in fl.flows.named_parameters() if "weight" in n], 0.05, 5)
+    with torch.no_grad():
+        net.outer_light.base.add_(0.5 * torch.randn(net.outer_light.base.shape, generator=g))
+    for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
+        for p in fl.parameters():
+            p.requires_grad = False                      # fields.py:1054-1065
+    net.use_flow_diffuse_copy = net.use_flow_specular_copy = True
+    net.eval()
+    pn = 40
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
+    w = torch.rand(pn, 3, generator=g)
+    net.zero_grad()
+    colors, outputs = net(pts, view, nrm, None, 600, False)
+    loss = (colors * w).sum() + outputs["loss_nis"]
+    loss.backward()
+    grads = {"grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    save("shading_grad", sd=net.state_dict(), pts=pts, view_in=view, normals_in=nrm, colors=colors, bwd_w=w,
+         loss_nis=outputs["loss_nis"], loss_nis_diffuse=outputs["loss_nis_diffuse"], loss_nis_specular=outputs["loss_nis_specular"],
+         verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine"]
+    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad"]
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
