@@ -110,3 +110,95 @@ class LightsFn(torch.autograd.Function):
                 out = torch.exp(h.clamp(max=ctx.exp_max))
                 grads = list(torch.autograd.grad(out, wb, g[rows]))
         return (g_base, None, None, None, None, None, None, None, *grads)
+
+
+class CompositeFn(torch.autograd.Function):
+    """(weights, acc, out) = packed-ray compositing (tf_composite_fwd); backward tf_composite_bwd wrt alpha and values."""
+
+    @staticmethod
+    def forward(ctx, alpha, values, ray_indices, n_rays):
+        # the kernel composites up to 8 value channels per launch; wider value rows go through in column chunks
+        a, v = alpha.detach(), values.detach()
+        outs = []
+        for c0 in range(0, v.shape[1], 8):
+            w, acc, o = ops.composite(a, ray_indices, v[:, c0:c0 + 8].contiguous(), n_rays)
+            outs.append(o)
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, -1)
+        ctx.save_for_backward(alpha, values, w, ray_indices)
+        ctx.n_rays = n_rays
+        return w, acc, out
+
+    @staticmethod
+    def backward(ctx, g_w, g_acc, g_out):
+        alpha, values, w, ridx = ctx.saved_tensors
+        # gradient arriving directly on the per-sample weights is folded in as an extra value channel of ones
+        if g_w is not None and bool((g_w != 0).any()):
+            raise RuntimeError("CompositeFn: gradients wrt the per-sample weights are not supported; use acc / out")
+        a, v = alpha.detach(), values.detach()
+        ga, gvs = None, []
+        for c0 in range(0, v.shape[1], 8):
+            # d/d alpha of acc is only counted once (first chunk); later chunks see a zero g_acc
+            gacc = g_acc.contiguous() if c0 == 0 else torch.zeros_like(g_acc)
+            gai, gvi = ops.composite_bwd(a, ridx, v[:, c0:c0 + 8].contiguous(), w, gacc, g_out[:, c0:c0 + 8].contiguous(), ctx.n_rays)
+            ga = gai if ga is None else ga + gai
+            gvs.append(gvi)
+        return ga, (gvs[0] if len(gvs) == 1 else torch.cat(gvs, -1)), None, None
+
+
+def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, inv_s, cos_anneal, aabb, units, n_levels):
+    """Differentiable restatement of tf_sdf_alpha_fwd used ONLY inside SdfAlphaFn.backward: the gather is the HIP kernel pair
+    (VmGatherFn), the two decoder products are library GEMMs over all 7 taps, the rest is elementwise."""
+    import torch.nn.functional as F
+    N = pts.shape[0]
+    u = torch.as_tensor(units, dtype=torch.float32, device=pts.device)
+    offs = torch.zeros(7, 3, device=pts.device)
+    for ax in range(3):
+        offs[1 + 2 * ax, ax] = u[ax]
+        offs[2 + 2 * ax, ax] = -u[ax]
+    P = (pts[None] + offs[:, None]).reshape(-1, 3).contiguous()
+    lv = None if level is None else level.reshape(-1).repeat(7).contiguous()
+    feat = VmGatherFn.apply(P, lv, aabb, n_levels, *planes, *lines)
+    h = F.softplus(F.linear(torch.cat([feat, P], -1), W1, b1), beta=100)
+    s = F.linear(h, W2[:1], b2[:1])[:, 0].view(7, N)
+    app = F.linear(h[:N], W2[1:], b2[1:])
+    sdf = s[0]
+    grad = torch.stack([(s[1 + 2 * ax] - s[2 + 2 * ax]) / (2 * u[ax]) for ax in range(3)], -1)
+    hess = torch.stack([(s[1 + 2 * ax] + s[2 + 2 * ax] - 2 * sdf) / (u[ax] ** 2) for ax in range(3)], -1)
+    nh = (grad * hess).sum(-1) / ((grad ** 2).sum(-1) + 1e-5)
+    true_cos = (dirs * grad).sum(-1)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + F.relu(-true_cos) * cos_anneal)
+    pc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s)
+    nc = torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
+    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+    return alpha, grad, app, sdf, nh
+
+
+class SdfAlphaFn(torch.autograd.Function):
+    """ShapeRenderer.compute_sdf_alpha: forward = the fused HIP kernel (tf_sdf_alpha_fwd).  Backward recomputes through
+    `sdf_alpha_composed` -- HIP gather/scatter for the field, library GEMMs for the decoder (a fused HIP backward of the
+    7-tap decoder is future work) -- and returns gradients for planes, lines, W1, b1, W2, b2 and inv_s."""
+
+    @staticmethod
+    def forward(ctx, pts, level, dists, dirs, inv_s, cos_anneal, aabb, units, n_levels, *params):
+        planes, lines = list(params[:3]), list(params[3:6])
+        W1, b1, W2, b2 = params[6:10]
+        packed = ops.VmPacked(planes, lines, n_levels)
+        alpha, grad, feat, sdf, nh = ops.sdf_alpha(packed, W1.detach(), b1.detach(), W2.detach(), b2.detach(), pts, level, dists, dirs,
+                                                   aabb, units, float(inv_s), cos_anneal)
+        ctx.save_for_backward(pts, level if level is not None else torch.empty(0, device=pts.device), dists, dirs, inv_s, *params)
+        ctx.cfg = (cos_anneal, aabb, units, n_levels, level is not None)
+        return alpha, grad, feat, sdf, nh
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_grad, g_feat, g_sdf, g_nh):
+        pts, level, dists, dirs, inv_s, *params = ctx.saved_tensors
+        cos_anneal, aabb, units, n_levels, has_level = ctx.cfg
+        with torch.enable_grad():
+            leaf = [p.detach().requires_grad_(True) for p in params]
+            inv = inv_s.detach().requires_grad_(True)
+            outs = sdf_alpha_composed(leaf[:3], leaf[3:6], leaf[6], leaf[7], leaf[8], leaf[9], pts, level if has_level else None,
+                                      dists, dirs, inv, cos_anneal, aabb, units, n_levels)
+            gs = [g_alpha, g_grad, g_feat, g_sdf, g_nh]
+            pairs = [(o, g) for o, g in zip(outs, gs) if g is not None]
+            grads = torch.autograd.grad([o for o, _ in pairs], leaf + [inv], [g for _, g in pairs], allow_unused=True)
+        return (None, None, None, None, grads[-1], None, None, None, None, *grads[:-1])

@@ -238,3 +238,35 @@ def test_mcshading_training_step_golden(golden, dev):
             checked += 1
     print("checked", checked, "worst", worst)
     assert checked >= 80
+
+
+def test_sdf_alpha_training_golden(golden, dev):
+    """Shape-stage training direction (geometry): loss over compute_sdf_alpha + compositing; gradients of the SDF planes, lines,
+    decoder and variance vs the reference autograd."""
+    from tensoflow_amd.autograd import CompositeFn, SdfAlphaFn
+    g = golden("march_grad")
+    P = lambda k: g.sd["sdf_network." + k].to(dev).requires_grad_(True)
+    params = [P(f"sdf_plane.{i}") for i in range(3)] + [P(f"sdf_line.{i}") for i in range(3)] + \
+             [P("sdf_mat.0.weight"), P("sdf_mat.0.bias"), P("sdf_mat.2.weight"), P("sdf_mat.2.bias")]
+    var = g.sd["deviation_network.variance"].to(dev).requires_grad_(True)
+    inv_s = torch.exp(var * 10.0)
+    c = lambda k: g[k].to(dev)
+    units = [2.0 / 31] * 3
+    rn = int(g["n_rays"])
+    alpha, grad, feat, sdf, nh = SdfAlphaFn.apply(c("pts"), c("level")[:, 0].contiguous(), c("dists"), c("dirs"), inv_s, 0.5, AABB, units,
+                                                  3, *params)
+    assert rel_err(alpha.detach().cpu(), g["alpha"]) < TOL
+    vals = torch.cat([grad, feat[:, :8]], -1).contiguous()
+    w, acc, out = CompositeFn.apply(alpha, vals, c("ray_indices"), rn)
+    inv_vec = inv_s.expand(alpha.shape[0]).clip(1e-6, 1e6)
+    loss = (acc[:, None] * c("wa")).sum() + (out[:, :3] * c("wn")).sum() + (out[:, 3:] * c("wf")).sum() \
+        + 0.1 * ((grad.norm(dim=-1) - 1.0) ** 2).mean() + 0.01 * nh.abs().mean() + torch.exp(-20.0 * sdf.abs()).mean() \
+        + torch.mean(1 / inv_vec)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
+    loss.backward()
+    names = [f"sdf_network.sdf_plane.{i}" for i in range(3)] + [f"sdf_network.sdf_line.{i}" for i in range(3)] + \
+            ["sdf_network.sdf_mat.0.weight", "sdf_network.sdf_mat.0.bias", "sdf_network.sdf_mat.2.weight", "sdf_network.sdf_mat.2.bias"]
+    for n, p in zip(names + ["deviation_network.variance"], params + [var]):
+        ref = g.grad[n]
+        l2 = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-20))
+        assert l2 < 1e-3, (n, l2)

@@ -349,9 +349,48 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
+def gen_march_grad():
+    """Geometry-only training direction of the ray-march: loss over compute_sdf_alpha + nerfacc compositing outputs
+    (shapeRenderer.py:995-1025, :1166-1206); gradients of the SDF field, decoder and variance from the reference autograd."""
+    from network.shapeRenderer import ShapeRenderer
+    import nerfacc
+    from tensoflow_amd.synth import pinhole_rays
+    R = 32
+    cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False, isBGWhite=True,
+               has_radiance_field=False, clip_sample_variance=False, device="cpu", database_name="tensoSDF/compressor",
+               nerfDataType=True, inv_s_init=0.3)
+    torch.manual_seed(6033)
+    r = ShapeRenderer(cfg, training=False)
+    perturb_(list(r.sdf_network.sdf_plane) + list(r.sdf_network.sdf_line), 0.02, 1)
+    g = torch.Generator().manual_seed(17)
+    rn = 64
+    o, d, radii, cos = [torch.from_numpy(a) for a in pinhole_rays(rn, seed=4)]
+    near, far = r.near_far_from_sphere(o, d)
+    with torch.no_grad():
+        t0, t1, ridx = r.sample_ray(o, d, near, far, 0, radiis=radii, rays_cos=cos)
+    mid = (t0 + t1) * 0.5
+    pts = o[ridx] + d[ridx] * mid[:, None]
+    lv = torch.log2(r.compute_ball_radii(mid[:, None], radii[ridx], cos[ridx]) / r.base_radii)
+    N = pts.shape[0]
+    wa, wn, wf = torch.rand(rn, 1, generator=g), torch.randn(rn, 3, generator=g), torch.randn(rn, 8, generator=g)
+    r.zero_grad()
+    alpha, grad, feat, inv_s, sdf, hess = r.compute_sdf_alpha(pts, lv, t1 - t0, d[ridx], 0.5, 100, True)
+    weights, _ = nerfacc.render_weight_from_alpha(alpha, ray_indices=ridx, n_rays=rn)
+    acc = nerfacc.accumulate_along_rays(weights, values=None, ray_indices=ridx, n_rays=rn)
+    nrm = nerfacc.accumulate_along_rays(weights, values=grad, ray_indices=ridx, n_rays=rn)
+    fac = nerfacc.accumulate_along_rays(weights, values=feat[:, :8], ray_indices=ridx, n_rays=rn)
+    loss = (acc * wa).sum() + (nrm * wn).sum() + (fac * wf).sum() + 0.1 * ((grad.norm(dim=-1) - 1.0) ** 2).mean() \
+        + 0.01 * hess.abs().mean() + torch.exp(-20.0 * sdf.abs()).mean() + torch.mean(1 / inv_s)
+    loss.backward()
+    grads = {"grad/" + k: p.grad for k, p in r.named_parameters() if p.grad is not None}
+    sd = {k: v for k, v in r.state_dict().items() if k.startswith("sdf_network.") and "gaussian" not in k or k.startswith("deviation")}
+    save("march_grad", sd=sd, pts=pts, level=lv, dists=t1 - t0, dirs=d[ridx], ray_indices=ridx, n_rays=np.int64(rn), wa=wa, wn=wn, wf=wf,
+         loss=loss.detach(), alpha=alpha, **grads)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad"]
+    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad", "march_grad"]
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
