@@ -180,6 +180,24 @@ int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_
                        const float* g_out, float* g_base, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Env-light prefilter: EnvLight.build_mips (network/light.py:52-64), rebuilt every shape-stage training step
+ * (network/shapeRenderer.py:1291).  Replaces light_utils.cubemap_mip (network/light_utils.py:66-70) and the renderutils
+ * plugin entry points diffuse_cubemap_fwd/bwd, specular_cubemap_fwd/bwd (network/renderutils/ops.py:391-458,
+ * c_src/cubemap.cu:112-168,239-349; the specular_bounds table of cubemap.cu:178-237 is not needed -- the lobe cone is
+ * culled in-kernel).  All maps are [6,res,res,3] float32.  The *_bwd entry points WRITE the full gradient (no atomics,
+ * no need to zero first).
+ * ------------------------------------------------------------------------------------------ */
+int tf_cubemap_mip_fwd(const float* cube, int32_t res, float* out /*[6,res/2,res/2,3]*/, tf_stream_t stream);
+int tf_cubemap_diffuse_fwd(const float* cube, int32_t res, float* out, tf_stream_t stream);
+int tf_cubemap_diffuse_bwd(const float* g_out, int32_t res, float* g_cube, tf_stream_t stream);
+/* cos_cutoff = cosine of the lobe half-angle keeping `cutoff` of the GGX NDF mass (ops.py:428-441, computed by the host).
+ * out = sum w*cube / sum w; wsum [6,res,res] (may be NULL) receives sum w for the backward. */
+int tf_cubemap_specular_fwd(const float* cube, int32_t res, float roughness, float cos_cutoff, float* out, float* wsum,
+                            tf_stream_t stream);
+int tf_cubemap_specular_bwd(const float* g_out, const float* wsum, int32_t res, float roughness, float cos_cutoff,
+                            float* g_cube, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * First-hit ray/mesh intersection: raytracing.RayTracer.trace (raytracing/raytracer.py:19-54) +
  * MaterialRenderer.trace post-processing (network/materialRenderer.py:253-263).
  * The BVH is built on the host (tf_bvh_build_host) and uploaded by the caller.

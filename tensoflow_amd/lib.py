@@ -63,6 +63,11 @@ SIGNATURES = {
     "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, sz, c_f]),
     "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
+    "tf_cubemap_mip_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
+    "tf_cubemap_diffuse_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
+    "tf_cubemap_diffuse_bwd": (C.c_int, [c_f, i32, c_f, c_f]),
+    "tf_cubemap_specular_fwd": (C.c_int, [c_f, i32, f32, f32, c_f, c_f, c_f]),
+    "tf_cubemap_specular_bwd": (C.c_int, [c_f, c_f, i32, f32, f32, c_f, c_f]),
     "tf_bvh_build_host": (i64, [C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p]),
     "tf_bvh_trace": (C.c_int, [c_f, c_f, i64, c_f, c_f, f32, f32, c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_inner_light_workspace_floats": (sz, []),

@@ -1,4 +1,5 @@
-"""EnvLight (reference: network/light.py:8-162): learnable log-radiance cube map, direct lookup with autograd."""
+"""EnvLight (reference: network/light.py:8-162): learnable log-radiance cube map; prefiltered mip stack (build_mips) and the
+diffuse / roughness-indexed specular fetch of the shape stage, direct fetch of the material stage -- all with autograd."""
 import numpy as np
 import torch
 
@@ -17,6 +18,85 @@ class _CubeLookup(torch.autograd.Function):
         return ops.cube_lookup_bwd(base, dirs, g.contiguous(), apply_exp=True), None
 
 
+def ndf_cutoff(roughness, cutoff=0.99, n=1000000):
+    """cos(theta) keeping `cutoff` of the GGX NDF mass -- renderutils/ops.py:428-441 (__ndfBounds), float64 on the host, cached."""
+    key = (float(roughness), float(cutoff))
+    if key not in _NDF_CUTOFF:
+        a2 = roughness ** 4
+        cos = np.cos(np.linspace(0, np.pi / 2.0, n))
+        c = np.clip(cos, 0.0, 1.0)
+        d = (c * a2 - c) * c + 1.0
+        D = np.cumsum(a2 / (d * d * np.pi))
+        _NDF_CUTOFF[key] = float(cos[np.argmax(D >= D[-1] * cutoff)])
+    return _NDF_CUTOFF[key]
+
+
+_NDF_CUTOFF = {}
+
+
+def _texel_centre_dirs(res, device):
+    """Directions of the texel centres as light_utils.py:72-80 builds them (torch.linspace grid + safe_normalize)."""
+    lin = torch.linspace(-1.0 + 1.0 / res, 1.0 - 1.0 / res, res, device=device)
+    gy, gx = torch.meshgrid(lin, lin, indexing="ij")
+    one = torch.ones_like(gx)
+    faces = [(one, -gy, -gx), (-one, -gy, gx), (gx, one, gy), (gx, -one, -gy), (gx, -gy, one), (-gx, -gy, -one)]
+    v = torch.stack([torch.stack(f, -1) for f in faces])
+    return (v / torch.sqrt(torch.clamp((v * v).sum(-1, keepdim=True), min=1e-20))).reshape(-1, 3).contiguous()
+
+
+class _CubeMip(torch.autograd.Function):
+    """light_utils.cubemap_mip (:66-80): 2x2 box forward; the backward is the reference's surrogate (cube-bilinear fetch of
+    0.25*dout at the fine texel centres), not the exact adjoint."""
+
+    @staticmethod
+    def forward(ctx, cube):
+        return ops.cubemap_mip(cube)
+
+    @staticmethod
+    def backward(ctx, g):
+        res = g.shape[1] * 2
+        out = ops.cube_lookup((g * 0.25).contiguous(), _texel_centre_dirs(res, g.device), apply_exp=False)
+        return out.view(6, res, res, 3)
+
+
+class _CubeDiffuse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cube):
+        return ops.cubemap_diffuse(cube)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.cubemap_diffuse(g.contiguous(), adjoint=True)
+
+
+class _CubeSpecular(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cube, roughness, cos_cutoff):
+        out, wsum = ops.cubemap_specular(cube, roughness, cos_cutoff)
+        ctx.save_for_backward(wsum)
+        ctx.cfg = (roughness, cos_cutoff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (wsum,) = ctx.saved_tensors
+        return ops.cubemap_specular_bwd(g.contiguous(), wsum, *ctx.cfg), None, None
+
+
+class _CubeLookupLinear(torch.autograd.Function):
+    """bilinear cube fetch without the exp (one mip level of EnvLight.__call__), gradient wrt the map only."""
+
+    @staticmethod
+    def forward(ctx, tex, dirs):
+        ctx.save_for_backward(tex, dirs)
+        return ops.cube_lookup(tex, dirs, apply_exp=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        tex, dirs = ctx.saved_tensors
+        return ops.cube_lookup_bwd(tex, dirs, g.contiguous(), apply_exp=False), None
+
+
 class EnvLight(torch.nn.Module):
     def __init__(self, path=None, device=None, scale=1.0, min_res=16, start_res=16, max_res=512, min_roughness=0.08,
                  max_roughness=0.5, trainable=False):
@@ -33,6 +113,46 @@ class EnvLight(torch.nn.Module):
     def upsample(self):
         if self.level > 0:
             self.level = max(self.level - 1, 0)
+
+    def build_mips(self, cutoff=0.99):
+        """light.py:52-64: box mips down to min_res, cosine filter of the coarsest level, GGX filter per level
+        (roughness min..max over levels 0..M-2, 1.0 for the last).  Differentiable wrt `base`."""
+        spec = [self.base]
+        while spec[-1].shape[1] > self.min_res:
+            spec.append(_CubeMip.apply(spec[-1]))
+        self.diffuse = _CubeDiffuse.apply(spec[-1])
+        for idx in range(len(spec) - 1):
+            r = (idx / (len(spec) - 2)) * (self.max_roughness - self.min_roughness) + self.min_roughness
+            spec[idx] = _CubeSpecular.apply(spec[idx], r, ndf_cutoff(r, cutoff))
+        spec[-1] = _CubeSpecular.apply(spec[-1], 1.0, ndf_cutoff(1.0, cutoff))
+        self.specular = spec
+
+    def get_mip(self, roughness):
+        n = len(self.specular)
+        return torch.where(roughness < self.max_roughness,
+                           (roughness.clamp(self.min_roughness, self.max_roughness) - self.min_roughness)
+                           / (self.max_roughness - self.min_roughness) * (n - 2),
+                           (roughness.clamp(self.max_roughness, 1.0) - self.max_roughness) / (1.0 - self.max_roughness) + n - 2)
+
+    def forward(self, l, roughness=None):
+        """light.py:95-122: exp of the cube fetch of the diffuse map, or of the trilinear fetch over the specular stack."""
+        prefix = l.shape[:-1]
+        d = l.reshape(-1, 3).contiguous()
+        if roughness is None:
+            return torch.exp(_CubeLookupLinear.apply(self.diffuse, d)).view(*prefix, -1)
+        n = len(self.specular)
+        mip = self.get_mip(roughness.reshape(-1)).clamp(0, n - 1)
+        l0 = mip.floor().clamp(max=n - 1)
+        f = (mip - l0)[:, None]
+        l0 = l0.long()
+        l1 = (l0 + 1).clamp(max=n - 1)
+        f = torch.where((l1 == l0)[:, None], torch.zeros_like(f), f)
+        out = torch.zeros(d.shape[0], 3, device=d.device)
+        for li, tex in enumerate(self.specular):
+            w = torch.where((l0 == li)[:, None], 1 - f, torch.zeros_like(f)) \
+                + torch.where(((l1 == li) & (l0 != li))[:, None], f, torch.zeros_like(f))
+            out = out + w * _CubeLookupLinear.apply(tex, d)
+        return torch.exp(out).view(*prefix, -1)
 
     def build_mips_direct(self, cutoff=0.99):
         """light.py:66-70: the material stage only ever looks up `base` (direct_light ignores the mips)."""

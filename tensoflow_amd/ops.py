@@ -329,6 +329,48 @@ def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
     return g_base
 
 
+# ------------------------------------------------------------------------------ env-light prefilter
+def _cube(c):
+    c = _f(c)
+    assert c.dim() == 4 and c.shape[0] == 6 and c.shape[1] == c.shape[2] and c.shape[3] == 3, f"bad cube map {tuple(c.shape)}"
+    return c
+
+
+def cubemap_mip(cube):
+    cube = _cube(cube)
+    R = cube.shape[1]
+    out = torch.empty(6, R // 2, R // 2, 3, dtype=torch.float32, device=cube.device)
+    L.check(L.load().tf_cubemap_mip_fwd(_p(cube), R, _p(out), _stream()), "tf_cubemap_mip_fwd")
+    return out
+
+
+def cubemap_diffuse(cube, adjoint=False):
+    cube = _cube(cube)
+    out = torch.empty_like(cube)
+    lib = L.load()
+    fn = lib.tf_cubemap_diffuse_bwd if adjoint else lib.tf_cubemap_diffuse_fwd
+    L.check(fn(_p(cube), cube.shape[1], _p(out), _stream()), "tf_cubemap_diffuse")
+    return out
+
+
+def cubemap_specular(cube, roughness, cos_cutoff):
+    """-> (filtered map, weight sums [6,R,R])"""
+    cube = _cube(cube)
+    out = torch.empty_like(cube)
+    wsum = torch.empty(cube.shape[:3], dtype=torch.float32, device=cube.device)
+    L.check(L.load().tf_cubemap_specular_fwd(_p(cube), cube.shape[1], float(roughness), float(cos_cutoff), _p(out), _p(wsum),
+                                             _stream()), "tf_cubemap_specular_fwd")
+    return out, wsum
+
+
+def cubemap_specular_bwd(g_out, wsum, roughness, cos_cutoff):
+    g_out = _cube(g_out)
+    g = torch.empty_like(g_out)
+    L.check(L.load().tf_cubemap_specular_bwd(_p(g_out), _p(_f(wsum)), g_out.shape[1], float(roughness), float(cos_cutoff), _p(g),
+                                             _stream()), "tf_cubemap_specular_bwd")
+    return g
+
+
 class Bvh:
     """Host-built BVH uploaded to the device (replaces raytracing.RayTracer, raytracing/raytracer.py:7-17)."""
 
