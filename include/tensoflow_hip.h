@@ -180,6 +180,24 @@ int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_
                        const float* g_out, float* g_base, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sample generation for the march.
+ * tf_alpha_mask_sample: AlphaGridMask.sample_alpha(pts) > 0 (network/shapeRenderer.py:78-97, :1120-1121) on a binary
+ *   u8 volume [D,H,W] (W <- x) spanning aabb_host[6]; alive[i] in {0,1}, bit-exact with the reference mask.
+ * tf_march_uniform: fixed-step sampler + occupancy culling + (ray, t)-ordered packing; stands in for
+ *   nerfacc.OccGridEstimator.sampling (shapeRenderer.py:950-959; third-party, unpinned) and is BASELINE configs[1]'s
+ *   "n uniform steps in the aabb slab" when step_size <= 0.  Ray/box slab test and near/far clamp as sample_ray
+ *   (shapeRenderer.py:878-884).  Call twice: (1) offsets = NULL -> counts[rn] = live samples per ray;
+ *   (2) offsets[rn] = exclusive prefix sum of counts -> t_starts/t_ends/ray_indices [sum counts] written densely.
+ *   volume may be NULL (no occupancy culling).
+ * ------------------------------------------------------------------------------------------ */
+int tf_alpha_mask_sample(const uint8_t* volume, int32_t D, int32_t H, int32_t W, const float* aabb_host, const float* pts,
+                         int64_t n, uint8_t* alive, tf_stream_t stream);
+int tf_march_uniform(const float* rays_o, const float* rays_d, const float* near, const float* far, int64_t rn,
+                     int32_t n_steps, float step_size, const float* aabb_host, const uint8_t* volume, int32_t D, int32_t H,
+                     int32_t W, const float* mask_aabb_host, const int64_t* offsets, int64_t* counts, float* t_starts,
+                     float* t_ends, int64_t* ray_indices, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Env-light prefilter: EnvLight.build_mips (network/light.py:52-64), rebuilt every shape-stage training step
  * (network/shapeRenderer.py:1291).  Replaces light_utils.cubemap_mip (network/light_utils.py:66-70) and the renderutils
  * plugin entry points diffuse_cubemap_fwd/bwd, specular_cubemap_fwd/bwd (network/renderutils/ops.py:391-458,

@@ -171,3 +171,35 @@ def render_core(sd, env, fg_lut, o, d, radiis, rays_cos, t0, t1, ridx, aabb, gri
     return dict(ray_rgb=rgb, acc=acc, normal=nrm, gradient_error=(grad.norm(dim=-1) - 1.0) ** 2,
                 std=torch.mean(1 / inv_s), loss_sparse=torch.exp(-20.0 * sdf.abs()).mean(),
                 loss_hessian=nh.abs().mean(), alpha=alpha, weights=w, color=color, sdf=sdf, grad=grad)
+
+
+def alpha_mask_sample(volume, aabb, pts):
+    """AlphaGridMask.sample_alpha (shapeRenderer.py:78-97): trilinear align_corners=True fetch of a [D,H,W] volume."""
+    size = aabb[1] - aabb[0]
+    g = (pts - aabb[0]) * (1.0 / size * 2) - 1
+    vol = volume.float().view(1, 1, *volume.shape[-3:])
+    return F.grid_sample(vol, g.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+
+
+def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume=None, mask_aabb=None):
+    """Fixed-step sampler of the build (stands in for nerfacc's OccGridEstimator.sampling, which is third-party and
+    unpinned): slab test / clamp as sample_ray (shapeRenderer.py:878-884); n_steps uniform intervals of [tmin, tmax]
+    (step_size <= 0) or intervals of step_size from tmin while t < tmax; a sample is kept when its mid-point is inside the
+    aabb and, with an occupancy volume, sample_alpha(mid) > 0.  PARITY: pinned only by the build's own fixtures."""
+    rn = o.shape[0]
+    vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+    ra, rb = (aabb[1] - o) / vec, (aabb[0] - o) / vec
+    tmin = torch.minimum(ra, rb).amax(-1).clamp(min=near.reshape(-1), max=far.reshape(-1))[:, None]
+    tmax = torch.maximum(ra, rb).amin(-1).clamp(min=near.reshape(-1), max=far.reshape(-1))[:, None]
+    step = torch.full_like(tmin, step_size) if step_size > 0 else (tmax - tmin) / n_steps
+    i = torch.arange(n_steps, dtype=torch.float32)[None]
+    t0 = tmin + step * i
+    t1 = t0 + step
+    mid = (t0 + t1) * 0.5
+    p = o[:, None] + d[:, None] * mid[..., None]
+    alive = (step > 0) & (tmax > tmin) & (t0 < tmax) & ~((aabb[0] > p) | (p > aabb[1])).any(-1)
+    if volume is not None:
+        a = alpha_mask_sample(volume, aabb if mask_aabb is None else mask_aabb, p.reshape(-1, 3)).reshape(rn, n_steps)
+        alive = alive & (a > 0)
+    ridx = torch.arange(rn)[:, None].expand(rn, n_steps)
+    return t0[alive], t1[alive], ridx[alive]

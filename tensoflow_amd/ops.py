@@ -329,6 +329,46 @@ def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
     return g_base
 
 
+# ------------------------------------------------------------------------------ march samplers
+def alpha_mask_sample(volume_u8, aabb, pts):
+    """AlphaGridMask.sample_alpha(pts) > 0 -> bool [n]; volume_u8 [D,H,W] in {0,1}."""
+    assert volume_u8.dim() == 3
+    pts = _f(pts)
+    n = pts.shape[0]
+    out = torch.empty(n, dtype=torch.uint8, device=pts.device)
+    D, H, W = volume_u8.shape
+    L.check(L.load().tf_alpha_mask_sample(_p(volume_u8, torch.uint8), D, H, W, C.byref(_aabb6(aabb)), _p(pts), n,
+                                          _p(out, torch.uint8), _stream()), "tf_alpha_mask_sample")
+    return out.bool()
+
+
+def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume_u8=None, mask_aabb=None):
+    """-> t_starts [N], t_ends [N], ray_indices [N] int64 packed by (ray, t).  One host read of N between the two passes."""
+    lib = L.load()
+    o, d, near, far = _f(o), _f(d), _f(near.reshape(-1)), _f(far.reshape(-1))
+    rn = o.shape[0]
+    dev = o.device
+    box = _aabb6(aabb)
+    mbox = _aabb6(aabb if mask_aabb is None else mask_aabb)
+    D, H, W = (0, 0, 0) if volume_u8 is None else volume_u8.shape
+    vol = _p(None if volume_u8 is None else volume_u8, torch.uint8)
+    counts = torch.empty(rn, dtype=torch.int64, device=dev)
+    null = C.c_void_p(0)
+    L.check(lib.tf_march_uniform(_p(o), _p(d), _p(near), _p(far), rn, n_steps, float(step_size), C.byref(box), vol, D, H, W,
+                                 C.byref(mbox), null, _p(counts, torch.int64), null, null, null, _stream()), "tf_march_uniform")
+    incl = torch.cumsum(counts, 0)
+    offsets = (incl - counts).contiguous()
+    n = int(incl[-1]) if rn > 0 else 0
+    t0 = torch.empty(n, dtype=torch.float32, device=dev)
+    t1 = torch.empty(n, dtype=torch.float32, device=dev)
+    ridx = torch.empty(n, dtype=torch.int64, device=dev)
+    if n > 0:
+        L.check(lib.tf_march_uniform(_p(o), _p(d), _p(near), _p(far), rn, n_steps, float(step_size), C.byref(box), vol, D, H, W,
+                                     C.byref(mbox), _p(offsets, torch.int64), null, _p(t0), _p(t1), _p(ridx, torch.int64),
+                                     _stream()), "tf_march_uniform")
+    return t0, t1, ridx
+
+
 # ------------------------------------------------------------------------------ env-light prefilter
 def _cube(c):
     c = _f(c)

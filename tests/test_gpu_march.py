@@ -1,5 +1,6 @@
 """GPU parity of the ray-march composition (sample_ray, render_core, split-sum shading) against the goldens
 generated from the imported reference (ShapeRenderer.sample_ray / render_core / ShapeShadingNetwork.forward)."""
+import numpy as np
 import pytest
 import torch
 
@@ -270,3 +271,48 @@ def test_sdf_alpha_training_golden(golden, dev):
         ref = g.grad[n]
         l2 = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-20))
         assert l2 < 1e-3, (n, l2)
+
+
+def _occupancy(seed=3, n=64):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(*[np.linspace(-1, 1, n)] * 3, indexing="ij")
+    vol = ((x ** 2 + y ** 2 + z ** 2 < 0.55 ** 2) | (rng.random((n, n, n)) < 0.002)).astype(np.uint8)
+    return torch.from_numpy(vol)
+
+
+def test_alpha_mask_sample_bit_exact(dev):
+    """A8: AlphaGridMask.sample_alpha > 0, incl. points outside the aabb and exactly on voxel planes."""
+    from oracle import march as om
+    from tensoflow_amd import ops
+    vol = _occupancy()
+    aabb = AABB.clone()
+    rng = np.random.default_rng(4)
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (200000, 3)).astype(np.float32))
+    lattice = torch.from_numpy(np.linspace(-1, 1, 64).astype(np.float32))
+    pts[:4096, 0] = lattice[torch.from_numpy(rng.integers(0, 64, 4096))]            # exact grid planes: zero weights
+    pts[2048:6144, 1] = lattice[torch.from_numpy(rng.integers(0, 64, 4096))]
+    ref = om.alpha_mask_sample(vol, aabb, pts) > 0
+    got = ops.alpha_mask_sample(vol.to(dev), aabb, pts.to(dev)).cpu()
+    assert torch.equal(got, ref)
+    assert 0.02 < ref.float().mean() < 0.5
+
+
+@pytest.mark.parametrize("mode", ["uniform", "uniform_mask", "fixed_step_mask"])
+def test_march_uniform_matches_oracle(dev, mode):
+    """A7': fixed-step sampler with per-wavefront compaction: packed (ray, t) order and integer ray indices bit-exact."""
+    from oracle import march as om
+    from tensoflow_amd import ops
+    from tensoflow_amd.synth import pinhole_rays
+    o, d, _, _ = [torch.from_numpy(a) for a in pinhole_rays(3000, seed=9)]
+    d[5] = torch.tensor([0.0, 0.0, -1.0]); o[5] = torch.tensor([0.1, 0.2, 2.0])      # zero direction components
+    o[6] = torch.tensor([5.0, 5.0, 5.0])                                              # misses the box
+    near, far = om.near_far_from_sphere(o, d)
+    aabb = AABB.clone()
+    vol = None if mode == "uniform" else _occupancy()
+    n_steps, step = (256, 0.0) if mode != "fixed_step_mask" else (400, 0.011)
+    rt0, rt1, rr = om.march_uniform(o, d, near, far, aabb, n_steps, step, vol)
+    t0, t1, ridx = ops.march_uniform(o.to(dev), d.to(dev), near.to(dev), far.to(dev), aabb, n_steps, step,
+                                     None if vol is None else vol.to(dev))
+    assert ridx.dtype == torch.int64 and torch.equal(ridx.cpu(), rr)
+    assert torch.equal(t0.cpu(), rt0) and torch.equal(t1.cpu(), rt1)
+    assert rr.numel() > 10000
