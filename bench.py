@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Points are sharded across ranks with no data-pat
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -72,41 +73,82 @@ def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
                        f"threads, brute-force visibility over a {len(faces)}-triangle version of the same scene, {dt:.1f} s")
 
 
-def march_probe(device, steps):
-    """Secondary figure (BASELINE config 2): fused sdf-alpha kernel, live march samples/s and algorithmic gather GB/s."""
-    from tensoflow_amd import ops
-    from tensoflow_amd.synth import pinhole_rays, random_sdf_state
+def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
+    """Secondary figure (BASELINE configs[1]): one full 800x800 frame of the shape stage -- fixed-step sampler with occupancy
+    culling (tf_march_uniform), fused 7-tap sdf/FD/alpha kernel, split-sum shading, compositing.  Reports rays/s, live
+    samples/s and the gather roofline of the sdf kernel (18 144 B and 466 944 flop per live sample, level >= ... one mip)."""
+    from tensoflow_amd import march
+    from tensoflow_amd.network.light import EnvLight
+    from tensoflow_amd.shape_shading import ShapeShader
+    from tensoflow_amd.synth import pinhole_rays, random_sdf_state, random_shape_shader_state, synthetic_fg_lut
     R = 300
-    sd = {k: v.to(device) for k, v in random_sdf_state(seed=1, R=R).items()}
-    packed = ops.VmPacked([sd[f"sdf_plane.{i}"] for i in range(3)], [sd[f"sdf_line.{i}"] for i in range(3)], 3)
-    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
-    n_rays, n_steps = 16384, 64
-    o, d, radii, cos = [torch.from_numpy(a).to(device) for a in pinhole_rays(n_rays, seed=2)]
-    t = torch.linspace(1.0, 3.0, n_steps, device=device)[None, :].expand(n_rays, n_steps)
-    pts = (o[:, None] + d[:, None] * t[..., None]).reshape(-1, 3)
-    inside = (pts.abs() < 1).all(-1)
-    pts = pts[inside].contiguous()
-    dirs = d[:, None].expand(n_rays, n_steps, 3).reshape(-1, 3)[inside].contiguous()
-    n = pts.shape[0]
-    level = torch.zeros(n, device=device)             # one mip level touched: 18 144 B / sample
-    dists = torch.full((n,), 2.0 / n_steps, device=device)
-    units = [2.0 / (R - 1)] * 3
-    W = [sd["sdf_mat.0.weight"], sd["sdf_mat.0.bias"], sd["sdf_mat.2.weight"], sd["sdf_mat.2.bias"]]
-    run = lambda: ops.sdf_alpha(packed, *W, pts, level, dists, dirs, aabb, units, 20.0, 1.0)
-    run()
+    sd = {"sdf_network." + k: v for k, v in random_sdf_state(seed=1, R=R).items()}
+    sd.update(random_shape_shader_state(seed=8))
+    field = march.SdfField(sd, [[-1.0, -1, -1], [1, 1, 1]], [R, R, R], 3, device=device)
+    env = EnvLight(trainable=False, max_res=128, device=device)
+    env.base.data = sd["color_network.envlight.base"].to(device)
+    t_env = time.perf_counter()
+    env.build_mips()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    t_env = time.perf_counter() - t_env
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(3):
+        env.build_mips()
+    e1.record()
+    torch.cuda.synchronize()
+    build_mips_ms = e0.elapsed_time(e1) / 3
+    shader = ShapeShader(sd, [s.detach() for s in env.specular], env.diffuse.detach(), synthetic_fg_lut(), device=device)
+    inv_s = math.exp(10 * 0.3)
+    e0.record()
+    mask, _ = march.update_alpha_mask(field, inv_s)
+    e1.record()
+    torch.cuda.synchronize()
+    mask_ms = e0.elapsed_time(e1)
+    o, d, radii, cos = [torch.from_numpy(a).to(device) for a in pinhole_rays(n_rays_total, seed=2)]
+    near, far = march.near_far_from_sphere(o, d)
+    base_radii = 2.0 / 2.0 / R
+    sdf_ms = [0.0]
+    sdf_ev = []
+    orig = field.sdf_alpha
+
+    def timed_sdf_alpha(*a, **k):
+        s, e = ev(), ev()
+        s.record()
+        out = orig(*a, **k)
+        e.record()
+        sdf_ev.append((s, e))
+        return out
+    field.sdf_alpha = timed_sdf_alpha
+
+    def frame():
+        live = 0
+        for c0 in range(0, n_rays_total, chunk):
+            sl = slice(c0, min(c0 + chunk, n_rays_total))
+            t0, t1, ridx = march.march_uniform(field, o[sl], d[sl], near[sl], far[sl], n_steps=n_steps, mask=mask)
+            out = march.render_core(field, o[sl], d[sl], radii[sl], cos[sl], t0, t1, ridx, base_radii, inv_s, 1.0,
+                                    shade_fn=lambda p, n, v, f: shader(p, n, v, f)[0])
+            live += t0.numel()
+        return live, out
+    frame()
+    sdf_ev.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(steps):
-        run()
-    e.record()
+        live, out = frame()
     torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / steps
-    sps = n / (ms * 1e-3)
-    return dict(live_samples=n, ms_per_launch=ms, samples_per_s=sps,
-                algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9, hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS,
-                tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12, mfma_f32_frac=sps * MARCH_FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                workload="TensoSDF R=300 C=36 3 mips, fused 7-tap sdf+FD+alpha, level=0")
+    dt = (time.perf_counter() - t0) / steps
+    sdf_s = sum(s.elapsed_time(e) for s, e in sdf_ev) * 1e-3 / steps
+    sps = live / sdf_s
+    return dict(workload=f"TensoSDF R=300 C=36 3 mips, {n_rays_total} rays x {n_steps} fixed steps, 128^3 occupancy culling, "
+                         f"fused 7-tap sdf+FD+alpha, split-sum shading, compositing (forward)",
+                rays_per_s=n_rays_total / dt, frame_ms=dt * 1e3, live_samples_per_frame=live,
+                live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
+                sdf_alpha_samples_per_s=sps, algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,
+                hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS, tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12,
+                mfma_f32_frac=sps * MARCH_FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                envlight_build_mips_ms=build_mips_ms, update_alpha_mask_ms=mask_ms)
 
 
 def main():

@@ -122,11 +122,66 @@ def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n
     return t[inner], (t + dists)[inner], ridx[inner]
 
 
+class AlphaMask:
+    """AlphaGridMask (shapeRenderer.py:78-97): binary occupancy volume [D,H,W] (u8 on the device) over `aabb`."""
+
+    def __init__(self, aabb, volume):
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).cpu()
+        self.volume = (volume > 0).to(torch.uint8).contiguous()
+
+    def alive(self, pts):
+        return ops.alpha_mask_sample(self.volume, self.aabb, pts)
+
+
 @torch.no_grad()
-def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radii, inv_s, cos_anneal, shade_fn=None):
+def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, mul_length=10, prev: AlphaMask = None, chunk=1 << 21):
+    """ShapeRenderer.updateAlphaMask + compute_gridAlpha + compute_grid_alpha (shapeRenderer.py:257-325): NeuS opacity of one
+    grid step at every lattice point (forced to 1 within mul_length steps of the surface), 3^3 max-pool dilation, threshold.
+    Returns (AlphaMask, new_aabb [2,3]).  The field evaluations run in tf_sdf_forward."""
+    dev = field.device
+    gx, gy, gz = grid
+    lin = [torch.linspace(0, 1, g, device=dev) for g in grid]
+    samples = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)
+    lo, hi = field.aabb_dev[0], field.aabb_dev[1]
+    xyz = lo * (1 - samples) + hi * samples                                    # [gx,gy,gz,3]
+    length = float(((field.aabb[1] - field.aabb[0]) / (torch.tensor(grid, dtype=torch.float32) - 1)).mean())
+    flat = xyz.reshape(-1, 3)
+    alpha = torch.zeros(flat.shape[0], device=dev)
+    for c0 in range(0, flat.shape[0], chunk):
+        p = flat[c0:c0 + chunk].contiguous()
+        live = prev.alive(p) if prev is not None else torch.ones(p.shape[0], dtype=torch.bool, device=dev)
+        sdf = field.sdf(p, None)
+        pc = torch.sigmoid((sdf + length * 0.5) * inv_s)
+        nc = torch.sigmoid((sdf - length * 0.5) * inv_s)
+        a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+        a = torch.where(sdf.abs() < mul_length * length, torch.ones_like(a), a)
+        alpha[c0:c0 + chunk] = torch.where(live, a, torch.zeros_like(a))
+    alpha = alpha.view(gx, gy, gz).clamp(0, 1).transpose(0, 2).contiguous()[None, None]           # [1,1,gz,gy,gx]
+    alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1)[0, 0]
+    vol = alpha >= thres
+    gxyz = xyz.transpose(0, 2)
+    valid = gxyz[vol]
+    new_aabb = torch.stack([valid.amin(0), valid.amax(0)]) if valid.numel() else field.aabb_dev.clone()
+    return AlphaMask(field.aabb, vol), new_aabb
+
+
+@torch.no_grad()
+def march_uniform(field: SdfField, o, d, near, far, n_steps=256, step_size=0.0, mask: AlphaMask = None):
+    """Fixed-step sampler with occupancy culling and per-wavefront compaction (tf_march_uniform) -> packed samples."""
+    return ops.march_uniform(o, d, near, far, field.aabb, n_steps, step_size, None if mask is None else mask.volume,
+                             None if mask is None else mask.aabb)
+
+
+@torch.no_grad()
+def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radii, inv_s, cos_anneal, shade_fn=None,
+                mask: AlphaMask = None):
     """Train-branch forward of ShapeRenderer.render_core with a white background.
-    shade_fn(points, normals, view_dirs, feat) -> color [N,3] (split-sum shading); None -> white (geometry-only march)."""
+    shade_fn(points, normals, view_dirs, feat) -> color [N,3] (split-sum shading); None -> white (geometry-only march).
+    mask: AlphaGridMask culling of the packed samples (shapeRenderer.py:1119-1129)."""
     rn = o.shape[0]
+    if mask is not None:
+        keep = mask.alive((o[ridx] + d[ridx] * ((t0 + t1) * 0.5)[:, None]).contiguous())
+        t0, t1, ridx = t0[keep], t1[keep], ridx[keep]
     mid = (t0 + t1) * 0.5
     dists = t1 - t0
     ro, rd = o[ridx], d[ridx]

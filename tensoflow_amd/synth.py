@@ -176,3 +176,32 @@ def random_sdf_state(seed=1, R=300, C=36, hidden=256, app=128):
     sd["sdf_mat.2.weight"] = math.sqrt(math.pi) / math.sqrt(hidden) + 1e-4 * torch.randn(1 + app, hidden, generator=gen)
     sd["sdf_mat.2.bias"] = torch.full((1 + app,), -0.2)
     return sd
+
+
+def random_shape_shader_state(seed=8, app=128):
+    """ShapeShadingNetwork parameters in the reference layout (network/fields.py:360-371; MLPs of other_field.py:50-84)."""
+    import torch
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, dims in (("mat_mlp", [(app, 128), (128, 128), (128, 5)]), ("inner_light", [(123, 128), (128, 128), (128, 3)]),
+                       ("inner_weight", [(90, 128), (128, 128), (128, 1)])):
+        for l, (fi, fo) in zip((0, 2, 4), dims):
+            _wn_linear(gen, fi, fo, sd, f"color_network.{name}.{l}")
+    sd["color_network.envlight.base"] = math.log(0.5) + 0.5 * torch.randn(6, 128, 128, 3, generator=gen)
+    return sd
+
+
+def synthetic_fg_lut(n=256):
+    """Stand-in for assets/bsdf_256_256.bin (the split-sum DFG table, [1,n,n,2], u = NoV, v = roughness): the analytic
+    fit of Karis' "Real Shading in UE4" mobile approximation -- same shape, range and smoothness; synthetic data for benches."""
+    import torch
+    nov = (torch.arange(n, dtype=torch.float32) + 0.5) / n
+    rough = (torch.arange(n, dtype=torch.float32) + 0.5) / n
+    r, c = torch.meshgrid(rough, nov, indexing="ij")
+    c0 = torch.tensor([-1.0, -0.0275, -0.572, 0.022])
+    c1 = torch.tensor([1.0, 0.0425, 1.04, -0.04])
+    rr = [r * c0[i] + c1[i] for i in range(4)]
+    a004 = torch.minimum(rr[0] * rr[0], torch.exp2(-9.28 * c)) * rr[0] + rr[1]
+    A = -1.04 * a004 + rr[2]
+    B = 1.04 * a004 + rr[3]
+    return torch.stack([A, B], -1)[None].clamp(0, 1).contiguous()
