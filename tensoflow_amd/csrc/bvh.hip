@@ -14,9 +14,15 @@
 #define BVH_MAX_DIST 10.0f
 #define BVH_LEAF 4
 #ifndef BVH_REFILL
-#define BVH_REFILL 48   // idle lanes per wave that trigger a refill from the ray pool
+#define BVH_REFILL 16   // idle lanes per wave that trigger a refill from the ray pool
 #endif
-#define BVH_STACK 64
+#define BVH_CHUNK_MAX 512  // rays a wave takes from the global pool per atomic (shrinks towards BVH_CHUNK_MIN at the end)
+#define BVH_CHUNK_MIN 64
+#define BVH_STACK 32       // per-ray traversal stack entries (LDS); the builder bounds the tree depth to match
+#define BVH_MAX_DEPTH 31   // deepest node level the builder may create (root = 0)
+#ifndef BVH_LEAF_W
+#define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
+#endif
 
 // ----------------------------------------------------------------------------- host build
 namespace {
@@ -40,8 +46,12 @@ struct Builder {
   std::vector<float> cen;  // [nf,3]
   TfBvhNode* nodes;
   int64_t n_nodes = 0;
+  int max_depth = 0;
 
-  void build(int64_t node, int64_t begin, int64_t end) {
+  // levels a balanced subdivision of n triangles still needs below this node
+  static int balanced_levels(int64_t n) { int l = 0; while (n > BVH_LEAF) { n = (n + 1) / 2; ++l; } return l; }
+
+  void build(int64_t node, int64_t begin, int64_t end, int depth) {
     Box b; b.reset();
     Box cb; cb.reset();
     for (int64_t i = begin; i < end; ++i) { b.grow(tbox[order[i]]); cb.grow(&cen[3 * order[i]]); }
@@ -86,12 +96,22 @@ struct Builder {
       mid = it - order.begin();
       if (mid == begin || mid == end) mid = begin + n / 2;
     }
+    // depth bound (the device keeps a BVH_STACK-entry traversal stack per ray): fall back to the median split as soon
+    // as the SAH split could push the subtree below depth BVH_MAX_DEPTH; median halving keeps depth + balanced_levels
+    // non-increasing, so the bound holds by induction.
+    if (depth + 1 + balanced_levels(std::max(mid - begin, end - mid)) > BVH_MAX_DEPTH) {
+      const int ax = best_axis < 0 ? 0 : best_axis;
+      mid = begin + (n + 1) / 2;
+      std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+                       [&](int32_t a, int32_t b) { return cen[3 * a + ax] < cen[3 * b + ax]; });
+    }
+    max_depth = std::max(max_depth, depth + 1);
     const int64_t left = n_nodes;
     n_nodes += 2;
     nd.left = (int32_t)left;
     nd.count = 0;
-    build(left, begin, mid);
-    build(left + 1, mid, end);
+    build(left, begin, mid, depth + 1);
+    build(left + 1, mid, end, depth + 1);
   }
 };
 }  // namespace
@@ -116,7 +136,7 @@ extern "C" int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const 
     for (int a = 0; a < 3; ++a) B.cen[3 * t + a] = c[a] / 3.f;
   }
   B.n_nodes = 1;
-  B.build(0, 0, nf);
+  B.build(0, 0, nf, 0);
   for (int64_t i = 0; i < nf; ++i) {
     int32_t t = B.order[i];
     for (int k = 0; k < 3; ++k)
@@ -125,180 +145,194 @@ extern "C" int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const 
   return B.n_nodes;
 }
 
+// ----------------------------------------------------------------------------- traversal layout (host)
+// The device does not walk TfBvhNode: one traversal step there costs two dependent memory round trips (the node, then
+// its two children).  tf_bvh_pack_host re-lays the tree out as 64-byte PAIRS -- one record per inner node holding BOTH
+// child boxes and both child references -- so a step is one 64-byte fetch (4 x dwordx4), and triangles as 48-byte
+// (a, e1, e2) records (3 x dwordx4; e1 = b - a, e2 = c - a rounded exactly as the kernel used to compute them).
+//   pair (16 floats): lo0.xyz hi0.xyz lo1.xyz hi1.xyz | c0 c1 0 0 (int32)
+//   child reference:  >= 0 pair index;  < -1 leaf = ~((first_triangle << 3) | count), count 1..4;  -1 none
+// Pairs are numbered in depth-first order (a subtree is contiguous; the top of the tree shares cache lines).
+namespace {
+struct Packer {
+  const TfBvhNode* nodes;
+  float* pairs;
+  int64_t n_pairs = 0;
+  static int32_t leaf_ref(const TfBvhNode& n) { return ~(int32_t)(((uint32_t)n.left << 3) | (uint32_t)n.count); }
+  int32_t emit(int64_t node) {   // node is an inner node
+    const TfBvhNode& nd = nodes[node];
+    const int64_t me = n_pairs++;
+    int32_t refs[2];
+    for (int c = 0; c < 2; ++c) {
+      const TfBvhNode& ch = nodes[nd.left + c];
+      float* q = pairs + 16 * me + 6 * c;
+      for (int k = 0; k < 3; ++k) { q[k] = ch.lo[k]; q[3 + k] = ch.hi[k]; }
+      refs[c] = ch.count > 0 ? leaf_ref(ch) : -1;
+    }
+    for (int c = 0; c < 2; ++c)
+      if (nodes[nd.left + c].count == 0) refs[c] = emit(nd.left + c);
+    int32_t* qi = reinterpret_cast<int32_t*>(pairs + 16 * me + 12);
+    qi[0] = refs[0]; qi[1] = refs[1]; qi[2] = 0; qi[3] = 0;
+    return (int32_t)me;
+  }
+};
+}  // namespace
+
+extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const float* tris_host, int64_t nf,
+                                    float* pairs_host, float* tris12_host) {
+  TF_REQUIRE(nodes_host && tris_host && pairs_host && tris12_host, TF_EINVAL, "tf_bvh_pack_host: null pointer");
+  TF_REQUIRE(n_nodes > 0 && nf > 0 && nf < (1LL << 28), TF_ESHAPE, "tf_bvh_pack_host: need n_nodes > 0 and 0 < nf < 2^28");
+  for (int64_t i = 0; i < n_nodes; ++i) {
+    const TfBvhNode& n = nodes_host[i];
+    if (n.count > 0) TF_REQUIRE(n.count <= 7 && n.left >= 0 && (int64_t)n.left + n.count <= nf, TF_ESHAPE,
+                                "tf_bvh_pack_host: leaf %lld out of range", (long long)i);
+    else TF_REQUIRE(n.count == 0 && n.left > 0 && (int64_t)n.left + 1 < n_nodes, TF_ESHAPE,
+                    "tf_bvh_pack_host: inner node %lld has bad children", (long long)i);
+  }
+  Packer P;
+  P.nodes = nodes_host; P.pairs = pairs_host;
+  if (nodes_host[0].count > 0) {
+    // the whole mesh is one leaf: a single pair whose second child is an empty box
+    const TfBvhNode& r = nodes_host[0];
+    for (int k = 0; k < 3; ++k) { pairs_host[k] = r.lo[k]; pairs_host[3 + k] = r.hi[k]; pairs_host[6 + k] = INFINITY; pairs_host[9 + k] = -INFINITY; }
+    int32_t* qi = reinterpret_cast<int32_t*>(pairs_host + 12);
+    qi[0] = Packer::leaf_ref(r); qi[1] = -1; qi[2] = qi[3] = 0;
+    P.n_pairs = 1;
+  } else {
+    P.emit(0);
+  }
+  for (int64_t t = 0; t < nf; ++t) {
+    const float* T = tris_host + 9 * t;
+    float* o = tris12_host + 12 * t;
+    for (int k = 0; k < 3; ++k) { o[k] = T[k]; o[3 + k] = T[3 + k] - T[k]; o[6 + k] = T[6 + k] - T[k]; o[9 + k] = 0.f; }
+  }
+  return P.n_pairs;
+}
+
 // ----------------------------------------------------------------------------- device trace
 #ifdef BVH_STATS
-__device__ unsigned long long g_bvh_stats[4];
+__device__ unsigned long long g_bvh_stats[4];   // inner lane-steps, leaf lane-steps, wave inner iterations x64, wave leaf iterations x64
 extern "C" void tf_bvh_stats(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_stats), 32); unsigned long long z[4] = {0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), z, 32); }
 #endif
-__device__ __forceinline__ bool box_hit(const TfBvhNode& nd, float ox, float oy, float oz, float ix, float iy, float iz,
-                                        float tmax, float& tnear) {
-  float t0 = (nd.lo[0] - ox) * ix, t1 = (nd.hi[0] - ox) * ix;
+
+__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz, float ox, float oy,
+                                        float oz, float ix, float iy, float iz, float tmax, float& tnear) {
+  float t0 = (lx - ox) * ix, t1 = (hx - ox) * ix;
   float tmin = fminf(t0, t1), tmx = fmaxf(t0, t1);
-  t0 = (nd.lo[1] - oy) * iy; t1 = (nd.hi[1] - oy) * iy;
+  t0 = (ly - oy) * iy; t1 = (hy - oy) * iy;
   tmin = fmaxf(tmin, fminf(t0, t1)); tmx = fminf(tmx, fmaxf(t0, t1));
-  t0 = (nd.lo[2] - oz) * iz; t1 = (nd.hi[2] - oz) * iz;
+  t0 = (lz - oz) * iz; t1 = (hz - oz) * iz;
   tmin = fmaxf(tmin, fminf(t0, t1)); tmx = fminf(tmx, fmaxf(t0, t1));
   tnear = tmin;
   // conservative: widen by a few ulps so that a hit the exact triangle test accepts is never culled
   return tmx * 1.0000004f + 1e-6f >= fmaxf(tmin, 0.f) - 1e-6f && tmin <= tmax;
 }
 
-__global__ void __launch_bounds__(256) bvh_trace_kernel(const TfBvhNode* __restrict__ nodes, const float* __restrict__ tris,
-                                                        const float* __restrict__ o, const float* __restrict__ d,
-                                                        float off0, float off1, const unsigned char* __restrict__ live,
-                                                        long long m, float* __restrict__ pos,
-                                                        float* __restrict__ nrm, float* __restrict__ depth,
-                                                        unsigned char* __restrict__ hit) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const float dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
-  // origin = (o + d*off0) + off1*d, with the reference's two separate roundings (no fma contraction)
-  float ox = __fadd_rn(__fadd_rn(o[3 * i], __fmul_rn(dx, off0)), __fmul_rn(off1, dx));
-  float oy = __fadd_rn(__fadd_rn(o[3 * i + 1], __fmul_rn(dy, off0)), __fmul_rn(off1, dy));
-  float oz = __fadd_rn(__fadd_rn(o[3 * i + 2], __fmul_rn(dz, off0)), __fmul_rn(off1, dz));
-  const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz;
-  float best = BVH_MAX_DIST;
-  int best_tri = -1;
-  int stack[BVH_STACK];
-  int sp = 0;
-  int cur = 0;
-  float tn;
-  if (!box_hit(nodes[0], ox, oy, oz, ix, iy, iz, best, tn)) cur = -1;
-  if (live && !live[i]) cur = -1;   // ray carries zero weight in the integral: reported as a miss, never traversed
-#ifdef BVH_STATS
-  unsigned n_inner = 0, n_leaf = 0, n_tri = 0, n_iter = 0;
-#endif
-  while (cur >= 0) {
-    const TfBvhNode nd = nodes[cur];
-#ifdef BVH_STATS
-    n_iter++;
-    if (nd.count > 0) { n_leaf++; n_tri += nd.count; } else n_inner++;
-#endif
-    if (nd.count > 0) {
-      for (int k = 0; k < nd.count; ++k) {
-        const float* T = tris + 9LL * (nd.left + k);
-        const float ax = T[0], ay = T[1], az = T[2];
-        const float e1x = T[3] - ax, e1y = T[4] - ay, e1z = T[5] - az;
-        const float e2x = T[6] - ax, e2y = T[7] - ay, e2z = T[8] - az;
-        const float rx = ox - ax, ry = oy - ay, rz = oz - az;
-        const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-        const float qx = ry * dz - rz * dy, qy = rz * dx - rx * dz, qz = rx * dy - ry * dx;
-        const float det = 1.f / (dx * nx + dy * ny + dz * nz);
-        const float u = det * -(qx * e2x + qy * e2y + qz * e2z);
-        const float v = det * (qx * e1x + qy * e1y + qz * e1z);
-        const float t = det * -(nx * rx + ny * ry + nz * rz);
-        if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) {
-          best = t;
-          best_tri = nd.left + k;
-        }
-      }
-      cur = sp > 0 ? stack[--sp] : -1;
-    } else {
-      float tl, tr;
-      const bool hl = box_hit(nodes[nd.left], ox, oy, oz, ix, iy, iz, best, tl);
-      const bool hr = box_hit(nodes[nd.left + 1], ox, oy, oz, ix, iy, iz, best, tr);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        if (sp < BVH_STACK) stack[sp++] = left_first ? nd.left + 1 : nd.left;
-        cur = left_first ? nd.left : nd.left + 1;
-      } else if (hl) {
-        cur = nd.left;
-      } else if (hr) {
-        cur = nd.left + 1;
-      } else {
-        cur = sp > 0 ? stack[--sp] : -1;
-      }
-    }
-  }
-#ifdef BVH_STATS
-  atomicAdd(&g_bvh_stats[0], (unsigned long long)n_inner); atomicAdd(&g_bvh_stats[1], (unsigned long long)n_leaf);
-  atomicAdd(&g_bvh_stats[2], (unsigned long long)n_tri);
-  { unsigned mx = n_iter; for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); if ((threadIdx.x & 63) == 0) atomicAdd(&g_bvh_stats[3], (unsigned long long)mx * 64ULL); }
-#endif
-  depth[i] = best;
-  if (hit) hit[i] = best < BVH_MAX_DIST ? 1 : 0;
-  if (pos) { pos[3 * i] = ox + best * dx; pos[3 * i + 1] = oy + best * dy; pos[3 * i + 2] = oz + best * dz; }
-  if (nrm) {
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (best_tri >= 0) {
-      const float* T = tris + 9LL * best_tri;
-      const float e1x = T[3] - T[0], e1y = T[4] - T[1], e1z = T[5] - T[2];
-      const float e2x = T[6] - T[0], e2y = T[7] - T[1], e2z = T[8] - T[2];
-      float fx = e1y * e2z - e1z * e2y, fy = e1z * e2x - e1x * e2z, fz = e1x * e2y - e1y * e2x;
-      float inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);   // face normal (raytracing)
-      fx = -fx * inv; fy = -fy * inv; fz = -fz * inv;                         // materialRenderer.py:256
-      inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);          // F.normalize (:257)
-      nx = fx * inv; ny = fy * inv; nz = fz * inv;
-    }
-    nrm[3 * i] = nx; nrm[3 * i + 1] = ny; nrm[3 * i + 2] = nz;
-  }
-}
+struct TraceArgs {
+  const float4* pairs;
+  const float4* tris;
+  const float* o;
+  const float* d;
+  const unsigned char* live;
+  long long m;
+  long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
+  float off0, off1;
+  unsigned long long* counter;
+  float* pos;
+  float* nrm;
+  float* depth;
+  unsigned char* hit;
+};
 
-// ---- persistent variant with dynamic ray fetch.  Measured on the bench scene: a ray visits 22 inner nodes and 0.9
-// leaves on average, but the slowest lane of a statically assigned wave needs 70 steps -- 2/3 of the lanes idle.
-// Here every lane pulls a new ray from a global counter as soon as >= 16 lanes of its wave are idle.
-__global__ void __launch_bounds__(256) bvh_trace_dyn_kernel(const TfBvhNode* __restrict__ nodes, const float* __restrict__ tris,
-                                                            const float* __restrict__ o, const float* __restrict__ d,
-                                                            float off0, float off1, const unsigned char* __restrict__ live,
-                                                            long long m, unsigned long long* __restrict__ counter,
-                                                            float* __restrict__ pos, float* __restrict__ nrm,
-                                                            float* __restrict__ depth, unsigned char* __restrict__ hit) {
-  const int lane = threadIdx.x & 63;
+#define BVH_NONE (-1)
+
+// One lane = one ray.  A wave alternates between INNER steps (lanes whose current reference is a pair test both child
+// boxes, descend into the nearer one and push the other on their LDS stack) and LEAF steps (lanes parked at a leaf
+// intersect its <= 4 triangles and pop): lanes that reach a leaf wait until enough of the wave is at a leaf too, so the
+// ~4x more expensive leaf body is not paid on every iteration for a couple of lanes.  DYN: persistent workgroups, a
+// lane pulls a new ray from a global counter once BVH_REFILL lanes of its wave are idle (a ray needs 5..70 steps).
+template <bool DYN>
+__global__ void __launch_bounds__(256) bvh_trace_kernel(TraceArgs A) {
+  __shared__ int stack[BVH_STACK * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
   long long rid = -1;
-  int cur = -1, sp = 0, best_tri = -1;
+  int cur = BVH_NONE, sp = 0, best_tri = -1;
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, best = BVH_MAX_DIST;
-  int stack[BVH_STACK];
   bool exhausted = false;
-  while (true) {
-    // ---- retire finished rays
-    if (rid >= 0 && cur < 0) {
-      depth[rid] = best;
-      if (hit) hit[rid] = best < BVH_MAX_DIST ? 1 : 0;
-      if (pos) { pos[3 * rid] = ox + best * dx; pos[3 * rid + 1] = oy + best * dy; pos[3 * rid + 2] = oz + best * dz; }
-      if (nrm) {
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        if (best_tri >= 0) {
-          const float* T = tris + 9LL * best_tri;
-          const float e1x = T[3] - T[0], e1y = T[4] - T[1], e1z = T[5] - T[2];
-          const float e2x = T[6] - T[0], e2y = T[7] - T[1], e2z = T[8] - T[2];
-          float fx = e1y * e2z - e1z * e2y, fy = e1z * e2x - e1x * e2z, fz = e1x * e2y - e1y * e2x;
-          float inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
-          fx = -fx * inv; fy = -fy * inv; fz = -fz * inv;
-          inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);
-          nx = fx * inv; ny = fy * inv; nz = fz * inv;
-        }
-        nrm[3 * rid] = nx; nrm[3 * rid + 1] = ny; nrm[3 * rid + 2] = nz;
+  long long q_next = 0, q_end = 0;   // wave-uniform: this wave's private chunk of the ray pool
+  int grab = BVH_CHUNK_MAX;
+#ifdef BVH_STATS
+  unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0;
+#endif
+  auto start_ray = [&](long long id) {
+    rid = id;
+    const long long oid = id / A.rays_per_origin;
+    dx = A.d[3 * id]; dy = A.d[3 * id + 1]; dz = A.d[3 * id + 2];
+    // origin = (o + d*off0) + off1*d, with the reference's two separate roundings (no fma contraction)
+    ox = __fadd_rn(__fadd_rn(A.o[3 * oid], __fmul_rn(dx, A.off0)), __fmul_rn(A.off1, dx));
+    oy = __fadd_rn(__fadd_rn(A.o[3 * oid + 1], __fmul_rn(dy, A.off0)), __fmul_rn(A.off1, dy));
+    oz = __fadd_rn(__fadd_rn(A.o[3 * oid + 2], __fmul_rn(dz, A.off0)), __fmul_rn(A.off1, dz));
+    ix = 1.f / dx; iy = 1.f / dy; iz = 1.f / dz;
+    best = BVH_MAX_DIST; best_tri = -1; sp = 0;
+    cur = 0;
+    if (A.live && !A.live[id]) cur = BVH_NONE;   // zero weight in the integral: reported as a miss, never traversed
+  };
+  auto retire = [&]() {
+    A.depth[rid] = best;
+    if (A.hit) A.hit[rid] = best < BVH_MAX_DIST ? 1 : 0;
+    if (A.pos) { A.pos[3 * rid] = ox + best * dx; A.pos[3 * rid + 1] = oy + best * dy; A.pos[3 * rid + 2] = oz + best * dz; }
+    if (A.nrm) {
+      float nx = 0.f, ny = 0.f, nz = 0.f;
+      if (best_tri >= 0) {
+        const float4 t0 = A.tris[3 * (long long)best_tri], t1 = A.tris[3 * (long long)best_tri + 1], t2 = A.tris[3 * (long long)best_tri + 2];
+        const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
+        float fx = e1y * e2z - e1z * e2y, fy = e1z * e2x - e1x * e2z, fz = e1x * e2y - e1y * e2x;
+        float inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);   // face normal (raytracing)
+        fx = -fx * inv; fy = -fy * inv; fz = -fz * inv;                         // materialRenderer.py:256
+        inv = 1.f / fmaxf(sqrtf(fx * fx + fy * fy + fz * fz), 1e-12f);          // F.normalize (:257)
+        nx = fx * inv; ny = fy * inv; nz = fz * inv;
       }
-      rid = -1;
+      A.nrm[3 * rid] = nx; A.nrm[3 * rid + 1] = ny; A.nrm[3 * rid + 2] = nz;
     }
-    // ---- fetch new rays for idle lanes
-    const unsigned long long active_b = __ballot(rid >= 0);
-    if (!exhausted) {
-      const bool want = rid < 0;
-      const unsigned long long wb = __ballot(want);
-      const int nw = __popcll(wb);
-      if (nw >= BVH_REFILL || active_b == 0ULL) {
-        unsigned long long base = 0;
-        const int leader = __ffsll((long long)wb) - 1;
-        if (lane == leader) base = atomicAdd(counter, (unsigned long long)nw);
-        base = __shfl(base, leader);
-        if (base + (unsigned long long)nw >= (unsigned long long)m) exhausted = true;
+    rid = -1;
+  };
+  if (!DYN) {
+    const long long i = (long long)blockIdx.x * 256 + tid;
+    if (i < A.m) start_ray(i);
+    exhausted = true;
+  }
+  while (true) {
+    if (rid >= 0 && cur == BVH_NONE) retire();
+    if (DYN && !exhausted) {
+      // ---- fetch new rays for idle lanes from the wave's private chunk [q_next, q_end); the chunk itself comes from ONE
+      // global atomic per BVH_CHUNK_MIN..BVH_CHUNK_MAX rays (a single counter word sustains only ~88 M atomics/s -- one
+      // atomic per refill made the counter, not the traversal, the limit).  Dead rays are retired on the spot and the
+      // lane asks again.
+      for (int round = 0; round < 4 && !exhausted; ++round) {
+        const bool want = rid < 0;
+        const unsigned long long wb = __ballot(want);
+        const int nw = __popcll(wb);
+        if (nw == 0 || (round > 0 && nw < BVH_REFILL)) break;
+        if (q_next >= q_end) {
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)grab);
+          base = __shfl(base, 0);
+          if (base >= (unsigned long long)A.m) { exhausted = true; break; }
+          q_next = (long long)base;
+          q_end = min((long long)base + grab, A.m);
+          // guided self-scheduling: chunks shrink as the pool drains so the last chunk of the slowest wave stays short
+          const long long share = (A.m - q_end) / (4LL * gridDim.x * 4);
+          grab = (int)min((long long)BVH_CHUNK_MAX, max((long long)BVH_CHUNK_MIN, share));
+        }
         if (want) {
-          const long long id = (long long)base + __popcll(wb & lt_mask);
-          if (id < m) {
-            rid = id;
-            dx = d[3 * id]; dy = d[3 * id + 1]; dz = d[3 * id + 2];
-            ox = __fadd_rn(__fadd_rn(o[3 * id], __fmul_rn(dx, off0)), __fmul_rn(off1, dx));
-            oy = __fadd_rn(__fadd_rn(o[3 * id + 1], __fmul_rn(dy, off0)), __fmul_rn(off1, dy));
-            oz = __fadd_rn(__fadd_rn(o[3 * id + 2], __fmul_rn(dz, off0)), __fmul_rn(off1, dz));
-            ix = 1.f / dx; iy = 1.f / dy; iz = 1.f / dz;
-            best = BVH_MAX_DIST; best_tri = -1; sp = 0;
-            float tn;
-            cur = box_hit(nodes[0], ox, oy, oz, ix, iy, iz, best, tn) ? 0 : -1;
-            if (live && !live[id]) cur = -1;
+          const long long id = q_next + __popcll(wb & lt_mask);
+          if (id < q_end) {
+            start_ray(id);
+            if (cur == BVH_NONE) retire();
           }
         }
+        q_next = min(q_next + nw, q_end);
       }
     }
     if (__ballot(rid >= 0) == 0ULL) {
@@ -307,14 +341,24 @@ __global__ void __launch_bounds__(256) bvh_trace_dyn_kernel(const TfBvhNode* __r
     }
     // ---- traverse until enough lanes have finished to make a refill worthwhile
     while (true) {
-      if (cur >= 0) {
-        const TfBvhNode nd = nodes[cur];
-        if (nd.count > 0) {
-          for (int k = 0; k < nd.count; ++k) {
-            const float* T = tris + 9LL * (nd.left + k);
-            const float ax = T[0], ay = T[1], az = T[2];
-            const float e1x = T[3] - ax, e1y = T[4] - ay, e1z = T[5] - az;
-            const float e2x = T[6] - ax, e2y = T[7] - ay, e2z = T[8] - az;
+      const int n_inner = __popcll(__ballot(cur >= 0));
+      const int n_leaf = __popcll(__ballot(cur < BVH_NONE));
+      if (n_inner + n_leaf == 0) break;
+      if (n_leaf > 0 && (n_inner == 0 || n_leaf * BVH_LEAF_W >= n_inner)) {
+#ifdef BVH_STATS
+        st_wl++;
+#endif
+        if (cur < BVH_NONE) {
+#ifdef BVH_STATS
+          st_leaf++;
+#endif
+          const int enc = ~cur;
+          const int first = enc >> 3, cnt = enc & 7;
+          for (int k = 0; k < cnt; ++k) {
+            const float4* T = A.tris + 3LL * (first + k);
+            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+            const float ax = t0.x, ay = t0.y, az = t0.z;
+            const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
             const float rx = ox - ax, ry = oy - ay, rz = oz - az;
             const float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
             const float qx = ry * dz - rz * dy, qy = rz * dx - rx * dz, qz = rx * dy - ry * dx;
@@ -322,49 +366,69 @@ __global__ void __launch_bounds__(256) bvh_trace_dyn_kernel(const TfBvhNode* __r
             const float u = det * -(qx * e2x + qy * e2y + qz * e2z);
             const float v = det * (qx * e1x + qy * e1y + qz * e1z);
             const float t = det * -(nx * rx + ny * ry + nz * rz);
-            if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) { best = t; best_tri = nd.left + k; }
+            if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) { best = t; best_tri = first + k; }
           }
-          cur = sp > 0 ? stack[--sp] : -1;
-        } else {
+          cur = sp > 0 ? stack[(--sp) * 256 + tid] : BVH_NONE;
+        }
+      } else {
+#ifdef BVH_STATS
+        st_wi++;
+#endif
+        if (cur >= 0) {
+#ifdef BVH_STATS
+          st_inner++;
+#endif
+          const float4* P = A.pairs + 4LL * cur;
+          const float4 q0 = P[0], q1 = P[1], q2 = P[2];
+          const int4 q3 = *reinterpret_cast<const int4*>(P + 3);
           float tl, tr;
-          const bool hl = box_hit(nodes[nd.left], ox, oy, oz, ix, iy, iz, best, tl);
-          const bool hr = box_hit(nodes[nd.left + 1], ox, oy, oz, ix, iy, iz, best, tr);
+          const bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, best, tl);
+          const bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, best, tr);
           if (hl && hr) {
             const bool left_first = tl <= tr;
-            if (sp < BVH_STACK) stack[sp++] = left_first ? nd.left + 1 : nd.left;
-            cur = left_first ? nd.left : nd.left + 1;
+            stack[(sp++) * 256 + tid] = left_first ? q3.y : q3.x;   // depth <= BVH_MAX_DEPTH bounds sp < BVH_STACK
+            cur = left_first ? q3.x : q3.y;
           } else if (hl) {
-            cur = nd.left;
+            cur = q3.x;
           } else if (hr) {
-            cur = nd.left + 1;
+            cur = q3.y;
           } else {
-            cur = sp > 0 ? stack[--sp] : -1;
+            cur = sp > 0 ? stack[(--sp) * 256 + tid] : BVH_NONE;
           }
         }
       }
-      const int n_act = __popcll(__ballot(cur >= 0));
-      if (n_act == 0 || (!exhausted && n_act <= 64 - BVH_REFILL)) break;
+      if (DYN && !exhausted && __popcll(__ballot(cur == BVH_NONE)) >= BVH_REFILL) break;
     }
   }
+#ifdef BVH_STATS
+  atomicAdd(&g_bvh_stats[0], (unsigned long long)st_inner); atomicAdd(&g_bvh_stats[1], (unsigned long long)st_leaf);
+  if (lane == 0) { atomicAdd(&g_bvh_stats[2], 64ULL * st_wi); atomicAdd(&g_bvh_stats[3], 64ULL * st_wl); }
+#endif
 }
 
-extern "C" int tf_bvh_trace(const TfBvhNode* nodes, const float* tris, int64_t n_nodes, const float* o, const float* d,
-                            float origin_offset0, float origin_offset1, const uint8_t* live, int64_t m, float* pos,
-                            float* nrm, float* depth, uint8_t* hit, int64_t* work_counter, tf_stream_t stream_) {
+extern "C" int tf_bvh_trace(const float* pairs, const float* tris12, int64_t n_pairs, const float* o, const float* d,
+                            int64_t rays_per_origin, float origin_offset0, float origin_offset1, const uint8_t* live,
+                            int64_t m, float* pos, float* nrm, float* depth, uint8_t* hit, int64_t* work_counter,
+                            tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TF_REQUIRE(m >= 0 && n_nodes > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
+  TF_REQUIRE(m >= 0 && n_pairs > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
+  TF_REQUIRE(rays_per_origin >= 1, TF_ESHAPE, "tf_bvh_trace: rays_per_origin must be >= 1");
   if (m == 0) return TF_OK;
-  TF_REQUIRE(nodes && tris && o && d && depth, TF_EINVAL, "tf_bvh_trace: null pointer");
+  TF_REQUIRE(pairs && tris12 && o && d && depth, TF_EINVAL, "tf_bvh_trace: null pointer");
+  TF_REQUIRE((((uintptr_t)pairs | (uintptr_t)tris12) & 15) == 0, TF_EINVAL, "tf_bvh_trace: pairs / tris12 must be 16-byte aligned");
+  TraceArgs A;
+  A.pairs = reinterpret_cast<const float4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
+  A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin;
+  A.off0 = origin_offset0; A.off1 = origin_offset1; A.counter = (unsigned long long*)work_counter;
+  A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit;
   if (work_counter) {
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int64_t), stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_bvh_trace: hipMemsetAsync failed: %s", hipGetErrorString(e));
     long long blocks = (m + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;   // 8 resident 256-thread blocks per CU pull rays until the pool is empty
-    bvh_trace_dyn_kernel<<<(unsigned)blocks, 256, 0, stream>>>(nodes, tris, o, d, origin_offset0, origin_offset1, live, m,
-                                                              (unsigned long long*)work_counter, pos, nrm, depth, hit);
+    if (blocks > 256 * 5) blocks = 256 * 5;   // 5 resident 256-thread blocks per CU (32 KB of LDS stack each) pull rays until the pool is empty
+    bvh_trace_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(A);
   } else {
-    bvh_trace_kernel<<<tf_blocks(m, 256), 256, 0, stream>>>(nodes, tris, o, d, origin_offset0, origin_offset1, live, m,
-                                                          pos, nrm, depth, hit);
+    bvh_trace_kernel<false><<<tf_blocks(m, 256), 256, 0, stream>>>(A);
   }
   TF_LAUNCH_CHECK("tf_bvh_trace");
   return TF_OK;

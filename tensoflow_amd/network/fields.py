@@ -143,7 +143,7 @@ class MCShadingNetwork(nn.Module):
                                                               ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit)
         T = dirs.shape[1]
         nd = sd + self._fixed.shape[0]
-        pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3).contiguous()
+        pts_rep = pts.contiguous()                       # T rays per origin row (tf_bvh_trace rays_per_origin)
         inner_wb = []
         for i in (0, 2, 4, 6):
             inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)

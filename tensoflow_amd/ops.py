@@ -426,12 +426,22 @@ class Bvh:
         if n <= 0:
             L.check(int(n), "tf_bvh_build_host")
         self.n_nodes = int(n)
-        self.nodes = torch.from_numpy(nodes[:n].copy()).to(device)
-        self.tris = torch.from_numpy(tris).to(device)
+        pairs = np.zeros((n // 2 + 1, 16), dtype=np.float32)
+        tris12 = np.zeros((f.shape[0], 12), dtype=np.float32)
+        npair = self.lib.tf_bvh_pack_host(nodes.ctypes.data, int(n), tris.ctypes.data, f.shape[0], pairs.ctypes.data, tris12.ctypes.data)
+        if npair <= 0:
+            L.check(int(npair), "tf_bvh_pack_host")
+        self.n_pairs = int(npair)
+        self.pairs = torch.from_numpy(pairs[:npair].copy()).to(device)
+        self.tris = torch.from_numpy(tris12).to(device)
 
     def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True):
+        """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3]."""
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
-        m = o.shape[0]
+        m = d.shape[0]
+        if o.shape[0] == 0 or m % o.shape[0] != 0:
+            raise RuntimeError(f"Bvh.trace: {m} directions cannot share {o.shape[0]} origins")
+        per_origin = m // o.shape[0]
         dev = o.device
         pos = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_pos else None
         nrm = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_nrm else None
@@ -439,7 +449,7 @@ class Bvh:
         hit = torch.empty(m, dtype=torch.uint8, device=dev)
         lv = None if live is None else live.reshape(-1).contiguous()
         ctr = torch.empty(1, dtype=torch.int64, device=dev) if dynamic else None
-        L.check(self.lib.tf_bvh_trace(_p(self.nodes), _p(self.tris), self.n_nodes, _p(o), _p(d), float(off0), float(off1),
+        L.check(self.lib.tf_bvh_trace(_p(self.pairs), _p(self.tris), self.n_pairs, _p(o), _p(d), per_origin, float(off0), float(off1),
                                       _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
                                       _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()

@@ -162,7 +162,7 @@ class MCShader:
         return out["metallic"], rough, out["albedo"]
 
     def lights(self, pts_rep, dirs, live=None):
-        """get_lights (fields.py:951-975): pts_rep, dirs [M,3] -> lights [M,3], hit [M] bool.
+        """get_lights (fields.py:951-975): pts_rep [M,3] (or [M // T, 3]: T consecutive rays per origin), dirs [M,3] -> lights [M,3], hit [M] bool.
         live [M] uint8 (optional): rays whose weight in the integral is exactly zero are neither traced nor shaded."""
         T = self.timer
         with T.stage("bvh_trace"):
@@ -197,9 +197,8 @@ class MCShader:
         with tm.stage("shade_dirs"):
             dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
         T = dirs.shape[1]
-        with tm.stage("light_merge"):
-            pts_rep = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
-        lights, hit, inters = self.lights(pts_rep, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
+        # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built
+        lights, hit, inters = self.lights(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
             colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)

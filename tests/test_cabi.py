@@ -85,6 +85,69 @@ def test_bvh_build_host(lib):
     assert lib.tf_bvh_build_host(v.ctypes.data, len(v), bad.ctypes.data, len(f), nodes.ctypes.data, tris.ctypes.data) == -2
 
 
+def test_bvh_pack_host(lib):
+    """Traversal layout: every triangle is reachable through exactly one leaf reference, child boxes are the nodes' boxes,
+    the tree respects the depth bound of the device stack, triangles are stored as (a, b - a, c - a)."""
+    from tensoflow_amd.synth import sphere_torus_mesh
+    v, f = sphere_torus_mesh(16, 24, 32, 12)
+    nodes = np.zeros((2 * len(f), 8), np.float32)
+    tris = np.zeros((len(f), 9), np.float32)
+    n = lib.tf_bvh_build_host(v.ctypes.data, len(v), f.ctypes.data, len(f), nodes.ctypes.data, tris.ctypes.data)
+    pairs = np.zeros((n // 2 + 1, 16), np.float32)
+    t12 = np.zeros((len(f), 12), np.float32)
+    npair = lib.tf_bvh_pack_host(nodes.ctypes.data, n, tris.ctypes.data, len(f), pairs.ctypes.data, t12.ctypes.data)
+    assert npair == (n - 1) // 2
+    refs = pairs[:npair, 12:14].view(np.int32)
+    seen = np.zeros(len(f), np.int32)
+    visited = np.zeros(npair, np.int32)
+    stack, max_depth = [(0, 1)], 0
+    while stack:
+        i, depth = stack.pop()
+        visited[i] += 1
+        max_depth = max(max_depth, depth)
+        for c in range(2):
+            r = int(refs[i, c])
+            box = pairs[i, 6 * c:6 * c + 6]
+            if r >= 0:
+                assert r > i                                   # depth-first numbering
+                stack.append((r, depth + 1))
+            else:
+                enc = ~r
+                first, cnt = enc >> 3, enc & 7
+                assert 1 <= cnt <= 4
+                seen[first:first + cnt] += 1
+                t = tris[first:first + cnt].reshape(-1, 3)
+                assert (t >= box[:3] - 1e-6).all() and (t <= box[3:] + 1e-6).all()
+    assert (seen == 1).all() and (visited == 1).all() and max_depth <= 31
+    assert np.array_equal(t12[:, 0:3], tris[:, 0:3]) and np.array_equal(t12[:, 3:6], tris[:, 3:6] - tris[:, 0:3])
+    assert np.array_equal(t12[:, 6:9], tris[:, 6:9] - tris[:, 0:3])
+    # a mesh that fits one leaf still packs to one (degenerate) pair
+    v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    f1 = np.array([[0, 1, 2], [0, 1, 3]], np.int32)
+    nodes1 = np.zeros((4, 8), np.float32); tris1 = np.zeros((2, 9), np.float32)
+    n1 = lib.tf_bvh_build_host(v1.ctypes.data, 4, f1.ctypes.data, 2, nodes1.ctypes.data, tris1.ctypes.data)
+    p1 = np.zeros((2, 16), np.float32); t1 = np.zeros((2, 12), np.float32)
+    assert n1 == 1 and lib.tf_bvh_pack_host(nodes1.ctypes.data, 1, tris1.ctypes.data, 2, p1.ctypes.data, t1.ctypes.data) == 1
+    assert p1[0, 12:14].view(np.int32).tolist() == [~((0 << 3) | 2), -1]
+
+
+def test_bvh_depth_bound_on_degenerate_mesh(lib):
+    """A sliver fan (SAH degenerates to a chain) must still respect the depth bound."""
+    k = 4000
+    ang = np.linspace(0, 1e-3, k + 1).astype(np.float32)
+    v = np.concatenate([np.zeros((1, 3), np.float32), np.stack([np.cos(ang), np.sin(ang), ang * 0 + np.arange(k + 1, dtype=np.float32) ** 3 * 1e-9], 1)])
+    f = np.stack([np.zeros(k, np.int32), np.arange(1, k + 1, dtype=np.int32), np.arange(2, k + 2, dtype=np.int32)], 1)
+    nodes = np.zeros((2 * k, 8), np.float32); tris = np.zeros((k, 9), np.float32)
+    n = lib.tf_bvh_build_host(v.ctypes.data, len(v), f.ctypes.data, k, nodes.ctypes.data, tris.ctypes.data)
+    assert n > 0
+    cnt = nodes[:n, 7].view(np.int32); left = nodes[:n, 3].view(np.int32)
+    depth = np.zeros(n, np.int32)
+    for i in range(n):
+        if cnt[i] == 0:
+            depth[left[i]] = depth[left[i] + 1] = depth[i] + 1        # children always follow their parent
+    assert depth.max() <= 31 and cnt[cnt > 0].sum() == k
+
+
 def test_ops_fail_loudly_without_gpu():
     import torch
     from tensoflow_amd import ops
