@@ -38,6 +38,9 @@ typedef enum TfStatus {
  * TF_PREC_F16X3: every operand split x = hi + lo in f16 and a_hi*b_hi + a_hi*b_lo + a_lo*b_hi accumulated in
  * fp32 on v_mfma_f32_32x32x16_f16 (22 significant bits per operand; 5.3x fewer matrix-core cycles). */
 typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1 } TfPrecision;
+/* OR-ed into a `precision` argument: `workspace` still holds this network's packed weights from an earlier call with
+ * the same weights and precision (the caller tracks weight updates), so the fragment re-pack launches are skipped. */
+#define TF_WEIGHTS_PACKED 0x100
 
 int tf_version(void);
 const char* tf_last_error(void);
@@ -288,6 +291,35 @@ int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm,
 /* idx[0 .. *count) = indices i with mask[i] != 0 (unordered); *count is zeroed by the call (replaces the boolean-mask
  * indexing of fields.py:962-971). */
 int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-surface-point preparation of the rendering integral in ONE launch (the reference runs ~30):
+ *   MCShadingNetwork.tenso_feature + predict_materials (network/fields.py:776-810, :1010-1017):
+ *     VM gather (C = 36, level 0) -> weight-norm MLPs 108-128-{1,1,3} (ReLU, sigmoid),
+ *     roughness = r * (1 - rough_min^2) + rough_min^2;
+ *   TensoFlow.tenso_feature of the diffuse and specular flows (network/flow.py:709-744) and the condition row
+ *     cat[feat16, embed3(view_angles) 14, 0 * embed3(rough) 7] of TensoFlow.sample / .forward (:836-848, :803-815).
+ * tf_point_pack: weights in torch layout (weight-norm folded by the caller) -> MFMA fragment order in `workspace`
+ *   (tf_point_workspace_floats() floats, caller-owned); call once per weight update.
+ * tf_point_fwd: pts [pn,3], view_angles [pn,2] (tf_view_angles) -> metallic [pn], roughness [pn], albedo [pn,3],
+ *   cond_d / cond_s [pn,37].  All three fields share `aabb_host` [2,3].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfPointNets {
+  const float* mat_w1[3]; /* metallic, roughness, albedo: [128,108] */
+  const float* mat_b1[3]; /* [128] */
+  const float* mat_w2[3]; /* [1,128] [1,128] [3,128] */
+  const float* mat_b2[3];
+  const float* nis_w1[2]; /* diffuse, specular flow: nis_mat.0 [64,57] */
+  const float* nis_b1[2];
+  const float* nis_w2[2]; /* nis_mat.2 [16,64] */
+  const float* nis_b2[2];
+} TfPointNets;
+size_t tf_point_workspace_floats(void);
+int tf_point_pack(const TfPointNets* nets, float* workspace, size_t workspace_floats, tf_stream_t stream);
+int tf_point_fwd(const float* workspace, const TfVmDesc* mat_desc, const float* mat_packed, const TfVmDesc* flow_d_desc,
+                 const float* flow_d_packed, const TfVmDesc* flow_s_desc, const float* flow_s_packed,
+                 const float* aabb_host, const float* pts, const float* view_angles, int64_t pn, float rough_min,
+                 float* metallic, float* roughness, float* albedo, float* cond_d, float* cond_s, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Monte-Carlo shading integral, MCShadingNetwork.shade_mixed (network/fields.py:1075-1235),

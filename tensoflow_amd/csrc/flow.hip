@@ -341,6 +341,8 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
                        const float* x, const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, float* out_xy,
                        float* out_lj, int32_t* bins, int32_t precision, float* workspace, size_t workspace_floats,
                        hipStream_t stream, const char* who) {
+  const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
+  precision &= ~TF_WEIGHTS_PACKED;
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
   TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
   if (m == 0) return TF_OK;
@@ -358,7 +360,8 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   float* netfrag = workspace;
   float* P = workspace + kWsNet;
   const bool h3 = precision == TF_PREC_F16X3;
-  if (int rc = h3 ? pack_nets_h3(nets, netfrag, stream) : pack_nets(nets, netfrag, stream)) return rc;
+  if (!packed)
+    if (int rc = h3 ? pack_nets_h3(nets, netfrag, stream) : pack_nets(nets, netfrag, stream)) return rc;
   flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
                                                                          nets[1].b[0], cond, pn, P);
   const size_t lds = (size_t)kWsNet * sizeof(float);

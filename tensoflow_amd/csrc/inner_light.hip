@@ -113,6 +113,13 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     // ---- encodings (each lane computes all 123 and keeps the half its MFMA operand slots need)
     float enc[128];
     const float p[3] = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
+#ifdef TF_ABLATE_ENC   // dev-only timing ablation
+#pragma unroll
+    for (int k = 0; k < 128; ++k) enc[k] = p[k % 3] * (float)k + nrm[3 * src] + view[3 * src];
+    if (false) {
+#else
+    {
+#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) enc[k] = p[k];
 #pragma unroll
@@ -161,6 +168,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     }
 #pragma unroll
     for (int k = 123; k < 128; ++k) enc[k] = 0.f;
+    }
     f32x16 a[8], b[8];
     {
       f32x16 in1[4];
@@ -199,33 +207,37 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
                               int32_t precision, float* out, float* workspace, size_t workspace_floats, hipStream_t stream,
                               const char* who) {
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
+  const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
+  precision &= ~TF_WEIGHTS_PACKED;
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kInnerWsFloats);
   for (int l = 0; l < 4; ++l) TF_REQUIRE(net->w[l] && net->b[l], TF_EINVAL, "%s: null weight pointer (layer %d)", who, l);
-  if (precision == TF_PREC_F32) {
-    tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
-  } else {
-    _Float16* hw = reinterpret_cast<_Float16*>(workspace);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
+  if (!packed) {
+    if (precision == TF_PREC_F32) {
+      tf_pack_wfrag_kernel<<<tf_blocks(8 * 64 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 64, workspace + kI1, 1);
+      tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 128, workspace + kI2, 1);
+      tf_pack_wfrag_kernel<<<tf_blocks(8 * 128 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 128, workspace + kI3, 1);
+      tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
+    } else {
+      _Float16* hw = reinterpret_cast<_Float16*>(workspace);
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
+    }
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
+    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[3], 3, 1, workspace + kIB4);
+    static float ide_host[17 * 36];
+    static bool ide_ready = false;
+    if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
+    hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+    TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   }
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[3], 3, 1, workspace + kIB4);
-  static float ide_host[17 * 36];
-  static bool ide_ready = false;
-  if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
-  hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
-  TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   long long blocks = (m + 127) / 128;
   if (blocks > 1024) blocks = 1024;
   if (precision == TF_PREC_F32)

@@ -101,9 +101,11 @@ typedef __attribute__((address_space(3))) void* tf_lptr_t;
 // each of the 4 waves moves 4 pieces of 1 KB (lane l supplies the source address of its 16 bytes).
 __device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*1024 + lane*4 */, float* __restrict__ lbuf,
                                             int wave) {
+#ifndef TF_ABLATE_DMA   // dev-only timing ablation (tools/build_variant.sh): results are garbage when defined
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
+#endif
 }
 
 template <int N>

@@ -202,8 +202,8 @@ def _coupling_nets(weights):
     return nets, keep
 
 
-def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1):
-    """-> angles [pn,sn,2], logj [pn,sn,1] (, bins [pn,sn,2] int32)."""
+def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1, cache=None):
+    """-> angles [pn,sn,2], logj [pn,sn,1] (, bins [pn,sn,2] int32).  cache: optional PackCache owned by this flow."""
     lib = L.load()
     cond, latent = _f(cond), _f(latent)
     pn, sn = cond.shape[0], latent.shape[0]
@@ -214,10 +214,14 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
     ang = torch.empty(pn, sn, 2, dtype=torch.float32, device=dev)
     lj = torch.empty(pn, sn, 1, dtype=torch.float32, device=dev)
     bins = torch.empty(pn, sn, 2, dtype=torch.int32, device=dev) if want_bins else None
-    ws = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev)
+    if cache is None:
+        ws, flag = _workspace("flow", lib.tf_flow_workspace_floats(pn), dev), 0
+    else:
+        ws = cache.workspace(lib.tf_flow_workspace_floats(pn), dev)
+        flag = cache.flag(keep, precision)
     jit = None if jitter is None else _f(jitter.reshape(pn, sn))
     L.check(lib.tf_flow_sample_fwd(C.byref(nets), _p(cond), _p(latent), _p(jit), pn, sn, _p(ang), _p(lj), _p(bins, torch.int32),
-                                   int(precision), _p(ws), ws.numel(), _stream()), "tf_flow_sample_fwd")
+                                   int(precision) | flag, _p(ws), ws.numel(), _stream()), "tf_flow_sample_fwd")
     return (ang, lj, bins) if want_bins else (ang, lj)
 
 
@@ -309,13 +313,17 @@ def _mlp4(weights):
     return net, keep
 
 
-def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=5.0, precision=1):
+def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=5.0, precision=1, cache=None):
     """In place: lights[i] = inner_light(pos[i], -dirs[i], nrm[i]) * (depth[i] > near_eps) for i in idx[:count]."""
     lib = L.load()
     net, keep = _mlp4(weights)
-    ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pos.device)
+    if cache is None:
+        ws, flag = _workspace("inner", lib.tf_inner_light_workspace_floats(), pos.device), 0
+    else:
+        ws = cache.workspace(lib.tf_inner_light_workspace_floats(), pos.device)
+        flag = cache.flag(keep, precision)
     L.check(lib.tf_inner_light_indexed_fwd(C.byref(net), _p(pos), _p(dirs), _p(nrm), _p(idx, torch.int64), _p(count, torch.int64),
-                                           idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision), _p(lights),
+                                           idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision) | flag, _p(lights),
                                            _p(ws), ws.numel(), _stream()), "tf_inner_light_indexed_fwd")
     return lights
 
@@ -455,7 +463,82 @@ class Bvh:
         return pos, nrm, depth, hit.bool()
 
 
+class PointPrep:
+    """Fused per-point stage (tf_point_pack / tf_point_fwd): materials + both flow condition rows in one launch.
+    mat_nets: {"metallic" | "roughness" | "albedo": [(W1 [128,108], b1), (W2, b2)]} (weight-norm folded);
+    nis_nets: [diffuse, specular] each [(W1 [64,57], b1), (W2 [16,64], b2)]."""
+
+    def __init__(self, mat_packed: VmPacked, flow_d_packed: VmPacked, flow_s_packed: VmPacked, mat_nets, nis_nets, aabb,
+                 rough_min=0.04):
+        self.lib = L.load()
+        self.fields = (mat_packed, flow_d_packed, flow_s_packed)
+        self.aabb6 = _aabb6(aabb)
+        self.rough_min = float(rough_min)
+        dev = mat_packed.data.device
+        self.ws = torch.empty(int(self.lib.tf_point_workspace_floats()), dtype=torch.float32, device=dev)
+        self.repack(mat_nets, nis_nets)
+
+    def repack(self, mat_nets, nis_nets):
+        nets = L.TfPointNets()
+        keep = []
+        for n, name in enumerate(("metallic", "roughness", "albedo")):
+            (w1, b1), (w2, b2) = mat_nets[name]
+            t = [_f(w1), _f(b1), _f(w2), _f(b2)]
+            if tuple(t[0].shape) != (128, 108) or t[2].shape[1] != 128 or t[2].shape[0] != (3 if name == "albedo" else 1):
+                raise RuntimeError(f"PointPrep: {name} predictor has shapes {tuple(t[0].shape)}, {tuple(t[2].shape)}")
+            keep += t
+            nets.mat_w1[n], nets.mat_b1[n], nets.mat_w2[n], nets.mat_b2[n] = [x.data_ptr() for x in t]
+        for f in range(2):
+            (w1, b1), (w2, b2) = nis_nets[f]
+            t = [_f(w1), _f(b1), _f(w2), _f(b2)]
+            if tuple(t[0].shape) != (64, 57) or tuple(t[2].shape) != (16, 64):
+                raise RuntimeError(f"PointPrep: flow feature net {f} has shapes {tuple(t[0].shape)}, {tuple(t[2].shape)}")
+            keep += t
+            nets.nis_w1[f], nets.nis_b1[f], nets.nis_w2[f], nets.nis_b2[f] = [x.data_ptr() for x in t]
+        for t in keep:
+            _p(t)
+        L.check(self.lib.tf_point_pack(C.byref(nets), _p(self.ws), self.ws.numel(), _stream()), "tf_point_pack")
+
+    def __call__(self, pts, view_angles):
+        """-> metallic [pn,1], roughness [pn,1], albedo [pn,3], cond_d [pn,37], cond_s [pn,37]"""
+        pts, va = _f(pts), _f(view_angles)
+        pn, dev = pts.shape[0], pts.device
+        met = torch.empty(pn, 1, dtype=torch.float32, device=dev)
+        rough = torch.empty(pn, 1, dtype=torch.float32, device=dev)
+        alb = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+        cd = torch.empty(pn, 37, dtype=torch.float32, device=dev)
+        cs = torch.empty(pn, 37, dtype=torch.float32, device=dev)
+        m, fd, fs = self.fields
+        L.check(self.lib.tf_point_fwd(_p(self.ws), C.byref(m.desc), _p(m.data), C.byref(fd.desc), _p(fd.data), C.byref(fs.desc),
+                                      _p(fs.data), C.byref(self.aabb6), _p(pts), _p(va), pn, self.rough_min, _p(met), _p(rough),
+                                      _p(alb), _p(cd), _p(cs), _stream()), "tf_point_fwd")
+        return met, rough, alb, cd, cs
+
+
 PREC_F32, PREC_F16X3 = 0, 1
+WEIGHTS_PACKED = 0x100
+
+
+class PackCache:
+    """Caller-side memo for ONE network's packed-weight workspace: repeated calls with unchanged weights pass
+    TF_WEIGHTS_PACKED and skip the fragment re-pack launches (the library itself is stateless).  Weight updates are
+    detected through (data_ptr, torch _version) of every weight tensor."""
+
+    def __init__(self):
+        self.ws = None
+        self.key = None
+
+    def workspace(self, n_floats, device):
+        if self.ws is None or self.ws.numel() < n_floats or self.ws.device != torch.device(device):
+            self.ws = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+            self.key = None
+        return self.ws
+
+    def flag(self, tensors, precision):
+        key = (int(precision), tuple((t.data_ptr(), t._version) for t in tensors))
+        hit = key == self.key
+        self.key = key
+        return WEIGHTS_PACKED if hit else 0
 
 
 def inner_light(weights, pts, view, nrm, exp_max=5.0, precision=PREC_F16X3):

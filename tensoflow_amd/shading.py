@@ -100,6 +100,21 @@ class _NoTimer:
         pass
 
 
+class ShadeOutputs(dict):
+    """Output dict of MCShader.shade.  `specular_rays_id` (fields.py:1209-1212: the point index of every unmasked specular
+    sample) has a data-dependent length, so building it forces a device->host sync; it is derived from `specular_mask` on
+    first access instead of on every call (the eval integral never reads it)."""
+
+    def __missing__(self, key):
+        if key != "specular_rays_id":
+            raise KeyError(key)
+        smask = self["specular_mask"]
+        pn, ss = smask.shape
+        rid = torch.arange(pn, device=smask.device)[:, None].expand(pn, ss)[smask]
+        self[key] = rid
+        return rid
+
+
 class FlowParams:
     """One TensoFlow (nis planes/lines + nis_mat + 2 coupling nets) resident on the device."""
 
@@ -110,6 +125,7 @@ class FlowParams:
         self.packed = ops.VmPacked(self.planes, self.lines, n_levels)
         self.mat = [(g("nis_mat.0.weight"), g("nis_mat.0.bias")), (g("nis_mat.2.weight"), g("nis_mat.2.bias"))]
         self.nets = [[(g(f"flows.{b}.nn.{l}.weight"), g(f"flows.{b}.nn.{l}.bias")) for l in (1, 3, 5, 7)] for b in range(2)]
+        self.cache = ops.PackCache()     # packed coupling-net fragments survive across calls while the weights are unchanged
 
     def condition(self, pts, view_angles, aabb):
         """[pn,37] = [feature 16 | embed3(view_angles) 14 | 7 zeros] (flow.py:803-815, :836-848)."""
@@ -142,7 +158,10 @@ class MCShader:
         self.env = g("outer_light.base")
         self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device)
         self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device)
+        self.inner_cache = ops.PackCache()
         self.bvh = ops.Bvh(vertices, triangles, device)
+        self.point_prep = ops.PointPrep(self.mat_packed, self.flow_d.packed, self.flow_s.packed, self.pred,
+                                        [self.flow_d.mat, self.flow_s.mat], self.aabb)
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
         self._latent = {}
         self.timer = _NoTimer()
@@ -174,7 +193,7 @@ class MCShader:
             idx, count = ops.compact_mask(hit.view(torch.uint8))
         with T.stage("inner_light"):
             ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5,
-                                    exp_max=self.exp_max, precision=self.precision)
+                                    exp_max=self.exp_max, precision=self.precision, cache=self.inner_cache)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return lights, hit, inters
 
@@ -184,15 +203,15 @@ class MCShader:
         pts = pts.to(self.device).float().contiguous()
         pn = pts.shape[0]
         tm = self.timer
-        with tm.stage("materials"):
-            metallic, rough, albedo = self.predict_materials(pts)
+        with tm.stage("point_prep"):
+            # materials + both flow condition rows: one fused launch (tf_point_fwd) after the view-angle kernel
             va = ops.view_angles(normals, view_dirs)
-        with tm.stage("flow_condition"):
-            cond_d = self.flow_d.condition(pts, va, self.aabb)
-            cond_s = self.flow_s.condition(pts, va, self.aabb)
+            metallic, rough, albedo, cond_d, cond_s = self.point_prep(pts, va)
         with tm.stage("flow_sample"):
-            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d, precision=self.precision)
-            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision)
+            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d, precision=self.precision,
+                                          cache=self.flow_d.cache)
+            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
+                                          cache=self.flow_s.cache)
         tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         with tm.stage("shade_dirs"):
             dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
@@ -202,8 +221,7 @@ class MCShader:
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
             colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
-        rid = torch.arange(pn, device=self.device)[:, None].expand(pn, sn_specular)[smask]
-        return dict(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
-                    specular_mask=smask, specular_rays_id=rid, hit=hit.reshape(pn, T), live=live, view_angles=va,
+        return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
+                    specular_mask=smask, hit=hit.reshape(pn, T), live=live, view_angles=va,
                     diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
                     lights=lights.reshape(pn, T, 3))

@@ -256,6 +256,31 @@ def test_inner_light_matches_oracle(golden, dev):
         assert err < TOL
 
 
+def test_point_prep_matches_oracle(golden, dev):
+    """Fused per-point launch (tf_point_fwd): materials and both flow condition rows vs the oracle, ragged last tile."""
+    from oracle import flow as ofl
+    from oracle import shading as osh
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import MCShader
+    g = golden("shading_small")
+    sh = MCShader(g.sd, g["verts"].numpy(), g["faces"].numpy(), AABB, float(g["unit_size"]), device=dev,
+                  n_fixed_diffuse=int(g["sn"][0]))
+    gen = torch.Generator().manual_seed(11)
+    pn = 1000 + 13                                          # not a multiple of 32
+    pts = torch.rand(pn, 3, generator=gen) * 2.2 - 1.1      # some points outside the aabb (clamped taps)
+    nrm = torch.nn.functional.normalize(torch.randn(pn, 3, generator=gen), dim=-1)
+    view = torch.nn.functional.normalize(torch.randn(pn, 3, generator=gen), dim=-1)
+    va = ops.view_angles(nrm.to(dev), view.to(dev))
+    met, rough, alb, cd, cs = sh.point_prep(pts.to(dev), va)
+    rm, rr, ra = osh.predict_materials(g.sd, pts, AABB)
+    assert rel_err(met.cpu(), rm) < TOL and rel_err(rough.cpu(), rr) < TOL and rel_err(alb.cpu(), ra) < TOL
+    for got, pfx in ((cd, "flow_diffuse_copy."), (cs, "flow_specular_copy.")):
+        ref = ofl.flow_condition(g.sd, pts, va.cpu(), rr, AABB, pfx=pfx)
+        assert got.shape == ref.shape == (pn, 37)
+        assert rel_err(got.cpu(), ref) < TOL
+        assert torch.equal(got[:, 30:].cpu(), torch.zeros(pn, 7))
+
+
 @pytest.mark.parametrize("tag", ["small", "default"])
 def test_shade_golden(golden, dev, tag):
     """Whole integral (flow samplers active) vs the reference's `*_nis` outputs."""
