@@ -53,6 +53,24 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
+// sin and cos of x: argument reduction by pi/2 in double precision (exact to 1e-10 for |x| < 1e6; x = 2^f p with
+// |p| <= ~1 here), then the Cephes single-precision kernels on [-pi/4, pi/4]: max abs error 9.3e-8 for |x| <= 1e7
+// (checked against double precision on 4e7 random arguments).  The libm sinf/cosf pair inlines its large-argument path
+// at each of the 48 call sites of a ray -- it was 17 % of the whole kernel.
+__device__ __forceinline__ void tf_sincos(float x, float& s, float& c) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134);
+  const float r = (float)fma(kd, -1.5707963267948966, xd);
+  const float z = r * r;
+  const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                        fmaf(z, -0.5f, 1.0f));
+  const int q = (int)(long long)kd & 3;
+  const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
 template <int K16, int TIN>
 __device__ __forceinline__ void hidden_layer_h3(const float* __restrict__ wslab, const float* __restrict__ bias,
                                                 float* __restrict__ lds, int tid, int lane, int h,
@@ -61,7 +79,7 @@ __device__ __forceinline__ void hidden_layer_h3(const float* __restrict__ wslab,
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_stream_h3<K16, 8, TIN, 1, 3>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, out);
+  tf_layer_stream_h3p<K16, 8, TIN>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -96,7 +114,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   if (m <= 0) return;
-  __shared__ __attribute__((aligned(16))) float lds[3 * 4096];
+  __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // weight-slab ring (f16x3: 4 slabs, f32: 3)
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
@@ -125,11 +143,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
 #pragma unroll
     for (int f = 0; f < 8; ++f)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float a = p[k] * (float)(1 << f);
-        enc[3 + 6 * f + k] = sinf(a);
-        enc[3 + 6 * f + 3 + k] = cosf(a);
-      }
+      for (int k = 0; k < 3; ++k) tf_sincos(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
     float n[3] = {nrm[3 * src], nrm[3 * src + 1], nrm[3 * src + 2]};
     float v[3] = {vsign * view[3 * src], vsign * view[3 * src + 1], vsign * view[3 * src + 2]};
     float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
@@ -152,15 +166,16 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
         cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
       }
       const float* mat = ws + kIdeMat;
-      int col = 0;
+      // column of (d, mm) = (2^d - 1) + d + mm: every index below is a compile-time constant once the loops are unrolled
+      // (a running `col++` counter left enc[] dynamically indexed, i.e. in scratch memory)
 #pragma unroll
       for (int d = 0; d < 5; ++d) {
-        const int l = 1 << d;
 #pragma unroll
-        for (int mm = 0; mm <= l; ++mm, ++col) {
+        for (int mm = 0; mm <= (1 << d); ++mm) {
+          const int col = (1 << d) - 1 + d + mm;
           float poly = 0.f;
 #pragma unroll
-          for (int k = 0; k <= l - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+          for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
           enc[51 + col] = cre[mm] * poly;
           enc[51 + 36 + col] = cim[mm] * poly;
         }
@@ -171,13 +186,16 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     }
     f32x16 a[8], b[8];
     {
+      const unsigned long long upper_half = 0xFFFFFFFF00000000ULL;   // lanes 32..63 (h = 1)
       f32x16 in1[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int k0 = 32 * t + (j & 3) + 8 * (j >> 2);
-          in1[t][j] = h ? enc[k0 + 4] : enc[k0];
+          // explicit v_cndmask: written as `h ? enc[k0 + 4] : enc[k0]` the compiler folds the select into the ADDRESS
+          // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
+          asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
         }
       if (H3) hidden_layer_h3<8, 4>(ws + kH1, ws + kIB1, lds, tid, lane, h, in1, a);
       else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
@@ -192,7 +210,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
-    if (H3) tf_layer_stream_h3<16, 1, 8, 8, 3>(reinterpret_cast<const _Float16*>(ws + kH4), lds, tid, lane, a, o);
+    if (H3) tf_layer_stream_h3p<16, 1, 8>(reinterpret_cast<const _Float16*>(ws + kH4), lds, tid, lane, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
       const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;

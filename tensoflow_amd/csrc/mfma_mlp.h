@@ -108,6 +108,12 @@ __device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*
 #endif
 }
 
+__device__ __forceinline__ void tf_slab_dma_piece(const float* gthread, float* __restrict__ lbuf, int wave, int i) {
+#ifndef TF_ABLATE_DMA
+  __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
+#endif
+}
+
 template <int N>
 __device__ __forceinline__ void tf_wait_vmcnt_barrier() {
   // counted wait (the N youngest vector-memory ops may stay in flight) + raw barrier: a __syncthreads() would make
@@ -274,6 +280,98 @@ __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ 
     if (AHEAD == 2 && g + 2 < G) tf_wait_vmcnt_barrier<4>();
     else tf_wait_vmcnt_barrier<0>();
   }
+}
+
+// ---- software-pipelined variant.  tf_layer_stream_h3 issues a slab's 16 fragment reads and then needs the first one:
+// all four waves leave the barrier together, their 64 KB of ds_read_b128 queue on the LDS (>= 256 cycles) while the
+// matrix cores idle -- a third of every slab step.  Here the fragments of slab g+1 are read into a SECOND register set
+// while the MFMAs of slab g run, and the LDS ring is 4 slabs deep (slab g+3 is requested while g computes).
+// Per step:  counted vmcnt -> s_barrier -> MFMAs of slab g with the reads of slab g+1 and the DMA of slab g+3 interleaved.
+// The compiler waits with lgkmcnt(0) before the first MFMA that needs a fragment; placing this step's reads BEHIND the
+// first MFMA group (scheduling barriers pin the order) makes that wait cover only reads issued most of a step earlier.
+//   RAW: a slab is read one phase after the vmcnt + barrier that retire its DMA.
+//   WAR: DMA(g+3) overwrites the buffer of slab g-1, whose reads every wave completed before its MFMAs of step g-1,
+//        i.e. before this step's barrier; the layer ends with a barrier after the last reads have returned.
+struct TfFrag { tf_h8 hi[8], lo[8]; };
+
+__device__ __forceinline__ void tf_frag_read(TfFrag& F, const tf_h8* __restrict__ buf /* slab + lane */) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { F.hi[c] = buf[c * 128]; F.lo[c] = buf[c * 128 + 64]; }
+}
+
+template <int K16, int TOUT, int TIN, int G, int SL16>
+__device__ __forceinline__ void tf_h3p_step(int g, const TfFrag& cur, TfFrag& nxt, const float*& gp, float* lds, int lane,
+                                            int wave, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+  if (g + 1 < G) {
+    if (g + 2 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slab g+1 landed (g+2 may still be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  tf_h8 b_hi[SL16], b_lo[SL16];
+#pragma unroll
+  for (int sl = 0; sl < SL16; ++sl) {
+    const int s16 = g * SL16 + sl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = in[s16 >> 1][8 * (s16 & 1) + e];
+      const _Float16 h = (_Float16)x;
+      b_hi[sl][e] = h;
+      b_lo[sl][e] = (_Float16)(x - (float)h);
+    }
+  }
+  // combo 0 first: its fragments were requested a whole step ago.  Behind it, each group of three MFMAs (96 matrix-core
+  // cycles) carries two fragment pairs of slab g+1 (combos 1-4) or one 1 KB DMA piece of slab g+3 (combos 4-7).
+  const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(lds + ((g + 1) & 3) * 4096) + lane;
+  float* dbuf = lds + ((g + 3) & 3) * 4096;
+  if (g + 3 < G) {
+    gp += 4096;
+    asm volatile("" : "+v"(gp));
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int sl = c / TOUT, t = c % TOUT;
+    if (g + 1 < G && c >= 1 && c <= 4) {
+#pragma unroll
+      for (int q = 2 * (c - 1); q < 2 * c; ++q) { nxt.hi[q] = nbuf[q * 128]; nxt.lo[q] = nbuf[q * 128 + 64]; }
+    }
+    if (g + 3 < G && c >= 4) tf_slab_dma_piece(gp, dbuf, wave, c - 4);
+    out[t] = tf_mfma_h(cur.hi[c], b_hi[sl], out[t]);
+    out[t] = tf_mfma_h(cur.hi[c], b_lo[sl], out[t]);
+    out[t] = tf_mfma_h(cur.lo[c], b_hi[sl], out[t]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// lds: 4 x 4096 floats (64 KB ring).  All four waves of the workgroup must call this together.
+template <int K16, int TOUT, int TIN>
+__device__ __forceinline__ void tf_layer_stream_h3p(const _Float16* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
+                                                    const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+  static_assert(8 % TOUT == 0, "a 16 KB slab holds 8 (k-step, tile) fragment pairs");
+  constexpr int SL16 = 8 / TOUT;
+  static_assert(K16 % SL16 == 0, "K16 must be a multiple of the slab size");
+  constexpr int G = K16 / SL16;
+  const int wave = tid >> 6;
+  const float* gp = reinterpret_cast<const float*>(wslab) + wave * 1024 + lane * 4;
+  asm volatile("" : "+v"(gp));
+  tf_slab_dma(gp, lds, wave);
+  if (G > 1) { gp += 4096; asm volatile("" : "+v"(gp)); tf_slab_dma(gp, lds + 4096, wave); }
+  if (G > 2) { gp += 4096; asm volatile("" : "+v"(gp)); tf_slab_dma(gp, lds + 8192, wave); }
+  if (G > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (G > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  TfFrag FA, FB;
+  tf_frag_read(FA, reinterpret_cast<const tf_h8*>(lds) + lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < G; g += 2) {
+    tf_h3p_step<K16, TOUT, TIN, G, SL16>(g, FA, FB, gp, lds, lane, wave, in, out);
+    if (g + 1 < G) tf_h3p_step<K16, TOUT, TIN, G, SL16>(g + 1, FB, FA, gp, lds, lane, wave, in, out);
+  }
+  __builtin_amdgcn_s_barrier();   // every wave has all its fragments in registers: the ring may be refilled
+  asm volatile("" ::: "memory");
 }
 
 // Dense layer, f16x3, fragment weights resident in LDS ([s16][tout][hi|lo][lane][8 halves]).
