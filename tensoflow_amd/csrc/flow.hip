@@ -153,21 +153,23 @@ static constexpr int hL1 = 0, hL2 = hL1 + 2 * 512, hL3 = hL2 + 8 * 512, hL4 = hL
                      hB3 = hB2 + 64, hB4 = hB3 + 64, hNetFloats = hB4 + 32;
 static_assert(hNetFloats <= kNetFloats + 512, "workspace sizing assumes the f16x3 image is not much larger");
 
-__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
+// LeakyReLU(0.01) as max(x, 0.01 x): two instructions instead of compare + multiply + select, same value for every x
+__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.01f * x); }
 
-// net eval for one tile: y_keep per lane (this lane's row), P row pointer -> wv[32] (all 21+pad outputs of the row)
+// net eval for one 32-row tile: y_keep / P row of the row on this lane's MFMA column (lane & 31) -> o: the 21 (+pad)
+// outputs of the tile in accumulator layout (lane half h holds units rho(j, h) of its column's row)
 template <bool H3>
 __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS*/, const float* __restrict__ Prow,
-                                             float y_keep, int lane, float (&wv)[32]) {
+                                             float y_keep, int lane, f32x16 (&o)[1]) {
   const int h = lane >> 5;
   constexpr int B2 = H3 ? hB2 : kB2, B3 = H3 ? hB3 : kB3, B4 = H3 ? hB4 : kB4;
   const tf_h8* nh = reinterpret_cast<const tf_h8*>(net) + lane;
   // layer-1 sample part: embed3(y) (7 values, Reshift 2x-1), k = rho(j,h), j = 0..3
   float emb[8];
   emb[0] = y_keep;
-  emb[1] = sinf(y_keep); emb[2] = cosf(y_keep);
-  emb[3] = sinf(y_keep * 2.f); emb[4] = cosf(y_keep * 2.f);
-  emb[5] = sinf(y_keep * 4.f); emb[6] = cosf(y_keep * 4.f);
+  tf_sincos_small(y_keep, emb[1], emb[2]);          // y_keep in (0,1): arguments <= 4 (libm sinf/cosf: ~100 instructions each)
+  tf_sincos_small(y_keep * 2.f, emb[3], emb[4]);
+  tf_sincos_small(y_keep * 4.f, emb[5], emb[6]);
   emb[7] = 0.5f;  // padded input: 2*0.5-1 = 0 (its weight column is zero anyway)
   f32x16 in1[1];
 #pragma unroll
@@ -201,7 +203,6 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
     }
   if (H3) tf_layer_h3<4, 2, 2>(nh + hL3 / 4, b, a);
   else tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
-  f32x16 o[1];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -210,14 +211,21 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
   for (int j = 0; j < 16; ++j) o[0][j] = net[B4 + j * 2 + h];
   if (H3) tf_layer_h3<4, 1, 2>(nh + hL4 / 4, a, o);
   else tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
-  // gather the row's 32 outputs: own 16 (rows rho(j,h)) + partner's 16 (rows rho(j,1-h))
+}
+
+// Two tiles (A: rows 0..31, B: rows 32..63 of a 64-row group) share one spline pass: lane l evaluates the spline of row l,
+// i.e. lanes 0..31 need all 32 outputs of tile A's column (lane & 31) and lanes 32..63 those of tile B's.  Each lane keeps
+// the 16 outputs it holds of ITS tile and receives the other 16 from its partner lane (l ^ 32), which holds them in the
+// accumulators of the tile it does not need itself.
+__device__ __forceinline__ void gather_outputs(const f32x16 (&oA)[1], const f32x16 (&oB)[1], int h, float (&wv)[32]) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    float mine = o[0][j];
-    float other = __shfl_xor(mine, 32);
-    int r0 = (j & 3) + 8 * (j >> 2);
-    wv[r0] = h ? other : mine;
-    wv[r0 + 4] = h ? mine : other;
+    const float own = h ? oB[0][j] : oA[0][j];
+    const float send = h ? oA[0][j] : oB[0][j];
+    const float recv = __shfl_xor(send, 32);
+    const int r0 = (j & 3) + 8 * (j >> 2);
+    wv[r0] = h ? recv : own;
+    wv[r0 + 4] = h ? own : recv;
   }
 }
 
@@ -235,11 +243,14 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
-  const long long n_tiles = (m + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * waves_per_block + wave; tile < n_tiles;
-       tile += (long long)gridDim.x * waves_per_block) {
+  // one iteration = 64 rows: lane l owns row 64*group + l (state, spline, output); the nets run per 32-row tile with row
+  // (lane & 31) resp. 32 + (lane & 31) on this lane's MFMA column, so every spline is evaluated once (not once per half)
+  const long long n_groups = (m + 63) / 64;
+  const int h = lane >> 5, col = lane & 31;
+  for (long long grp = (long long)blockIdx.x * waves_per_block + wave; grp < n_groups;
+       grp += (long long)gridDim.x * waves_per_block) {
     asm volatile("" ::: "memory");  // keep the LDS weight fragments out of registers across tiles (LICM)
-    long long row = tile * 32 + (lane & 31);
+    long long row = grp * 64 + lane;
     const bool valid = row < m;
     if (!valid) row = m - 1;
     long long pt;
@@ -259,22 +270,31 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
       x1 = fminf(fmaxf(xin[2 * row + 1], 1e-6f), 1.f - 1e-6f);
       lj = 0.f;
     }
+    const int ptA = __shfl((int)pt, col), ptB = __shfl((int)pt, 32 + col);   // pn < 2^31 (checked by the launcher)
     float wv[32];
+    f32x16 oA[1], oB[1];
     int bin0, bin1;
     float t, l;
+    // one coupling block for both tiles: `keep` is the conditioning coordinate of this lane's own row
+    auto run_block = [&](const float* net, long long pbase, float keep) {
+      const float kA = __shfl(keep, col), kB = __shfl(keep, 32 + col);
+      coupling_net<H3>(net, P + (pbase + ptA) * 64, kA, lane, oA);
+      coupling_net<H3>(net, P + (pbase + ptB) * 64, kB, lane, oB);
+      gather_outputs(oA, oB, h, wv);
+    };
     if (SAMPLE) {
-      coupling_net<H3>(lds, P + pt * 64, x0, lane, wv);                  // block 0 keeps x0, moves x1
+      run_block(lds, 0, x0);                                             // block 0 keeps x0, moves x1
       pw_inverse(x1, wv, t, l, bin0); x1 = t; lj += l;
-      coupling_net<H3>(lds + NF, P + (pn + pt) * 64, x1, lane, wv);     // block 1 keeps x1, moves x0
+      run_block(lds + NF, pn, x1);                                       // block 1 keeps x1, moves x0
       pw_inverse(x0, wv, t, l, bin1); x0 = t; lj += l;
     } else {
-      coupling_net<H3>(lds + NF, P + (pn + pt) * 64, x1, lane, wv);
+      run_block(lds + NF, pn, x1);
       pw_forward(x0, wv, t, l, bin1); x0 = t; lj += l;
-      coupling_net<H3>(lds, P + pt * 64, x0, lane, wv);
+      run_block(lds, 0, x0);
       pw_forward(x1, wv, t, l, bin0); x1 = t; lj += l;
       lj += logf(cosf(x1 * kHalfPi));   // + latent_prior.log_prob(z)
     }
-    if (valid && lane < 32) {
+    if (valid) {
       reinterpret_cast<float2*>(out_xy)[row] = make_float2(x0, x1);
       out_lj[row] = lj;
       if (bins) reinterpret_cast<int2*>(bins)[row] = make_int2(bin0, bin1);
@@ -373,7 +393,8 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
     hipFuncSetAttribute((const void*)flow_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const long long tiles = (m + 31) / 32;
+  TF_REQUIRE(pn < (1LL << 31), TF_ESHAPE, "%s: pn must be < 2^31", who);
+  const long long tiles = (m + 63) / 64;   // 64-row groups
   const int waves_per_block = 8;
   long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles

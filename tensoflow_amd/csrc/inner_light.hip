@@ -53,24 +53,6 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
-// sin and cos of x: argument reduction by pi/2 in double precision (exact to 1e-10 for |x| < 1e6; x = 2^f p with
-// |p| <= ~1 here), then the Cephes single-precision kernels on [-pi/4, pi/4]: max abs error 9.3e-8 for |x| <= 1e7
-// (checked against double precision on 4e7 random arguments).  The libm sinf/cosf pair inlines its large-argument path
-// at each of the 48 call sites of a ray -- it was 17 % of the whole kernel.
-__device__ __forceinline__ void tf_sincos(float x, float& s, float& c) {
-  const double xd = (double)x;
-  const double kd = rint(xd * 0.63661977236758134);
-  const float r = (float)fma(kd, -1.5707963267948966, xd);
-  const float z = r * r;
-  const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-  const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                        fmaf(z, -0.5f, 1.0f));
-  const int q = (int)(long long)kd & 3;
-  const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
-  s = (q & 2) ? -a : a;
-  c = ((q + 1) & 2) ? -b : b;
-}
-
 template <int K16, int TIN>
 __device__ __forceinline__ void hidden_layer_h3(const float* __restrict__ wslab, const float* __restrict__ bias,
                                                 float* __restrict__ lds, int tid, int lane, int h,

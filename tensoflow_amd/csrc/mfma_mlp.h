@@ -27,6 +27,33 @@ __device__ __forceinline__ f32x16 tf_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- sin / cos without the libm call (which inlines its large-argument path at every call site).
+// tf_sincos: argument reduction by pi/2 in double precision (exact to 1e-10 for |x| < 1e6), Cephes single-precision
+// kernels on [-pi/4, pi/4]: max abs error 9.3e-8 for |x| <= 1e7 (checked against double precision, 4e7 random arguments).
+__device__ __forceinline__ void tf_sincos_poly(float r, int q, float& s, float& c) {
+  const float z = r * r;
+  const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                        fmaf(z, -0.5f, 1.0f));
+  const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ void tf_sincos(float x, float& s, float& c) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134);
+  const float r = (float)fma(kd, -1.5707963267948966, xd);
+  tf_sincos_poly(r, (int)(long long)kd & 3, s, c);
+}
+// |x| < 200: three-constant Cody-Waite reduction in fp32 (k * A and k * B are exact for |k| < 2^8), max abs error 1.2e-7.
+__device__ __forceinline__ void tf_sincos_small(float x, float& s, float& c) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(k, -1.57073974609375f, x);
+  r = fmaf(k, -5.657970905303955e-05f, r);
+  r = fmaf(k, -9.920936294705029e-10f, r);
+  tf_sincos_poly(r, (int)k & 3, s, c);
+}
+
 // Pack W [nout, ld] (columns col0 .. col0+kin-1 used) into fragment order; zero padded.
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                             int kin, int tout_tiles, int ksteps,
@@ -202,6 +229,38 @@ __device__ __forceinline__ f32x16 tf_mfma_h(tf_h8 a, tf_h8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// x[0..7] -> hi = f16(x) (round to nearest even), lo = f16(x - hi).  Three instructions per PAIR of values:
+// v_cvt_pk_f16_f32, then v_fma_mixlo_f16 / v_fma_mixhi_f16 compute (f32)hi * -1 + x in fp32 (exact: the difference has
+// <= 13 significant bits) and round it to f16 straight into the packed lo register (bit-identical to the C expression
+// on 1 M random values incl. the f16-subnormal range).  Written as (_Float16)(x - (float)h) the compiler spends 3
+// instructions per VALUE (convert back, subtract, convert).  ONE statement ending in `s_nop 1`: the outputs feed MFMA
+// B operands, and hipcc's hazard recognizer does not see VALU writes made inside an asm string (VALU write -> MFMA
+// operand needs 2 wait states; without them a few samples per launch read the stale register).
+__device__ __forceinline__ void tf_split8(const float (&x)[8], tf_h8& hi, tf_h8& lo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h, l;
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+      "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+      "v_cvt_pk_f16_f32 %2, %12, %13\n\t"
+      "v_cvt_pk_f16_f32 %3, %14, %15\n\t"
+      "v_fma_mixlo_f16 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %5, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %6, %2, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %7, %3, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %4, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %5, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %6, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %7, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
+  l[0] = l0; l[1] = l1; l[2] = l2; l[3] = l3;
+  hi = __builtin_bit_cast(tf_h8, h);
+  lo = __builtin_bit_cast(tf_h8, l);
+}
+
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_h3_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                                int kin, int tout_tiles, int ksteps16,
                                                                _Float16* __restrict__ dst) {
@@ -256,12 +315,11 @@ __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ 
     for (int sl = 0; sl < SL16; ++sl) {
       const int s16 = g * SL16 + sl;
       tf_h8 b_hi, b_lo;
+      {
+        float x8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = in[s16 >> 1][8 * (s16 & 1) + e];
-        const _Float16 h = (_Float16)x;
-        b_hi[e] = h;
-        b_lo[e] = (_Float16)(x - (float)h);
+        for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
+        tf_split8(x8, b_hi, b_lo);
       }
       tf_h8 a_hi = buf[(sl * TOUT) * 128], a_lo = buf[(sl * TOUT) * 128 + 64];
 #pragma unroll
@@ -312,13 +370,10 @@ __device__ __forceinline__ void tf_h3p_step(int g, const TfFrag& cur, TfFrag& nx
 #pragma unroll
   for (int sl = 0; sl < SL16; ++sl) {
     const int s16 = g * SL16 + sl;
+    float x8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = in[s16 >> 1][8 * (s16 & 1) + e];
-      const _Float16 h = (_Float16)x;
-      b_hi[sl][e] = h;
-      b_lo[sl][e] = (_Float16)(x - (float)h);
-    }
+    for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
+    tf_split8(x8, b_hi[sl], b_lo[sl]);
   }
   // combo 0 first: its fragments were requested a whole step ago.  Behind it, each group of three MFMAs (96 matrix-core
   // cycles) carries two fragment pairs of slab g+1 (combos 1-4) or one 1 KB DMA piece of slab g+3 (combos 4-7).
@@ -381,12 +436,11 @@ __device__ __forceinline__ void tf_layer_h3(const tf_h8* __restrict__ wf /* + la
 #pragma unroll
   for (int s16 = 0; s16 < K16; ++s16) {
     tf_h8 b_hi, b_lo;
+    {
+      float x8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = in[s16 >> 1][8 * (s16 & 1) + e];
-      const _Float16 h = (_Float16)x;
-      b_hi[e] = h;
-      b_lo[e] = (_Float16)(x - (float)h);
+      for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
+      tf_split8(x8, b_hi, b_lo);
     }
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {

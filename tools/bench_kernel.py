@@ -65,3 +65,17 @@ elif which == "bvh":
     for dyn in (False, True):
         ms = timeit(lambda: bvh.trace(o, d, 1e-5, 2 * 2 / 511, dynamic=dyn))
         print(f"bvh_trace dynamic={dyn} {o.shape[0]} rays, {len(faces)} tris: {ms:.2f} ms  {o.shape[0]/ms*1e-6:.2f} Grays/s")
+elif which == "flow":
+    from tensoflow_amd.shading import FlowParams, sphere_latent
+    sd = random_mc_state(seed=4, R=64, flow_R=64, env_res=8)
+    fp = FlowParams(sd, "flow_diffuse_copy.", dev)
+    pn, sn = 16384, 128
+    cond = torch.rand(pn, 37, device=dev)
+    lat = sphere_latent(sn).to(dev)
+    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+        ms = timeit(lambda: ops.flow_sample(fp.nets, cond, lat, precision=prec, cache=fp.cache))
+        print(f"flow_sample pn={pn} sn={sn} precision={prec}: {ms:.3f} ms  {pn*sn/ms*1e-6:.2f} Gsamples/s  {pn*sn*49408/ms*1e-9:.1f} TF/s (reference flop count)")
+    x = torch.rand(pn, sn, 2, device=dev)
+    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+        ms = timeit(lambda: ops.flow_logq(fp.nets, cond, x, precision=prec))
+        print(f"flow_logq pn={pn} sn={sn} precision={prec}: {ms:.3f} ms")
