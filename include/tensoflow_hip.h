@@ -235,20 +235,26 @@ typedef struct TfBvhNode { /* 32 bytes */
 int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const int32_t* faces_host, int64_t nf,
                           TfBvhNode* nodes_host, float* tris_host);
 
-/* Traversal layout for the device (tf_bvh_trace does not walk TfBvhNode): `pairs_host` receives one 64-byte record per
- * inner node -- both child boxes + both child references, depth-first order -- capacity (n_nodes/2 + 1) x 16 floats;
- * `tris12_host` [nf,12] receives (a, e1 = b - a, e2 = c - a, 0 0 0) per triangle of the reordered soup.  Child reference:
- * >= 0 pair index, < -1 leaf = ~((first_triangle << 3) | count), -1 none.  Returns the number of pairs (> 0) or a
- * negative TfStatus. */
+/* Traversal layout for the device (tf_bvh_trace does not walk TfBvhNode): `pairs_host` receives one 32-byte record per
+ * inner node -- both child boxes quantised to 16 bits per coordinate on one global grid (rounded outward) + both child
+ * references, depth-first order -- capacity (n_nodes/2 + 1) x 8 uint32; `frame_host` [6] receives the grid (origin xyz,
+ * scale xyz: coordinate = origin + q * scale); `tris12_host` [nf,12] receives (a, e1 = b - a, e2 = c - a, 0 0 0) per
+ * triangle of the reordered soup (full precision: hits and depths are exact).  Child reference: >= 0 pair index,
+ * < -1 leaf = ~((first_triangle << 3) | count), -1 none.  Returns the number of pairs (> 0) or a negative TfStatus. */
 int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const float* tris_host, int64_t nf,
-                         float* pairs_host, float* tris12_host);
+                         uint32_t* pairs_host, float* tris12_host, float* frame_host);
 
 /* Replaces raytracing.RayTracer.trace + MaterialRenderer.trace (network/materialRenderer.py:221-223,253-263).
- * pairs [n_pairs,16], tris12 [nf,12]: device copies of tf_bvh_pack_host's output (16-byte aligned).
+ * pairs [n_pairs,8] uint32, tris12 [nf,12]: device copies of tf_bvh_pack_host's output (16-byte aligned); frame_host [6]:
+ * its quantisation grid (host memory).
  * o [m / rays_per_origin, 3], d [m,3] -> pos [m,3] (= origin + depth*d), nrm [m,3] (= normalize(-face_normal), 0 on a
  * miss), depth [m] (10.0 on a miss), hit [m] uint8 (depth < 10); pos/nrm/hit may be NULL.
  * rays_per_origin: ray i starts at row i / rays_per_origin of o (1 = one origin row per ray; T = the T secondary rays of
  * one surface point share its row, so the caller need not materialise pts[:,None].expand(pn,T,3), fields.py:1188).
+ * slot_order [rays_per_origin] int32 (device) or NULL: traversal ORDER of the rays of one point -- the j-th ray traced is
+ * slot slot_order[j]; results are still written at the ray's own index.  The integral's direction sets are Fibonacci
+ * spirals (consecutive slots point ~222 degrees apart); sorting the slots along a space-filling curve makes the 64 rays
+ * of a wavefront walk the same part of the tree.
  * origin = (o + d*origin_offset0) + origin_offset1*d, the two roundings of the reference's
  * `p + 1e-5 d` (fields.py:955) followed by `o + 2*unit_size*d` (materialRenderer.py:223); pass 0,0 for
  * a plain trace.
@@ -256,8 +262,9 @@ int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const flo
  * integral is exactly zero -- below-horizon samples, fields.py:1156,1209 -- per-wavefront live-sample culling).
  * work_counter: 8 bytes of device scratch (zeroed by the call) that switches on the persistent kernel with dynamic
  * ray fetch (lanes pull new rays as their wave-mates finish); NULL = one statically assigned ray per lane. */
-int tf_bvh_trace(const float* pairs, const float* tris12, int64_t n_pairs, const float* o, const float* d,
-                 int64_t rays_per_origin, float origin_offset0, float origin_offset1, const uint8_t* live, int64_t m,
+int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const float* frame_host, int64_t n_pairs, const float* o, const float* d,
+                 int64_t rays_per_origin, const int32_t* slot_order, float origin_offset0, float origin_offset1,
+                 const uint8_t* live, int64_t m,
                  float* pos, float* nrm, float* depth, uint8_t* hit, int64_t* work_counter, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

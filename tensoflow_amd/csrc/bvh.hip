@@ -12,13 +12,21 @@
 #include "tf_common.h"
 
 #define BVH_MAX_DIST 10.0f
+#ifndef BVH_LEAF
 #define BVH_LEAF 4
+#endif
 #ifndef BVH_REFILL
 #define BVH_REFILL 16   // idle lanes per wave that trigger a refill from the ray pool
 #endif
 #define BVH_CHUNK_MAX 512  // rays a wave takes from the global pool per atomic (shrinks towards BVH_CHUNK_MIN at the end)
 #define BVH_CHUNK_MIN 64
-#define BVH_STACK 32       // per-ray traversal stack entries (LDS); the builder bounds the tree depth to match
+#define BVH_STACK 32       // per-ray traversal stack entries; the builder bounds the tree depth to match
+#ifndef BVH_LDS_STACK
+#define BVH_LDS_STACK 12   // of which in LDS (the rest is a per-lane scratch array, touched by the rare deep pile-ups only)
+#endif
+#ifndef BVH_WAVES
+#define BVH_WAVES 8        // resident 256-thread blocks per CU the kernel is compiled for (register budget)
+#endif
 #define BVH_MAX_DEPTH 31   // deepest node level the builder may create (root = 0)
 #ifndef BVH_LEAF_W
 #define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
@@ -147,40 +155,61 @@ extern "C" int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const 
 
 // ----------------------------------------------------------------------------- traversal layout (host)
 // The device does not walk TfBvhNode: one traversal step there costs two dependent memory round trips (the node, then
-// its two children).  tf_bvh_pack_host re-lays the tree out as 64-byte PAIRS -- one record per inner node holding BOTH
-// child boxes and both child references -- so a step is one 64-byte fetch (4 x dwordx4), and triangles as 48-byte
-// (a, e1, e2) records (3 x dwordx4; e1 = b - a, e2 = c - a rounded exactly as the kernel used to compute them).
-//   pair (16 floats): lo0.xyz hi0.xyz lo1.xyz hi1.xyz | c0 c1 0 0 (int32)
+// its two children), and profiling the first pair layout (64-byte records, full-precision boxes) showed the kernel bound by
+// the per-CU vector L1, which serves ONE divergent 16-byte access per clock (rocprofv3: TCP_TOTAL_CACHE_ACCESSES = rays x
+// steps x 4).  tf_bvh_pack_host therefore lays the tree out as 32-byte PAIRS -- one record per inner node holding BOTH
+// child boxes, quantised to 16 bits per coordinate on ONE global grid, and both child references -- so a step is two
+// dwordx4 fetches per lane and the whole inner tree (2.6 MB on the bench mesh) fits an XCD's L2.
+//   pair (8 dwords): child0 {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16}, child1 {same}, c0, c1
+//   grid:  x = frame.origin + q * frame.scale per axis; boxes are rounded OUTWARD after being inflated by `margin`
+//          (8e-6 of the scene extent), which also absorbs the rounding of the kernel's slab test t = fma(q, s/d, (o0-o)/d)
+//          -- the quantised box test never culls a box the exact one accepts.  Triangles stay full precision, so hits
+//          and depths are unchanged.
 //   child reference:  >= 0 pair index;  < -1 leaf = ~((first_triangle << 3) | count), count 1..4;  -1 none
 // Pairs are numbered in depth-first order (a subtree is contiguous; the top of the tree shares cache lines).
+// Triangles are stored as 48-byte (a, e1, e2) records (3 x dwordx4; e1 = b - a, e2 = c - a).
 namespace {
 struct Packer {
   const TfBvhNode* nodes;
-  float* pairs;
+  uint32_t* pairs;
   int64_t n_pairs = 0;
+  double org[3], scl[3], margin[3];
   static int32_t leaf_ref(const TfBvhNode& n) { return ~(int32_t)(((uint32_t)n.left << 3) | (uint32_t)n.count); }
+  void quantise(const float* lo, const float* hi, uint32_t* q /*[3]*/) const {
+    uint32_t ql[3], qh[3];
+    for (int k = 0; k < 3; ++k) {
+      if (!(hi[k] >= lo[k])) { ql[k] = 65535; qh[k] = 0; continue; }   // empty box: never hit
+      double a = std::floor(((double)lo[k] - margin[k] - org[k]) / scl[k]);
+      double b = std::ceil(((double)hi[k] + margin[k] - org[k]) / scl[k]);
+      a = std::min(std::max(a, 0.0), 65535.0);
+      b = std::min(std::max(b, 0.0), 65535.0);
+      ql[k] = (uint32_t)a; qh[k] = (uint32_t)b;
+    }
+    q[0] = ql[0] | (ql[1] << 16);
+    q[1] = ql[2] | (qh[0] << 16);
+    q[2] = qh[1] | (qh[2] << 16);
+  }
   int32_t emit(int64_t node) {   // node is an inner node
     const TfBvhNode& nd = nodes[node];
     const int64_t me = n_pairs++;
     int32_t refs[2];
     for (int c = 0; c < 2; ++c) {
       const TfBvhNode& ch = nodes[nd.left + c];
-      float* q = pairs + 16 * me + 6 * c;
-      for (int k = 0; k < 3; ++k) { q[k] = ch.lo[k]; q[3 + k] = ch.hi[k]; }
+      quantise(ch.lo, ch.hi, pairs + 8 * me + 3 * c);
       refs[c] = ch.count > 0 ? leaf_ref(ch) : -1;
     }
     for (int c = 0; c < 2; ++c)
       if (nodes[nd.left + c].count == 0) refs[c] = emit(nd.left + c);
-    int32_t* qi = reinterpret_cast<int32_t*>(pairs + 16 * me + 12);
-    qi[0] = refs[0]; qi[1] = refs[1]; qi[2] = 0; qi[3] = 0;
+    pairs[8 * me + 6] = (uint32_t)refs[0];
+    pairs[8 * me + 7] = (uint32_t)refs[1];
     return (int32_t)me;
   }
 };
 }  // namespace
 
 extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const float* tris_host, int64_t nf,
-                                    float* pairs_host, float* tris12_host) {
-  TF_REQUIRE(nodes_host && tris_host && pairs_host && tris12_host, TF_EINVAL, "tf_bvh_pack_host: null pointer");
+                                    uint32_t* pairs_host, float* tris12_host, float* frame_host) {
+  TF_REQUIRE(nodes_host && tris_host && pairs_host && tris12_host && frame_host, TF_EINVAL, "tf_bvh_pack_host: null pointer");
   TF_REQUIRE(n_nodes > 0 && nf > 0 && nf < (1LL << 28), TF_ESHAPE, "tf_bvh_pack_host: need n_nodes > 0 and 0 < nf < 2^28");
   for (int64_t i = 0; i < n_nodes; ++i) {
     const TfBvhNode& n = nodes_host[i];
@@ -191,12 +220,22 @@ extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes
   }
   Packer P;
   P.nodes = nodes_host; P.pairs = pairs_host;
-  if (nodes_host[0].count > 0) {
+  const TfBvhNode& root = nodes_host[0];
+  for (int k = 0; k < 3; ++k) {
+    const double ext = std::max((double)root.hi[k] - (double)root.lo[k], 1e-6);
+    P.margin[k] = 8e-6 * ext;
+    P.org[k] = (double)root.lo[k] - 2.0 * P.margin[k];
+    P.scl[k] = (ext + 4.0 * P.margin[k]) / 65535.0;
+    // the kernel evaluates origin + q * scale in fp32: store fp32 values and quantise against exactly those
+    frame_host[k] = (float)P.org[k]; frame_host[3 + k] = (float)P.scl[k];
+    P.org[k] = frame_host[k]; P.scl[k] = frame_host[3 + k];
+  }
+  if (root.count > 0) {
     // the whole mesh is one leaf: a single pair whose second child is an empty box
-    const TfBvhNode& r = nodes_host[0];
-    for (int k = 0; k < 3; ++k) { pairs_host[k] = r.lo[k]; pairs_host[3 + k] = r.hi[k]; pairs_host[6 + k] = INFINITY; pairs_host[9 + k] = -INFINITY; }
-    int32_t* qi = reinterpret_cast<int32_t*>(pairs_host + 12);
-    qi[0] = Packer::leaf_ref(r); qi[1] = -1; qi[2] = qi[3] = 0;
+    P.quantise(root.lo, root.hi, pairs_host);
+    const float elo[3] = {1.f, 1.f, 1.f}, ehi[3] = {0.f, 0.f, 0.f};
+    P.quantise(elo, ehi, pairs_host + 3);
+    pairs_host[6] = (uint32_t)Packer::leaf_ref(root); pairs_host[7] = (uint32_t)-1;
     P.n_pairs = 1;
   } else {
     P.emit(0);
@@ -215,13 +254,16 @@ __device__ unsigned long long g_bvh_stats[4];   // inner lane-steps, leaf lane-s
 extern "C" void tf_bvh_stats(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_stats), 32); unsigned long long z[4] = {0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), z, 32); }
 #endif
 
-__device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, float hy, float hz, float ox, float oy,
-                                        float oz, float ix, float iy, float iz, float tmax, float& tnear) {
-  float t0 = (lx - ox) * ix, t1 = (hx - ox) * ix;
+// Slab test on a quantised box: plane coordinate x = org + q * scl, so t = (x - o) / d = q * (scl / d) + (org - o) / d
+// = fma(q, A, B) with the per-ray constants A, B -- the de-quantisation costs nothing (one fma per plane instead of a
+// subtract and a multiply).  w0, w1, w2 = {lo.x|lo.y<<16, lo.z|hi.x<<16, hi.y|hi.z<<16}.
+__device__ __forceinline__ bool box_hit(unsigned w0, unsigned w1, unsigned w2, float Ax, float Ay, float Az, float Bx, float By,
+                                        float Bz, float tmax, float& tnear) {
+  float t0 = fmaf((float)(w0 & 0xffffu), Ax, Bx), t1 = fmaf((float)(w1 >> 16), Ax, Bx);
   float tmin = fminf(t0, t1), tmx = fmaxf(t0, t1);
-  t0 = (ly - oy) * iy; t1 = (hy - oy) * iy;
+  t0 = fmaf((float)(w0 >> 16), Ay, By); t1 = fmaf((float)(w2 & 0xffffu), Ay, By);
   tmin = fmaxf(tmin, fminf(t0, t1)); tmx = fminf(tmx, fmaxf(t0, t1));
-  t0 = (lz - oz) * iz; t1 = (hz - oz) * iz;
+  t0 = fmaf((float)(w1 & 0xffffu), Az, Bz); t1 = fmaf((float)(w2 >> 16), Az, Bz);
   tmin = fmaxf(tmin, fminf(t0, t1)); tmx = fminf(tmx, fmaxf(t0, t1));
   tnear = tmin;
   // conservative: widen by a few ulps so that a hit the exact triangle test accepts is never culled
@@ -229,13 +271,15 @@ __device__ __forceinline__ bool box_hit(float lx, float ly, float lz, float hx, 
 }
 
 struct TraceArgs {
-  const float4* pairs;
+  float org[3], scl[3];        // quantisation grid of the pair boxes
+  const uint4* pairs;          // two uint4 per pair
   const float4* tris;
   const float* o;
   const float* d;
   const unsigned char* live;
   long long m;
   long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
+  const int* order;            // [rays_per_origin] or null: the j-th ray traced of a point is its slot order[j]
   float off0, off1;
   unsigned long long* counter;
   float* pos;
@@ -251,32 +295,52 @@ struct TraceArgs {
 // intersect its <= 4 triangles and pop): lanes that reach a leaf wait until enough of the wave is at a leaf too, so the
 // ~4x more expensive leaf body is not paid on every iteration for a couple of lanes.  DYN: persistent workgroups, a
 // lane pulls a new ray from a global counter once BVH_REFILL lanes of its wave are idle (a ray needs 5..70 steps).
+// The kernel is latency-bound (two thirds of a wave's life is s_waitcnt on the node fetch: rocprofv3 SQ_WAIT_ANY), so
+// occupancy is the lever: only the BVH_LDS_STACK deepest-used entries of the stack live in LDS (12 KB per block instead of
+// 32 KB -- a ray keeps ~4 entries pending on average, the tree is 24 deep on the bench mesh).
 template <bool DYN>
-__global__ void __launch_bounds__(256) bvh_trace_kernel(TraceArgs A) {
-  __shared__ int stack[BVH_STACK * 256];
+__global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) {
+  __shared__ int stack[BVH_LDS_STACK * 256];
+  int deep[BVH_STACK - BVH_LDS_STACK];
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
   long long rid = -1;
   int cur = BVH_NONE, sp = 0, best_tri = -1;
-  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, best = BVH_MAX_DIST;
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, best = BVH_MAX_DIST;
+  float Ax = 0, Ay = 0, Az = 0, Bx = 0, By = 0, Bz = 0;   // slab-test constants of the current ray
   bool exhausted = false;
   long long q_next = 0, q_end = 0;   // wave-uniform: this wave's private chunk of the ray pool
   int grab = BVH_CHUNK_MAX;
 #ifdef BVH_STATS
   unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0;
 #endif
-  auto start_ray = [&](long long id) {
+  auto start_ray = [&](long long seq) {
+    // trace order -> ray id: consecutive lanes take the slots of one point in `order` (directions sorted along a
+    // space-filling curve by the caller), so a wave's rays share an origin AND point the same way
+    const long long oid = seq / A.rays_per_origin;
+    const long long id = A.order ? oid * A.rays_per_origin + A.order[seq - oid * A.rays_per_origin] : seq;
     rid = id;
-    const long long oid = id / A.rays_per_origin;
     dx = A.d[3 * id]; dy = A.d[3 * id + 1]; dz = A.d[3 * id + 2];
     // origin = (o + d*off0) + off1*d, with the reference's two separate roundings (no fma contraction)
     ox = __fadd_rn(__fadd_rn(A.o[3 * oid], __fmul_rn(dx, A.off0)), __fmul_rn(A.off1, dx));
     oy = __fadd_rn(__fadd_rn(A.o[3 * oid + 1], __fmul_rn(dy, A.off0)), __fmul_rn(A.off1, dy));
     oz = __fadd_rn(__fadd_rn(A.o[3 * oid + 2], __fmul_rn(dz, A.off0)), __fmul_rn(A.off1, dz));
-    ix = 1.f / dx; iy = 1.f / dy; iz = 1.f / dz;
+    const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz;
+    Ax = A.scl[0] * ix; Ay = A.scl[1] * iy; Az = A.scl[2] * iz;
+    Bx = (A.org[0] - ox) * ix; By = (A.org[1] - oy) * iy; Bz = (A.org[2] - oz) * iz;
     best = BVH_MAX_DIST; best_tri = -1; sp = 0;
     cur = 0;
     if (A.live && !A.live[id]) cur = BVH_NONE;   // zero weight in the integral: reported as a miss, never traversed
+  };
+  auto push = [&](int ref) {
+    if (sp < BVH_LDS_STACK) stack[sp * 256 + tid] = ref;
+    else deep[sp - BVH_LDS_STACK] = ref;
+    ++sp;
+  };
+  auto pop = [&]() -> int {
+    if (sp == 0) return BVH_NONE;
+    --sp;
+    return sp < BVH_LDS_STACK ? stack[sp * 256 + tid] : deep[sp - BVH_LDS_STACK];
   };
   auto retire = [&]() {
     A.depth[rid] = best;
@@ -368,7 +432,7 @@ __global__ void __launch_bounds__(256) bvh_trace_kernel(TraceArgs A) {
             const float t = det * -(nx * rx + ny * ry + nz * rz);
             if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) { best = t; best_tri = first + k; }
           }
-          cur = sp > 0 ? stack[(--sp) * 256 + tid] : BVH_NONE;
+          cur = pop();
         }
       } else {
 #ifdef BVH_STATS
@@ -378,22 +442,22 @@ __global__ void __launch_bounds__(256) bvh_trace_kernel(TraceArgs A) {
 #ifdef BVH_STATS
           st_inner++;
 #endif
-          const float4* P = A.pairs + 4LL * cur;
-          const float4 q0 = P[0], q1 = P[1], q2 = P[2];
-          const int4 q3 = *reinterpret_cast<const int4*>(P + 3);
+          const uint4* P = A.pairs + 2LL * cur;
+          const uint4 q0 = P[0], q1 = P[1];
+          const int c0 = (int)q1.z, c1 = (int)q1.w;
           float tl, tr;
-          const bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, best, tl);
-          const bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, best, tr);
+          const bool hl = box_hit(q0.x, q0.y, q0.z, Ax, Ay, Az, Bx, By, Bz, best, tl);
+          const bool hr = box_hit(q0.w, q1.x, q1.y, Ax, Ay, Az, Bx, By, Bz, best, tr);
           if (hl && hr) {
             const bool left_first = tl <= tr;
-            stack[(sp++) * 256 + tid] = left_first ? q3.y : q3.x;   // depth <= BVH_MAX_DEPTH bounds sp < BVH_STACK
-            cur = left_first ? q3.x : q3.y;
+            push(left_first ? c1 : c0);                             // depth <= BVH_MAX_DEPTH bounds sp < BVH_STACK
+            cur = left_first ? c0 : c1;
           } else if (hl) {
-            cur = q3.x;
+            cur = c0;
           } else if (hr) {
-            cur = q3.y;
+            cur = c1;
           } else {
-            cur = sp > 0 ? stack[(--sp) * 256 + tid] : BVH_NONE;
+            cur = pop();
           }
         }
       }
@@ -406,26 +470,34 @@ __global__ void __launch_bounds__(256) bvh_trace_kernel(TraceArgs A) {
 #endif
 }
 
-extern "C" int tf_bvh_trace(const float* pairs, const float* tris12, int64_t n_pairs, const float* o, const float* d,
-                            int64_t rays_per_origin, float origin_offset0, float origin_offset1, const uint8_t* live,
+extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const float* frame_host, int64_t n_pairs, const float* o, const float* d,
+                            int64_t rays_per_origin, const int32_t* slot_order, float origin_offset0, float origin_offset1, const uint8_t* live,
                             int64_t m, float* pos, float* nrm, float* depth, uint8_t* hit, int64_t* work_counter,
                             tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(m >= 0 && n_pairs > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
   TF_REQUIRE(rays_per_origin >= 1, TF_ESHAPE, "tf_bvh_trace: rays_per_origin must be >= 1");
   if (m == 0) return TF_OK;
-  TF_REQUIRE(pairs && tris12 && o && d && depth, TF_EINVAL, "tf_bvh_trace: null pointer");
+  TF_REQUIRE(pairs && tris12 && frame_host && o && d && depth, TF_EINVAL, "tf_bvh_trace: null pointer");
   TF_REQUIRE((((uintptr_t)pairs | (uintptr_t)tris12) & 15) == 0, TF_EINVAL, "tf_bvh_trace: pairs / tris12 must be 16-byte aligned");
   TraceArgs A;
-  A.pairs = reinterpret_cast<const float4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
-  A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin;
+  A.pairs = reinterpret_cast<const uint4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
+  for (int k = 0; k < 3; ++k) { A.org[k] = frame_host[k]; A.scl[k] = frame_host[3 + k]; }
+  A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order;
+  TF_REQUIRE(!slot_order || m % rays_per_origin == 0, TF_ESHAPE, "tf_bvh_trace: slot_order needs m to be a multiple of rays_per_origin");
   A.off0 = origin_offset0; A.off1 = origin_offset1; A.counter = (unsigned long long*)work_counter;
   A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit;
   if (work_counter) {
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int64_t), stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_bvh_trace: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    static int resident = 0;    // blocks per CU the hardware admits (registers / LDS), queried once
+    if (!resident) {
+      int nb = 0;
+      hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true>, 256, 0);
+      resident = (e2 == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;
+    }
     long long blocks = (m + 255) / 256;
-    if (blocks > 256 * 5) blocks = 256 * 5;   // 5 resident 256-thread blocks per CU (32 KB of LDS stack each) pull rays until the pool is empty
+    if (blocks > 256LL * resident) blocks = 256LL * resident;   // persistent blocks pull rays until the pool is empty
     bvh_trace_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(A);
   } else {
     bvh_trace_kernel<false><<<tf_blocks(m, 256), 256, 0, stream>>>(A);

@@ -434,22 +434,26 @@ class Bvh:
         if n <= 0:
             L.check(int(n), "tf_bvh_build_host")
         self.n_nodes = int(n)
-        pairs = np.zeros((n // 2 + 1, 16), dtype=np.float32)
+        pairs = np.zeros((n // 2 + 1, 8), dtype=np.uint32)
         tris12 = np.zeros((f.shape[0], 12), dtype=np.float32)
-        npair = self.lib.tf_bvh_pack_host(nodes.ctypes.data, int(n), tris.ctypes.data, f.shape[0], pairs.ctypes.data, tris12.ctypes.data)
+        self.frame = (C.c_float * 6)()
+        npair = self.lib.tf_bvh_pack_host(nodes.ctypes.data, int(n), tris.ctypes.data, f.shape[0], pairs.ctypes.data, tris12.ctypes.data,
+                                          C.addressof(self.frame))
         if npair <= 0:
             L.check(int(npair), "tf_bvh_pack_host")
         self.n_pairs = int(npair)
-        self.pairs = torch.from_numpy(pairs[:npair].copy()).to(device)
+        self.pairs = torch.from_numpy(pairs[:npair].view(np.int32).copy()).to(device)
         self.tris = torch.from_numpy(tris12).to(device)
 
-    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True):
+    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True, slot_order=None):
         """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3]."""
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = d.shape[0]
         if o.shape[0] == 0 or m % o.shape[0] != 0:
             raise RuntimeError(f"Bvh.trace: {m} directions cannot share {o.shape[0]} origins")
         per_origin = m // o.shape[0]
+        if slot_order is not None and (slot_order.dtype != torch.int32 or slot_order.numel() != per_origin):
+            raise RuntimeError("Bvh.trace: slot_order must be an int32 permutation of the rays of one origin")
         dev = o.device
         pos = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_pos else None
         nrm = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_nrm else None
@@ -457,7 +461,7 @@ class Bvh:
         hit = torch.empty(m, dtype=torch.uint8, device=dev)
         lv = None if live is None else live.reshape(-1).contiguous()
         ctr = torch.empty(1, dtype=torch.int64, device=dev) if dynamic else None
-        L.check(self.lib.tf_bvh_trace(_p(self.pairs), _p(self.tris), self.n_pairs, _p(o), _p(d), per_origin, float(off0), float(off1),
+        L.check(self.lib.tf_bvh_trace(_p(self.pairs, torch.int32), _p(self.tris), C.byref(self.frame), self.n_pairs, _p(o), _p(d), per_origin, _p(slot_order, torch.int32), float(off0), float(off1),
                                       _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
                                       _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()

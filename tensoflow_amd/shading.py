@@ -164,6 +164,8 @@ class MCShader:
                                         [self.flow_d.mat, self.flow_s.mat], self.aabb)
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
         self._latent = {}
+        self._order = {}
+        self.sort_rays = True           # trace each point's rays in direction-sorted order (results unchanged)
         self.timer = _NoTimer()
         self.hit_total = None
 
@@ -180,12 +182,31 @@ class MCShader:
         rough = out["roughness"] * (1.0 - 0.04 ** 2) + 0.04 ** 2
         return out["metallic"], rough, out["albedo"]
 
-    def lights(self, pts_rep, dirs, live=None):
+    def slot_order(self, sn_d, sn_s):
+        """Traversal order of a point's T = sn_d + n_fixed + sn_s secondary rays (tf_bvh_trace slot_order): inside each of
+        the three direction sets the slots are sorted along a Morton curve over their (azimuth, elevation) cell, so the 64
+        rays of a wavefront point the same way.  The sets themselves are Fibonacci spirals -- neighbouring slots are ~222
+        degrees apart in azimuth.  (The flow-warped sets are sorted by their latent position: the warp is smooth.)"""
+        key = (sn_d, sn_s)
+        if key not in self._order:
+            def morton(a):                      # a [n,2] in [0,1]^2 -> sort index
+                q = np.clip((a * 16).astype(np.int64), 0, 15)
+                code = np.zeros(len(a), np.int64)
+                for b in range(4):
+                    code |= ((q[:, 0] >> b) & 1) << (2 * b + 1) | ((q[:, 1] >> b) & 1) << (2 * b)
+                return np.argsort(code, kind="stable")
+            nf = self.fixed_d.shape[0]
+            parts = [morton(sphere_latent(sn_d).numpy()), sn_d + morton(self.fixed_d.cpu().numpy()),
+                     sn_d + nf + morton(sphere_latent(sn_s).numpy())]
+            self._order[key] = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(self.device)
+        return self._order[key]
+
+    def lights(self, pts_rep, dirs, live=None, slot_order=None):
         """get_lights (fields.py:951-975): pts_rep [M,3] (or [M // T, 3]: T consecutive rays per origin), dirs [M,3] -> lights [M,3], hit [M] bool.
         live [M] uint8 (optional): rays whose weight in the integral is exactly zero are neither traced nor shaded."""
         T = self.timer
         with T.stage("bvh_trace"):
-            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live)
+            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live, slot_order=slot_order)
         with T.stage("cube_lookup"):
             # miss branch + near mask of get_lights in one pass (every ray; hit rays are overwritten below)
             lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)
@@ -217,7 +238,8 @@ class MCShader:
             dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built
-        lights, hit, inters = self.lights(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
+        lights, hit, inters = self.lights(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
+                                          slot_order=self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
             colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)

@@ -86,18 +86,29 @@ def test_bvh_build_host(lib):
 
 
 def test_bvh_pack_host(lib):
-    """Traversal layout: every triangle is reachable through exactly one leaf reference, child boxes are the nodes' boxes,
-    the tree respects the depth bound of the device stack, triangles are stored as (a, b - a, c - a)."""
+    """Traversal layout: every triangle is reachable through exactly one leaf reference, the quantised child boxes contain
+    the triangles of their leaves (rounded outward, within a few grid cells), the tree respects the depth bound of the device
+    stack, triangles are stored as (a, b - a, c - a)."""
     from tensoflow_amd.synth import sphere_torus_mesh
     v, f = sphere_torus_mesh(16, 24, 32, 12)
     nodes = np.zeros((2 * len(f), 8), np.float32)
     tris = np.zeros((len(f), 9), np.float32)
     n = lib.tf_bvh_build_host(v.ctypes.data, len(v), f.ctypes.data, len(f), nodes.ctypes.data, tris.ctypes.data)
-    pairs = np.zeros((n // 2 + 1, 16), np.float32)
+    pairs = np.zeros((n // 2 + 1, 8), np.uint32)
     t12 = np.zeros((len(f), 12), np.float32)
-    npair = lib.tf_bvh_pack_host(nodes.ctypes.data, n, tris.ctypes.data, len(f), pairs.ctypes.data, t12.ctypes.data)
+    frame = np.zeros(6, np.float32)
+    npair = lib.tf_bvh_pack_host(nodes.ctypes.data, n, tris.ctypes.data, len(f), pairs.ctypes.data, t12.ctypes.data, frame.ctypes.data)
     assert npair == (n - 1) // 2
-    refs = pairs[:npair, 12:14].view(np.int32)
+    org, scl = frame[:3].astype(np.float64), frame[3:].astype(np.float64)
+    assert (org < nodes[0, 0:3]).all() and (org + 65535 * scl > nodes[0, 4:7]).all()      # the grid covers the root box
+
+    def box(i, c):
+        w = pairs[i, 3 * c:3 * c + 3].astype(np.int64)
+        qlo = np.array([w[0] & 0xffff, w[0] >> 16, w[1] & 0xffff])
+        qhi = np.array([w[1] >> 16, w[2] & 0xffff, w[2] >> 16])
+        return org + qlo * scl, org + qhi * scl
+
+    refs = pairs[:npair, 6:8].view(np.int32)
     seen = np.zeros(len(f), np.int32)
     visited = np.zeros(npair, np.int32)
     stack, max_depth = [(0, 1)], 0
@@ -107,7 +118,7 @@ def test_bvh_pack_host(lib):
         max_depth = max(max_depth, depth)
         for c in range(2):
             r = int(refs[i, c])
-            box = pairs[i, 6 * c:6 * c + 6]
+            lo, hi = box(i, c)
             if r >= 0:
                 assert r > i                                   # depth-first numbering
                 stack.append((r, depth + 1))
@@ -117,18 +128,20 @@ def test_bvh_pack_host(lib):
                 assert 1 <= cnt <= 4
                 seen[first:first + cnt] += 1
                 t = tris[first:first + cnt].reshape(-1, 3)
-                assert (t >= box[:3] - 1e-6).all() and (t <= box[3:] + 1e-6).all()
+                assert (t.min(0) >= lo).all() and (t.max(0) <= hi).all()                   # conservative ...
+                assert (t.min(0) - lo < 3 * scl + 1e-4).all() and (hi - t.max(0) < 3 * scl + 1e-4).all()   # ... and tight
     assert (seen == 1).all() and (visited == 1).all() and max_depth <= 31
     assert np.array_equal(t12[:, 0:3], tris[:, 0:3]) and np.array_equal(t12[:, 3:6], tris[:, 3:6] - tris[:, 0:3])
     assert np.array_equal(t12[:, 6:9], tris[:, 6:9] - tris[:, 0:3])
-    # a mesh that fits one leaf still packs to one (degenerate) pair
+    # a mesh that fits one leaf still packs to one (degenerate) pair whose second box is empty
     v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
     f1 = np.array([[0, 1, 2], [0, 1, 3]], np.int32)
     nodes1 = np.zeros((4, 8), np.float32); tris1 = np.zeros((2, 9), np.float32)
     n1 = lib.tf_bvh_build_host(v1.ctypes.data, 4, f1.ctypes.data, 2, nodes1.ctypes.data, tris1.ctypes.data)
-    p1 = np.zeros((2, 16), np.float32); t1 = np.zeros((2, 12), np.float32)
-    assert n1 == 1 and lib.tf_bvh_pack_host(nodes1.ctypes.data, 1, tris1.ctypes.data, 2, p1.ctypes.data, t1.ctypes.data) == 1
-    assert p1[0, 12:14].view(np.int32).tolist() == [~((0 << 3) | 2), -1]
+    p1 = np.zeros((2, 8), np.uint32); t1 = np.zeros((2, 12), np.float32); fr1 = np.zeros(6, np.float32)
+    assert n1 == 1 and lib.tf_bvh_pack_host(nodes1.ctypes.data, 1, tris1.ctypes.data, 2, p1.ctypes.data, t1.ctypes.data, fr1.ctypes.data) == 1
+    assert p1[0, 6:8].view(np.int32).tolist() == [~((0 << 3) | 2), -1]
+    assert (p1[0, 3] & 0xffff) > (p1[0, 4] >> 16)                                          # empty: lo.x > hi.x
 
 
 def test_bvh_depth_bound_on_degenerate_mesh(lib):

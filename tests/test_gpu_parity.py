@@ -308,6 +308,11 @@ def test_shade_golden(golden, dev, tag):
     out2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
     assert torch.equal(out2["hit"][:, :nd].cpu(), ref["diffuse_hit"])
     assert torch.equal(out2["colors"], out["colors"])                                 # culling changes nothing, bit for bit
+    sh.cull_dead_rays, sh.sort_rays = True, False                                     # traversal in slot order instead of direction-sorted
+    out3 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
+    assert torch.equal(out3["hit"], out["hit"]) and torch.equal(out3["colors"], out["colors"])
+    order = sh.slot_order(sn_d, sn_s).cpu().long()
+    assert torch.equal(order.sort().values, torch.arange(sn_d + n_fd + sn_s))         # a permutation of the slots
 
 
 # ------------------------------------------------------------------------------ env-light prefilter (A12)
