@@ -128,7 +128,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
             sl = slice(c0, min(c0 + chunk, n_rays_total))
             t0, t1, ridx = march.march_uniform(field, o[sl], d[sl], near[sl], far[sl], n_steps=n_steps, mask=mask)
             out = march.render_core(field, o[sl], d[sl], radii[sl], cos[sl], t0, t1, ridx, base_radii, inv_s, 1.0,
-                                    shade_fn=lambda p, n, v, f: shader(p, n, v, f)[0])
+                                    shade_fn=lambda p, n, v, f: shader(p, n, v, f)[0], is_train=False)
             live += t0.numel()
         return live, out
     frame()
@@ -142,7 +142,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     sdf_s = sum(s.elapsed_time(e) for s, e in sdf_ev) * 1e-3 / steps
     sps = live / sdf_s
     return dict(workload=f"TensoSDF R=300 C=36 3 mips, {n_rays_total} rays x {n_steps} fixed steps, 128^3 occupancy culling, "
-                         f"fused 7-tap sdf+FD+alpha, split-sum shading, compositing (forward)",
+                         f"fused 7-tap sdf+FD+alpha (eval: no hessian term, f16x3 decoder), split-sum shading, compositing (forward)",
                 rays_per_s=n_rays_total / dt, frame_ms=dt * 1e3, live_samples_per_frame=live,
                 live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
                 sdf_alpha_samples_per_s=sps, algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,

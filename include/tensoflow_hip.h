@@ -101,10 +101,13 @@ size_t tf_sdf_workspace_floats(void);
 
 /* TensoSDF.forward (fields.py:262-299), returned split the way every caller slices it
  * (fields.py:148-152): sdf [n] = out[:,0], feat [n,A] = out[:,1:] (feat may be NULL: sdf only).
- * This build instantiates C = 36, Hd = 256, A = 128 (configs/shape/syn/compressor.yaml:64-66). */
+ * This build instantiates C = 36, Hd = 256, A = 128 (configs/shape/syn/compressor.yaml:64-66).  * precision (TfPrecision): arithmetic of the two decoder products.  TF_PREC_F16X3 (3 x f16 MFMA per fp32 product term,
+ * ~22 significant bits) makes the fused march kernel gather-bound instead of fp32-MFMA-bound; the second finite difference
+ * `nhess` divides the decoder's rounding noise by eps^2, so training passes that need it use TF_PREC_F32.
+ */
 int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* xyz,
                    const float* level, const float* aabb_host, int64_t n, float* sdf, float* feat,
-                   float* workspace, size_t workspace_floats, tf_stream_t stream);
+                   int32_t precision, float* workspace, size_t workspace_floats, tf_stream_t stream);
 
 /* ShapeRenderer.compute_sdf_alpha (shapeRenderer.py:995-1025) = forward + 6-tap central
  * differences (fields.py:227-260) + NeuS alpha.  units_host[3] = aabbSize/(R-1).
@@ -112,7 +115,7 @@ int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, 
 int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
                      const float* level, const float* dists, const float* dirs, const float* aabb_host,
                      const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha,
-                     float* grad, float* feat, float* sdf, float* nhess, float* workspace,
+                     float* grad, float* feat, float* sdf, float* nhess, int32_t precision, float* workspace,
                      size_t workspace_floats, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -113,7 +113,7 @@ __device__ __forceinline__ float4 blend_chunk(const ChunkRaw (&r)[NL], float fl)
 // NL = number of mip levels fetched (1 when no lane of the wave has a fractional LOD, else 2).
 // Layer 1 runs as 7 feature groups of 2 chunks (8 k-steps x 8 unit tiles = 64 MFMAs each): while group g's MFMAs
 // execute, the 12*NL texel loads of group g+1 are already in flight.
-template <int NL>
+template <int NL, bool H3>
 __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
                                                int l1, float fl, int lane, f32x16 (&acc)[8]) {
   // Make the LDS base opaque per call: every LDS operand of this function (W1 fragments, biases, the sdf row of
@@ -156,6 +156,23 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
     }
     if (g + 1 < 7) issue(g + 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (H3) {
+      // f16x3: the 16 features of group g are exactly one 32x32x16 k-step (lane half h supplies k = 16g + 4h + {0..3} and
+      // 16g + 8 + 4h + {0..3}: the two chunks it has just blended); fragments [g][tile][hi|lo][lane][8 halves] in LDS
+      tf_h8 b_hi, b_lo;
+      tf_split8(f8, b_hi, b_lo);
+      const tf_h8* wf16 = reinterpret_cast<const tf_h8*>(lds + kW1f) + (8 * g) * 128 + lane;
+      tf_h8 a_hi = wf16[0], a_lo = wf16[64];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        tf_h8 n_hi = a_hi, n_lo = a_lo;
+        if (tt + 1 < 8) { n_hi = wf16[(tt + 1) * 128]; n_lo = wf16[(tt + 1) * 128 + 64]; }
+        acc[tt] = tf_mfma_h(a_hi, b_hi, acc[tt]);
+        acc[tt] = tf_mfma_h(a_hi, b_lo, acc[tt]);
+        acc[tt] = tf_mfma_h(a_lo, b_hi, acc[tt]);
+        a_hi = n_hi; a_lo = n_lo;
+      }
+    } else {
     const float* wf = lds + kW1f + (8 * g) * 64 + lane;
     float a_cur[8], a_nxt[8];
 #pragma unroll
@@ -171,6 +188,7 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
 #pragma unroll
       for (int tt = 0; tt < 8; ++tt) a_cur[tt] = a_nxt[tt];
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   float part = 0.f;
@@ -185,14 +203,15 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
   return part + A.b2[0];
 }
 
+template <bool H3>
 __device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
                                             int l1, float fl, int lane, f32x16 (&acc)[8]) {
   // wave-uniform choice: one mip level is enough when no lane has a fractional LOD
-  if (__any(fl != 0.f)) return sdf_hidden_nl<2>(A, lds, x, l0, l1, fl, lane, acc);
-  return sdf_hidden_nl<1>(A, lds, x, l0, l1, fl, lane, acc);
+  if (__any(fl != 0.f)) return sdf_hidden_nl<2, H3>(A, lds, x, l0, l1, fl, lane, acc);
+  return sdf_hidden_nl<1, H3>(A, lds, x, l0, l1, fl, lane, acc);
 }
 
-template <int MODE>  // 0: sdf + feat, 1: sdf only, 2: alpha (7 taps)
+template <int MODE, bool H3>  // MODE 0: sdf + feat, 1: sdf only, 2: alpha (7 taps); H3: f16x3 matrix arithmetic
 __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
@@ -221,7 +240,7 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
     float fl;
     mip_select(A.level ? A.level[row] : 0.f, A.g.n_levels, l0, l1, fl);
     f32x16 acc[8];
-    const float s_c = sdf_hidden(A, lds, x, l0, l1, fl, lane, acc);
+    const float s_c = sdf_hidden<H3>(A, lds, x, l0, l1, fl, lane, acc);
     if (MODE != 1 && A.feat) {
       // appearance features: [128 x 256] * H^T, W2 fragments streamed from L2
       f32x16 o[4];
@@ -229,7 +248,8 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[t][j] = lds[kB2a + (t * 16 + j) * 2 + h];
-      tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kStream, threadIdx.x, lane, acc, o);
+      if (H3) tf_layer_stream_h3<16, 4, 8, 2, 2>(reinterpret_cast<const _Float16*>(A.ws + kW2f), lds + kStream, threadIdx.x, lane, acc, o);
+      else tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kStream, threadIdx.x, lane, acc, o);
       if (valid) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -250,9 +270,9 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
     for (int ax = 0; ax < 3; ++ax) {
       float xt[3] = {x[0], x[1], x[2]};
       xt[ax] = x[ax] + A.units[ax];
-      sp[ax] = sdf_hidden(A, lds, xt, l0, l1, fl, lane, acc);
+      sp[ax] = sdf_hidden<H3>(A, lds, xt, l0, l1, fl, lane, acc);
       xt[ax] = x[ax] - A.units[ax];
-      sn[ax] = sdf_hidden(A, lds, xt, l0, l1, fl, lane, acc);
+      sn[ax] = sdf_hidden<H3>(A, lds, xt, l0, l1, fl, lane, acc);
     }
     if (valid && h == 0) {
       float g[3], hs[3];
@@ -276,7 +296,8 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
 }
 
 static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb_host, float* workspace,
-                       size_t workspace_floats, SdfArgs* A, hipStream_t stream, const char* who) {
+                       size_t workspace_floats, SdfArgs* A, int32_t precision, hipStream_t stream, const char* who) {
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
   TF_REQUIRE(d && mlp && aabb_host && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(d->C == SDF_C && mlp->hidden == SDF_HID && mlp->app_dim == SDF_APP, TF_ESHAPE,
              "%s: this build instantiates C=%d hidden=%d app_dim=%d (got %d/%d/%d)", who, SDF_C, SDF_HID, SDF_APP, d->C,
@@ -289,61 +310,73 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
              workspace_floats, kSdfWsFloats);
   TF_REQUIRE(mlp->w1 && mlp->b1 && mlp->w2 && mlp->b2, TF_EINVAL, "%s: null weight pointer", who);
   const int K = 3 * SDF_C + 3;
-  tf_pack_wfrag_kernel<<<tf_blocks(8 * SDF_KSTEPS * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS,
-                                                                                workspace + kW1f);
+  // the f16x3 images have the same size as the fp32 fragment images they replace (hi + lo halves = 4 bytes per weight)
+  if (precision == TF_PREC_F16X3)
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 7 * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, 7,
+                                                                            reinterpret_cast<_Float16*>(workspace + kW1f));
+  else
+    tf_pack_wfrag_kernel<<<tf_blocks(8 * SDF_KSTEPS * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS,
+                                                                                  workspace + kW1f);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b1, SDF_HID, 8, workspace + kB1a);
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
   tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
-  tf_pack_wfrag_kernel<<<tf_blocks(4 * 128 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4,
-                                                                         128, workspace + kW2f, 1);
+  if (precision == TF_PREC_F16X3)
+    tf_pack_wfrag_h3_kernel<<<tf_blocks(4 * 16 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4, 16,
+                                                                             reinterpret_cast<_Float16*>(workspace + kW2f));
+  else
+    tf_pack_wfrag_kernel<<<tf_blocks(4 * 128 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4,
+                                                                           128, workspace + kW2f, 1);
   A->ws = workspace;
   return TF_OK;
 }
 
-template <int MODE>
+template <int MODE, bool H3>
 static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
   A.b2 = b2_dev;
   const size_t lds = (size_t)kLdsTotal * sizeof(float);  // weights + W2 streaming double buffer + geometry table
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[MODE]) {
-    hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
-    attr_set[MODE] = true;
+    attr_set = true;
   }
   long long blocks = (A.n + 127) / 128;
   if (blocks > 256) blocks = 256;  // one 150 KB-LDS workgroup per CU; waves loop over tile groups
-  sdf_kernel<MODE><<<(unsigned)blocks, 256, lds, stream>>>(A);
+  sdf_kernel<MODE, H3><<<(unsigned)blocks, 256, lds, stream>>>(A);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
 
 extern "C" int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* xyz,
                               const float* level, const float* aabb_host, int64_t n, float* sdf, float* feat,
-                              float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+                              int32_t precision, float* workspace, size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_forward: n < 0");
   if (n == 0) return TF_OK;
   TF_REQUIRE(packed && xyz && sdf, TF_EINVAL, "tf_sdf_forward: null pointer");
   SdfArgs A = {};
-  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, stream, "tf_sdf_forward")) return rc;
+  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, precision, stream, "tf_sdf_forward")) return rc;
   A.packed = packed; A.pts = xyz; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
-  return feat ? sdf_launch<0>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1>(A, mlp->b2, stream, "tf_sdf_forward");
+  if (precision == TF_PREC_F16X3)
+    return feat ? sdf_launch<0, true>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1, true>(A, mlp->b2, stream, "tf_sdf_forward");
+  return feat ? sdf_launch<0, false>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1, false>(A, mlp->b2, stream, "tf_sdf_forward");
 }
 
 extern "C" int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
                                 const float* level, const float* dists, const float* dirs, const float* aabb_host,
                                 const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha, float* grad,
-                                float* feat, float* sdf, float* nhess, float* workspace, size_t workspace_floats,
-                                tf_stream_t stream_) {
+                                float* feat, float* sdf, float* nhess, int32_t precision, float* workspace,
+                                size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_alpha_fwd: n < 0");
   if (n == 0) return TF_OK;
   TF_REQUIRE(packed && pts && dists && dirs && units_host && alpha && grad && sdf, TF_EINVAL, "tf_sdf_alpha_fwd: null pointer");
   SdfArgs A = {};
-  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, stream, "tf_sdf_alpha_fwd")) return rc;
+  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, precision, stream, "tf_sdf_alpha_fwd")) return rc;
   A.packed = packed; A.pts = pts; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
   A.dists = dists; A.dirs = dirs; A.inv_s = inv_s; A.cos_anneal = cos_anneal;
   for (int k = 0; k < 3; ++k) A.units[k] = units_host[k];
   A.alpha = alpha; A.grad = grad; A.nhess = nhess;
-  return sdf_launch<2>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
+  return precision == TF_PREC_F16X3 ? sdf_launch<2, true>(A, mlp->b2, stream, "tf_sdf_alpha_fwd")
+                                    : sdf_launch<2, false>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
 }

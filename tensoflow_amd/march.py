@@ -51,9 +51,9 @@ class SdfField:
     def forward(self, pts, level=None):
         return ops.sdf_forward(self.packed, *self.W, pts, level, self.aabb, want_feat=True)
 
-    def sdf_alpha(self, pts, level, dists, dirs, inv_s, cos_anneal, want_feat=True, want_hess=True):
+    def sdf_alpha(self, pts, level, dists, dirs, inv_s, cos_anneal, want_feat=True, want_hess=True, precision=None):
         return ops.sdf_alpha(self.packed, *self.W, pts, level, dists, dirs, self.aabb, self.units, inv_s, cos_anneal,
-                             want_feat=want_feat, want_hess=want_hess)
+                             want_feat=want_feat, want_hess=want_hess, precision=precision)
 
 
 def _sample_pdf_det(bins, weights, n):
@@ -174,8 +174,10 @@ def march_uniform(field: SdfField, o, d, near, far, n_steps=256, step_size=0.0, 
 
 @torch.no_grad()
 def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radii, inv_s, cos_anneal, shade_fn=None,
-                mask: AlphaMask = None):
-    """Train-branch forward of ShapeRenderer.render_core with a white background.
+                mask: AlphaMask = None, is_train=True, precision=None):
+    """Forward of ShapeRenderer.render_core with a white background.  is_train=True also returns the hessian regulariser
+    term (TensoSDF.gradient computes it only when training, fields.py:244-258); is_train=False (nvs / eval) skips it.
+    precision: decoder arithmetic (ops.PREC_F16X3 default, ops.PREC_F32 exact).
     shade_fn(points, normals, view_dirs, feat) -> color [N,3] (split-sum shading); None -> white (geometry-only march).
     mask: AlphaGridMask culling of the packed samples (shapeRenderer.py:1119-1129)."""
     rn = o.shape[0]
@@ -187,7 +189,7 @@ def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radi
     ro, rd = o[ridx], d[ridx]
     pts = ro + rd * mid[:, None]
     lv = torch.log2(ball_radii(mid[:, None], radiis[ridx], rays_cos[ridx]) / base_radii)[:, 0]
-    alpha, grad, feat, sdf, nh = field.sdf_alpha(pts, lv, dists, rd, inv_s, cos_anneal)
+    alpha, grad, feat, sdf, nh = field.sdf_alpha(pts, lv, dists, rd, inv_s, cos_anneal, want_hess=is_train, precision=precision)
     color = shade_fn(pts, F.normalize(grad, dim=-1), -rd, feat) if shade_fn is not None else torch.ones_like(pts)
     vals = torch.cat([color, grad], -1).contiguous()
     w, acc, out = ops.composite(alpha, ridx, vals, rn)
@@ -196,4 +198,4 @@ def render_core(field: SdfField, o, d, radiis, rays_cos, t0, t1, ridx, base_radi
     nrm = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * torch.tensor([0.0, 0.0, 1.0], device=o.device), dim=-1)
     return dict(ray_rgb=rgb, acc=acc, normal=nrm, gradient_error=(grad.norm(dim=-1) - 1.0) ** 2, alpha=alpha, weights=w,
                 sdf=sdf, grad=grad, feat=feat, normal_hessian=nh, points=pts, levels=lv,
-                loss_sparse=torch.exp(-20.0 * sdf.abs()).mean(), loss_hessian=nh.abs().mean())
+                loss_sparse=torch.exp(-20.0 * sdf.abs()).mean(), loss_hessian=None if nh is None else nh.abs().mean())

@@ -12,6 +12,9 @@ import torch
 from . import lib as L
 
 
+PREC_F32, PREC_F16X3 = 0, 1      # TfPrecision
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -118,8 +121,8 @@ def _workspace(key, n_floats, device):
     return t
 
 
-def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=True):
-    """TensoSDF.forward -> (sdf [n], feat [n,A] or None)."""
+def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=True, precision=1):
+    """TensoSDF.forward -> (sdf [n], feat [n,A] or None).  precision: PREC_F16X3 (default) or PREC_F32."""
     lib = packed.lib
     xyz = _f(xyz)
     n = xyz.shape[0]
@@ -129,13 +132,17 @@ def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=Tr
     ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), xyz.device)
     lv = None if level is None else _f(level.reshape(-1))
     L.check(lib.tf_sdf_forward(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
-                               n, _p(sdf), _p(feat), _p(ws), ws.numel(), _stream()), "tf_sdf_forward")
+                               n, _p(sdf), _p(feat), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_forward")
     return sdf, feat
 
 
 def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, units, inv_s, cos_anneal,
-              want_feat=True, want_hess=True):
-    """ShapeRenderer.compute_sdf_alpha -> alpha, grad, feat, sdf, normal_hessian."""
+              want_feat=True, want_hess=True, precision=None):
+    """ShapeRenderer.compute_sdf_alpha -> alpha, grad, feat, sdf, normal_hessian.
+    precision: PREC_F16X3 (default) / PREC_F32.  (The hessian term's second difference divides rounding noise by eps^2;
+    against the reference it measures 1.1e-3 with either decoder -- the reference's own fp32 rounding dominates.)"""
+    if precision is None:
+        precision = PREC_F16X3
     lib = packed.lib
     pts, dists, dirs = _f(pts), _f(dists.reshape(-1)), _f(dirs)
     n = pts.shape[0]
@@ -151,7 +158,7 @@ def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, u
     un = (C.c_float * 3)(*[float(u) for u in units])
     L.check(lib.tf_sdf_alpha_fwd(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
                                  C.byref(_aabb6(aabb)), C.byref(un), float(inv_s), float(cos_anneal), n, _p(alpha), _p(grad),
-                                 _p(feat), _p(sdf), _p(nh), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
+                                 _p(feat), _p(sdf), _p(nh), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
     return alpha, grad, feat, sdf, nh
 
 
@@ -519,7 +526,6 @@ class PointPrep:
         return met, rough, alb, cd, cs
 
 
-PREC_F32, PREC_F16X3 = 0, 1
 WEIGHTS_PACKED = 0x100
 
 

@@ -35,8 +35,9 @@ if which == "sdf":
     n = pts.shape[0]
     dists = torch.full((n,), 2.0 / n_steps, device=dev)
     W = [sd["sdf_mat.0.weight"], sd["sdf_mat.0.bias"], sd["sdf_mat.2.weight"], sd["sdf_mat.2.bias"]]
-    for name, level in (("level=0", torch.zeros(n, device=dev)), ("level=U(0,2)", torch.rand(n, device=dev) * 2)):
-        ms = timeit(lambda: ops.sdf_alpha(packed, *W, pts, level, dists, dirs, aabb, [2.0 / (R - 1)] * 3, 20.0, 1.0))
+    for name, level, prec in (("level=0 f32", torch.zeros(n, device=dev), 0), ("level=0 f16x3", torch.zeros(n, device=dev), 1),
+                              ("level=U(0,2) f32", torch.rand(n, device=dev) * 2, 0), ("level=U(0,2) f16x3", torch.rand(n, device=dev) * 2, 1)):
+        ms = timeit(lambda: ops.sdf_alpha(packed, *W, pts, level, dists, dirs, aabb, [2.0 / (R - 1)] * 3, 20.0, 1.0, precision=prec))
         print(f"sdf_alpha {name}: n={n} {ms:.2f} ms  {n/ms*1e-3:.1f} Msamples/s  {n/ms*1e-6*466944/1e3:.1f} TF/s  alg {n/ms*1e-6*18144:.0f} GB/s")
     ms = timeit(lambda: ops.sdf_forward(packed, *W, pts, None, aabb, want_feat=False))
     print(f"sdf_forward sdf-only: {ms:.2f} ms {n/ms*1e-3:.1f} Mevals/s")
