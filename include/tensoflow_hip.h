@@ -303,6 +303,36 @@ int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm,
 int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Split-sum shading of the shape stage in ONE launch: ShapeShadingNetwork.forward (network/fields.py:448-567,
+ * predict_specular_lights :419-439) + EnvLight.__call__ (network/light.py:72-80, :95-122) over the pre-filtered stack of
+ * EnvLight.build_mips (tf_cubemap_*).  Per live march sample: mat_mlp 128-128-128-5 -> albedo / roughness / metallic,
+ * diffuse + two-mip specular cube lookups, inner_light [pos_enc8 51, IDE5 72] 123-128-128-3, inner_weight
+ * [pos_enc8 51, pos_enc6(refl) 39] 90-128-128-1, FG LUT, sRGB.  Decoders run in f16x3 (TF_PREC_F16X3 arithmetic).
+ * tf_shape_shade_pack: weights in torch layout (weight-norm folded by the caller) -> fragment order in `workspace`
+ *   (tf_shape_shade_workspace_floats() floats, caller-owned); once per weight update.
+ * tf_shape_shade_fwd: spec_mips [n_spec] device pointers to [6,R_i,R_i,3] log-radiance maps (host array of pointers),
+ *   spec_res [n_spec] (host), diffuse_map [6,Rd,Rd,3], fg_lut [H,W,2]; pts / normals / view [n,3] (normals, view need not
+ *   be normalised), feat [n,128] -> color [n,3] (sRGB, clamped), occ [n] (unclamped occlusion probability), roughness [n],
+ *   refl [n,3]; occ / roughness / refl may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct TfMlp3 {
+  const float* w[3];
+  const float* b[3];
+} TfMlp3;
+typedef struct TfShapeNets {
+  TfMlp3 mat_mlp;      /* [128,128] [128,128] [5,128] */
+  TfMlp3 inner_light;  /* [128,123] [128,128] [3,128] */
+  TfMlp3 inner_weight; /* [128,90]  [128,128] [1,128] */
+} TfShapeNets;
+size_t tf_shape_shade_workspace_floats(void);
+int tf_shape_shade_pack(const TfShapeNets* nets, float* workspace, size_t workspace_floats, tf_stream_t stream);
+int tf_shape_shade_fwd(const float* workspace, const float* const* spec_mips, const int32_t* spec_res, int32_t n_spec,
+                       const float* diffuse_map, int32_t diffuse_res, const float* fg_lut, int32_t fg_h, int32_t fg_w,
+                       float min_roughness, float max_roughness, float light_exp_max, const float* pts, const float* normals,
+                       const float* view, const float* feat, int64_t n, float* color, float* occ, float* roughness,
+                       float* refl, tf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-surface-point preparation of the rendering integral in ONE launch (the reference runs ~30):
  *   MCShadingNetwork.tenso_feature + predict_materials (network/fields.py:776-810, :1010-1017):
  *     VM gather (C = 36, level 0) -> weight-norm MLPs 108-128-{1,1,3} (ReLU, sigmoid),

@@ -4,79 +4,8 @@
 // 4 taps x 3 channels; taps that leave the face are re-projected onto the neighbouring face,
 // the tap that falls off a cube corner is dropped and the other three renormalised
 // (same rule as oracle/texture.py:cube_bilinear).
+#include "cube.h"
 #include "tf_common.h"
-
-struct CubeTaps {
-  int idx[4];   // flat texel index (face*R + y)*R + x
-  float w[4];
-};
-
-__device__ __forceinline__ void cube_face_uv(float dx, float dy, float dz, int& face, float& x, float& y) {
-  const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-  if (az > fmaxf(ax, ay)) {
-    const float m = 1.f / az;
-    face = dz < 0.f ? 5 : 4;
-    x = (dz < 0.f ? -dx : dx) * m;
-    y = -dy * m;
-  } else if (ay > ax) {
-    const float m = 1.f / ay;
-    face = dy < 0.f ? 3 : 2;
-    x = dx * m;
-    y = (dy < 0.f ? -dz : dz) * m;
-  } else {
-    const float m = 1.f / ax;
-    face = dx < 0.f ? 1 : 0;
-    x = (dx < 0.f ? dz : -dz) * m;
-    y = -dy * m;
-  }
-}
-
-__device__ __forceinline__ void cube_face_dir(int face, float x, float y, float& dx, float& dy, float& dz) {
-  switch (face) {
-    case 0: dx = 1.f; dy = -y; dz = -x; break;
-    case 1: dx = -1.f; dy = -y; dz = x; break;
-    case 2: dx = x; dy = 1.f; dz = y; break;
-    case 3: dx = x; dy = -1.f; dz = -y; break;
-    case 4: dx = x; dy = -y; dz = 1.f; break;
-    default: dx = -x; dy = -y; dz = -1.f; break;
-  }
-}
-
-__device__ __forceinline__ void cube_taps(float dx, float dy, float dz, int R, CubeTaps& T) {
-  int face;
-  float x, y;
-  cube_face_uv(dx, dy, dz, face, x, y);
-  const float u = (x * 0.5f + 0.5f) * (float)R - 0.5f;
-  const float v = (y * 0.5f + 0.5f) * (float)R - 0.5f;
-  const float fu0 = floorf(u), fv0 = floorf(v);
-  const float fu = u - fu0, fv = v - fv0;
-  const int iu0 = (int)fu0, iv0 = (int)fv0;
-  float wsum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int du = t & 1, dv = t >> 1;
-    const int iu = iu0 + du, iv = iv0 + dv;
-    float w = (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
-    const bool ou = iu < 0 || iu > R - 1, ov = iv < 0 || iv > R - 1;
-    int f2 = face, ju = iu, jv = iv;
-    if (ou || ov) {
-      const float tx = ((float)iu + 0.5f) / (float)R * 2.f - 1.f;
-      const float ty = ((float)iv + 0.5f) / (float)R * 2.f - 1.f;
-      float ex, ey, ez, x2, y2;
-      cube_face_dir(face, tx, ty, ex, ey, ez);
-      cube_face_uv(ex, ey, ez, f2, x2, y2);
-      ju = min(max((int)floorf((x2 * 0.5f + 0.5f) * (float)R), 0), R - 1);
-      jv = min(max((int)floorf((y2 * 0.5f + 0.5f) * (float)R), 0), R - 1);
-      if (ou && ov) w = 0.f;
-    }
-    T.idx[t] = (f2 * R + jv) * R + ju;
-    T.w[t] = w;
-    wsum += w;
-  }
-  const float inv = 1.f / wsum;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) T.w[t] *= inv;
-}
 
 __global__ void __launch_bounds__(256) cube_lookup_fwd_kernel(const float* __restrict__ base, int R,
                                                               const float* __restrict__ dirs, long long m, int apply_exp,

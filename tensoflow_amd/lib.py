@@ -34,6 +34,14 @@ class TfMlp4(C.Structure):
     _fields_ = [("w", c_f * 4), ("b", c_f * 4)]
 
 
+class TfMlp3(C.Structure):
+    _fields_ = [("w", c_f * 3), ("b", c_f * 3)]
+
+
+class TfShapeNets(C.Structure):
+    _fields_ = [("mat_mlp", TfMlp3), ("inner_light", TfMlp3), ("inner_weight", TfMlp3)]
+
+
 class TfPointNets(C.Structure):
     _fields_ = [("mat_w1", c_f * 3), ("mat_b1", c_f * 3), ("mat_w2", c_f * 3), ("mat_b2", c_f * 3),
                 ("nis_w1", c_f * 2), ("nis_b1", c_f * 2), ("nis_w2", c_f * 2), ("nis_b2", c_f * 2)]
@@ -82,6 +90,10 @@ SIGNATURES = {
     "tf_inner_light_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, i64, f32, i32, c_f, c_f, sz, c_f]),
     "tf_inner_light_indexed_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, c_f, c_f, i64, c_f, f32, f32, i32, c_f, c_f, sz, c_f]),
     "tf_compact_mask": (C.c_int, [c_f, i64, c_f, c_f, c_f]),
+    "tf_shape_shade_workspace_floats": (sz, []),
+    "tf_shape_shade_pack": (C.c_int, [P(TfShapeNets), c_f, sz, c_f]),
+    "tf_shape_shade_fwd": (C.c_int, [c_f, C.c_void_p, C.c_void_p, i32, c_f, i32, c_f, i32, i32, f32, f32, f32, c_f, c_f, c_f, c_f, i64,
+                                     c_f, c_f, c_f, c_f, c_f]),
     "tf_point_workspace_floats": (sz, []),
     "tf_point_pack": (C.c_int, [P(TfPointNets), c_f, sz, c_f]),
     "tf_point_fwd": (C.c_int, [c_f, P(TfVmDesc), c_f, P(TfVmDesc), c_f, P(TfVmDesc), c_f, P(f32 * 6), c_f, c_f, i64, f32,

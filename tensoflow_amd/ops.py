@@ -474,6 +474,58 @@ class Bvh:
         return pos, nrm, depth, hit.bool()
 
 
+class ShapeShade:
+    """Fused split-sum shading of the shape stage (tf_shape_shade_pack / tf_shape_shade_fwd).
+    nets: {"mat_mlp" | "inner_light" | "inner_weight": [(W, b)] * 3} (weight-norm folded); spec: list of [6,R,R,3] pre-filtered
+    specular mips, diff [6,Rd,Rd,3], fg_lut [1,H,W,2] or [H,W,2]."""
+
+    def __init__(self, nets, spec, diff, fg_lut, min_roughness=0.08, max_roughness=0.5, light_exp_max=0.0):
+        self.lib = L.load()
+        dev = spec[0].device
+        self.spec = [_f(t) for t in spec]
+        self.diff = _f(diff)
+        self.fg = _f(fg_lut.reshape(fg_lut.shape[-3], fg_lut.shape[-2], 2))
+        for t in self.spec + [self.diff, self.fg]:
+            _p(t)
+        self.spec_ptrs = (C.c_void_p * len(self.spec))(*[t.data_ptr() for t in self.spec])
+        self.spec_res = (C.c_int32 * len(self.spec))(*[t.shape[1] for t in self.spec])
+        self.consts = (float(min_roughness), float(max_roughness), float(light_exp_max))
+        self.ws = torch.empty(int(self.lib.tf_shape_shade_workspace_floats()), dtype=torch.float32, device=dev)
+        self.repack(nets)
+
+    def repack(self, nets):
+        sn = L.TfShapeNets()
+        keep = []
+        expect = {"mat_mlp": [(128, 128), (128, 128), (5, 128)], "inner_light": [(128, 123), (128, 128), (3, 128)],
+                  "inner_weight": [(128, 90), (128, 128), (1, 128)]}
+        for name in ("mat_mlp", "inner_light", "inner_weight"):
+            m = getattr(sn, name)
+            for l in range(3):
+                W, b = _f(nets[name][l][0]), _f(nets[name][l][1])
+                if tuple(W.shape) != expect[name][l]:
+                    raise RuntimeError(f"ShapeShade: {name} layer {l} has shape {tuple(W.shape)}, expected {expect[name][l]}")
+                _p(W), _p(b)
+                keep += [W, b]
+                m.w[l], m.b[l] = W.data_ptr(), b.data_ptr()
+        L.check(self.lib.tf_shape_shade_pack(C.byref(sn), _p(self.ws), self.ws.numel(), _stream()), "tf_shape_shade_pack")
+
+    def __call__(self, pts, normals, view, feat):
+        """-> color [n,3], occ [n,1], roughness [n,1], refl [n,3]"""
+        pts, normals, view, feat = _f(pts), _f(normals), _f(view), _f(feat)
+        n, dev = pts.shape[0], pts.device
+        if feat.shape != (n, 128):
+            raise RuntimeError(f"ShapeShade: feat must be [n,128], got {tuple(feat.shape)}")
+        color = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        occ = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        rough = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        refl = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        L.check(self.lib.tf_shape_shade_fwd(_p(self.ws), C.addressof(self.spec_ptrs), C.addressof(self.spec_res), len(self.spec),
+                                            _p(self.diff), self.diff.shape[1], _p(self.fg), self.fg.shape[0], self.fg.shape[1],
+                                            *self.consts, _p(pts), _p(normals), _p(view), _p(feat), n, _p(color), _p(occ), _p(rough),
+                                            _p(refl), _stream()), "tf_shape_shade_fwd")
+        return color, occ, rough, refl
+
+
 class PointPrep:
     """Fused per-point stage (tf_point_pack / tf_point_fwd): materials + both flow condition rows in one launch.
     mat_nets: {"metallic" | "roughness" | "albedo": [(W1 [128,108], b1), (W2, b2)]} (weight-norm folded);

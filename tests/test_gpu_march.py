@@ -47,6 +47,29 @@ def test_shape_shading(golden, dev):
     assert rel_err(refl.cpu(), g["shade_reflective"]) < TOL
 
 
+def test_shape_shading_ragged_and_degenerate(golden, dev):
+    """Fused shape-shade launch vs the oracle on inputs the golden does not hold: a sample count that is not a multiple of
+    the 128-sample workgroup tile, unnormalised normals / view vectors, and the degenerate normal the reference patches
+    (n.x + n.y == 0 -> (0, 1e-6, 1), fields.py:455-456)."""
+    from oracle import march as om
+    from tensoflow_amd.shape_shading import ShapeShader
+    g = golden("march_r32")
+    env = {"specular": [g["env_spec0"], g["env_spec1"], g["env_spec2"]], "diffuse": g["env_diffuse"]}
+    sh = ShapeShader(g.sd, env["specular"], env["diffuse"], g["fg_lut"], device=dev)
+    gen = torch.Generator().manual_seed(21)
+    n = 1000 + 37
+    pts = torch.rand(n, 3, generator=gen) * 2 - 1
+    nrm = torch.randn(n, 3, generator=gen) * 3.0
+    nrm[5] = torch.tensor([0.0, 0.0, 2.0])
+    nrm[77] = torch.tensor([0.5, -0.5, 1.0])
+    view = torch.randn(n, 3, generator=gen) * 0.3
+    feat = torch.randn(n, 128, generator=gen) * 0.5
+    col, occ, rough, refl = sh(pts.to(dev), nrm.to(dev), view.to(dev), feat.to(dev))
+    rc, ro, rr, rf = om.shape_shade(g.sd, env, g["fg_lut"], pts, nrm, view, feat)
+    assert rel_err(col.cpu(), rc) < TOL and rel_err(occ.cpu(), ro) < TOL
+    assert rel_err(rough.cpu(), rr) < TOL and rel_err(refl.cpu(), rf) < TOL
+
+
 def test_render_core(golden, dev):
     from tensoflow_amd import march
     from tensoflow_amd.shape_shading import ShapeShader
