@@ -38,6 +38,22 @@ MARCH_BYTES_PER_SAMPLE = 18_144   # 7 evals x 18 texels x 36 ch 
 MARCH_FLOP_PER_SAMPLE = 466_944
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
+    are collected in separate --pmc runs of this same command, tools/collect_profiles.sh; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no summary has been collected."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t.get(kernel)
+        return None if e is None else e["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def build_scene(device, seed, mesh_res):
     from tensoflow_amd.shading import MCShader
     from tensoflow_amd.synth import random_mc_state, sphere_torus_mesh
@@ -147,7 +163,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
                 live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
                 sdf_alpha_samples_per_s=sps, algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,
                 hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS, tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12,
-                mfma_f32_frac=sps * MARCH_FLOP_PER_SAMPLE / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                hbm_traffic_per_launch=pmc_traffic("sdf_kernel"),
                 envlight_build_mips_ms=build_mips_ms, update_alpha_mask_ms=mask_ms)
 
 
@@ -227,10 +243,13 @@ def main():
             n_launch = summ[dom][1]
             ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+            # executed matrix-core flop: 1008 v_mfma_f32_32x32x16_f16 per 32-ray tile (K padded to 128/256, 3 terms per product)
+            executed = hits / 32.0 * 1008 * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
             roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
-                        frac=ach / peak, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
+                        frac=ach / peak, traffic=pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
+                        executed_tflops=executed, frac_executed=executed / peak,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
-                                   f"({args.precision} MFMA: {'3 f16 MFMAs per fp32 product term, peak = dense f16' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
+                                   f"({args.precision} MFMA: {'3 f16 MFMAs per fp32 product term, peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
         elif dom == "flow_sample":
             n_launch = summ[dom][1]
             samples = timer.units.get("flow_sample", 0)
@@ -243,7 +262,7 @@ def main():
             rays = pn * (2 * S + 512) * args.steps
             ach = rays * 53 / (summ[dom][0] * 1e-3) / 1e9
             roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                        traffic=None, avg_launch_ms=summ[dom][0] / summ[dom][1],
+                        traffic=pmc_traffic("bvh_trace_kernel" if dom == "bvh_trace" else dom), avg_launch_ms=summ[dom][0] / summ[dom][1],
                         per_launch=f"{rays // args.steps} rays x 53 B of ray in/out (BVH node traffic is data-dependent, not algorithmic)")
         line = {
             "metric": "shaded surface points/s @128 flow samples", "value": value, "unit": "points/s", "n_gpus": world,
