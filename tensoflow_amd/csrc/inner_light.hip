@@ -53,15 +53,16 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
 
 __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
+// hidden layer on the continuous weight stream (mfma_mlp.h): every hidden layer here has an even slab count, so the
+// fragment-set parity is 0 at each layer start
 template <int K16, int TIN>
-__device__ __forceinline__ void hidden_layer_h3(const float* __restrict__ wslab, const float* __restrict__ bias,
-                                                float* __restrict__ lds, int tid, int lane, int h,
+__device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_stream_h3p<K16, 8, TIN>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, out);
+  tf_layer_h3s<K16, 8, TIN, 0>(S, FA, FB, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -99,6 +100,10 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // weight-slab ring (f16x3: 4 slabs, f32: 3)
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
+  // f16x3: the four layers' fragment images are contiguous (kH1..kH4): one stream of 8 + 16 + 16 + 2 = 42 slabs per tile
+  TfStream S;
+  TfFrag FA, FB;
+  if (H3) tf_stream_begin(S, reinterpret_cast<const _Float16*>(ws_arg + kH1), 42, lds, tid, lane, FA);
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
     // opaque per-iteration copy of the workspace base: biases / IDE table / slab addresses are loop-invariant and
     // would otherwise be hoisted out of the tile loop, spilled, and reloaded behind s_waitcnt vmcnt(0)
@@ -179,12 +184,12 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
           asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
         }
-      if (H3) hidden_layer_h3<8, 4>(ws + kH1, ws + kIB1, lds, tid, lane, h, in1, a);
+      if (H3) hidden_layer_h3<8, 4>(S, FA, FB, ws + kIB1, h, in1, a);
       else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
     if (H3) {
-      hidden_layer_h3<16, 8>(ws + kH2, ws + kIB2, lds, tid, lane, h, a, b);
-      hidden_layer_h3<16, 8>(ws + kH3, ws + kIB3, lds, tid, lane, h, b, a);
+      hidden_layer_h3<16, 8>(S, FA, FB, ws + kIB2, h, a, b);
+      hidden_layer_h3<16, 8>(S, FA, FB, ws + kIB3, h, b, a);
     } else {
       hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
       hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
-    if (H3) tf_layer_stream_h3p<16, 1, 8>(reinterpret_cast<const _Float16*>(ws + kH4), lds, tid, lane, a, o);
+    if (H3) tf_layer_h3s<16, 1, 8, 0>(S, FA, FB, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
       const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
       for (int c = 0; c < 3; ++c) out[3 * src + c] = expf(fminf(o[0][c], exp_max)) * near;
     }
   }
+  if (H3) tf_stream_end();
 }
 
 static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,

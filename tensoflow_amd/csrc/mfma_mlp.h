@@ -340,7 +340,7 @@ __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ 
   }
 }
 
-// ---- software-pipelined variant.  tf_layer_stream_h3 issues a slab's 16 fragment reads and then needs the first one:
+// ---- software-pipelined streaming.  tf_layer_stream_h3 issues a slab's 16 fragment reads and then needs the first one:
 // all four waves leave the barrier together, their 64 KB of ds_read_b128 queue on the LDS (>= 256 cycles) while the
 // matrix cores idle -- a third of every slab step.  Here the fragments of slab g+1 are read into a SECOND register set
 // while the MFMAs of slab g run, and the LDS ring is 4 slabs deep (slab g+3 is requested while g computes).
@@ -349,7 +349,7 @@ __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ 
 // first MFMA group (scheduling barriers pin the order) makes that wait cover only reads issued most of a step earlier.
 //   RAW: a slab is read one phase after the vmcnt + barrier that retire its DMA.
 //   WAR: DMA(g+3) overwrites the buffer of slab g-1, whose reads every wave completed before its MFMAs of step g-1,
-//        i.e. before this step's barrier; the layer ends with a barrier after the last reads have returned.
+//        i.e. before this step's barrier.
 struct TfFrag { tf_h8 hi[8], lo[8]; };
 
 __device__ __forceinline__ void tf_frag_read(TfFrag& F, const tf_h8* __restrict__ buf /* slab + lane */) {
@@ -357,76 +357,104 @@ __device__ __forceinline__ void tf_frag_read(TfFrag& F, const tf_h8* __restrict_
   for (int c = 0; c < 8; ++c) { F.hi[c] = buf[c * 128]; F.lo[c] = buf[c * 128 + 64]; }
 }
 
-template <int K16, int TOUT, int TIN, int G, int SL16>
-__device__ __forceinline__ void tf_h3p_step(int g, const TfFrag& cur, TfFrag& nxt, const float*& gp, float* lds, int lane,
-                                            int wave, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
-  if (g + 1 < G) {
-    if (g + 2 < G) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slab g+1 landed (g+2 may still be in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+// ---- continuous weight stream.  A pipeline restarted at every layer pays three slab requests, an L2 round trip and a barrier
+// before the layer's first MFMA.  A network's whole f16x3 image is therefore laid out as ONE sequence of 16 KB slabs (layer
+// after layer), and the ring simply keeps running: the last steps of a layer already request and read the first slabs of the
+// next one, and the last layer of a tile those of the next tile's first layer (the sequence wraps).  Per step, unconditionally:
+//   s_waitcnt vmcnt(4) -> s_barrier -> MFMAs of slab s, interleaved with the fragment reads of slab s+1 and the DMA of s+3.
+// (vmcnt(4): at least the four DMA pieces of slab s+2 were issued after slab s+1; other vector-memory operations issued in
+// between only make the wait longer.)  Ring slots are run-time (slab count per pass need not be a multiple of 4); the two
+// fragment register sets alternate per slab, so a layer is instantiated for the parity P0 of its first slab.
+struct TfStream {
+  const float* gp;    // this thread's source pointer of the next slab to request
+  const float* g0;    // ... of slab 0
+  int next, total;    // index of the next slab to request / slabs per pass
+  unsigned slot_req;  // ring slot the next request goes to
+  unsigned slot_rd;   // ring slot of the slab whose fragments are read next
+  float* lds;         // 4 x 4096 floats
+  int lane, wave;
+};
+
+__device__ __forceinline__ void tf_stream_advance(TfStream& S) {
+  S.gp += 4096;
+  if (++S.next == S.total) { S.next = 0; S.gp = S.g0; }
+  S.slot_req = (S.slot_req + 1) & 3;
+}
+
+// Once per kernel, by all four waves: request slabs 0..2, read slab 0 into F0.  `total` >= 3.
+__device__ __forceinline__ void tf_stream_begin(TfStream& S, const _Float16* wslab, int total, float* lds, int tid, int lane, TfFrag& F0) {
+  S.lds = lds; S.lane = lane; S.wave = tid >> 6; S.total = total; S.next = 0; S.slot_req = 0;
+  S.g0 = reinterpret_cast<const float*>(wslab) + S.wave * 1024 + lane * 4;
+  S.gp = S.g0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    asm volatile("" : "+v"(S.gp));
+    tf_slab_dma(S.gp, S.lds + S.slot_req * 4096, S.wave);
+    tf_stream_advance(S);
   }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  tf_frag_read(F0, reinterpret_cast<const tf_h8*>(S.lds) + lane);
+  S.slot_rd = 1;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Before the kernel returns: the requests issued for a tile that does not exist must land before the LDS is released.
+__device__ __forceinline__ void tf_stream_end() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int TOUT, int TIN, int SL16>
+__device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFrag& cur, TfFrag& nxt, const f32x16 (&in)[TIN],
+                                            f32x16 (&out)[TOUT]) {
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   tf_h8 b_hi[SL16], b_lo[SL16];
 #pragma unroll
   for (int sl = 0; sl < SL16; ++sl) {
-    const int s16 = g * SL16 + sl;
+    const int s16 = s16base + sl;
     float x8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
     tf_split8(x8, b_hi[sl], b_lo[sl]);
   }
-  // combo 0 first: its fragments were requested a whole step ago.  Behind it, each group of three MFMAs (96 matrix-core
-  // cycles) carries two fragment pairs of slab g+1 (combos 1-4) or one 1 KB DMA piece of slab g+3 (combos 4-7).
-  const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(lds + ((g + 1) & 3) * 4096) + lane;
-  float* dbuf = lds + ((g + 3) & 3) * 4096;
-  if (g + 3 < G) {
-    gp += 4096;
-    asm volatile("" : "+v"(gp));
-  }
+  const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(S.lds + S.slot_rd * 4096) + S.lane;
+  float* dbuf = S.lds + S.slot_req * 4096;
+  const float* gsrc = S.gp;
+  asm volatile("" : "+v"(gsrc));
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int sl = c / TOUT, t = c % TOUT;
-    if (g + 1 < G && c >= 1 && c <= 4) {
+    if (c >= 1 && c <= 4) {
 #pragma unroll
       for (int q = 2 * (c - 1); q < 2 * c; ++q) { nxt.hi[q] = nbuf[q * 128]; nxt.lo[q] = nbuf[q * 128 + 64]; }
     }
-    if (g + 3 < G && c >= 4) tf_slab_dma_piece(gp, dbuf, wave, c - 4);
+    if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
     out[t] = tf_mfma_h(cur.hi[c], b_hi[sl], out[t]);
     out[t] = tf_mfma_h(cur.hi[c], b_lo[sl], out[t]);
     out[t] = tf_mfma_h(cur.lo[c], b_hi[sl], out[t]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  tf_stream_advance(S);
+  S.slot_rd = (S.slot_rd + 1) & 3;
 }
 
-// lds: 4 x 4096 floats (64 KB ring).  All four waves of the workgroup must call this together.
-template <int K16, int TOUT, int TIN>
-__device__ __forceinline__ void tf_layer_stream_h3p(const _Float16* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,
-                                                    const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+// One dense layer on the stream: K16 k-steps of TOUT unit tiles (G = K16 * TOUT / 8 slabs); P0 = parity of its first slab
+// (which of FA / FB already holds that slab's fragments).  Returns nothing; the caller continues with parity (P0 + G) & 1.
+template <int K16, int TOUT, int TIN, int P0>
+__device__ __forceinline__ void tf_layer_h3s(TfStream& S, TfFrag& FA, TfFrag& FB, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
   static_assert(8 % TOUT == 0, "a 16 KB slab holds 8 (k-step, tile) fragment pairs");
   constexpr int SL16 = 8 / TOUT;
   static_assert(K16 % SL16 == 0, "K16 must be a multiple of the slab size");
   constexpr int G = K16 / SL16;
-  const int wave = tid >> 6;
-  const float* gp = reinterpret_cast<const float*>(wslab) + wave * 1024 + lane * 4;
-  asm volatile("" : "+v"(gp));
-  tf_slab_dma(gp, lds, wave);
-  if (G > 1) { gp += 4096; asm volatile("" : "+v"(gp)); tf_slab_dma(gp, lds + 4096, wave); }
-  if (G > 2) { gp += 4096; asm volatile("" : "+v"(gp)); tf_slab_dma(gp, lds + 8192, wave); }
-  if (G > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (G > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  TfFrag FA, FB;
-  tf_frag_read(FA, reinterpret_cast<const tf_h8*>(lds) + lane);
-  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int g = 0; g < G; g += 2) {
-    tf_h3p_step<K16, TOUT, TIN, G, SL16>(g, FA, FB, gp, lds, lane, wave, in, out);
-    if (g + 1 < G) tf_h3p_step<K16, TOUT, TIN, G, SL16>(g + 1, FB, FA, gp, lds, lane, wave, in, out);
+  for (int g = 0; g < G; ++g) {
+    if (((P0 + g) & 1) == 0) tf_h3s_step<TOUT, TIN, SL16>(S, g * SL16, FA, FB, in, out);
+    else tf_h3s_step<TOUT, TIN, SL16>(S, g * SL16, FB, FA, in, out);
   }
-  __builtin_amdgcn_s_barrier();   // every wave has all its fragments in registers: the ring may be refilled
-  asm volatile("" ::: "memory");
 }
 
 // Dense layer, f16x3, fragment weights resident in LDS ([s16][tout][hi|lo][lane][8 halves]).

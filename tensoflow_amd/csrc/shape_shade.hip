@@ -76,26 +76,29 @@ static void shape_ide_tables_host(float* mat /*[17][36]*/) {
   }
 }
 
-// hidden layer: out = relu(W in + b), 128 outputs (4 tiles), weights streamed
-template <int K16, int TIN>
-__device__ __forceinline__ void ss_hidden(const float* __restrict__ wslab, const float* __restrict__ bias, float* __restrict__ lds,
-                                          int tid, int lane, int h, const f32x16 (&in)[TIN], f32x16 (&out)[4]) {
+// The nine layers' fragment images are one continuous weight stream (mfma_mlp.h TfStream), consumed in workspace order:
+//   mat 4 + 4 + 1 | light 4 + 4 + 1 | weight 3 + 4 + 1 slabs = 26 per tile.  P0 = parity of the layer's first slab.
+// hidden layer: out = relu(W in + b), 128 outputs (4 tiles)
+template <int K16, int TIN, int P0>
+__device__ __forceinline__ void ss_hidden(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
+                                          const f32x16 (&in)[TIN], f32x16 (&out)[4]) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_stream_h3p<K16, 4, TIN>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, out);
+  tf_layer_h3s<K16, 4, TIN, P0>(S, FA, FB, in, out);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[t][j] = fmaxf(out[t][j], 0.f);
 }
 
-__device__ __forceinline__ void ss_out(const float* __restrict__ wslab, const float* __restrict__ bias, float* __restrict__ lds,
-                                       int tid, int lane, int h, const f32x16 (&in)[4], f32x16 (&o)[1]) {
+template <int P0>
+__device__ __forceinline__ void ss_out(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
+                                       const f32x16 (&in)[4], f32x16 (&o)[1]) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) o[0][j] = bias[j * 2 + h];
-  tf_layer_stream_h3p<8, 1, 4>(reinterpret_cast<const _Float16*>(wslab), lds, tid, lane, in, o);
+  tf_layer_h3s<8, 1, 4, P0>(S, FA, FB, in, o);
 }
 
 // operand slots of this lane half: in1[t][j] <- enc[32 t + (j & 3) + 8 (j >> 2) + 4 h]   (explicit v_cndmask: see inner_light.hip)
@@ -115,6 +118,9 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // weight-slab ring
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (A.n + 127) / 128;   // a workgroup advances 4 tiles (128 samples) in lockstep
+  TfStream S;
+  TfFrag FA, FB;
+  tf_stream_begin(S, reinterpret_cast<const _Float16*>(A.ws + kSM1), 26, lds, tid, lane, FA);
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
     const float* ws = A.ws;
     asm volatile("" : "+s"(ws));   // keep biases / tables / slab addresses from being hoisted out of the tile loop and spilled
@@ -146,10 +152,10 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
           const float4 v4 = *reinterpret_cast<const float4*>(frow + 32 * t + 8 * jq);
           in1[t][4 * jq] = v4.x; in1[t][4 * jq + 1] = v4.y; in1[t][4 * jq + 2] = v4.z; in1[t][4 * jq + 3] = v4.w;
         }
-      ss_hidden<8, 4>(ws + kSM1, ws + kSBias, lds, tid, lane, h, in1, a);
+      ss_hidden<8, 4, 0>(S, FA, FB, ws + kSBias, h, in1, a);
     }
-    ss_hidden<8, 4>(ws + kSM2, ws + kSBias + 128, lds, tid, lane, h, a, b);
-    ss_out(ws + kSM3, ws + kSBias + 256, lds, tid, lane, h, b, o);
+    ss_hidden<8, 4, 0>(S, FA, FB, ws + kSBias + 128, h, a, b);
+    ss_out<0>(S, FA, FB, ws + kSBias + 256, h, b, o);
     // units 0..3 sit in registers 0..3 of lane half 0, unit 4 in register 0 of lane half 1
     float albedo[3], rough, metal;
     {
@@ -248,15 +254,15 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
 
     // ---------------- inner_light -> indirect radiance
     float indirect[3];
-    ss_hidden<8, 4>(ws + kSL1, ws + kSBias + 288, lds, tid, lane, h, il_in, a);
-    ss_hidden<8, 4>(ws + kSL2, ws + kSBias + 288 + 128, lds, tid, lane, h, a, b);
-    ss_out(ws + kSL3, ws + kSBias + 288 + 256, lds, tid, lane, h, b, o);
+    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 288, h, il_in, a);
+    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 288 + 128, h, a, b);
+    ss_out<1>(S, FA, FB, ws + kSBias + 288 + 256, h, b, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) indirect[c] = expf(fminf(o[0][c], A.exp_max));
     // ---------------- inner_weight -> occlusion probability
-    ss_hidden<6, 3>(ws + kSW1, ws + kSBias + 576, lds, tid, lane, h, iw_in, a);
-    ss_hidden<8, 4>(ws + kSW2, ws + kSBias + 576 + 128, lds, tid, lane, h, a, b);
-    ss_out(ws + kSW3, ws + kSBias + 576 + 256, lds, tid, lane, h, b, o);
+    ss_hidden<6, 3, 0>(S, FA, FB, ws + kSBias + 576, h, iw_in, a);
+    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 576 + 128, h, a, b);
+    ss_out<1>(S, FA, FB, ws + kSBias + 576 + 256, h, b, o);
     const float occ = o[0][0] * 0.5f + 0.5f;
 
     // ---------------- combine (lane half 0 holds albedo / indirect / occ)
@@ -290,6 +296,7 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
       if (A.refl) { A.refl[3 * row] = rx; A.refl[3 * row + 1] = ry; A.refl[3 * row + 2] = rz; }
     }
   }
+  tf_stream_end();
 }
 
 extern "C" int tf_shape_shade_pack(const TfShapeNets* nets, float* workspace, size_t workspace_floats, tf_stream_t stream_) {
