@@ -60,6 +60,36 @@ def test_packed_floats_and_validation(lib):
     assert lib.tf_sdf_workspace_floats() > 8 * 56 * 64
 
 
+def test_fused_stage_validation(lib):
+    """The fused per-point, shape-shading and trace entry points validate their arguments on the host (no launch)."""
+    from tensoflow_amd import lib as L
+    assert lib.tf_point_workspace_floats() > 3 * 4 * 56 * 64 and lib.tf_shape_shade_workspace_floats() > 26 * 4096
+    assert lib.tf_point_pack(None, None, 0, None) == -1 and b"null" in lib.tf_last_error()
+    nets = L.TfPointNets()
+    dummy = (C.c_float * 4)()
+    assert lib.tf_point_pack(C.byref(nets), C.addressof(dummy), 4, None) == -2 and b"workspace too small" in lib.tf_last_error()
+    assert lib.tf_shape_shade_pack(None, None, 0, None) == -1
+    # n == 0 is a no-op, n < 0 a shape error, a bad mip count a shape error (checked before any pointer is dereferenced on the device)
+    assert lib.tf_shape_shade_fwd(None, None, None, 3, None, 16, None, 256, 256, 0.08, 0.5, 0.0, None, None, None, None, 0,
+                                  None, None, None, None, None) == 0
+    assert lib.tf_shape_shade_fwd(None, None, None, 3, None, 16, None, 256, 256, 0.08, 0.5, 0.0, None, None, None, None, -1,
+                                  None, None, None, None, None) == -2
+    one = (C.c_float * 4)()
+    ptrs = (C.c_void_p * 1)(C.addressof(one))
+    res = (C.c_int32 * 1)(16)
+    a = C.addressof(one)
+    assert lib.tf_shape_shade_fwd(a, C.addressof(ptrs), C.addressof(res), 1, a, 16, a, 256, 256, 0.08, 0.5, 0.0, a, a, a, a, 5,
+                                  a, None, None, None, None) == -2 and b"specular mips" in lib.tf_last_error()
+    assert lib.tf_point_fwd(None, None, None, None, None, None, None, None, None, None, 0, 0.04, None, None, None, None, None, None) == 0
+    frame = (C.c_float * 6)()
+    assert lib.tf_bvh_trace(None, None, C.byref(frame), 1, None, None, 0, None, 0.0, 0.0, None, 5, None, None, None, None, None,
+                            None) == -2 and b"rays_per_origin" in lib.tf_last_error()
+    assert lib.tf_bvh_trace(None, None, C.byref(frame), 1, None, None, 1, None, 0.0, 0.0, None, 5, None, None, None, None, None,
+                            None) == -1
+    # unknown precision codes are rejected
+    assert lib.tf_sdf_forward(None, None, None, None, None, None, 5, None, None, 7, None, 0, None) != 0
+
+
 def test_bvh_build_host(lib):
     from tensoflow_amd.synth import sphere_torus_mesh
     v, f = sphere_torus_mesh(8, 12, 16, 8)
