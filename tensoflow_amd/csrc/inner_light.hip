@@ -55,13 +55,19 @@ __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 
 // hidden layer on the continuous weight stream (mfma_mlp.h): every hidden layer here has an even slab count, so the
 // fragment-set parity is 0 at each layer start
+// `bias`: this lane half's 256 biases in accumulator order, in LDS (all 32 lanes of a half read the same 16 bytes: broadcast).
+// Fetched from the global workspace the 128 single-dword loads per layer cost ~10 % of the kernel: their issue slots, and
+// the counted vmcnt of the weight ring has to wait for them.
 template <int K16, int TIN>
 __device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
+    for (int q = 0; q < 4; ++q) {
+      const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
+      out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
+    }
   tf_layer_h3s<K16, 8, TIN, 0>(S, FA, FB, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -101,9 +107,17 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
   // f16x3: the four layers' fragment images are contiguous (kH1..kH4): one stream of 8 + 16 + 16 + 2 = 42 slabs per tile
+  // biases of the four layers, re-laid-out per lane half: lbias[layer][half][n] = packed[(n) * 2 + half]
+  __shared__ __attribute__((aligned(16))) float lbias[4 * 2 * 128 * 2];
+  if (H3) {
+    for (int i = tid; i < 3 * 256 + 32; i += 256) {
+      const int layer = i < 768 ? i / 256 : 3, r = i < 768 ? i % 256 : i - 768;   // r = n * 2 + half
+      lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
+    }
+  }
   TfStream S;
   TfFrag FA, FB;
-  if (H3) tf_stream_begin(S, reinterpret_cast<const _Float16*>(ws_arg + kH1), 42, lds, tid, lane, FA);
+  if (H3) tf_stream_begin(S, reinterpret_cast<const _Float16*>(ws_arg + kH1), 42, lds, tid, lane, FA);   // contains a barrier
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
     // opaque per-iteration copy of the workspace base: biases / IDE table / slab addresses are loop-invariant and
     // would otherwise be hoisted out of the tile loop, spilled, and reloaded behind s_waitcnt vmcnt(0)
@@ -184,19 +198,19 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
           asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
         }
-      if (H3) hidden_layer_h3<8, 4>(S, FA, FB, ws + kIB1, h, in1, a);
+      if (H3) hidden_layer_h3<8, 4>(S, FA, FB, lbias + h * 256, h, in1, a);
       else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
     if (H3) {
-      hidden_layer_h3<16, 8>(S, FA, FB, ws + kIB2, h, a, b);
-      hidden_layer_h3<16, 8>(S, FA, FB, ws + kIB3, h, b, a);
+      hidden_layer_h3<16, 8>(S, FA, FB, lbias + 512 + h * 256, h, a, b);
+      hidden_layer_h3<16, 8>(S, FA, FB, lbias + 1024 + h * 256, h, b, a);
     } else {
       hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
       hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
     }
     f32x16 o[1];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) o[0][j] = ws[kIB4 + j * 2 + h];
+    for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
     if (H3) tf_layer_h3s<16, 1, 8, 0>(S, FA, FB, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {

@@ -79,13 +79,17 @@ static void shape_ide_tables_host(float* mat /*[17][36]*/) {
 // The nine layers' fragment images are one continuous weight stream (mfma_mlp.h TfStream), consumed in workspace order:
 //   mat 4 + 4 + 1 | light 4 + 4 + 1 | weight 3 + 4 + 1 slabs = 26 per tile.  P0 = parity of the layer's first slab.
 // hidden layer: out = relu(W in + b), 128 outputs (4 tiles)
+// `bias`: this lane half's biases in accumulator order, in LDS (broadcast b128 reads; see inner_light.hip)
 template <int K16, int TIN, int P0>
 __device__ __forceinline__ void ss_hidden(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                           const f32x16 (&in)[TIN], f32x16 (&out)[4]) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
+    for (int q = 0; q < 4; ++q) {
+      const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
+      out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
+    }
   tf_layer_h3s<K16, 4, TIN, P0>(S, FA, FB, in, out);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -97,7 +101,7 @@ template <int P0>
 __device__ __forceinline__ void ss_out(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                        const f32x16 (&in)[4], f32x16 (&o)[1]) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) o[0][j] = bias[j * 2 + h];
+  for (int j = 0; j < 16; ++j) o[0][j] = bias[j];
   tf_layer_h3s<8, 1, 4, P0>(S, FA, FB, in, o);
 }
 
@@ -118,9 +122,16 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // weight-slab ring
   const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
   const long long n_groups = (A.n + 127) / 128;   // a workgroup advances 4 tiles (128 samples) in lockstep
+  // biases, re-laid-out per lane half: lbias[net][half][b1 64 | b2 64 | (pad) | b3 16 at 256] <- packed[(n) * 2 + half]
+  __shared__ __attribute__((aligned(16))) float lbias[3 * 2 * 272];
+  for (int i = tid; i < 3 * 288; i += 256) {
+    const int net = i / 288, r = i % 288;
+    const int seg = r < 256 ? 0 : 1, rr = seg ? r - 256 : r;       // rr = n * 2 + half within the segment
+    lbias[net * 544 + (rr & 1) * 272 + (seg ? 256 : 0) + (rr >> 1)] = A.ws[kSBias + i];
+  }
   TfStream S;
   TfFrag FA, FB;
-  tf_stream_begin(S, reinterpret_cast<const _Float16*>(A.ws + kSM1), 26, lds, tid, lane, FA);
+  tf_stream_begin(S, reinterpret_cast<const _Float16*>(A.ws + kSM1), 26, lds, tid, lane, FA);   // contains a barrier
   for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
     const float* ws = A.ws;
     asm volatile("" : "+s"(ws));   // keep biases / tables / slab addresses from being hoisted out of the tile loop and spilled
@@ -152,10 +163,10 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
           const float4 v4 = *reinterpret_cast<const float4*>(frow + 32 * t + 8 * jq);
           in1[t][4 * jq] = v4.x; in1[t][4 * jq + 1] = v4.y; in1[t][4 * jq + 2] = v4.z; in1[t][4 * jq + 3] = v4.w;
         }
-      ss_hidden<8, 4, 0>(S, FA, FB, ws + kSBias, h, in1, a);
+      ss_hidden<8, 4, 0>(S, FA, FB, lbias + h * 272, h, in1, a);
     }
-    ss_hidden<8, 4, 0>(S, FA, FB, ws + kSBias + 128, h, a, b);
-    ss_out<0>(S, FA, FB, ws + kSBias + 256, h, b, o);
+    ss_hidden<8, 4, 0>(S, FA, FB, lbias + h * 272 + 64, h, a, b);
+    ss_out<0>(S, FA, FB, lbias + h * 272 + 256, h, b, o);
     // units 0..3 sit in registers 0..3 of lane half 0, unit 4 in register 0 of lane half 1
     float albedo[3], rough, metal;
     {
@@ -254,15 +265,15 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
 
     // ---------------- inner_light -> indirect radiance
     float indirect[3];
-    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 288, h, il_in, a);
-    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 288 + 128, h, a, b);
-    ss_out<1>(S, FA, FB, ws + kSBias + 288 + 256, h, b, o);
+    ss_hidden<8, 4, 1>(S, FA, FB, lbias + 544 + h * 272, h, il_in, a);
+    ss_hidden<8, 4, 1>(S, FA, FB, lbias + 544 + h * 272 + 64, h, a, b);
+    ss_out<1>(S, FA, FB, lbias + 544 + h * 272 + 256, h, b, o);
 #pragma unroll
     for (int c = 0; c < 3; ++c) indirect[c] = expf(fminf(o[0][c], A.exp_max));
     // ---------------- inner_weight -> occlusion probability
-    ss_hidden<6, 3, 0>(S, FA, FB, ws + kSBias + 576, h, iw_in, a);
-    ss_hidden<8, 4, 1>(S, FA, FB, ws + kSBias + 576 + 128, h, a, b);
-    ss_out<1>(S, FA, FB, ws + kSBias + 576 + 256, h, b, o);
+    ss_hidden<6, 3, 0>(S, FA, FB, lbias + 1088 + h * 272, h, iw_in, a);
+    ss_hidden<8, 4, 1>(S, FA, FB, lbias + 1088 + h * 272 + 64, h, a, b);
+    ss_out<1>(S, FA, FB, lbias + 1088 + h * 272 + 256, h, b, o);
     const float occ = o[0][0] * 0.5f + 0.5f;
 
     // ---------------- combine (lane half 0 holds albedo / indirect / occ)
