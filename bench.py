@@ -89,6 +89,39 @@ def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
                        f"threads, brute-force visibility over a {len(faces)}-triangle version of the same scene, {dt:.1f} s")
 
 
+def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
+    """Secondary figure: one TRAINING step of the material stage (BASELINE configs[2], train mode): MCShadingNetwork.forward
+    with autograd (shade_mixed + both NIS losses, fields.py:1075-1335) + backward over every trainable tensor, on the
+    reference's batch of 2048 surface points.  Forward and the HIP backward ops (VM gather / BRDF weights / cube map / flow
+    log-density) run in libtensoflow_hip.so; the inner-light weight gradients are library GEMMs."""
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    from tensoflow_amd.synth import sphere_surface_points
+    torch.manual_seed(6033)
+    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, unit)
+    for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
+        for p in fl.parameters():
+            p.requires_grad = False
+    m.train()
+    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=99)]
+    w = torch.rand(pn, 3, device=device)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        colors, out = m(pts, view, nrm, None, 600, True)
+        ((colors * w).sum() + out["loss_nis"]).backward()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_par = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    return dict(workload=f"MCShadingNetwork train step: {pn} points x ({S} + 512 + {S}) rays, NIS losses on, fwd + bwd (no optimizer)",
+                ms_per_step=dt * 1e3, points_per_s=pn / dt, trainable_parameters=n_par)
+
+
 def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     """Secondary figure (BASELINE configs[1]): one full 800x800 frame of the shape stage -- fixed-step sampler with occupancy
     culling (tf_march_uniform), fused 7-tap sdf/FD/alpha kernel, split-sum shading, compositing.  Reports rays/s, live
@@ -179,6 +212,7 @@ def main():
                     help="matrix-core arithmetic of the 256-wide decoder: f16x3 split (fp32-accurate) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,6 +312,11 @@ def main():
         if world == 1 and not args.no_march:
             sh.timer = type("N", (), {"stage": lambda s, n: __import__("contextlib").nullcontext(), "add_units": lambda s, n, k: None})()
             line["march"] = march_probe(device, max(2, args.steps))
+        if world == 1 and not args.no_train:
+            try:
+                line["train"] = train_probe(device, verts, faces, aabb, unit, S, max(2, args.steps))
+            except Exception as e:      # the probe is informative only: never lose the headline line over it
+                line["train"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, aabb, unit, 4096, S)
         print(json.dumps(line))

@@ -24,12 +24,23 @@ static constexpr int kT4 = 0, kT3 = kT4 + 2 * 16 * 64, kT2 = kT3 + 2 * 32 * 64, 
 static constexpr int kBwdWs = 2 * kNetFloats + 2 * kTNet;   // + P [2][pn][64]
 static constexpr int kTileLds = 64 * 33;                     // one transposed [64 units][32 rows (+1 pad)] tile
 
-extern "C" size_t tf_flow_bwd_workspace_floats(int64_t pn) { return (size_t)kBwdWs + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0); }
+// Weight / bias gradients are accumulated per WORKGROUP in a private slice of the workspace and folded into the caller's
+// tensors by a second launch: every tile adds all ~25 k gradient values, and with all workgroups adding into the same
+// 100 KB the float atomics ran at a third of their rate (memory-side atomics serialise on an address).
+//   slice (per net, floats): w0 [64,44] | w1 [64,64] | w2 [64,64] | w3 [21,64] | b1 64 | b2 64 | b3 32
+static constexpr int kGW0 = 0, kGW1 = kGW0 + 64 * 44, kGW2 = kGW1 + 64 * 64, kGW3 = kGW2 + 64 * 64, kGB1 = kGW3 + 21 * 64,
+                     kGB2 = kGB1 + 64, kGB3 = kGB2 + 64, kGNet = kGB3 + 32, kGradFloats = 2 * kGNet;
+static constexpr int kBwdBlocks = 256;   // persistent workgroups (one per CU)
+
+extern "C" size_t tf_flow_bwd_workspace_floats(int64_t pn) {
+  return (size_t)kBwdWs + (size_t)2 * 64 * (size_t)(pn > 0 ? pn : 0) + (size_t)kBwdBlocks * kGradFloats;
+}
 
 struct FlowGrads {
   float* w[2][4];
   float* b[2][4];
-  float* gP;   // [2][pn][64]
+  float* gP;       // [2][pn][64]
+  float* slices;   // [kBwdBlocks][kGradFloats]
 };
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.01f * x; }
@@ -394,8 +405,9 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     for (int k = 0; k < 32; ++k) g_wv0[k] = 0.f;
     pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);
     float g_in8[8];
-    float* const gW0[4] = {G.w[0][0], G.w[0][1], G.w[0][2], G.w[0][3]};
-    float* const gB0[4] = {G.b[0][0], G.b[0][1], G.b[0][2], G.b[0][3]};
+    float* const sl0 = G.slices + (size_t)blockIdx.x * kGradFloats;
+    float* const gW0[4] = {sl0 + kGW0, sl0 + kGW1, sl0 + kGW2, sl0 + kGW3};
+    float* const gB0[4] = {nullptr, sl0 + kGB1, sl0 + kGB2, sl0 + kGB3};
     net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, gW0, gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
     // d(2*emb(z0) - 1)/dz0
     const float g_z0 = 2.f * (g_in8[0] + g_in8[1] * cosf(z0) - g_in8[2] * sinf(z0) + 2.f * g_in8[3] * cosf(2.f * z0) -
@@ -404,11 +416,31 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
     pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
-    float* const gW1[4] = {G.w[1][0], G.w[1][1], G.w[1][2], G.w[1][3]};
-    float* const gB1[4] = {G.b[1][0], G.b[1][1], G.b[1][2], G.b[1][3]};
+    float* const sl1 = sl0 + kGNet;
+    float* const gW1[4] = {sl1 + kGW0, sl1 + kGW1, sl1 + kGW2, sl1 + kGW3};
+    float* const gB1[4] = {nullptr, sl1 + kGB1, sl1 + kGB2, sl1 + kGB3};
     net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, gW1, gB1, G.gP + (pn + pt) * 64, uniform_pt, lane,
             g_in8);
   }
+}
+
+// fold the per-workgroup slices into the caller's gradient tensors (+=): one thread per gradient element
+__global__ void __launch_bounds__(256) flow_grad_fold_kernel(FlowGrads G, int n_blocks) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kGradFloats) return;
+  float s = 0.f;
+  for (int b = 0; b < n_blocks; ++b) s += G.slices[(size_t)b * kGradFloats + e];
+  const int net = e / kGNet, r = e % kGNet;
+  float* dst;
+  if (r < kGW1) dst = G.w[net][0] + r;
+  else if (r < kGW2) dst = G.w[net][1] + (r - kGW1);
+  else if (r < kGW3) dst = G.w[net][2] + (r - kGW2);
+  else if (r < kGB1) dst = G.w[net][3] + (r - kGW3);
+  else if (r < kGB2) dst = G.b[net][1] + (r - kGB1);
+  else if (r < kGB3) dst = G.b[net][2] + (r - kGB2);
+  else if (r < kGB3 + 21) dst = G.b[net][3] + (r - kGB3);
+  else return;
+  *dst += s;
 }
 
 // shared with flow.hip
@@ -474,8 +506,12 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   }
   const long long tiles = (m + 31) / 32;
   long long blocks = (tiles + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  if (blocks > kBwdBlocks) blocks = kBwdBlocks;
+  G.slices = workspace + kBwdWs + (size_t)2 * 64 * (size_t)pn;
+  hipError_t e2 = hipMemsetAsync(G.slices, 0, (size_t)blocks * kGradFloats * sizeof(float), stream);
+  TF_REQUIRE(e2 == hipSuccess, TF_EHIP, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e2));
   flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G);
+  flow_grad_fold_kernel<<<tf_blocks(kGradFloats, 256), 256, 0, stream>>>(G, (int)blocks);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
