@@ -148,7 +148,7 @@ class MCShadingNetwork(nn.Module):
         for i in (0, 2, 4, 6):
             inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)
         lights, hit = LightsFn.apply(self.outer_light.base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
-                                     self.cfg["inner_light_exp_max"], ops.PREC_F32, *inner_wb)
+                                     self.cfg["inner_light_exp_max"], self.cfg.get("precision", ops.PREC_F16X3), *inner_wb)
         lights = lights.view(pn, T, 3)
         contrib = wgt * lights
         diffuse_lin, specular_lin = contrib[:, :nd].sum(1), contrib[:, nd:].sum(1)
