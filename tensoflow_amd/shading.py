@@ -1,10 +1,10 @@
 """Host-side composition of the flow-sampled rendering integral on the MI355X.
 
 Mirrors MCShadingNetwork.forward -> shade_mixed (network/fields.py:1453-1473, :1075-1235) and
-MCShadingNetwork.get_lights (:951-975) with every per-sample stage on the HIP kernels of
-libtensoflow_hip.so (flow sampling, direction/pdf/BRDF construction, BVH visibility, cube-map
-lookup, inner-light MLP, reduction).  Only the per-POINT tiny MLPs (material predictors
-108-128-{1,1,3}, flow feature net 57-64-16) are plain library GEMMs through torch.
+MCShadingNetwork.get_lights (:951-975) with every stage on the HIP kernels of libtensoflow_hip.so:
+the fused per-point stage (material predictors 108-128-{1,1,3}, flow feature nets 57-64-16, condition
+rows), flow sampling, direction/pdf/BRDF construction, BVH visibility, cube-map lookup, inner-light
+MLP, reduction.  PyTorch only allocates the tensors.
 
 Parameters are taken from a reference-layout state_dict (same keys as MCShadingNetwork).
 """
@@ -12,7 +12,6 @@ import math
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -127,14 +126,6 @@ class FlowParams:
         self.nets = [[(g(f"flows.{b}.nn.{l}.weight"), g(f"flows.{b}.nn.{l}.bias")) for l in (1, 3, 5, 7)] for b in range(2)]
         self.cache = ops.PackCache()     # packed coupling-net fragments survive across calls while the weights are unchanged
 
-    def condition(self, pts, view_angles, aabb):
-        """[pn,37] = [feature 16 | embed3(view_angles) 14 | 7 zeros] (flow.py:803-815, :836-848)."""
-        feat = ops.vm_gather(self.packed, pts, None, aabb)
-        h = torch.cat([feat, posenc(pts, 3)], -1)
-        h = F.softplus(F.linear(h, *self.mat[0]), beta=100)
-        h = F.linear(h, *self.mat[1])
-        return torch.cat([h, posenc(view_angles, 3), torch.zeros(pts.shape[0], 7, device=pts.device)], -1).contiguous()
-
 
 class MCShader:
     """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
@@ -173,14 +164,6 @@ class MCShader:
         if sn not in self._latent:
             self._latent[sn] = sphere_latent(sn).to(self.device)
         return self._latent[sn]
-
-    def predict_materials(self, pts):
-        feat = ops.vm_gather(self.mat_packed, pts, None, self.aabb)
-        out = {}
-        for name, layers in self.pred.items():
-            out[name] = torch.sigmoid(F.linear(F.relu(F.linear(feat, *layers[0])), *layers[1]))
-        rough = out["roughness"] * (1.0 - 0.04 ** 2) + 0.04 ** 2
-        return out["metallic"], rough, out["albedo"]
 
     def slot_order(self, sn_d, sn_s):
         """Traversal order of a point's T = sn_d + n_fixed + sn_s secondary rays (tf_bvh_trace slot_order): inside each of
