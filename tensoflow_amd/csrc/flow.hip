@@ -25,6 +25,22 @@ struct PwTables {
   float w[FLOW_NB], wss[FLOW_NB + 1], v[FLOW_NB + 1], vw[FLOW_NB + 1];
 };
 
+// x / d for many x and one d: reciprocal refined by one Newton step, quotient corrected by its fma residual (Markstein):
+// 3 instructions per quotient instead of the ~10 of the IEEE sequence (v_div_scale / v_div_fmas / v_div_fixup); the result
+// is the correctly rounded quotient except for rare 1-ulp cases -- far below the 1e-6 the MFMA summation order already
+// moves the spline parameters by.  Divisors here are sums of exponentials (positive, normal range).
+struct SharedDiv {
+  float d, r;
+  __device__ __forceinline__ explicit SharedDiv(float d_) : d(d_) {
+    const float r0 = __builtin_amdgcn_rcpf(d_);
+    r = fmaf(fmaf(-d_, r0, 1.f), r0, r0);
+  }
+  __device__ __forceinline__ float operator()(float x) const {
+    const float q = x * r;
+    return fmaf(fmaf(-d, q, x), r, q);
+  }
+};
+
 template <bool CLAMP_W>
 __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
   // wv[0..10] = v_tilde, wv[11..20] = w_tilde   (flow.py:337-350 / :420-434)
@@ -38,14 +54,14 @@ __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
     run += e;
     wsum[i] = run;
   }
-  const float wn = run;
+  const SharedDiv by_wn(run);
   T.wss[0] = 0.f;
 #pragma unroll
   for (int i = 0; i < FLOW_NB; ++i) {
-    float wi = T.w[i] / wn;
+    float wi = by_wn(T.w[i]);
     if (CLAMP_W) wi = fmaxf(wi, 1e-6f);
     T.w[i] = wi;
-    T.wss[i + 1] = wsum[i] / wn;
+    T.wss[i + 1] = by_wn(wsum[i]);
   }
   float ev[FLOW_NB + 1];
 #pragma unroll
@@ -53,8 +69,9 @@ __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
   float den = 0.f;
 #pragma unroll
   for (int i = 0; i < FLOW_NB; ++i) den += (ev[i] + ev[i + 1]) / 2.f * T.w[i];
+  const SharedDiv by_den(den);
 #pragma unroll
-  for (int i = 0; i <= FLOW_NB; ++i) T.v[i] = fmaxf(ev[i] / den, 1e-6f);
+  for (int i = 0; i <= FLOW_NB; ++i) T.v[i] = fmaxf(by_den(ev[i]), 1e-6f);
   T.vw[0] = 0.f;
   float acc = 0.f;
 #pragma unroll
@@ -101,7 +118,8 @@ __device__ __forceinline__ void pw_inverse(float y, const float (&wv)[32], float
   a = fabsf(a) < kEps32 ? kEps32 : a;
   float d = fmaxf(b * b - 2.f * a * c, 0.f);
   float sq = sqrtf(d);
-  float s1 = (-b - sq) / a, s2 = (-b + sq) / a;
+  const SharedDiv by_a(a);
+  float s1 = by_a(-b - sq), s2 = by_a(-b + sq);
   float sol = (s1 >= 0.f && s1 < 1.f) ? s1 : s2;
   sol = fminf(fmaxf(sol, kEps32), 1.f - kEps32);
   x = fminf(fmaxf(we * sol + wsse, kEps32), 1.f - kEps32);
