@@ -280,6 +280,7 @@ struct TraceArgs {
   long long m;
   long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
   const int* order;            // [rays_per_origin] or null: the j-th ray traced of a point is its slot order[j]
+  int hits_only;               // 1: pos / nrm rows are written for rays that hit only (nobody reads a miss's row)
   float off0, off1;
   unsigned long long* counter;
   float* pos;
@@ -345,8 +346,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   auto retire = [&]() {
     A.depth[rid] = best;
     if (A.hit) A.hit[rid] = best < BVH_MAX_DIST ? 1 : 0;
-    if (A.pos) { A.pos[3 * rid] = ox + best * dx; A.pos[3 * rid + 1] = oy + best * dy; A.pos[3 * rid + 2] = oz + best * dz; }
-    if (A.nrm) {
+    // 85 % of the integral's secondary rays miss; their position / normal rows are never read, and writing them cost 12 %
+    // of the kernel (scattered partial-line stores: 4x write amplification at the fabric)
+    const bool rows = !A.hits_only || best < BVH_MAX_DIST;
+    if (A.pos && rows) { A.pos[3 * rid] = ox + best * dx; A.pos[3 * rid + 1] = oy + best * dy; A.pos[3 * rid + 2] = oz + best * dz; }
+    if (A.nrm && rows) {
       float nx = 0.f, ny = 0.f, nz = 0.f;
       if (best_tri >= 0) {
         const float4 t0 = A.tris[3 * (long long)best_tri], t1 = A.tris[3 * (long long)best_tri + 1], t2 = A.tris[3 * (long long)best_tri + 2];
@@ -472,8 +476,8 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 
 extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const float* frame_host, int64_t n_pairs, const float* o, const float* d,
                             int64_t rays_per_origin, const int32_t* slot_order, float origin_offset0, float origin_offset1, const uint8_t* live,
-                            int64_t m, float* pos, float* nrm, float* depth, uint8_t* hit, int64_t* work_counter,
-                            tf_stream_t stream_) {
+                            int64_t m, float* pos, float* nrm, float* depth, uint8_t* hit, int32_t hit_rows_only,
+                            int64_t* work_counter, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(m >= 0 && n_pairs > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
   TF_REQUIRE(rays_per_origin >= 1, TF_ESHAPE, "tf_bvh_trace: rays_per_origin must be >= 1");
@@ -486,7 +490,7 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
   A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order;
   TF_REQUIRE(!slot_order || m % rays_per_origin == 0, TF_ESHAPE, "tf_bvh_trace: slot_order needs m to be a multiple of rays_per_origin");
   A.off0 = origin_offset0; A.off1 = origin_offset1; A.counter = (unsigned long long*)work_counter;
-  A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit;
+  A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit; A.hits_only = hit_rows_only ? 1 : 0;
   if (work_counter) {
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int64_t), stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_bvh_trace: hipMemsetAsync failed: %s", hipGetErrorString(e));

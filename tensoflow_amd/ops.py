@@ -452,8 +452,10 @@ class Bvh:
         self.pairs = torch.from_numpy(pairs[:npair].view(np.int32).copy()).to(device)
         self.tris = torch.from_numpy(tris12).to(device)
 
-    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True, slot_order=None):
-        """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3]."""
+    def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True, slot_order=None,
+              hit_rows_only=False):
+        """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3].
+        hit_rows_only: the pos / nrm rows of rays that miss are left UNINITIALISED (callers that only read hit rows)."""
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = d.shape[0]
         if o.shape[0] == 0 or m % o.shape[0] != 0:
@@ -470,7 +472,7 @@ class Bvh:
         ctr = torch.empty(1, dtype=torch.int64, device=dev) if dynamic else None
         L.check(self.lib.tf_bvh_trace(_p(self.pairs, torch.int32), _p(self.tris), C.byref(self.frame), self.n_pairs, _p(o), _p(d), per_origin, _p(slot_order, torch.int32), float(off0), float(off1),
                                       _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
-                                      _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
+                                      int(bool(hit_rows_only)), _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()
 
 

@@ -189,7 +189,9 @@ class MCShader:
         live [M] uint8 (optional): rays whose weight in the integral is exactly zero are neither traced nor shaded."""
         T = self.timer
         with T.stage("bvh_trace"):
-            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live, slot_order=slot_order)
+            # the hit point / normal rows are only read through the compacted hit list below
+            inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live, slot_order=slot_order,
+                                                     hit_rows_only=True)
         with T.stage("cube_lookup"):
             # miss branch + near mask of get_lights in one pass (every ray; hit rays are overwritten below)
             lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)

@@ -231,6 +231,10 @@ def test_bvh_trace_matches_brute_force(golden, dev):
     pos2, nrm2, depth2, hit2 = bvh.trace(o.to(dev), d.to(dev), dynamic=False)
     # same algorithm, different instruction selection (FMA contraction): flags identical, values to the last bits
     assert torch.equal(hit, hit2) and rel_err(depth, depth2) < 1e-6 and rel_err(pos, pos2) < 1e-6
+    # hit_rows_only: identical depth / hit, identical pos / nrm rows where the ray hits (the other rows are not written)
+    pos3, nrm3, depth3, hit3 = bvh.trace(o.to(dev), d.to(dev), hit_rows_only=True)
+    assert torch.equal(hit3, hit) and torch.equal(depth3, depth)
+    assert torch.equal(pos3[hit], pos[hit]) and torch.equal(nrm3[hit], nrm[hit])
     rpos, rnrm, rdepth, rhit = tr(o, d)
     assert torch.equal(hit.cpu(), rhit)                     # boolean, bit-exact
     assert 0.2 < rhit.float().mean() < 0.98
