@@ -395,6 +395,13 @@ int tf_shade_dirs_bwd(const float* normals, const float* view, const float* meta
                       const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd,
                       int32_t nf, int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness,
                       tf_stream_t stream);
+/* Same reduction with get_lights' miss branch folded in (fields.py:951-975): a slot whose ray hit the mesh (hit[r] != 0)
+ * takes hit_lights[r] (tf_inner_light_indexed_fwd's scatter target; other rows are never read), a slot whose ray missed
+ * takes exp(cube(env_base, dirs[r])) * (depth[r] > near_eps) evaluated on the fly -- the [pn,T,3] light array of the
+ * miss branch is never written or read.  Zero-weight slots are skipped. */
+int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit, const float* hit_lights,
+                        const float* env_base, int32_t env_res, float near_eps, int64_t pn, int32_t n_diffuse, int32_t ss,
+                        float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);

@@ -2,6 +2,7 @@
 // direction construction from the flow samples + the fixed cosine set, pdfs, GGX/Schlick BRDF
 // weights, and the final reduction + sRGB.  Elementwise over pn*T slots; HBM-bound
 // (reads 12 B of flow output per slot, writes 24 B of direction + weight).
+#include "cube.h"
 #include "tf_common.h"
 
 static constexpr float kPi = 3.14159265358979323846f;
@@ -249,6 +250,64 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const float* __restri
       if (specular_lin) specular_lin[3 * pt + k] = s[k];
     }
   }
+}
+
+// Reduction with the environment light evaluated on the fly: a ray that missed the mesh takes exp(cube(dirs)) * near-mask
+// (MCShadingNetwork.get_lights, fields.py:951-975 + EnvLight.direct_light) computed HERE instead of being written to and
+// re-read from a [pn,T,3] light array; a ray that hit reads the inner-light result from `hit_lights` (rows of missing rays are
+// never touched).  Slots with zero weight (culled rays, masked specular samples) cost nothing.
+__global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __restrict__ wgt, const float* __restrict__ dirs,
+                                                               const float* __restrict__ depth, const unsigned char* __restrict__ hit,
+                                                               const float* __restrict__ hit_lights, const float* __restrict__ env,
+                                                               int env_res, float near_eps, long long pn, int n_diff, int ss,
+                                                               float* __restrict__ colors, float* __restrict__ diffuse_lin,
+                                                               float* __restrict__ specular_lin) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= pn) return;
+  const int T = n_diff + ss;
+  float d[3] = {0, 0, 0}, s[3] = {0, 0, 0};
+  for (int t = lane; t < T; t += 64) {
+    const long long r = pt * T + t, e = r * 3;
+    const float w0 = wgt[e], w1 = wgt[e + 1], w2 = wgt[e + 2];
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
+      if (hit[r]) {
+        l0 = hit_lights[e]; l1 = hit_lights[e + 1]; l2 = hit_lights[e + 2];
+      } else if (depth[r] > near_eps) {
+        cube_fetch_rgb(env, env_res, dirs[e], dirs[e + 1], dirs[e + 2], l0, l1, l2);
+        l0 = expf(l0); l1 = expf(l1); l2 = expf(l2);
+      }
+    }
+    const float c0 = w0 * l0, c1 = w1 * l1, c2 = w2 * l2;
+    if (t < n_diff) { d[0] += c0; d[1] += c1; d[2] += c2; } else { s[0] += c0; s[1] += c1; s[2] += c2; }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d[k] += __shfl_xor(d[k], o); s[k] += __shfl_xor(s[k], o); }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      colors[3 * pt + k] = srgb(d[k] + s[k]);
+      if (diffuse_lin) diffuse_lin[3 * pt + k] = d[k];
+      if (specular_lin) specular_lin[3 * pt + k] = s[k];
+    }
+  }
+}
+
+extern "C" int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit,
+                                   const float* hit_lights, const float* env_base, int32_t env_res, float near_eps, int64_t pn,
+                                   int32_t n_diffuse, int32_t ss, float* colors, float* diffuse_lin, float* specular_lin,
+                                   tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && env_res > 0, TF_ESHAPE, "tf_shade_reduce_env: negative size / env_res <= 0");
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(wgt && dirs && depth && hit && hit_lights && env_base && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
+  shade_reduce_env_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, dirs, depth, hit, hit_lights, env_base, env_res,
+                                                                            near_eps, pn, n_diffuse, ss, colors, diffuse_lin,
+                                                                            specular_lin);
+  TF_LAUNCH_CHECK("tf_shade_reduce_env");
+  return TF_OK;
 }
 
 extern "C" int tf_view_angles(const float* normals, const float* view, int64_t pn, float* view_angles, tf_stream_t stream) {

@@ -681,6 +681,21 @@ def inner_light_encode(pos, dirs, nrm, idx=None, count=None):
     return X
 
 
+def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, ss, near_eps=1e-5):
+    """colors / diffuse / specular sums with the miss branch of get_lights evaluated inside the reduction."""
+    lib = L.load()
+    pn = wgt.shape[0]
+    dev = wgt.device
+    colors = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    dl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    sl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
+    env_base = _f(env_base)
+    L.check(lib.tf_shade_reduce_env(_p(_f(wgt)), _p(_f(dirs)), _p(_f(depth)), _p(hit_u8, torch.uint8), _p(_f(hit_lights)), _p(env_base),
+                                    env_base.shape[1], float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl), _stream()),
+            "tf_shade_reduce_env")
+    return colors, dl, sl
+
+
 def shade_reduce(wgt, lights, n_diffuse, ss):
     lib = L.load()
     pn = wgt.shape[0]

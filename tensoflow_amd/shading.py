@@ -105,6 +105,13 @@ class ShadeOutputs(dict):
     first access instead of on every call (the eval integral never reads it)."""
 
     def __missing__(self, key):
+        if key == "lights":     # [pn,T,3] light of every ray (fields.py:951-975): hit rows from the inner-light net, the rest env light
+            hit = self["hit"]
+            pn, T = hit.shape
+            env = ops.cube_lookup(self["_env"], self["dirs"].reshape(-1, 3), apply_exp=True, depth=self["depth"].reshape(-1), near_eps=1e-5)
+            lights = torch.where(hit.reshape(-1, 1), self["hit_lights"].reshape(-1, 3), env).reshape(pn, T, 3)
+            self[key] = lights
+            return lights
         if key != "specular_rays_id":
             raise KeyError(key)
         smask = self["specular_mask"]
@@ -184,23 +191,30 @@ class MCShader:
             self._order[key] = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(self.device)
         return self._order[key]
 
-    def lights(self, pts_rep, dirs, live=None, slot_order=None):
-        """get_lights (fields.py:951-975): pts_rep [M,3] (or [M // T, 3]: T consecutive rays per origin), dirs [M,3] -> lights [M,3], hit [M] bool.
-        live [M] uint8 (optional): rays whose weight in the integral is exactly zero are neither traced nor shaded."""
+    def trace_and_inner(self, pts_rep, dirs, live=None, slot_order=None):
+        """Hit branch of get_lights (fields.py:951-975): BVH visibility + inner-light MLP on the rays that hit.
+        -> hit_lights [M,3] (rows of rays that hit; the others are uninitialised), hit [M] bool, depth [M], inters [M,3]."""
         T = self.timer
         with T.stage("bvh_trace"):
             # the hit point / normal rows are only read through the compacted hit list below
             inters, nrm, depth, hit = self.bvh.trace(pts_rep, dirs, 1e-5, 2 * self.unit, live=live, slot_order=slot_order,
                                                      hit_rows_only=True)
-        with T.stage("cube_lookup"):
-            # miss branch + near mask of get_lights in one pass (every ray; hit rays are overwritten below)
-            lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)
         with T.stage("hit_compaction"):
             idx, count = ops.compact_mask(hit.view(torch.uint8))
         with T.stage("inner_light"):
-            ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5,
+            hit_lights = torch.empty_like(dirs)
+            ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, hit_lights, near_eps=1e-5,
                                     exp_max=self.exp_max, precision=self.precision, cache=self.inner_cache)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
+        return hit_lights, hit, depth, inters
+
+    def lights(self, pts_rep, dirs, live=None, slot_order=None):
+        """get_lights (fields.py:951-975) for every ray: pts_rep [M,3] (or [M // T, 3]: T consecutive rays per origin),
+        dirs [M,3] -> lights [M,3], hit [M] bool, inters.  (shade() does not materialise this array: the miss branch is
+        evaluated inside the reduction, tf_shade_reduce_env.)"""
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts_rep, dirs, live=live, slot_order=slot_order)
+        lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)
+        lights = torch.where(hit[:, None], hit_lights, lights)
         return lights, hit, inters
 
     @torch.no_grad()
@@ -223,12 +237,13 @@ class MCShader:
             dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built
-        lights, hit, inters = self.lights(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
-                                          slot_order=self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None)
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
+                                                              slot_order=self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
-            colors, dl, sl = ops.shade_reduce(wgt, lights.reshape(pn, T, 3), n_diff, sn_specular)
+            # environment light of the rays that missed is evaluated inside the reduction (no [pn,T,3] light array)
+            colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, n_diff, sn_specular)
         return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                     specular_mask=smask, hit=hit.reshape(pn, T), live=live, view_angles=va,
                     diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
-                    lights=lights.reshape(pn, T, 3))
+                    hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env)

@@ -311,6 +311,11 @@ def test_shade_golden(golden, dev, tag):
     live = out["live"].bool().cpu()
     assert torch.equal(out["hit"][:, :nd].cpu(), ref["diffuse_hit"] & live[:, :nd])     # dead rays are never traced
     assert 0.5 < float(live.float().mean()) < 1.0
+    # the fused reduction (environment light of the missing rays evaluated in place) equals the two-step form: the full
+    # [pn,T,3] light array of get_lights (materialised on demand) reduced by tf_shade_reduce
+    from tensoflow_amd import ops as _ops
+    col2, dl2, sl2 = _ops.shade_reduce(out["wgt"], out["lights"], nd, sn_s)
+    assert rel_err(col2.cpu(), out["colors"].cpu()) < 1e-6 and rel_err(dl2.cpu(), out["diffuse_lin"].cpu()) < 1e-6
     sh.cull_dead_rays = False                                                         # reference-faithful: trace everything
     out2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
     assert torch.equal(out2["hit"][:, :nd].cpu(), ref["diffuse_hit"])
