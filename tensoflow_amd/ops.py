@@ -458,9 +458,12 @@ class Bvh:
         hit_rows_only: the pos / nrm rows of rays that miss are left UNINITIALISED (callers that only read hit rows)."""
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = d.shape[0]
-        if o.shape[0] == 0 or m % o.shape[0] != 0:
+        if m == 0:
+            per_origin = 1
+        elif o.shape[0] == 0 or m % o.shape[0] != 0:
             raise RuntimeError(f"Bvh.trace: {m} directions cannot share {o.shape[0]} origins")
-        per_origin = m // o.shape[0]
+        else:
+            per_origin = m // o.shape[0]
         if slot_order is not None and (slot_order.dtype != torch.int32 or slot_order.numel() != per_origin):
             raise RuntimeError("Bvh.trace: slot_order must be an int32 permutation of the rays of one origin")
         dev = o.device
