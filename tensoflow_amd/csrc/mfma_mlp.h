@@ -410,7 +410,9 @@ template <int TOUT, int TIN, int SL16>
 __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFrag& cur, TfFrag& nxt, const f32x16 (&in)[TIN],
                                             f32x16 (&out)[TOUT]) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifndef TF_ABLATE_BARRIER   // dev-only timing ablation: results are garbage when defined
   __builtin_amdgcn_s_barrier();
+#endif
   asm volatile("" ::: "memory");
   tf_h8 b_hi[SL16], b_lo[SL16];
 #pragma unroll
