@@ -7,7 +7,7 @@ tag=${1:-final}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD > $out/stats.log 2>&1
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $CMD > $out/fetch.log 2>&1

@@ -47,7 +47,7 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KiB_avg"] + e["WRITE_SIZE_KiB_avg"]) * 1024.0
         traffic[k] = dict(hbm_bytes_per_launch=e["hbm_bytes_per_launch"], fetch_kib=e["FETCH_SIZE_KiB_avg"],
                           write_kib=e["WRITE_SIZE_KiB_avg"], launches=e["launches"],
-                          note="2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 2 --no-cpu-baseline`")
+                          note="2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train`")
     if k in sq:
         c = {n: sum(v) / len(v) for n, v in sq[k].items()}
         wc = c.get("SQ_WAVE_CYCLES", 0.0)
