@@ -89,6 +89,24 @@ def cpu_baseline(sd, aabb, unit, n_points, sn, budget_s=25.0):
                        f"threads, brute-force visibility over a {len(faces)}-triangle version of the same scene, {dt:.1f} s")
 
 
+def flow_only_probe(device, sd, verts, faces, aabb, unit, S, steps, pn):
+    """Secondary figure (SURVEY.md 8(d) reading (i) of the metric): the same eval pass WITHOUT the 512 fixed cosine directions the
+    reference always appends -- 128 flow samples per lobe = 256 secondary rays per point."""
+    from tensoflow_amd.shading import MCShader
+    from tensoflow_amd.synth import sphere_surface_points
+    sh = MCShader(sd, verts, faces, aabb, unit, device=device, n_fixed_diffuse=0)
+    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=6)]
+    for _ in range(2):
+        sh.shade(pts, view, nrm, S, S)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sh.shade(pts, view, nrm, S, S)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dict(workload=f"{pn} points x ({S} + {S}) flow-sampled rays, no fixed diffuse set", ms_per_step=dt * 1e3, points_per_s=pn / dt)
+
+
 def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
     """Secondary figure: one TRAINING step of the material stage (BASELINE configs[2], train mode): MCShadingNetwork.forward
     with autograd (shade_mixed + both NIS losses, fields.py:1075-1335) + backward over every trainable tensor, on the
@@ -313,6 +331,10 @@ def main():
             sh.timer = type("N", (), {"stage": lambda s, n: __import__("contextlib").nullcontext(), "add_units": lambda s, n, k: None})()
             line["march"] = march_probe(device, max(2, args.steps))
         if world == 1 and not args.no_train:
+            try:
+                line["flow_only"] = flow_only_probe(device, sd, verts, faces, aabb, unit, S, max(2, args.steps), pn)
+            except Exception as e:
+                line["flow_only"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 line["train"] = train_probe(device, verts, faces, aabb, unit, S, max(2, args.steps))
             except Exception as e:      # the probe is informative only: never lose the headline line over it
