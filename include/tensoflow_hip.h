@@ -184,6 +184,11 @@ int tf_cube_lookup_fwd(const float* base, int32_t res, const float* dirs, int64_
 /* g_base += d out/d base (atomics; zero first); out = forward result (needed when apply_exp). */
 int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
                        const float* g_out, float* g_base, tf_stream_t stream);
+/* Same, plus the gradient wrt the lookup direction (dr.texture is differentiable in its coordinates; the shape stage
+ * reaches the SDF through envlight(normal) / envlight(reflective, roughness), network/fields.py:436-446, :419-439).
+ * g_base [6,R,R,3] (+=, zero first) or NULL; g_dirs [m,3] (overwritten) or NULL; at least one of them. */
+int tf_cube_lookup_bwd_dirs(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                            const float* g_out, float* g_base, float* g_dirs, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sample generation for the march.

@@ -26,28 +26,71 @@ __global__ void __launch_bounds__(256) cube_lookup_fwd_kernel(const float* __res
   out[3 * i] = r; out[3 * i + 1] = g; out[3 * i + 2] = b;
 }
 
+// Backward of the lookup.  g_base (nullable): += d out / d map (float atomics).  g_dirs (nullable): d out / d direction --
+// dr.texture is differentiable in its coordinates, and the shape stage reaches the SDF through them (envlight(normal),
+// envlight(reflective, roughness), fields.py:436-446): the bilinear weights are differentiated in the face coordinates
+// (x, y) of the major face (taps re-projected across a seam keep the weight of the major face; at a cube corner the
+// dropped tap renormalises the other three -- quotient rule), then mapped through x = +-d_minor / |d_major|.
 __global__ void __launch_bounds__(256) cube_lookup_bwd_kernel(const float* __restrict__ base, int R,
                                                               const float* __restrict__ dirs, long long m, int apply_exp,
-                                                              const float* __restrict__ g_out, float* __restrict__ g_base) {
+                                                              const float* __restrict__ g_out, float* __restrict__ g_base,
+                                                              float* __restrict__ g_dirs) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
+  const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
   CubeTaps T;
-  cube_taps(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], R, T);
+  cube_taps(dx, dy, dz, R, T);
   float gr = g_out[3 * i], gg = g_out[3 * i + 1], gb = g_out[3 * i + 2];
-  if (apply_exp) {
-    float r = 0.f, g = 0.f, b = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float* p = base + 3LL * T.idx[t];
-      r += T.w[t] * p[0]; g += T.w[t] * p[1]; b += T.w[t] * p[2];
-    }
-    gr *= expf(r); gg *= expf(g); gb *= expf(b);
-  }
+  float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    if (T.w[t] == 0.f) continue;
-    float* p = g_base + 3LL * T.idx[t];
-    atomicAdd(p, T.w[t] * gr); atomicAdd(p + 1, T.w[t] * gg); atomicAdd(p + 2, T.w[t] * gb);
+    const float* p = base + 3LL * T.idx[t];
+    r += T.w[t] * p[0]; g += T.w[t] * p[1]; b += T.w[t] * p[2];
+  }
+  if (apply_exp) { gr *= expf(r); gg *= expf(g); gb *= expf(b); }
+  if (g_base) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (T.w[t] == 0.f) continue;
+      float* p = g_base + 3LL * T.idx[t];
+      atomicAdd(p, T.w[t] * gr); atomicAdd(p + 1, T.w[t] * gg); atomicAdd(p + 2, T.w[t] * gb);
+    }
+  }
+  if (g_dirs) {
+    int face;
+    float x, y;
+    cube_face_uv(dx, dy, dz, face, x, y);
+    const float u = (x * 0.5f + 0.5f) * (float)R - 0.5f, v = (y * 0.5f + 0.5f) * (float)R - 0.5f;
+    const float fu = u - floorf(u), fv = v - floorf(v);
+    // raw (un-normalised) weights and their u / v derivatives; a dropped corner tap has T.w == 0 and raw weight 0
+    float wsum = 0.f, su = 0.f, sv = 0.f, au = 0.f, av = 0.f;   // sum w, sum dw/du, sum dw/dv, sum dw/du * (g . T), sum dw/dv * (g . T)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int du = t & 1, dv = t >> 1;
+      const bool dropped = T.w[t] == 0.f && ((du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv)) != 0.f;
+      if (dropped) continue;
+      const float* p = base + 3LL * T.idx[t];
+      const float gt = gr * p[0] + gg * p[1] + gb * p[2];
+      const float wu = (du ? 1.f : -1.f) * (dv ? fv : 1.f - fv), wv = (du ? fu : 1.f - fu) * (dv ? 1.f : -1.f);
+      wsum += (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
+      su += wu; sv += wv; au += wu * gt; av += wv * gt;
+    }
+    const float gval = gr * r + gg * g + gb * b;
+    const float inv = 1.f / wsum;
+    const float gu = (au - gval * su) * inv, gv = (av - gval * sv) * inv;
+    const float gx = gu * 0.5f * (float)R, gy = gv * 0.5f * (float)R;
+    float ox, oy, oz;
+    if (face >= 4) {            // major z: x = +-dx / |dz|, y = -dy / |dz|
+      const float mz = 1.f / fabsf(dz), sg = dz < 0.f ? -1.f : 1.f;
+      ox = sg * mz * gx; oy = -mz * gy; oz = -(x * gx + y * gy) * mz * sg;
+    } else if (face >= 2) {     // major y: x = dx / |dy|, y = +-dz / |dy|
+      const float my = 1.f / fabsf(dy), sg = dy < 0.f ? -1.f : 1.f;
+      ox = my * gx; oz = sg * my * gy; oy = -(x * gx + y * gy) * my * sg;
+    } else {                    // major x: x = -+dz / |dx|, y = -dy / |dx|
+      const float mx = 1.f / fabsf(dx), sg = dx < 0.f ? -1.f : 1.f;
+      oz = -sg * mx * gx; oy = -mx * gy; ox = -(x * gx + y * gy) * mx * sg;
+    }
+    g_dirs[3 * i] = ox; g_dirs[3 * i + 1] = oy; g_dirs[3 * i + 2] = oz;
   }
 }
 
@@ -66,7 +109,17 @@ extern "C" int tf_cube_lookup_bwd(const float* base, int32_t res, const float* d
   TF_REQUIRE(m >= 0 && res > 0, TF_ESHAPE, "tf_cube_lookup_bwd: m < 0 or res <= 0");
   if (m == 0) return TF_OK;
   TF_REQUIRE(base && dirs && g_out && g_base, TF_EINVAL, "tf_cube_lookup_bwd: null pointer");
-  cube_lookup_bwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, g_out, g_base);
+  cube_lookup_bwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, g_out, g_base, nullptr);
   TF_LAUNCH_CHECK("tf_cube_lookup_bwd");
+  return TF_OK;
+}
+
+extern "C" int tf_cube_lookup_bwd_dirs(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
+                                       const float* g_out, float* g_base, float* g_dirs, tf_stream_t stream) {
+  TF_REQUIRE(m >= 0 && res > 0, TF_ESHAPE, "tf_cube_lookup_bwd_dirs: m < 0 or res <= 0");
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(base && dirs && g_out && (g_base || g_dirs), TF_EINVAL, "tf_cube_lookup_bwd_dirs: null pointer");
+  cube_lookup_bwd_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream>>>(base, res, dirs, m, apply_exp, g_out, g_base, g_dirs);
+  TF_LAUNCH_CHECK("tf_cube_lookup_bwd_dirs");
   return TF_OK;
 }

@@ -1,0 +1,59 @@
+"""Differentiable encodings of the training direction (device-resident torch; the inference kernels evaluate the same
+functions in registers: csrc/inner_light.hip, csrc/shape_shade.hip).
+
+* `posenc`  -- get_embedder (utils/network_utils.py:38-50): [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(n-1) x), cos(2^(n-1) x)]
+* `ide5`    -- generate_ide_fn(5) (utils/ref_utils.py:53-117): integrated directional encoding, 72 values
+               [Re(38 terms... 36) | Im(36)], attenuated by exp(-l(l+1)/2 * kappa_inv)
+* `linear_to_srgb` -- utils/raw_utils.py:4-17
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def posenc(x, n_freq):
+    out = [x]
+    for k in range(n_freq):
+        out += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
+    return torch.cat(out, -1)
+
+
+def _ide_tables():
+    """-> mat [17, 36] (coefficient of z^k for column (l, m)), m_of_col [36], l_of_col [36]; l = 1, 2, 4, 8, 16, m = 0..l."""
+    f = math.factorial
+    cols = [(1 << d, m) for d in range(5) for m in range((1 << d) + 1)]
+    mat = np.zeros((17, len(cols)))
+    for c, (l, m) in enumerate(cols):
+        for k in range(l - m + 1):
+            a = 0.5 * (l + k + m - 1.0)
+            gb = np.prod([a - j for j in range(l)]) / f(l)           # generalised binomial C(a, l)
+            leg = (-1.0) ** m * 2.0 ** l * f(l) / f(k) / f(l - k - m) * gb
+            mat[k, c] = math.sqrt((2.0 * l + 1.0) * f(l - m) / (4.0 * math.pi * f(l + m))) * leg
+    return mat.astype(np.float32), np.array([m for _, m in cols]), np.array([l for l, _ in cols], np.float32)
+
+
+_IDE = {}
+
+
+def ide5(xyz, kappa_inv):
+    """xyz [..., 3] unit directions, kappa_inv [..., 1] -> [..., 72]."""
+    dev = xyz.device
+    if dev not in _IDE:
+        mat, ms, ls = _ide_tables()
+        _IDE[dev] = (torch.from_numpy(mat).to(dev), torch.from_numpy(ms).to(dev), torch.from_numpy(0.5 * ls * (ls + 1)).to(dev))
+    mat, ms, sigma = _IDE[dev]
+    x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
+    vmz = torch.cat([torch.ones_like(z)] + [z ** i for i in range(1, mat.shape[0])], -1)
+    re, im = [torch.ones_like(x)], [torch.zeros_like(x)]                 # (x + iy)^m, m = 0..16
+    for _ in range(16):
+        re, im = re + [re[-1] * x - im[-1] * y], im + [re[-1] * y + im[-1] * x]
+    re, im = torch.cat(re, -1)[..., ms], torch.cat(im, -1)[..., ms]
+    poly = vmz @ mat
+    att = torch.exp(-sigma * kappa_inv)
+    return torch.cat([re * poly * att, im * poly * att], -1)
+
+
+def linear_to_srgb(lin):
+    eps = torch.finfo(torch.float32).eps
+    return torch.where(lin <= 0.0031308, 323 / 25 * lin, (211 * lin.clamp(min=eps) ** (5 / 12) - 11) / 200)

@@ -40,6 +40,23 @@ class TensoSDF(nn.Module):
         self.units = self.aabbSize / (self.gridSize - 1)
         self.n_levels = n_levels
 
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """fields.py:155-178: bilinear (align_corners) resampling of planes / lines to `res_target` rounded down to a multiple of
+        2^(levels-1), one more mip level.  The optimizer has to be rebuilt by the caller (new Parameters), as in the reference."""
+        new_levels = self.n_levels + 1
+        res_target = torch.as_tensor(res_target).cpu()
+        res_target = (res_target / 2 ** (new_levels - 1)).int() * 2 ** (new_levels - 1)
+        for i in range(3):
+            m0, m1 = self.matMode[i]
+            self.sdf_plane[i] = nn.Parameter(F.interpolate(self.sdf_plane[i].data, size=(int(res_target[m1]), int(res_target[m0])),
+                                                           mode="bilinear", align_corners=True))
+            self.sdf_line[i] = nn.Parameter(F.interpolate(self.sdf_line[i].data, size=(int(res_target[self.vecMode[i]]), 1),
+                                                          mode="bilinear", align_corners=True))
+        self.update_gridSize_aabb(res_target, self.aabb, new_levels)
+        self._packed = None
+        return res_target, self.n_levels
+
     def _field(self):
         ver = tuple(p._version for p in list(self.sdf_plane) + list(self.sdf_line)) + (self.n_levels,)
         if self._packed is None or ver != self._packed_version:
@@ -115,6 +132,17 @@ class MCShadingNetwork(nn.Module):
                                 exp_max=self.cfg["inner_light_exp_max"])
         return self._shader
 
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001, lr_init_envlight=0.001):
+        """fields.py:1580-1595."""
+        from ..trainer import material_param_groups
+        return material_param_groups(self, lr_init_spatialxyz, lr_init_network, lr_init_envlight)
+
+    def predict_materials(self, pts):
+        """fields.py:1010-1017 -> metallic [pn,1], roughness [pn,1] (squared-roughness convention, remapped), albedo [pn,3]."""
+        feat = VmGatherFn.apply(pts.contiguous(), None, self.aabb, 3, *self.mat_plane, *self.mat_line)
+        return (self.metallic_predictor(feat), self.roughness_predictor(feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2,
+                self.albedo_predictor(feat))
+
     def _linear_to_srgb(self, lin):
         eps = torch.finfo(torch.float32).eps
         return torch.where(lin <= 0.0031308, 323 / 25 * lin, (211 * lin.clamp(min=eps) ** (5 / 12) - 11) / 200)
@@ -186,3 +214,157 @@ class MCShadingNetwork(nn.Module):
         outputs = {"albedo": out["albedo"], "roughness": out["roughness"], "metallic": out["metallic"],
                    "normal": (F.normalize(normals, dim=-1) + 1) / 2, "specular_rays_id": out["specular_rays_id"]}
         return out["colors"], outputs
+
+
+def _predictor3(feats_dim, out_dim, final, run_dim=128):
+    """make_predictor_3layer (network/other_field.py:50-84): weight-normed Linear-ReLU-Linear-ReLU-Linear + final activation."""
+    wn = nn.utils.parametrizations.weight_norm
+    return nn.Sequential(wn(nn.Linear(feats_dim, run_dim)), nn.ReLU(), wn(nn.Linear(run_dim, run_dim)), nn.ReLU(),
+                         wn(nn.Linear(run_dim, out_dim)), final)
+
+
+class _Exp(nn.Module):
+    """ExpActivation (other_field.py:12-18)."""
+
+    def __init__(self, max_light):
+        super().__init__()
+        self.max_light = max_light
+
+    def forward(self, x):
+        return torch.exp(torch.clamp(x, max=self.max_light))
+
+
+class SingleVarianceNetwork(nn.Module):
+    """other_field.py:193-207 with activation='exp': inv_s = exp(10 * variance), one scalar parameter."""
+
+    def __init__(self, init_val, activation="exp"):
+        super().__init__()
+        if activation != "exp":
+            raise NotImplementedError("std_act='exp' (configs/shape/*: default)")
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
+
+    def inv_s(self):
+        return torch.exp(self.variance * 10.0)
+
+    def forward(self, x):
+        return torch.ones([*x.shape[:-1], 1], device=x.device) * self.inv_s()
+
+
+class ShapeShadingNetwork(nn.Module):
+    """Split-sum shading of the shape stage (reference: network/fields.py:319-575) with the reference's parameter names.
+
+    Without autograd the whole forward is ONE launch of tf_shape_shade_fwd (three 128-wide MLPs, encodings, cube taps, FG
+    LUT, sRGB).  With autograd the same arithmetic is composed from device-resident torch ops (MLP products = library GEMMs)
+    and the HIP cube-map autograd ops of EnvLight, so that gradients reach the MLPs, the environment map and -- through the
+    normals / reflective directions / roughness -- the SDF.  `rad_mlp` (has_radiance_field) and human lights are not built."""
+    default_cfg = {"human_light": False, "sphere_direction": False, "light_pos_freq": 8, "inner_init": -0.95, "light_exp_max": 0.0,
+                   "app_feats_dim": 128, "has_radiance_field": False, "radiance_field_step": 0, "mat_pos_multires": -1,
+                   "fg_lut_path": "assets/bsdf_256_256.bin"}
+
+    def __init__(self, cfg, device="cuda"):
+        super().__init__()
+        import os
+        from ..synth import synthetic_fg_lut
+        self.cfg = {**self.default_cfg, **cfg}
+        if self.cfg["human_light"] or self.cfg["sphere_direction"] or self.cfg["mat_pos_multires"] >= 0:
+            raise NotImplementedError("round 1 covers human_light=False, sphere_direction=False, mat_pos_multires=-1 (configs/shape/syn)")
+        fd, em = self.cfg["app_feats_dim"], self.cfg["light_exp_max"]
+        self.mat_mlp = _predictor3(fd, 5, nn.Sigmoid())
+        path = self.cfg["fg_lut_path"]
+        if path and os.path.exists(path):
+            lut = torch.from_numpy(np.fromfile(path, dtype=np.float32).reshape(1, 256, 256, 2))
+        else:   # analytic stand-in until load_state_dict brings the table of a reference checkpoint (buffer 'FG_LUT')
+            lut = synthetic_fg_lut()
+        self.register_buffer("FG_LUT", lut)
+        pos_dim = 3 + 6 * self.cfg["light_pos_freq"]
+        self.outer_light = _predictor3(72, 3, _Exp(em))      # present in reference checkpoints, unused by forward (fields.py:428)
+        nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
+        self.envlight = EnvLight(trainable=True, max_res=128, device=device)
+        self.inner_light = _predictor3(pos_dim + 72, 3, _Exp(em))
+        nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))
+        self.inner_weight = _predictor3(pos_dim + 39, 1, nn.Identity())
+        nn.init.constant_(self.inner_weight[-2].bias, self.cfg["inner_init"])
+        self.to(device)
+        self._op, self._op_version = None, None
+
+    def get_optparam_groups(self, lr_init_network, lr_init_envlight):
+        return [{"params": self.envlight.parameters(), "lr": lr_init_envlight},
+                {"params": [p for n, p in self.named_parameters() if "envlight" not in n], "lr": lr_init_network}]
+
+    # ------------------------------------------------------------------ fused inference path
+    def _fused(self):
+        env = self.envlight
+        if not hasattr(env, "specular"):
+            env.build_mips()
+        ver = tuple(p._version for p in self.parameters()) + tuple(id(s) for s in env.specular) + (id(env.diffuse), self.FG_LUT._version)
+        if self._op is None or ver != self._op_version:
+            nets = {}
+            for name in ("mat_mlp", "inner_light", "inner_weight"):
+                seq = getattr(self, name)
+                nets[name] = [(seq[i].weight.detach().contiguous(), seq[i].bias.detach().contiguous()) for i in (0, 2, 4)]
+            self._op = ops.ShapeShade(nets, [s.detach() for s in env.specular], env.diffuse.detach(), self.FG_LUT,
+                                      env.min_roughness, env.max_roughness, self.cfg["light_exp_max"])
+            self._op_version = ver
+        return self._op
+
+    # ------------------------------------------------------------------ differentiable composition
+    def _composed(self, points, normals, view_dirs, feat, inter_results):
+        from ..encodings import ide5, linear_to_srgb, posenc
+        env = self.envlight
+        if not hasattr(env, "specular"):
+            env.build_mips()
+        normals = F.normalize(normals, dim=-1)
+        bad = (normals[:, :2].sum(-1) == 0.0)[:, None]
+        normals = torch.where(bad, torch.tensor([0.0, 1e-6, 1.0], device=normals.device), normals)
+        view_dirs = F.normalize(view_dirs, dim=-1)
+        NoV = (normals * view_dirs).sum(-1, keepdim=True)
+        reflective = NoV * normals * 2 - view_dirs
+        mat = self.mat_mlp(feat)
+        albedo, roughness, metallic = mat[..., :3] * 0.77 + 0.03, mat[..., 3:4] * 0.9 + 0.09, mat[..., 4:]
+        diffuse_albedo = (1 - metallic) * albedo
+        diffuse_light = env(normals)
+        diffuse_color = diffuse_albedo * diffuse_light
+        specular_albedo = 0.04 * (1 - metallic) + metallic * albedo
+        direct_light = env(reflective, roughness)
+        pts = posenc(points, self.cfg["light_pos_freq"])
+        indirect_light = self.inner_light(torch.cat([pts, ide5(reflective, roughness)], -1))
+        occ_prob = self.inner_weight(torch.cat([pts.detach(), posenc(reflective, 6).detach()], -1)) * 0.5 + 0.5
+        occ = occ_prob.clamp(0, 1)
+        specular_light = indirect_light * occ + direct_light * (1 - occ)
+        # FG LUT: dr.texture(filter_mode='linear', boundary_mode='clamp'), texel centres at (i + .5) / n
+        uv = torch.cat([NoV.clamp(0, 1), roughness.clamp(0, 1)], -1)
+        lut = self.FG_LUT.reshape(self.FG_LUT.shape[-3], self.FG_LUT.shape[-2], 2).permute(2, 0, 1)[None]
+        fg = F.grid_sample(lut, (uv * 2 - 1)[None, :, None, :], mode="bilinear", padding_mode="border", align_corners=False)[0, :, :, 0].t()
+        specular_ref = specular_albedo * fg[:, 0:1] + fg[:, 1:2]
+        specular_color = specular_ref * specular_light
+        color = linear_to_srgb(diffuse_color + specular_color).clamp(0.0, 1.0)
+        occ_info = {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
+        if not inter_results:
+            return color, None, occ_info
+        c01 = lambda t: t.clamp(0.0, 1.0)
+        inter = {"specular_albedo": specular_albedo, "specular_ref": c01(specular_ref), "specular_direct_light": direct_light,
+                 "specular_light": c01(linear_to_srgb(specular_light)), "specular_color": c01(linear_to_srgb(specular_color)),
+                 "diffuse_albedo": diffuse_albedo, "diffuse_light": c01(linear_to_srgb(diffuse_light)),
+                 "diffuse_color": c01(linear_to_srgb(diffuse_color)), "metallic": metallic, "roughness": roughness, "albedo": albedo,
+                 "occ_prob": c01(occ_prob), "indirect_light": indirect_light * occ}
+        return color, occ_info, inter
+
+    def forward(self, points, normals, view_dirs, feature_vectors, human_poses=None, inter_results=False, step=None):
+        """fields.py:448-567 -> (color [N,3], None, occ_info) or, with inter_results, (color, occ_info, intermediate dict)."""
+        if self.cfg["has_radiance_field"] and step is not None and step > self.cfg["radiance_field_step"]:
+            raise NotImplementedError("rad_mlp (has_radiance_field) is not built")
+        if points.shape[0] == 0:
+            z = lambda c: torch.zeros(0, c, device=points.device)
+            occ_info = {"reflective": z(1), "occ_prob": z(1), "roughness": z(1)}
+            return (z(3), occ_info, {}) if inter_results else (z(3), None, occ_info)
+        needs_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or normals.requires_grad
+                                                   or feature_vectors.requires_grad)
+        if needs_graph or inter_results:
+            return self._composed(points, normals, view_dirs, feature_vectors, inter_results)
+        color, occ_prob, roughness, reflective = self._fused()(points, normals, view_dirs, feature_vectors)
+        return color, None, {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
+
+    def predict_materials(self, points, feature_vectors):
+        """fields.py:569-575: raw mat_mlp outputs (no albedo / roughness remapping, as in the reference)."""
+        mat = self.mat_mlp(feature_vectors)
+        return mat[..., 4:], mat[..., 3:4], mat[..., :3]

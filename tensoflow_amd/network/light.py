@@ -84,7 +84,8 @@ class _CubeSpecular(torch.autograd.Function):
 
 
 class _CubeLookupLinear(torch.autograd.Function):
-    """bilinear cube fetch without the exp (one mip level of EnvLight.__call__), gradient wrt the map only."""
+    """bilinear cube fetch without the exp (one mip level of EnvLight.__call__); gradient wrt the map and -- when the
+    directions carry a graph (shape stage: normals / reflective come from the SDF) -- wrt the direction."""
 
     @staticmethod
     def forward(ctx, tex, dirs):
@@ -94,6 +95,8 @@ class _CubeLookupLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         tex, dirs = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            return ops.cube_lookup_bwd_dirs(tex, dirs, g.contiguous(), apply_exp=False, want_base=ctx.needs_input_grad[0])
         return ops.cube_lookup_bwd(tex, dirs, g.contiguous(), apply_exp=False), None
 
 

@@ -1,0 +1,200 @@
+"""MaterialRenderer (reference: network/materialRenderer.py:98-830) on the HIP kernels -- the drop-in module of the material stage.
+
+Same constructor (`MaterialRenderer(cfg, training, nvs)`), sub-module names (`shader_network`, `sdf_network`, `deviation_net`)
+and call surface for everything on the hot path:
+
+    trace / trace_in_batch / trace_sdf_with_mesh / near_far_from_sphere / shade / compute_rgb_loss /
+    compute_diffuse_light_regularization / get_train_opt_params / ckpt_to_save / load_ckpt / init_sdf / nvs / predict_materials
+
+`cfg['mesh']` is the geometry the reference reads with open3d and hands to raytracing.RayTracer (:147-149): here a
+(vertices [V,3] float, triangles [F,3] int) pair or the path of an .npz holding `vertices` / `triangles` (mesh file parsing
+is the export side).  The dataset side (`_init_dataset`, `train_step`, `test_step`: image tables,
+ray shuffling) is outside the hot path: construct with nvs=True and feed surface points to `shade`.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops, surface
+from ..march import SdfField, near_far_from_sphere
+from ..trainer import material_param_groups
+from .fields import MCShadingNetwork, SingleVarianceNetwork, TensoSDF
+
+
+class MaterialRenderer(nn.Module):
+    default_cfg = {"train_ray_num": 2048, "test_ray_num": 8192, "rgb_loss": "charbonier", "mesh": None, "shader_cfg": {},
+                   "reg_mat": True, "reg_diffuse_light": True, "reg_diffuse_light_lambda": 0.1, "nerfDataType": False,
+                   "device": "cuda", "direct_sn0": 128, "direct_sn1": 9, "sec_sn0": 64, "sec_sn1": 6, "geo_model_path": "",
+                   "std_act": "exp", "inv_s_init": 0.3, "downsample_ratio": 1,
+                   "aabb": [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], "gridSize": [512, 512, 512]}
+
+    def __init__(self, cfg, training=True, nvs=False):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if training or not nvs:
+            raise NotImplementedError("the dataset side of MaterialRenderer (_init_dataset / train_step / test_step) is outside the hot "
+                                      "path: construct with training=False, nvs=True and pass surface points to shade()")
+        self.device = self.cfg["device"]
+        self._init_geometry()
+        # without a geometry checkpoint the reference has no aabb either; the cfg values let the module stand alone
+        self.aabb = torch.tensor(self.cfg["aabb"], dtype=torch.float32)
+        self.gridSize = torch.tensor(self.cfg["gridSize"])
+        self._set_extent()
+        self.sdf_network = None
+        geo = self.cfg["geo_model_path"]
+        if isinstance(geo, dict):
+            self.init_sdf(geo)
+        elif geo and os.path.exists(geo):
+            self.init_sdf(torch.load(geo, weights_only=False))
+        self._init_shader()
+
+    def _set_extent(self):
+        self.center = self.aabb.mean(0).float().view(1, 1, 3)
+        self.radius = (self.aabb[1] - self.center).mean().float()
+        self.unit_size = torch.mean((self.aabb[1] - self.aabb[0]) / (self.gridSize - 1), dim=-1)
+
+    def _init_geometry(self):
+        mesh = self.cfg["mesh"]
+        if isinstance(mesh, str):
+            if not mesh.endswith(".npz"):
+                raise NotImplementedError("mesh file parsing (open3d) is the export side of the path: pass (vertices, triangles) or an .npz")
+            z = np.load(mesh)
+            mesh = (z["vertices"], z["triangles"])
+        if mesh is None:
+            raise ValueError("cfg['mesh'] = (vertices [V,3], triangles [F,3]) is required")
+        v, f = mesh
+        self.mesh = (np.ascontiguousarray(np.asarray(v, np.float32)), np.ascontiguousarray(np.asarray(f, np.int32)))
+        self.ray_tracer = ops.Bvh(self.mesh[0], self.mesh[1], self.device)
+
+    def init_sdf(self, ckpt):
+        """materialRenderer.py:151-179: frozen TensoSDF + variance from a shape-stage checkpoint (ShapeRenderer.ckpt_to_save)."""
+        kw = ckpt["kwargs"]
+        self.aabb = torch.as_tensor(kw["aabb"], dtype=torch.float32).cpu()
+        self.gridSize = torch.tensor(kw["gridSize"])
+        self._set_extent()
+        self.sdf_network = TensoSDF(self.gridSize, self.aabb, device=self.device, init_n_levels=kw["max_levels"], sdf_n_comp=kw["sdf_n_comp"],
+                                    sdf_dim=kw["sdf_dim"], app_dim=kw["app_dim"], sdf_multires=kw.get("sdf_multires", 0))
+        self.deviation_net = SingleVarianceNetwork(self.cfg["inv_s_init"], self.cfg["std_act"]).to(self.device)
+        sd = ckpt["network_state_dict"]
+        self.sdf_network.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("sdf") and "gaussian" not in k})
+        self.deviation_net.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("deviation")})
+        for p in list(self.sdf_network.parameters()) + list(self.deviation_net.parameters()):
+            p.requires_grad = False
+        self.sdf_inter_fun = lambda x: self.sdf_network.sdf(x, None)
+
+    def _init_shader(self):
+        self.shader_network = MCShadingNetwork(self.cfg["shader_cfg"], self.mesh, self.aabb, float(self.unit_size))
+
+    # ------------------------------------------------------------------------------ bookkeeping
+    def get_train_opt_params(self, learning_rate_xyz, learning_rate_net, learning_rate_env):
+        return material_param_groups(self.shader_network, learning_rate_xyz, learning_rate_net, learning_rate_env)
+
+    def ckpt_to_save(self):
+        return {"network_state_dict": self.state_dict()}
+
+    def load_ckpt(self, ckpt):
+        self.load_state_dict(ckpt["network_state_dict"], strict=False)
+        self.shader_network._shader = None
+
+    # ------------------------------------------------------------------------------ geometry queries
+    def near_far_from_sphere(self, rays_o, rays_d):
+        return near_far_from_sphere(rays_o, rays_d, float(self.radius))
+
+    @torch.no_grad()
+    def trace(self, rays_o, rays_d):
+        """materialRenderer.py:253-263 -> inters [M,3], normals [M,3] (flipped, unit), depth [M,1], hit_mask [M,1] bool."""
+        inters, normals, depth, hit = self.ray_tracer.trace(rays_o.contiguous(), rays_d.contiguous())
+        return inters, normals, depth[:, None], hit[:, None]
+
+    def trace_in_batch(self, rays_o, rays_d, batch_size=512 ** 2, cpu=False):
+        outs = [self.trace(rays_o[i:i + batch_size], rays_d[i:i + batch_size]) for i in range(0, rays_o.shape[0], batch_size)]
+        cat = [torch.cat(c, 0) for c in zip(*outs)]
+        return tuple(c.cpu() for c in cat) if cpu else tuple(cat)
+
+    def _sdf_field(self):
+        net = self.sdf_network
+        if net is None:
+            raise RuntimeError("trace_sdf_with_mesh needs the shape-stage checkpoint (cfg['geo_model_path'])")
+        f = SdfField.__new__(SdfField)
+        f.planes, f.lines = [p.detach() for p in net.sdf_plane], [p.detach() for p in net.sdf_line]
+        f.W = [w.detach() for w in net._w()]
+        f.aabb, f.aabb_dev = self.aabb.cpu(), self.aabb.to(self.device)
+        f.grid_size = self.gridSize.float().cpu()
+        f.units = [float(u) for u in net.units]
+        f.n_levels, f.device, f.packed = net.n_levels, self.device, net._field()
+        return f
+
+    @torch.no_grad()
+    def trace_sdf_with_mesh(self, rays_o, rays_d, sn0=32, sn1=9):
+        """materialRenderer.py:316-343: mesh hit refined on the SDF (sn0 uniform + sn1 importance evaluations, FD normal)."""
+        return surface.trace_sdf_with_mesh(self.ray_tracer, self._sdf_field(), rays_o.contiguous(), rays_d.contiguous(),
+                                           float(self.deviation_net.inv_s()), float(self.unit_size), sn0=sn0, sn1=sn1)
+
+    def trace_sdf_in_batch(self, rays_o, rays_d, batch_size=10240 * 5, cpu=False):
+        outs = [self.trace_sdf_with_mesh(rays_o[i:i + batch_size], rays_d[i:i + batch_size]) for i in range(0, rays_o.shape[0], batch_size)]
+        cat = [torch.cat(c, 0) for c in zip(*outs)]
+        return tuple(c.cpu() for c in cat) if cpu else tuple(cat)
+
+    # ------------------------------------------------------------------------------ shading
+    def shade(self, pts, view_dirs, normals, human_poses=None, is_train=False, step=None):
+        """materialRenderer.py:518-521 -> outputs dict with 'rgb_pr'."""
+        rgb_pr, outputs = self.shader_network(pts, view_dirs, normals, human_poses, step, is_train)
+        outputs["rgb_pr"] = rgb_pr
+        return outputs
+
+    def compute_rgb_loss(self, rgb_pr, rgb_gt):
+        if self.cfg["rgb_loss"] == "l1":
+            return torch.sum(F.l1_loss(rgb_pr, rgb_gt, reduction="none"), -1)
+        if self.cfg["rgb_loss"] == "charbonier":
+            return torch.sqrt(torch.sum((rgb_gt - rgb_pr) ** 2, dim=-1) + 0.001)
+        raise NotImplementedError
+
+    def compute_diffuse_light_regularization(self, diffuse_lights):
+        return torch.sum(torch.abs(diffuse_lights - torch.mean(diffuse_lights, dim=-1, keepdim=True)), dim=-1) * self.cfg["reg_diffuse_light_lambda"]
+
+    @torch.no_grad()
+    def nvs(self, pose, K, h, w, chunk=65536):
+        """materialRenderer.py:641-752 (nerfDataType rays): primary rays -> BVH -> SDF refinement -> flow-sampled shading.
+        -> dict of [h,w,C] numpy arrays (color, normal, albedo, roughness, metallic).  The reference shades 512 rays per pass."""
+        dev = self.device
+        K = torch.from_numpy(np.asarray(K, np.float32)).to(dev)
+        pose = torch.from_numpy(np.asarray(pose, np.float32)).to(dev)
+        i, j = torch.meshgrid(torch.linspace(0, w - 1, w, device=dev), torch.linspace(0, h - 1, h, device=dev), indexing="ij")
+        i, j = i.t(), j.t()
+        dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)
+        rays_d = F.normalize(dirs @ pose[:3, :3].t(), dim=-1).contiguous()
+        rays_o = pose[:3, 3].expand(h * w, 3).contiguous()
+        rn = h * w
+        out = {"color": torch.ones(rn, 3, device=dev), "normal": torch.zeros(rn, 3, device=dev), "albedo": torch.zeros(rn, 3, device=dev),
+               "roughness": torch.zeros(rn, 1, device=dev), "metallic": torch.zeros(rn, 1, device=dev)}
+        out["normal"][:, 2] = 1.0
+        for s in range(0, rn, chunk):
+            o, d = rays_o[s:s + chunk], rays_d[s:s + chunk]
+            inters, nrm, depth, hit = self.trace_sdf_with_mesh(o, d) if self.sdf_network is not None else self.trace(o, d)
+            idx = torch.nonzero(hit[:, 0], as_tuple=False)[:, 0]
+            if idx.numel() == 0:
+                continue
+            sh = self.shade(inters[idx].contiguous(), (-d[idx]).contiguous(), nrm[idx].contiguous(), None, False)
+            out["color"][s + idx] = sh["rgb_pr"]
+            out["normal"][s + idx] = nrm[idx]
+            out["albedo"][s + idx] = sh["albedo"]
+            out["roughness"][s + idx] = torch.sqrt(sh["roughness"])      # predictions are squared roughness (:743)
+            out["metallic"][s + idx] = sh["metallic"]
+        return {k: v.reshape(h, w, -1).cpu().numpy() for k, v in out.items()}
+
+    @torch.no_grad()
+    def predict_materials(self, batch_size=8192):
+        """materialRenderer.py:770-782: per-vertex metallic / roughness (sqrt of the squared prediction) / albedo as numpy arrays."""
+        verts = torch.from_numpy(self.mesh[0]).to(self.device)
+        m_, r_, a_ = [], [], []
+        for vi in range(0, verts.shape[0], batch_size):
+            m, r, a = self.shader_network.predict_materials(verts[vi:vi + batch_size].contiguous())
+            m_.append(m.cpu().numpy()); r_.append(torch.sqrt(torch.clamp(r, min=1e-7)).cpu().numpy()); a_.append(a.cpu().numpy())
+        return {"metallic": np.concatenate(m_, 0), "roughness": np.concatenate(r_, 0), "albedo": np.concatenate(a_, 0)}
+
+    def forward(self, data):
+        raise NotImplementedError("MaterialRenderer.forward drives the dataset tables (train_step / test_step); call shade() with "
+                                  "surface points, or nvs(pose, K, h, w)")

@@ -1,0 +1,346 @@
+"""ShapeRenderer (reference: network/shapeRenderer.py:100-1310) on the HIP kernels -- the drop-in module of the shape stage.
+
+Same constructor (`ShapeRenderer(cfg, training)`), sub-module names (`sdf_network`, `deviation_network`, `color_network`),
+`state_dict` keys and call surface as the reference for everything on the hot path:
+
+    render_core / render / sample_ray / compute_sdf_alpha / compute_alpha / near_far_from_sphere / compute_ball_radii
+    updateAlphaMask / upsample_sdf_grid / get_train_opt_params / ckpt_to_save / load_ckpt / get_anneal_val / nvs
+
+Without autograd every field evaluation, the split-sum shading and the compositing scan are fused HIP launches
+(march.render_core).  With autograd (training) the same quantities come from the autograd ops of tensoflow_amd.autograd
+(SdfAlphaFn, CompositeFn) and the differentiable ShapeShadingNetwork, so `loss.backward()` reaches every parameter the
+reference trains.  The dataset side of the reference class (`_init_dataset`, `train_step`, `test_step`: image / pose tables,
+ray shuffling) is outside the hot path: construct with training=False and feed ray batches to `render`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import march, ops
+from ..autograd import CompositeFn, SdfAlphaFn
+from ..surface import _neus_weights
+from .fields import ShapeShadingNetwork, SingleVarianceNetwork, TensoSDF
+
+
+class AlphaGridMask(nn.Module):
+    """shapeRenderer.py:79-97: binary occupancy volume [D,H,W] over `aabb`; sample_alpha = trilinear fetch (align_corners)."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:]).float().to(device)
+        self._mask = march.AlphaMask(self.aabb.cpu(), self.alpha_volume[0, 0])
+
+    def sample_alpha(self, xyz_sampled):
+        """-> [N] float; only `> 0` is ever read (shapeRenderer.py:1120, :301), which tf_alpha_mask_sample evaluates bit-exactly."""
+        return self._mask.alive(xyz_sampled.reshape(-1, 3).contiguous()).float()
+
+
+class ShapeRenderer(nn.Module):
+    default_cfg = {
+        "std_act": "exp", "inv_s_init": 0.3, "freeze_inv_s_step": None, "shader_config": {},
+        "n_samples": 64, "n_importance": 64, "up_sample_steps": 4, "perturb": 1.0, "anneal_end": 50000,
+        "train_ray_num": 1024, "test_ray_num": 2048, "clip_sample_variance": True,
+        "apply_occ_loss": True, "apply_tv_loss": True, "apply_sparse_loss": True, "apply_hessian_loss": True,
+        "apply_gaussian_loss": False, "occ_loss_step": 20000, "gaussianLoss_step": 20000,
+        "device": "cuda", "gridSize": [512, 512, 512], "aabb": [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], "step_ratio": 0.5,
+        "alphaMask_thres": 0.0001, "marched_weights_thres": 0.0001, "sdf_n_comp": 16, "app_n_comp": 36, "sdf_dim": 128,
+        "app_dim": 128, "sdf_multires": 0, "max_levels": 1, "has_radiance_field": False, "radiance_field_step": 0,
+        "predict_BG": True, "isBGWhite": True, "nerfDataType": False, "mul_length": 10, "use_occ_grid": False,
+        "occ_grid_reso": 128, "blend_ratio": 0,
+    }
+
+    def __init__(self, cfg, training=True):
+        super().__init__()
+        self.cfg = {**self.default_cfg, **cfg}
+        if training:
+            raise NotImplementedError("the dataset side of ShapeRenderer (_init_dataset / train_step) is outside the hot path: "
+                                      "construct with training=False and pass ray batches to render()")
+        if self.cfg["predict_BG"]:
+            raise NotImplementedError("predict_BG (NeRF++ background) raises in the reference's render_core as well (:1109); "
+                                      "set predict_BG=False as configs/shape/* do")
+        if self.cfg["use_occ_grid"]:
+            raise NotImplementedError("nerfacc.OccGridEstimator is third-party and unpinned; use march.march_uniform for fixed-step marching")
+        self.device = self.cfg["device"]
+        aabb = self.cfg["aabb"]
+        self.aabb = torch.tensor(aabb.cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb, dtype=torch.float32, device=self.device)
+        self.center = self.aabb.mean(0).float().view(1, 1, 3)
+        self.radius = (self.aabb[1] - self.center).mean().float()
+        self.alphaMask = None
+        self.occ_grid = None
+        self.step_ratio = self.cfg["step_ratio"]
+        self.alphaMask_thres = self.cfg["alphaMask_thres"]
+        self.marched_weights_thres = self.cfg["marched_weights_thres"]
+        self.sdf_n_comp, self.app_n_comp = self.cfg["sdf_n_comp"], self.cfg["app_n_comp"]
+        self.sdf_dim, self.app_dim = self.cfg["sdf_dim"], self.cfg["app_dim"]
+        self.update_stepSize(torch.tensor(self.cfg["gridSize"]), self.cfg["max_levels"])
+        self.sdf_network = TensoSDF(self.gridSize.cpu(), self.aabb.cpu(), device=self.device, init_n_levels=self.max_levels,
+                                    sdf_n_comp=self.sdf_n_comp, sdf_dim=self.sdf_dim, app_dim=self.app_dim,
+                                    sdf_multires=self.cfg["sdf_multires"])
+        self.deviation_network = SingleVarianceNetwork(self.cfg["inv_s_init"], self.cfg["std_act"]).to(self.device)
+        self.cfg["shader_config"] = {**self.cfg["shader_config"], "occ_loss_step": self.cfg["occ_loss_step"],
+                                     "has_radiance_field": self.cfg["has_radiance_field"],
+                                     "radiance_field_step": self.cfg["radiance_field_step"], "app_feats_dim": self.cfg["app_dim"]}
+        self.color_network = ShapeShadingNetwork(self.cfg["shader_config"], device=self.device)
+        self.sdf_inter_fun = lambda x: self.sdf_network.sdf(x, None)
+
+    # ------------------------------------------------------------------------------ bookkeeping
+    def update_stepSize(self, gridSize, max_levels):
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.tensor(torch.as_tensor(gridSize).cpu().tolist(), dtype=torch.int32).to(self.device)
+        self.max_levels = max_levels
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.base_radii = self.aabbSize[0] / 2.0 / self.gridSize[0]
+        self.nSamples = self.cfg["n_samples"] + self.cfg["n_importance"]
+
+    def get_kwargs(self):
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "sdf_n_comp": self.sdf_n_comp,
+                "appearance_n_comp": self.app_n_comp, "sdf_dim": self.sdf_dim, "app_dim": self.app_dim,
+                "sdf_multires": self.cfg["sdf_multires"], "alphaMask_thres": self.alphaMask_thres,
+                "marched_weights_thres": self.marched_weights_thres, "step_ratio": self.step_ratio, "max_levels": self.max_levels}
+
+    def ckpt_to_save(self):
+        """shapeRenderer.py:343-353: kwargs + state_dict (+ bit-packed alpha mask)."""
+        ckpt = {"kwargs": self.get_kwargs(), "network_state_dict": self.state_dict()}
+        if self.alphaMask is not None:
+            vol = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({"alphaMask.shape": vol.shape, "alphaMask.mask": np.packbits(vol.reshape(-1)),
+                         "alphaMask.aabb": self.alphaMask.aabb.cpu()})
+        return ckpt
+
+    def load_ckpt(self, ckpt):
+        """shapeRenderer.py:355-362.  Reference checkpoints also carry the Gaussian-blur buffers of a regulariser that is not
+        built here (`sdf_network.gaussian*`): those keys are skipped, every other key must match."""
+        if "alphaMask.aabb" in ckpt:
+            length = int(np.prod(ckpt["alphaMask.shape"]))
+            vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
+            self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"], vol.float())
+        sd = {k: v for k, v in ckpt["network_state_dict"].items() if "gaussian" not in k}
+        self.load_state_dict(sd)
+
+    def upsample_sdf_grid(self, res_target):
+        new_res, max_levels = self.sdf_network.upsample_volume_grid(torch.as_tensor(res_target))
+        self.update_stepSize(new_res, max_levels)
+
+    def get_train_opt_params(self, learning_rate_xyz, learning_rate_net, learning_rate_env):
+        grad_vars = self.sdf_network.get_optparam_groups(learning_rate_xyz, learning_rate_net)
+        grad_vars += [{"params": self.deviation_network.parameters(), "lr": learning_rate_net}]
+        grad_vars += self.color_network.get_optparam_groups(learning_rate_net, learning_rate_env)
+        return grad_vars
+
+    def get_anneal_val(self, step):
+        return 1.0 if self.cfg["anneal_end"] < 0 else float(np.min([1.0, step / self.cfg["anneal_end"]]))
+
+    # ------------------------------------------------------------------------------ field views
+    def _field(self):
+        """Eval-side view of sdf_network for the march composition (shares the packed pyramid of the module)."""
+        net = self.sdf_network
+        f = march.SdfField.__new__(march.SdfField)
+        f.planes, f.lines = [p.detach() for p in net.sdf_plane], [p.detach() for p in net.sdf_line]
+        f.W = [w.detach() for w in net._w()]
+        f.aabb = self.aabb.cpu()
+        f.aabb_dev = self.aabb
+        f.grid_size = self.gridSize.float().cpu()
+        f.units = [float(u) for u in self.units]
+        f.n_levels = self.max_levels
+        f.device = self.device
+        f.packed = net._field()
+        return f
+
+    def _inv_s(self):
+        return self.deviation_network.inv_s().clip(1e-6, 1e6)
+
+    def near_far_from_sphere(self, rays_o, dirs):
+        return march.near_far_from_sphere(rays_o, dirs, float(self.radius))
+
+    @staticmethod
+    def compute_ball_radii(distance, radiis, cos):
+        return march.ball_radii(distance, radiis, cos)
+
+    # ------------------------------------------------------------------------------ occupancy
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(128, 128, 128)):
+        """shapeRenderer.py:257-283 -> new_aabb [2,3]; the lattice evaluation runs in tf_sdf_forward."""
+        prev = None if self.alphaMask is None else self.alphaMask._mask
+        mask, new_aabb = march.update_alpha_mask(self._field(), float(self._inv_s()), grid=tuple(gridSize), thres=self.alphaMask_thres,
+                                                 mul_length=self.cfg["mul_length"], prev=prev)
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, mask.volume.float())
+        return new_aabb
+
+    @torch.no_grad()
+    def compute_alpha(self, points):
+        """shapeRenderer.py:972-993: NeuS opacity of one march step at `points`."""
+        if points.shape[0] == 0:
+            return torch.zeros(0, device=self.device)
+        sdf = self.sdf_network.sdf(points)[:, 0]
+        inv_s = self._inv_s()
+        pc = torch.sigmoid((sdf + self.stepSize * 0.5) * inv_s)
+        nc = torch.sigmoid((sdf - self.stepSize * 0.5) * inv_s)
+        return ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+
+    # ------------------------------------------------------------------------------ sampling + rendering
+    @torch.no_grad()
+    def sample_ray(self, rays_o, dirs, near, far, perturb, radiis=None, rays_cos=None):
+        """shapeRenderer.py:871-932 (deterministic form: perturb = 0, clip_sample_variance = False) -> packed
+        t_starts, t_ends, ray_indices (int64, bit-exact)."""
+        if perturb > 0:
+            raise NotImplementedError("stratified jitter of sample_ray is not built (pass perturb_overwrite=0)")
+        return march.sample_ray(self._field(), rays_o, dirs, near, far, radiis, rays_cos, float(self.base_radii),
+                                n_samples=self.cfg["n_samples"], n_importance=self.cfg["n_importance"],
+                                up_steps=self.cfg["up_sample_steps"])
+
+    def compute_sdf_alpha(self, points, level, dists, dirs, cos_anneal_ratio, step, is_train):
+        """shapeRenderer.py:995-1025 -> alpha, gradients, feature_vector, inv_s [N], sdf, hessian (None when not training)."""
+        N = points.shape[0]
+        net = self.sdf_network
+        if N == 0:
+            z = lambda *s: torch.zeros(*s, device=self.device)
+            return z(0), z(0, 3), z(0, net.app_dim), z(0), z(0), z(0, 3)
+        inv_s = self._inv_s()
+        if self.cfg["freeze_inv_s_step"] is not None and step is not None and step < self.cfg["freeze_inv_s_step"]:
+            inv_s = inv_s.detach()
+        lv = None if level is None else level.reshape(-1).contiguous()
+        units = [float(u) for u in self.units]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in list(net.parameters()) + [self.deviation_network.variance]):
+            alpha, grad, feat, sdf, nh = SdfAlphaFn.apply(points.contiguous(), lv, dists.contiguous(), dirs.contiguous(), inv_s,
+                                                          float(cos_anneal_ratio), self.aabb.cpu(), units, self.max_levels,
+                                                          *net.sdf_plane, *net.sdf_line, *net._w())
+        else:
+            alpha, grad, feat, sdf, nh = ops.sdf_alpha(net._field(), *[w.detach() for w in net._w()], points, lv, dists, dirs,
+                                                       self.aabb.cpu(), units, float(inv_s), float(cos_anneal_ratio), want_hess=is_train)
+        return alpha, grad, feat, inv_s.expand(N), sdf, (nh if is_train else None)
+
+    def render(self, ray_batch, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True, step=None):
+        """shapeRenderer.py:934-963."""
+        perturb = self.cfg["perturb"] if perturb_overwrite < 0 else perturb_overwrite
+        if not is_train:
+            perturb = 0
+        o, d, dirs, radiis, cos = ray_batch["rays_o"], ray_batch["rays_d"], ray_batch["dirs"], ray_batch["radiis"], ray_batch["rays_cos"]
+        t0, t1, ridx = self.sample_ray(o, dirs, near, far, perturb, radiis=radiis, rays_cos=cos)
+        return self.render_core(o, d, dirs, radiis, cos, t0, t1, ridx, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
+                                is_train=is_train)
+
+    def render_core(self, rays_o, rays_d, viewdirs, radiis, rays_cos, t_starts, t_ends, ray_indices, human_poses=None,
+                    cos_anneal_ratio=0.0, step=None, is_train=True):
+        """shapeRenderer.py:1105-1277 (white background).  Output keys as the reference's: ray_rgb, gradient_error, acc, sample_num,
+        normal, std, loss_sparse, loss_hessian (+ the validation keys when is_train is False)."""
+        rn = rays_o.shape[0]
+        mid = (t_starts + t_ends) * 0.5
+        dists = t_ends - t_starts
+        if self.alphaMask is not None:
+            pts = rays_o[ray_indices] + viewdirs[ray_indices] * mid[:, None]
+            keep = self.alphaMask.sample_alpha(pts) > 0
+            ray_indices, mid, dists = ray_indices[keep], mid[keep], dists[keep]
+        N = ray_indices.shape[0]
+        viewdir = viewdirs[ray_indices]
+        points = rays_o[ray_indices] + viewdir * mid[:, None]
+        levels = torch.log2(self.compute_ball_radii(mid[:, None], radiis[ray_indices], rays_cos[ray_indices]) / self.base_radii)
+        alpha, gradients, feat, inv_s, sdf, hessian = self.compute_sdf_alpha(points, levels, dists, viewdir, cos_anneal_ratio, step, is_train)
+        normals = F.normalize(gradients, dim=-1)
+        color, _, occ_info = self.color_network(points, normals, -viewdir, feat, None, step=step)
+        gradient_error = (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2
+        zero = torch.zeros(1, device=rays_o.device)
+        vals = torch.cat([color, gradients], -1).contiguous()
+        if torch.is_grad_enabled() and (alpha.requires_grad or vals.requires_grad):
+            weights, acc, out = CompositeFn.apply(alpha, vals, ray_indices, rn)
+        else:
+            weights, acc, out = ops.composite(alpha, ray_indices, vals, rn)
+        acc = acc[:, None]
+        rgb = out[:, :3]
+        if self.cfg["isBGWhite"]:
+            rgb = rgb + (1 - acc)
+        normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * torch.tensor([0.0, 0.0, 1.0], device=rays_o.device), dim=-1)
+        outputs = {"ray_rgb": rgb, "gradient_error": gradient_error, "acc": acc, "sample_num": N / max(rn, 1), "normal": normal,
+                   "std": torch.mean(1 / inv_s) if N > 0 else zero}
+        if self.cfg["apply_sparse_loss"]:
+            outputs["loss_sparse"] = torch.exp(-20.0 * sdf.abs()).mean() if N > 0 else zero
+        if self.cfg["apply_hessian_loss"]:
+            outputs["loss_hessian"] = hessian.abs().mean() if (hessian is not None and N > 0) else zero
+        if step is not None and step < 1000:
+            outputs["sdf_pts"], outputs["sdf_vals"] = (points, sdf) if N > 0 else (zero, zero)
+        if not is_train:
+            outputs.update(self._validation_outputs(rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step))
+        return outputs
+
+    @torch.no_grad()
+    def _validation_outputs(self, rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step):
+        """Eval branch of render_core (shapeRenderer.py:1239-1275): expected depth -> surface point -> materials / lights there,
+        traced occlusion probability along the reflected direction (get_intersection, utils/network_utils.py:172-202)."""
+        rn = rays_o.shape[0]
+        t_depth = torch.zeros(rn, device=rays_o.device).index_add_(0, ray_indices, weights.detach() * mid)[:, None]
+        points = t_depth * viewdirs + rays_o
+        level = torch.log2(self.compute_ball_radii(t_depth, radiis, rays_cos) / self.base_radii)
+        gradients, _ = self.sdf_network.gradient(points.contiguous(), level.reshape(-1).contiguous(), training=False)
+        normals = F.normalize(gradients, dim=-1)
+        inner = ~((self.aabb[0] > points) | (points > self.aabb[1])).any(-1)[:, None]
+        out = {"normal_vis": ((normal + 1.0) * 0.5) * acc + (1.0 - acc), "depth": t_depth * rays_cos}
+        if not self.cfg["nerfDataType"]:
+            out["normal_vis"] = ((normals + 1.0) * 0.5) * inner
+        feat = self.sdf_network(points.contiguous(), level.reshape(-1).contiguous())[..., 1:]
+        _, occ_info, inter = self.color_network(points, normals, -viewdirs, feat.contiguous(), None, inter_results=True, step=step)
+        # traced occlusion along the reflected ray: 128 uniform + 9 importance field evaluations per pixel
+        refl = occ_info["reflective"]
+        occ_gt = torch.zeros(rn, 1, device=rays_o.device)
+        inside = points.norm(dim=-1) < 0.999
+        if bool(inside.any()):
+            p, d = points[inside], refl[inside]
+            dtx, xtx = (p * d).sum(-1, keepdim=True), (p ** 2).sum(-1, keepdim=True)
+            max_dist = -dtx + torch.sqrt((dtx ** 2 - xtx + 1).clamp(min=0) + 1e-6)
+            field, inv_s = self._field(), float(self._inv_s())
+            z = max_dist * torch.linspace(0, 1, 128, device=p.device)[None]
+            w = _neus_weights(field, inv_s, z, p, d)
+            z_new = march._sample_pdf_det(z, w, 9)
+            w = _neus_weights(field, inv_s, z_new, p, d)
+            occ_gt[inside] = w.sum(-1, keepdim=True)
+        out["occ_prob_gt"] = occ_gt
+        out.update({k: v * inner for k, v in inter.items()})
+        return out
+
+    # ------------------------------------------------------------------------------ novel view
+    @torch.no_grad()
+    def nvs(self, pose, K, h, w):
+        """shapeRenderer.py:569-668 (nerfDataType ray construction) -> dict of [h,w,C] numpy arrays.  The reference renders 2048
+        rays per pass (launch-bound); here `test_ray_num` rays per pass, default raised by the caller as HBM allows."""
+        if not self.cfg["nerfDataType"]:
+            raise NotImplementedError("the reference's non-NeRF ray construction raises as well (:577)")
+        dev = self.device
+        K = torch.from_numpy(np.asarray(K, np.float32)).to(dev)
+        pose = torch.from_numpy(np.asarray(pose, np.float32)).to(dev)
+        i, j = torch.meshgrid(torch.linspace(0, w - 1, w, device=dev), torch.linspace(0, h - 1, h, device=dev), indexing="ij")
+        i, j = i.t(), j.t()
+        rays_d = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+        dx = (rays_d[:, :-1, :] - rays_d[:, 1:, :]).norm(dim=-1, keepdim=True)
+        dx = torch.cat([dx, dx[:, -2:-1, :]], 1)
+        dy = (rays_d[:-1, :, :] - rays_d[1:, :, :]).norm(dim=-1, keepdim=True)
+        dy = torch.cat([dy, dy[-2:-1, :, :]], 0)
+        radiis = torch.sqrt(dx * dy / torch.pi).reshape(-1, 1)
+        rays_d = rays_d.reshape(-1, 3)
+        rays_cos = 1 / rays_d.norm(dim=-1, keepdim=True)
+        rays_o = pose[:3, -1].expand(h * w, 3)
+        rays_d = (rays_d[:, None, :] * pose[:3, :3]).sum(-1)
+        dirs = F.normalize(rays_d, dim=-1)
+        keys = {"color": "ray_rgb", "albedo": "albedo", "roughness": "roughness", "normal": "normal", "normal_vis": "normal_vis",
+                "occ_predict": "occ_prob", "occ_trace": "occ_prob_gt", "diff_color": "diffuse_color", "spec_color": "specular_color",
+                "diff_light": "diffuse_light", "spec_light": "specular_light", "indirect_light": "indirect_light"}
+        output = {k: [] for k in keys}
+        trn = self.cfg["test_ray_num"]
+        for ri in range(0, h * w, trn):
+            sl = slice(ri, ri + trn)
+            batch = {"rays_o": rays_o[sl].contiguous(), "rays_d": rays_d[sl].contiguous(), "dirs": dirs[sl].contiguous(),
+                     "radiis": radiis[sl].contiguous(), "rays_cos": rays_cos[sl].contiguous()}
+            near, far = self.near_far_from_sphere(batch["rays_o"], batch["rays_d"])
+            cur = self.render(batch, near, far, None, is_train=False, step=300000)
+            for k, src in keys.items():
+                output[k].append(cur[src].detach().cpu().numpy())
+        for k in output:
+            val = np.concatenate(output[k], 0)
+            output[k] = np.reshape(val, [h, w, val.shape[-1]])
+        return output
+
+    def forward(self, data):
+        raise NotImplementedError("ShapeRenderer.forward drives the dataset tables (train_step / test_step); call render() with a "
+                                  "ray batch, or nvs(pose, K, h, w)")

@@ -344,6 +344,17 @@ def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
     return g_base
 
 
+def cube_lookup_bwd_dirs(base, dirs, g_out, apply_exp=False, want_base=True):
+    """-> (g_base [6,R,R,3] or None, g_dirs [m,3]): gradient of the bilinear cube fetch wrt the map and wrt the direction."""
+    lib = L.load()
+    base, dirs, g_out = _f(base), _f(dirs.reshape(-1, 3)), _f(g_out.reshape(-1, 3))
+    g_base = torch.zeros_like(base) if want_base else None
+    g_dirs = torch.empty_like(dirs)
+    L.check(lib.tf_cube_lookup_bwd_dirs(_p(base), base.shape[1], _p(dirs), dirs.shape[0], int(apply_exp), _p(g_out), _p(g_base),
+                                        _p(g_dirs), _stream()), "tf_cube_lookup_bwd_dirs")
+    return g_base, g_dirs
+
+
 # ------------------------------------------------------------------------------ march samplers
 def alpha_mask_sample(volume_u8, aabb, pts):
     """AlphaGridMask.sample_alpha(pts) > 0 -> bool [n]; volume_u8 [D,H,W] in {0,1}."""
