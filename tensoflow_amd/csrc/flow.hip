@@ -176,10 +176,13 @@ __device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.01f * x); }
 
 // net eval for one 32-row tile: y_keep / P row of the row on this lane's MFMA column (lane & 31) -> o: the 21 (+pad)
 // outputs of the tile in accumulator layout (lane half h holds units rho(j, h) of its column's row)
-template <bool H3>
+// MODE: 0 = exact fp32 MFMA, 3 = f16x3, 1 = plain f16 operands (TF_PREC_F16; same fragment image as f16x3, lo halves unused)
+template <int MODE>
 __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS*/, const float* __restrict__ Prow,
                                              float y_keep, int lane, f32x16 (&o)[1]) {
   const int h = lane >> 5;
+  constexpr bool H3 = MODE != 0;
+  constexpr int TERMS = MODE == 1 ? 1 : 3;
   constexpr int B2 = H3 ? hB2 : kB2, B3 = H3 ? hB3 : kB3, B4 = H3 ? hB4 : kB4;
   const tf_h8* nh = reinterpret_cast<const tf_h8*>(net) + lane;
   // layer-1 sample part: embed3(y) (7 values, Reshift 2x-1), k = rho(j,h), j = 0..3
@@ -201,7 +204,7 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[t][j] = Prow[32 * t + tf_rho(j, h)];
-  if (H3) tf_layer_h3<1, 2, 1>(nh + hL1 / 4, in1, a);
+  if (H3) tf_layer_h3<1, 2, 1, TERMS>(nh + hL1 / 4, in1, a);
   else tf_layer<4, 2, 1>(net + kL1 + lane, in1, a);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -210,7 +213,7 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
       a[t][j] = leaky(a[t][j]);
       b[t][j] = net[B2 + (t * 16 + j) * 2 + h];
     }
-  if (H3) tf_layer_h3<4, 2, 2>(nh + hL2 / 4, a, b);
+  if (H3) tf_layer_h3<4, 2, 2, TERMS>(nh + hL2 / 4, a, b);
   else tf_layer<32, 2, 2>(net + kL2 + lane, a, b);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -219,7 +222,7 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
       b[t][j] = leaky(b[t][j]);
       a[t][j] = net[B3 + (t * 16 + j) * 2 + h];
     }
-  if (H3) tf_layer_h3<4, 2, 2>(nh + hL3 / 4, b, a);
+  if (H3) tf_layer_h3<4, 2, 2, TERMS>(nh + hL3 / 4, b, a);
   else tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -227,7 +230,7 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
     for (int j = 0; j < 16; ++j) a[t][j] = leaky(a[t][j]);
 #pragma unroll
   for (int j = 0; j < 16; ++j) o[0][j] = net[B4 + j * 2 + h];
-  if (H3) tf_layer_h3<4, 1, 2>(nh + hL4 / 4, a, o);
+  if (H3) tf_layer_h3<4, 1, 2, TERMS>(nh + hL4 / 4, a, o);
   else tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
 }
 
@@ -247,7 +250,7 @@ __device__ __forceinline__ void gather_outputs(const f32x16 (&oA)[1], const f32x
   }
 }
 
-template <bool SAMPLE, bool H3>
+template <bool SAMPLE, int MODE>
 __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
                                                    const float* __restrict__ P /*[2][pn][64]*/,
                                                    const float* __restrict__ latent, const float* __restrict__ jitter,
@@ -255,6 +258,7 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
                                                    long long m, int sn, long long pn, float* __restrict__ out_xy,
                                                    float* __restrict__ out_lj, int* __restrict__ bins) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool H3 = MODE != 0;
   constexpr int NF = H3 ? hNetFloats : kNetFloats;
   for (int i = threadIdx.x; i < 2 * NF; i += blockDim.x) lds[i] = netfrag[i];
   __syncthreads();
@@ -296,8 +300,8 @@ __global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ net
     // one coupling block for both tiles: `keep` is the conditioning coordinate of this lane's own row
     auto run_block = [&](const float* net, long long pbase, float keep) {
       const float kA = __shfl(keep, col), kB = __shfl(keep, 32 + col);
-      coupling_net<H3>(net, P + (pbase + ptA) * 64, kA, lane, oA);
-      coupling_net<H3>(net, P + (pbase + ptB) * 64, kB, lane, oB);
+      coupling_net<MODE>(net, P + (pbase + ptA) * 64, kA, lane, oA);
+      coupling_net<MODE>(net, P + (pbase + ptB) * 64, kB, lane, oB);
       gather_outputs(oA, oB, h, wv);
     };
     if (SAMPLE) {
@@ -381,7 +385,8 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
                        hipStream_t stream, const char* who) {
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16, TF_EINVAL,
+             "%s: unknown precision %d", who, precision);
   TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
   if (m == 0) return TF_OK;
   TF_REQUIRE(nets && cond && out_xy && out_lj && workspace, TF_EINVAL, "%s: null pointer", who);
@@ -397,7 +402,7 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   }
   float* netfrag = workspace;
   float* P = workspace + kWsNet;
-  const bool h3 = precision == TF_PREC_F16X3;
+  const bool h3 = precision != TF_PREC_F32;      // TF_PREC_F16 runs on the f16x3 fragment image (hi halves only)
   if (!packed)
     if (int rc = h3 ? pack_nets_h3(nets, netfrag, stream) : pack_nets(nets, netfrag, stream)) return rc;
   flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
@@ -405,10 +410,12 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   const size_t lds = (size_t)kWsNet * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)flow_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)flow_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)flow_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)flow_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)flow_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   TF_REQUIRE(pn < (1LL << 31), TF_ESHAPE, "%s: pn must be < 2^31", who);
@@ -416,11 +423,14 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   const int waves_per_block = 8;
   long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles
-  if (h3)
-    flow_kernel<SAMPLE, true><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+  if (precision == TF_PREC_F16)
+    flow_kernel<SAMPLE, 1><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+        netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
+  else if (h3)
+    flow_kernel<SAMPLE, 3><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
         netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
   else
-    flow_kernel<SAMPLE, false><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
+    flow_kernel<SAMPLE, 0><<<(unsigned)blocks, 64 * waves_per_block, lds, stream>>>(
         netfrag, P, latent, jitter, x, (const long long*)rays_id, m, sn, pn, out_xy, out_lj, bins);
   TF_LAUNCH_CHECK(who);
   return TF_OK;

@@ -58,7 +58,7 @@ __device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
 // `bias`: this lane half's 256 biases in accumulator order, in LDS (all 32 lanes of a half read the same 16 bytes: broadcast).
 // Fetched from the global workspace the 128 single-dword loads per layer cost ~10 % of the kernel: their issue slots, and
 // the counted vmcnt of the weight ring has to wait for them.
-template <int K16, int TIN>
+template <int K16, int TIN, int TERMS>
 __device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
 #pragma unroll
@@ -68,7 +68,7 @@ __device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag&
       const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
       out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
     }
-  tf_layer_h3s<K16, 8, TIN, 0>(S, FA, FB, in, out);
+  tf_layer_h3s<K16, 8, TIN, 0, TERMS>(S, FA, FB, in, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -93,13 +93,16 @@ __device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, co
 // Dense mode (idx == nullptr): row r reads pts/view/nrm[r] and writes out[r].
 // Indexed mode: row r stands for ray i = idx[r], r < *count_dev (device-side count: no host sync between the BVH
 // trace and this kernel); view = -view[i] (the ray direction is passed), out[i] = light * (depth[i] > near_eps).
-template <bool H3>
+// MODE: 0 = exact fp32 MFMA, 3 = f16x3, 1 = plain f16 operands (TF_PREC_F16: the same slab stream, hi halves only)
+template <int MODE>
 __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts,
                                                           const float* __restrict__ view, const float* __restrict__ nrm,
                                                           long long m_arg, const long long* __restrict__ idx,
                                                           const long long* __restrict__ count_dev,
                                                           const float* __restrict__ depth, float near_eps, float exp_max,
                                                           float* __restrict__ out) {
+  constexpr bool H3 = MODE != 0;
+  constexpr int TERMS = MODE == 1 ? 1 : 3;
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   if (m <= 0) return;
@@ -198,12 +201,12 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
           asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
         }
-      if (H3) hidden_layer_h3<8, 4>(S, FA, FB, lbias + h * 256, h, in1, a);
+      if (H3) hidden_layer_h3<8, 4, TERMS>(S, FA, FB, lbias + h * 256, h, in1, a);
       else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
     if (H3) {
-      hidden_layer_h3<16, 8>(S, FA, FB, lbias + 512 + h * 256, h, a, b);
-      hidden_layer_h3<16, 8>(S, FA, FB, lbias + 1024 + h * 256, h, b, a);
+      hidden_layer_h3<16, 8, TERMS>(S, FA, FB, lbias + 512 + h * 256, h, a, b);
+      hidden_layer_h3<16, 8, TERMS>(S, FA, FB, lbias + 1024 + h * 256, h, b, a);
     } else {
       hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
       hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
-    if (H3) tf_layer_h3s<16, 1, 8, 0>(S, FA, FB, a, o);
+    if (H3) tf_layer_h3s<16, 1, 8, 0, TERMS>(S, FA, FB, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
     if (valid && h == 0) {
       const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;
@@ -229,7 +232,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: unknown precision %d", who, precision);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16, TF_EINVAL,
+             "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
@@ -261,11 +265,14 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   long long blocks = (m + 127) / 128;
   if (blocks > 1024) blocks = 1024;
   if (precision == TF_PREC_F32)
-    inner_light_kernel<false><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
-                                                                   (const long long*)count_dev, depth, near_eps, exp_max, out);
+    inner_light_kernel<0><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
+                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
+  else if (precision == TF_PREC_F16)
+    inner_light_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
+                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
   else
-    inner_light_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
-                                                                  (const long long*)count_dev, depth, near_eps, exp_max, out);
+    inner_light_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
+                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }

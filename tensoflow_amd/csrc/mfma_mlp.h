@@ -261,6 +261,22 @@ __device__ __forceinline__ void tf_split8(const float (&x)[8], tf_h8& hi, tf_h8&
   lo = __builtin_bit_cast(tf_h8, l);
 }
 
+// hi part only (TF_PREC_F16: plain f16 operands, one MFMA per product term)
+__device__ __forceinline__ void tf_cvt8(const float (&x)[8], tf_h8& hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 h;
+  unsigned h0, h1, h2, h3;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_cvt_pk_f16_f32 %2, %8, %9\n\t"
+      "v_cvt_pk_f16_f32 %3, %10, %11\n\t"
+      "s_nop 1"
+      : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  h[0] = h0; h[1] = h1; h[2] = h2; h[3] = h3;
+  hi = __builtin_bit_cast(tf_h8, h);
+}
+
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_h3_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                                int kin, int tout_tiles, int ksteps16,
                                                                _Float16* __restrict__ dst) {
@@ -406,7 +422,8 @@ __device__ __forceinline__ void tf_stream_end() {
   __builtin_amdgcn_s_barrier();
 }
 
-template <int TOUT, int TIN, int SL16>
+// TERMS = 3: f16x3 (fp32-accurate).  TERMS = 1: plain f16 operands (TF_PREC_F16) -- the lo fragments are neither read nor used.
+template <int TOUT, int TIN, int SL16, int TERMS = 3>
 __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFrag& cur, TfFrag& nxt, const f32x16 (&in)[TIN],
                                             f32x16 (&out)[TOUT]) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -421,7 +438,8 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
     float x8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
-    tf_split8(x8, b_hi[sl], b_lo[sl]);
+    if (TERMS == 3) tf_split8(x8, b_hi[sl], b_lo[sl]);
+    else tf_cvt8(x8, b_hi[sl]);
   }
   const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(S.lds + S.slot_rd * 4096) + S.lane;
   float* dbuf = S.lds + S.slot_req * 4096;
@@ -432,12 +450,17 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
     const int sl = c / TOUT, t = c % TOUT;
     if (c >= 1 && c <= 4) {
 #pragma unroll
-      for (int q = 2 * (c - 1); q < 2 * c; ++q) { nxt.hi[q] = nbuf[q * 128]; nxt.lo[q] = nbuf[q * 128 + 64]; }
+      for (int q = 2 * (c - 1); q < 2 * c; ++q) {
+        nxt.hi[q] = nbuf[q * 128];
+        if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
+      }
     }
     if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
     out[t] = tf_mfma_h(cur.hi[c], b_hi[sl], out[t]);
-    out[t] = tf_mfma_h(cur.hi[c], b_lo[sl], out[t]);
-    out[t] = tf_mfma_h(cur.lo[c], b_hi[sl], out[t]);
+    if (TERMS == 3) {
+      out[t] = tf_mfma_h(cur.hi[c], b_lo[sl], out[t]);
+      out[t] = tf_mfma_h(cur.lo[c], b_hi[sl], out[t]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   tf_stream_advance(S);
@@ -446,7 +469,7 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
 
 // One dense layer on the stream: K16 k-steps of TOUT unit tiles (G = K16 * TOUT / 8 slabs); P0 = parity of its first slab
 // (which of FA / FB already holds that slab's fragments).  Returns nothing; the caller continues with parity (P0 + G) & 1.
-template <int K16, int TOUT, int TIN, int P0>
+template <int K16, int TOUT, int TIN, int P0, int TERMS = 3>
 __device__ __forceinline__ void tf_layer_h3s(TfStream& S, TfFrag& FA, TfFrag& FB, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
   static_assert(8 % TOUT == 0, "a 16 KB slab holds 8 (k-step, tile) fragment pairs");
   constexpr int SL16 = 8 / TOUT;
@@ -454,13 +477,13 @@ __device__ __forceinline__ void tf_layer_h3s(TfStream& S, TfFrag& FA, TfFrag& FB
   constexpr int G = K16 / SL16;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    if (((P0 + g) & 1) == 0) tf_h3s_step<TOUT, TIN, SL16>(S, g * SL16, FA, FB, in, out);
-    else tf_h3s_step<TOUT, TIN, SL16>(S, g * SL16, FB, FA, in, out);
+    if (((P0 + g) & 1) == 0) tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, g * SL16, FA, FB, in, out);
+    else tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, g * SL16, FB, FA, in, out);
   }
 }
 
 // Dense layer, f16x3, fragment weights resident in LDS ([s16][tout][hi|lo][lane][8 halves]).
-template <int K16, int TOUT, int TIN>
+template <int K16, int TOUT, int TIN, int TERMS = 3>
 __device__ __forceinline__ void tf_layer_h3(const tf_h8* __restrict__ wf /* + lane */, const f32x16 (&in)[TIN],
                                             f32x16 (&out)[TOUT]) {
 #pragma unroll
@@ -470,14 +493,18 @@ __device__ __forceinline__ void tf_layer_h3(const tf_h8* __restrict__ wf /* + la
       float x8[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
-      tf_split8(x8, b_hi, b_lo);
+      if (TERMS == 3) tf_split8(x8, b_hi, b_lo);
+      else tf_cvt8(x8, b_hi);
     }
 #pragma unroll
     for (int t = 0; t < TOUT; ++t) {
-      const tf_h8 a_hi = wf[(s16 * TOUT + t) * 128], a_lo = wf[(s16 * TOUT + t) * 128 + 64];
+      const tf_h8 a_hi = wf[(s16 * TOUT + t) * 128];
       out[t] = tf_mfma_h(a_hi, b_hi, out[t]);
-      out[t] = tf_mfma_h(a_hi, b_lo, out[t]);
-      out[t] = tf_mfma_h(a_lo, b_hi, out[t]);
+      if (TERMS == 3) {
+        const tf_h8 a_lo = wf[(s16 * TOUT + t) * 128 + 64];
+        out[t] = tf_mfma_h(a_hi, b_lo, out[t]);
+        out[t] = tf_mfma_h(a_lo, b_hi, out[t]);
+      }
     }
   }
 }

@@ -409,3 +409,27 @@ def test_envlight_build_mips_autograd(dev):
     g1 = g_levels[1] + oc.mip_bwd(g2)
     g0 = g_levels[0] + oc.mip_bwd(g1)
     assert rel_err(env.base.grad.cpu(), torch.from_numpy(g0)) < 5e-4
+
+
+def test_f16_mode_is_close_but_not_parity_grade(golden, dev):
+    """TF_PREC_F16 (plain f16 decoder operands; BASELINE configs[4]) on the default shading golden: the per-pixel colour stays
+    within ~1e-3 of the reference (PSNR > 60 dB) -- reported as a separate mode, never used for parity claims."""
+    import math
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import MCShader
+    g = golden("shading_default")
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    sh = MCShader(g.sd, g["verts"].numpy(), g["faces"].numpy(), AABB, float(g["unit_size"]), device=dev, n_fixed_diffuse=n_fd)
+    args = (g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
+    ref = sh.shade(*args)["colors"].cpu()
+    sh.precision = ops.PREC_F16
+    got = sh.shade(*args)["colors"].cpu()
+    assert rel_err(ref, g.out["rgb_pr_nis"]) < TOL
+    mse = float(((got - g.out["rgb_pr_nis"]) ** 2).mean())
+    assert 20 * math.log10(1 / math.sqrt(mse)) > 60.0 and rel_err(got, g.out["rgb_pr_nis"]) < 5e-3
+    assert not torch.equal(got, ref)                      # the mode really is a different arithmetic
+    with pytest.raises(RuntimeError):                     # entry points that do not implement the mode refuse it
+        from tensoflow_amd.march import SdfField
+        f = SdfField(golden("march_r32").sd, AABB, [32, 32, 32], 3, device=dev)
+        f.sdf_alpha(torch.zeros(4, 3, device=dev), None, torch.zeros(4, device=dev), torch.zeros(4, 3, device=dev), 1.0, 0.0,
+                    precision=ops.PREC_F16)

@@ -52,3 +52,28 @@ def test_flow_backward(golden):
     (-(g["bwd_w"] * logq).mean()).backward()
     for k, ref in g.grad.items():
         assert rel_err(sd[k].grad, ref) < 2e-5, k
+
+
+def test_reference_spline_root_is_ill_conditioned_in_fp32():
+    """Evidence behind the documented parity exception: the reference's own closed form of the inverse
+    spline, (-b +- sqrt(b^2 - 2ac)) / a (flow.py:470-500), cancels catastrophically when a bin's two knot heights nearly
+    coincide.  Evaluated in fp32 and in fp64 on identical inputs it disagrees with ITSELF by > 1e-4 on a few samples per
+    100 000 (max ~1e-2), and so does fp32 vs fp32 after a 1e-6 relative perturbation of the net outputs (what a different
+    GEMM summation order produces).  No implementation -- the reference on another device included -- can hold 1e-4 on those
+    samples; everywhere else the formula is stable to ~1e-6."""
+    import torch
+    from oracle import flow as of
+    g = torch.Generator().manual_seed(5)
+    M = 400_000
+    wv = torch.randn(M, 21, generator=g)
+    y = torch.rand(M, generator=g).clamp(1e-6, 1 - 1e-6)
+    x32, _, e32 = of.pwquad_inverse(y, wv)
+    x64, _, e64 = of.pwquad_inverse(y.double(), wv.double())
+    assert torch.equal(e32, e64)                                     # integer bin indices are stable
+    d = (x32.double() - x64).abs()
+    assert float(torch.quantile(d, 0.999)) < 1e-5                   # well conditioned almost everywhere ...
+    bad = int((d > 1e-4).sum())
+    assert 1 <= bad <= 100 and float(d.max()) > 1e-3                # ... and ill conditioned on isolated samples
+    x32b, _, e32b = of.pwquad_inverse(y, wv * (1 + 1e-6 * torch.randn(M, 21, generator=g)))
+    same = e32 == e32b
+    assert float((x32 - x32b).abs()[same].max()) > 1e-3
