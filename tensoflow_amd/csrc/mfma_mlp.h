@@ -126,19 +126,32 @@ typedef __attribute__((address_space(3))) void* tf_lptr_t;
 
 // One 16 KB weight slab global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, asynchronous):
 // each of the 4 waves moves 4 pieces of 1 KB (lane l supplies the source address of its 16 bytes).
-__device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*1024 + lane*4 */, float* __restrict__ lbuf,
-                                            int wave) {
+// The DMA is issued from an asm statement, not through __builtin_amdgcn_global_load_lds: hipcc's wait-count pass treats every
+// outstanding LDS-DMA as a possible alias of every later LDS read and puts `s_waitcnt vmcnt(0)` in front of each ds_read
+// group -- i.e. every slab step drained the whole ring (the slab requested a few hundred cycles earlier included) and the
+// hand-counted vmcnt(4) never got to act.  Hidden from the compiler, the only waits on the ring are the counted ones placed
+// by this file (tf_wait_vmcnt_barrier / tf_h3s_step / tf_stream_begin / tf_stream_end); its own vmcnt bookkeeping for other
+// loads stays safe (unknown extra operations in flight can only make a counted wait longer, never shorter).
+// M0 = LDS byte address of the piece (wave-uniform); lane l writes its 16 bytes at M0 + 16 l.
+__device__ __forceinline__ void tf_dma16(const float* gsrc, float* ldst) {
 #ifndef TF_ABLATE_DMA   // dev-only timing ablation (tools/build_variant.sh): results are garbage when defined
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
+#ifdef TF_DMA_BUILTIN
+  __builtin_amdgcn_global_load_lds((tf_gptr_t)gsrc, (tf_lptr_t)ldst, 16, 0, 0);
+#else
+  const unsigned laddr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(tf_lptr_t)ldst);
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(laddr), "v"(gsrc) : "memory");
+#endif
 #endif
 }
 
+__device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*1024 + lane*4 */, float* __restrict__ lbuf,
+                                            int wave) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tf_dma16(gthread + i * 256, lbuf + (wave * 4 + i) * 256);
+}
+
 __device__ __forceinline__ void tf_slab_dma_piece(const float* gthread, float* __restrict__ lbuf, int wave, int i) {
-#ifndef TF_ABLATE_DMA
-  __builtin_amdgcn_global_load_lds((tf_gptr_t)(gthread + i * 256), (tf_lptr_t)(lbuf + (wave * 4 + i) * 256), 16, 0, 0);
-#endif
+  tf_dma16(gthread + i * 256, lbuf + (wave * 4 + i) * 256);
 }
 
 template <int N>
@@ -445,6 +458,7 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
   float* dbuf = S.lds + S.slot_req * 4096;
   const float* gsrc = S.gp;
   asm volatile("" : "+v"(gsrc));
+#ifndef TF_MFMA_TERM_MAJOR   // default: the three product terms of a tile issued back to back on its accumulator
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int sl = c / TOUT, t = c % TOUT;
@@ -463,6 +477,29 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+  // dev-only experiment (tools/build_variant.sh -DTF_MFMA_TERM_MAJOR): the eight hi*hi products of the step first, then the
+  // eight hi*lo, then the eight lo*hi, so that no MFMA accumulates into the register its predecessor is still writing.
+  // Measured SLOWER (2.76 vs 2.60 ms per 3 M rays): back-to-back accumulation on one register is the fast path of the
+  // matrix pipe; results are bit-identical either way (same order per accumulator).
+#pragma unroll
+  for (int p = 0; p < TERMS; ++p) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int sl = c / TOUT, t = c % TOUT;
+      if (p == 0 && c >= 1 && c <= 4) {
+#pragma unroll
+        for (int q = 2 * (c - 1); q < 2 * c; ++q) {
+          nxt.hi[q] = nbuf[q * 128];
+          if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
+        }
+      }
+      if (p == TERMS - 1 && c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
+      out[t] = tf_mfma_h(p == 2 ? cur.lo[c] : cur.hi[c], p == 1 ? b_lo[sl] : b_hi[sl], out[t]);
+      if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#endif
   tf_stream_advance(S);
   S.slot_rd = (S.slot_rd + 1) & 3;
 }

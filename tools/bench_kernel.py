@@ -50,7 +50,7 @@ elif which == "inner":
     m = 3_000_000
     pts = torch.rand(m, 3, device=dev) * 2 - 1
     v = torch.randn(m, 3, device=dev); nr = torch.randn(m, 3, device=dev)
-    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16):
         ms = timeit(lambda: ops.inner_light(W, pts, v, nr, precision=prec))
         print(f"inner_light m={m} precision={prec}: {ms:.2f} ms  {m*326656/ms*1e-9:.1f} TF/s (algorithmic)")
 elif which == "bvh":
@@ -73,10 +73,10 @@ elif which == "flow":
     pn, sn = 16384, 128
     cond = torch.rand(pn, 37, device=dev)
     lat = sphere_latent(sn).to(dev)
-    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16):
         ms = timeit(lambda: ops.flow_sample(fp.nets, cond, lat, precision=prec, cache=fp.cache))
         print(f"flow_sample pn={pn} sn={sn} precision={prec}: {ms:.3f} ms  {pn*sn/ms*1e-6:.2f} Gsamples/s  {pn*sn*49408/ms*1e-9:.1f} TF/s (reference flop count)")
     x = torch.rand(pn, sn, 2, device=dev)
-    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16):
         ms = timeit(lambda: ops.flow_logq(fp.nets, cond, x, precision=prec))
         print(f"flow_logq pn={pn} sn={sn} precision={prec}: {ms:.3f} ms")
