@@ -118,6 +118,9 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
       lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
     }
   }
+#ifdef TF_CLOCK_PROBE   // dev-only: shader-clock ticks spent by workgroup 0 (s_memtime counts shader clocks on this part)
+  const unsigned long long probe_t0 = __builtin_readcyclecounter();
+#endif
   TfStream S;
   TfFrag FA, FB;
   if (H3) tf_stream_begin(S, reinterpret_cast<const _Float16*>(ws_arg + kH1), 42, lds, tid, lane, FA);   // contains a barrier
@@ -223,6 +226,11 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     }
   }
   if (H3) tf_stream_end();
+#ifdef TF_CLOCK_PROBE
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("inner_light<%d> wg0: %llu ticks for %lld tiles\n", MODE, __builtin_readcyclecounter() - probe_t0,
+           (n_groups - blockIdx.x + gridDim.x - 1) / gridDim.x);
+#endif
 }
 
 static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,

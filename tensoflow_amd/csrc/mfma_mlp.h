@@ -436,29 +436,40 @@ __device__ __forceinline__ void tf_stream_end() {
 }
 
 // TERMS = 3: f16x3 (fp32-accurate).  TERMS = 1: plain f16 operands (TF_PREC_F16) -- the lo fragments are neither read nor used.
-template <int TOUT, int TIN, int SL16, int TERMS = 3>
-__device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFrag& cur, TfFrag& nxt, const f32x16 (&in)[TIN],
-                                            f32x16 (&out)[TOUT]) {
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#ifndef TF_ABLATE_BARRIER   // dev-only timing ablation: results are garbage when defined
-  __builtin_amdgcn_s_barrier();
-#endif
-  asm volatile("" ::: "memory");
-  tf_h8 b_hi[SL16], b_lo[SL16];
+// B operands (activations) of one slab step: SL16 k-steps, split hi | lo.
+template <int SL16>
+struct TfBsplit { tf_h8 hi[SL16], lo[SL16]; };
+
+template <int SL16, int TIN, int TERMS>
+__device__ __forceinline__ void tf_bsplit(TfBsplit<SL16>& B, int s16base, const f32x16 (&in)[TIN]) {
 #pragma unroll
   for (int sl = 0; sl < SL16; ++sl) {
     const int s16 = s16base + sl;
     float x8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
-    if (TERMS == 3) tf_split8(x8, b_hi[sl], b_lo[sl]);
-    else tf_cvt8(x8, b_hi[sl]);
+    if (TERMS == 3) tf_split8(x8, B.hi[sl], B.lo[sl]);
+    else tf_cvt8(x8, B.hi[sl]);
   }
+}
+
+// TERMS = 3: f16x3 (fp32-accurate).  TERMS = 1: plain f16 operands (TF_PREC_F16) -- the lo fragments are neither read nor used.
+// `bc`: this step's B operands, prepared by the PREVIOUS step (or by the layer prologue); `bn` (NEXT >= 0): the next step's are
+// split here, behind the second MFMA group -- at the step boundary the split's 13 vector instructions ran with an idle matrix
+// pipe (one wave per SIMD: nothing else to issue), 42 times per tile.
+template <int TOUT, int TIN, int SL16, int TERMS>
+__device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFrag& nxt, const TfBsplit<SL16>& bc, TfBsplit<SL16>& bn,
+                                            int NEXT /* first k-step of the next slab step, -1: none (constant after inlining) */,
+                                            const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#ifndef TF_ABLATE_BARRIER   // dev-only timing ablation: results are garbage when defined
+  __builtin_amdgcn_s_barrier();
+#endif
+  asm volatile("" ::: "memory");
   const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(S.lds + S.slot_rd * 4096) + S.lane;
   float* dbuf = S.lds + S.slot_req * 4096;
   const float* gsrc = S.gp;
   asm volatile("" : "+v"(gsrc));
-#ifndef TF_MFMA_TERM_MAJOR   // default: the three product terms of a tile issued back to back on its accumulator
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int sl = c / TOUT, t = c % TOUT;
@@ -470,35 +481,18 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
       }
     }
     if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
-    out[t] = tf_mfma_h(cur.hi[c], b_hi[sl], out[t]);
+#ifndef TF_SPLIT_AT_BOUNDARY
+    if (c == 5 && NEXT >= 0) tf_bsplit<SL16, TIN, TERMS>(bn, NEXT, in);
+#endif
+    out[t] = tf_mfma_h(cur.hi[c], bc.hi[sl], out[t]);
     if (TERMS == 3) {
-      out[t] = tf_mfma_h(cur.hi[c], b_lo[sl], out[t]);
-      out[t] = tf_mfma_h(cur.lo[c], b_hi[sl], out[t]);
+      out[t] = tf_mfma_h(cur.hi[c], bc.lo[sl], out[t]);
+      out[t] = tf_mfma_h(cur.lo[c], bc.hi[sl], out[t]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-#else
-  // dev-only experiment (tools/build_variant.sh -DTF_MFMA_TERM_MAJOR): the eight hi*hi products of the step first, then the
-  // eight hi*lo, then the eight lo*hi, so that no MFMA accumulates into the register its predecessor is still writing.
-  // Measured SLOWER (2.76 vs 2.60 ms per 3 M rays): back-to-back accumulation on one register is the fast path of the
-  // matrix pipe; results are bit-identical either way (same order per accumulator).
-#pragma unroll
-  for (int p = 0; p < TERMS; ++p) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int sl = c / TOUT, t = c % TOUT;
-      if (p == 0 && c >= 1 && c <= 4) {
-#pragma unroll
-        for (int q = 2 * (c - 1); q < 2 * c; ++q) {
-          nxt.hi[q] = nbuf[q * 128];
-          if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
-        }
-      }
-      if (p == TERMS - 1 && c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
-      out[t] = tf_mfma_h(p == 2 ? cur.lo[c] : cur.hi[c], p == 1 ? b_lo[sl] : b_hi[sl], out[t]);
-      if ((c & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+#ifdef TF_SPLIT_AT_BOUNDARY   // dev-only: the previous placement
+  if (NEXT >= 0) tf_bsplit<SL16, TIN, TERMS>(bn, NEXT, in);
 #endif
   tf_stream_advance(S);
   S.slot_rd = (S.slot_rd + 1) & 3;
@@ -506,16 +500,26 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, int s16base, const TfFr
 
 // One dense layer on the stream: K16 k-steps of TOUT unit tiles (G = K16 * TOUT / 8 slabs); P0 = parity of its first slab
 // (which of FA / FB already holds that slab's fragments).  Returns nothing; the caller continues with parity (P0 + G) & 1.
+// (Issuing the three terms of a tile back to back on its accumulator is the fast order: a term-major order -- eight hi*hi,
+// then eight hi*lo, then eight lo*hi -- measured 6 % slower.)
 template <int K16, int TOUT, int TIN, int P0, int TERMS = 3>
 __device__ __forceinline__ void tf_layer_h3s(TfStream& S, TfFrag& FA, TfFrag& FB, const f32x16 (&in)[TIN], f32x16 (&out)[TOUT]) {
   static_assert(8 % TOUT == 0, "a 16 KB slab holds 8 (k-step, tile) fragment pairs");
   constexpr int SL16 = 8 / TOUT;
   static_assert(K16 % SL16 == 0, "K16 must be a multiple of the slab size");
   constexpr int G = K16 / SL16;
+  TfBsplit<SL16> B0, B1;
+  tf_bsplit<SL16, TIN, TERMS>(B0, 0, in);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    if (((P0 + g) & 1) == 0) tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, g * SL16, FA, FB, in, out);
-    else tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, g * SL16, FB, FA, in, out);
+    // static indices after unrolling: parity of the fragment sets and of the operand sets
+    if (((P0 + g) & 1) == 0) {
+      if ((g & 1) == 0) tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FA, FB, B0, B1, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
+      else tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FA, FB, B1, B0, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
+    } else {
+      if ((g & 1) == 0) tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FB, FA, B0, B1, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
+      else tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FB, FA, B1, B0, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
+    }
   }
 }
 
