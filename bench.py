@@ -321,143 +321,6 @@ def main():
     # every rank shades its own shard of the point stream (weak scaling), inputs resident in HBM
     pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=6 + 1000 * rank)]
 
-    def step():
-        m.zero_grad(set_to_none=True)
-        colors, out = m(pts, view, nrm, None, 600, True)
-        ((colors * w).sum() + out["loss_nis"]).backward()
-
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    n_par = sum(p.numel() for p in m.parameters() if p.requires_grad)
-    return dict(workload=f"MCShadingNetwork train step: {pn} points x ({S} + 512 + {S}) rays, NIS losses on, fwd + bwd (no optimizer)",
-                ms_per_step=dt * 1e3, points_per_s=pn / dt, trainable_parameters=n_par)
-
-
-def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
-    """Secondary figure (BASELINE configs[1]): one full 800x800 frame of the shape stage -- fixed-step sampler with occupancy
-    culling (tf_march_uniform), fused 7-tap sdf/FD/alpha kernel, split-sum shading, compositing.  Reports rays/s, live
-    samples/s and the gather roofline of the sdf kernel (18 144 B and 466 944 flop per live sample, level >= ... one mip)."""
-    from tensoflow_amd import march
-    from tensoflow_amd.network.light import EnvLight
-    from tensoflow_amd.shape_shading import ShapeShader
-    from tensoflow_amd.synth import pinhole_rays, random_sdf_state, random_shape_shader_state, synthetic_fg_lut
-    R = 300
-    sd = {"sdf_network." + k: v for k, v in random_sdf_state(seed=1, R=R).items()}
-    sd.update(random_shape_shader_state(seed=8))
-    field = march.SdfField(sd, [[-1.0, -1, -1], [1, 1, 1]], [R, R, R], 3, device=device)
-    env = EnvLight(trainable=False, max_res=128, device=device)
-    env.base.data = sd["color_network.envlight.base"].to(device)
-    t_env = time.perf_counter()
-    env.build_mips()
-    torch.cuda.synchronize()
-    t_env = time.perf_counter() - t_env
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    e0, e1 = ev(), ev()
-    e0.record()
-    for _ in range(3):
-        env.build_mips()
-    e1.record()
-    torch.cuda.synchronize()
-    build_mips_ms = e0.elapsed_time(e1) / 3
-    shader = ShapeShader(sd, [s.detach() for s in env.specular], env.diffuse.detach(), synthetic_fg_lut(), device=device)
-    inv_s = math.exp(10 * 0.3)
-    e0.record()
-    mask, _ = march.update_alpha_mask(field, inv_s)
-    e1.record()
-    torch.cuda.synchronize()
-    mask_ms = e0.elapsed_time(e1)
-    o, d, radii, cos = [torch.from_numpy(a).to(device) for a in pinhole_rays(n_rays_total, seed=2)]
-    near, far = march.near_far_from_sphere(o, d)
-    base_radii = 2.0 / 2.0 / R
-    sdf_ms = [0.0]
-    sdf_ev = []
-    orig = field.sdf_alpha
-
-    def timed_sdf_alpha(*a, **k):
-        s, e = ev(), ev()
-        s.record()
-        out = orig(*a, **k)
-        e.record()
-        sdf_ev.append((s, e))
-        return out
-    field.sdf_alpha = timed_sdf_alpha
-
-    def frame():
-        live = 0
-        for c0 in range(0, n_rays_total, chunk):
-            sl = slice(c0, min(c0 + chunk, n_rays_total))
-            t0, t1, ridx = march.march_uniform(field, o[sl], d[sl], near[sl], far[sl], n_steps=n_steps, mask=mask)
-            out = march.render_core(field, o[sl], d[sl], radii[sl], cos[sl], t0, t1, ridx, base_radii, inv_s, 1.0,
-                                    shade_fn=lambda p, n, v, f: shader(p, n, v, f)[0], is_train=False)
-            live += t0.numel()
-        return live, out
-    frame()
-    sdf_ev.clear()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        live, out = frame()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    sdf_s = sum(s.elapsed_time(e) for s, e in sdf_ev) * 1e-3 / steps
-    sps = live / sdf_s
-    return dict(workload=f"TensoSDF R=300 C=36 3 mips, {n_rays_total} rays x {n_steps} fixed steps, 128^3 occupancy culling, "
-                         f"fused 7-tap sdf+FD+alpha (eval: no hessian term, f16x3 decoder), split-sum shading, compositing (forward)",
-                rays_per_s=n_rays_total / dt, frame_ms=dt * 1e3, live_samples_per_frame=live,
-                live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
-                sdf_alpha_samples_per_s=sps, algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,
-                hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS, tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12,
-                hbm_traffic_per_launch=pmc_traffic("sdf_kernel"),
-                envlight_build_mips_ms=build_mips_ms, update_alpha_mask_ms=mask_ms)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=65536, help="surface points per GPU per step")
-    ap.add_argument("--flow-samples", type=int, default=128)
-    ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
-    ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
-                    help="matrix-core arithmetic of the 256-wide decoder: f16x3 split (fp32-accurate) or exact fp32 MFMA")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-march", action="store_true")
-    ap.add_argument("--no-train", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (there is no CPU path for the product kernels)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist_on = world > 1
-    if dist_on:
-        import torch.distributed as dist
-        backend = os.environ.get("TENSOFLOW_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for 1-GPU dry runs
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-
-    from tensoflow_amd.shading import StageTimer
-    from tensoflow_amd.synth import sphere_surface_points
-    mesh_res = tuple(int(v) for v in args.mesh.split(","))
-    sh, sd, verts, faces, aabb, unit = build_scene(device, 4, mesh_res)
-    from tensoflow_amd import ops as _ops
-    sh.precision = _ops.PREC_F16X3 if args.precision == "f16x3" else _ops.PREC_F32
-    S = args.flow_samples
-    pn = args.points
-    # every rank shades its own shard of the point stream (weak scaling), inputs resident in HBM
-    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=6 + 1000 * rank)]
-
     if os.environ.get("TF_BENCH_PRESORT"):          # dev experiment: spatially coherent point order
         q = ((pts * 0.5 + 0.5).clamp(0, 1) * 1023).long()
         code = torch.zeros(pn, dtype=torch.long, device=device)
