@@ -398,8 +398,6 @@ def main():
         }
         from tensoflow_amd.shading import _NoTimer
         sh.timer = _NoTimer()                     # the secondary probes below are not part of the timed region
-        if world == 1 and not args.no_march:
-            line["march"] = march_probe(device, max(2, args.steps))
         if world == 1 and not args.no_train:
             try:
                 line["flow_only"] = flow_only_probe(device, sd, verts, faces, aabb, unit, S, max(2, args.steps), pn)
@@ -420,6 +418,11 @@ def main():
                 line["config3_flow256"] = flow_count_probe(sh, pts, view, nrm, 256, max(2, args.steps))
             except Exception as e:
                 line["config3_flow256"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_march:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()              # the probes above leave ~20 GB of cached blocks behind
+            line["march"] = march_probe(device, max(2, args.steps))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["psnr"] = cpu_baseline(sd, aabb, unit, 4096, S, device=device)
         print(json.dumps(line))
