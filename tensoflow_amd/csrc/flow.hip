@@ -41,6 +41,18 @@ struct SharedDiv {
   }
 };
 
+// exp / log on the transcendental unit: v_exp_f32(x * log2 e) and v_log_f32(x) * ln 2 (2 instructions each) instead of the
+// ~10 / ~15 of the libm sequences (range scaling for denormal results, extra-precision argument) -- 42 exponentials per row made
+// them 8 % of the kernel's vector instructions.  Relative error <= |x| * 6e-8 + 1 ulp; arguments here are net outputs of
+// magnitude O(1) and knot heights >= 1e-6 (normal range), and the spline already moves by ~1e-6 with the MFMA summation order.
+#ifdef TF_FLOW_LIBM   // dev-only switch
+__device__ __forceinline__ float tf_exp(float x) { return expf(x); }
+__device__ __forceinline__ float tf_log(float x) { return logf(x); }
+#else
+__device__ __forceinline__ float tf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float tf_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+#endif
+
 template <bool CLAMP_W>
 __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
   // wv[0..10] = v_tilde, wv[11..20] = w_tilde   (flow.py:337-350 / :420-434)
@@ -48,7 +60,7 @@ __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
   float run = 0.f;
 #pragma unroll
   for (int i = 0; i < FLOW_NB; ++i) {
-    float e = expf(wv[11 + i]);
+    float e = tf_exp(wv[11 + i]);
     if (CLAMP_W) e = fmaxf(e, 1e-6f);
     T.w[i] = e;
     run += e;
@@ -65,7 +77,7 @@ __device__ __forceinline__ void pw_tables(const float (&wv)[32], PwTables& T) {
   }
   float ev[FLOW_NB + 1];
 #pragma unroll
-  for (int i = 0; i <= FLOW_NB; ++i) ev[i] = expf(wv[i]);
+  for (int i = 0; i <= FLOW_NB; ++i) ev[i] = tf_exp(wv[i]);
   float den = 0.f;
 #pragma unroll
   for (int i = 0; i < FLOW_NB; ++i) den += (ev[i] + ev[i + 1]) / 2.f * T.w[i];
@@ -123,8 +135,9 @@ __device__ __forceinline__ void pw_inverse(float y, const float (&wv)[32], float
   float sol = (s1 >= 0.f && s1 < 1.f) ? s1 : s2;
   sol = fminf(fmaxf(sol, kEps32), 1.f - kEps32);
   x = fminf(fmaxf(we * sol + wsse, kEps32), 1.f - kEps32);
-  logj = -logf(ve + sol * (ve1 - ve));  // torch.lerp(start,end,w) = start + w*(end-start) for w < 0.5 ...
-  if (sol >= 0.5f) logj = -logf(ve1 - (ve1 - ve) * (1.f - sol));  // ... and end - (end-start)*(1-w) otherwise
+  // torch.lerp(start, end, w) = start + w*(end-start) for w < 0.5 and end - (end-start)*(1-w) otherwise
+  const float lerp = sol < 0.5f ? ve + sol * (ve1 - ve) : ve1 - (ve1 - ve) * (1.f - sol);
+  logj = -tf_log(lerp);
   bin = e;
 }
 
@@ -155,7 +168,7 @@ __device__ __forceinline__ void pw_forward(float xin, const float (&wv)[32], flo
   float o = (al * al) / 2.f * ((vm1 - vm) * wm) + al * vm * wm + vwm;
   out = fminf(fmaxf(o, kEps32), 1.f - kEps32);
   float lerp = al < 0.5f ? vm + al * (vm1 - vm) : vm1 - (vm1 - vm) * (1.f - al);
-  logj = logf(lerp);
+  logj = tf_log(lerp);
   bin = m;
 }
 
@@ -172,7 +185,24 @@ static constexpr int hL1 = 0, hL2 = hL1 + 2 * 512, hL3 = hL2 + 8 * 512, hL4 = hL
 static_assert(hNetFloats <= kNetFloats + 512, "workspace sizing assumes the f16x3 image is not much larger");
 
 // LeakyReLU(0.01) as max(x, 0.01 x): two instructions instead of compare + multiply + select, same value for every x
-__device__ __forceinline__ float leaky(float x) { return fmaxf(x, 0.01f * x); }
+// One v_mul + one v_med3: median(x, 0.01 x, +inf) = max(x, 0.01 x).  Written as fmaxf() the compiler first canonicalises the
+// accumulator value (v_max x, x: the matrix-core result is not a known-canonical float to it) -- three instructions per
+// activation, 1 150 per 64 rows.  (A packed v_pk_mul_f32 for the products was tried and is NOT safe here: results changed
+// from run to run on 9 % of the samples -- a packed-FP32 read of a matrix-core result that hipcc's hazard recogniser does not
+// cover; tools/exp_flow_determinism.py is the check.)
+__device__ __forceinline__ float leaky(float x) {
+#ifdef TF_FLOW_FMAX_LEAKY   // dev-only switch: the previous form
+  return fmaxf(x, 0.01f * x);
+#else
+  float big = 3.0e38f;             // opaque to the optimiser (med3 with a literal +inf is folded back into the canonicalising max)
+  asm("" : "+s"(big));
+  return __builtin_amdgcn_fmed3f(x, 0.01f * x, big);
+#endif
+}
+__device__ __forceinline__ void leaky16(f32x16& v) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = leaky(v[j]);
+}
 
 // net eval for one 32-row tile: y_keep / P row of the row on this lane's MFMA column (lane & 31) -> o: the 21 (+pad)
 // outputs of the tile in accumulator layout (lane half h holds units rho(j, h) of its column's row)
@@ -209,25 +239,21 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      a[t][j] = leaky(a[t][j]);
-      b[t][j] = net[B2 + (t * 16 + j) * 2 + h];
-    }
+    for (int j = 0; j < 16; ++j) b[t][j] = net[B2 + (t * 16 + j) * 2 + h];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) leaky16(a[t]);
   if (H3) tf_layer_h3<4, 2, 2, TERMS>(nh + hL2 / 4, a, b);
   else tf_layer<32, 2, 2>(net + kL2 + lane, a, b);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      b[t][j] = leaky(b[t][j]);
-      a[t][j] = net[B3 + (t * 16 + j) * 2 + h];
-    }
+    for (int j = 0; j < 16; ++j) a[t][j] = net[B3 + (t * 16 + j) * 2 + h];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) leaky16(b[t]);
   if (H3) tf_layer_h3<4, 2, 2, TERMS>(nh + hL3 / 4, b, a);
   else tf_layer<32, 2, 2>(net + kL3 + lane, b, a);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[t][j] = leaky(a[t][j]);
+  for (int t = 0; t < 2; ++t) leaky16(a[t]);
 #pragma unroll
   for (int j = 0; j < 16; ++j) o[0][j] = net[B4 + j * 2 + h];
   if (H3) tf_layer_h3<4, 1, 2, TERMS>(nh + hL4 / 4, a, o);

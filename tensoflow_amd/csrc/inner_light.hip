@@ -51,7 +51,7 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
   }
 }
 
-__device__ __forceinline__ float relu(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ float relu(float x) { return tf_relu(x); }
 
 // hidden layer on the continuous weight stream (mfma_mlp.h): every hidden layer here has an even slab count, so the
 // fragment-set parity is 0 at each layer start

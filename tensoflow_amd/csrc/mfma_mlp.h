@@ -436,6 +436,15 @@ __device__ __forceinline__ void tf_stream_end() {
 }
 
 // TERMS = 3: f16x3 (fp32-accurate).  TERMS = 1: plain f16 operands (TF_PREC_F16) -- the lo fragments are neither read nor used.
+// ReLU of a matrix-core result in ONE instruction: median(x, 0, big) = max(x, 0).  fmaxf(x, 0.f) costs two -- the compiler first
+// canonicalises x (v_max x, x), because an MFMA result is not a known-canonical float to it; `big` is made opaque so that the
+// median is not folded back into that form.
+__device__ __forceinline__ float tf_relu(float x) {
+  float big = 3.0e38f;
+  asm("" : "+s"(big));
+  return __builtin_amdgcn_fmed3f(x, 0.f, big);
+}
+
 // B operands (activations) of one slab step: SL16 k-steps, split hi | lo.
 template <int SL16>
 struct TfBsplit { tf_h8 hi[SL16], lo[SL16]; };

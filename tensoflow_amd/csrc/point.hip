@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64) point_prep_kernel(PointArgs A) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[t][j] = fmaxf(acc[t][j], 0.f);
+      for (int j = 0; j < 16; ++j) acc[t][j] = tf_relu(acc[t][j]);
     f32x16 o[1];
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[0][j] = ws[kPmB2 + j * 2 + h];

@@ -94,7 +94,7 @@ __device__ __forceinline__ void ss_hidden(TfStream& S, TfFrag& FA, TfFrag& FB, c
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = fmaxf(out[t][j], 0.f);
+    for (int j = 0; j < 16; ++j) out[t][j] = tf_relu(out[t][j]);
 }
 
 template <int P0>
