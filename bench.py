@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=65536, help="surface points per GPU per step")
+    ap.add_argument("--points", type=int, default=262144, help="surface points per GPU per step (SURVEY.md 8(d) config 3 shades 2^20 points; the rate is flat from 2^16 up: +3 % at 2^18)")
     ap.add_argument("--flow-samples", type=int, default=128)
     ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
