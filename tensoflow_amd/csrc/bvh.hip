@@ -341,7 +341,13 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   auto pop = [&]() -> int {
     if (sp == 0) return BVH_NONE;
     --sp;
-    return sp < BVH_LDS_STACK ? stack[sp * 256 + tid] : deep[sp - BVH_LDS_STACK];
+    // always a plain LDS read; the scratch tail is a separate, rarely taken branch.  Written as one conditional expression the
+    // two arrays become one generic pointer and the pop a flat_load behind `s_waitcnt vmcnt(0) lgkmcnt(0)` -- on the dependent
+    // chain of every second traversal step.
+    int v = stack[min(sp, BVH_LDS_STACK - 1) * 256 + tid];
+    asm volatile("" : "+v"(v));                 // keeps the LDS read an instruction of its own (not a select of two pointers)
+    if (sp >= BVH_LDS_STACK) v = deep[sp - BVH_LDS_STACK];
+    return v;
   };
   auto retire = [&]() {
     A.depth[rid] = best;
