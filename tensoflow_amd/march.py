@@ -90,8 +90,10 @@ def _upsample(o, d, z, sdf, n_imp, inv_s):
 
 
 @torch.no_grad()
-def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n_samples=64, n_importance=64, up_steps=4):
-    """ShapeRenderer.sample_ray with perturb=0, clip_sample_variance=False -> packed t_starts, t_ends, ray_indices (int64)."""
+def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n_samples=64, n_importance=64, up_steps=4,
+               t_rand=None, inv_s_cap=None):
+    """ShapeRenderer.sample_ray -> packed t_starts, t_ends, ray_indices (int64).  t_rand [rn,1] in [-0.5, 0.5): the per-ray
+    stratification offset of perturb > 0 (shapeRenderer.py:888-890); inv_s_cap: clip_sample_variance (:905-907)."""
     rn = o.shape[0]
     dev = o.device
     aabb = field.aabb_dev
@@ -100,11 +102,13 @@ def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n
     tmin = torch.minimum(ra, rb).amax(-1).clamp(min=near[:, 0], max=far[:, 0])[:, None]
     tmax = torch.maximum(ra, rb).amin(-1).clamp(min=near[:, 0], max=far[:, 0])[:, None]
     t = tmin + (tmax - tmin) * torch.linspace(0.0, 1.0, n_samples, device=dev)[None]
+    if t_rand is not None:
+        t = t + t_rand * 2.0 / n_samples
     pts = o[:, None] + d[:, None] * t[..., None]
     lv = torch.log2(ball_radii(t[..., None], radiis[:, None], rays_cos[:, None]) / base_radii)
     sdf = field.sdf(pts.reshape(-1, 3), lv.reshape(-1)).reshape(rn, n_samples)
     for i in range(up_steps):
-        inv_s = torch.ones(rn, t.shape[1] - 1, device=dev) * 64 * 2 ** i
+        inv_s = torch.ones(rn, t.shape[1] - 1, device=dev) * (64 * 2 ** i if inv_s_cap is None else min(inv_s_cap, 64 * 2 ** i))
         new_t = _upsample(o, d, t, sdf, n_importance // up_steps, inv_s)
         t_all, index = torch.sort(torch.cat([t, new_t], -1), -1)
         if i + 1 < up_steps:

@@ -11,9 +11,64 @@ from .flow import TensoFlow, _check_no_grad
 from .light import EnvLight
 
 
+class TVLoss(nn.Module):
+    """other_field.py:170-191: squared-difference total variation of a [B,C,H,W] grid (parameter-only regulariser)."""
+
+    def __init__(self, TVLoss_weight=1):
+        super().__init__()
+        self.TVLoss_weight = TVLoss_weight
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        count_h, count_w = c * (h - 1) * w, c * h * (w - 1)
+        total = 0.0
+        if count_h != 0:
+            total = total + torch.pow(x[:, :, 1:, :] - x[:, :, :h - 1, :], 2).sum() / count_h
+        if count_w != 0:
+            total = total + torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).sum() / count_w
+        return self.TVLoss_weight * 2 * total / b
+
+
+def _gauss_kernel(kernel_size, sigma, dims):
+    x = torch.arange(-kernel_size // 2 + 1.0, kernel_size // 2 + 1.0)
+    if dims == 1:
+        k = torch.exp(-x ** 2 / (2 * sigma ** 2))
+    else:
+        xx, yy = torch.meshgrid(x, x, indexing="ij")
+        k = torch.exp(-(xx ** 2 + yy ** 2) / (2 * sigma ** 2))
+    return k[None, None, ...] / k.sum()
+
+
+class GaussianBlur2D(nn.Module):
+    """other_field.py:146-156 (buffer `kernel` is part of the reference state_dict)."""
+
+    def __init__(self, kernel_size=5, sigma=1.0, stride=2, device="cuda"):
+        super().__init__()
+        self.kernel_size, self.sigma, self.stride = kernel_size, sigma, stride
+        self.register_buffer("kernel", _gauss_kernel(kernel_size, sigma, 2).to(device))
+
+    def forward(self, x):
+        return F.conv2d(x, self.kernel, stride=self.stride, padding=self.kernel_size // 2)
+
+
+class GaussianBlur1D(nn.Module):
+    """other_field.py:158-168."""
+
+    def __init__(self, kernel_size=5, sigma=1.0, stride=2, device="cuda"):
+        super().__init__()
+        self.kernel_size, self.sigma, self.stride = kernel_size, sigma, stride
+        self.register_buffer("kernel", _gauss_kernel(kernel_size, sigma, 1).to(device))
+
+    def forward(self, x):
+        return F.conv1d(x, self.kernel, stride=self.stride, padding=self.kernel_size // 2)
+
+
 class TensoSDF(nn.Module):
     def __init__(self, gridSize, aabb, device="cuda", sdf_n_comp=36, sdf_dim=256, app_dim=128, init_n_levels=3, sdf_multires=0):
         super().__init__()
+        self.kernel_size, self.sigma = 5, 0.5                       # fields.py:34-36
+        self.gaussian1d = GaussianBlur1D(self.kernel_size, self.sigma, stride=1, device=device)
+        self.gaussian2d = GaussianBlur2D(self.kernel_size, self.sigma, stride=1, device=device)
         if sdf_multires != 0:
             raise NotImplementedError("the fused decoder instantiates sdf_multires=0 (configs/shape/*: default)")
         self.sdf_n_comp, self.sdf_dim, self.app_dim, self.device = sdf_n_comp, sdf_dim, app_dim, device
@@ -70,6 +125,24 @@ class TensoSDF(nn.Module):
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
         return [{"params": self.sdf_line, "lr": lr_init_spatialxyz}, {"params": self.sdf_plane, "lr": lr_init_spatialxyz},
                 {"params": self.sdf_mat.parameters(), "lr": lr_init_network}]
+
+    # parameter-only regularisers (device-resident torch; they never touch a ray)
+    def TV_loss_sdf(self, reg):
+        """fields.py:133-138."""
+        total = 0
+        for i in range(self.nplane):
+            total = total + reg(self.sdf_plane[i]) + reg(self.sdf_line[i])
+        return total
+
+    def grid_gaussian_loss(self):
+        """fields.py:301-309: squared distance of every plane / line to its Gaussian-blurred self (borders excluded)."""
+        total, k = 0.0, self.kernel_size // 2
+        for i in range(self.nplane):
+            pg = self.gaussian2d(self.sdf_plane[i].permute(1, 0, 2, 3)).permute(1, 0, 2, 3)
+            lg = self.gaussian1d(self.sdf_line[i].permute(1, 0, 2, 3).squeeze(-1)).unsqueeze(-1).permute(1, 0, 2, 3)
+            total = total + torch.sum((self.sdf_plane[i][..., k:-k, k:-k] - pg[..., k:-k, k:-k]).square())
+            total = total + torch.sum((self.sdf_line[i][..., k:-k, :] - lg[..., k:-k, :]).square())
+        return total
 
     def forward(self, xyz_sampled, level_vol):
         """fields.py:262-299 -> [N, 1+app_dim]."""
@@ -256,7 +329,8 @@ class ShapeShadingNetwork(nn.Module):
     Without autograd the whole forward is ONE launch of tf_shape_shade_fwd (three 128-wide MLPs, encodings, cube taps, FG
     LUT, sRGB).  With autograd the same arithmetic is composed from device-resident torch ops (MLP products = library GEMMs)
     and the HIP cube-map autograd ops of EnvLight, so that gradients reach the MLPs, the environment map and -- through the
-    normals / reflective directions / roughness -- the SDF.  `rad_mlp` (has_radiance_field) and human lights are not built."""
+    normals / reflective directions / roughness -- the SDF.  `rad_mlp` (has_radiance_field: 161-128-128-3 on [feat, xyz,
+    embed4(view), normal], fields.py:407-417,476-483) is a torch module in both modes; human lights are not built."""
     default_cfg = {"human_light": False, "sphere_direction": False, "light_pos_freq": 8, "inner_init": -0.95, "light_exp_max": 0.0,
                    "app_feats_dim": 128, "has_radiance_field": False, "radiance_field_step": 0, "mat_pos_multires": -1,
                    "fg_lut_path": "assets/bsdf_256_256.bin"}
@@ -269,6 +343,8 @@ class ShapeShadingNetwork(nn.Module):
         if self.cfg["human_light"] or self.cfg["sphere_direction"] or self.cfg["mat_pos_multires"] >= 0:
             raise NotImplementedError("round 1 covers human_light=False, sphere_direction=False, mat_pos_multires=-1 (configs/shape/syn)")
         fd, em = self.cfg["app_feats_dim"], self.cfg["light_exp_max"]
+        if self.cfg["has_radiance_field"]:
+            self.rad_mlp = _predictor3(fd + 3 + 27 + 3, 3, nn.Sigmoid())      # pos_multires=0 (raw xyz), dir_multires=4
         self.mat_mlp = _predictor3(fd, 5, nn.Sigmoid())
         path = self.cfg["fg_lut_path"]
         if path and os.path.exists(path):
@@ -307,16 +383,28 @@ class ShapeShadingNetwork(nn.Module):
             self._op_version = ver
         return self._op
 
+    def _wants_radiance(self, step):
+        return bool(self.cfg["has_radiance_field"]) and step is not None and step > self.cfg["radiance_field_step"]
+
+    def _radiance(self, points, normals, view_dirs, feat):
+        """fields.py:476-483 on normalised / patched normals and normalised view directions."""
+        from ..encodings import posenc
+        return self.rad_mlp(torch.cat([feat, points, posenc(view_dirs, 4), normals], -1))
+
+    @staticmethod
+    def _unit_inputs(normals, view_dirs):
+        normals = F.normalize(normals, dim=-1)
+        bad = (normals[:, :2].sum(-1) == 0.0)[:, None]
+        normals = torch.where(bad, torch.tensor([0.0, 1e-6, 1.0], device=normals.device), normals)
+        return normals, F.normalize(view_dirs, dim=-1)
+
     # ------------------------------------------------------------------ differentiable composition
-    def _composed(self, points, normals, view_dirs, feat, inter_results):
+    def _composed(self, points, normals, view_dirs, feat, inter_results, want_rad=False):
         from ..encodings import ide5, linear_to_srgb, posenc
         env = self.envlight
         if not hasattr(env, "specular"):
             env.build_mips()
-        normals = F.normalize(normals, dim=-1)
-        bad = (normals[:, :2].sum(-1) == 0.0)[:, None]
-        normals = torch.where(bad, torch.tensor([0.0, 1e-6, 1.0], device=normals.device), normals)
-        view_dirs = F.normalize(view_dirs, dim=-1)
+        normals, view_dirs = self._unit_inputs(normals, view_dirs)
         NoV = (normals * view_dirs).sum(-1, keepdim=True)
         reflective = NoV * normals * 2 - view_dirs
         mat = self.mat_mlp(feat)
@@ -340,7 +428,7 @@ class ShapeShadingNetwork(nn.Module):
         color = linear_to_srgb(diffuse_color + specular_color).clamp(0.0, 1.0)
         occ_info = {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
         if not inter_results:
-            return color, None, occ_info
+            return color, (self._radiance(points, normals, view_dirs, feat) if want_rad else None), occ_info
         c01 = lambda t: t.clamp(0.0, 1.0)
         inter = {"specular_albedo": specular_albedo, "specular_ref": c01(specular_ref), "specular_direct_light": direct_light,
                  "specular_light": c01(linear_to_srgb(specular_light)), "specular_color": c01(linear_to_srgb(specular_color)),
@@ -351,18 +439,18 @@ class ShapeShadingNetwork(nn.Module):
 
     def forward(self, points, normals, view_dirs, feature_vectors, human_poses=None, inter_results=False, step=None):
         """fields.py:448-567 -> (color [N,3], None, occ_info) or, with inter_results, (color, occ_info, intermediate dict)."""
-        if self.cfg["has_radiance_field"] and step is not None and step > self.cfg["radiance_field_step"]:
-            raise NotImplementedError("rad_mlp (has_radiance_field) is not built")
+        want_rad = self._wants_radiance(step) and not inter_results
         if points.shape[0] == 0:
             z = lambda c: torch.zeros(0, c, device=points.device)
             occ_info = {"reflective": z(1), "occ_prob": z(1), "roughness": z(1)}
-            return (z(3), occ_info, {}) if inter_results else (z(3), None, occ_info)
+            return (z(3), occ_info, {}) if inter_results else (z(3), z(3) if want_rad else None, occ_info)
         needs_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or normals.requires_grad
                                                    or feature_vectors.requires_grad)
         if needs_graph or inter_results:
-            return self._composed(points, normals, view_dirs, feature_vectors, inter_results)
+            return self._composed(points, normals, view_dirs, feature_vectors, inter_results, want_rad)
         color, occ_prob, roughness, reflective = self._fused()(points, normals, view_dirs, feature_vectors)
-        return color, None, {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
+        rad = self._radiance(points, *self._unit_inputs(normals, view_dirs), feature_vectors) if want_rad else None
+        return color, rad, {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
 
     def predict_materials(self, points, feature_vectors):
         """fields.py:569-575: raw mat_mlp outputs (no albedo / roughness remapping, as in the reference)."""

@@ -79,7 +79,9 @@ class MaterialRenderer(nn.Module):
                                     sdf_dim=kw["sdf_dim"], app_dim=kw["app_dim"], sdf_multires=kw.get("sdf_multires", 0))
         self.deviation_net = SingleVarianceNetwork(self.cfg["inv_s_init"], self.cfg["std_act"]).to(self.device)
         sd = ckpt["network_state_dict"]
-        self.sdf_network.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("sdf") and "gaussian" not in k})
+        own = self.sdf_network.state_dict()                       # materialRenderer.py:166-173: model dict updated by the trained one
+        own.update({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("sdf")})
+        self.sdf_network.load_state_dict(own)
         self.deviation_net.load_state_dict({k.split(".", 1)[1]: v for k, v in sd.items() if k.startswith("deviation")})
         for p in list(self.sdf_network.parameters()) + list(self.deviation_net.parameters()):
             p.requires_grad = False

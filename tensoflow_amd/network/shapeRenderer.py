@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from .. import march, ops
 from ..autograd import CompositeFn, SdfAlphaFn
 from ..surface import _neus_weights
-from .fields import ShapeShadingNetwork, SingleVarianceNetwork, TensoSDF
+from .fields import ShapeShadingNetwork, SingleVarianceNetwork, TensoSDF, TVLoss
 
 
 class AlphaGridMask(nn.Module):
@@ -44,7 +44,7 @@ class ShapeRenderer(nn.Module):
         "n_samples": 64, "n_importance": 64, "up_sample_steps": 4, "perturb": 1.0, "anneal_end": 50000,
         "train_ray_num": 1024, "test_ray_num": 2048, "clip_sample_variance": True,
         "apply_occ_loss": True, "apply_tv_loss": True, "apply_sparse_loss": True, "apply_hessian_loss": True,
-        "apply_gaussian_loss": False, "occ_loss_step": 20000, "gaussianLoss_step": 20000,
+        "apply_gaussian_loss": False, "occ_loss_step": 20000, "occ_loss_max_pn": 2048, "occ_sdf_thresh": 0.01, "gaussianLoss_step": 20000,
         "device": "cuda", "gridSize": [512, 512, 512], "aabb": [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]], "step_ratio": 0.5,
         "alphaMask_thres": 0.0001, "marched_weights_thres": 0.0001, "sdf_n_comp": 16, "app_n_comp": 36, "sdf_dim": 128,
         "app_dim": 128, "sdf_multires": 0, "max_levels": 1, "has_radiance_field": False, "radiance_field_step": 0,
@@ -85,6 +85,7 @@ class ShapeRenderer(nn.Module):
                                      "radiance_field_step": self.cfg["radiance_field_step"], "app_feats_dim": self.cfg["app_dim"]}
         self.color_network = ShapeShadingNetwork(self.cfg["shader_config"], device=self.device)
         self.sdf_inter_fun = lambda x: self.sdf_network.sdf(x, None)
+        self.tv_reg = TVLoss()
 
     # ------------------------------------------------------------------------------ bookkeeping
     def update_stepSize(self, gridSize, max_levels):
@@ -113,14 +114,12 @@ class ShapeRenderer(nn.Module):
         return ckpt
 
     def load_ckpt(self, ckpt):
-        """shapeRenderer.py:355-362.  Reference checkpoints also carry the Gaussian-blur buffers of a regulariser that is not
-        built here (`sdf_network.gaussian*`): those keys are skipped, every other key must match."""
+        """shapeRenderer.py:355-362 (strict: every key of a reference checkpoint has a home, incl. the Gaussian-blur buffers)."""
         if "alphaMask.aabb" in ckpt:
             length = int(np.prod(ckpt["alphaMask.shape"]))
             vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
             self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"], vol.float())
-        sd = {k: v for k, v in ckpt["network_state_dict"].items() if "gaussian" not in k}
-        self.load_state_dict(sd)
+        self.load_state_dict(ckpt["network_state_dict"])
 
     def upsample_sdf_grid(self, res_target):
         new_res, max_levels = self.sdf_network.upsample_volume_grid(torch.as_tensor(res_target))
@@ -185,13 +184,14 @@ class ShapeRenderer(nn.Module):
     # ------------------------------------------------------------------------------ sampling + rendering
     @torch.no_grad()
     def sample_ray(self, rays_o, dirs, near, far, perturb, radiis=None, rays_cos=None):
-        """shapeRenderer.py:871-932 (deterministic form: perturb = 0, clip_sample_variance = False) -> packed
-        t_starts, t_ends, ray_indices (int64, bit-exact)."""
-        if perturb > 0:
-            raise NotImplementedError("stratified jitter of sample_ray is not built (pass perturb_overwrite=0)")
+        """shapeRenderer.py:871-932 -> packed t_starts, t_ends, ray_indices (int64; bit-exact against the reference for
+        perturb = 0).  perturb > 0: one uniform offset per ray of +-1/n_samples (:888-890, torch.rand on the device);
+        clip_sample_variance: the up-sampling sharpness 64 * 2^i is capped by the learned inv_s (:905-907)."""
+        t_rand = (torch.rand(rays_o.shape[0], 1, device=rays_o.device) - 0.5) if perturb > 0 else None
+        cap = float(self._inv_s()) if self.cfg["clip_sample_variance"] else None
         return march.sample_ray(self._field(), rays_o, dirs, near, far, radiis, rays_cos, float(self.base_radii),
                                 n_samples=self.cfg["n_samples"], n_importance=self.cfg["n_importance"],
-                                up_steps=self.cfg["up_sample_steps"])
+                                up_steps=self.cfg["up_sample_steps"], t_rand=t_rand, inv_s_cap=cap)
 
     def compute_sdf_alpha(self, points, level, dists, dirs, cos_anneal_ratio, step, is_train):
         """shapeRenderer.py:995-1025 -> alpha, gradients, feature_vector, inv_s [N], sdf, hessian (None when not training)."""
@@ -217,8 +217,6 @@ class ShapeRenderer(nn.Module):
     def render(self, ray_batch, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True, step=None):
         """shapeRenderer.py:934-963."""
         perturb = self.cfg["perturb"] if perturb_overwrite < 0 else perturb_overwrite
-        if not is_train:
-            perturb = 0
         o, d, dirs, radiis, cos = ray_batch["rays_o"], ray_batch["rays_d"], ray_batch["dirs"], ray_batch["radiis"], ray_batch["rays_cos"]
         t0, t1, ridx = self.sample_ray(o, dirs, near, far, perturb, radiis=radiis, rays_cos=cos)
         return self.render_core(o, d, dirs, radiis, cos, t0, t1, ridx, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
@@ -241,14 +239,19 @@ class ShapeRenderer(nn.Module):
         levels = torch.log2(self.compute_ball_radii(mid[:, None], radiis[ray_indices], rays_cos[ray_indices]) / self.base_radii)
         alpha, gradients, feat, inv_s, sdf, hessian = self.compute_sdf_alpha(points, levels, dists, viewdir, cos_anneal_ratio, step, is_train)
         normals = F.normalize(gradients, dim=-1)
-        color, _, occ_info = self.color_network(points, normals, -viewdir, feat, None, step=step)
+        color, radiance, occ_info = self.color_network(points, normals, -viewdir, feat, None, step=step)
         gradient_error = (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2
         zero = torch.zeros(1, device=rays_o.device)
-        vals = torch.cat([color, gradients], -1).contiguous()
+        vals = [color, gradients] + ([radiance, occ_info["roughness"]] if radiance is not None else [])
+        vals = torch.cat(vals, -1).contiguous()
         if torch.is_grad_enabled() and (alpha.requires_grad or vals.requires_grad):
             weights, acc, out = CompositeFn.apply(alpha, vals, ray_indices, rn)
-        else:
-            weights, acc, out = ops.composite(alpha, ray_indices, vals, rn)
+        else:                                               # the kernel composites up to 8 value channels per launch
+            outs = []
+            for c0 in range(0, vals.shape[1], 8):
+                weights, acc, o = ops.composite(alpha, ray_indices, vals[:, c0:c0 + 8].contiguous(), rn)
+                outs.append(o)
+            out = outs[0] if len(outs) == 1 else torch.cat(outs, -1)
         acc = acc[:, None]
         rgb = out[:, :3]
         if self.cfg["isBGWhite"]:
@@ -256,6 +259,15 @@ class ShapeRenderer(nn.Module):
         normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * torch.tensor([0.0, 0.0, 1.0], device=rays_o.device), dim=-1)
         outputs = {"ray_rgb": rgb, "gradient_error": gradient_error, "acc": acc, "sample_num": N / max(rn, 1), "normal": normal,
                    "std": torch.mean(1 / inv_s) if N > 0 else zero}
+        if radiance is not None:                                   # has_radiance_field and step > radiance_field_step (:1195-1206)
+            outputs["radiance"] = out[:, 6:9] + (1 - acc) if self.cfg["isBGWhite"] else out[:, 6:9]
+            outputs["roughness_weights"] = out[:, 9].clone().detach()
+        if self.cfg["apply_occ_loss"]:
+            outputs["loss_occ"] = self.compute_occ_loss(occ_info, points, sdf, normals, viewdir, step) if N > 0 else zero
+        if self.cfg["apply_gaussian_loss"] and step is not None and step > self.cfg["gaussianLoss_step"]:
+            outputs["loss_gaussian"] = self.sdf_network.grid_gaussian_loss() if N > 0 else zero
+        if self.cfg["apply_tv_loss"]:
+            outputs["loss_tv_sdf"] = self.sdf_network.TV_loss_sdf(self.tv_reg)
         if self.cfg["apply_sparse_loss"]:
             outputs["loss_sparse"] = torch.exp(-20.0 * sdf.abs()).mean() if N > 0 else zero
         if self.cfg["apply_hessian_loss"]:
@@ -265,6 +277,39 @@ class ShapeRenderer(nn.Module):
         if not is_train:
             outputs.update(self._validation_outputs(rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step))
         return outputs
+
+    @torch.no_grad()
+    def _traced_occlusion(self, points, dirs, sn0, sn1):
+        """Sum of the NeuS weights along (points, dirs) up to the unit sphere: get_intersection (utils/network_utils.py:172-202),
+        sn0 uniform + sn1 importance field evaluations per ray in tf_sdf_forward -> [n,1] (0 for points outside r = 0.999)."""
+        occ = torch.zeros(points.shape[0], 1, device=points.device)
+        inside = points.norm(dim=-1) < 0.999
+        if bool(inside.any()):
+            p, d = points[inside].contiguous(), dirs[inside].contiguous()
+            dtx, xtx = (p * d).sum(-1, keepdim=True), (p ** 2).sum(-1, keepdim=True)
+            max_dist = -dtx + torch.sqrt((dtx ** 2 - xtx + 1).clamp(min=0) + 1e-6)
+            field, inv_s = self._field(), float(self._inv_s())
+            z = max_dist * torch.linspace(0, 1, sn0, device=p.device)[None]
+            w = _neus_weights(field, inv_s, z, p, d)
+            z_new = march._sample_pdf_det(z, w, sn1)
+            occ[inside] = _neus_weights(field, inv_s, z_new, p, d).sum(-1, keepdim=True)
+        return occ
+
+    def compute_occ_loss(self, occ_info, points, sdf, gradients, dirs, step):
+        """shapeRenderer.py:1027-1103: L1 between the predicted occlusion probability (inner_weight net) and the traced one on
+        up to occ_loss_max_pn near-surface, front-facing samples."""
+        zero = torch.zeros(1, device=points.device)
+        if step is None or step < self.cfg["occ_loss_step"]:
+            return zero
+        inner = ~((self.aabb[0] > points) | (points > self.aabb[1])).any(-1)
+        mask = inner & ((gradients * dirs).sum(-1) < 0) & (sdf.abs() < self.cfg["occ_sdf_thresh"])
+        idx = torch.nonzero(mask)[:, 0]
+        if idx.numel() > self.cfg["occ_loss_max_pn"]:
+            idx = idx[torch.randperm(idx.numel(), device=idx.device)[:self.cfg["occ_loss_max_pn"]]].sort().values
+        if idx.numel() == 0:
+            return zero
+        gt = self._traced_occlusion(points[idx].detach(), occ_info["reflective"][idx].detach(), 64, 16)
+        return F.l1_loss(occ_info["occ_prob"][idx], gt)
 
     @torch.no_grad()
     def _validation_outputs(self, rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step):
@@ -283,19 +328,7 @@ class ShapeRenderer(nn.Module):
         feat = self.sdf_network(points.contiguous(), level.reshape(-1).contiguous())[..., 1:]
         _, occ_info, inter = self.color_network(points, normals, -viewdirs, feat.contiguous(), None, inter_results=True, step=step)
         # traced occlusion along the reflected ray: 128 uniform + 9 importance field evaluations per pixel
-        refl = occ_info["reflective"]
-        occ_gt = torch.zeros(rn, 1, device=rays_o.device)
-        inside = points.norm(dim=-1) < 0.999
-        if bool(inside.any()):
-            p, d = points[inside], refl[inside]
-            dtx, xtx = (p * d).sum(-1, keepdim=True), (p ** 2).sum(-1, keepdim=True)
-            max_dist = -dtx + torch.sqrt((dtx ** 2 - xtx + 1).clamp(min=0) + 1e-6)
-            field, inv_s = self._field(), float(self._inv_s())
-            z = max_dist * torch.linspace(0, 1, 128, device=p.device)[None]
-            w = _neus_weights(field, inv_s, z, p, d)
-            z_new = march._sample_pdf_det(z, w, 9)
-            w = _neus_weights(field, inv_s, z_new, p, d)
-            occ_gt[inside] = w.sum(-1, keepdim=True)
+        occ_gt = self._traced_occlusion(points, occ_info["reflective"], 128, 9)
         out["occ_prob_gt"] = occ_gt
         out.update({k: v * inner for k, v in inter.items()})
         return out

@@ -117,7 +117,7 @@ def test_module_tensosdf(golden, dev):
     from tensoflow_amd.network.fields import TensoSDF
     g = golden("tensosdf_r32_l3")
     m = TensoSDF(torch.tensor([32, 32, 32]), AABB, device=dev, init_n_levels=3)
-    m.load_state_dict({k: v for k, v in g.sd.items() if "gaussian" not in k})
+    m.load_state_dict(g.sd)
     with torch.no_grad():
         out = m(g["pts"].to(dev), g["level"].to(dev))
         assert rel_err(out.cpu(), g["out_lvl"]) < TOL

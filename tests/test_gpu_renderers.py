@@ -18,13 +18,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _shape_renderer(g, dev):
+def _shape_renderer(g, dev, **over):
     from tensoflow_amd.network.shapeRenderer import ShapeRenderer
     cfg = dict(gridSize=[32, 32, 32], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False, isBGWhite=True,
                has_radiance_field=False, clip_sample_variance=False, device="cuda", nerfDataType=True, inv_s_init=0.3)
+    cfg.update(over)
     r = ShapeRenderer(cfg, training=False)
     missing, unexpected = r.load_state_dict(g.sd, strict=False)
-    assert not unexpected and all("FG_LUT" in k or "envlight.base" in k or "outer_light" in k for k in missing), (missing, unexpected)
+    assert not unexpected and all("FG_LUT" in k or "envlight.base" in k or "outer_light" in k or "gaussian" in k for k in missing), (missing, unexpected)
     cn = r.color_network
     cn.envlight.specular = [g[f"env_spec{i}"].to(dev) for i in range(3)]       # injected pre-filtered stack, as the generator did
     cn.envlight.diffuse = g["env_diffuse"].to(dev)
@@ -127,6 +128,45 @@ def test_shape_renderer_training_gradients(golden, dev):
         checked += 1
     print("checked", checked, "worst l2", worst)
     assert checked == len(g.grad)
+
+
+def test_shape_renderer_late_training_golden(golden, dev):
+    """render_core at step 30000 with the switches of configs/shape/syn/compressor.yaml on: radiance field (rad_mlp), occlusion
+    loss (traced with 64 + 16 field evaluations per sample), TV and Gaussian regularisers, frozen-no-more inv_s -- outputs and
+    the gradients of all 47 trainable tensors vs the reference."""
+    g = golden("march_late_r32")
+    r = _shape_renderer(g, dev, has_radiance_field=True, radiance_field_step=20000, apply_occ_loss=True, occ_loss_step=10000,
+                        occ_sdf_thresh=0.05, apply_gaussian_loss=True, gaussianLoss_step=20000, freeze_inv_s_step=8000)
+    c = lambda k: g[k].to(dev)
+    with torch.no_grad():
+        t0, t1, ridx = r.sample_ray(c("rays_o"), c("dirs"), c("near"), c("far"), 0, radiis=c("radiis"), rays_cos=c("rays_cos"))
+        assert torch.equal(ridx.cpu(), g["ray_indices"])
+        fused = r.render_core(c("rays_o"), c("dirs"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"),
+                              None, cos_anneal_ratio=0.6, step=30000, is_train=True)
+    out = r.render_core(c("rays_o"), c("dirs"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"), None,
+                        cos_anneal_ratio=0.6, step=30000, is_train=True)
+    for res, tag in ((fused, "fused"), (out, "autograd")):
+        for k in ("ray_rgb", "acc", "normal", "radiance", "roughness_weights", "std", "loss_occ", "loss_gaussian", "loss_tv_sdf", "loss_sparse"):
+            assert rel_err(res[k].detach().cpu().reshape(g["rc/" + k].shape), g["rc/" + k]) < TOL, (tag, k)
+        assert rel_err(res["loss_hessian"].detach().cpu(), g["rc/loss_hessian"]) < 2e-3
+    w = c("bwd_w")
+    loss = ((out["ray_rgb"] * w).sum() + (out["radiance"] * w.flip(0)).sum() + out["acc"].sum() + 0.1 * out["gradient_error"].mean()
+            + out["loss_occ"].sum() + 1e-3 * out["loss_gaussian"] + out["loss_tv_sdf"] + 0.1 * out["loss_sparse"])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    checked = 0
+    for name, p in r.named_parameters():
+        if name in g.grad:
+            assert p.grad is not None, name
+            l2 = float((p.grad.cpu() - g.grad[name]).norm() / (g.grad[name].norm() + 1e-20))
+            assert l2 < 2e-3, (name, l2)
+            checked += 1
+    assert checked == len(g.grad) == 47
+    # stratified jitter: offsets of at most +-1/n_samples, still packed and sorted per ray
+    with torch.no_grad():
+        torch.manual_seed(0)
+        j0, j1, jr = r.sample_ray(c("rays_o"), c("dirs"), c("near"), c("far"), 1.0, radiis=c("radiis"), rays_cos=c("rays_cos"))
+    assert (jr[1:] >= jr[:-1]).all() and (j1 >= j0).all() and jr.numel() > 0 and not torch.equal(j0[: min(j0.numel(), t0.numel())], t0[: min(j0.numel(), t0.numel())])
 
 
 def test_shape_renderer_alpha_mask_and_nvs(golden, dev):

@@ -16,8 +16,16 @@ def test_shape_renderer_state_dict_and_groups(golden):
     r = ShapeRenderer(SHAPE_CFG, training=False)
     sd = r.state_dict()
     # the golden holds the reference ShapeRenderer's state_dict minus the keys its generator strips (tools/gen_golden.py:275)
-    stripped = lambda k: "FG_LUT" in k or "envlight.base" in k or "outer_light" in k
+    stripped = lambda k: "FG_LUT" in k or "envlight.base" in k or "outer_light" in k or "gaussian" in k
     assert {k for k in sd if not stripped(k)} == set(g.sd)
+    # the late-training golden keeps the Gaussian buffers and has the radiance MLP: the full key set matches
+    gl = golden("march_late_r32")
+    rl = ShapeRenderer({**SHAPE_CFG, "has_radiance_field": True}, training=False)
+    strip2 = lambda k: "FG_LUT" in k or "envlight.base" in k or "outer_light" in k
+    assert {k for k in rl.state_dict() if not strip2(k)} == set(gl.sd)
+    for k, v in gl.sd.items():
+        assert tuple(rl.state_dict()[k].shape) == tuple(v.shape), k
+    assert torch.allclose(rl.state_dict()["sdf_network.gaussian2d.kernel"], gl.sd["sdf_network.gaussian2d.kernel"])
     for k, v in g.sd.items():
         assert tuple(sd[k].shape) == tuple(v.shape), k
     assert abs(float(r.stepSize) - float(g["step_size"])) < 1e-7 and abs(float(r.base_radii) - float(g["base_radii"])) < 1e-7
@@ -49,7 +57,6 @@ def test_shape_renderer_ckpt_layout_and_upsample():
     assert set(ck["kwargs"]) == {"aabb", "gridSize", "sdf_n_comp", "appearance_n_comp", "sdf_dim", "app_dim", "sdf_multires",
                                  "alphaMask_thres", "marched_weights_thres", "step_ratio", "max_levels"}
     r2 = ShapeRenderer({**SHAPE_CFG, "gridSize": [16, 16, 16], "max_levels": 1}, training=False)
-    ck["network_state_dict"]["sdf_network.gaussian_kernel"] = torch.zeros(3)        # reference-only buffer: skipped
     r2.load_ckpt(ck)
     assert torch.equal(r2.alphaMask.alpha_volume[0, 0], vol)
     for (k, a), (_, b) in zip(r.state_dict().items(), r2.state_dict().items()):

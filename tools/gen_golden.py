@@ -278,6 +278,53 @@ def gen_march():
          env_spec2=spec[2], step_size=r.stepSize, base_radii=r.base_radii, **arr, **grads)
 
 
+def gen_march_late():
+    """ShapeRenderer.render_core late in training (step 30000, configs/shape/syn/compressor.yaml switches): radiance field on
+    (rad_mlp, 'radiance' / 'roughness_weights'), occlusion loss (compute_occ_loss -> get_intersection 64 + 16), TV and Gaussian
+    regularisers; plus the gradients of every parameter under a loss touching all of them."""
+    from network.shapeRenderer import ShapeRenderer
+    from tensoflow_amd.synth import pinhole_rays
+    R = 32
+    cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
+               isBGWhite=True, has_radiance_field=True, radiance_field_step=20000, clip_sample_variance=False, apply_occ_loss=True,
+               occ_loss_step=10000, occ_sdf_thresh=0.05, device="cpu", database_name="tensoSDF/compressor", nerfDataType=True,
+               apply_gaussian_loss=True, gaussianLoss_step=20000, inv_s_init=0.3, freeze_inv_s_step=8000)
+    torch.manual_seed(6033)
+    r = ShapeRenderer(cfg, training=False)
+    net = r.sdf_network
+    perturb_(list(net.sdf_plane) + list(net.sdf_line), 0.02, 1)
+    g = torch.Generator().manual_seed(17)
+    cn = r.color_network
+    perturb_([p for n, p in cn.named_parameters() if "original1" in n], 0.05, 9)
+    spec = [0.5 * torch.randn(6, s, s, 3, generator=g) - 0.7 for s in (16, 8, 4)]
+    diff = 0.5 * torch.randn(6, 4, 4, 3, generator=g) - 0.7
+    cn.envlight.specular, cn.envlight.diffuse = spec, diff
+    u = torch.linspace(0, 1, 32)
+    lut = torch.stack(torch.meshgrid(u, u, indexing="ij"), -1)
+    cn.FG_LUT = torch.stack([0.9 * (1 - lut[..., 1]) * lut[..., 0] + 0.05, 0.1 * (1 - lut[..., 0]) ** 2], -1)[None].contiguous()
+    r.eval()
+    rn = 64
+    o, d, radii, cos = [torch.from_numpy(a) for a in pinhole_rays(rn, seed=12)]
+    near, far = r.near_far_from_sphere(o, d)
+    with torch.no_grad():
+        t0, t1, ridx = r.sample_ray(o, d, near, far, 0, radiis=radii, rays_cos=cos)
+    hp = torch.zeros(rn, 3, 4)
+    w = torch.rand(rn, 3, generator=g)
+    r.zero_grad()
+    out = r.render_core(o, d, d, radii, cos, t0, t1, ridx, hp, cos_anneal_ratio=0.6, step=30000, is_train=True)
+    arr = dict(rays_o=o, dirs=d, radiis=radii, rays_cos=cos, near=near, far=far, t_starts=t0, t_ends=t1, ray_indices=ridx, bwd_w=w)
+    for k in ("ray_rgb", "acc", "normal", "radiance", "roughness_weights", "std", "loss_occ", "loss_gaussian", "loss_tv_sdf",
+              "loss_sparse", "loss_hessian"):
+        arr["rc/" + k] = out[k]
+    loss = ((out["ray_rgb"] * w).sum() + (out["radiance"] * w.flip(0)).sum() + out["acc"].sum() + 0.1 * out["gradient_error"].mean()
+            + out["loss_occ"].sum() + 1e-3 * out["loss_gaussian"] + out["loss_tv_sdf"] + 0.1 * out["loss_sparse"])
+    loss.backward()
+    grads = {"grad/" + k: p.grad for k, p in r.named_parameters() if p.grad is not None and "envlight" not in k}
+    sd = {k: v for k, v in r.state_dict().items() if "FG_LUT" not in k and "envlight.base" not in k and "outer_light" not in k}
+    save("march_late_r32", sd=sd, fg_lut=cn.FG_LUT, env_diffuse=diff, env_spec0=spec[0], env_spec1=spec[1], env_spec2=spec[2],
+         loss=loss.detach(), **arr, **grads)
+
+
 def gen_refine():
     """MaterialRenderer.trace_sdf_with_mesh (materialRenderer.py:316-343) on a sphere mesh + a TensoSDF of the same sphere."""
     from network.fields import TensoSDF
@@ -390,7 +437,7 @@ def gen_march_grad():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad", "march_grad"]
+    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad", "march_grad", "march_late"]
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
