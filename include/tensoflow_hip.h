@@ -397,6 +397,16 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                   float* flow_logjac /* [pn, sd+ss] = log max(4 pi^2 HoV sin(theta), 1e-6) of the flow slots (NIS loss,
                                         fields.py:1275,1312), may be NULL */,
                   tf_stream_t stream);
+/* The sampler of the NON-NIS pass of shade_mixed (nis_sample False / flows not yet active; the pass whose colours
+ * MCShadingNetwork.forward returns in eval, fields.py:1467-1473): nf fixed cosine directions (sample_diffuse_directions,
+ * fields.py:824-856) followed by ss fixed specular directions -- the GGX half-vector warp of the Fibonacci samples fixed_s [ss,2]
+ * by the point's (squared) roughness with pdf D NoH / (4 VoH) x the elevation Jacobian (sample_specular_directions,
+ * fields.py:858-903).  Slot layout [0,nf) diffuse | [nf,nf+ss) specular; outputs as tf_shade_dirs.  az_jitter / az_jitter_s [pn]
+ * = the training-mode random azimuths (random_azimuth) or NULL. */
+int tf_shade_dirs_fixed(const float* normals, const float* view, const float* metallic, const float* roughness,
+                        const float* albedo, const float* fixed_d, const float* az_jitter, int32_t nf,
+                        const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
+                        uint8_t* spec_mask, uint8_t* live, tf_stream_t stream);
 /* Backward of the BRDF weights wrt the per-point materials (training): g_wgt [pn,T,3] ->
  * g_albedo [pn,3], g_metallic [pn], g_roughness [pn] (overwritten).  dirs / wgt are tf_shade_dirs' outputs. */
 int tf_shade_dirs_bwd(const float* normals, const float* view, const float* metallic, const float* roughness,

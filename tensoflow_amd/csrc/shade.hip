@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
     const float* __restrict__ logq_d, int sd, const float* __restrict__ fixed_d, const float* __restrict__ az_jitter, int nf,
-    const float* __restrict__ ang_s, const float* __restrict__ logq_s, int ss, long long pn, float* __restrict__ dirs,
+    const float* __restrict__ ang_s, const float* __restrict__ logq_s, const float* __restrict__ fixed_s,
+    const float* __restrict__ az_jitter_s, int ss, long long pn, float* __restrict__ dirs,
     float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live,
     float* __restrict__ flow_logjac) {
   const int T = sd + nf + ss;
@@ -83,7 +84,25 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
   const float alb[3] = {albedo[3 * pt], albedo[3 * pt + 1], albedo[3 * pt + 2]};
   float dir[3], pdf;
   const bool is_spec = slot >= sd + nf;
-  if (slot < sd || is_spec) {
+  if (is_spec && fixed_s) {
+    // fixed specular set: GGX half-vector warp of the Fibonacci samples by the point's (squared) roughness
+    // (sample_specular_directions, fields.py:858-903) -- the sampler of the non-NIS pass of shade_mixed
+    const int s = slot - sd - nf;
+    float phi = fixed_s[2 * s] * kPi * 2.f;
+    const float el = fixed_s[2 * s + 1];
+    if (az_jitter_s) phi = fmodf(phi + az_jitter_s[pt] * kPi * 2.f, kTwoPi);
+    const float ct = sqrtf(fmaxf((1.f - el) / fmaxf(1.f + (rough * rough - 1.f) * el, kEPS), kEPS));
+    const float st = sqrtf(fmaxf(1.f - ct * ct, kEPS));
+    const float cxh = cosf(phi) * st, cyh = sinf(phi) * st;
+    float H[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) H[k] = cxh * F.x[k] + cyh * F.y[k] + ct * F.n[k];
+    const float VoH = sat(dot3(v, H));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dir[k] = VoH * H[k] * 2.f - v[k];
+    const float NoH = fmaxf(ct, 0.f);
+    pdf = ggx_d(NoH, rough) * NoH / fmaxf(4.f * VoH, kEPS) * (cosf((1.f - el) * kPi / 2.f) * kPi / 2.f);
+  } else if (slot < sd || is_spec) {
     // flow sample = half-vector angles in [0,1]^2 (fields.py:1085-1108 / :1164-1188)
     const long long r = is_spec ? pt * ss + (slot - sd - nf) : pt * sd + slot;
     const float* ang = is_spec ? ang_s : ang_d;
@@ -319,22 +338,41 @@ extern "C" int tf_view_angles(const float* normals, const float* view, int64_t p
   return TF_OK;
 }
 
+static int shade_dirs_launch(const float* normals, const float* view, const float* metallic, const float* roughness,
+                             const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
+                             const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, const float* fixed_s,
+                             const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
+                             uint8_t* live, float* flow_logjac, tf_stream_t stream, const char* who) {
+  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "%s: negative size", who);
+  if (pn == 0 || sd + nf + ss == 0) return TF_OK;
+  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "%s: null pointer", who);
+  TF_REQUIRE((sd == 0 || (ang_d && logq_d)) && (nf == 0 || fixed_d) && (ss == 0 || (((ang_s && logq_s) || fixed_s) && spec_mask)),
+             TF_EINVAL, "%s: null sample pointer for a non-empty sample set", who);
+  TF_REQUIRE(!(fixed_s && ang_s), TF_EINVAL, "%s: the specular set is either flow-sampled (ang_s) or fixed (fixed_s), not both", who);
+  long long work = (long long)pn * (sd + nf + ss);
+  shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
+                                                                          logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, fixed_s,
+                                                                          az_jitter_s, ss, pn, dirs, wgt, spec_mask, live,
+                                                                          fixed_s ? nullptr : flow_logjac);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+
 extern "C" int tf_shade_dirs(const float* normals, const float* view, const float* metallic, const float* roughness,
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
                              int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
                              tf_stream_t stream) {
-  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs: negative size");
-  if (pn == 0 || sd + nf + ss == 0) return TF_OK;
-  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "tf_shade_dirs: null pointer");
-  TF_REQUIRE((sd == 0 || (ang_d && logq_d)) && (nf == 0 || fixed_d) && (ss == 0 || (ang_s && logq_s && spec_mask)),
-             TF_EINVAL, "tf_shade_dirs: null sample pointer for a non-empty sample set");
-  long long work = (long long)pn * (sd + nf + ss);
-  shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
-                                                                          logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, ss,
-                                                                          pn, dirs, wgt, spec_mask, live, flow_logjac);
-  TF_LAUNCH_CHECK("tf_shade_dirs");
-  return TF_OK;
+  return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
+                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, stream, "tf_shade_dirs");
+}
+
+extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                   const float* albedo, const float* fixed_d, const float* az_jitter, int32_t nf,
+                                   const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
+                                   uint8_t* spec_mask, uint8_t* live, tf_stream_t stream) {
+  return shade_dirs_launch(normals, view, metallic, roughness, albedo, nullptr, nullptr, 0, fixed_d, az_jitter, nf, nullptr, nullptr,
+                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, stream, "tf_shade_dirs_fixed");
 }
 
 extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,

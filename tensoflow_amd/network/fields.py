@@ -202,7 +202,7 @@ class MCShadingNetwork(nn.Module):
         v, f = self.ray_tracer
         sd = {k: t.detach() for k, t in self.state_dict().items()}
         self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
-                                exp_max=self.cfg["inner_light_exp_max"])
+                                exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"])
         return self._shader
 
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001, lr_init_envlight=0.001):
@@ -282,11 +282,21 @@ class MCShadingNetwork(nn.Module):
 
     @torch.no_grad()
     def _forward_eval(self, pts, view_dirs, normals):
+        """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
+        pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
+        from ..shading import aux_outputs
         sh = self._shader if self._shader is not None else self.shader()
-        out = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"])
-        outputs = {"albedo": out["albedo"], "roughness": out["roughness"], "metallic": out["metallic"],
-                   "normal": (F.normalize(normals, dim=-1) + 1) / 2, "specular_rays_id": out["specular_rays_id"]}
-        return out["colors"], outputs
+        nrm = (F.normalize(normals, dim=-1) + 1) / 2
+        # the unweighted light maps (diffuse_light, visibility ...) average over EVERY ray, incl. those whose BRDF weight is zero:
+        # the zero-weight culling of the throughput path is switched off here
+        sh.cull_dead_rays = False
+        fx = sh.shade_fixed(pts, view_dirs, normals)
+        outputs = {"albedo": fx["albedo"], "roughness": fx["roughness"], "metallic": fx["metallic"], "normal": nrm, **aux_outputs(fx)}
+        nis = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"])
+        outputs.update({k + "_nis": v for k, v in {"albedo": nis["albedo"], "roughness": nis["roughness"], "metallic": nis["metallic"],
+                                                  "normal": nrm, "rgb_pr": nis["colors"], **aux_outputs(nis)}.items()})
+        outputs["specular_rays_id_nis"] = nis["specular_rays_id"]
+        return fx["colors"], outputs
 
 
 def _predictor3(feats_dim, out_dim, final, run_dim=128):

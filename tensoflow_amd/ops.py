@@ -671,6 +671,23 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     return dirs, wgt, mask.bool(), live
 
 
+def shade_dirs_fixed(normals, view, metallic, roughness, albedo, fixed_d, fixed_s, az_jitter=None, az_jitter_s=None):
+    """Direction sets of the non-NIS pass of shade_mixed: nf fixed cosine + ss fixed GGX-warped directions per point.
+    -> dirs [pn,nf+ss,3], wgt [pn,nf+ss,3], spec_mask [pn,ss] bool, live [pn,nf+ss] u8."""
+    lib = L.load()
+    pn, nf, ss = normals.shape[0], fixed_d.shape[0], fixed_s.shape[0]
+    dev = normals.device
+    dirs = torch.empty(pn, nf + ss, 3, dtype=torch.float32, device=dev)
+    wgt = torch.empty(pn, nf + ss, 3, dtype=torch.float32, device=dev)
+    mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
+    live = torch.empty(pn, nf + ss, dtype=torch.uint8, device=dev)
+    g = lambda t: None if t is None else _f(t)
+    L.check(lib.tf_shade_dirs_fixed(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                                    _p(_f(albedo)), _p(_f(fixed_d)), _p(g(az_jitter)), nf, _p(_f(fixed_s)), _p(g(az_jitter_s)), ss, pn,
+                                    _p(dirs), _p(wgt), _p(mask, torch.uint8), _p(live, torch.uint8), _stream()), "tf_shade_dirs_fixed")
+    return dirs, wgt, mask.bool(), live
+
+
 def shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss):
     lib = L.load()
     pn = normals.shape[0]

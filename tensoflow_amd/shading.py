@@ -121,6 +121,21 @@ class ShadeOutputs(dict):
         return rid
 
 
+def aux_outputs(out):
+    """The auxiliary per-point outputs of shade_mixed (fields.py:1232-1251) from a ShadeOutputs dict: diffuse / specular light and
+    colour maps, visibility and indirect light of the unmasked specular rays.  Device-resident torch reductions over [pn,T,3]
+    (evaluation images only; the throughput path never asks for them)."""
+    from .encodings import linear_to_srgb
+    lights, hit, smask, nd = out["lights"], out["hit"], out["specular_mask"], out["n_diffuse"]
+    ns = smask.shape[1]
+    m = smask[..., None].float()
+    spec_l, spec_hit = lights[:, nd:], hit[:, nd:, None].float()
+    c01 = lambda t: t.clamp(0, 1)
+    return {"diffuse_light": c01(linear_to_srgb(lights[:, :nd].mean(1))), "specular_light": c01(linear_to_srgb((spec_l * m).sum(1) / ns)),
+            "diffuse_color": c01(linear_to_srgb(out["diffuse_lin"])), "specular_color": c01(linear_to_srgb(out["specular_lin"])),
+            "visibility": 1 - (spec_hit * m).sum(1) / ns, "indirect_light": (spec_l * spec_hit * m).sum(1) / ns}
+
+
 class FlowParams:
     """One TensoFlow (nis planes/lines + nis_mat + 2 coupling nets) resident on the device."""
 
@@ -138,7 +153,7 @@ class MCShader:
     """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
-                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3):
+                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         self.cull_dead_rays = True      # skip BVH + inner light for rays whose weight is exactly 0 (result unchanged)
@@ -161,6 +176,7 @@ class MCShader:
         self.point_prep = ops.PointPrep(self.mat_packed, self.flow_d.packed, self.flow_s.packed, self.pred,
                                         [self.flow_d.mat, self.flow_s.mat], self.aabb)
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)
+        self.fixed_s = fibonacci_samples(n_fixed_specular).to(device)      # non-NIS pass only (fields.py:739-742)
         self._latent = {}
         self._order = {}
         self.sort_rays = True           # trace each point's rays in direction-sorted order (results unchanged)
@@ -218,6 +234,23 @@ class MCShader:
         return lights, hit, inters
 
     @torch.no_grad()
+    def shade_fixed(self, pts, view_dirs, normals):
+        """The non-NIS pass of shade_mixed (nis_sample=False, fields.py:1075-1235 with the `else` samplers): the fixed cosine set
+        for the diffuse lobe and the fixed GGX-warped set for the specular lobe (sample_diffuse_directions /
+        sample_specular_directions, :824-903).  Same output dict as `shade` (without the flow arrays)."""
+        pts = pts.to(self.device).float().contiguous()
+        pn = pts.shape[0]
+        va = ops.view_angles(normals, view_dirs)
+        metallic, rough, albedo, _, _ = self.point_prep(pts, va)
+        dirs, wgt, smask, live = ops.shade_dirs_fixed(normals, view_dirs, metallic, rough, albedo, self.fixed_d, self.fixed_s)
+        T, nd, ns = dirs.shape[1], self.fixed_d.shape[0], self.fixed_s.shape[0]
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
+        colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, nd, ns)
+        return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
+                            specular_mask=smask, hit=hit.reshape(pn, T), live=live, view_angles=va, dirs=dirs, wgt=wgt,
+                            hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=nd)
+
+    @torch.no_grad()
     def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None):
         """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)"""
         pts = pts.to(self.device).float().contiguous()
@@ -246,4 +279,4 @@ class MCShader:
         return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                     specular_mask=smask, hit=hit.reshape(pn, T), live=live, view_angles=va,
                     diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
-                    hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env)
+                    hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=n_diff)

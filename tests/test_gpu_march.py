@@ -150,15 +150,26 @@ def test_module_mcshading(golden, dev):
     from tensoflow_amd.network.fields import MCShadingNetwork
     g = golden("shading_small")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
-    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, nis_diffuse_sample_num=sn_d,
+    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
                nis_specular_sample_num=sn_s)
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     missing, unexpected = m.load_state_dict(g.sd, strict=False)
     assert not missing, missing                                  # every parameter of the mirror exists in the reference checkpoint
     m.shader()
-    colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
-    assert rel_err(colors.cpu(), g.out["rgb_pr_nis"]) < TOL
-    assert rel_err(outputs["albedo"].cpu(), g.out["albedo"]) < TOL
+    colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)   # autograd on: flow pass
+    assert rel_err(colors.detach().cpu(), g.out["rgb_pr_nis"]) < TOL
+    assert rel_err(outputs["albedo"].detach().cpu(), g.out["albedo"]) < TOL
+    # eval (no autograd, step=None): the reference runs the fixed-sampler pass (-> colors and the plain outputs) and the
+    # flow-sampler pass (-> the *_nis outputs), fields.py:1467-1473
+    with torch.no_grad():
+        colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
+    assert rel_err(colors.cpu(), g["colors"]) < TOL
+    assert rel_err(outputs["rgb_pr_nis"].cpu(), g.out["rgb_pr_nis"]) < TOL
+    for k in ("albedo", "roughness", "metallic", "diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility",
+              "indirect_light"):
+        assert rel_err(outputs[k].cpu(), g.out[k]) < TOL, k
+        if k + "_nis" in g.out:
+            assert rel_err(outputs[k + "_nis"].cpu(), g.out[k + "_nis"]) < TOL, k + "_nis"
     env = m.outer_light.direct_light(g["env_dirs"].to(dev)[None, None])
     assert env.shape == (1, 1, g["env_dirs"].shape[0], 3) and rel_err(env[0, 0].detach().cpu(), g["env_direct"]) < TOL
     env.sum().backward()                                          # cube lookup has a HIP backward
@@ -231,7 +242,7 @@ def test_mcshading_training_step_golden(golden, dev):
     from tensoflow_amd.network.fields import MCShadingNetwork
     g = golden("shading_grad")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
-    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, nis_diffuse_sample_num=sn_d,
+    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
                nis_specular_sample_num=sn_s)
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     missing, _ = m.load_state_dict(g.sd, strict=False)

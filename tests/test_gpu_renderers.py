@@ -203,7 +203,7 @@ def test_material_renderer(golden, dev):
     from tensoflow_amd.network.materialRenderer import MaterialRenderer
     gs, gr = golden("shading_small"), golden("refine_r32")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in gs["sn"]]
-    shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, nis_diffuse_sample_num=sn_d,
+    shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
                       nis_specular_sample_num=sn_s)
     geo_ckpt = {"step": 0, "kwargs": {"aabb": AABB, "gridSize": [32, 32, 32], "max_levels": 3, "sdf_n_comp": 36, "sdf_dim": 256, "app_dim": 128},
                 "network_state_dict": {**gr.sd, "deviation_network.variance": torch.log(gr["inv_s"]) / 10.0}}
@@ -223,7 +223,8 @@ def test_material_renderer(golden, dev):
     assert not missing
     with torch.no_grad():
         out = m2.shade(gs["pts"].to(dev), gs["view_in"].to(dev), gs["normals_in"].to(dev), None, False)
-    assert rel_err(out["rgb_pr"].cpu(), gs.out["rgb_pr_nis"]) < TOL and rel_err(out["albedo"].cpu(), gs.out["albedo"]) < TOL
+    assert rel_err(out["rgb_pr"].cpu(), gs["colors"]) < TOL and rel_err(out["rgb_pr_nis"].cpu(), gs.out["rgb_pr_nis"]) < TOL
+    assert rel_err(out["albedo"].cpu(), gs.out["albedo"]) < TOL and rel_err(out["visibility"].cpu(), gs.out["visibility"]) < TOL
     mats = m2.predict_materials(batch_size=500)
     assert mats["albedo"].shape == (gs["verts"].shape[0], 3) and np.isfinite(mats["roughness"]).all()
     ck = m2.ckpt_to_save()
