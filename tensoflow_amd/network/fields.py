@@ -173,7 +173,9 @@ class MCShadingNetwork(nn.Module):
     `ray_tracer` is the (vertices, triangles) pair the reference hands to raytracing.RayTracer (materialRenderer.py:147-149)."""
     default_cfg = {"diffuse_sample_num": 512, "specular_sample_num": 256, "outer_light_version": "envlight", "light_exp_max": 5.0,
                    "inner_light_exp_max": 5.0, "human_lights": False, "gridSize": [512, 512, 512], "nis_diffuse_sample_num": 64,
-                   "nis_specular_sample_num": 32, "light_reso": 128, "mat_grid": 512}
+                   "nis_specular_sample_num": 32, "light_reso": 128, "mat_grid": 512, "reg_min_max": True,
+                   "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000, "nis_update_interval_diffuse": 1000,
+                   "nis_update_interval_specular": 1000, "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500}
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -209,6 +211,53 @@ class MCShadingNetwork(nn.Module):
         """fields.py:1580-1595."""
         from ..trainer import material_param_groups
         return material_param_groups(self, lr_init_spatialxyz, lr_init_network, lr_init_envlight)
+
+    def update_step(self, step):
+        """fields.py:1050-1065: every nis_update_interval steps from nis_start_iter on, the frozen sampling copies take the weights of
+        the trained flows."""
+        done = []
+        for name in ("diffuse", "specular"):
+            start, every = self.cfg[f"nis_start_iter_{name}"], self.cfg[f"nis_update_interval_{name}"]
+            if (step + 1) >= start and (step + 1 - start) % every == 0:
+                src, dst = getattr(self, f"flow_{name}"), getattr(self, f"flow_{name}_copy")
+                dst.load_state_dict(src.state_dict())
+                for p in dst.parameters():
+                    p.requires_grad = False
+                setattr(self, f"use_flow_{name}_copy", True)
+                self._shader = None
+                done.append(name)
+        return done
+
+    def TV_loss(self):
+        """fields.py:1525-1530."""
+        reg = TVLoss()
+        total = 0
+        for i in range(3):
+            total = total + reg(self.mat_plane[i]) + reg(self.mat_line[i])
+        return total
+
+    def material_regularization(self, pts, normals, metallic, roughness, albedo, step):
+        """fields.py:1547-1578 (the active terms): 0.1 TV of the material grids + the range hinge of the first 2000 steps."""
+        reg = self.TV_loss() * 0.1
+        if self.cfg["reg_min_max"] and step is not None and step < 2000:
+            reg = reg + torch.sum(torch.clamp(roughness - 0.9 ** 2, min=0)) + torch.sum(torch.clamp(0.1 ** 2 - roughness, min=0))
+            reg = reg + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0))
+        return reg.reshape(1)
+
+    def predict_outer_lights_pts(self, pts):
+        return self.outer_light.direct_light(pts)
+
+    def env_light(self, h, w, gamma=True, no_grad=True):
+        """fields.py:1475-1510: lat-long image [h,w,3] of the learned environment light."""
+        from ..encodings import linear_to_srgb
+        dev = self.outer_light.base.device
+        azs = torch.linspace(1.0, 0.0, w, device=dev) * np.pi * 2 - np.pi / 2
+        els = torch.linspace(1.0, -1.0, h, device=dev) * np.pi / 2
+        els, azs = torch.meshgrid(els, azs, indexing="ij")
+        xyz = torch.stack([torch.cos(els) * torch.cos(azs), torch.cos(els) * torch.sin(azs), torch.sin(els)], -1).reshape(h * w, 3)
+        with torch.set_grad_enabled(not no_grad):
+            lights = self.predict_outer_lights_pts(xyz.contiguous())
+        return (linear_to_srgb(lights) if gamma else lights).reshape(h, w, 3)
 
     def predict_materials(self, pts):
         """fields.py:1010-1017 -> metallic [pn,1], roughness [pn,1] (squared-roughness convention, remapped), albedo [pn,3]."""

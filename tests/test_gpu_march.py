@@ -170,6 +170,11 @@ def test_module_mcshading(golden, dev):
         assert rel_err(outputs[k].cpu(), g.out[k]) < TOL, k
         if k + "_nis" in g.out:
             assert rel_err(outputs[k + "_nis"].cpu(), g.out[k + "_nis"]) < TOL, k + "_nis"
+    img = m.env_light(16, 32)
+    assert img.shape == (16, 32, 3) and torch.isfinite(img).all() and not img.requires_grad
+    reg = m.material_regularization(g["pts"].to(dev), None, outputs["metallic"], outputs["roughness"], outputs["albedo"], 100)
+    assert reg.shape == (1,) and float(reg) >= 0
+    assert m.update_step(998) == [] and m.update_step(999) == ["diffuse", "specular"] and m.use_flow_diffuse_copy
     env = m.outer_light.direct_light(g["env_dirs"].to(dev)[None, None])
     assert env.shape == (1, 1, g["env_dirs"].shape[0], 3) and rel_err(env[0, 0].detach().cpu(), g["env_direct"]) < TOL
     env.sum().backward()                                          # cube lookup has a HIP backward
