@@ -489,7 +489,11 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
         if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
       }
     }
+#ifdef TF_ABLATE_HALF_DMA   // dev-only timing ablation: half the weight bytes are fetched (results are garbage)
+    if (c >= 4 && ((c - 4) & 1) == 0) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
+#else
     if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
+#endif
 #ifndef TF_SPLIT_AT_BOUNDARY
     if (c == 5 && NEXT >= 0) tf_bsplit<SL16, TIN, TERMS>(bn, NEXT, in);
 #endif
