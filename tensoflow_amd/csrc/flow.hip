@@ -276,8 +276,13 @@ __device__ __forceinline__ void gather_outputs(const f32x16 (&oA)[1], const f32x
   }
 }
 
+// Occupancy: the kernel alternates matrix-core phases (the nets) and long vector phases (the spline); neither unit is busy more than
+// ~37 % of the time with two waves per SIMD, so the f16 variants are compiled for THREE (768 threads per workgroup, <= 168 VGPRs).
+#ifndef FLOW_WPB_H3
+#define FLOW_WPB_H3 12
+#endif
 template <bool SAMPLE, int MODE>
-__global__ void __launch_bounds__(512) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
+__global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
                                                    const float* __restrict__ P /*[2][pn][64]*/,
                                                    const float* __restrict__ latent, const float* __restrict__ jitter,
                                                    const float* __restrict__ xin, const long long* __restrict__ rays_id,
@@ -446,7 +451,7 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   }
   TF_REQUIRE(pn < (1LL << 31), TF_ESHAPE, "%s: pn must be < 2^31", who);
   const long long tiles = (m + 63) / 64;   // 64-row groups
-  const int waves_per_block = 8;
+  const int waves_per_block = h3 ? FLOW_WPB_H3 : 8;
   long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles
   if (precision == TF_PREC_F16)
