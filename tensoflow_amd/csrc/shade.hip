@@ -63,6 +63,11 @@ __device__ __forceinline__ float schlick_g1(float c, float a) {
   return c / (c * (1.f - k) + k + 1e-5f);
 }
 
+// 12-byte rows as ONE memory instruction (global_load_dwordx3 / global_store_dwordx3) instead of three strided dword accesses
+struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
+__device__ __forceinline__ void st3(float* p, float x, float y, float z) { *reinterpret_cast<F3*>(p) = F3{x, y, z}; }
+
 __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
@@ -157,8 +162,8 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
       w[k] = keep ? D * fres * geo * inv : 0.f;
     }
   }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { dirs[3 * e + k] = dir[k]; wgt[3 * e + k] = w[k]; }
+  st3(dirs + 3 * e, dir[0], dir[1], dir[2]);
+  st3(wgt + 3 * e, w[0], w[1], w[2]);
   if (live) live[e] = (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f) ? 1 : 0;
 }
 
@@ -288,13 +293,16 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
   float d[3] = {0, 0, 0}, s[3] = {0, 0, 0};
   for (int t = lane; t < T; t += 64) {
     const long long r = pt * T + t, e = r * 3;
-    const float w0 = wgt[e], w1 = wgt[e + 1], w2 = wgt[e + 2];
+    const F3 w = ld3(wgt + e);
+    const float w0 = w.x, w1 = w.y, w2 = w.z;
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
       if (hit[r]) {
-        l0 = hit_lights[e]; l1 = hit_lights[e + 1]; l2 = hit_lights[e + 2];
+        const F3 hl = ld3(hit_lights + e);
+        l0 = hl.x; l1 = hl.y; l2 = hl.z;
       } else if (depth[r] > near_eps) {
-        cube_fetch_rgb(env, env_res, dirs[e], dirs[e + 1], dirs[e + 2], l0, l1, l2);
+        const F3 dd = ld3(dirs + e);
+        cube_fetch_rgb(env, env_res, dd.x, dd.y, dd.z, l0, l1, l2);
         l0 = expf(l0); l1 = expf(l1); l2 = expf(l2);
       }
     }
