@@ -252,6 +252,9 @@ int64_t tf_bvh_build_host(const float* verts_host, int64_t nv, const int32_t* fa
  * scale xyz: coordinate = origin + q * scale); `tris12_host` [nf,12] receives (a, e1 = b - a, e2 = c - a, 0 0 0) per
  * triangle of the reordered soup (full precision: hits and depths are exact).  Child reference: >= 0 pair index,
  * < -1 leaf = ~((first_triangle << 3) | count), -1 none.  Returns the number of pairs (> 0) or a negative TfStatus. */
+/* dwords per record of the traversal layout tf_bvh_pack_host writes (a build-time property of the library: 8 = child pairs,
+ * 16 = 4-wide nodes); the caller sizes `pairs_host` as [n_nodes / 2 + 1, tf_bvh_record_dwords()]. */
+int32_t tf_bvh_record_dwords(void);
 int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const float* tris_host, int64_t nf,
                          uint32_t* pairs_host, float* tris12_host, float* frame_host);
 

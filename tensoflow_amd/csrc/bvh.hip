@@ -20,14 +20,22 @@
 #endif
 #define BVH_CHUNK_MAX 512  // rays a wave takes from the global pool per atomic (shrinks towards BVH_CHUNK_MIN at the end)
 #define BVH_CHUNK_MIN 64
+#ifdef BVH_WIDE
+#define BVH_STACK 40       // 4-wide nodes: <= 13 levels (binary depth <= BVH_MAX_DEPTH = 25) x up to 3 postponed children per level
+#else
 #define BVH_STACK 32       // per-ray traversal stack entries; the builder bounds the tree depth to match
+#endif
 #ifndef BVH_LDS_STACK
 #define BVH_LDS_STACK 12   // of which in LDS (the rest is a per-lane scratch array, touched by the rare deep pile-ups only)
 #endif
 #ifndef BVH_WAVES
 #define BVH_WAVES 8        // resident 256-thread blocks per CU the kernel is compiled for (register budget)
 #endif
+#ifdef BVH_WIDE
+#define BVH_MAX_DEPTH 25   // deepest node level the builder may create (root = 0): 13 four-wide levels, <= 39 postponed children
+#else
 #define BVH_MAX_DEPTH 31   // deepest node level the builder may create (root = 0)
+#endif
 #ifndef BVH_LEAF_W
 #define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
 #endif
@@ -189,6 +197,37 @@ struct Packer {
     q[1] = ql[2] | (qh[0] << 16);
     q[2] = qh[1] | (qh[2] << 16);
   }
+#ifdef BVH_WIDE
+  // 4-wide record (16 dwords): an inner node's children are replaced by THEIR children where those are inner nodes too, so one
+  // step descends two levels of the binary tree: half the dependent fetches per ray.
+  //   dwords 3k .. 3k+2: quantised box of child k (k = 0..3, empty box for an unused slot); dwords 12..15: child references
+  int32_t emit(int64_t node) {
+    const TfBvhNode& nd = nodes[node];
+    const int64_t me = n_pairs++;
+    int64_t kids[4];
+    int nk = 0;
+    for (int c = 0; c < 2; ++c) {
+      const int64_t ch = nd.left + c;
+      if (nodes[ch].count == 0) { kids[nk++] = nodes[ch].left; kids[nk++] = nodes[ch].left + 1; }
+      else kids[nk++] = ch;
+    }
+    int32_t refs[4] = {-1, -1, -1, -1};
+    for (int k = 0; k < 4; ++k) {
+      if (k < nk) {
+        const TfBvhNode& ch = nodes[kids[k]];
+        quantise(ch.lo, ch.hi, pairs + 16 * me + 3 * k);
+        if (ch.count > 0) refs[k] = leaf_ref(ch);
+      } else {
+        const float elo[3] = {1.f, 1.f, 1.f}, ehi[3] = {0.f, 0.f, 0.f};
+        quantise(elo, ehi, pairs + 16 * me + 3 * k);
+      }
+    }
+    for (int k = 0; k < nk; ++k)
+      if (nodes[kids[k]].count == 0) refs[k] = emit(kids[k]);
+    for (int k = 0; k < 4; ++k) pairs[16 * me + 12 + k] = (uint32_t)refs[k];
+    return (int32_t)me;
+  }
+#else
   int32_t emit(int64_t node) {   // node is an inner node
     const TfBvhNode& nd = nodes[node];
     const int64_t me = n_pairs++;
@@ -204,8 +243,17 @@ struct Packer {
     pairs[8 * me + 7] = (uint32_t)refs[1];
     return (int32_t)me;
   }
+#endif
 };
 }  // namespace
+
+extern "C" int32_t tf_bvh_record_dwords(void) {
+#ifdef BVH_WIDE
+  return 16;
+#else
+  return 8;
+#endif
+}
 
 extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const float* tris_host, int64_t nf,
                                     uint32_t* pairs_host, float* tris12_host, float* frame_host) {
@@ -231,11 +279,17 @@ extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes
     P.org[k] = frame_host[k]; P.scl[k] = frame_host[3 + k];
   }
   if (root.count > 0) {
-    // the whole mesh is one leaf: a single pair whose second child is an empty box
+    // the whole mesh is one leaf: a single record whose other children are empty boxes
     P.quantise(root.lo, root.hi, pairs_host);
     const float elo[3] = {1.f, 1.f, 1.f}, ehi[3] = {0.f, 0.f, 0.f};
+#ifdef BVH_WIDE
+    for (int k = 1; k < 4; ++k) P.quantise(elo, ehi, pairs_host + 3 * k);
+    pairs_host[12] = (uint32_t)Packer::leaf_ref(root);
+    for (int k = 1; k < 4; ++k) pairs_host[12 + k] = (uint32_t)-1;
+#else
     P.quantise(elo, ehi, pairs_host + 3);
     pairs_host[6] = (uint32_t)Packer::leaf_ref(root); pairs_host[7] = (uint32_t)-1;
+#endif
     P.n_pairs = 1;
   } else {
     P.emit(0);
@@ -350,6 +404,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     return v;
   };
   auto retire = [&]() {
+#ifdef BVH_ABLATE_STORE   // dev-only timing ablation: results are not written
+    if (best == -123.f) A.depth[rid] = best;
+    rid = -1;
+    return;
+#endif
     A.depth[rid] = best;
     if (A.hit) A.hit[rid] = best < BVH_MAX_DIST ? 1 : 0;
     // 85 % of the integral's secondary rays miss; their position / normal rows are never read, and writing them cost 12 %
@@ -428,7 +487,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #endif
           const int enc = ~cur;
           const int first = enc >> 3, cnt = enc & 7;
+#ifdef BVH_ABLATE_LEAF    // dev-only timing ablation: no triangle is tested
+          for (int k = 0; k < 0; ++k) {
+#else
           for (int k = 0; k < cnt; ++k) {
+#endif
             const float4* T = A.tris + 3LL * (first + k);
             const float4 t0 = T[0], t1 = T[1], t2 = T[2];
             const float ax = t0.x, ay = t0.y, az = t0.z;
@@ -452,6 +515,29 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #ifdef BVH_STATS
           st_inner++;
 #endif
+#ifdef BVH_WIDE
+          const uint4* P = A.pairs + 4LL * cur;
+          const uint4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3];
+          float t0, t1, t2, t3;
+          const bool h0 = box_hit(q0.x, q0.y, q0.z, Ax, Ay, Az, Bx, By, Bz, best, t0);
+          const bool h1 = box_hit(q0.w, q1.x, q1.y, Ax, Ay, Az, Bx, By, Bz, best, t1);
+          const bool h2 = box_hit(q1.z, q1.w, q2.x, Ax, Ay, Az, Bx, By, Bz, best, t2);
+          const bool h3 = box_hit(q2.y, q2.z, q2.w, Ax, Ay, Az, Bx, By, Bz, best, t3);
+          int r0 = (int)q3.x, r1 = (int)q3.y, r2 = (int)q3.z, r3 = (int)q3.w;
+          // an unused slot (reference -1) holds an inverted box, which the symmetric slab test does NOT reject: mask it here
+          float k0 = (h0 && r0 != BVH_NONE) ? t0 : INFINITY, k1 = (h1 && r1 != BVH_NONE) ? t1 : INFINITY;
+          float k2 = (h2 && r2 != BVH_NONE) ? t2 : INFINITY, k3 = (h3 && r3 != BVH_NONE) ? t3 : INFINITY;
+          // sort the four (entry distance, reference) pairs ascending: 5-comparator network
+#define BVH_CSWAP(ka, ra, kb, rb) { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; kb = sw_ ? ka : kb; ka = tk_; \
+                                    const int tr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = tr_; }
+          BVH_CSWAP(k0, r0, k1, r1) BVH_CSWAP(k2, r2, k3, r3) BVH_CSWAP(k0, r0, k2, r2) BVH_CSWAP(k1, r1, k3, r3) BVH_CSWAP(k1, r1, k2, r2)
+#undef BVH_CSWAP
+          // postpone the farther hit children (farthest pushed first), descend into the nearest
+          if (k3 < INFINITY) push(r3);
+          if (k2 < INFINITY) push(r2);
+          if (k1 < INFINITY) push(r1);
+          cur = k0 < INFINITY ? r0 : pop();
+#else
           const uint4* P = A.pairs + 2LL * cur;
           const uint4 q0 = P[0], q1 = P[1];
           const int c0 = (int)q1.z, c1 = (int)q1.w;
@@ -469,6 +555,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           } else {
             cur = pop();
           }
+#endif
         }
       }
       if (DYN && !exhausted && __popcll(__ballot(cur == BVH_NONE)) >= BVH_REFILL) break;

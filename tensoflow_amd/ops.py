@@ -452,7 +452,8 @@ class Bvh:
         if n <= 0:
             L.check(int(n), "tf_bvh_build_host")
         self.n_nodes = int(n)
-        pairs = np.zeros((n // 2 + 1, 8), dtype=np.uint32)
+        rec = int(self.lib.tf_bvh_record_dwords())          # 8: child pairs; 16: 4-wide nodes (a build-time choice of the library)
+        pairs = np.zeros((n // 2 + 1, rec), dtype=np.uint32)
         tris12 = np.zeros((f.shape[0], 12), dtype=np.float32)
         self.frame = (C.c_float * 6)()
         npair = self.lib.tf_bvh_pack_host(nodes.ctypes.data, int(n), tris.ctypes.data, f.shape[0], pairs.ctypes.data, tris12.ctypes.data,

@@ -1,0 +1,19 @@
+"""Dev: run bench.py's headline pass against an alternative library build.  python tools/exp_bench_lib.py lib.so [points]"""
+import os, sys, json, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tensoflow_amd.lib as L
+if len(sys.argv) > 1 and sys.argv[1] != "-":
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch, bench
+from tensoflow_amd.shading import StageTimer
+from tensoflow_amd.synth import sphere_surface_points
+dev = torch.device("cuda:0")
+pn = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+sh, sd, verts, faces, aabb, unit = bench.build_scene(dev, 4, (224, 448, 256, 128))
+pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(pn, seed=6)]
+for _ in range(2): out = sh.shade(pts, view, nrm, 128, 128)
+t = StageTimer(); sh.timer = t
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): out = sh.shade(pts, view, nrm, 128, 128)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print(sys.argv[1] if len(sys.argv) > 1 else "-", f"{pn/dt/1e6:.3f} M points/s", {k: round(v[0] / 5, 2) for k, v in t.summary().items()}, "colors checksum", float(out["colors"].double().sum()))
