@@ -198,3 +198,23 @@ def test_ops_fail_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.cube_lookup(torch.zeros(6, 4, 4, 3), torch.zeros(5, 3))
+
+
+def test_late_round1_entry_points_validate(lib):
+    """Entry points added late in round 1 (fixed-sampler direction sets, cube-map direction gradient, the plain-f16 mode) validate
+    on the host before any launch."""
+    a = C.addressof((C.c_float * 4)())
+    assert lib.tf_bvh_record_dwords() in (8, 16)
+    # tf_shade_dirs_fixed: empty work is a no-op, negative sizes a shape error, a missing sample table an argument error
+    assert lib.tf_shade_dirs_fixed(None, None, None, None, None, None, None, 0, None, None, 0, 5, None, None, None, None, None) == 0
+    assert lib.tf_shade_dirs_fixed(None, None, None, None, None, None, None, -1, None, None, 4, 5, None, None, None, None, None) == -2
+    assert lib.tf_shade_dirs_fixed(a, a, a, a, a, a, None, 4, None, None, 4, 5, a, a, a, None, None) == -1 \
+        and b"null sample pointer" in lib.tf_last_error()
+    # tf_cube_lookup_bwd_dirs needs at least one of the two gradient outputs
+    assert lib.tf_cube_lookup_bwd_dirs(a, 4, a, 0, 0, a, None, None, None) == 0
+    assert lib.tf_cube_lookup_bwd_dirs(a, 4, a, 3, 0, a, None, None, None) == -1
+    assert lib.tf_cube_lookup_bwd_dirs(a, 0, a, 3, 0, a, a, a, None) == -2
+    # TF_PREC_F16 (2) is accepted by the flow / inner-light entry points (they proceed to the next check) and refused elsewhere
+    assert lib.tf_inner_light_fwd(None, None, None, None, 5, 5.0, 2, None, None, 0, None) == -1 and b"null pointer" in lib.tf_last_error()
+    assert lib.tf_inner_light_fwd(None, None, None, None, 5, 5.0, 9, None, None, 0, None) == -1 and b"unknown precision" in lib.tf_last_error()
+    assert lib.tf_sdf_forward(None, None, None, None, None, None, 5, None, None, 2, None, 0, None) != 0
