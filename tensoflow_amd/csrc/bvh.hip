@@ -36,6 +36,9 @@
 #else
 #define BVH_MAX_DEPTH 31   // deepest node level the builder may create (root = 0)
 #endif
+#ifndef BVH_TOP
+#define BVH_TOP 127        // pair records of the top of the tree kept in LDS per workgroup (4 KB; numbered breadth-first by the packer)
+#endif
 #ifndef BVH_LEAF_W
 #define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
 #endif
@@ -228,20 +231,37 @@ struct Packer {
     return (int32_t)me;
   }
 #else
-  int32_t emit(int64_t node) {   // node is an inner node
+  // Numbering: the first BVH_TOP records are the top of the tree in BREADTH-first order (every ray walks them: the kernel serves
+  // them from LDS), the rest depth-first (a subtree is contiguous).  A child's index is always larger than its parent's.
+  std::vector<int32_t> index_of;
+  void dfs_number(int64_t node) {
+    if (index_of[node] < 0) index_of[node] = (int32_t)n_pairs++;
+    for (int c = 0; c < 2; ++c)
+      if (nodes[nodes[node].left + c].count == 0) dfs_number(nodes[node].left + c);
+  }
+  void fill(int64_t node) {
     const TfBvhNode& nd = nodes[node];
-    const int64_t me = n_pairs++;
-    int32_t refs[2];
+    const int64_t me = index_of[node];
     for (int c = 0; c < 2; ++c) {
       const TfBvhNode& ch = nodes[nd.left + c];
       quantise(ch.lo, ch.hi, pairs + 8 * me + 3 * c);
-      refs[c] = ch.count > 0 ? leaf_ref(ch) : -1;
+      pairs[8 * me + 6 + c] = (uint32_t)(ch.count > 0 ? leaf_ref(ch) : index_of[nd.left + c]);
     }
     for (int c = 0; c < 2; ++c)
-      if (nodes[nd.left + c].count == 0) refs[c] = emit(nd.left + c);
-    pairs[8 * me + 6] = (uint32_t)refs[0];
-    pairs[8 * me + 7] = (uint32_t)refs[1];
-    return (int32_t)me;
+      if (nodes[nd.left + c].count == 0) fill(nd.left + c);
+  }
+  int32_t emit(int64_t root, int64_t n_nodes_total) {   // root is an inner node
+    index_of.assign((size_t)n_nodes_total, -1);
+    std::vector<int64_t> queue{root};
+    for (size_t head = 0; head < queue.size() && n_pairs < BVH_TOP; ++head) {
+      const int64_t nd = queue[head];
+      index_of[nd] = (int32_t)n_pairs++;
+      for (int c = 0; c < 2; ++c)
+        if (nodes[nodes[nd].left + c].count == 0) queue.push_back(nodes[nd].left + c);
+    }
+    dfs_number(root);
+    fill(root);
+    return 0;
   }
 #endif
 };
@@ -292,7 +312,11 @@ extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes
 #endif
     P.n_pairs = 1;
   } else {
+#ifdef BVH_WIDE
     P.emit(0);
+#else
+    P.emit(0, n_nodes);
+#endif
   }
   for (int64_t t = 0; t < nf; ++t) {
     const float* T = tris_host + 9 * t;
@@ -332,6 +356,7 @@ struct TraceArgs {
   const float* d;
   const unsigned char* live;
   long long m;
+  int n_top;                   // pair records [0, n_top) are served from LDS (breadth-first top of the tree)
   long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
   const int* order;            // [rays_per_origin] or null: the j-th ray traced of a point is its slot order[j]
   int hits_only;               // 1: pos / nrm rows are written for rays that hit only (nobody reads a miss's row)
@@ -355,9 +380,15 @@ struct TraceArgs {
 // 32 KB -- a ray keeps ~4 entries pending on average, the tree is 24 deep on the bench mesh).
 template <bool DYN>
 __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) {
-  __shared__ int stack[BVH_LDS_STACK * 256];
+  __shared__ int stack[(BVH_LDS_STACK + 1) * 256];   // + one dummy row: the target of predicated-off pushes
   int deep[BVH_STACK - BVH_LDS_STACK];
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef BVH_TOP_LDS   // dev-only experiment: a third of every ray's steps touch the same ~127 records at the top of the tree (the
+  // packer numbers them breadth-first, first); serving them from LDS changed nothing (19.7 vs 19.2 ms): node fetches are not the bound
+  __shared__ uint4 top[2 * BVH_TOP];
+  for (int i = tid; i < 2 * A.n_top; i += 256) top[i] = A.pairs[i];
+  __syncthreads();
+#endif
   const unsigned long long lt_mask = (1ULL << lane) - 1ULL;
   long long rid = -1;
   int cur = BVH_NONE, sp = 0, best_tri = -1;
@@ -538,12 +569,21 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           if (k1 < INFINITY) push(r1);
           cur = k0 < INFINITY ? r0 : pop();
 #else
-          const uint4* P = A.pairs + 2LL * cur;
-          const uint4 q0 = P[0], q1 = P[1];
+          uint4 q0, q1;
+#ifdef BVH_TOP_LDS
+          if (cur < A.n_top) {
+            q0 = top[2 * cur]; q1 = top[2 * cur + 1];
+          } else
+#endif
+          {
+            const uint4* P = A.pairs + 2LL * cur;
+            q0 = P[0]; q1 = P[1];
+          }
           const int c0 = (int)q1.z, c1 = (int)q1.w;
           float tl, tr;
           const bool hl = box_hit(q0.x, q0.y, q0.z, Ax, Ay, Az, Bx, By, Bz, best, tl);
           const bool hr = box_hit(q0.w, q1.x, q1.y, Ax, Ay, Az, Bx, By, Bz, best, tr);
+#ifndef BVH_PREDICATED   // default: one branch per case
           if (hl && hr) {
             const bool left_first = tl <= tr;
             push(left_first ? c1 : c0);                             // depth <= BVH_MAX_DEPTH bounds sp < BVH_STACK
@@ -555,6 +595,26 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           } else {
             cur = pop();
           }
+#else
+          // dev-only experiment (-DBVH_PREDICATED): the four cases as selects, the push an unconditional LDS write (to a dummy row
+          // when predicated off), the pop an unconditional LDS read, one rare wave-uniform branch for the scratch tail.  Results
+          // identical, time unchanged (19.7 vs 19.2 ms): the lane-mask algebra moves to the scalar unit instead of the branches
+          // (55 vs 59 scalar, 84 vs 74 vector instructions per step).
+          const bool both = hl && hr, any = hl || hr;
+          const bool left_first = tl <= tr;
+          const int near = (hl && (!hr || left_first)) ? c0 : c1;
+          const int far = left_first ? c1 : c0;
+          const int sp0 = sp;
+          const bool deep_push = both && sp0 >= BVH_LDS_STACK, deep_pop = !any && sp0 > BVH_LDS_STACK;
+          stack[((both && !deep_push) ? sp0 : BVH_LDS_STACK) * 256 + tid] = far;
+          int popped = stack[min(max(sp0 - 1, 0), BVH_LDS_STACK - 1) * 256 + tid];
+          if (__builtin_expect(__ballot(deep_push || deep_pop) != 0ULL, 0)) {
+            if (deep_push) deep[sp0 - BVH_LDS_STACK] = far;
+            if (deep_pop) popped = deep[sp0 - 1 - BVH_LDS_STACK];
+          }
+          cur = any ? near : (sp0 > 0 ? popped : BVH_NONE);
+          sp = any ? sp0 + (both ? 1 : 0) : max(sp0 - 1, 0);
+#endif
 #endif
         }
       }
@@ -581,6 +641,11 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
   A.pairs = reinterpret_cast<const uint4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
   for (int k = 0; k < 3; ++k) { A.org[k] = frame_host[k]; A.scl[k] = frame_host[3 + k]; }
   A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order;
+#ifdef BVH_NO_TOP   // dev-only switch: every record from global memory
+  A.n_top = 0;
+#else
+  A.n_top = (int)std::min<int64_t>(BVH_TOP, n_pairs);
+#endif
   TF_REQUIRE(!slot_order || m % rays_per_origin == 0, TF_ESHAPE, "tf_bvh_trace: slot_order needs m to be a multiple of rays_per_origin");
   A.off0 = origin_offset0; A.off1 = origin_offset1; A.counter = (unsigned long long*)work_counter;
   A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit; A.hits_only = hit_rows_only ? 1 : 0;

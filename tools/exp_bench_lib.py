@@ -10,6 +10,9 @@ from tensoflow_amd.synth import sphere_surface_points
 dev = torch.device("cuda:0")
 pn = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 sh, sd, verts, faces, aabb, unit = bench.build_scene(dev, 4, (224, 448, 256, 128))
+if os.environ.get("TF_BVH_STATIC"):          # dev experiment: one ray per lane, no refill (lanes of a wave stay in phase)
+    _trace = sh.bvh.trace
+    sh.bvh.trace = lambda *a, **k: _trace(*a, **{**k, "dynamic": False})
 pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(pn, seed=6)]
 for _ in range(2): out = sh.shade(pts, view, nrm, 128, 128)
 t = StageTimer(); sh.timer = t
