@@ -172,7 +172,10 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
         cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
         cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
       }
-      const float* mat = ws + kIdeMat;
+      // the 17 x 36 polynomial table is wave-uniform: read it through the scalar cache (s_load) -- as a generic pointer the reads
+      // were 44 flat_load_dwordx4 per tile, each tile start waiting on vmcnt(0) behind the weight DMAs in flight
+      const __attribute__((address_space(4))) float* mat =
+          (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
       // column of (d, mm) = (2^d - 1) + d + mm: every index below is a compile-time constant once the loops are unrolled
       // (a running `col++` counter left enc[] dynamically indexed, i.e. in scratch memory)
 #pragma unroll
