@@ -244,7 +244,8 @@ __global__ void __launch_bounds__(256) shape_shade_kernel(ShapeArgs A) {
         cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
         cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
       }
-      const float* mat = ws + kSIde;
+      // wave-uniform table: scalar-cache reads (see inner_light.hip)
+      const __attribute__((address_space(4))) float* mat = (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kSIde);
 #pragma unroll
       for (int d = 0; d < 5; ++d) {
         const float att = expf(-0.5f * (float)((1 << d) * ((1 << d) + 1)) * rough);
