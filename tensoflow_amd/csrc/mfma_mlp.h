@@ -133,25 +133,35 @@ typedef __attribute__((address_space(3))) void* tf_lptr_t;
 // by this file (tf_wait_vmcnt_barrier / tf_h3s_step / tf_stream_begin / tf_stream_end); its own vmcnt bookkeeping for other
 // loads stays safe (unknown extra operations in flight can only make a counted wait longer, never shorter).
 // M0 = LDS byte address of the piece (wave-uniform); lane l writes its 16 bytes at M0 + 16 l.
+template <int BYTE_OFFSET = 0>
 __device__ __forceinline__ void tf_dma16(const float* gsrc, float* ldst) {
 #ifndef TF_ABLATE_DMA   // dev-only timing ablation (tools/build_variant.sh): results are garbage when defined
 #ifdef TF_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((tf_gptr_t)gsrc, (tf_lptr_t)ldst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((tf_gptr_t)(gsrc + BYTE_OFFSET / 4), (tf_lptr_t)(ldst + BYTE_OFFSET / 4), 16, 0, 0);
 #else
+  // BYTE_OFFSET goes into the instruction's immediate offset field (one 64-bit address per slab instead of one per piece).
+  // The hardware adds that offset to the GLOBAL address and to the LDS address (M0 + offset + 16 * lane): `ldst` is therefore
+  // the LDS address of the wave's FIRST piece for all four.
   const unsigned laddr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(tf_lptr_t)ldst);
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(laddr), "v"(gsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off offset:%2" ::"s"(laddr), "v"(gsrc), "n"(BYTE_OFFSET) : "memory");
 #endif
 #endif
 }
 
 __device__ __forceinline__ void tf_slab_dma(const float* gthread /* slab + wave*1024 + lane*4 */, float* __restrict__ lbuf,
                                             int wave) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tf_dma16(gthread + i * 256, lbuf + (wave * 4 + i) * 256);
+  tf_dma16<0>(gthread, lbuf + wave * 1024);
+  tf_dma16<1024>(gthread, lbuf + wave * 1024);
+  tf_dma16<2048>(gthread, lbuf + wave * 1024);
+  tf_dma16<3072>(gthread, lbuf + wave * 1024);
 }
 
 __device__ __forceinline__ void tf_slab_dma_piece(const float* gthread, float* __restrict__ lbuf, int wave, int i) {
-  tf_dma16(gthread + i * 256, lbuf + (wave * 4 + i) * 256);
+  // `i` is a compile-time constant at every (unrolled) call site
+  if (i == 0) tf_dma16<0>(gthread, lbuf + wave * 1024);
+  else if (i == 1) tf_dma16<1024>(gthread, lbuf + wave * 1024);
+  else if (i == 2) tf_dma16<2048>(gthread, lbuf + wave * 1024);
+  else tf_dma16<3072>(gthread, lbuf + wave * 1024);
 }
 
 template <int N>
