@@ -3,6 +3,7 @@
 // weights, and the final reduction + sRGB.  Elementwise over pn*T slots; HBM-bound
 // (reads 12 B of flow output per slot, writes 24 B of direction + weight).
 #include "cube.h"
+#include "mfma_mlp.h"   // tf_sincos_small
 #include "tf_common.h"
 
 static constexpr float kPi = 3.14159265358979323846f;
@@ -68,6 +69,12 @@ struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 __device__ __forceinline__ F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
 __device__ __forceinline__ void st3(float* p, float x, float y, float z) { *reinterpret_cast<F3*>(p) = F3{x, y, z}; }
 
+// The kernel is vector-instruction bound (201 M slots x ~600 instructions per step of the bench), most of them inside libm:
+// sinf / cosf carry their large-argument path to every call site although every angle here is below 4 pi, powf(x, 5) and expf
+// their full-range scaffolding.  (tf_sincos_small: max abs error 1.2e-7 for |x| < 200.)
+__device__ __forceinline__ float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ ang_d,
@@ -98,7 +105,9 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     if (az_jitter_s) phi = fmodf(phi + az_jitter_s[pt] * kPi * 2.f, kTwoPi);
     const float ct = sqrtf(fmaxf((1.f - el) / fmaxf(1.f + (rough * rough - 1.f) * el, kEPS), kEPS));
     const float st = sqrtf(fmaxf(1.f - ct * ct, kEPS));
-    const float cxh = cosf(phi) * st, cyh = sinf(phi) * st;
+    float sphi, cphi;
+    tf_sincos_small(phi, sphi, cphi);
+    const float cxh = cphi * st, cyh = sphi * st;
     float H[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) H[k] = cxh * F.x[k] + cyh * F.y[k] + ct * F.n[k];
@@ -106,22 +115,26 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) dir[k] = VoH * H[k] * 2.f - v[k];
     const float NoH = fmaxf(ct, 0.f);
-    pdf = ggx_d(NoH, rough) * NoH / fmaxf(4.f * VoH, kEPS) * (cosf((1.f - el) * kPi / 2.f) * kPi / 2.f);
+    float sj, cj;
+    tf_sincos_small((1.f - el) * kPi / 2.f, sj, cj);
+    pdf = ggx_d(NoH, rough) * NoH / fmaxf(4.f * VoH, kEPS) * (cj * kPi / 2.f);
   } else if (slot < sd || is_spec) {
     // flow sample = half-vector angles in [0,1]^2 (fields.py:1085-1108 / :1164-1188)
     const long long r = is_spec ? pt * ss + (slot - sd - nf) : pt * sd + slot;
     const float* ang = is_spec ? ang_s : ang_d;
     const float lq = (is_spec ? logq_s : logq_d)[r];
     const float phi = ang[2 * r] * kTwoPi, theta = ang[2 * r + 1] * kHalfPi_;
-    const float st = sinf(theta), ct = cosf(theta);
-    const float cxh = st * cosf(phi), cyh = st * sinf(phi);
+    float st, ct, sphi, cphi;
+    tf_sincos_small(theta, st, ct);
+    tf_sincos_small(phi, sphi, cphi);
+    const float cxh = st * cphi, cyh = st * sphi;
     float H[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) H[k] = cxh * F.x[k] + cyh * F.y[k] + ct * F.n[k];
     const float HoV = sat(dot3(v, H));
 #pragma unroll
     for (int k = 0; k < 3; ++k) dir[k] = HoV * H[k] * 2.f - v[k];
-    pdf = expf(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(4.f * kPi * kPi * HoV * st, kEPS);
+    pdf = fast_exp(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(4.f * kPi * kPi * HoV * st, kEPS);
     // log of the (angles -> outgoing direction) Jacobian used by the NIS loss (fields.py:1275, :1312)
     if (flow_logjac) flow_logjac[pt * (sd + ss) + (is_spec ? sd + (slot - sd - nf) : slot)] = logf(fmaxf(4.f * kPi * kPi * HoV * st, kEPS));
   } else {
@@ -132,10 +145,13 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     if (az_jitter) az = fmodf(az + az_jitter[pt] * kPi * 2.f, kTwoPi);
     const float el_sqrt = sqrtf(el + 1e-7f);
     const float cz = sqrtf(1.f - el + 1e-7f);
-    const float cx = el_sqrt * cosf(az), cy = el_sqrt * sinf(az);
+    float saz, caz, sj, cj;
+    tf_sincos_small(az, saz, caz);
+    tf_sincos_small((1.f - el) * kPi / 2.f, sj, cj);
+    const float cx = el_sqrt * caz, cy = el_sqrt * saz;
 #pragma unroll
     for (int k = 0; k < 3; ++k) dir[k] = cx * F.x[k] + cy * F.y[k] + cz * F.n[k];
-    pdf = sat(dot3(dir, F.n)) / kPi * (cosf((1.f - el) * kPi / 2.f) * kPi / 2.f);
+    pdf = sat(dot3(dir, F.n)) / kPi * (cj * kPi / 2.f);
   }
   float w[3];
   if (!is_spec) {
@@ -150,7 +166,7 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     float Hs[3] = {v[0] + dir[0], v[1] + dir[1], v[2] + dir[2]};
     normalize3(Hs);
     const float HoV = sat(dot3(Hs, v));
-    const float f5 = powf(sat(1.f - HoV), 5.f);
+    const float f5 = pow5(sat(1.f - HoV));
     const float NoV = sat(dot3(F.n, v)), NoL = sat(dot3(F.n, dir)), NoH = sat(dot3(F.n, Hs));
     const float geo = schlick_g1(NoV, rough) * schlick_g1(NoL, rough);
     const float D = ggx_d(NoH, rough);
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
       } else if (depth[r] > near_eps) {
         const F3 dd = ld3(dirs + e);
         cube_fetch_rgb(env, env_res, dd.x, dd.y, dd.z, l0, l1, l2);
-        l0 = expf(l0); l1 = expf(l1); l2 = expf(l2);
+        l0 = fast_exp(l0); l1 = fast_exp(l1); l2 = fast_exp(l2);
       }
     }
     const float c0 = w0 * l0, c1 = w1 * l1, c2 = w2 * l2;

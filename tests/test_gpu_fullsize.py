@@ -130,3 +130,25 @@ def test_empty_inputs_are_noops(dev):
     assert depth.shape == (0,) and hit.shape == (0,)
     idx, count = ops.compact_mask(torch.empty(0, dtype=torch.uint8, device=dev))
     assert int(count) == 0
+
+
+def test_fixed_pass_full_size_properties(dev):
+    """The fixed-sampler pass (512 cosine + 256 GGX-warped directions per point) at the BASELINE field sizes: finite colours in
+    range, repeatable bits, specular mask consistent with the directions, and -- the flow being irrelevant to this pass -- no
+    dependence on the flow parameters."""
+    from tensoflow_amd.shading import MCShader
+    from tensoflow_amd.synth import random_mc_state, sphere_surface_points, sphere_torus_mesh
+    sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
+    verts, faces = sphere_torus_mesh(48, 96, 64, 32)
+    sh = MCShader(sd, verts, faces, AABB, 2.0 / 511, device=dev, n_fixed_diffuse=512, n_fixed_specular=256)
+    pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(4096, seed=11)]
+    out = sh.shade_fixed(pts, view, nrm)
+    c = out["colors"]
+    assert c.shape == (4096, 3) and torch.isfinite(c).all() and float(c.min()) >= 0.0
+    assert torch.equal(sh.shade_fixed(pts, view, nrm)["colors"], c)
+    d_spec = out["dirs"][:, 512:]
+    assert torch.equal(out["specular_mask"], (d_spec * torch.nn.functional.normalize(nrm, dim=-1)[:, None]).sum(-1) > 0)
+    assert out["dirs"].shape == (4096, 768, 3) and rel_err(out["dirs"].norm(dim=-1).cpu(), torch.ones(4096, 768)) < 1e-5
+    sd2 = {k: (v * 0.5 if "flow_" in k and v.is_floating_point() else v) for k, v in sd.items()}
+    sh2 = MCShader(sd2, verts, faces, AABB, 2.0 / 511, device=dev, n_fixed_diffuse=512, n_fixed_specular=256)
+    assert torch.equal(sh2.shade_fixed(pts, view, nrm)["colors"], c)
