@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AABB
+from conftest import AABB, rel_err
 
 pytestmark = pytest.mark.gpu
 
