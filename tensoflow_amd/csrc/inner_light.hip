@@ -61,6 +61,14 @@ __device__ __forceinline__ float relu(float x) { return tf_relu(x); }
 template <int K16, int TIN, int TERMS>
 __device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
                                                 const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
+#ifdef TF_ABLATE_EPILOGUE   // dev-only timing ablation: no bias read, no ReLU (results are garbage)
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = 0.f;
+  tf_layer_h3s<K16, 8, TIN, 0, TERMS>(S, FA, FB, in, out);
+  return;
+#endif
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -69,6 +77,24 @@ __device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag&
       out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
     }
   tf_layer_h3s<K16, 8, TIN, 0, TERMS>(S, FA, FB, in, out);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
+}
+
+// pre-split form (mfma_mlp.h): `B` = this layer's input as f16 (hi | lo) operands; the output is ReLU'd in place.
+template <int K16, int TERMS>
+__device__ __forceinline__ void hidden_layer_ps(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias,
+                                                const TfSplitIn<K16>& B, f32x16 (&out)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
+      out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
+    }
+  tf_layer_h3s_ps<K16, 8, 0, TERMS>(S, FA, FB, B, out);
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -216,6 +242,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
           // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
           asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
         }
+#ifndef TF_INNER_PRESPLIT   // default: operands split k-step by k-step inside the slab steps
       if (H3) hidden_layer_h3<8, 4, TERMS>(S, FA, FB, lbias + h * 256, h, in1, a);
       else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
     }
@@ -231,6 +258,34 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
     for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
     if (H3) tf_layer_h3s<16, 1, 8, 0, TERMS>(S, FA, FB, a, o);
     else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
+#else
+      if (H3) {
+        TfSplitIn<8> B1;
+        tf_presplit<8, 4, TERMS>(in1, B1);
+        hidden_layer_ps<8, TERMS>(S, FA, FB, lbias + h * 256, B1, a);
+      } else {
+        hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
+      }
+    }
+    f32x16 o[1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
+    if (H3) {
+      // dev-only variant (-DTF_INNER_PRESPLIT): each layer's input converted to MFMA operands once, at the layer boundary.
+      // Measured: f16x3 2.65 ms vs 2.52 in-step per 3 M rays (plain f16: 1.25 vs 1.35) -- the conversion is not hidden either way
+      TfSplitIn<16> B2;
+      tf_presplit<16, 8, TERMS>(a, B2);
+      hidden_layer_ps<16, TERMS>(S, FA, FB, lbias + 512 + h * 256, B2, b);
+      tf_presplit<16, 8, TERMS>(b, B2);
+      hidden_layer_ps<16, TERMS>(S, FA, FB, lbias + 1024 + h * 256, B2, a);
+      tf_presplit<16, 8, TERMS>(a, B2);
+      tf_layer_h3s_ps<16, 1, 0, TERMS>(S, FA, FB, B2, o);
+    } else {
+      hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
+      hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
+      tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
+    }
+#endif
     if (valid && h == 0) {
       const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;
 #pragma unroll

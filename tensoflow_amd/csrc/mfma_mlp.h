@@ -300,6 +300,35 @@ __device__ __forceinline__ void tf_cvt8(const float (&x)[8], tf_h8& hi) {
   hi = __builtin_bit_cast(tf_h8, h);
 }
 
+// tf_split8 in three pieces of four instructions (convert | low halves of lo | high halves of lo), for placement between MFMAs:
+// issued as one 13-instruction block the split kept the matrix pipe idle for ~50 cycles per slab step (-15 % when ablated); a
+// lone wave issues a vector instruction every 4 cycles, so four of them fit the 32-cycle shadow of one MFMA.  The consumer is the
+// NEXT slab step (behind a barrier), so no hazard nop is needed here.
+__device__ __forceinline__ void tf_split8_p0(const float (&x)[8], unsigned (&h)[4]) {
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_cvt_pk_f16_f32 %2, %8, %9\n\t"
+      "v_cvt_pk_f16_f32 %3, %10, %11"
+      : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+__device__ __forceinline__ void tf_split8_p1(const float (&x)[8], const unsigned (&h)[4], unsigned (&l)[4]) {
+  asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %5, -1.0, %9 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %2, %6, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %7, -1.0, %11 op_sel_hi:[1,0,0]"
+      : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3])
+      : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(x[0]), "v"(x[2]), "v"(x[4]), "v"(x[6]));
+}
+__device__ __forceinline__ void tf_split8_p2(const float (&x)[8], const unsigned (&h)[4], unsigned (&l)[4]) {
+  asm("v_fma_mixhi_f16 %0, %4, -1.0, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %5, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %6, -1.0, %10 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %7, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])
+      : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(x[1]), "v"(x[3]), "v"(x[5]), "v"(x[7]));
+}
+
 static __global__ void __launch_bounds__(256) tf_pack_wfrag_h3_kernel(const float* __restrict__ W, int nout, int ld, int col0,
                                                                int kin, int tout_tiles, int ksteps16,
                                                                _Float16* __restrict__ dst) {
@@ -467,8 +496,15 @@ __device__ __forceinline__ void tf_bsplit(TfBsplit<SL16>& B, int s16base, const 
     float x8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x8[e] = in[s16 >> 1][8 * (s16 & 1) + e];
+#ifdef TF_ABLATE_SPLIT   // dev-only timing ablation: operands are register reinterpretations, no conversion (results are garbage)
+    typedef float tf_f4 __attribute__((ext_vector_type(4)));
+    const tf_f4 va = {x8[0], x8[1], x8[2], x8[3]}, vb = {x8[4], x8[5], x8[6], x8[7]};
+    B.hi[sl] = __builtin_bit_cast(tf_h8, va);
+    B.lo[sl] = __builtin_bit_cast(tf_h8, vb);
+#else
     if (TERMS == 3) tf_split8(x8, B.hi[sl], B.lo[sl]);
     else tf_cvt8(x8, B.hi[sl]);
+#endif
   }
 }
 
@@ -489,6 +525,7 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
   float* dbuf = S.lds + S.slot_req * 4096;
   const float* gsrc = S.gp;
   asm volatile("" : "+v"(gsrc));
+  unsigned sp_h[SL16 <= 2 ? SL16 : 1][4], sp_l[SL16 <= 2 ? SL16 : 1][4];   // split pieces in flight across the MFMA groups
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int sl = c / TOUT, t = c % TOUT;
@@ -505,7 +542,31 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
     if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
 #endif
 #ifndef TF_SPLIT_AT_BOUNDARY
-    if (c == 5 && NEXT >= 0) tf_bsplit<SL16, TIN, TERMS>(bn, NEXT, in);
+    if (NEXT >= 0) {
+      if (TERMS == 3 && SL16 <= 2) {
+        // one four-instruction piece per MFMA group: k-step 0 of the next slab in groups 5, 6, 7 (SL16 = 1) or 2, 3, 4 with
+        // k-step 1 in 5, 6, 7 (SL16 = 2)
+        const int first = SL16 == 1 ? 5 : 2;
+        if (c >= first) {
+          const int sl_n = (c - first) / 3, piece = (c - first) % 3, s16n = NEXT + sl_n;
+          float x8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = in[s16n >> 1][8 * (s16n & 1) + e];
+          if (piece == 0) tf_split8_p0(x8, sp_h[sl_n]);
+          else if (piece == 1) tf_split8_p1(x8, sp_h[sl_n], sp_l[sl_n]);
+          else {
+            tf_split8_p2(x8, sp_h[sl_n], sp_l[sl_n]);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 hv = {sp_h[sl_n][0], sp_h[sl_n][1], sp_h[sl_n][2], sp_h[sl_n][3]};
+            const u32x4 lv = {sp_l[sl_n][0], sp_l[sl_n][1], sp_l[sl_n][2], sp_l[sl_n][3]};
+            bn.hi[sl_n] = __builtin_bit_cast(tf_h8, hv);
+            bn.lo[sl_n] = __builtin_bit_cast(tf_h8, lv);
+          }
+        }
+      } else if (c == 5) {
+        tf_bsplit<SL16, TIN, TERMS>(bn, NEXT, in);
+      }
+    }
 #endif
     out[t] = tf_mfma_h(cur.hi[c], bc.hi[sl], out[t]);
     if (TERMS == 3) {
@@ -543,6 +604,70 @@ __device__ __forceinline__ void tf_layer_h3s(TfStream& S, TfFrag& FA, TfFrag& FB
       if ((g & 1) == 0) tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FB, FA, B0, B1, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
       else tf_h3s_step<TOUT, TIN, SL16, TERMS>(S, FB, FA, B1, B0, g + 1 < G ? (g + 1) * SL16 : -1, in, out);
     }
+  }
+}
+
+// ---- pre-split variant: the layer's whole input is converted to (hi | lo) f16 operands ONCE, at the layer boundary, instead of
+// k-step by k-step inside the slab steps.  Inside a step every operand conversion reads accumulator registers of the previous
+// layer while the matrix pipe is writing the current ones, and costs 15 % of the kernel (ablation) wherever its instructions are
+// placed; at the boundary nothing is in flight.  The fp32 input dies with the conversion (its registers become the next output).
+template <int K16>
+struct TfSplitIn { tf_h8 hi[K16], lo[K16]; };
+
+template <int K16, int TIN, int TERMS>
+__device__ __forceinline__ void tf_presplit(const f32x16 (&x)[TIN], TfSplitIn<K16>& B) {
+#pragma unroll
+  for (int s16 = 0; s16 < K16; ++s16) {
+    float x8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x8[e] = x[s16 >> 1][8 * (s16 & 1) + e];
+    if (TERMS == 3) tf_split8(x8, B.hi[s16], B.lo[s16]);
+    else tf_cvt8(x8, B.hi[s16]);
+  }
+}
+
+template <int TOUT, int K16, int SL16, int TERMS>
+__device__ __forceinline__ void tf_h3s_step_ps(TfStream& S, int s16base, const TfFrag& cur, TfFrag& nxt, const TfSplitIn<K16>& B,
+                                               f32x16 (&out)[TOUT]) {
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const tf_h8* nbuf = reinterpret_cast<const tf_h8*>(S.lds + S.slot_rd * 4096) + S.lane;
+  float* dbuf = S.lds + S.slot_req * 4096;
+  const float* gsrc = S.gp;
+  asm volatile("" : "+v"(gsrc));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int sl = c / TOUT, t = c % TOUT;
+    if (c >= 1 && c <= 4) {
+#pragma unroll
+      for (int q = 2 * (c - 1); q < 2 * c; ++q) {
+        nxt.hi[q] = nbuf[q * 128];
+        if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
+      }
+    }
+    if (c >= 4) tf_slab_dma_piece(gsrc, dbuf, S.wave, c - 4);
+    out[t] = tf_mfma_h(cur.hi[c], B.hi[s16base + sl], out[t]);
+    if (TERMS == 3) {
+      out[t] = tf_mfma_h(cur.hi[c], B.lo[s16base + sl], out[t]);
+      out[t] = tf_mfma_h(cur.lo[c], B.hi[s16base + sl], out[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  tf_stream_advance(S);
+  S.slot_rd = (S.slot_rd + 1) & 3;
+}
+
+template <int K16, int TOUT, int P0, int TERMS>
+__device__ __forceinline__ void tf_layer_h3s_ps(TfStream& S, TfFrag& FA, TfFrag& FB, const TfSplitIn<K16>& B, f32x16 (&out)[TOUT]) {
+  static_assert(8 % TOUT == 0, "a 16 KB slab holds 8 (k-step, tile) fragment pairs");
+  constexpr int SL16 = 8 / TOUT;
+  static_assert(K16 % SL16 == 0, "K16 must be a multiple of the slab size");
+  constexpr int G = K16 / SL16;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (((P0 + g) & 1) == 0) tf_h3s_step_ps<TOUT, K16, SL16, TERMS>(S, g * SL16, FA, FB, B, out);
+    else tf_h3s_step_ps<TOUT, K16, SL16, TERMS>(S, g * SL16, FB, FA, B, out);
   }
 }
 
