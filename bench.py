@@ -201,6 +201,49 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
                 ms_per_step=dt * 1e3, points_per_s=pn / dt, trainable_parameters=n_par)
 
 
+def shape_train_probe(device, steps, n_rays=1024):
+    """Secondary figure: one TRAINING step of the shape stage through the drop-in ShapeRenderer (BASELINE configs[1] field: R = 300,
+    C = 36, 3 mips; the reference's batch of 1024 rays): sample_ray (64 + 4 x 16 importance samples), render_core with autograd
+    (SdfAlphaFn, differentiable ShapeShadingNetwork, CompositeFn), eikonal / sparse / hessian / TV terms, backward over every
+    trainable tensor.  HIP: field gathers and their scatter, the fused 7-tap forward, compositing forward / backward, cube-map
+    lookups and their gradients, EnvLight.build_mips and its adjoints; library GEMMs: decoder and shading-MLP products."""
+    from tensoflow_amd.network.shapeRenderer import ShapeRenderer
+    from tensoflow_amd.synth import pinhole_rays, random_sdf_state, random_shape_shader_state
+    R = 300
+    cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False, device="cuda",
+               nerfDataType=True, clip_sample_variance=False, apply_occ_loss=False)
+    r = ShapeRenderer(cfg, training=False)
+    sd = {"sdf_network." + k: v for k, v in random_sdf_state(seed=1, R=R).items()}
+    sd.update(random_shape_shader_state(seed=8))
+    r.load_state_dict(sd, strict=False)
+    r.train()
+    o, d, radii, cos = [torch.from_numpy(a).to(device) for a in pinhole_rays(n_rays, seed=2)]
+    near, far = r.near_far_from_sphere(o, d)
+    batch = {"rays_o": o, "rays_d": d, "dirs": d, "radiis": radii, "rays_cos": cos}
+    target = torch.rand(n_rays, 3, device=device)
+    samples = [0]
+
+    def step():
+        r.zero_grad(set_to_none=True)
+        r.color_network.envlight.build_mips()
+        out = r.render(batch, near, far, None, perturb_overwrite=0, cos_anneal_ratio=0.5, is_train=True, step=2000)
+        samples[0] = out["sample_num"] * n_rays
+        loss = ((out["ray_rgb"] - target) ** 2).mean() + 0.1 * out["gradient_error"].mean() + 0.1 * out["loss_sparse"] \
+            + 5e-4 * out["loss_hessian"] + out["loss_tv_sdf"]
+        loss.backward()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_par = sum(p.numel() for p in r.parameters() if p.requires_grad)
+    return dict(workload=f"ShapeRenderer train step: {n_rays} rays, {int(samples[0])} samples (sample_ray + render_core fwd + bwd + build_mips, no optimizer)",
+                ms_per_step=dt * 1e3, rays_per_s=n_rays / dt, trainable_parameters=n_par)
+
+
 def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     """Secondary figure (BASELINE configs[1]): one full 800x800 frame of the shape stage -- fixed-step sampler with occupancy
     culling (tf_march_uniform), fused 7-tap sdf/FD/alpha kernel, split-sum shading, compositing.  Reports rays/s, live
@@ -418,6 +461,11 @@ def main():
                 line["config3_flow256"] = flow_count_probe(sh, pts, view, nrm, 256, max(2, args.steps))
             except Exception as e:
                 line["config3_flow256"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train:
+            try:
+                line["shape_train"] = shape_train_probe(device, max(2, args.steps))
+            except Exception as e:
+                line["shape_train"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_march:
             import gc
             gc.collect()
