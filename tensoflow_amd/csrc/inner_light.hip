@@ -337,8 +337,11 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   }
+#ifndef TF_INNER_BLOCKS
+#define TF_INNER_BLOCKS 1024   // persistent workgroups (one resident per CU at a time)
+#endif
   long long blocks = (m + 127) / 128;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > TF_INNER_BLOCKS) blocks = TF_INNER_BLOCKS;
   if (precision == TF_PREC_F32)
     inner_light_kernel<0><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
                                                                (const long long*)count_dev, depth, near_eps, exp_max, out);
