@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
       if (jitter) { x0 = x0 + jitter[row]; x0 = x0 - floorf(x0); }   // (x + u) % 1
       x0 = fminf(fmaxf(x0, 1e-6f), 1.f - 1e-6f);
       x1 = fminf(fmaxf(x1, 1e-6f), 1.f - 1e-6f);
-      lj = -logf(cosf(x1 * kHalfPi));
+      { float sn_, cs_; tf_sincos_small(x1 * kHalfPi, sn_, cs_); lj = -tf_log(cs_); }   // x1 in (0,1): argument < pi/2
     } else {
       pt = rays_id ? rays_id[row] : row / sn;
       x0 = fminf(fmaxf(xin[2 * row], 1e-6f), 1.f - 1e-6f);
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
       pw_forward(x0, wv, t, l, bin1); x0 = t; lj += l;
       run_block(lds, 0, x0);
       pw_forward(x1, wv, t, l, bin0); x1 = t; lj += l;
-      lj += logf(cosf(x1 * kHalfPi));   // + latent_prior.log_prob(z)
+      { float sn_, cs_; tf_sincos_small(x1 * kHalfPi, sn_, cs_); lj += tf_log(cs_); }   // + latent_prior.log_prob(z)
     }
     if (valid) {
       reinterpret_cast<float2*>(out_xy)[row] = make_float2(x0, x1);
