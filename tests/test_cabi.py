@@ -161,6 +161,15 @@ def test_bvh_pack_host(lib):
                 assert (t.min(0) >= lo).all() and (t.max(0) <= hi).all()                   # conservative ...
                 assert (t.min(0) - lo < 3 * scl + 1e-4).all() and (hi - t.max(0) < 3 * scl + 1e-4).all()   # ... and tight
     assert (seen == 1).all() and (visited == 1).all() and max_depth <= 31
+    # numbering: the first records are the top of the tree in breadth-first order (level by level), the rest depth-first
+    level = np.zeros(npair, np.int32)
+    for i in range(npair):
+        for c in range(2):
+            r = int(refs[i, c])
+            if r >= 0:
+                level[r] = level[i] + 1
+    n_top = min(127, npair)
+    assert (np.diff(level[:n_top]) >= 0).all() and level[n_top - 1] <= level[n_top:].max()
     assert np.array_equal(t12[:, 0:3], tris[:, 0:3]) and np.array_equal(t12[:, 3:6], tris[:, 3:6] - tris[:, 0:3])
     assert np.array_equal(t12[:, 6:9], tris[:, 6:9] - tris[:, 0:3])
     # a mesh that fits one leaf still packs to one (degenerate) pair whose second box is empty
