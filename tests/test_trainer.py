@@ -80,3 +80,95 @@ def test_material_trainer_fits_and_checkpoints(tmp_path):
         col2, _ = net2(pts, view, nrm)
     assert torch.equal(col2, ref_col)
     assert math.isfinite(float(tr2.train_step(pts, view, nrm, target)["loss"]))
+
+
+def test_shape_schedule_and_loss_terms():
+    """Shape-stage bookkeeping on CPU: the voxel schedule of configs/shape/syn/compressor.yaml, the staged weights and the
+    reductions of network/loss.py on hand-made render outputs."""
+    from tensoflow_amd.trainer import SHAPE_CFG, _staged_ratio, n_to_reso, shape_loss_terms, voxel_schedule
+    sched = voxel_schedule(128 ** 3 + 1, 512 ** 3 + 1, [20000, 40000])
+    assert sched[0] == 128 ** 3 + 1 and sched[-1] == 512 ** 3 + 1 and len(sched) == 3
+    assert abs(sched[1] - 256 ** 3) / 256 ** 3 < 1e-3                                  # log-spaced: the geometric mean
+    assert n_to_reso(sched[0], SHAPE_CFG["aabb"]) == [128, 128, 128]
+    assert voxel_schedule(1000, 8000, None) == [1000]
+    assert _staged_ratio(5, None, [1.0, 1.0]) == 1.0
+    assert _staged_ratio(5, [0, 10], [0.3, 0.1]) == 1.0 and _staged_ratio(10, [0, 10], [0.3, 0.1]) == 0.1
+
+    torch.manual_seed(0)
+    rn, N = 16, 200
+    out = {"ray_rgb": torch.rand(rn, 3), "gradient_error": torch.rand(N), "acc": torch.rand(rn, 1), "std": torch.tensor(0.05),
+           "radiance": torch.rand(rn, 3), "roughness_weights": torch.rand(rn), "loss_occ": torch.rand(7), "loss_sparse": torch.tensor(0.4),
+           "loss_hessian": torch.tensor(2.0), "loss_tv_sdf": torch.tensor(0.3), "loss_gaussian": torch.tensor(9.0),
+           "sdf_pts": torch.randn(N, 3) * 0.7, "sdf_vals": torch.randn(N) * 0.1}
+    batch = {"rgbs": torch.rand(rn, 3), "masks": (torch.rand(rn) > 0.5).float()}
+    cfg = {**SHAPE_CFG, "loss": SHAPE_CFG["loss"] + ["Hessian"], "hessian_update_list": [0, 100], "hessian_ratio": [0.1, 0.05],
+           "eikonal_weight_anneal_end": 200}
+    t = shape_loss_terms(cfg, out, batch, step=100)
+    w = out["roughness_weights"]
+    char = lambda a: torch.sqrt(((a - batch["rgbs"]) ** 2).sum(-1) + 0.001)
+    assert torch.allclose(t["loss_rgb"], char(out["ray_rgb"]) * (1 - w)) and torch.allclose(t["loss_radiance"], char(out["radiance"]) * w)
+    assert torch.allclose(t["loss_eikonal"], out["gradient_error"] * 0.05)              # annealed: half way to 0.1
+    assert float(t["loss_hessian"]) == pytest.approx(2.0 * 5e-4 * 0.05) and float(t["loss_sparse"]) == pytest.approx(0.4 * 0.02)
+    assert float(t["loss_tv_sdf"]) == pytest.approx(0.03) and float(t["loss_gaussian"]) == pytest.approx(9.0 * 5e-4)
+    assert float(t["loss_occ"]) == pytest.approx(float(out["loss_occ"].mean()))
+    bce = torch.nn.functional.binary_cross_entropy(out["acc"].clip(1e-3, 1 - 1e-3)[:, 0], batch["masks"])
+    assert float(t["loss_mask"]) == pytest.approx(float(bce) * 0.01, rel=1e-6)
+    assert "loss_std" not in t and {"loss_sdf_large", "loss_sdf_small"} <= set(t)
+    # the initial-SDF regulariser: points inside r < 0.1 must have sdf < r - 0.1, points beyond 1.05 sdf > r - 1.05; cosine-annealed
+    norm = out["sdf_pts"].norm(dim=-1)
+    big = norm > 1.05
+    ll = torch.clamp((norm[big] - 1.05) - out["sdf_vals"][big], min=0)
+    anneal = (math.cos(0.1 * math.pi) + 1) / 2
+    assert float(t["loss_sdf_large"]) == pytest.approx(float(ll.sum() / ((ll > 1e-5).sum() + 1e-3)) * anneal, rel=1e-5)
+    assert "loss_sdf_large" not in shape_loss_terms(cfg, out, batch, step=1000)
+    assert float(shape_loss_terms({**cfg, "eikonal_weight_anneal_begin": 150}, out, batch, 100)["loss_eikonal"].sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_shape_trainer_runs_schedule_and_resumes(tmp_path):
+    """A short shape-stage run on synthetic rays: the loss falls, the alpha mask is refreshed and the grid is upsampled at the
+    scheduled steps (new Parameters, new optimizer, one more mip level), and a checkpoint in the reference layout resumes."""
+    from tensoflow_amd.network.shapeRenderer import ShapeRenderer
+    from tensoflow_amd.synth import pinhole_rays
+    from tensoflow_amd.trainer import ShapeTrainer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6033)
+
+    def make(grid, max_levels=1):
+        return ShapeRenderer(dict(gridSize=list(grid), max_levels=max_levels, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
+                                  device="cuda", nerfDataType=True, clip_sample_variance=False, apply_occ_loss=False,
+                                  anneal_end=20), training=False).to(dev)
+
+    tr = ShapeTrainer(make, dict(total_step=100, N_voxel_init=24 ** 3, N_voxel_final=48 ** 3, upsample_list=[5], update_AlphaMask_lst=[3],
+                                 loss=["nerf_render", "eikonal", "std", "init_sdf_reg", "Sparse", "TV", "mask", "Hessian"]))
+    assert tr.net.gridSize.tolist() == [24, 24, 24] and tr.N_voxel_list == [48 ** 3]
+    lrs = [g["lr"] for g in tr.optimizer.param_groups]
+    assert lrs == [1e-2, 1e-2, 1e-3, 1e-3, 1e-2, 1e-3]                  # sdf lines / planes, decoder, variance, env map, shading MLPs
+    o, d, radii, cos = [torch.from_numpy(a).to(dev) for a in pinhole_rays(512, seed=2)]
+    inside = ((torch.cross(o, d, dim=-1).norm(dim=-1)) < 0.45).float()                # rays passing a sphere of radius 0.45
+    batch = {"rays_o": o, "rays_d": d, "dirs": d, "radiis": radii, "rays_cos": cos, "masks": inside,
+             "rgbs": torch.where(inside[:, None] > 0, torch.tensor([0.2, 0.5, 0.8], device=dev), torch.ones(3, device=dev)).expand(-1, 3).contiguous()}
+    hist, events = [], {}
+    planes_before = [p for p in tr.net.sdf_network.sdf_plane]
+    opt_before = tr.optimizer
+    for s in range(12):
+        info = tr.train_step(batch)
+        assert torch.isfinite(info["loss"]), (s, info)
+        hist.append(float(info["loss"]))
+        for e in info["events"]:
+            events[e] = s
+    assert events == {"alpha_mask": 3, "upsample": 5}
+    assert tr.net.alphaMask is not None and tr.net.max_levels == 2 and tr.net.gridSize.tolist() == [48, 48, 48] and tr.N_voxel_list == []
+    assert tr.optimizer is not opt_before and all(a is not b for a, b in zip(planes_before, tr.net.sdf_network.sdf_plane))
+    assert {id(p) for p in tr.net.sdf_network.sdf_plane} <= {id(p) for p in tr.trainable()}
+    assert tr.cur_lr_xyz < 1e-2 * 0.5 + 1e-12 and min(hist[-3:]) < hist[0]
+    path = str(tmp_path / "shape.pth")
+    tr.save(path)
+    ck = torch.load(path, weights_only=False)
+    assert {"step", "best_para", "lr_factor", "pre_lr_factor", "lr_xyz", "lr_net", "optimizer_state_dict", "N_voxel_list",
+            "network_state_dict", "kwargs", "alphaMask.mask", "alphaMask.shape", "alphaMask.aabb"} <= set(ck)
+    tr2 = ShapeTrainer.resume(path, make, tr.cfg)
+    assert tr2.step_count == 12 and tr2.net.gridSize.tolist() == [48, 48, 48] and tr2.net.max_levels == 2 and tr2.net.alphaMask is not None
+    a, b = tr.net.state_dict(), tr2.net.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.isfinite(tr2.train_step(batch)["loss"])
