@@ -7,8 +7,8 @@ and call surface for everything on the hot path:
     compute_diffuse_light_regularization / get_train_opt_params / ckpt_to_save / load_ckpt / init_sdf / nvs / predict_materials
 
 `cfg['mesh']` is the geometry the reference reads with open3d and hands to raytracing.RayTracer (:147-149): here a
-(vertices [V,3] float, triangles [F,3] int) pair or the path of an .npz holding `vertices` / `triangles` (mesh file parsing
-is the export side).  The dataset side (`_init_dataset`, `train_step`, `test_step`: image tables,
+(vertices [V,3] float, triangles [F,3] int) pair, the path of a triangle .ply (tensoflow_amd.mesh.read_ply; the file
+extract_mesh.py / tensoflow_amd.mesh.extract_mesh writes) or of an .npz holding `vertices` / `triangles`.  The dataset side (`_init_dataset`, `train_step`, `test_step`: image tables,
 ray shuffling) is outside the hot path: construct with nvs=True and feed surface points to `shade`.
 """
 import os
@@ -59,10 +59,14 @@ class MaterialRenderer(nn.Module):
     def _init_geometry(self):
         mesh = self.cfg["mesh"]
         if isinstance(mesh, str):
-            if not mesh.endswith(".npz"):
-                raise NotImplementedError("mesh file parsing (open3d) is the export side of the path: pass (vertices, triangles) or an .npz")
-            z = np.load(mesh)
-            mesh = (z["vertices"], z["triangles"])
+            if mesh.endswith(".ply"):                    # what extract_mesh.py writes and the reference reads through open3d (:148)
+                from ..mesh import read_ply
+                mesh = read_ply(mesh)
+            elif mesh.endswith(".npz"):
+                z = np.load(mesh)
+                mesh = (z["vertices"], z["triangles"])
+            else:
+                raise NotImplementedError("mesh files: .ply (tensoflow_amd.mesh.read_ply) or .npz with `vertices` / `triangles`")
         if mesh is None:
             raise ValueError("cfg['mesh'] = (vertices [V,3], triangles [F,3]) is required")
         v, f = mesh

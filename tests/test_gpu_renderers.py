@@ -199,7 +199,8 @@ def test_shape_renderer_alpha_mask_and_nvs(golden, dev):
         assert img["color"].min() >= 0 and img["color"].max() <= 1 + 1e-5
 
 
-def test_material_renderer(golden, dev):
+def test_material_renderer(golden, dev, tmp_path):
+    from tensoflow_amd.mesh import write_ply
     from tensoflow_amd.network.materialRenderer import MaterialRenderer
     gs, gr = golden("shading_small"), golden("refine_r32")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in gs["sn"]]
@@ -225,6 +226,13 @@ def test_material_renderer(golden, dev):
         out = m2.shade(gs["pts"].to(dev), gs["view_in"].to(dev), gs["normals_in"].to(dev), None, False)
     assert rel_err(out["rgb_pr"].cpu(), gs["colors"]) < TOL and rel_err(out["rgb_pr_nis"].cpu(), gs.out["rgb_pr_nis"]) < TOL
     assert rel_err(out["albedo"].cpu(), gs.out["albedo"]) < TOL and rel_err(out["visibility"].cpu(), gs.out["visibility"]) < TOL
+    # the same geometry handed over as a .ply file (what the reference reads with open3d): identical colours
+    write_ply(str(tmp_path / "golden.ply"), gs["verts"].numpy(), gs["faces"].numpy())
+    m3 = MaterialRenderer({"mesh": str(tmp_path / "golden.ply"), "shader_cfg": shader_cfg, "gridSize": [32, 32, 32]}, training=False, nvs=True)
+    m3.shader_network.load_state_dict(gs.sd, strict=False)
+    with torch.no_grad():
+        out3 = m3.shade(gs["pts"].to(dev), gs["view_in"].to(dev), gs["normals_in"].to(dev), None, False)
+    assert torch.equal(out3["rgb_pr_nis"], out["rgb_pr_nis"])
     mats = m2.predict_materials(batch_size=500)
     assert mats["albedo"].shape == (gs["verts"].shape[0], 3) and np.isfinite(mats["roughness"]).all()
     ck = m2.ckpt_to_save()

@@ -68,9 +68,11 @@ def test_shape_renderer_ckpt_layout_and_upsample():
     assert abs(float(r2.stepSize) - 2.0 / 35 * 0.5) < 1e-6
 
 
-def test_material_renderer_requires_arrays_or_npz():
+def test_material_renderer_mesh_argument():
     from tensoflow_amd.network.materialRenderer import MaterialRenderer
     with pytest.raises(NotImplementedError):
-        MaterialRenderer({"mesh": "x.ply"}, training=True)
+        MaterialRenderer({"mesh": "x.ply"}, training=True)                 # the dataset side is not mirrored
+    with pytest.raises(FileNotFoundError):
+        MaterialRenderer({"mesh": "no_such_mesh.ply", "device": "cpu"}, training=False, nvs=True)
     with pytest.raises(NotImplementedError):
-        MaterialRenderer({"mesh": "mesh.ply", "device": "cpu"}, training=False, nvs=True)
+        MaterialRenderer({"mesh": "mesh.obj", "device": "cpu"}, training=False, nvs=True)
