@@ -201,6 +201,20 @@ class MaterialRenderer(nn.Module):
             m_.append(m.cpu().numpy()); r_.append(torch.sqrt(torch.clamp(r, min=1e-7)).cpu().numpy()); a_.append(a.cpu().numpy())
         return {"metallic": np.concatenate(m_, 0), "roughness": np.concatenate(r_, 0), "albedo": np.concatenate(a_, 0)}
 
+    def extract_materials(self, material_dir, albedo_ratio=None, batch_size=8192):
+        """eval_mat.py:114-134: per-vertex metallic / roughness / albedo of the mesh as `metallic.npy`, `roughness.npy`, `albedo.npy`
+        under `material_dir`, sRGB-encoded like the reference (its Blender script stores them as vertex colours).  `albedo_ratio`:
+        the optional rescale (scalar or [3]) the reference derives from ground-truth albedo images (dataset side, not mirrored)."""
+        os.makedirs(material_dir, exist_ok=True)
+        mats = self.predict_materials(batch_size)
+        if albedo_ratio is not None:
+            mats["albedo"] = mats["albedo"] * np.asarray(albedo_ratio, np.float32)
+        for name in ("metallic", "roughness", "albedo"):
+            lin = mats[name]
+            srgb = np.where(lin <= 0.0031308, 323 / 25 * lin, (211 * np.maximum(np.finfo(np.float32).eps, lin) ** (5 / 12) - 11) / 200)
+            np.save(os.path.join(material_dir, name + ".npy"), srgb)
+        return mats
+
     def forward(self, data):
         raise NotImplementedError("MaterialRenderer.forward drives the dataset tables (train_step / test_step); call shade() with "
                                   "surface points, or nvs(pose, K, h, w)")

@@ -235,6 +235,13 @@ def test_material_renderer(golden, dev, tmp_path):
     assert torch.equal(out3["rgb_pr_nis"], out["rgb_pr_nis"])
     mats = m2.predict_materials(batch_size=500)
     assert mats["albedo"].shape == (gs["verts"].shape[0], 3) and np.isfinite(mats["roughness"]).all()
+    lin = m2.extract_materials(str(tmp_path / "materials"), albedo_ratio=[1.0, 0.5, 2.0], batch_size=500)
+    alb = np.load(str(tmp_path / "materials" / "albedo.npy"))
+    from tensoflow_amd.encodings import linear_to_srgb
+    assert np.allclose(alb, linear_to_srgb(torch.from_numpy(mats["albedo"] * np.array([1.0, 0.5, 2.0], np.float32))).numpy(), atol=1e-6)
+    assert np.allclose(lin["albedo"], mats["albedo"] * np.array([1.0, 0.5, 2.0], np.float32))
+    assert np.load(str(tmp_path / "materials" / "roughness.npy")).shape == mats["roughness"].shape
+    assert np.load(str(tmp_path / "materials" / "metallic.npy")).shape == mats["metallic"].shape
     ck = m2.ckpt_to_save()
     assert any(k.startswith("shader_network.mat_plane") for k in ck["network_state_dict"])
     groups = m2.get_train_opt_params(0.02, 0.001, 0.001)
