@@ -440,34 +440,58 @@ extern "C" int tf_inner_light_encode(const float* pos, const float* dirs, const 
 
 // ---------------------------------------------------------------- stream compaction of a byte mask (hit rays)
 #define COMPACT_ITEMS 8192   // elements per workgroup: one global atomic per 8192 rays instead of one per wave
+// One pass over the mask: a thread owns 32 consecutive bytes (two 16-byte loads, kept in registers), the workgroup's offsets come
+// from a wave scan + 4 LDS words, the indices of a thread are written as one run.  (The first version read single bytes twice:
+// 64-byte wave loads, 0.45 ms per 201 M rays.)  The order of `idx` across workgroups follows the atomic, as before: consumers
+// scatter through it, no result depends on it.
 __global__ void __launch_bounds__(256) compact_mask_kernel(const unsigned char* __restrict__ mask, long long m,
                                                            long long* __restrict__ idx, unsigned long long* __restrict__ count) {
-  __shared__ unsigned int s_cnt, s_off;
+  __shared__ unsigned int s_wave[4];
   __shared__ unsigned long long s_base;
-  const int lane = threadIdx.x & 63;
-  const long long first = (long long)blockIdx.x * COMPACT_ITEMS;
-  if (threadIdx.x == 0) { s_cnt = 0; s_off = 0; }
-  __syncthreads();
-  unsigned int mine = 0;
-  for (int k = 0; k < COMPACT_ITEMS / 256; ++k) {
-    const long long i = first + k * 256 + threadIdx.x;
-    mine += (i < m && mask[i] != 0) ? 1u : 0u;
-  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long first = (long long)blockIdx.x * COMPACT_ITEMS + 32LL * threadIdx.x;
+  unsigned int w[8];
+  if (first + 32 <= m && (((uintptr_t)mask) & 15) == 0) {
+    const uint4 a = *reinterpret_cast<const uint4*>(mask + first), b = *reinterpret_cast<const uint4*>(mask + first + 16);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-  if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    for (int q = 0; q < 8; ++q) {
+      unsigned int v = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long long i = first + 4 * q + e;
+        if (i < m) v |= (unsigned int)mask[i] << (8 * e);
+      }
+      w[q] = v;
+    }
+  }
+  // bit j of `bits` = byte j of the 32 is non-zero
+  unsigned int bits = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bits |= ((w[q] >> (8 * e)) & 0xffu) ? (1u << (4 * q + e)) : 0u;
+  const unsigned int mine = __popc(bits);
+  unsigned int incl = mine;                       // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(count, (unsigned long long)s_cnt) : 0ULL;
+  if (threadIdx.x == 0) {
+    const unsigned int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = total ? atomicAdd(count, (unsigned long long)total) : 0ULL;
+  }
   __syncthreads();
-  const unsigned long long base = s_base;
-  for (int k = 0; k < COMPACT_ITEMS / 256; ++k) {
-    const long long i = first + k * 256 + threadIdx.x;
-    const bool on = i < m && mask[i] != 0;
-    const unsigned long long b = __ballot(on);
-    unsigned int wbase = 0;
-    if (lane == 0 && b) wbase = atomicAdd(&s_off, (unsigned int)__popcll(b));
-    wbase = __shfl(wbase, 0);
-    if (on) idx[base + wbase + __popcll(b & ((1ULL << lane) - 1ULL))] = i;
+  unsigned long long at = s_base + (incl - mine);
+  for (int k = 0; k < wave; ++k) at += s_wave[k];
+  while (bits) {
+    const int j = __ffs(bits) - 1;
+    bits &= bits - 1;
+    idx[at++] = first + j;
   }
 }
 

@@ -152,3 +152,29 @@ def test_fixed_pass_full_size_properties(dev):
     sd2 = {k: (v * 0.5 if "flow_" in k and v.is_floating_point() else v) for k, v in sd.items()}
     sh2 = MCShader(sd2, verts, faces, AABB, 2.0 / 511, device=dev, n_fixed_diffuse=512, n_fixed_specular=256)
     assert torch.equal(sh2.shade_fixed(pts, view, nrm)["colors"], c)
+
+
+def test_compact_mask_ragged_and_unaligned(dev):
+    """tf_compact_mask: the index SET equals nonzero() for ragged lengths around the 32-byte / 8192-element granules, for views that
+    start at an odd byte (the vector loads need 16-byte alignment: the kernel falls back to byte loads), for any non-zero byte
+    value, for all-zero and all-one masks; at 201 M elements the count matches and every index points at a set byte."""
+    from tensoflow_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for m in (1, 31, 32, 33, 255, 8191, 8192, 8193, 100003):
+        for shift in (0, 1, 5):
+            base = (torch.rand(m + shift, generator=g) < 0.15).to(torch.uint8) * torch.randint(1, 256, (m + shift,), generator=g, dtype=torch.int64).to(torch.uint8)
+            mask = base.to(dev)[shift:]
+            idx, count = ops.compact_mask(mask)
+            n = int(count)
+            ref = torch.nonzero(mask).reshape(-1)
+            assert n == ref.numel(), (m, shift)
+            assert torch.equal(torch.sort(idx[:n]).values, ref), (m, shift)
+    for fill in (0, 1):
+        mask = torch.full((20000,), fill, dtype=torch.uint8, device=dev)
+        idx, count = ops.compact_mask(mask)
+        assert int(count) == 20000 * fill and (fill == 0 or torch.equal(torch.sort(idx[:20000]).values, torch.arange(20000, device=dev)))
+    m = 262144 * 768
+    mask = (torch.rand(m, device=dev) < 0.1475).to(torch.uint8)
+    idx, count = ops.compact_mask(mask)
+    n = int(count)
+    assert n == int(mask.sum(dtype=torch.int64)) and bool(mask[idx[:n]].all()) and idx[:n].unique().numel() == n
