@@ -1,0 +1,64 @@
+"""The two stages chained as a user of the reference would run them (run_training.py shape -> extract_mesh.py -> run_training.py
+material -> eval_mat.py), on a synthetic object: every hand-over goes through the files the reference uses (TrainerInv checkpoint,
+PLY mesh, .npy materials)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_shape_stage_to_material_stage(tmp_path):
+    from tensoflow_amd.mesh import extract_mesh
+    from tensoflow_amd.network.materialRenderer import MaterialRenderer
+    from tensoflow_amd.network.shapeRenderer import ShapeRenderer
+    from tensoflow_amd.synth import pinhole_rays, random_sdf_state
+    from tensoflow_amd.trainer import MaterialTrainer, ShapeTrainer
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test collected but no GPU is visible")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6033)
+    R = 48
+
+    def make(grid, max_levels=3):
+        r = ShapeRenderer(dict(gridSize=list(grid), max_levels=max_levels, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
+                               device="cuda", nerfDataType=True, clip_sample_variance=False, apply_occ_loss=False, blend_ratio=0.2),
+                          training=False).to(dev)
+        return r
+
+    # ---- shape stage: a few optimisation steps from an object-sized initial surface, then the checkpoint
+    st = ShapeTrainer(make, dict(total_step=50, N_voxel_init=R ** 3, N_voxel_final=R ** 3))
+    sd = random_sdf_state(seed=1, R=st.net.gridSize.tolist()[0])
+    sd["sdf_mat.2.bias"][0] -= 0.35
+    st.net.load_state_dict({"sdf_network." + k: v for k, v in sd.items()}, strict=False)
+    o, d, radii, cos = [torch.from_numpy(a).to(dev) for a in pinhole_rays(512, seed=2, h=64, w=64, focal=90.0)]
+    batch = {"rays_o": o, "rays_d": d, "dirs": d, "radiis": radii, "rays_cos": cos, "rgbs": torch.rand(512, 3, device=dev),
+             "masks": torch.ones(512, device=dev)}
+    for _ in range(3):
+        assert torch.isfinite(st.train_step(batch)["loss"])
+    ckpt = str(tmp_path / "shape.pth")
+    st.save(ckpt)
+    # ---- mesh hand-over
+    ply = str(tmp_path / "shape.ply")
+    v, f = extract_mesh(st.net, 64, ply)
+    assert f.shape[0] > 500
+    # ---- material stage on the files
+    shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=64, nis_diffuse_sample_num=32,
+                      nis_specular_sample_num=32)
+    mat = MaterialRenderer({"mesh": ply, "geo_model_path": ckpt, "shader_cfg": shader_cfg}, training=False, nvs=True)
+    assert mat.gridSize.tolist() == st.net.gridSize.tolist()
+    o2, d2, _, _ = [torch.from_numpy(a).to(dev) for a in pinhole_rays(2048, seed=3, h=64, w=64, focal=90.0)]
+    pts, nrm, depth, hit = mat.trace_sdf_with_mesh(o2, d2)
+    hit = hit.reshape(-1)
+    assert int(hit.sum()) > 50
+    # refined points sit on the trained SDF's zero set, normals face the camera
+    with torch.no_grad():
+        s = st.net.sdf_network.sdf(pts[hit].contiguous(), None)[:, 0]
+    assert float(s.abs().max()) < 2e-2 and float((nrm[hit] * d2[hit]).sum(-1).max()) < 0.2
+    mt = MaterialTrainer(mat.shader_network, dict(total_step=50, nis_loss_iter=1))
+    P, V, Nn = pts[hit].contiguous(), (-d2[hit]).contiguous(), nrm[hit].contiguous()
+    target = torch.sigmoid(3.0 * P)
+    losses = [float(mt.train_step(P, V, Nn, target)["loss_rgb"]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    mats = mat.extract_materials(str(tmp_path / "materials"))
+    assert np.load(str(tmp_path / "materials" / "albedo.npy")).shape == (v.shape[0], 3) and np.isfinite(mats["roughness"]).all()
