@@ -1,0 +1,122 @@
+"""The data side in front of the shape stage (reader side): the TensoSDF synthetic scene layout
+(`transforms_{train,val,test}.json` + RGBA PNGs) -> the per-ray training table ShapeRenderer.train_step slices.
+
+* `TensoSDFSynDatabase`      -- dataset/database.py:479-579: frames of the listed splits; RGB composited over white (or black)
+                                with the alpha channel and quantised to uint8 exactly like the reference; mask = alpha;
+                                K from `camera_angle_x`; `get_pose` halves the translation (scale_factor 0.5).
+                                PNG decoding: PIL (the reference uses skimage.io.imread -- same 8-bit samples).  The test-split
+                                extras (`_normal.png`; `_diffColor.exr` needs an EXR decoder, absent here) are not read.
+* `construct_ray_batch_nerf` -- shapeRenderer.py:471-518: pinhole rays through pixel centres in the OpenGL camera frame, cone radii
+                                from neighbouring-ray distances, `rays_cos = 1 / |rays_d|`, colours, masks, per-ray pose rows.
+* `RayTable`                 -- `_shuffle_train_batch` / `train_step`'s slicing (:411-415, :778-782) with the data-parallel split of
+                                SURVEY.md 8(e): every rank shuffles with the same generator and takes its own stride of each batch.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class TensoSDFSynDatabase:
+    def __init__(self, root, splits=("train", "val"), white_bg=True):
+        from PIL import Image
+        self.root = root
+        self.imgs_all, self.masks_all, self.pose_all = [], [], []
+        meta = None
+        for s in splits:
+            with open(os.path.join(root, f"transforms_{s}.json")) as fp:
+                meta = json.load(fp)
+            for fr in meta["frames"]:
+                im = Image.open(os.path.join(root, fr["file_path"] + ".png"))
+                if im.mode != "RGBA":
+                    raise ValueError(f"{fr['file_path']}.png: RGBA expected (the alpha channel is the object mask), got {im.mode}")
+                img = np.asarray(im).astype(np.float32) / 255.0
+                mask = img[..., -1:]
+                rgb = img[..., :3] * mask + (1 - mask) if white_bg else img[..., :3] * mask
+                self.imgs_all.append((rgb * 255.0).astype(np.uint8))
+                self.masks_all.append(mask)
+                self.pose_all.append(np.array(fr["transform_matrix"], dtype=np.float64))
+        if not self.imgs_all:
+            raise ValueError(f"{root}: no frames in splits {splits}")
+        self.H, self.W = self.imgs_all[0].shape[:2]
+        self.focal = 0.5 * self.W / np.tan(0.5 * float(meta["camera_angle_x"]))
+        self.K = np.array([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]], dtype=np.float32)
+        self.scale_factor = 0.5
+        self.img_ids = list(range(len(self.imgs_all)))
+
+    def get_image(self, i):
+        return self.imgs_all[i]
+
+    def get_mask(self, i):
+        return self.masks_all[int(i)][..., -1]
+
+    def get_K(self, i):
+        return self.K
+
+    def get_pose(self, i):
+        pose = self.pose_all[i].copy()
+        pose[:, 3:] *= self.scale_factor            # the whole last column, as the reference does (its bottom 1 becomes 0.5; unused)
+        return pose
+
+    def get_img_ids(self):
+        return self.img_ids
+
+    def imgs_info(self, ids=None):
+        """build_imgs_info + imgs_info_to_torch for this database -> imgs [n,3,h,w] in [0,1], masks [n,1,h,w], Ks [n,3,3], poses [n,4,4]."""
+        ids = self.img_ids if ids is None else ids
+        imgs = np.stack([self.get_image(i) for i in ids]).astype(np.float32) / 255.0
+        return {"imgs": torch.from_numpy(imgs).permute(0, 3, 1, 2).contiguous(),
+                "masks": torch.from_numpy(np.stack([self.get_mask(i) for i in ids]).astype(np.float32))[:, None],
+                "Ks": torch.from_numpy(np.stack([self.get_K(i) for i in ids])),
+                "poses": torch.from_numpy(np.stack([self.get_pose(i) for i in ids]).astype(np.float32))}
+
+
+def construct_ray_batch_nerf(imgs_info, device="cpu", is_train=True):
+    """-> (ray_batch dict of [rn, .] tensors, rn, h, w); keys: dirs, rays_d, rays_o, radiis, rays_cos, rgbs, human_poses (, masks)."""
+    imn, _, h, w = imgs_info["imgs"].shape
+    K, poses = imgs_info["Ks"][0], imgs_info["poses"]
+    i, j = torch.meshgrid(torch.linspace(0, w - 1, w), torch.linspace(0, h - 1, h), indexing="ij")
+    i, j = i.t(), j.t()
+    cam = torch.stack([(i - K[0][2] + 0.5) / K[0][0], -(j - K[1][2] + 0.5) / K[1][1], -torch.ones_like(i)], -1)       # h,w,3
+    dx = (cam[:, :-1] - cam[:, 1:]).norm(dim=-1, keepdim=True)
+    dx = torch.cat([dx, dx[:, -2:-1]], 1)
+    dy = (cam[:-1] - cam[1:]).norm(dim=-1, keepdim=True)
+    dy = torch.cat([dy, dy[-2:-1]], 0)
+    radiis = torch.sqrt(dx * dy / torch.pi)[None].expand(imn, h, w, 1).reshape(-1, 1)
+    rn = imn * h * w
+    idx = torch.arange(imn)[:, None].expand(imn, h * w).reshape(-1)
+    rays_o = poses[:, :3, -1][:, None].expand(imn, h * w, 3).reshape(rn, 3)
+    rays_d = (cam.reshape(1, h * w, 1, 3) * poses[:, None, :3, :3]).sum(-1).reshape(rn, 3)
+    batch = {"dirs": F.normalize(rays_d, dim=-1), "rays_d": rays_d, "rays_o": rays_o, "radiis": radiis,
+             "rays_cos": 1 / rays_d.norm(dim=-1, keepdim=True),
+             "rgbs": imgs_info["imgs"].permute(0, 2, 3, 1).reshape(rn, 3), "human_poses": poses[idx, :3, :]}
+    if is_train:
+        batch["masks"] = imgs_info["masks"].reshape(rn, 1).float()
+    return {k: v.float().contiguous().to(device) for k, v in batch.items()}, rn, h, w
+
+
+class RayTable:
+    """The shuffled per-ray table of the training loop.  `next_batch(rn)` returns this rank's rows of the next rn-row slice (on
+    `device`); the table reshuffles when fewer than 2 rn rows remain, like the reference (:782)."""
+
+    def __init__(self, ray_batch, rank=0, world=1, seed=6033, device="cuda"):
+        self.table = ray_batch
+        self.tbn = next(iter(ray_batch.values())).shape[0]
+        self.rank, self.world, self.device = rank, world, device
+        self.gen = torch.Generator().manual_seed(seed)              # same seed on every rank: identical permutations
+        self.shuffle()
+
+    def shuffle(self):
+        self.i = 0
+        perm = torch.randperm(self.tbn, generator=self.gen)
+        self.table = {k: v[perm] for k, v in self.table.items()}
+
+    def next_batch(self, rn):
+        sl = slice(self.i + self.rank, self.i + rn, self.world)
+        out = {k: v[sl].to(self.device, non_blocking=True) for k, v in self.table.items()}
+        self.i += rn
+        if self.i + rn >= self.tbn:
+            self.shuffle()
+        return out

@@ -1,0 +1,90 @@
+"""Reader side of the shape stage (tensoflow_amd/dataset.py): scene files -> ray table, on CPU."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_scene(root, n=3, h=6, w=8, seed=0):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(root, "train"), exist_ok=True)
+    frames, raw = [], []
+    for k in range(n):
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img[0, 0, 3], img[0, 1, 3] = 0, 255
+        Image.fromarray(img, "RGBA").save(os.path.join(root, "train", f"r_{k}.png"))
+        a, b = 0.3 + k, 0.2 * k
+        Rz = np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+        T = np.eye(4)
+        T[:3, :3] = Rz @ Rx
+        T[:3, 3] = T[:3, :3] @ np.array([0, 0, 4.0])
+        frames.append({"file_path": f"./train/r_{k}", "transform_matrix": T.tolist()})
+        raw.append(img)
+    for split in ("train", "val"):
+        with open(os.path.join(root, f"transforms_{split}.json"), "w") as fp:
+            json.dump({"camera_angle_x": 0.6911, "frames": frames if split == "train" else frames[:1]}, fp)
+    return raw, frames
+
+
+def test_database_and_ray_table(tmp_path):
+    from tensoflow_amd.dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf
+    root = str(tmp_path / "scene")
+    raw, frames = _write_scene(root)
+    db = TensoSDFSynDatabase(root)
+    assert len(db.get_img_ids()) == 4 and (db.H, db.W) == (6, 8)                       # train (3) + val (1)
+    assert db.focal == pytest.approx(0.5 * 8 / math.tan(0.5 * 0.6911)) and db.K[0, 2] == 4 and db.K[1, 2] == 3
+    a = raw[0].astype(np.float32) / 255.0
+    want = ((a[..., :3] * a[..., 3:] + (1 - a[..., 3:])) * 255.0).astype(np.uint8)      # composited over white, truncated to 8 bits
+    assert np.array_equal(db.get_image(0), want) and (db.get_image(0)[0, 0] == 255).all() and np.array_equal(db.get_image(0)[0, 1], raw[0][0, 1, :3])
+    assert np.allclose(db.get_mask(0), a[..., 3]) and db.get_mask(0).shape == (6, 8)
+    black = TensoSDFSynDatabase(root, splits=("train",), white_bg=False)
+    assert (black.get_image(0)[0, 0] == 0).all() and len(black.img_ids) == 3
+    T = np.array(frames[1]["transform_matrix"])
+    assert np.allclose(db.get_pose(1)[:3, 3], 0.5 * T[:3, 3]) and np.allclose(db.get_pose(1)[:3, :3], T[:3, :3])
+    assert np.allclose(db.pose_all[1], T)                                              # get_pose works on a copy
+
+    info = db.imgs_info()
+    batch, rn, h, w = construct_ray_batch_nerf(info)
+    assert rn == 4 * 48 and (h, w) == (6, 8) and set(batch) == {"dirs", "rays_d", "rays_o", "radiis", "rays_cos", "rgbs", "human_poses", "masks"}
+    # ray of image 2, pixel (row 4, col 5): through the pixel centre, camera looks down -z, y up
+    k, r, c = 2, 4, 5
+    row = k * 48 + r * 8 + c
+    pose = torch.from_numpy(db.get_pose(k)).float()
+    cam = torch.tensor([(c - 4 + 0.5) / db.focal, -(r - 3 + 0.5) / db.focal, -1.0], dtype=torch.float32)
+    assert torch.allclose(batch["rays_d"][row], pose[:3, :3] @ cam, atol=1e-6) and torch.allclose(batch["rays_o"][row], pose[:3, 3])
+    assert torch.allclose(batch["dirs"][row], torch.nn.functional.normalize(pose[:3, :3] @ cam, dim=0), atol=1e-6)
+    assert float(batch["rays_cos"][row]) == pytest.approx(1 / float(cam.norm()), rel=1e-6)
+    assert float(batch["radiis"][row]) == pytest.approx(math.sqrt((1 / db.focal) ** 2 / math.pi), rel=1e-5)       # pixel footprint disc
+    assert torch.allclose(batch["rgbs"][row], torch.from_numpy(db.get_image(k)[r, c].astype(np.float32) / 255))
+    assert float(batch["masks"][row]) == pytest.approx(float(db.get_mask(k)[r, c])) and batch["human_poses"].shape == (rn, 3, 4)
+    test_batch, _, _, _ = construct_ray_batch_nerf(info, is_train=False)
+    assert "masks" not in test_batch
+
+    # the shuffled table: ranks of a 2-process run split every batch without overlap; one process sees the same rows in order
+    one = RayTable(dict(batch), device="cpu")
+    r0, r1 = RayTable(dict(batch), 0, 2, device="cpu"), RayTable(dict(batch), 1, 2, device="cpu")
+    for _ in range(5):                                                                  # crosses a reshuffle (192 rows, 64 per batch)
+        full, a0, a1 = one.next_batch(64), r0.next_batch(64), r1.next_batch(64)
+        assert a0["rays_o"].shape[0] == a1["rays_o"].shape[0] == 32
+        assert torch.equal(full["rgbs"][0::2], a0["rgbs"]) and torch.equal(full["rgbs"][1::2], a1["rgbs"])
+    assert one.i == r0.i == r1.i
+    seen = torch.cat([RayTable(dict(batch), device="cpu").next_batch(192 - 1)["rays_d"]])
+    assert seen.shape[0] == 191
+
+
+def test_database_refuses_rgb_files(tmp_path):
+    from PIL import Image
+    from tensoflow_amd.dataset import TensoSDFSynDatabase
+    root = str(tmp_path / "s")
+    os.makedirs(os.path.join(root, "train"))
+    Image.fromarray(np.zeros((4, 4, 3), np.uint8), "RGB").save(os.path.join(root, "train", "r_0.png"))
+    for s in ("train", "val"):
+        with open(os.path.join(root, f"transforms_{s}.json"), "w") as fp:
+            json.dump({"camera_angle_x": 0.7, "frames": [{"file_path": "./train/r_0", "transform_matrix": np.eye(4).tolist()}]}, fp)
+    with pytest.raises(ValueError):
+        TensoSDFSynDatabase(root)
