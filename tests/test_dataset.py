@@ -88,3 +88,35 @@ def test_database_refuses_rgb_files(tmp_path):
             json.dump({"camera_angle_x": 0.7, "frames": [{"file_path": "./train/r_0", "transform_matrix": np.eye(4).tolist()}]}, fp)
     with pytest.raises(ValueError):
         TensoSDFSynDatabase(root)
+
+
+@pytest.mark.gpu
+def test_shape_renderer_dataset_side(tmp_path):
+    """ShapeRenderer(cfg, training=True) on a (tiny) scene in the TensoSDF synthetic layout: forward({'step'}) is a training
+    iteration with the reference's loss keys, forward({'eval', 'index', 'step'}) renders a validation image."""
+    from tensoflow_amd.network.shapeRenderer import ShapeRenderer
+    root = str(tmp_path / "data" / "toy")
+    _write_scene(root, n=5, h=16, w=16)
+    cfg = dict(gridSize=[32, 32, 32], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False, device="cuda",
+               nerfDataType=True, clip_sample_variance=False, apply_occ_loss=False, database_name="tensoSDF/toy",
+               dataset_dir=str(tmp_path / "data"), apply_mask_loss=True, train_ray_num=256, test_ray_num=128, downsample_ratio=0.5)
+    torch.manual_seed(0)
+    r = ShapeRenderer(cfg, training=True).cuda()
+    assert r.train_num == 5 and r.test_num == 1 and r.tbn == 5 * 256                    # val split holds 1 frame; default split: first image tests
+    r.train()
+    out = r({"step": 10})
+    assert {"ray_rgb", "loss_rgb", "psnr", "loss_mask", "gradient_error", "acc", "loss_sparse", "loss_tv_sdf"} <= set(out)
+    assert out["loss_rgb"].shape == (256,) and torch.isfinite(out["loss_rgb"]).all() and out["ray_rgb"].requires_grad
+    (out["loss_rgb"].mean() + out["loss_mask"] + 0.1 * out["gradient_error"].mean()).backward()
+    assert r.sdf_network.sdf_plane[0].grad is not None and float(r.sdf_network.sdf_plane[0].grad.abs().sum()) > 0
+    r.eval()
+    ev = r({"eval": True, "index": 0, "step": 10})
+    assert ev["ray_rgb"].shape == (8, 8, 3) and ev["gt_rgb"].shape == (8, 8, 3) and ev["loss_rgb"].shape == (64,)      # downsampled by 2
+    assert torch.isfinite(ev["ray_rgb"]).all() and ev["gt_mask"].shape == (8, 8, 1)
+    # gt of the downsampled image = 2x2 box average of the file's composited pixels
+    want = torch.from_numpy(r.database.get_image(r.test_ids[0]).astype(np.float32) / 255).reshape(8, 2, 8, 2, 3).mean((1, 3))
+    assert torch.allclose(ev["gt_rgb"].cpu(), want, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        ShapeRenderer({**cfg, "database_name": "nerf_synthetic/lego"}, training=True)
+    with pytest.raises(NotImplementedError):
+        ShapeRenderer(cfg, training=False)({"step": 0})
