@@ -34,9 +34,11 @@ class MaterialRenderer(nn.Module):
     def __init__(self, cfg, training=True, nvs=False):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        if training or not nvs:
-            raise NotImplementedError("the dataset side of MaterialRenderer (_init_dataset / train_step / test_step) is outside the hot "
-                                      "path: construct with training=False, nvs=True and pass surface points to shade()")
+        with_data = training or not nvs
+        if with_data and not (self.cfg["nerfDataType"] and str(self.cfg.get("database_name", "")).startswith("tensoSDF/")):
+            raise NotImplementedError("the dataset side of MaterialRenderer (_init_dataset / train_step) reads the TensoSDF synthetic "
+                                      "layout only (database_name 'tensoSDF/<scene>', nerfDataType=True): for anything else "
+                                      "construct with training=False, nvs=True and pass surface points to shade()")
         self.device = self.cfg["device"]
         self._init_geometry()
         # without a geometry checkpoint the reference has no aabb either; the cfg values let the module stand alone
@@ -50,6 +52,70 @@ class MaterialRenderer(nn.Module):
         elif geo and os.path.exists(geo):
             self.init_sdf(torch.load(geo, weights_only=False))
         self._init_shader()
+        if with_data:
+            self._init_dataset()
+
+    # ------------------------------------------------------------------------------ dataset side (TensoSDF synthetic scenes)
+    def _init_dataset(self):
+        """materialRenderer.py:345-382 + filtering_train_rays (:384-417): database, split, per-pixel ray table, every training ray
+        traced against the mesh and refined on the SDF on the device (chunks of 512^2 rays, no CPU round trip per chunk); rays that
+        miss are dropped; the table of surface points is shuffled.  cfg['rank'] / cfg['world']: this process's stride of a batch."""
+        from ..dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf
+        scene = self.cfg["database_name"].split("/")[1]
+        self.database = TensoSDFSynDatabase(os.path.join(self.cfg["dataset_dir"], scene), white_bg=self.cfg.get("isBGWhite", True))
+        ids = self.database.get_img_ids()
+        if self.cfg.get("split_manul", False):
+            border = self.cfg.get("split_borderline", 100)
+            self.train_ids, test = ids[:border], ids[border:]
+            self.test_ids = test[::50] if len(test) > 10 else test[::4]
+        else:
+            self.test_ids, self.train_ids = ids[:1], ids[1:]
+        self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
+        batch, n_rays, _, _ = construct_ray_batch_nerf(self.database.imgs_info(self.train_ids))
+        batch["rgb"] = batch.pop("rgbs")
+        self.train_batch = self.filtering_train_rays(batch)
+        self.tbn = self.train_batch["rays_o"].shape[0]
+        self.ray_mask_ratio = self.tbn / max(n_rays, 1)
+        self.train_table = RayTable(self.train_batch, rank=self.cfg.get("rank", 0), world=self.cfg.get("world", 1),
+                                    seed=self.cfg.get("random_seed", 6033), device=self.device)
+
+    @torch.no_grad()
+    def filtering_train_rays(self, batch, chunk=512 ** 2):
+        out = {}
+        n = batch["rays_o"].shape[0]
+        for i in range(0, n, chunk):
+            cur = {k: v[i:i + chunk].to(self.device) for k, v in batch.items()}
+            inters, normals, depth, hit = self.trace_sdf_with_mesh(cur["rays_o"].contiguous(), cur["rays_d"].contiguous())
+            hit = hit.reshape(-1)
+            cur = {k: v[hit] for k, v in cur.items()}
+            cur.update({"inters": inters.reshape(-1, 3)[hit], "normals": normals.reshape(-1, 3)[hit], "depth": depth.reshape(-1, 1)[hit]})
+            for k, v in cur.items():
+                out.setdefault(k, []).append(v.cpu())
+        return {k: torch.cat(v, 0) for k, v in out.items()}
+
+    def train_step(self, step):
+        """materialRenderer.py:539-566."""
+        b = self.train_table.next_batch(self.cfg["train_ray_num"])
+        pts, view_dirs, normals, rgb_gt = b["inters"], -b["rays_d"], b["normals"], b["rgb"]
+        self.shader_network.update_step(step)
+        out = self.shade(pts, view_dirs, normals, b["human_poses"], True, step)
+        out["rgb_gt"] = rgb_gt
+        out["loss_rgb"] = self.compute_rgb_loss(out["rgb_pr"], rgb_gt)
+        out["psnr"] = 20 * torch.log10(1.0 / torch.sqrt(F.mse_loss(out["rgb_pr"], rgb_gt)))
+        if self.cfg["reg_mat"]:
+            out["loss_mat_reg"] = self.shader_network.material_regularization(pts, normals, out["metallic"], out["roughness"], out["albedo"], step)
+        if self.cfg["reg_diffuse_light"]:
+            out["loss_diffuse_light"] = self.compute_diffuse_light_regularization(out["diffuse_light"])
+        return out
+
+    @torch.no_grad()
+    def test_step(self, index):
+        """materialRenderer.py:568-640, reduced to what the validation metrics read: the rendered and the ground-truth image."""
+        i = self.test_ids[index]
+        h, w = self.database.H, self.database.W
+        img = self.nvs(self.database.get_pose(i)[:3], self.database.get_K(i), h, w)
+        return {"rgb_pr": torch.from_numpy(img["color"]), "rgb_gt": torch.from_numpy(self.database.get_image(i).astype(np.float32) / 255.0),
+                "gt_mask": torch.from_numpy(self.database.get_mask(i) > 0)[..., None], **{k: torch.from_numpy(v) for k, v in img.items() if k != "color"}}
 
     def _set_extent(self):
         self.center = self.aabb.mean(0).float().view(1, 1, 3)
@@ -216,5 +282,10 @@ class MaterialRenderer(nn.Module):
         return mats
 
     def forward(self, data):
-        raise NotImplementedError("MaterialRenderer.forward drives the dataset tables (train_step / test_step); call shade() with "
-                                  "surface points, or nvs(pose, K, h, w)")
+        """materialRenderer.py:754-768: a training iteration (`data['step']`) or a validation image (`data['eval']`, `data['index']`)."""
+        if not hasattr(self, "train_table"):
+            raise NotImplementedError("MaterialRenderer.forward drives the dataset tables: construct with training=True on a TensoSDF "
+                                      "synthetic scene, or call shade() with surface points / nvs(pose, K, h, w)")
+        if "eval" not in data:
+            return self.train_step(data["step"])
+        return self.test_step(data["index"])
