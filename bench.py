@@ -407,13 +407,14 @@ def main():
             n_launch = summ[dom][1]
             ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-            # executed matrix-core flop: 1008 v_mfma_f32_32x32x16_f16 per 32-ray tile (K padded to 128/256, 3 terms per product)
-            executed = hits / 32.0 * 1008 * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
+            # executed matrix-core flop: 336 v_mfma_f32_32x32x16_f16 per 32-ray tile and product term (K padded to 128 / 256)
+            terms = {_ops.PREC_F16X3: 3, _ops.PREC_F16X2: 2, _ops.PREC_F16: 1}.get(sh.inner_precision, 3)
+            executed = hits / 32.0 * 336 * terms * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
             roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
                         frac=ach / peak, traffic=pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         executed_tflops=executed, frac_executed=executed / peak,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
-                                   f"({args.precision} MFMA: {'3 f16 MFMAs per fp32 product term, peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
+                                   f"({'f16 MFMA operands, fp32 accumulate, ' + str(terms) + ' MFMA per product term; peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
         elif dom == "flow_sample":
             n_launch = summ[dom][1]
             samples = timer.units.get("flow_sample", 0)
@@ -431,7 +432,7 @@ def main():
         line = {
             "metric": "shaded surface points/s @128 flow samples", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (f16x3 split on the f16 MFMA for the 256-wide decoder)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (matrix products on the f16 MFMA with fp32 accumulate: f16x3 operand split in the flow nets, f16 operands in the inner-light decoder; per-pixel parity 1e-4 in tests/)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
                                    f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",

@@ -26,9 +26,12 @@ static constexpr int kH1 = ((kIdeMat + 17 * 36 + 1023) / 1024) * 1024;   // 123 
 static constexpr int kH2 = kH1 + 8 * 4096;          // 256 -> 256: 16 k-steps16
 static constexpr int kH3 = kH2 + 16 * 4096;
 static constexpr int kH4 = kH3 + 16 * 4096;         // 256 -> 3: 16 k-steps16 x 1 tile = 2 slabs
-static constexpr int kInnerWsFloats = kH4 + 2 * 4096;
+static constexpr int kP1 = kH4 + 2 * 4096;          // 123 -> 256 with the IDE features first (inner_light_cols_kernel): 8 k-steps16
+static constexpr int kWp = kP1 + 8 * 4096;          // [256][123] scratch of the column permutation
+static constexpr int kInnerWsFloats = kWp + 256 * 123 + 32;
 
 extern "C" size_t tf_inner_light_workspace_floats(void) { return kInnerWsFloats; }
+static void ide_tables_host(float* mat);
 
 // ---- IDE tables (Ref-NeRF eq. 6-8; utils/ref_utils.py:8-78): (l, m) for l = 1,2,4,8,16, m = 0..l
 static void ide_tables_host(float* mat /*[17][36]*/) {
@@ -49,6 +52,13 @@ static void ide_tables_host(float* mat /*[17][36]*/) {
       }
     }
   }
+}
+
+// computed once per process (C++11 magic static: thread-safe), read-only afterwards
+static const float* ide_tables_cached() {
+  struct Table { float v[17 * 36]; Table() { ide_tables_host(v); } };
+  static const Table t;
+  return t.v;
 }
 
 __device__ __forceinline__ float relu(float x) { return tf_relu(x); }
@@ -128,7 +138,7 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
                                                           const float* __restrict__ depth, float near_eps, float exp_max,
                                                           float* __restrict__ out) {
   constexpr bool H3 = MODE != 0;
-  constexpr int TERMS = MODE == 1 ? 1 : 3;
+  constexpr int TERMS = MODE == 1 ? 1 : MODE == 2 ? 2 : 3;
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   if (m <= 0) return;
@@ -300,6 +310,381 @@ __global__ void __launch_bounds__(256) inner_light_kernel(const float* __restric
 #endif
 }
 
+
+// =====================================================================================================================
+// Column-owned form (f16x3 / f16x2 / f16 arithmetic).  The kernel above walks the whole weight image once per 128 rays through
+// an LDS ring: 42 slab steps per pass, each with a workgroup barrier, four LDS-DMA pieces and 16 fragment reads per wave in
+// front of 24 MFMAs -- the matrix pipe is busy 57 % of the time and every weight byte crosses the LDS once per 32 rays.
+// Here the roles of weights and activations are swapped:
+//   * a wave OWNS 64 of a layer's 256 output units (two 32-unit tiles) for all R = 128 rays of the pass (four 32-ray
+//     tiles): its weight fragments come straight from L2 into registers (1 KB coalesced wave loads, nobody else in the
+//     workgroup needs them) and each one feeds 4 ray tiles x TERMS MFMAs;
+//   * the ACTIVATIONS of a layer live in LDS as f16 MFMA B-fragments ([k-step][ray tile][hi|lo][lane][8 halves], written
+//     by the wave that produced them straight from its accumulator registers -- the unit permutation folded into the weight
+//     packing makes an accumulator lane's 8 registers one 16-byte B-fragment), every wave reads all of them;
+//   * two barriers per layer (inputs read / outputs written) instead of one per 16 KB of weights; per k-step a wave issues 2-4
+//     global loads + 4-8 ds_read_b128 for 8-24 MFMAs.
+// TERMS = 3: weights and activations split hi + lo (fp32-grade products, 128 KB of LDS, one workgroup per CU).
+// TERMS = 2: weights split, activations rounded to f16 once per layer.  TERMS = 1: plain f16 operands.  (64 KB of LDS: two
+// workgroups per CU -- one computes its encodings / epilogues under the other's MFMAs.)
+// The input row is cat[IDE (72), pos_enc8 (51), 0 (5)] -- IDE first so that no 4-value store granule straddles the two encoders
+// (waves 0-1 compute the positional encoding of the pass's 128 rays, waves 2-3 the IDE); layer 1's weight columns are packed in
+// that order (kP1).
+template <int TERMS>
+struct IL2 {
+  static constexpr int R = 128, RT = 4;
+  static constexpr int XP = TERMS == 3 ? 2 : 1;     // activation planes in LDS (hi | lo)
+  static constexpr int AP = TERMS >= 2 ? 2 : 1;     // weight planes fetched
+  static constexpr int ACT16 = 16 * RT * XP * 64;   // 16-byte units
+};
+
+// 8-byte slot of feature k (k % 4 == 0) of ray (r, j) in the layer-1 B-fragment image; `plane` 0 = hi, 1 = lo
+template <int XP>
+__device__ __forceinline__ int il2_slot8(int k, int r, int j, int plane) {
+  const int s = 2 * (k >> 5) + ((k >> 4) & 1), c = (k >> 3) & 1, h = (k >> 2) & 1;
+  return ((((s * 4 + r) * XP + plane) * 64 + j + 32 * h) << 1) + c;   // in 8-byte units
+}
+
+template <int XP>
+__device__ __forceinline__ void il2_store4(uint2* act8, int k, int r, int j, float a, float b, float c, float d) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h01 = {(_Float16)a, (_Float16)b}, h23 = {(_Float16)c, (_Float16)d};
+  uint2 v;
+  v.x = __builtin_bit_cast(unsigned, h01); v.y = __builtin_bit_cast(unsigned, h23);
+  act8[il2_slot8<XP>(k, r, j, 0)] = v;
+  if (XP == 2) {
+    const h2 l01 = {(_Float16)(a - (float)h01[0]), (_Float16)(b - (float)h01[1])};
+    const h2 l23 = {(_Float16)(c - (float)h23[0]), (_Float16)(d - (float)h23[1])};
+    v.x = __builtin_bit_cast(unsigned, l01); v.y = __builtin_bit_cast(unsigned, l23);
+    act8[il2_slot8<XP>(k, r, j, 1)] = v;
+  }
+}
+
+// Weight fragments in flight: a ring of PF + 1 k-steps (two unit tiles x AP planes each).  A layer starts with its first PF
+// k-steps already requested (il2_prefetch, issued before the barriers / epilogue of the layer in front of it: an L2 round trip
+// per layer start was otherwise exposed four times per pass).
+constexpr int kIl2Pf = 3;
+template <int TERMS>
+struct Il2Ring { tf_h8 a[kIl2Pf + 1][2][IL2<TERMS>::AP]; };
+
+template <int TERMS>
+__device__ __forceinline__ void il2_prefetch(const tf_h8* __restrict__ Wl /* wave-uniform */, int T0, int lane, Il2Ring<TERMS>& ring) {
+  typedef IL2<TERMS> C;
+  // scalar base + 32-bit lane offset (global_load ... v_off, s[base:base+1]): written as a per-lane 64-bit pointer every
+  // k-step's address became a loop-invariant VGPR pair, hoisted out of the pass loop and spilled
+  const tf_h8* wp = Wl + T0 * 128;
+#pragma unroll
+  for (int s = 0; s < kIl2Pf; ++s)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < C::AP; ++p) ring.a[s][t][p] = wp[(unsigned)((s * 8 + t) * 128 + p * 64 + lane)];
+}
+
+// One hidden layer for this wave's two unit tiles T0, T0 + 1: acc[t][r] = bias + W x over K16 k-steps.
+// Wl: the layer's fragment image [k-step][8 unit tiles][hi|lo][lane] in 16-byte units, already offset by `lane`.
+template <int K16, int TERMS>
+__device__ __forceinline__ void il2_layer(const tf_h8* __restrict__ Wl /* wave-uniform */, int T0, int lane,
+                                          const tf_h8* __restrict__ actl /* + lane */,
+                                          Il2Ring<TERMS>& ring, const f32x16 (&bias)[2], f32x16 (&acc)[2][4]) {
+  typedef IL2<TERMS> C;
+  constexpr int PF = kIl2Pf;
+  const tf_h8* wp = Wl + T0 * 128;                    // (unit tile T0, plane 0) of k-step 0
+#ifdef IL2_NO_XPF
+  il2_prefetch<TERMS>(Wl, T0, lane, ring);
+#endif
+#pragma unroll
+  for (int s = 0; s < K16; ++s) {
+    if (s + PF < K16) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < C::AP; ++p) ring.a[(s + PF) % (PF + 1)][t][p] = wp[(unsigned)(((s + PF) * 8 + t) * 128 + p * 64 + lane)];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const tf_h8 b_hi = actl[((s * 4 + r) * C::XP) * 64];
+      tf_h8 b_lo = b_hi;
+      if (TERMS == 3) b_lo = actl[((s * 4 + r) * C::XP + 1) * 64];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const tf_h8 a_hi = ring.a[s % (PF + 1)][t][0];
+        acc[t][r] = tf_mfma_h(a_hi, b_hi, s == 0 ? bias[t] : acc[t][r]);
+        if (TERMS == 3) acc[t][r] = tf_mfma_h(a_hi, b_lo, acc[t][r]);
+        if (TERMS >= 2) acc[t][r] = tf_mfma_h(ring.a[s % (PF + 1)][t][C::AP - 1], b_hi, acc[t][r]);
+      }
+    }
+#ifndef IL2_NO_SB
+    __builtin_amdgcn_sched_barrier(0);      // bounds how far the B-fragment reads of later k-steps are hoisted (registers)
+#endif
+  }
+}
+
+// ReLU + conversion of this wave's 64 output units into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3).
+template <int TERMS>
+__device__ __forceinline__ void il2_publish(tf_h8* __restrict__ actl /* + lane */, int T0, const f32x16 (&acc)[2][4]) {
+  typedef IL2<TERMS> C;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
+        tf_h8* dst = actl + (((2 * (T0 + t) + u) * 4 + r) * C::XP) * 64;
+        if (TERMS == 3) {
+          tf_h8 hi, lo;
+          tf_split8(x8, hi, lo);
+          dst[0] = hi; dst[64] = lo;
+        } else {
+          tf_h8 hi;
+          tf_cvt8(x8, hi);
+          dst[0] = hi;
+        }
+      }
+}
+
+template <int TERMS>
+__global__ void __launch_bounds__(256, TERMS == 3 ? 1 : 2)
+inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
+                    const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
+                    const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
+                    float* __restrict__ out) {
+  typedef IL2<TERMS> C;
+  long long m = m_arg;
+  if (count_dev) m = min(m_arg, *count_dev);
+  if (m <= 0) return;
+  __shared__ __attribute__((aligned(16))) tf_h8 act[C::ACT16];
+  __shared__ __attribute__((aligned(16))) float lbias[4 * 2 * 256];   // [layer][lane half][tile * 16 + reg]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
+  for (int i = tid; i < 3 * 256 + 32; i += 256) {
+    const int layer = i < 768 ? i / 256 : 3, r = i < 768 ? i % 256 : i - 768;   // packed order: r = n * 2 + half
+    lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
+  }
+  const long long n_pass = (m + C::R - 1) / C::R;
+  const float vsign = idx ? -1.f : 1.f;
+  const int T0 = 2 * wave;
+#ifdef IL2_CLOCK    // dev-only: shader clock held inside this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
+  const unsigned long long ck0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  uint2* act8 = reinterpret_cast<uint2*>(act);
+  const int q_enc = 64 * (wave & 1) + lane;                // ray of the pass this lane encodes
+  const int q_out = 32 * wave + (lane & 31);               // ray of the pass whose radiance this lane stores (lanes 0..31)
+  // inputs of the first pass; inside the loop the NEXT pass's index row and input rows are requested a layer or two ahead
+  // of their use (two dependent L2 / HBM round trips otherwise open every pass)
+  float in6[6];
+  long long nsrc;
+  {
+    long long row = (long long)blockIdx.x * C::R + q_enc;
+    if (row >= m) row = m - 1;
+    nsrc = idx ? idx[row] : row;
+    if (wave < 2) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) in6[k] = pts[3 * nsrc + k];
+#pragma unroll
+      for (int k = 3; k < 6; ++k) in6[k] = 0.f;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { in6[k] = nrm[3 * nsrc + k]; in6[3 + k] = view[3 * nsrc + k]; }
+    }
+  }
+  Il2Ring<TERMS> ring;
+#ifndef IL2_NO_XPF
+  il2_prefetch<TERMS>(reinterpret_cast<const tf_h8*>(ws_arg) + kP1 / 4, T0, lane, ring);
+#endif
+#ifdef IL2_STAMPS   // dev-only: shader-clock stamps of one pass of workgroup 0, per wave
+  unsigned long long st[12];
+  int n_st = 0;
+#define IL2_STAMP() do { if (blockIdx.x == 0 && pass == blockIdx.x + 4LL * gridDim.x && n_st < 12) st[n_st++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IL2_STAMP() do {} while (0)
+#endif
+  for (long long pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    const float* ws = ws_arg;
+    asm volatile("" : "+s"(ws));
+    IL2_STAMP();
+    const tf_h8* W = reinterpret_cast<const tf_h8*>(ws);     // wave-uniform, 16-byte units (kP1 etc. are float offsets)
+    // ---- encodings of the pass's 128 rays: waves 0-1 positional (features 72..122), waves 2-3 IDE (features 0..71)
+    {
+      const int r = q_enc >> 5, j = q_enc & 31;
+      if (wave < 2) {
+        const float p[3] = {in6[0], in6[1], in6[2]};
+        float enc[56];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) enc[k] = p[k];
+        if (__all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f)) {
+#pragma unroll
+          for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tf_sincos_small(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
+        } else {
+#pragma unroll
+          for (int f = 0; f < 8; ++f)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tf_sincos(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
+        }
+#pragma unroll
+        for (int k = 51; k < 56; ++k) enc[k] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 14; ++g) il2_store4<C::XP>(act8, 72 + 4 * g, r, j, enc[4 * g], enc[4 * g + 1], enc[4 * g + 2], enc[4 * g + 3]);
+      } else {
+        float n[3] = {in6[0], in6[1], in6[2]};
+        float v[3] = {vsign * in6[3], vsign * in6[4], vsign * in6[5]};
+        float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+        n[0] *= inv; n[1] *= inv; n[2] *= inv;
+        inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+        const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+        const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+        float zp[17], cre[17], cim[17];
+        zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
+#pragma unroll
+        for (int k = 1; k < 17; ++k) {
+          zp[k] = zp[k - 1] * rz;
+          cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
+          cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
+        }
+        // wave-uniform table through the scalar cache.  (As compile-time literals the 222 coefficients were materialised in
+        // SGPRs, hoisted out of the pass loop as loop invariants and spilled: 175 scalar + 300 vector spills.)
+        const __attribute__((address_space(4))) float* mat =
+            (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
+        float enc[72];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+#pragma unroll
+          for (int mm = 0; mm <= (1 << d); ++mm) {
+            const int col = (1 << d) - 1 + d + mm;
+            float poly = 0.f;
+#pragma unroll
+            for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+            enc[col] = cre[mm] * poly;
+            enc[36 + col] = cim[mm] * poly;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 18; ++g) il2_store4<C::XP>(act8, 4 * g, r, j, enc[4 * g], enc[4 * g + 1], enc[4 * g + 2], enc[4 * g + 3]);
+      }
+    }
+    // index rows: this pass's output ray, the next pass's input ray
+    long long orow = pass * C::R + q_out;
+    const bool ovalid = orow < m;
+    if (!ovalid) orow = m - 1;
+    const long long osrc = idx ? idx[orow] : orow;
+    const long long npass = pass + gridDim.x;
+    if (npass < n_pass) {
+      long long row = npass * C::R + q_enc;
+      if (row >= m) row = m - 1;
+      nsrc = idx ? idx[row] : row;
+    }
+    IL2_STAMP();
+    __syncthreads();
+    IL2_STAMP();
+    f32x16 acc[2][4], bias[2];
+    // ---- layer 1 (K = 128)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const float4 v4 = *reinterpret_cast<const float4*>(lbias + hh * 256 + (T0 + t) * 16 + 4 * qd);
+        bias[t][4 * qd] = v4.x; bias[t][4 * qd + 1] = v4.y; bias[t][4 * qd + 2] = v4.z; bias[t][4 * qd + 3] = v4.w;
+      }
+    il2_layer<8, TERMS>(W + kP1 / 4, T0, lane, act + lane, ring, bias, acc);
+#ifndef IL2_NO_XPF
+    il2_prefetch<TERMS>(W + kH2 / 4, T0, lane, ring);
+#endif
+    IL2_STAMP();
+    __syncthreads();
+    IL2_STAMP();
+    il2_publish<TERMS>(act + lane, T0, acc);
+    IL2_STAMP();
+    __syncthreads();
+    IL2_STAMP();
+    // ---- layers 2, 3 (K = 256)
+    const float dep = depth ? depth[osrc] : 1.f;
+    if (npass < n_pass) {                                   // next pass's input rows (consumed at the top of the next iteration)
+      if (wave < 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in6[k] = pts[3 * nsrc + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { in6[k] = nrm[3 * nsrc + k]; in6[3 + k] = view[3 * nsrc + k]; }
+      }
+    }
+    tf_h8 a4[16];                                            // layer 4's weight fragments (hi), requested under layer 3's epilogue
+#pragma unroll
+    for (int layer = 1; layer < 3; ++layer) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const float4 v4 = *reinterpret_cast<const float4*>(lbias + layer * 512 + hh * 256 + (T0 + t) * 16 + 4 * qd);
+          bias[t][4 * qd] = v4.x; bias[t][4 * qd + 1] = v4.y; bias[t][4 * qd + 2] = v4.z; bias[t][4 * qd + 3] = v4.w;
+        }
+      il2_layer<16, TERMS>(W + (layer == 1 ? kH2 : kH3) / 4, T0, lane, act + lane, ring, bias, acc);
+#ifndef IL2_NO_XPF
+      if (layer == 1) il2_prefetch<TERMS>(W + kH3 / 4, T0, lane, ring);
+#endif
+      if (layer == 2) {
+        const tf_h8* W4 = W + kH4 / 4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a4[s] = W4[(unsigned)(s * 128 + lane)];
+      }
+      if (layer == 1) IL2_STAMP();
+      __syncthreads();
+      il2_publish<TERMS>(act + lane, T0, acc);
+      __syncthreads();
+      if (layer == 1) IL2_STAMP();
+    }
+    IL2_STAMP();
+    // ---- layer 4 (256 -> 3): wave w takes ray tile w
+    {
+      f32x16 o;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = lbias[1536 + hh * 256 + j];
+      const tf_h8* W4 = W + kH4 / 4;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const tf_h8 b_hi = act[((s * 4 + wave) * C::XP) * 64 + lane];
+        o = tf_mfma_h(a4[s], b_hi, o);
+        if (TERMS == 3) o = tf_mfma_h(a4[s], act[((s * 4 + wave) * C::XP + 1) * 64 + lane], o);
+        if (TERMS >= 2) o = tf_mfma_h(W4[(unsigned)(s * 128 + 64 + lane)], b_hi, o);
+      }
+#ifndef IL2_NO_XPF
+      il2_prefetch<TERMS>(W + kP1 / 4, T0, lane, ring);           // the next pass's first layer
+#endif
+      if (ovalid && hh == 0) {
+        const float near = (depth && !(dep > near_eps)) ? 0.f : 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[3 * osrc + c] = expf(fminf(o[c], exp_max)) * near;
+      }
+    }
+    IL2_STAMP();
+    __syncthreads();      // the next pass's encodings overwrite the activation image
+  }
+#ifdef IL2_CLOCK
+  if (blockIdx.x == 0 && tid == 0) {
+    const unsigned long long ck1 = __builtin_readcyclecounter(), rt1 = __builtin_amdgcn_s_memrealtime();
+    printf("il2<%d> block 0: %llu shader ticks in %.1f us -> %.3f GHz\n", TERMS, ck1 - ck0, (rt1 - rt0) * 0.01, (double)(ck1 - ck0) / ((rt1 - rt0) * 10.0));
+  }
+#endif
+#ifdef IL2_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && n_st > 1) {
+    printf("il2<%d> wave %d: enc %llu | bar %llu | L1 %llu | bar %llu | pub %llu | bar %llu | L2 %llu | bar+pub+bar %llu | L3.. %llu | L4 %llu | total %llu\n", TERMS, wave,
+           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[10] - st[9], st[10] - st[0]);
+  }
+#endif
+}
+
+// Layer-1 weights with the columns in the order of the column-owned kernel's input row: [IDE (72) | pos_enc8 (51)].
+static __global__ void __launch_bounds__(256) inner_light_cols_kernel(const float* __restrict__ W /*[256,123]*/, float* __restrict__ Wp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 256 * 123) return;
+  const int row = e / 123, k = e % 123;
+  Wp[e] = W[row * 123 + (k < 72 ? 51 + k : k - 72)];
+}
+
 static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
                               const int64_t* idx, const int64_t* count_dev, const float* depth, float near_eps, float exp_max,
                               int32_t precision, float* out, float* workspace, size_t workspace_floats, hipStream_t stream,
@@ -307,7 +692,9 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16, TF_EINVAL,
+  const bool ring = (precision & 0x200) != 0;   // dev-only: the slab-ring kernel (kept for A/B timing of the column-owned one)
+  precision &= ~0x200;
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16 || precision == TF_PREC_F16X2, TF_EINVAL,
              "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
@@ -326,31 +713,48 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
+      inner_light_cols_kernel<<<tf_blocks(256 * 123, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kP1);
     }
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[3], 3, 1, workspace + kIB4);
-    static float ide_host[17 * 36];
-    static bool ide_ready = false;
-    if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
-    hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+    hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_tables_cached(), 17 * 36 * sizeof(float), hipMemcpyHostToDevice, stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   }
 #ifndef TF_INNER_BLOCKS
 #define TF_INNER_BLOCKS 1024   // persistent workgroups (one resident per CU at a time)
 #endif
+#define IL_ARGS workspace, pts, view, nrm, m, (const long long*)idx, (const long long*)count_dev, depth, near_eps, exp_max, out
+  // f16x3 stays on the slab-ring kernel (measured: 6.1 ms against 6.8 ms column-owned per 7.4 M rays -- with hi + lo activations
+  // the column-owned image needs 128 KB of LDS, one workgroup per CU, and loses its overlap partner); IL2_X3 (dev) switches it over
+#ifdef IL2_X3
+  const bool cols = precision != TF_PREC_F32 && !ring;
+#else
+  const bool cols = (precision == TF_PREC_F16 || precision == TF_PREC_F16X2) && !ring;
+#endif
+  if (cols) {
+    // column-owned kernel: 128 rays per pass, persistent workgroups (two resident per CU)
+    long long blocks = (m + 127) / 128;
+    const long long cap = precision == TF_PREC_F16X3 ? 256 : 512;
+    if (blocks > cap) blocks = cap;
+#ifdef IL2_X3
+    if (precision == TF_PREC_F16X3) inner_light2_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+    else
+#endif
+    if (precision == TF_PREC_F16X2) inner_light2_kernel<2><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+    else inner_light2_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+    TF_LAUNCH_CHECK(who);
+    return TF_OK;
+  }
   long long blocks = (m + 127) / 128;
   if (blocks > TF_INNER_BLOCKS) blocks = TF_INNER_BLOCKS;
-  if (precision == TF_PREC_F32)
-    inner_light_kernel<0><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
-                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
-  else if (precision == TF_PREC_F16)
-    inner_light_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
-                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
-  else
-    inner_light_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(workspace, pts, view, nrm, m, (const long long*)idx,
-                                                               (const long long*)count_dev, depth, near_eps, exp_max, out);
+  if (precision == TF_PREC_F32) inner_light_kernel<0><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+  else if (precision == TF_PREC_F16) inner_light_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+  else if (precision == TF_PREC_F16X2) inner_light_kernel<2><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+  else inner_light_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
+#undef IL_ARGS
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -427,10 +831,7 @@ extern "C" int tf_inner_light_encode(const float* pos, const float* dirs, const 
   if (capacity == 0) return TF_OK;
   TF_REQUIRE(pos && dirs && nrm && X && workspace, TF_EINVAL, "tf_inner_light_encode: null pointer");
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_encode: workspace too small");
-  static float ide_host[17 * 36];
-  static bool ide_ready = false;
-  if (!ide_ready) { ide_tables_host(ide_host); ide_ready = true; }
-  hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+  hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_tables_cached(), 17 * 36 * sizeof(float), hipMemcpyHostToDevice, stream);
   TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_encode: hipMemcpyAsync failed: %s", hipGetErrorString(e));
   inner_light_encode_kernel<<<tf_blocks(capacity, 256), 256, 0, stream>>>(workspace + kIdeMat, pos, dirs, nrm, capacity,
                                                                          (const long long*)idx, (const long long*)count_dev, X);

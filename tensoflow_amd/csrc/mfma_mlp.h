@@ -502,13 +502,15 @@ __device__ __forceinline__ void tf_bsplit(TfBsplit<SL16>& B, int s16base, const 
     B.hi[sl] = __builtin_bit_cast(tf_h8, va);
     B.lo[sl] = __builtin_bit_cast(tf_h8, vb);
 #else
-    if (TERMS == 3) tf_split8(x8, B.hi[sl], B.lo[sl]);
+    if (TERMS >= 3) tf_split8(x8, B.hi[sl], B.lo[sl]);
     else tf_cvt8(x8, B.hi[sl]);
 #endif
   }
 }
 
 // TERMS = 3: f16x3 (fp32-accurate).  TERMS = 1: plain f16 operands (TF_PREC_F16) -- the lo fragments are neither read nor used.
+// TERMS = 2: weights split (hi + lo), activations rounded to f16 once per layer (w_hi x + w_lo x).
+// TERMS = 4: weights rounded to f16, activations split (w_hi x_hi + w_hi x_lo): the lo fragments are not read.
 // `bc`: this step's B operands, prepared by the PREVIOUS step (or by the layer prologue); `bn` (NEXT >= 0): the next step's are
 // split here, behind the second MFMA group -- at the step boundary the split's 13 vector instructions ran with an idle matrix
 // pipe (one wave per SIMD: nothing else to issue), 42 times per tile.
@@ -533,7 +535,7 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
 #pragma unroll
       for (int q = 2 * (c - 1); q < 2 * c; ++q) {
         nxt.hi[q] = nbuf[q * 128];
-        if (TERMS == 3) nxt.lo[q] = nbuf[q * 128 + 64];
+        if (TERMS == 3 || TERMS == 2) nxt.lo[q] = nbuf[q * 128 + 64];
       }
     }
 #ifdef TF_ABLATE_HALF_DMA   // dev-only timing ablation: half the weight bytes are fetched (results are garbage)
@@ -543,7 +545,7 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
 #endif
 #ifndef TF_SPLIT_AT_BOUNDARY
     if (NEXT >= 0) {
-      if (TERMS == 3 && SL16 <= 2) {
+      if (TERMS >= 3 && SL16 <= 2) {
         // one four-instruction piece per MFMA group: k-step 0 of the next slab in groups 5, 6, 7 (SL16 = 1) or 2, 3, 4 with
         // k-step 1 in 5, 6, 7 (SL16 = 2)
         const int first = SL16 == 1 ? 5 : 2;
@@ -569,10 +571,8 @@ __device__ __forceinline__ void tf_h3s_step(TfStream& S, const TfFrag& cur, TfFr
     }
 #endif
     out[t] = tf_mfma_h(cur.hi[c], bc.hi[sl], out[t]);
-    if (TERMS == 3) {
-      out[t] = tf_mfma_h(cur.hi[c], bc.lo[sl], out[t]);
-      out[t] = tf_mfma_h(cur.lo[c], bc.hi[sl], out[t]);
-    }
+    if (TERMS >= 3) out[t] = tf_mfma_h(cur.hi[c], bc.lo[sl], out[t]);
+    if (TERMS == 3 || TERMS == 2) out[t] = tf_mfma_h(cur.lo[c], bc.hi[sl], out[t]);
     __builtin_amdgcn_sched_barrier(0);
   }
 #ifdef TF_SPLIT_AT_BOUNDARY   // dev-only: the previous placement

@@ -12,7 +12,7 @@ import torch
 from . import lib as L
 
 
-PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2      # TfPrecision (PREC_F16: flow + inner-light decoders only, outside the 1e-4 bar)
+PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2 = 0, 1, 2, 3      # TfPrecision (PREC_F16: flow + inner-light decoders only, outside the 1e-4 bar)
 
 
 def _stream():

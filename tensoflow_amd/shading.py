@@ -156,6 +156,11 @@ class MCShader:
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
+        # Inner-light decoder (123-256-256-256-3): plain f16 MFMA operands, fp32 accumulate.  Its operand rounding stays below the
+        # fp32 evaluation noise of the reference's own degree-16 IDE features and an order of magnitude inside the 1e-4 per-pixel
+        # bar (tests/test_gpu_parity.py::test_inner_light_operand_modes_on_trained_like_net, golden shading_stress); set to
+        # ops.PREC_F16X3 / ops.PREC_F32 for fp32-grade products at 2.4x / 7.7x the kernel time.
+        self.inner_precision = ops.PREC_F16
         self.cull_dead_rays = True      # skip BVH + inner light for rays whose weight is exactly 0 (result unchanged)
         self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
         self.unit = float(unit_size)
@@ -220,7 +225,8 @@ class MCShader:
         with T.stage("inner_light"):
             hit_lights = torch.empty_like(dirs)
             ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, hit_lights, near_eps=1e-5,
-                                    exp_max=self.exp_max, precision=self.precision, cache=self.inner_cache)
+                                    exp_max=self.exp_max, precision=self.inner_precision if self.precision != ops.PREC_F32 else ops.PREC_F32,
+                                    cache=self.inner_cache)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return hit_lights, hit, depth, inters
 

@@ -219,6 +219,69 @@ def gen_shading():
                           cfg.get("nis_specular_sample_num", 32)], np.int32), **arr)
 
 
+def gen_shading_wide():
+    """BASELINE configs[3] / [4] sample counts (256 / 512 flow samples per lobe) and a trained-like inner-light net, on the
+    `shading_default` network (same seed, same state_dict: only the arrays that differ are stored, the tests merge them over
+    shading_default.npz).  `stress`: the inner-light net's weight-norm gains are raised until its output log-radiance spans about
+    +-2 (a freshly initialised net answers ~0 everywhere, which would hide operand-rounding error of its 256-wide layers)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, o + 2 * unit * d, d)
+    base_sd = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_default.npz")).items() if k.startswith("sd/")}
+    for tag, extra, pn, seed in (("s256", dict(nis_diffuse_sample_num=256, nis_specular_sample_num=256), 5, 16),
+                                 ("s512", dict(nis_diffuse_sample_num=512, nis_specular_sample_num=512), 4, 26),
+                                 ("stress", dict(), 24, 36)):
+        torch.manual_seed(4)
+        cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+                   gridSize=[R, R, R], light_reso=16, **extra)
+        net = MCShadingNetwork(cfg, trace, AABB)
+        g = torch.Generator().manual_seed(3)
+        net.mat_plane = torch.nn.ParameterList(
+            [torch.nn.Parameter(0.3 * torch.randn(1, 36, R, R, generator=g)) for _ in range(3)])
+        net.mat_line = torch.nn.ParameterList(
+            [torch.nn.Parameter(0.5 + 0.3 * torch.randn(1, 36, R, 1, generator=g)) for _ in range(3)])
+        for fl in (net.flow_diffuse, net.flow_specular, net.flow_diffuse_copy, net.flow_specular_copy):
+            perturb_(list(fl.nis_plane) + list(fl.nis_line), 0.1, 3)
+            perturb_([p for n, p in fl.flows.named_parameters() if "weight" in n], 0.05, 5)
+        with torch.no_grad():
+            net.outer_light.base.add_(0.5 * torch.randn(net.outer_light.base.shape, generator=g))
+        changed = {}
+        if tag == "stress":
+            with torch.no_grad():
+                for n_, p_ in net.inner_light.named_parameters():
+                    if n_.endswith("original0"):                      # weight-norm gain g
+                        p_.mul_(6.0 if n_.startswith("6.") else 1.6)
+                    if n_.endswith("bias") and not n_.startswith("6."):
+                        p_.add_(0.05 * torch.randn(p_.shape, generator=g))
+        net.eval()
+        sd = net.state_dict()
+        for k, v in sd.items():
+            if k not in base_sd or not torch.equal(v, base_sd[k]):
+                changed[k] = v
+        assert all(k.startswith("inner_light.") for k in changed), list(changed)[:5]
+        pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=seed)]
+        with torch.no_grad():
+            colors, outputs = net(pts, view, nrm, None, None, False)
+            gd = torch.Generator().manual_seed(seed + 1)
+            dirs = torch.nn.functional.normalize(torch.randn(pn * 16, 3, generator=gd), dim=-1)
+            lights, _, inters, lnrm, hit = net.get_lights(pts.repeat_interleave(16, 0)[:, None], dirs[:, None], None)
+        hl = lights[:, 0][hit[:, 0]]
+        print(tag, "hit rays", int(hit.sum()), "log-radiance of hit rays: mean %.3f std %.3f min %.3f max %.3f" % (
+            float(hl.log().mean()), float(hl.log().std()), float(hl.log().min()), float(hl.log().max())))
+        keep = ("albedo", "roughness", "metallic", "rgb_pr_nis", "diffuse_color_nis", "specular_color_nis", "visibility_nis",
+                "indirect_light_nis", "diffuse_light_nis", "specular_light_nis")
+        arr = {"out/" + k: outputs[k] for k in keep}
+        save(f"shading_{tag}", sd=changed, pts=pts, view_in=view, normals_in=nrm, colors=colors, unit_size=np.float32(unit),
+             gl_dirs=dirs, gl_lights=lights[:, 0], gl_hit=hit[:, 0], gl_inters=inters[:, 0], gl_normals=lnrm[:, 0],
+             sn=np.array([512, 256, cfg.get("nis_diffuse_sample_num", 64), cfg.get("nis_specular_sample_num", 32)], np.int32), **arr)
+
+
 def gen_march():
     """ShapeRenderer.sample_ray / compute_sdf_alpha / render_core (shapeRenderer.py:871,995,1105)."""
     from network.shapeRenderer import ShapeRenderer
