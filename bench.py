@@ -10,10 +10,14 @@ Workload = BASELINE.json configs[2] ("compressor material stage, 128 flow direct
 1xMI355X") at the reference's field sizes (R = 512, C = 36 / 12), random-init weights, analytic
 sphere+torus mesh (no dataset / checkpoint exists offline).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  Points are sharded across ranks with no data-path collective
-(weak scaling: fixed points per GPU).
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank;
+started plainly with --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>`
+itself, BEFORE touching the GPU, and exits with the launcher's code.  Rank 0 prints ONE JSON line.  Eval leg: points are
+sharded across ranks with no data-path collective (weak scaling: fixed points per GPU).  Training leg (`train_dp`, BASELINE
+configs[3]): 256 flow samples, every rank trains on its own 2048-point shard and the parameter gradients (~190 MB fp32) are
+averaged by RCCL (reduce-scatter + all-gather over xGMI, tensoflow_amd/dist.py) before the Adam step.
 """
 import argparse
 import json
@@ -322,6 +326,146 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
                 envlight_build_mips_ms=build_mips_ms, update_alpha_mask_ms=mask_ms)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (rendezvous on 127.0.0.1, a free
+    port) as a CHILD process -- nothing in this process has touched the GPU yet -- and return its exit code (non-zero if any rank
+    failed: torch.distributed.run propagates it)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# trainable tensors of the material stage at the reference's sizes (MCShadingNetwork.get_optparam_groups, fields.py:1580-1595;
+# SURVEY.md 5.8): [count, shape]
+MATERIAL_GRAD_SHAPES = [
+    (3, (1, 36, 512, 512)), (3, (1, 36, 512, 1)),                       # mat_plane / mat_line
+    (1, (6, 128, 128, 3)),                                              # outer_light.base
+    (2 * 3, (1, 12, 512, 512)), (2 * 3, (1, 12, 512, 1)),               # two trainable flows' nis_plane / nis_line
+    (1, (256, 123)), (2, (256, 256)), (1, (3, 256)),                    # inner_light
+    (3, (128, 108)), (2 * 8, (64, 64)),                                 # predictors, coupling nets (order of magnitude)
+]
+
+
+def allreduce_probe(device, world, steps, stats_mode="auto"):
+    """The exchange step alone: average a synthetic gradient set of the material stage's sizes across ranks (same buckets, same
+    collectives as the training step).  -> dict(ms, bytes, algbw, busbw)."""
+    import torch.distributed as dist
+    from tensoflow_amd.dist import allreduce_gradients
+    params = []
+    g = torch.Generator().manual_seed(1234 + dist.get_rank())
+    for count, shape in MATERIAL_GRAD_SHAPES:
+        for _ in range(count):
+            p = torch.nn.Parameter(torch.zeros(shape, device=device))
+            p.grad = torch.randn(shape, generator=g).to(device)
+            params.append(p)
+    expect = None
+    if world <= 8:           # correctness of the mean on one small tensor (all ranks know every rank's seed)
+        last = MATERIAL_GRAD_SHAPES[-1][1]
+        expect = 0
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1234 + r)
+            for count, shape in MATERIAL_GRAD_SHAPES:
+                for _ in range(count):
+                    t = torch.randn(shape, generator=gr)
+            expect = expect + t
+        expect = expect / world
+    allreduce_gradients(params, world=world, mode=stats_mode)           # warm-up (communicator set-up) + correctness
+    ok = True
+    if expect is not None:
+        ok = bool(torch.allclose(params[-1].grad.cpu(), expect, atol=1e-5))
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    stats = {}
+    for _ in range(steps):
+        allreduce_gradients(params, world=world, mode=stats_mode, stats=stats)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    nbytes = stats["bytes"] / steps
+    return dict(ms=dt * 1e3, bytes=int(nbytes), collectives_per_step=stats["collectives"] // steps, mode=stats.get("mode"),
+                algbw_GBps=nbytes / dt / 1e9, busbw_GBps=nbytes / dt / 1e9 * 2 * (world - 1) / world, ranks=world,
+                mean_matches_reference=ok, backend=dist.get_backend())
+
+
+def allreduce_only(args):
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("TENSOFLOW_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group(backend)
+    res = allreduce_probe(device, world, max(1, args.steps))
+    if rank == 0:
+        print(json.dumps({"metric": "gradient all-reduce (material stage sizes)", "n_gpus": world, "allreduce": res}))
+    ok = torch.tensor([1.0 if res["mean_matches_reference"] else 0.0], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if float(ok) == 1.0 else 3
+
+
+def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256):
+    """BASELINE configs[3] at this node's rank count: MCShadingNetwork training step with S flow samples per lobe on every rank's
+    own shard of the surface points (rank-strided in a real run; here seeded by rank), NIS losses on, backward, gradient
+    averaging over all ranks (dist.allreduce_gradients: reduce-scatter + all-gather on RCCL), Adam step.  Timed between barriers,
+    max over ranks; the collective's own time comes from HIP events around it."""
+    import torch.distributed as dist
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    from tensoflow_amd.synth import sphere_surface_points
+    from tensoflow_amd.trainer import MaterialTrainer
+    torch.manual_seed(6033)                                                  # identical replicas
+    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, unit)
+    tr = MaterialTrainer(m, {"total_step": 100000}, world=world)
+    tr.step_count = 600                                                      # past nis_loss_iter: every trainable tensor gets a gradient
+    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=99 + 1000 * rank)]
+    target = torch.rand(pn, 3, device=device)
+    tr.train_step(pts, view, nrm, target)
+    tr.comm_stats = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(pts, view, nrm, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    dt /= steps
+    n_par = sum(p.numel() for p in tr.trainable())
+    res = dict(workload=f"BASELINE configs[3]: MCShadingNetwork train step, {pn} points per GPU x ({S} + 512 + {S}) rays, NIS losses, "
+                        f"fwd + bwd + gradient averaging + Adam", ms_per_step=dt * 1e3, points_per_s=world * pn / dt,
+               trainable_parameters=n_par, gradient_bytes=4 * n_par, ranks=world)
+    ev = tr.comm_stats.get("events", [])
+    if ev:
+        ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        nbytes = tr.comm_stats["bytes"] / steps
+        res["allreduce"] = dict(ms_per_step=ms, bytes=int(nbytes), collectives_per_step=tr.comm_stats["collectives"] // steps,
+                                mode=tr.comm_stats.get("mode"), algbw_GBps=nbytes / ms / 1e6,
+                                busbw_GBps=nbytes / ms / 1e6 * 2 * (world - 1) / world, backend=dist.get_backend(), ranks=world)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,7 +479,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-points", type=int, default=2048, help="surface points per GPU per training step (the reference's batch)")
+    ap.add_argument("--allreduce-only", action="store_true",
+                    help="launcher + gradient-collective leg only, on synthetic gradient buffers of the material stage's parameter "
+                         "sizes (no kernels: runs on CPU under TENSOFLOW_BENCH_BACKEND=gloo; used by tests/test_dist_gloo.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.allreduce_only:
+        return allreduce_only(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -397,6 +550,16 @@ def main():
         dt = float(tt)
     value = world * pn * args.steps / dt
 
+    train_dp = None
+    if dist_on and not args.no_train:
+        from tensoflow_amd.shading import _NoTimer as _NT
+        sh.timer = _NT()
+        try:
+            train_dp = train_dp_leg(device, verts, faces, aabb, unit, world, rank, max(2, args.steps), args.train_points)
+        except Exception as e:      # every rank takes the same branch (same code, same inputs); the eval line is never lost over it
+            train_dp = {"error": f"{type(e).__name__}: {e}"}
+        sh.timer = timer
+
     if rank == 0:
         summ = timer.summary()
         stages = {k: dict(ms_per_step=v[0] / args.steps, launches=v[1]) for k, v in summ.items()}
@@ -440,6 +603,8 @@ def main():
             "roofline": roof,
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }
+        if train_dp is not None:
+            line["train_dp"] = train_dp
         from tensoflow_amd.shading import _NoTimer
         sh.timer = _NoTimer()                     # the secondary probes below are not part of the timed region
         if world == 1 and not args.no_train:

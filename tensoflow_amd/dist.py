@@ -24,17 +24,28 @@ def shard_batch(batch_start, batch_size, rank, world):
     return batch_start + lo, batch_start + hi
 
 
-def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True):
+def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True, mode="auto", stats=None):
     """Sum (then average) .grad of `params` across ranks in a few large flat buckets.
     Large buckets suit xGMI: RCCL rings are per-link bound (7 x ~153 GB/s), so fewer, bigger collectives win.
-    Parameters whose grad is None on every rank (e.g. the frozen `*_copy` flows, fields.py:1054-1065) are skipped
-    consistently because the decision only depends on the parameter list, not on rank-local state: a missing grad
-    is treated as zeros."""
+
+    mode "rs_ag": every bucket is reduce-scattered (each rank owns 1/world of it), scaled, then all-gathered -- the split
+    SURVEY.md 8(e) sizes for the 7 direct links (the 1/world scaling runs on the owned slice only).  mode "allreduce": one
+    all_reduce per bucket.  "auto" = rs_ag where the backend has reduce_scatter_tensor (nccl = RCCL), all_reduce under gloo.
+
+    Parameters whose grad is None on THIS rank but not on others would desynchronise the replicas' Adam states; a parameter
+    therefore takes part iff `requires_grad` (a decision every rank makes identically from the parameter list) and a missing
+    grad counts as zeros -- callers that must not step untouched parameters (flows before nis_loss_iter, fields.py:1284) pass only
+    the parameters that receive gradients at this step (MaterialTrainer.trainable(step)).
+
+    stats (dict, optional): accumulates 'bytes', 'collectives' and -- on CUDA tensors -- a list of (start, end) events under
+    'events' so that the caller can report the collective's time and bus bandwidth without a host sync inside the step."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     params = [p for p in params if p.requires_grad]
     if world == 1 or not params:
         return 0
+    if mode == "auto":
+        mode = "rs_ag" if dist.get_backend() == "nccl" else "allreduce"
     n_coll = 0
     bucket, size = [], 0
 
@@ -42,20 +53,49 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True)
         nonlocal bucket, size, n_coll
         if not bucket:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        if average:
-            flat /= world
+        n = sum(p.numel() for p in bucket)
+        pad = (-n) % world
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket]
+        if pad:
+            parts.append(torch.zeros(pad, dtype=parts[0].dtype, device=parts[0].device))
+        flat = torch.cat(parts)
+        ev = None
+        if stats is not None and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if mode == "rs_ag":
+            shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+            if average:
+                shard /= world
+            dist.all_gather_into_tensor(flat, shard)
+            n_coll += 2
+        else:
+            if flat.is_cuda and dist.get_backend() == "gloo":      # 1-GPU dry runs of the N-rank path: stage through the host
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                flat.copy_(host)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat /= world
+            n_coll += 1
+        if ev is not None:
+            ev[1].record()
+            stats.setdefault("events", []).append(ev)
+        if stats is not None:
+            stats["bytes"] = stats.get("bytes", 0) + flat.numel() * flat.element_size()
+            stats["collectives"] = stats.get("collectives", 0) + (2 if mode == "rs_ag" else 1)
+            stats["mode"] = mode
         off = 0
         for p in bucket:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p)
+            k = p.numel()
+            g = flat[off:off + k].view_as(p)
             if p.grad is None:
                 p.grad = g.clone()
             else:
                 p.grad.copy_(g)
-            off += n
-        n_coll += 1
+            off += k
         bucket, size = [], 0
 
     for p in params:

@@ -106,7 +106,7 @@ class MaterialTrainer:
         loss = loss_rgb + outputs["loss_nis"]
         loss.backward()
         if self.world > 1:
-            tdist.allreduce_gradients(self.trainable(), world=self.world)
+            tdist.allreduce_gradients(self.trainable(), world=self.world, stats=getattr(self, "comm_stats", None))
         self.optimizer.step()
         # learning-rate bookkeeping, in the reference's order (:247-252)
         for g in self.optimizer.param_groups:

@@ -63,3 +63,29 @@ def test_allreduce_and_gather_two_ranks():
         p.join(timeout=30)
     assert all(ok for _, ok, _ in res), res
     assert all(n >= 2 for _, _, n in res)
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_spawns_ranks_and_averages_gradients():
+    """`python bench.py --gpus 2` started WITHOUT a launcher spawns its own two ranks (torch.distributed.run, 127.0.0.1) and runs
+    the exchange step of BASELINE configs[3] -- the material stage's ~190 MB gradient set through dist.allreduce_gradients -- here
+    on CPU tensors over gloo (--allreduce-only: no kernels).  The same launcher and the same collective code serve the GPU run."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TENSOFLOW_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--allreduce-only", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["allreduce"]["ranks"] == 2 and d["allreduce"]["mean_matches_reference"] is True
+    assert 150e6 < d["allreduce"]["bytes"] < 250e6           # SURVEY.md 5.8: ~190 MB of fp32 gradients in the material stage
+    # a failing rank makes the launcher exit non-zero
+    env["TENSOFLOW_BENCH_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--allreduce-only", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
