@@ -64,7 +64,7 @@ def ide5(xyz, kappa_inv=0.0):
         ms, ls, mat = ide_tables(5)
         _IDE = (torch.tensor(ms, dtype=torch.float32), torch.tensor(ls, dtype=torch.float32),
                 torch.from_numpy(mat))
-    ms, ls, mat = _IDE
+    ms, ls, mat = [t.to(xyz.dtype) for t in _IDE]       # fp32 in the reference; follows the input for the fp64 re-evaluation
     x, y, z = xyz[..., 0:1], xyz[..., 1:2], xyz[..., 2:3]
     vmz = torch.cat([z ** i for i in range(mat.shape[0])], -1)
     zc = x + 1j * y

@@ -33,8 +33,8 @@ def sphere_latent(sn):
         z = 2.0 * n / num_points - 1.0
         phis.append(2 * np.pi * n * g % (2 * np.pi))
         thetas.append(np.arcsin(z))
-    phi = torch.tensor(phis, dtype=torch.float32) / (2 * np.pi)
-    theta = torch.tensor(thetas, dtype=torch.float32) / (0.5 * np.pi)
+    phi = (torch.tensor(phis, dtype=torch.float32) / (2 * np.pi)).to(torch.get_default_dtype())
+    theta = (torch.tensor(thetas, dtype=torch.float32) / (0.5 * np.pi)).to(torch.get_default_dtype())
     return torch.stack([phi, theta], -1)
 
 

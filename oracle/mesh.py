@@ -61,3 +61,68 @@ class BruteForceRayTracer:
         pos = o + t[:, None] * d
         nrm = torch.where((f >= 0)[:, None], self.normals[f.clamp(min=0)], torch.zeros_like(pos))
         return pos.reshape(*prefix, 3), nrm.reshape(*prefix, 3), t.reshape(*prefix)
+
+
+# ---------------------------------------------------------------- CPU BVH (oracle/bvh_cpu.c): the same first-hit contract at
+# mesh sizes the brute-force form cannot reach (the bench scene has 265 k triangles)
+_LIB = None
+
+
+def build_bvh_cpu_lib(force=False):
+    """gcc -O2 -fopenmp -ffp-contract=off oracle/bvh_cpu.c -> oracle/_bvh_cpu.so (test infrastructure; also built by
+    __graft_entry__.build()).  Returns the path."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, out = os.path.join(here, "bvh_cpu.c"), os.path.join(here, "_bvh_cpu.so")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", out, "-lm"], check=True)
+    return out
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        import ctypes as C
+        L = C.CDLL(build_bvh_cpu_lib())
+        L.obvh_build.restype = C.c_void_p
+        L.obvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.obvh_free.argtypes = [C.c_void_p]
+        L.obvh_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class BvhRayTracer:
+    """BruteForceRayTracer's call surface over the C BVH: same per-triangle arithmetic as the brute-force form (t within an ulp or two, identical hit sets; tests/test_oracle_shading.py::test_cpu_bvh_equals_brute_force)."""
+
+    def __init__(self, vertices, triangles):
+        self.v = np.ascontiguousarray(np.asarray(vertices, dtype=np.float32))
+        self.f = np.ascontiguousarray(np.asarray(triangles).astype(np.int32))
+        self.h = _lib().obvh_build(self.v.ctypes.data, self.f.ctypes.data, len(self.f))
+        tri = torch.from_numpy(self.v)[torch.from_numpy(self.f.astype(np.int64))]
+        self.tri = tri
+        self.normals = torch.nn.functional.normalize(torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=-1), dim=-1)
+
+    def __del__(self):
+        try:
+            _lib().obvh_free(self.h)
+        except Exception:
+            pass
+
+    def first_hit(self, o, d):
+        """o, d [M,3] float32 tensors -> (t [M], face [M] long, -1 on a miss)."""
+        o = np.ascontiguousarray(o.detach().numpy().astype(np.float32).reshape(-1, 3))
+        d = np.ascontiguousarray(d.detach().numpy().astype(np.float32).reshape(-1, 3))
+        t = np.empty(len(o), np.float32)
+        f = np.empty(len(o), np.int32)
+        _lib().obvh_trace(self.h, o.ctypes.data, d.ctypes.data, len(o), t.ctypes.data, f.ctypes.data)
+        return torch.from_numpy(t), torch.from_numpy(f.astype(np.int64))
+
+    def trace(self, rays_o, rays_d, inplace=False):
+        prefix = rays_o.shape[:-1]
+        o, d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
+        t, f = self.first_hit(o, d)
+        pos = o + t[:, None] * d
+        nrm = torch.where((f >= 0)[:, None], self.normals[f.clamp(min=0)], torch.zeros_like(pos))
+        return pos.reshape(*prefix, 3), nrm.reshape(*prefix, 3), t.reshape(*prefix)

@@ -41,7 +41,7 @@ def fibonacci_az_el(num_samples, begin_elevation=0):
 def fixed_direction_samples(n):
     """fields.py:734-742 -> [n,2] float32 (az/2pi, 1-2el/pi)."""
     az, el = fibonacci_az_el(n, 0)
-    return torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32))
+    return torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32)).to(torch.get_default_dtype())
 
 
 def sat_dot(a, b):
@@ -107,15 +107,17 @@ def inner_light(sd, pts, view, nrm, exp_max=5.0):
 
 
 class MeshTracer:
-    """materialRenderer.trace (:253-263) over a triangle soup, brute force."""
+    """materialRenderer.trace (:253-263) over a triangle soup: brute force, or -- `bvh` = an oracle.mesh.BvhRayTracer over the
+    same triangles -- through the CPU BVH (same hits, t within an ulp or two; the only way to trace the 265 k-triangle bench scene on the host)."""
 
-    def __init__(self, tri):
+    def __init__(self, tri, bvh=None):
         self.tri = tri
+        self.bvh = bvh
         n = torch.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], dim=-1)
         self.nrm = F.normalize(n, dim=-1)
 
     def __call__(self, o, d):
-        t, f = ray_triangles(o, d, self.tri)
+        t, f = self.bvh.first_hit(o, d) if self.bvh is not None else ray_triangles(o, d, self.tri)
         pos = o + t[:, None] * d
         fn = torch.where((f >= 0)[:, None], self.nrm[f.clamp(min=0)], torch.zeros_like(pos))
         nrm = F.normalize(-fn, dim=-1)
@@ -134,7 +136,7 @@ def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0):
         lights[miss] = env_direct_light(sd["outer_light.base"], dirs[miss])
     if hit.any():
         lights[hit] = inner_light(sd, inters[hit], -dirs[hit], nrm[hit], exp_max)
-    lights = lights * (depth > eps).float()
+    lights = lights * (depth > eps).to(lights.dtype)
     return lights, hit, inters
 
 
@@ -240,8 +242,8 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     out.update(colors=colors, diffuse_lin=diffuse, specular_lin=specular, metallic=metallic,
                roughness=rough, albedo=albedo, specular_rays_id=rid, specular_mask=smask,
                diffuse_hit=dhit.reshape(pn, dn), specular_hit=shit,
-               visibility=1 - segment_coo(shit.float(), rid, torch.zeros(pn))[:, None] / sn,
-               indirect_light=segment_coo(sl * shit[:, None].float(), rid, torch.zeros(pn, 3)) / sn,
+               visibility=1 - segment_coo(shit.to(sl.dtype), rid, torch.zeros(pn))[:, None] / sn,
+               indirect_light=segment_coo(sl * shit[:, None].to(sl.dtype), rid, torch.zeros(pn, 3)) / sn,
                diffuse_light=torch.clamp(linear_to_srgb(dl.mean(1)), 0, 1),
                specular_light=torch.clamp(linear_to_srgb(segment_coo(sl, rid, torch.zeros(pn, 3)) / sn), 0, 1),
                diffuse_dirs=ddirs, diffuse_pdf=dpdf, specular_dirs=sdirs, specular_pdf=spdf)

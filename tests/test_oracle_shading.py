@@ -49,3 +49,31 @@ def test_env_and_lights(golden):
     assert 0.02 < hit.float().mean() < 0.98          # both branches exercised
     assert rel_err(lights, g["gl_lights"]) < 1e-5
     assert rel_err(inters, g["gl_inters"]) < 1e-6
+
+
+def test_cpu_bvh_equals_brute_force():
+    """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
+    unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along
+    axes (zero direction components) and rays starting on the surface included."""
+    import numpy as np
+    from oracle.mesh import BvhRayTracer, ray_triangles
+    from tensoflow_amd.synth import sphere_surface_points, sphere_torus_mesh
+    verts, faces = sphere_torus_mesh(12, 24, 32, 16)
+    tr = BvhRayTracer(verts, faces)
+    g = torch.Generator().manual_seed(5)
+    pts, nrm, _ = [torch.from_numpy(a) for a in sphere_surface_points(64, seed=3)]
+    d = torch.nn.functional.normalize(torch.randn(64, 48, 3, generator=g) + nrm[:, None], dim=-1).reshape(-1, 3)
+    o = pts[:, None].expand(64, 48, 3).reshape(-1, 3) + 0.01 * d
+    o2 = torch.rand(512, 3, generator=g) * 3 - 1.5
+    d2 = torch.nn.functional.normalize(torch.randn(512, 3, generator=g), dim=-1)
+    d2[:6] = torch.tensor([[1.0, 0, 0], [0, 1, 0], [0, 0, -1], [-1, 0, 0], [0.6, 0.8, 0], [0, -0.6, 0.8]])
+    o2[:6] = torch.tensor([[-2.0, 0.01, 0.02], [0.3, -2, 0.1], [0.1, 0.2, 2], [2, 0, 0], [-1.2, -1.6, 0.05], [0.05, 1.2, -1.6]])
+    o, d = torch.cat([o, o2]), torch.cat([d, d2])
+    t_ref, f_ref = ray_triangles(o, d, tr.tri)
+    t, f = tr.first_hit(o, d)
+    assert torch.equal(t < 10, t_ref < 10) and float(((t - t_ref).abs() / t_ref.abs().clamp_min(1e-3)).max()) < 1e-4     # ill-conditioned determinants of grazing rays
+    assert 0.1 < float((t < 10).float().mean()) < 0.9
+    same = f == f_ref
+    assert float(same.float().mean()) > 0.99           # the rest: two faces at exactly the same t (shared edge)
+    pos, n, depth = tr.trace(o, d)
+    assert torch.equal(depth, t)
