@@ -164,6 +164,13 @@ int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, const float
                      int32_t* bins, int32_t precision /* TfPrecision */, float* workspace,
                      size_t workspace_floats, tf_stream_t stream);
 
+/* ElementWisePWQuadraticTransform alone (network/flow.py:332-413 forward / density direction, :415-525 inverse / sampling
+ * direction): wv [m,21] = (v_tilde[11], w_tilde[10]) rows, y [m] in (0,1) -> out [m], logj [m], bins [m] int32 or NULL.
+ * Runs the same device functions the fused flow kernels call; exists so that the reference's spline vectors (edge rows:
+ * y -> 0 / 1, equal knots, w_tilde = -12 / +6, all-zero rows) are exercised on the device. */
+int tf_pwquad_eval(const float* wv, const float* y, int64_t m, int32_t inverse, float* out, float* logj,
+                   int32_t* bins, tf_stream_t stream);
+
 /* Backward of tf_flow_logq_fwd (the NIS-loss training direction, fields.py:1257-1333): gradient of
  * sum_r g_logq[r]*logq[r] wrt the 16 net tensors (accumulated with float atomics: zero them first) and wrt the
  * hoisted per-point layer-1 pre-activation, g_point [2,pn,64] (zero first).  The caller folds g_point into

@@ -480,3 +480,31 @@ extern "C" int tf_flow_logq_fwd(const TfCouplingNet nets[2], const float* cond, 
   return flow_launch<false>(nets, cond, nullptr, nullptr, x, rays_id, m, sn, pn, z, logq, bins, precision, workspace,
                             workspace_floats, (hipStream_t)stream, "tf_flow_logq_fwd");
 }
+
+// ---------------------------------------------------------------- the spline alone (the kernels above call pw_inverse / pw_forward
+// on the coupling nets' outputs; this entry runs the SAME device functions on caller-supplied parameter rows, so that the
+// reference's spline vectors -- tests/golden/pwquad.npz, incl. its degenerate rows -- are checked on the GPU too)
+__global__ void __launch_bounds__(256) pwquad_kernel(const float* __restrict__ wv, const float* __restrict__ y, long long m, int inverse,
+                                                     float* __restrict__ out, float* __restrict__ logj, int* __restrict__ bins) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  float row[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) row[k] = k < 21 ? wv[i * 21 + k] : 0.f;
+  float o, lj;
+  int bin;
+  if (inverse) pw_inverse(y[i], row, o, lj, bin);
+  else pw_forward(y[i], row, o, lj, bin);
+  out[i] = o; logj[i] = lj;
+  if (bins) bins[i] = bin;
+}
+
+extern "C" int tf_pwquad_eval(const float* wv, const float* y, int64_t m, int32_t inverse, float* out, float* logj, int32_t* bins,
+                              tf_stream_t stream_) {
+  TF_REQUIRE(m >= 0, TF_ESHAPE, "tf_pwquad_eval: m < 0");
+  if (m == 0) return TF_OK;
+  TF_REQUIRE(wv && y && out && logj, TF_EINVAL, "tf_pwquad_eval: null pointer");
+  pwquad_kernel<<<tf_blocks(m, 256), 256, 0, (hipStream_t)stream_>>>(wv, y, m, inverse, out, logj, bins);
+  TF_LAUNCH_CHECK("tf_pwquad_eval");
+  return TF_OK;
+}

@@ -97,6 +97,43 @@ def construct_ray_batch_nerf(imgs_info, device="cpu", is_train=True):
     return {k: v.float().contiguous().to(device) for k, v in batch.items()}, rn, h, w
 
 
+def human_coordinate_poses(poses, fixed_camera=False):
+    """MaterialRenderer.get_human_coordinate_poses (materialRenderer.py:364-380): poses [n,3,4] -> [n,3,4]."""
+    pn = poses.shape[0]
+    cam_cen = (-poses[:, :, :3].permute(0, 2, 1) @ poses[:, :, 3:])[..., 0]
+    if not fixed_camera:
+        cam_cen[..., 2] = 0
+    Y = torch.zeros(pn, 3, device=poses.device)
+    Y[:, 2] = -1.0
+    Z = poses[:, 2, :3].clone()
+    Z[:, 2] = 0
+    Z = F.normalize(Z, dim=-1)
+    X = torch.cross(Y, Z, dim=-1)
+    R = torch.stack([X, Y, Z], 1)
+    t = -R @ cam_cen[:, :, None]
+    return torch.cat([R, t], -1)
+
+
+def construct_ray_batch_nerf_material(imgs_info, device="cpu", fixed_camera=False):
+    """MaterialRenderer._construct_ray_batch_nerf (materialRenderer.py:452-480) -- NOT the shape stage's constructor: pixel
+    coordinates without the half-pixel offset, rays_d = normalize(R @ dirs), the 'human' poses of get_human_coordinate_poses.
+    -> (dict rays_o, rays_d, human_poses [rn,3,4], rgb; rn, h, w)."""
+    imn, _, h, w = imgs_info["imgs"].shape
+    i, j = torch.meshgrid(torch.linspace(0, w - 1, w), torch.linspace(0, h - 1, h), indexing="ij")
+    i, j = i.t(), j.t()
+    K = imgs_info["Ks"][0]
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1)
+    rays_d = dirs[None].repeat(imn, 1, 1, 1).reshape(imn, h * w, 3)
+    poses = imgs_info["poses"][:, :3, :].float()
+    R, t = poses[:, :, :3], poses[:, :, 3:]
+    rays_d = F.normalize((R @ rays_d.permute(0, 2, 1)).permute(0, 2, 1), dim=-1)
+    rays_o = t.permute(0, 2, 1).repeat(1, h * w, 1)
+    hp = human_coordinate_poses(poses, fixed_camera).unsqueeze(1).repeat(1, h * w, 1, 1)
+    rgb = imgs_info["imgs"].reshape(imn, 3, h * w).permute(0, 2, 1)
+    batch = {"rays_o": rays_o.reshape(-1, 3), "rays_d": rays_d.reshape(-1, 3), "human_poses": hp.reshape(-1, 3, 4), "rgb": rgb.reshape(-1, 3)}
+    return {k: v.float().contiguous().to(device) for k, v in batch.items()}, imn * h * w, h, w
+
+
 class RayTable:
     """The shuffled per-ray table of the training loop.  `next_batch(rn)` returns this rank's rows of the next rn-row slice (on
     `device`); the table reshuffles when fewer than 2 rn rows remain, like the reference (:782)."""

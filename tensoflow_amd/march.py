@@ -138,7 +138,8 @@ class AlphaMask:
 
 
 @torch.no_grad()
-def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, mul_length=10, prev: AlphaMask = None, chunk=1 << 21):
+def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, mul_length=10, prev: AlphaMask = None, chunk=1 << 21,
+                      return_alpha=False):
     """ShapeRenderer.updateAlphaMask + compute_gridAlpha + compute_grid_alpha (shapeRenderer.py:257-325): NeuS opacity of one
     grid step at every lattice point (forced to 1 within mul_length steps of the surface), 3^3 max-pool dilation, threshold.
     Returns (AlphaMask, new_aabb [2,3]).  The field evaluations run in tf_sdf_forward."""
@@ -160,12 +161,15 @@ def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, 
         a = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
         a = torch.where(sdf.abs() < mul_length * length, torch.ones_like(a), a)
         alpha[c0:c0 + chunk] = torch.where(live, a, torch.zeros_like(a))
-    alpha = alpha.view(gx, gy, gz).clamp(0, 1).transpose(0, 2).contiguous()[None, None]           # [1,1,gz,gy,gx]
+    raw = alpha.view(gx, gy, gz)                                                                    # compute_gridAlpha's lattice
+    alpha = raw.clamp(0, 1).transpose(0, 2).contiguous()[None, None]                               # [1,1,gz,gy,gx]
     alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1)[0, 0]
     vol = alpha >= thres
     gxyz = xyz.transpose(0, 2)
     valid = gxyz[vol]
     new_aabb = torch.stack([valid.amin(0), valid.amax(0)]) if valid.numel() else field.aabb_dev.clone()
+    if return_alpha:
+        return AlphaMask(field.aabb, vol), new_aabb, raw
     return AlphaMask(field.aabb, vol), new_aabb
 
 

@@ -196,15 +196,26 @@ class MCShadingNetwork(nn.Module):
         mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda")
         self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
         self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
-        self._shader = None
+        self._shader, self._shader_version = None, None
+
+    def _param_version(self):
+        """Every in-place update of a parameter (optimizer.step, load_state_dict, copy_) bumps its _version counter."""
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def shader(self):
-        """(Re)build the device-side evaluator from the current parameters (repacks the pyramids, folds weight-norm,
-        uploads the BVH the first time).  Call again after an optimizer step / load_state_dict."""
+        """The device-side evaluator of the CURRENT parameters (packed pyramids, weight-norm folded, fragment-ordered decoders; the
+        BVH is uploaded once and kept).  Cached on the parameters' version counters, like TensoSDF._field: an optimizer step,
+        load_state_dict or a flow-copy refresh between two evaluations rebuilds it -- a validation render never sees stale weights."""
+        ver = self._param_version()
+        if self._shader is not None and ver == self._shader_version:
+            return self._shader
         v, f = self.ray_tracer
         sd = {k: t.detach() for k, t in self.state_dict().items()}
+        old = self._shader
         self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
-                                exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"])
+                                exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"],
+                                bvh=old.bvh if old is not None else None)
+        self._shader_version = ver
         return self._shader
 
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001, lr_init_envlight=0.001):
@@ -334,7 +345,7 @@ class MCShadingNetwork(nn.Module):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
         from ..shading import aux_outputs
-        sh = self._shader if self._shader is not None else self.shader()
+        sh = self.shader()
         nrm = (F.normalize(normals, dim=-1) + 1) / 2
         # the unweighted light maps (diffuse_light, visibility ...) average over EVERY ray, incl. those whose BRDF weight is zero:
         # the zero-weight culling of the throughput path is switched off here

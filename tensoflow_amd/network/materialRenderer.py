@@ -60,7 +60,7 @@ class MaterialRenderer(nn.Module):
         """materialRenderer.py:345-382 + filtering_train_rays (:384-417): database, split, per-pixel ray table, every training ray
         traced against the mesh and refined on the SDF on the device (chunks of 512^2 rays, no CPU round trip per chunk); rays that
         miss are dropped; the table of surface points is shuffled.  cfg['rank'] / cfg['world']: this process's stride of a batch."""
-        from ..dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf
+        from ..dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf_material
         scene = self.cfg["database_name"].split("/")[1]
         self.database = TensoSDFSynDatabase(os.path.join(self.cfg["dataset_dir"], scene), white_bg=self.cfg.get("isBGWhite", True))
         ids = self.database.get_img_ids()
@@ -71,8 +71,9 @@ class MaterialRenderer(nn.Module):
         else:
             self.test_ids, self.train_ids = ids[:1], ids[1:]
         self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
-        batch, n_rays, _, _ = construct_ray_batch_nerf(self.database.imgs_info(self.train_ids))
-        batch["rgb"] = batch.pop("rgbs")
+        # the material stage's OWN ray table (materialRenderer.py:452-480): unit directions, no half-pixel offset -- the same
+        # convention nvs() / test_step render with, so depth, the +-4 unit refinement window and the NeuS cosine are in world units
+        batch, n_rays, _, _ = construct_ray_batch_nerf_material(self.database.imgs_info(self.train_ids), fixed_camera=self.cfg.get("fixed_camera", False))
         self.train_batch = self.filtering_train_rays(batch)
         self.tbn = self.train_batch["rays_o"].shape[0]
         self.ray_mask_ratio = self.tbn / max(n_rays, 1)

@@ -232,6 +232,20 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
     return (ang, lj, bins) if want_bins else (ang, lj)
 
 
+def pwquad(wv, y, inverse):
+    """ElementWisePWQuadraticTransform.flow_inv (inverse=False: density direction) / .flow (inverse=True: sampling direction) on
+    parameter rows wv [m,21] and y [m] -> out [m], logj [m], bins [m] int32 (flow.py:332-525; the device functions of the fused
+    flow kernels)."""
+    lib = L.load()
+    wv, y = _f(wv), _f(y)
+    m = y.shape[0]
+    assert wv.shape == (m, 21)
+    out, logj = torch.empty_like(y), torch.empty_like(y)
+    bins = torch.empty(m, dtype=torch.int32, device=y.device)
+    L.check(lib.tf_pwquad_eval(_p(wv), _p(y), m, 1 if inverse else 0, _p(out), _p(logj), _p(bins, torch.int32), _stream()), "tf_pwquad_eval")
+    return out, logj, bins
+
+
 def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
     """x [pn,sn,2] (rays_id None) or [m,2] with rays_id [m] int64 -> z (same shape), logq [...,1]."""
     lib = L.load()

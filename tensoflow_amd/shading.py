@@ -153,7 +153,7 @@ class MCShader:
     """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
-                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256):
+                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         # Inner-light decoder (123-256-256-256-3): plain f16 MFMA operands, fp32 accumulate.  Its operand rounding stays below the
@@ -177,7 +177,7 @@ class MCShader:
         self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device)
         self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device)
         self.inner_cache = ops.PackCache()
-        self.bvh = ops.Bvh(vertices, triangles, device)
+        self.bvh = bvh if bvh is not None else ops.Bvh(vertices, triangles, device)   # `bvh`: reuse an uploaded tree (same mesh)
         self.point_prep = ops.PointPrep(self.mat_packed, self.flow_d.packed, self.flow_s.packed, self.pred,
                                         [self.flow_d.mat, self.flow_s.mat], self.aabb)
         self.fixed_d = fibonacci_samples(n_fixed_diffuse).to(device)

@@ -31,6 +31,8 @@ DEFAULT_CFG = {
     "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000,           # fields.py:649-650
     "nis_update_interval_diffuse": 1000, "nis_update_interval_specular": 1000,  # :655-656
     "nis_loss_iter": 500,
+    # material objective (configs/mat/syn/*.yaml + MaterialRenderer.default_cfg + NISLoss.default_cfg)
+    "rgb_loss": "charbonier", "reg_mat": True, "reg_diffuse_light": True, "reg_diffuse_light_lambda": 0.1, "nis_loss_weight": 1e-4,
 }
 
 
@@ -62,14 +64,39 @@ def material_param_groups(net, lr_xyz, lr_net, lr_env):
     return groups
 
 
+def material_loss_terms(cfg, colors, outputs, target_rgb, mat_reg, step):
+    """The `loss_*` terms TrainerInv sums for the material stage (configs/mat/syn/*.yaml: loss = ['nerf_render', 'mat_reg', 'nis']):
+    MaterialRenderer.train_step (materialRenderer.py:555-565) + NeRFRenderLoss / MaterialRegLoss / NISLoss (network/loss.py).
+    -> {name: tensor}; the caller adds up their means (trainer_inv.py:196-207)."""
+    terms = {"loss_rgb": rgb_loss(cfg["rgb_loss"], colors, target_rgb)}                      # compute_rgb_loss, default charbonier
+    if cfg["reg_mat"] and mat_reg is not None:
+        terms["loss_mat_reg"] = mat_reg                                                       # material_regularization (fields.py:1547-1578)
+    if cfg["reg_diffuse_light"] and "diffuse_light" in outputs:
+        dl = outputs["diffuse_light"]
+        terms["loss_diffuse_light"] = torch.sum(torch.abs(dl - dl.mean(-1, keepdim=True)), -1) * cfg["reg_diffuse_light_lambda"]
+    if "loss_nis" in outputs:
+        terms["loss_nis"] = outputs["loss_nis"].reshape(1) * cfg["nis_loss_weight"]          # NISLoss: weight 1e-4
+    return terms
+
+
 class MaterialTrainer:
-    """One process per GPU; `world` > 1 adds the RCCL gradient all-reduce (mean) before every optimizer step."""
+    """One process per GPU; `world` > 1 adds the RCCL gradient averaging before every optimizer step.
+    `net`: the drop-in MCShadingNetwork, or a MaterialRenderer (its shader_network is trained; its sdf_network / deviation_net ride
+    along in the checkpoint, as in the reference, whose material checkpoints are MaterialRenderer.state_dict())."""
 
     def __init__(self, net, cfg=None, world=1):
         self.cfg = {**DEFAULT_CFG, **(cfg or {})}
         if self.cfg["lr_decay_iters"] < 0:
             self.cfg["lr_decay_iters"] = self.cfg["total_step"]
-        self.net, self.world = net, world
+        self.renderer = net if hasattr(net, "shader_network") else None
+        self.net = net.shader_network if self.renderer is not None else net
+        net = self.net
+        self.world = world
+        for k in ("nis_start_iter_diffuse", "nis_start_iter_specular", "nis_update_interval_diffuse", "nis_update_interval_specular"):
+            if cfg and k in cfg:                                         # schedule keys live in the shader cfg (fields.py:649-656)
+                net.cfg[k] = cfg[k]
+        if cfg and "nis_loss_iter" in cfg:
+            net.cfg["nis_loss_iter_diffuse"] = net.cfg["nis_loss_iter_specular"] = cfg["nis_loss_iter"]
         for fl in (net.flow_diffuse_copy, net.flow_specular_copy):       # the samplers' copies are never trained (fields.py:1054-1065)
             for p in fl.parameters():
                 p.requires_grad = False
@@ -79,34 +106,36 @@ class MaterialTrainer:
         self.lr_factor = self.pre_lr_factor = 1.0
         self.step_count, self.best_para = 0, 0.0
 
-    def trainable(self):
-        return [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+    def trainable(self, step=None):
+        """Parameters that receive a gradient at `step` -- a decision every rank makes identically from the step alone, so the
+        replicas' Adam states stay in lockstep with a single-process run: the two trainable flows are only reached through the
+        NIS losses, which start at nis_loss_iter (fields.py:1257,1296); before that their .grad stays None and Adam skips them."""
+        ps = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+        if step is not None and step < self.cfg["nis_loss_iter"]:
+            flow = {id(p) for fl in (self.net.flow_diffuse, self.net.flow_specular) for p in fl.parameters()}
+            ps = [p for p in ps if id(p) not in flow]
+        return ps
 
     def refresh_flow_copies(self, step):
         """MCShadingNetwork.update_step (fields.py:1056-1065)."""
-        c = self.cfg
-        done = []
-        for name, start, every in (("diffuse", c["nis_start_iter_diffuse"], c["nis_update_interval_diffuse"]),
-                                   ("specular", c["nis_start_iter_specular"], c["nis_update_interval_specular"])):
-            if (step + 1) >= start and (step + 1 - start) % every == 0:
-                src, dst = getattr(self.net, f"flow_{name}"), getattr(self.net, f"flow_{name}_copy")
-                dst.load_state_dict(src.state_dict())
-                for p in dst.parameters():
-                    p.requires_grad = False
-                done.append(name)
-        return done
+        return self.net.update_step(step)
 
     def train_step(self, pts, view_dirs, normals, target_rgb):
-        """One iteration of the loop at trainer_inv.py:181-252 on a batch of surface points: loss_rgb (L2 on sRGB) + loss_nis."""
+        """One iteration of the loop at trainer_inv.py:181-252 on a batch of surface points, with the reference's objective:
+        sum of the means of loss_rgb (charbonier), loss_mat_reg, loss_diffuse_light and 1e-4 loss_nis."""
         step = self.step_count
         self.net.train()
         self.optimizer.zero_grad(set_to_none=True)
-        colors, outputs = self.net(pts, view_dirs, normals, None, step if step >= self.cfg["nis_loss_iter"] else None, True)
-        loss_rgb = ((colors - target_rgb) ** 2).mean()
-        loss = loss_rgb + outputs["loss_nis"]
+        self.refresh_flow_copies(step)                                    # MaterialRenderer.train_step calls update_step first (:549)
+        colors, outputs = self.net(pts, view_dirs, normals, None, step, True)
+        mat_reg = None
+        if self.cfg["reg_mat"]:
+            mat_reg = self.net.material_regularization(pts, normals, outputs["metallic"], outputs["roughness"], outputs["albedo"], step)
+        terms = material_loss_terms(self.cfg, colors, outputs, target_rgb, mat_reg, step)
+        loss = sum(v.mean() for v in terms.values())
         loss.backward()
         if self.world > 1:
-            tdist.allreduce_gradients(self.trainable(), world=self.world, stats=getattr(self, "comm_stats", None))
+            tdist.allreduce_gradients(self.trainable(step), world=self.world, stats=getattr(self, "comm_stats", None))
         self.optimizer.step()
         # learning-rate bookkeeping, in the reference's order (:247-252)
         for g in self.optimizer.param_groups:
@@ -116,23 +145,45 @@ class MaterialTrainer:
         cur = cosine_lr_factor(step, self.cfg["lr_decay_iters"], self.cfg["lr_decay_target_ratio"])
         self.lr_factor = cur / self.pre_lr_factor
         self.pre_lr_factor = cur
-        self.refresh_flow_copies(step)
         self.step_count += 1
-        return {"loss": loss.detach(), "loss_rgb": loss_rgb.detach(), "loss_nis": outputs["loss_nis"].detach()}
+        return {"loss": loss.detach(), **{k: v.detach().mean() for k, v in terms.items()}}
 
-    # ---- checkpoint (TrainerInv._save_model, trainer_inv.py:355-369)
+    # ---- checkpoint (TrainerInv._save_model, trainer_inv.py:355-369; network part = MaterialRenderer.ckpt_to_save, :230-232)
+    def network_state_dict(self):
+        """MaterialRenderer.state_dict() layout: 'shader_network.<key>' (+ 'sdf_network.*' / 'deviation_net.*' when a renderer is wrapped)."""
+        if self.renderer is not None:
+            return self.renderer.state_dict()
+        return {"shader_network." + k: v for k, v in self.net.state_dict().items()}
+
     def state(self):
         return {"step": self.step_count, "best_para": self.best_para, "lr_factor": self.lr_factor,
                 "pre_lr_factor": self.pre_lr_factor, "lr_xyz": self.cur_lr_xyz, "lr_net": self.cur_lr_net,
                 "optimizer_state_dict": self.optimizer.state_dict(), "N_voxel_list": [],
-                "network_state_dict": self.net.state_dict(), "kwargs": {k: v for k, v in self.cfg.items()}}
+                "network_state_dict": self.network_state_dict(), "trainer_cfg": {k: v for k, v in self.cfg.items()}}
 
     def save(self, path):
         torch.save(self.state(), path)
 
     def load(self, ckpt, load_optimizer=True):
+        """Accepts a reference material checkpoint (keys 'shader_network.*', 'sdf_network.*', 'deviation_net.*') or a round-1 file of
+        this trainer (bare MCShadingNetwork keys).  Raises if NOTHING in the file matches a parameter (strict=False would hide it)."""
         ckpt = torch.load(ckpt, weights_only=False) if isinstance(ckpt, str) else ckpt
-        self.net.load_state_dict(ckpt["network_state_dict"], strict=False)
+        sd = ckpt["network_state_dict"]
+        own = set(self.net.state_dict().keys())
+        mapped = {}
+        for k, v in sd.items():
+            kk = k[len("shader_network."):] if k.startswith("shader_network.") else k
+            if kk in own:
+                mapped[kk] = v
+        if not mapped:
+            raise RuntimeError("MaterialTrainer.load: no key of the checkpoint's network_state_dict matches the shading network "
+                               f"(first keys: {list(sd)[:3]})")
+        self.net.load_state_dict(mapped, strict=False)
+        if self.renderer is not None:
+            rest = {k: v for k, v in sd.items() if k.startswith(("sdf_network.", "deviation_net."))}
+            if rest:
+                self.renderer.load_state_dict(rest, strict=False)
+        self.loaded_keys = len(mapped)
         if load_optimizer and "optimizer_state_dict" in ckpt:
             self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         self.step_count, self.best_para = ckpt["step"], ckpt["best_para"]

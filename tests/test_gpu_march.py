@@ -181,6 +181,65 @@ def test_module_mcshading(golden, dev):
     assert m.outer_light.base.grad is not None and float(m.outer_light.base.grad.abs().sum()) > 0
 
 
+def test_mcshading_eval_follows_parameter_updates(golden, dev):
+    """The fused evaluator is cached on the parameters' version counters: train step -> eval -> train step -> eval must render
+    with the weights of THAT moment (a stale pack would make every validation between two flow-copy refreshes reuse the first
+    pack), and equal an evaluator built from scratch."""
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    from tensoflow_amd.shading import MCShader
+    g = golden("shading_small")
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
+               nis_specular_sample_num=sn_s)
+    m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
+    m.load_state_dict(g.sd, strict=False)
+    args = (g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev))
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-2)
+
+    def eval_colors():
+        with torch.no_grad():
+            return m(*args, None, None, False)[0].clone()
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        colors, out = m(*args, None, 600, True)
+        (colors.sum() + out["loss_nis"]).backward()
+        opt.step()
+
+    c0 = eval_colors()
+    assert m.shader() is m.shader()                       # unchanged parameters: the pack is reused
+    train_step()
+    c1 = eval_colors()
+    train_step()
+    c2 = eval_colors()
+    assert not torch.equal(c0, c1) and not torch.equal(c1, c2)
+    fresh = MCShader({k: t.detach() for k, t in m.state_dict().items()}, g["verts"].numpy(), g["faces"].numpy(), AABB, float(g["unit_size"]),
+                     device=dev, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs)
+    assert torch.equal(fresh.shade_fixed(*args)["colors"], c2)
+    m.load_state_dict(g.sd, strict=False)                 # load_state_dict copies in place: versions move, the pack follows
+    assert torch.equal(eval_colors(), c0)
+
+
+def test_update_alpha_mask_golden(golden, dev):
+    """ShapeRenderer.updateAlphaMask / compute_gridAlpha (shapeRenderer.py:257-325) run by the reference on the march_r32 network
+    (tests/golden/alpha_mask_r32.npz): the binary volumes bit-exact, the raw alpha lattice to 1e-4, the shrunk aabb equal --
+    first without a previous mask, then on a finer lattice sampled through the first mask."""
+    from tensoflow_amd import march
+    g, base = golden("alpha_mask_r32"), golden("march_r32")
+    assert bool(g["sd_is_march_r32"])
+    f = march.SdfField(base.sd, AABB, [32, 32, 32], 3, device=dev)
+    inv_s, thres, mul = float(g["inv_s"]), float(g["thres"]), float(g["mul_length"])
+    m1, aabb1, raw1 = march.update_alpha_mask(f, inv_s, grid=(24, 20, 28), thres=thres, mul_length=mul, return_alpha=True)
+    assert rel_err(raw1.cpu(), g["alpha_24x20x28"]) < TOL
+    assert torch.equal(m1.volume.cpu().bool(), g["mask1"].bool())
+    assert torch.allclose(aabb1.cpu(), g["aabb1"], atol=1e-6)
+    m2, aabb2, raw2 = march.update_alpha_mask(f, inv_s, grid=(40, 40, 40), thres=thres, mul_length=mul, prev=m1, return_alpha=True)
+    assert rel_err(raw2.cpu(), g["alpha_40_masked"]) < TOL
+    assert torch.equal(m2.volume.cpu().bool(), g["mask2"].bool())
+    assert torch.allclose(aabb2.cpu(), g["aabb2"], atol=1e-6)
+    assert 0.1 < float(m2.volume.float().mean()) < 0.4
+
+
 def test_trace_sdf_with_mesh(golden, dev):
     from tensoflow_amd import ops, surface
     from tensoflow_amd.march import SdfField

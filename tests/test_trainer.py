@@ -54,14 +54,19 @@ def test_material_trainer_fits_and_checkpoints(tmp_path):
     pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(512, seed=5)]
     target = torch.sigmoid(4.0 * pts)                                               # a smooth colour field on the surface
     first = None
+    copy0 = {k: v.clone() for k, v in net.flow_diffuse_copy.state_dict().items()}
     for _ in range(40):
         info = tr.train_step(pts, view, nrm, target)
         assert torch.isfinite(info["loss"])
         first = float(info["loss_rgb"]) if first is None else first
     assert float(info["loss_rgb"]) < 0.7 * first
     assert tr.step_count == 40 and tr.pre_lr_factor < 1.0
-    # the frozen copies were refreshed from the trainable flows at steps 9, 19, 29, 39
+    # the frozen copies are refreshed from the trainable flows at the START of steps 9, 19, 29, 39 (update_step precedes the
+    # shading in MaterialRenderer.train_step, materialRenderer.py:549): after step 39's optimizer update they trail by one step
     a, b = net.flow_diffuse.state_dict(), net.flow_diffuse_copy.state_dict()
+    assert not all(torch.equal(a[k], b[k]) for k in a) and not all(torch.equal(copy0[k], b[k]) for k in b)
+    assert tr.refresh_flow_copies(49) == ["diffuse", "specular"]
+    b = net.flow_diffuse_copy.state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert not any(p.requires_grad for p in net.flow_diffuse_copy.parameters())
     # checkpoint round trip
@@ -72,6 +77,9 @@ def test_material_trainer_fits_and_checkpoints(tmp_path):
     ck = torch.load(path, weights_only=False)
     assert {"step", "best_para", "lr_factor", "pre_lr_factor", "lr_xyz", "lr_net", "optimizer_state_dict", "N_voxel_list",
             "network_state_dict"} <= set(ck)
+    # the reference's material checkpoints are MaterialRenderer.state_dict(): every key under 'shader_network.'
+    assert all(k.startswith("shader_network.") for k in ck["network_state_dict"]) and "shader_network.mat_plane.0" in ck["network_state_dict"]
+    assert {"loss_rgb", "loss_mat_reg", "loss_diffuse_light", "loss_nis"} <= set(info)      # the reference's objective, term by term
     net2 = MCShadingNetwork(cfg, (verts, faces), aabb, 2.0 / 31)
     tr2 = MaterialTrainer(net2, tr.cfg)
     tr2.load(path)
@@ -79,7 +87,17 @@ def test_material_trainer_fits_and_checkpoints(tmp_path):
     with torch.no_grad():
         col2, _ = net2(pts, view, nrm)
     assert torch.equal(col2, ref_col)
+    assert tr2.loaded_keys == len(ck["network_state_dict"])
     assert math.isfinite(float(tr2.train_step(pts, view, nrm, target)["loss"]))
+    # a round-1 file (bare keys) still loads; a file with nothing in common raises instead of silently loading nothing
+    bare = dict(ck, network_state_dict={k[len("shader_network."):]: v for k, v in ck["network_state_dict"].items()})
+    tr2.load(bare, load_optimizer=False)
+    assert tr2.loaded_keys == len(ck["network_state_dict"])
+    with pytest.raises(RuntimeError):
+        tr2.load(dict(ck, network_state_dict={"color_network.foo": torch.zeros(1)}), load_optimizer=False)
+    # before nis_loss_iter the two trainable flows receive no gradient: they are not exchanged (and Adam skips them on every rank)
+    early, late = tr.trainable(step=0), tr.trainable(step=10)
+    assert len(early) < len(late) == len(tr.trainable())
 
 
 def test_shape_schedule_and_loss_terms():
@@ -172,3 +190,55 @@ def test_shape_trainer_runs_schedule_and_resumes(tmp_path):
     a, b = tr.net.state_dict(), tr2.net.state_dict()
     assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
     assert torch.isfinite(tr2.train_step(batch)["loss"])
+
+
+
+def test_trainer_pinned_to_reference_loss_and_schedule(golden):
+    """tests/golden/trainer.npz = outputs of the reference's OWN network/loss.py classes, compute_rgb_loss of both renderers,
+    compute_diffuse_light_regularization, TrainerInv.update_learning_rate / N_voxel_list / N_to_reso and
+    MaterialRenderer._construct_ray_batch_nerf on seeded inputs (tools/gen_golden.py:gen_trainer)."""
+    import types
+    from tensoflow_amd import trainer as T
+    from tensoflow_amd.dataset import construct_ray_batch_nerf_material
+    g = golden("trainer")
+    pr = {k[3:]: v for k, v in g.a.items() if k.startswith("pr/")}
+    gt = {k[3:]: v for k, v in g.a.items() if k.startswith("gt/")}
+    for kind in ("l2", "l1", "smooth_l1", "charbonier"):
+        assert torch.allclose(T.rgb_loss(kind, pr["ray_rgb"], gt["rgbs"]), g[f"shape_rgb_loss/{kind}"], atol=1e-7)
+    upsample = [2000, 5000, 10000, 20000]
+    cfg = {**T.SHAPE_CFG, "loss": ["nerf_render", "eikonal", "std", "init_sdf_reg", "occ", "Sparse", "Hessian", "TV", "mask", "Gaussian"],
+           "eikonal_weight": 0.1, "eikonal_weight_anneal_begin": 1000, "eikonal_weight_anneal_end": 4000, "sparse_update_list": upsample,
+           "sparse_ratio": [1.0, 0.5, 0.25, 0.1], "hessian_update_list": upsample, "hessian_ratio": [1.0, 0.8, 0.3, 0.0],
+           "apply_std_loss": True, "std_loss_weight": 0.05}
+    mcfg = {**T.DEFAULT_CFG}
+    for st in [int(v) for v in g["steps"]]:
+        out = {k: v for k, v in pr.items() if k not in ("radiance", "roughness_weights") or st > 20000}
+        terms = T.shape_loss_terms(cfg, out, {"rgbs": gt["rgbs"], "masks": gt["masks"]}, st)
+        ref = {k.split("/")[-1]: v for k, v in g.a.items() if k.startswith(f"shape/{st}/")}
+        assert set(terms) == set(ref) - {"total"}, (st, sorted(terms), sorted(ref))
+        for k, v in terms.items():
+            assert float(v.mean()) == pytest.approx(float(ref[k]), rel=1e-6, abs=1e-9), (st, k)
+        assert float(sum(v.mean() for v in terms.values())) == pytest.approx(float(ref["total"]), rel=1e-6)
+        mterms = T.material_loss_terms(mcfg, pr["ray_rgb"], {"diffuse_light": pr["diffuse_light"], "loss_nis": pr["loss_nis"]}, gt["rgbs"],
+                                       pr["loss_mat_reg"], st)
+        mref = {k.split("/")[-1]: v for k, v in g.a.items() if k.startswith(f"mat/{st}/")}
+        assert set(mterms) == set(mref) - {"total"}
+        for k, v in mterms.items():
+            assert float(v.mean()) == pytest.approx(float(mref[k]), rel=1e-6, abs=1e-9), (st, k)
+        assert float(sum(v.mean() for v in mterms.values())) == pytest.approx(float(mref["total"]), rel=1e-6)
+    # learning-rate factor (multiplicative form), voxel schedule, N_to_reso
+    pre = 1.0
+    for st, fac, cur in g["lr_factor"].tolist():
+        c = T.cosine_lr_factor(st, 40000, 5e-2)
+        assert c == pytest.approx(cur, rel=1e-12) and c / pre == pytest.approx(fac, rel=1e-12)
+        pre = c
+    nv = T.voxel_schedule(128 ** 3, 400 ** 3, upsample)
+    assert nv == g["N_voxel_list"].tolist()
+    assert [T.n_to_reso(n, g["N_to_reso_bbox"]) for n in nv] == g["N_to_reso"].tolist()
+    # the material stage's ray table
+    info = {"imgs": g["rays/imgs"], "Ks": g["rays/Ks"], "poses": g["rays/poses"]}
+    batch, rn, h, w = construct_ray_batch_nerf_material(info)
+    assert (rn, h, w) == (60, 5, 6)
+    for k in ("rays_o", "rays_d", "human_poses", "rgb"):
+        assert torch.allclose(batch[k], g["rays/out_" + k], atol=1e-6), k
+    assert torch.allclose(batch["rays_d"].norm(dim=-1), torch.ones(rn), atol=1e-6)      # unit directions: depth is in world units

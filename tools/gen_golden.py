@@ -498,6 +498,128 @@ def gen_march_grad():
          loss=loss.detach(), alpha=alpha, **grads)
 
 
+def gen_trainer():
+    """Pins the trainer harness to the reference's OWN code: the loss classes of network/loss.py applied to
+    a seeded render-output dict at several steps (shape- and material-stage loss lists), ShapeRenderer / MaterialRenderer
+    .compute_rgb_loss, compute_diffuse_light_regularization, TrainerInv.update_learning_rate / N_voxel_list / N_to_reso over the
+    step range, MaterialRenderer._construct_ray_batch_nerf (+ get_human_coordinate_poses) on a tiny image set."""
+    from network.loss import name2loss
+    from network.materialRenderer import MaterialRenderer
+    from network.shapeRenderer import ShapeRenderer
+    from train.trainer_inv import TrainerInv
+    g = torch.Generator().manual_seed(101)
+    rn, N = 24, 200
+    R = lambda *sh: torch.rand(*sh, generator=g)
+    pr = {"ray_rgb": R(rn, 3), "radiance": R(rn, 3), "roughness_weights": R(rn), "gradient_error": R(N), "std": R(()) + 0.1,
+          "sdf_pts": torch.randn(N, 3, generator=g) * 0.7, "sdf_vals": torch.randn(N, generator=g) * 0.3, "loss_occ": R(rn, 1),
+          "loss_sparse": R(()), "loss_hessian": R(()), "loss_tv_sdf": R(3), "loss_gaussian": R(()), "acc": R(rn), "loss_nis": R(()),
+          "loss_mat_reg": R(1), "diffuse_light": R(rn, 3)}
+    gt = {"rgbs": R(rn, 3), "masks": (R(rn) > 0.4).float()}
+    arr = {"pr/" + k: v for k, v in pr.items()}
+    arr.update({"gt/" + k: v for k, v in gt.items()})
+    # compute_rgb_loss of both renderers, every kind
+    for kind in ("l2", "l1", "smooth_l1", "charbonier"):
+        host = types.SimpleNamespace(cfg={"rgb_loss": kind})
+        arr[f"shape_rgb_loss/{kind}"] = ShapeRenderer.compute_rgb_loss(host, pr["ray_rgb"], gt["rgbs"])
+        if kind in ("l1", "charbonier"):
+            arr[f"mat_rgb_loss/{kind}"] = MaterialRenderer.compute_rgb_loss(host, pr["ray_rgb"], gt["rgbs"])
+    arr["diffuse_light_reg"] = MaterialRenderer.compute_diffuse_light_regularization(
+        types.SimpleNamespace(cfg={"reg_diffuse_light_lambda": 0.1}), pr["diffuse_light"])
+    # the shape stage's loss list (configs/shape/syn/compressor.yaml) through the reference's Loss classes
+    upsample = [2000, 5000, 10000, 20000]
+    shape_cfg = {"loss": ["nerf_render", "eikonal", "std", "init_sdf_reg", "occ", "Sparse", "Hessian", "TV", "mask", "Gaussian"],
+                 "eikonal_weight": 0.1, "eikonal_weight_anneal_begin": 1000, "eikonal_weight_anneal_end": 4000,
+                 "sparse_update_list": upsample, "sparse_ratio": [1.0, 0.5, 0.25, 0.1], "hessian_update_list": upsample,
+                 "hessian_ratio": [1.0, 0.8, 0.3, 0.0], "apply_std_loss": True, "std_loss_weight": 0.05}
+    host = types.SimpleNamespace(cfg={"rgb_loss": "charbonier"})
+    steps = [0, 500, 999, 1000, 2500, 5000, 12000, 30000]
+    arr["steps"] = np.array(steps)
+    for name, cfg, extra in (("shape", shape_cfg, {}), ("mat", {"loss": ["nerf_render", "mat_reg", "nis"]}, {})):
+        losses = [name2loss[n](cfg) for n in cfg["loss"]]
+        for st in steps:
+            d = dict(pr)
+            if name == "shape":      # what ShapeRenderer.train_step adds before the Loss classes see the dict (:787-793)
+                d["loss_rgb"] = ShapeRenderer.compute_rgb_loss(host, pr["ray_rgb"], gt["rgbs"])
+                if st > 20000:
+                    d["loss_radiance"] = ShapeRenderer.compute_rgb_loss(host, pr["radiance"], gt["rgbs"]) * pr["roughness_weights"]
+                    d["loss_rgb"] = d["loss_rgb"] * (1.0 - pr["roughness_weights"])
+                d["loss_mask"] = torch.nn.functional.binary_cross_entropy(pr["acc"].clip(1e-3, 1.0 - 1e-3), (gt["masks"] > 0.5).float())
+            else:                    # MaterialRenderer.train_step (:555-565)
+                d["loss_rgb"] = MaterialRenderer.compute_rgb_loss(host, pr["ray_rgb"], gt["rgbs"])
+                d["loss_diffuse_light"] = arr["diffuse_light_reg"]
+            log = {}
+            for L in losses:
+                log.update(L(d, gt, st))
+            total = 0
+            for k, v in log.items():
+                if k.startswith("loss"):
+                    total = total + torch.mean(torch.as_tensor(v, dtype=torch.float32))
+                    arr[f"{name}/{st}/{k}"] = torch.mean(torch.as_tensor(v, dtype=torch.float32))
+            arr[f"{name}/{st}/total"] = total
+    # learning-rate factor, voxel schedule, N_to_reso (trainer_inv.py:118-127, :339-353)
+    tr = types.SimpleNamespace(cfg={"lr_decay_iters": 40000, "lr_decay_target_ratio": 5e-2}, lr_factor=1.0, pre_lr_factor=1.0)
+    fac = []
+    for st in range(0, 40000, 997):
+        TrainerInv.update_learning_rate(tr, st)
+        fac.append([st, tr.lr_factor, tr.pre_lr_factor])
+    arr["lr_factor"] = np.array(fac, np.float64)
+    nv = (np.round(np.exp(np.linspace(np.log(128 ** 3), np.log(400 ** 3), len(upsample) + 1))).astype(np.int32)).tolist()
+    arr["N_voxel_list"] = np.array(nv, np.int64)
+    bbox = [[-1.0, -0.8, -1.2], [1.0, 1.1, 0.9]]
+    arr["N_to_reso"] = np.array([TrainerInv.N_to_reso(tr, n, bbox) for n in nv], np.int64)
+    arr["N_to_reso_bbox"] = np.array(bbox, np.float32)
+    # the material stage's own ray constructor
+    imn, h, w = 2, 5, 6
+    poses = torch.eye(4)[None].repeat(imn, 1, 1)
+    rot = torch.linalg.qr(torch.randn(imn, 3, 3, generator=g))[0]
+    poses[:, :3, :3] = rot
+    poses[:, :3, 3] = torch.randn(imn, 3, generator=g)
+    info = {"imgs": R(imn, 3, h, w), "Ks": torch.tensor([[[7.5, 0, 3.0], [0, 7.5, 2.5], [0, 0, 1]]]).repeat(imn, 1, 1), "poses": poses}
+    mhost = types.SimpleNamespace(cfg={"fixed_camera": False}, _warn_ray_tracing=lambda c: None)
+    mhost.get_human_coordinate_poses = types.MethodType(MaterialRenderer.get_human_coordinate_poses, mhost)
+    rb = MaterialRenderer._construct_ray_batch_nerf(mhost, info)
+    arr.update({"rays/imgs": info["imgs"], "rays/Ks": info["Ks"], "rays/poses": poses, **{"rays/out_" + k: v for k, v in rb.items()}})
+    save("trainer", **arr)
+
+
+def gen_alpha_mask():
+    """ShapeRenderer.updateAlphaMask / compute_gridAlpha / compute_grid_alpha (shapeRenderer.py:257-325) on the march_r32 network:
+    first call (no previous mask), second call on a finer lattice with the first mask in place; AlphaGridMask volumes, the raw
+    alpha lattice and the shrunk aabb.  (torch.set_default_tensor_type('torch.cuda.FloatTensor') inside updateAlphaMask is made a
+    no-op for the call: there is no CUDA device here.)"""
+    from network.shapeRenderer import ShapeRenderer
+    R = 32
+    cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
+               isBGWhite=True, has_radiance_field=False, clip_sample_variance=False, apply_occ_loss=True,
+               occ_loss_step=10000, device="cpu", database_name="tensoSDF/compressor", nerfDataType=True,
+               apply_gaussian_loss=False, inv_s_init=0.3)
+    torch.manual_seed(6033)
+    r = ShapeRenderer(cfg, training=False)
+    perturb_(list(r.sdf_network.sdf_plane) + list(r.sdf_network.sdf_line), 0.02, 1)
+    r.eval()
+    keep = torch.set_default_tensor_type
+    torch.set_default_tensor_type = lambda *a, **k: None
+    try:
+        arr = {}
+        alpha0, xyz0 = r.compute_gridAlpha((24, 20, 28))
+        arr["alpha_24x20x28"] = alpha0
+        aabb1 = r.updateAlphaMask((24, 20, 28))
+        arr["mask1"], arr["aabb1"] = r.alphaMask.alpha_volume[0, 0], aabb1
+        alpha2, _ = r.compute_gridAlpha((40, 40, 40))          # sampled through mask1
+        arr["alpha_40_masked"] = alpha2
+        aabb2 = r.updateAlphaMask((40, 40, 40))
+        arr["mask2"], arr["aabb2"] = r.alphaMask.alpha_volume[0, 0], aabb2
+    finally:
+        torch.set_default_tensor_type = keep
+    arr["thres"], arr["mul_length"] = np.float32(r.alphaMask_thres), np.float32(r.cfg["mul_length"])
+    arr["inv_s"] = r.deviation_network(torch.zeros(1, 3))[0, 0]
+    print("mask1 kept %.3f, mask2 kept %.3f" % (float(arr["mask1"].float().mean()), float(arr["mask2"].float().mean())), "aabb1", aabb1.tolist())
+    sd = {k: v for k, v in r.state_dict().items() if k.startswith("sdf_network.") and "gaussian" not in k or k.startswith("deviation")}
+    base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "march_r32.npz")).items() if k.startswith("sd/")}
+    same = all(k in base and torch.equal(base[k], v) for k, v in sd.items())
+    save("alpha_mask_r32", sd=None if same else sd, sd_is_march_r32=np.bool_(same), **arr)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad", "march_grad", "march_late"]
