@@ -328,8 +328,8 @@ extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes
 
 // ----------------------------------------------------------------------------- device trace
 #ifdef BVH_STATS
-__device__ unsigned long long g_bvh_stats[4];   // inner lane-steps, leaf lane-steps, wave inner iterations x64, wave leaf iterations x64
-extern "C" void tf_bvh_stats(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_stats), 32); unsigned long long z[4] = {0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), z, 32); }
+__device__ unsigned long long g_bvh_stats[8];   // inner lane-steps, leaf lane-steps, wave inner iterations x64, wave leaf iterations x64
+extern "C" void tf_bvh_stats(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_stats), 64); unsigned long long z[8] = {0,0,0,0,0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), z, 64); }
 #endif
 
 // Slab test on a quantised box: plane coordinate x = org + q * scl, so t = (x - o) / d = q * (scl / d) + (org - o) / d
@@ -356,10 +356,13 @@ struct TraceArgs {
   const float* d;
   const unsigned char* live;
   long long m;
-  int n_top;                   // pair records [0, n_top) are served from LDS (breadth-first top of the tree)
+  int n_top;                   // pair records [0, n_top) are numbered breadth-first (top of the tree), the rest depth-first
+  int n_pairs;
   long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
   const int* order;            // [rays_per_origin] or null: the j-th ray traced of a point is its slot order[j]
   int hits_only;               // 1: pos / nrm rows are written for rays that hit only (nobody reads a miss's row)
+  int unit_parts, unit_size;   // SPINE: an origin's rays_per_origin rays are handed out in unit_parts units of <= unit_size rays
+  float spine_radius;          // SPINE: ray origins lie within this distance of their origin row (|off0| + |off1| for unit directions)
   float off0, off1;
   unsigned long long* counter;
   float* pos;
@@ -378,9 +381,41 @@ struct TraceArgs {
 // The kernel is latency-bound (two thirds of a wave's life is s_waitcnt on the node fetch: rocprofv3 SQ_WAIT_ANY), so
 // occupancy is the lever: only the BVH_LDS_STACK deepest-used entries of the stack live in LDS (12 KB per block instead of
 // 32 KB -- a ray keeps ~4 entries pending on average, the tree is 24 deep on the bench mesh).
-template <bool DYN>
+// SPINE (shared origins, rays_per_origin >= 64): three quarters of a ray's pair steps only re-discover where its ORIGIN sits in
+// the tree -- the root-to-leaf chain of boxes that contain the origin, the same for all rays of a surface point (measured: 22.2
+// pair steps per ray, ~17 of them on that chain; inner SIMD efficiency 0.52).  A wave therefore takes its rays one ORIGIN at a
+// time (units of <= 512 rays of one origin), walks that chain ONCE per unit (wave-uniform: follow the child whose box contains
+// the ball of possible ray origins, record the sibling's box and reference in LDS) and every ray of the unit starts with a
+// uniform loop of single-box tests over the recorded siblings (no dependent fetch, no divergence: all starting lanes run the
+// same list) that pushes the siblings it hits; the per-ray traversal proper starts at the chain's last node.  ANY root-to-node
+// chain is a valid start (its siblings are box-tested, its end is traversed unconditionally), so the ball only steers speed:
+// results are bit-identical to the plain traversal.
+#define BVH_SPINE_MAX 28
+// ... and the chain is followed (past the point where the ball straddles a split: any chain is valid) until the subtree below it
+// has at most BVH_NEAR pair records -- contiguous in memory (the packer numbers everything below the breadth-first top of the
+// tree depth-first) -- which the wave copies into LDS.  The kernel is bound by the per-CU vector L1 (one divergent 16-byte access
+// per clock: ~57 accesses per ray before, two per pair step); the steps a ray spends around its own origin are now LDS reads.
+// Measured on the bench (201 M rays, one box, ms per launch): no spine 17.6; spine while the ball fits (the default) 17.1;
+// + units claimed 16 per atomic 18.3 (the counter alone costs 6 ms with the traversal switched off, 2.7 ms grouped -- and the
+// whole kernel still gets slower); + chain followed to the origin's leaf region, no LDS subtree 17.6; + LDS subtree of 32 records
+// 18.4.  Pair steps per ray fall 20.4 -> 11.2 and wave iterations 35 -> 21 with the full form while the time does not move:
+// what is left is the latency of the deep, L2-missing fetches (TCC hit rate 66 % -> 60 %), not the count of steps.
+#ifndef BVH_NEAR
+#define BVH_NEAR 0          // records of the LDS subtree (0: off)
+#endif
+#ifndef BVH_SPINE_FOLLOW
+#define BVH_SPINE_FOLLOW 0  // 1: keep following the child that holds the origin row once the ball straddles a split
+#endif
+#ifndef BVH_UNIT_GROUP
+#define BVH_UNIT_GROUP 1    // units claimed per atomic
+#endif
+template <bool DYN, bool SPINE>
 __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) {
   __shared__ int stack[(BVH_LDS_STACK + 1) * 256];   // + one dummy row: the target of predicated-off pushes
+  __shared__ uint4 spine[SPINE ? 4 * BVH_SPINE_MAX : 1];
+  __shared__ uint4 near_tree[SPINE && BVH_NEAR > 0 ? 4 * 2 * BVH_NEAR : 1];   // per wave: the records of the subtree around the unit's origin
+  int spine_n = 0, spine_end = 0;                    // wave-uniform
+  int near_base = 0, near_size = 0;                  // wave-uniform: pair records [near_base, near_base + near_size) are in near_tree
   int deep[BVH_STACK - BVH_LDS_STACK];
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef BVH_TOP_LDS   // dev-only experiment: a third of every ray's steps touch the same ~127 records at the top of the tree (the
@@ -396,9 +431,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   float Ax = 0, Ay = 0, Az = 0, Bx = 0, By = 0, Bz = 0;   // slab-test constants of the current ray
   bool exhausted = false;
   long long q_next = 0, q_end = 0;   // wave-uniform: this wave's private chunk of the ray pool
+  long long u_next = 0, u_end = 0;   // SPINE: this wave's private range of units
+  int ugrab = BVH_UNIT_GROUP;
   int grab = BVH_CHUNK_MAX;
 #ifdef BVH_STATS
-  unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0;
+  unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0, st_spine = 0, st_spush = 0, st_walks = 0, st_ray = 0, st_max = 0, st_gt100 = 0, st_gt1000 = 0;
 #endif
   auto start_ray = [&](long long seq) {
     // trace order -> ray id: consecutive lanes take the slots of one point in `order` (directions sorted along a
@@ -417,6 +454,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     best = BVH_MAX_DIST; best_tri = -1; sp = 0;
     cur = 0;
     if (A.live && !A.live[id]) cur = BVH_NONE;   // zero weight in the integral: reported as a miss, never traversed
+#ifdef BVH_ABLATE_TRAVERSE   // dev-only timing ablation: ray fetch + scheduling + result stores only
+    cur = BVH_NONE;
+#endif
   };
   auto push = [&](int ref) {
     if (sp < BVH_LDS_STACK) stack[sp * 256 + tid] = ref;
@@ -435,6 +475,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     return v;
   };
   auto retire = [&]() {
+#ifdef BVH_STATS
+    st_max = max(st_max, st_ray); st_gt100 += st_ray > 100; st_gt1000 += st_ray > 1000; st_ray = 0;
+#endif
 #ifdef BVH_ABLATE_STORE   // dev-only timing ablation: results are not written
     if (best == -123.f) A.depth[rid] = best;
     rid = -1;
@@ -461,6 +504,70 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     }
     rid = -1;
   };
+  // ---- SPINE helpers
+  auto build_spine = [&](long long oid) {             // wave-uniform: every lane runs it on the same origin
+    const float px = A.o[3 * oid], py = A.o[3 * oid + 1], pz = A.o[3 * oid + 2];
+    uint4* my = spine + (tid >> 6) * BVH_SPINE_MAX;
+    int node = 0, n = 0, end = A.n_pairs;              // records of the subtree under `node`: [node, end) once node >= n_top
+    near_size = 0;
+    while (n < BVH_SPINE_MAX) {
+      if (BVH_NEAR > 0 && node >= A.n_top && end - node <= BVH_NEAR) break;   // small enough: this subtree goes to LDS, per-ray traversal starts here
+      const uint4 q0 = A.pairs[2LL * node], q1 = A.pairs[2LL * node + 1];
+      const int c0 = (int)q1.z, c1 = (int)q1.w;
+      auto inside = [&](unsigned w0, unsigned w1, unsigned w2, float r) {
+        const float lx = fmaf((float)(w0 & 0xffffu), A.scl[0], A.org[0]), hx = fmaf((float)(w1 >> 16), A.scl[0], A.org[0]);
+        const float ly = fmaf((float)(w0 >> 16), A.scl[1], A.org[1]), hy = fmaf((float)(w2 & 0xffffu), A.scl[1], A.org[1]);
+        const float lz = fmaf((float)(w1 & 0xffffu), A.scl[2], A.org[2]), hz = fmaf((float)(w2 >> 16), A.scl[2], A.org[2]);
+        return lx <= px - r && px + r <= hx && ly <= py - r && py + r <= hy && lz <= pz - r && pz + r <= hz;
+      };
+      // prefer the child that holds the whole ball of ray origins; where the ball straddles the split, the child that holds the
+      // origin row itself (a ray whose own origin lies in the sibling finds it through the sibling's box test like any other hit)
+      bool in0 = c0 != BVH_NONE && inside(q0.x, q0.y, q0.z, A.spine_radius), in1 = c1 != BVH_NONE && inside(q0.w, q1.x, q1.y, A.spine_radius);
+      if (!in0 && !in1) {
+#if BVH_SPINE_FOLLOW
+        in0 = c0 != BVH_NONE && inside(q0.x, q0.y, q0.z, 0.f); in1 = c1 != BVH_NONE && inside(q0.w, q1.x, q1.y, 0.f);
+        if (!in0 && !in1) break;
+#else
+        break;
+#endif
+      }
+      const bool f0 = in0;                             // both contain it: either is valid, take child 0
+      const int sib = f0 ? c1 : c0, next = f0 ? c0 : c1;
+      if (next < 0) break;                             // the chain would end in a leaf: stop one level above (traversal from `node`)
+      if (sib != BVH_NONE) {
+        if (lane == 0) my[n] = f0 ? make_uint4(q0.w, q1.x, q1.y, (unsigned)sib) : make_uint4(q0.x, q0.y, q0.z, (unsigned)sib);
+        ++n;
+      }
+      // depth-first numbering below the top: left subtree = [c0, c1), right subtree = [c1, end)
+      if (node >= A.n_top && f0 && c1 >= 0) end = c1;
+      else if (node < A.n_top) end = A.n_pairs;        // inside the breadth-first top the range is not contiguous yet
+      node = next;
+    }
+    spine_n = n; spine_end = node;
+    if (BVH_NEAR > 0 && node >= A.n_top && end - node <= BVH_NEAR && end > node) {
+      near_base = node; near_size = end - node;
+      uint4* nt = near_tree + (tid >> 6) * 2 * BVH_NEAR;
+      for (int i = lane; i < 2 * near_size; i += 64) nt[i] = A.pairs[2LL * node + i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // list and subtree are in LDS before any lane of this wave reads them
+  };
+  auto spine_walk = [&]() {                            // by every lane that has just started a ray of the current unit
+    const uint4* my = spine + (tid >> 6) * BVH_SPINE_MAX;
+    for (int e = 0; e < spine_n; ++e) {
+      const uint4 sb = my[e];
+      float tn;
+      if (box_hit(sb.x, sb.y, sb.z, Ax, Ay, Az, Bx, By, Bz, best, tn)) {
+        push((int)sb.w);
+#ifdef BVH_STATS
+        st_spush++;
+#endif
+      }
+    }
+#ifdef BVH_STATS
+    st_spine += spine_n; if (lane == __ffsll(__ballot(1)) - 1) st_walks++;
+#endif
+    cur = spine_end;
+  };
   if (!DYN) {
     const long long i = (long long)blockIdx.x * 256 + tid;
     if (i < A.m) start_ray(i);
@@ -480,6 +587,26 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
         if (nw == 0 || (round > 0 && nw < BVH_REFILL)) break;
         if (q_next >= q_end) {
           unsigned long long base = 0;
+          if (SPINE) {
+            // one unit = the rays [part * unit_size, (part + 1) * unit_size) of ONE origin: all rays started from it share a spine.
+            // Units are claimed several at a time: a single counter word sustains ~88 M atomics/s, and one atomic per 384-ray
+            // unit (524 k of them per 201 M rays) held the whole kernel at 6 ms with the traversal switched off.
+            const long long n_units = (A.m / A.rays_per_origin) * A.unit_parts;
+            if (u_next >= u_end) {
+              if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)ugrab);
+              base = __shfl(base, 0);
+              if (base >= (unsigned long long)n_units) { exhausted = true; break; }
+              u_next = (long long)base;
+              u_end = min(u_next + ugrab, n_units);
+              const long long share = (n_units - u_end) / (4LL * gridDim.x * 4);       // guided: shrinks as the pool drains
+              ugrab = (int)min((long long)BVH_UNIT_GROUP, max(1LL, share));
+            }
+            base = (unsigned long long)u_next++;
+            const long long oid = (long long)base / A.unit_parts, part = (long long)base - oid * A.unit_parts;
+            q_next = oid * A.rays_per_origin + part * A.unit_size;
+            q_end = min(q_next + A.unit_size, (oid + 1) * A.rays_per_origin);
+            build_spine(oid);
+          } else {
           if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)grab);
           base = __shfl(base, 0);
           if (base >= (unsigned long long)A.m) { exhausted = true; break; }
@@ -488,12 +615,14 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           // guided self-scheduling: chunks shrink as the pool drains so the last chunk of the slowest wave stays short
           const long long share = (A.m - q_end) / (4LL * gridDim.x * 4);
           grab = (int)min((long long)BVH_CHUNK_MAX, max((long long)BVH_CHUNK_MIN, share));
+          }
         }
         if (want) {
           const long long id = q_next + __popcll(wb & lt_mask);
           if (id < q_end) {
             start_ray(id);
             if (cur == BVH_NONE) retire();
+            else if (SPINE) spine_walk();
           }
         }
         q_next = min(q_next + nw, q_end);
@@ -549,7 +678,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #endif
         if (cur >= 0) {
 #ifdef BVH_STATS
-          st_inner++;
+          st_inner++; st_ray++;
 #endif
 #ifdef BVH_WIDE
           const uint4* P = A.pairs + 4LL * cur;
@@ -580,7 +709,10 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
             q0 = top[2 * cur]; q1 = top[2 * cur + 1];
           } else
 #endif
-          {
+          if (SPINE && BVH_NEAR > 0 && (unsigned)(cur - near_base) < (unsigned)near_size) {
+            const uint4* P = near_tree + (tid >> 6) * 2 * BVH_NEAR + 2 * (cur - near_base);
+            q0 = P[0]; q1 = P[1];
+          } else {
             const uint4* P = A.pairs + 2LL * cur;
             q0 = P[0]; q1 = P[1];
           }
@@ -632,6 +764,8 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #ifdef BVH_STATS
   atomicAdd(&g_bvh_stats[0], (unsigned long long)st_inner); atomicAdd(&g_bvh_stats[1], (unsigned long long)st_leaf);
   if (lane == 0) { atomicAdd(&g_bvh_stats[2], 64ULL * st_wi); atomicAdd(&g_bvh_stats[3], 64ULL * st_wl); }
+  atomicMax(&g_bvh_stats[7], (unsigned long long)st_max); atomicAdd(&g_bvh_stats[6], 0ULL);
+  atomicAdd(&g_bvh_stats[4], (unsigned long long)st_spine); atomicAdd(&g_bvh_stats[5], (unsigned long long)st_spush); atomicAdd(&g_bvh_stats[6], ((unsigned long long)st_gt1000 << 32) | (unsigned long long)st_gt100);
 #endif
 }
 
@@ -648,6 +782,7 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
   TraceArgs A;
   A.pairs = reinterpret_cast<const uint4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
   for (int k = 0; k < 3; ++k) { A.org[k] = frame_host[k]; A.scl[k] = frame_host[3 + k]; }
+  A.n_pairs = (int)n_pairs;
   A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order;
 #ifdef BVH_NO_TOP   // dev-only switch: every record from global memory
   A.n_top = 0;
@@ -663,14 +798,24 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
     static int resident = 0;    // blocks per CU the hardware admits (registers / LDS), queried once
     if (!resident) {
       int nb = 0;
-      hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true>, 256, 0);
+      hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true, true>, 256, 0);
       resident = (e2 == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;
     }
     long long blocks = (m + 255) / 256;
     if (blocks > 256LL * resident) blocks = 256LL * resident;   // persistent blocks pull rays until the pool is empty
-    bvh_trace_kernel<true><<<(unsigned)blocks, 256, 0, stream>>>(A);
+#ifndef BVH_NO_SPINE
+    const bool use_spine = rays_per_origin >= 64 && m % rays_per_origin == 0;
+#else
+    const bool use_spine = false;
+#endif
+    A.unit_parts = (int)((rays_per_origin + BVH_CHUNK_MAX - 1) / BVH_CHUNK_MAX);
+    A.unit_size = (int)((rays_per_origin + A.unit_parts - 1) / A.unit_parts);
+    A.spine_radius = (fabsf(origin_offset0) + fabsf(origin_offset1)) * 1.001f + 1e-6f;
+    if (use_spine) bvh_trace_kernel<true, true><<<(unsigned)blocks, 256, 0, stream>>>(A);
+    else bvh_trace_kernel<true, false><<<(unsigned)blocks, 256, 0, stream>>>(A);
   } else {
-    bvh_trace_kernel<false><<<tf_blocks(m, 256), 256, 0, stream>>>(A);
+    A.unit_parts = 1; A.unit_size = 1; A.spine_radius = 0.f;
+    bvh_trace_kernel<false, false><<<tf_blocks(m, 256), 256, 0, stream>>>(A);
   }
   TF_LAUNCH_CHECK("tf_bvh_trace");
   return TF_OK;

@@ -20,3 +20,14 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): out = sh.shade(pts, view, nrm, 128, 128)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print(sys.argv[1] if len(sys.argv) > 1 else "-", f"{pn/dt/1e6:.3f} M points/s", {k: round(v[0] / 5, 2) for k, v in t.summary().items()}, "colors checksum", float(out["colors"].double().sum()))
+try:
+    import ctypes as C
+    lib = L.load()
+    lib.tf_bvh_stats.argtypes = [C.c_void_p]
+    st = (C.c_ulonglong * 8)()
+    lib.tf_bvh_stats(st)
+    m = pn * 768 * 7
+    print(f"bvh stats over {m} rays: inner lane-steps/ray {st[0]/m:.1f} leaf {st[1]/m:.2f} wave inner x64/ray {st[2]/m:.1f} wave leaf x64/ray {st[3]/m:.1f} "
+          f"spine entries/ray {st[4]/m:.1f} pushes/ray {st[5]/m:.2f} max steps {st[7]}")
+except AttributeError:
+    pass
