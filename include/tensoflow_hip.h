@@ -46,6 +46,15 @@ typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1, TF_PREC_F16 = 2, 
  * the same weights and precision (the caller tracks weight updates), so the fragment re-pack launches are skipped. */
 #define TF_WEIGHTS_PACKED 0x100
 
+/* Activation fused into tf_linear_fwd / differentiated by tf_linear_bwd. */
+typedef enum TfActivation {
+  TF_ACT_NONE = 0,
+  TF_ACT_RELU = 1,
+  TF_ACT_SOFTPLUS = 2,  /* torch.nn.Softplus(beta = act_param, threshold = 20): TensoSDF decoder (network/fields.py:79) */
+  TF_ACT_SIGMOID = 3,   /* material predictors' final activation (network/other_field.py:50-84) */
+  TF_ACT_EXP_CLAMP = 4  /* ExpActivation: exp(min(z, act_param)) (network/other_field.py:12-18) */
+} TfActivation;
+
 int tf_version(void);
 const char* tf_last_error(void);
 
@@ -434,6 +443,20 @@ int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth,
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);
+
+/* -----------------------------------------------------------------------------------
+ * Dense layers of the training direction.  Replace torch.nn.Linear + activation -- the library GEMMs under the reference's
+ * TensoSDF decoder (network/fields.py:78-81), make_predictor_3layer / _4layer (network/other_field.py:50-119: material
+ * predictors fields.py:1010-1017, inner-light net :905-911, ShapeShadingNetwork's nets :448-567) -- in forward AND backward.
+ * Exact fp32 matrix cores (v_mfma_f32_32x32x2_f32).  X [n,K], W [N,K] (torch layout), b [N] or NULL, Y [n,N] row-major.
+ * tf_linear_bwd: Y = the forward OUTPUT (post-activation), gY [n,N]; gZ [n,N] scratch that receives gY * act'(Y);
+ * gX [n,K] or NULL; gW [N,K] / gb [N] or NULL are overwritten (zeroed, then accumulated with fp32 atomics over row slabs).
+ * n_dev (device pointer, or NULL): only the first min(n, *n_dev) rows are valid -- the row count of a compacted list (hit rays)
+ * stays on the device, the launch is sized for the capacity n and surplus workgroups exit (no host sync in a training step). */
+int tf_linear_fwd(const float* X, const float* W, const float* b, int64_t n, int32_t K, int32_t N, int32_t act /* TfActivation */,
+                  float act_param, float* Y, const int64_t* n_dev, tf_stream_t stream);
+int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
+                  float act_param, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev, tf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,59 @@ import torch
 from . import ops
 
 
+class LinearActFn(torch.autograd.Function):
+    """y = act(x w^T + b): forward tf_linear_fwd, backward tf_linear_bwd (data, weight and bias gradients) -- the dense layers of
+    every MLP in a training step run on the exact-fp32 matrix cores of libtensoflow_hip.so, none on a library GEMM.
+    n_dev: optional device-side row count (compacted hit lists): rows beyond it are neither computed nor differentiated."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, act_param, n_dev=None):
+        x, w = x.contiguous(), w.contiguous()
+        y = ops.linear_fwd(x.detach(), w.detach(), None if b is None else b.detach(), act, act_param, n_dev=n_dev)
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (act, act_param, b is not None, n_dev)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        act, act_param, has_b, n_dev = ctx.cfg
+        gx, gw, gb = ops.linear_bwd(x, w, y, gy.contiguous(), act, act_param, need_gx=ctx.needs_input_grad[0],
+                                    need_gw=ctx.needs_input_grad[1], need_gb=has_b and ctx.needs_input_grad[2], n_dev=n_dev)
+        return gx, gw, gb, None, None, None
+
+
+def mlp_apply(seq, x, n_dev=None):
+    """Evaluate an nn.Sequential of Linear / activation modules (make_predictor_3layer / _4layer and TensoSDF.sdf_mat shapes) with
+    every Linear + its following activation as ONE LinearActFn.  The modules keep their parameters (weight-norm parametrizations
+    included: `layer.weight` composes g v / |v| under autograd) and their state_dict keys; only the arithmetic moves."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if not isinstance(m, torch.nn.Linear):
+            raise NotImplementedError(f"mlp_apply: unexpected module {type(m).__name__} at position {i}")
+        act, prm, step = ops.ACT_NONE, 0.0, 1
+        if i + 1 < len(mods) and not isinstance(mods[i + 1], torch.nn.Linear):
+            a = mods[i + 1]
+            step = 2
+            if isinstance(a, torch.nn.ReLU):
+                act = ops.ACT_RELU
+            elif isinstance(a, torch.nn.Softplus):
+                act, prm = ops.ACT_SOFTPLUS, float(a.beta)
+            elif isinstance(a, torch.nn.Sigmoid):
+                act = ops.ACT_SIGMOID
+            elif isinstance(a, torch.nn.Identity):
+                act = ops.ACT_NONE
+            elif hasattr(a, "max_light"):                       # ExpActivation (other_field.py:12-18)
+                act, prm = ops.ACT_EXP_CLAMP, float(a.max_light)
+            else:
+                raise NotImplementedError(f"mlp_apply: activation {type(a).__name__}")
+        x = LinearActFn.apply(x, m.weight, m.bias, act, prm, n_dev)
+        i += step
+    return x
+
+
 class VmGatherFn(torch.autograd.Function):
     """feat = gather(planes, lines)(xyz, level): forward tf_vm_gather_fwd on the packed pyramid; backward
     tf_vm_gather_bwd (float atomics into a pyramid-shaped buffer) + tf_vm_pack_bwd (box-filter adjoint, layout restore)."""
@@ -75,7 +128,7 @@ class ShadeWeightsFn(torch.autograd.Function):
 class LightsFn(torch.autograd.Function):
     """lights [M,3] of MCShadingNetwork.get_lights (fields.py:951-975): BVH visibility, cube-map light on a miss, inner-light MLP
     on a hit, near mask -- forward entirely in the HIP kernels.  Backward: the cube-map gradient is tf_cube_lookup_bwd (scatter);
-    the inner-light weight gradients are plain library GEMMs on the [hits,123] encoding produced by tf_inner_light_encode."""
+    the inner-light weight gradients come from tf_linear_fwd / tf_linear_bwd on the [hits,123] encoding of tf_inner_light_encode."""
 
     @staticmethod
     def forward(ctx, env_base, pts_rep, dirs, live, bvh, unit, exp_max, precision, *inner_wb):
@@ -95,20 +148,23 @@ class LightsFn(torch.autograd.Function):
         near = (depth > 1e-5).float()[:, None]
         g = (g_lights * near).contiguous()
         g_base = ops.cube_lookup_bwd(env_base.detach(), dirs, g * (~hit).float()[:, None], apply_exp=True)
+        # inner-light net on the hit rows: recompute the four layers and differentiate them with the HIP dense-layer kernels.  The
+        # number of hit rays stays on the device (`count`): launches are sized for the capacity and clamp to it in-kernel, so a
+        # training step has no host sync here.
+        cap = idx.numel()
+        X = ops.inner_light_encode(inters, dirs, nrm, idx, count)                 # [cap, 123], rows >= count unspecified
+        gsel = g.index_select(0, idx.clamp(0, g.shape[0] - 1))                    # [cap, 3]
+        ws = [t.detach() for t in inner_wb]
+        acts = [ops.ACT_RELU, ops.ACT_RELU, ops.ACT_RELU, ops.ACT_EXP_CLAMP]
+        hs = [X]
+        for l in range(4):
+            hs.append(ops.linear_fwd(hs[-1], ws[2 * l], ws[2 * l + 1], acts[l], ctx.exp_max, n_dev=count))
         grads = [None] * 8
-        n_hit = int(count.item())                                    # training only: one sync per step
-        if n_hit > 0:
-            rows = idx[:n_hit]
-            X = ops.inner_light_encode(inters, dirs, nrm, idx, count)[:n_hit]
-            with torch.enable_grad():
-                wb = [t.detach().requires_grad_(True) for t in inner_wb]
-                h = X
-                for l in range(4):
-                    h = torch.nn.functional.linear(h, wb[2 * l], wb[2 * l + 1])
-                    if l < 3:
-                        h = torch.relu(h)
-                out = torch.exp(h.clamp(max=ctx.exp_max))
-                grads = list(torch.autograd.grad(out, wb, g[rows]))
+        gy = gsel
+        for l in (3, 2, 1, 0):
+            gx, gw, gb = ops.linear_bwd(hs[l], ws[2 * l], hs[l + 1], gy, acts[l], ctx.exp_max, need_gx=l > 0, n_dev=count)
+            grads[2 * l], grads[2 * l + 1] = gw, gb
+            gy = gx
         return (g_base, None, None, None, None, None, None, None, *grads)
 
 
@@ -147,7 +203,7 @@ class CompositeFn(torch.autograd.Function):
 
 def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, inv_s, cos_anneal, aabb, units, n_levels):
     """Differentiable restatement of tf_sdf_alpha_fwd used ONLY inside SdfAlphaFn.backward: the gather is the HIP kernel pair
-    (VmGatherFn), the two decoder products are library GEMMs over all 7 taps, the rest is elementwise."""
+    (VmGatherFn), the two decoder products are the HIP dense-layer kernels (LinearActFn) over all 7 taps, the rest is elementwise."""
     import torch.nn.functional as F
     N = pts.shape[0]
     u = torch.as_tensor(units, dtype=torch.float32, device=pts.device)
@@ -158,9 +214,9 @@ def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, i
     P = (pts[None] + offs[:, None]).reshape(-1, 3).contiguous()
     lv = None if level is None else level.reshape(-1).repeat(7).contiguous()
     feat = VmGatherFn.apply(P, lv, aabb, n_levels, *planes, *lines)
-    h = F.softplus(F.linear(torch.cat([feat, P], -1), W1, b1), beta=100)
-    s = F.linear(h, W2[:1], b2[:1])[:, 0].view(7, N)
-    app = F.linear(h[:N], W2[1:], b2[1:])
+    h = LinearActFn.apply(torch.cat([feat, P], -1), W1, b1, ops.ACT_SOFTPLUS, 100.0)
+    s = LinearActFn.apply(h, W2[:1].contiguous(), b2[:1].contiguous(), ops.ACT_NONE, 0.0)[:, 0].view(7, N)
+    app = LinearActFn.apply(h[:N].contiguous(), W2[1:].contiguous(), b2[1:].contiguous(), ops.ACT_NONE, 0.0)
     sdf = s[0]
     grad = torch.stack([(s[1 + 2 * ax] - s[2 + 2 * ax]) / (2 * u[ax]) for ax in range(3)], -1)
     hess = torch.stack([(s[1 + 2 * ax] + s[2 + 2 * ax] - 2 * sdf) / (u[ax] ** 2) for ax in range(3)], -1)
@@ -175,8 +231,8 @@ def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, i
 
 class SdfAlphaFn(torch.autograd.Function):
     """ShapeRenderer.compute_sdf_alpha: forward = the fused HIP kernel (tf_sdf_alpha_fwd).  Backward recomputes through
-    `sdf_alpha_composed` -- HIP gather/scatter for the field, library GEMMs for the decoder (a fused HIP backward of the
-    7-tap decoder is future work) -- and returns gradients for planes, lines, W1, b1, W2, b2 and inv_s."""
+    `sdf_alpha_composed` -- HIP gather/scatter for the field, HIP dense-layer kernels for the decoder -- and returns gradients for
+    planes, lines, W1, b1, W2, b2 and inv_s."""
 
     @staticmethod
     def forward(ctx, pts, level, dists, dirs, inv_s, cos_anneal, aabb, units, n_levels, *params):

@@ -273,8 +273,8 @@ class MCShadingNetwork(nn.Module):
     def predict_materials(self, pts):
         """fields.py:1010-1017 -> metallic [pn,1], roughness [pn,1] (squared-roughness convention, remapped), albedo [pn,3]."""
         feat = VmGatherFn.apply(pts.contiguous(), None, self.aabb, 3, *self.mat_plane, *self.mat_line)
-        return (self.metallic_predictor(feat), self.roughness_predictor(feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2,
-                self.albedo_predictor(feat))
+        return (_mlp(self.metallic_predictor, feat), _mlp(self.roughness_predictor, feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2,
+                _mlp(self.albedo_predictor, feat))
 
     def _linear_to_srgb(self, lin):
         eps = torch.finfo(torch.float32).eps
@@ -288,9 +288,9 @@ class MCShadingNetwork(nn.Module):
         pn = pts.shape[0]
         sd, ss = self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"]
         feat = VmGatherFn.apply(pts.contiguous(), None, self.aabb, 3, *self.mat_plane, *self.mat_line)
-        metallic = self.metallic_predictor(feat)
-        roughness = self.roughness_predictor(feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2
-        albedo = self.albedo_predictor(feat)
+        metallic = _mlp(self.metallic_predictor, feat)
+        roughness = _mlp(self.roughness_predictor, feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2
+        albedo = _mlp(self.albedo_predictor, feat)
         if not hasattr(self, "_bvh"):
             self._bvh = ops.Bvh(self.ray_tracer[0], self.ray_tracer[1], dev)
             self._fixed = fibonacci_samples(self.cfg["diffuse_sample_num"]).to(dev)
@@ -357,6 +357,16 @@ class MCShadingNetwork(nn.Module):
                                                   "normal": nrm, "rgb_pr": nis["colors"], **aux_outputs(nis)}.items()})
         outputs["specular_rays_id_nis"] = nis["specular_rays_id"]
         return fx["colors"], outputs
+
+
+def _mlp(seq, x):
+    """A predictor's nn.Sequential on the device: every Linear + activation pair is one tf_linear_fwd launch, differentiated by
+    tf_linear_bwd (autograd.mlp_apply) -- no library GEMM in a training step.  (CPU tensors -- module construction tests -- take the
+    plain module call.)"""
+    if x.is_cuda:
+        from ..autograd import mlp_apply
+        return mlp_apply(seq, x.contiguous())
+    return seq(x)
 
 
 def _predictor3(feats_dim, out_dim, final, run_dim=128):
@@ -459,7 +469,7 @@ class ShapeShadingNetwork(nn.Module):
     def _radiance(self, points, normals, view_dirs, feat):
         """fields.py:476-483 on normalised / patched normals and normalised view directions."""
         from ..encodings import posenc
-        return self.rad_mlp(torch.cat([feat, points, posenc(view_dirs, 4), normals], -1))
+        return _mlp(self.rad_mlp, torch.cat([feat, points, posenc(view_dirs, 4), normals], -1))
 
     @staticmethod
     def _unit_inputs(normals, view_dirs):
@@ -477,7 +487,7 @@ class ShapeShadingNetwork(nn.Module):
         normals, view_dirs = self._unit_inputs(normals, view_dirs)
         NoV = (normals * view_dirs).sum(-1, keepdim=True)
         reflective = NoV * normals * 2 - view_dirs
-        mat = self.mat_mlp(feat)
+        mat = _mlp(self.mat_mlp, feat)
         albedo, roughness, metallic = mat[..., :3] * 0.77 + 0.03, mat[..., 3:4] * 0.9 + 0.09, mat[..., 4:]
         diffuse_albedo = (1 - metallic) * albedo
         diffuse_light = env(normals)
@@ -485,8 +495,8 @@ class ShapeShadingNetwork(nn.Module):
         specular_albedo = 0.04 * (1 - metallic) + metallic * albedo
         direct_light = env(reflective, roughness)
         pts = posenc(points, self.cfg["light_pos_freq"])
-        indirect_light = self.inner_light(torch.cat([pts, ide5(reflective, roughness)], -1))
-        occ_prob = self.inner_weight(torch.cat([pts.detach(), posenc(reflective, 6).detach()], -1)) * 0.5 + 0.5
+        indirect_light = _mlp(self.inner_light, torch.cat([pts, ide5(reflective, roughness)], -1))
+        occ_prob = _mlp(self.inner_weight, torch.cat([pts.detach(), posenc(reflective, 6).detach()], -1)) * 0.5 + 0.5
         occ = occ_prob.clamp(0, 1)
         specular_light = indirect_light * occ + direct_light * (1 - occ)
         # FG LUT: dr.texture(filter_mode='linear', boundary_mode='clamp'), texel centres at (i + .5) / n
@@ -524,5 +534,5 @@ class ShapeShadingNetwork(nn.Module):
 
     def predict_materials(self, points, feature_vectors):
         """fields.py:569-575: raw mat_mlp outputs (no albedo / roughness remapping, as in the reference)."""
-        mat = self.mat_mlp(feature_vectors)
+        mat = _mlp(self.mat_mlp, feature_vectors)
         return mat[..., 4:], mat[..., 3:4], mat[..., :3]

@@ -232,6 +232,39 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
     return (ang, lj, bins) if want_bins else (ang, lj)
 
 
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_EXP_CLAMP = 0, 1, 2, 3, 4      # TfActivation
+
+
+def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None):
+    """Y = act(x w^T + b) on the exact-fp32 matrix cores (tf_linear_fwd): x [n,K], w [N,K], b [N] or None -> [n,N].
+    n_dev: device int64 scalar -- only the first min(n, n_dev) rows are computed (the rest of Y stays uninitialised)."""
+    lib = L.load()
+    x, w = _f(x), _f(w)
+    n, K = x.shape
+    N = w.shape[0]
+    assert w.shape == (N, K)
+    y = torch.empty(n, N, device=x.device)
+    L.check(lib.tf_linear_fwd(_p(x), _p(w), _p(_f(b)) if b is not None else None, n, K, N, int(act), float(act_param), _p(y),
+                              _p(n_dev, torch.int64) if n_dev is not None else None, _stream()), "tf_linear_fwd")
+    return y
+
+
+def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=True, need_gb=True, n_dev=None):
+    """-> (gx [n,K] | None, gw [N,K] | None, gb [N] | None) of Y = act(x w^T + b) given the forward output y and gy (tf_linear_bwd)."""
+    lib = L.load()
+    x, w, y, gy = _f(x), _f(w), _f(y), _f(gy)
+    n, K = x.shape
+    N = w.shape[0]
+    gz = torch.empty(n, N, device=x.device)
+    gx = torch.empty(n, K, device=x.device) if need_gx else None
+    gw = torch.empty(N, K, device=x.device) if need_gw else None
+    gb = torch.empty(N, device=x.device) if need_gb else None
+    L.check(lib.tf_linear_bwd(_p(x), _p(w), _p(y), _p(gy), n, K, N, int(act), float(act_param), _p(gz), _p(gx) if need_gx else None,
+                              _p(gw) if need_gw else None, _p(gb) if need_gb else None,
+                              _p(n_dev, torch.int64) if n_dev is not None else None, _stream()), "tf_linear_bwd")
+    return gx, gw, gb
+
+
 def pwquad(wv, y, inverse):
     """ElementWisePWQuadraticTransform.flow_inv (inverse=False: density direction) / .flow (inverse=True: sampling direction) on
     parameter rows wv [m,21] and y [m] -> out [m], logj [m], bins [m] int32 (flow.py:332-525; the device functions of the fused

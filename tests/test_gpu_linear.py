@@ -1,0 +1,72 @@
+"""tf_linear_fwd / tf_linear_bwd (the dense layers of the training direction) against torch.nn.functional on the same device."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_act(z, act, p):
+    from tensoflow_amd import ops
+    return {ops.ACT_NONE: lambda: z, ops.ACT_RELU: lambda: torch.relu(z), ops.ACT_SOFTPLUS: lambda: F.softplus(z, beta=p),
+            ops.ACT_SIGMOID: lambda: torch.sigmoid(z), ops.ACT_EXP_CLAMP: lambda: torch.exp(z.clamp(max=p))}[act]()
+
+
+@pytest.mark.parametrize("n,K,N", [(1, 3, 1), (777, 111, 256), (4096, 256, 129), (2048, 108, 128), (300, 128, 3), (5000, 123, 256), (130, 256, 256)])
+def test_linear_fwd_bwd_matches_torch(n, K, N):
+    from tensoflow_amd import ops
+    from tensoflow_amd.autograd import LinearActFn
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n + K + N)
+    for act, p in ((ops.ACT_NONE, 0.0), (ops.ACT_RELU, 0.0), (ops.ACT_SOFTPLUS, 100.0), (ops.ACT_SIGMOID, 0.0), (ops.ACT_EXP_CLAMP, 0.5)):
+        x = torch.randn(n, K, generator=g).to(dev).requires_grad_(True)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_(True)
+        b = (0.1 * torch.randn(N, generator=g)).to(dev).requires_grad_(True)
+        gy = torch.randn(n, N, generator=g).to(dev)
+        y = LinearActFn.apply(x, w, b, act, p)
+        y.backward(gy)
+        got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        x.grad = w.grad = b.grad = None
+        yr = _ref_act(F.linear(x.double(), w.double(), b.double()), act, p)
+        yr.backward(gy.double())
+        ref = (yr.detach(), x.grad, w.grad, b.grad)
+        for name, a, r in zip(("y", "gx", "gw", "gb"), got, ref):
+            scale = float(r.abs().max()) + 1e-12
+            assert float((a.double() - r.double()).abs().max()) / scale < 2e-5, (act, name, n, K, N)
+
+
+def test_linear_device_side_row_count():
+    """n_dev: rows beyond the device-side count are neither computed nor differentiated (compacted hit lists, no host sync)."""
+    from tensoflow_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    n, K, N, nv = 1000, 123, 256, 437
+    x, w, b = torch.randn(n, K, device=dev), torch.randn(N, K, device=dev) / 11, torch.randn(N, device=dev)
+    cnt = torch.tensor([nv], dtype=torch.int64, device=dev)
+    y = ops.linear_fwd(x, w, b, ops.ACT_RELU, n_dev=cnt)
+    ref = torch.relu(F.linear(x[:nv], w, b))
+    assert torch.allclose(y[:nv], ref, atol=1e-4)
+    gy = torch.randn(n, N, device=dev)
+    yfull = torch.relu(F.linear(x, w, b))
+    gx, gw, gb = ops.linear_bwd(x, w, yfull, gy, ops.ACT_RELU, n_dev=cnt)
+    gz = gy[:nv] * (yfull[:nv] > 0)
+    assert torch.allclose(gw, gz.t() @ x[:nv], atol=2e-3, rtol=1e-4) and torch.allclose(gb, gz.sum(0), atol=1e-3)
+    assert torch.allclose(gx[:nv], gz @ w, atol=1e-4)
+
+
+def test_mlp_apply_walks_weight_normed_sequentials():
+    from tensoflow_amd.autograd import mlp_apply
+    from tensoflow_amd.network.fields import _predictor3
+    import torch.nn as nn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    seq = _predictor3(108, 3, nn.Sigmoid()).to(dev)
+    x = torch.randn(513, 108, device=dev, requires_grad=True)
+    y = mlp_apply(seq, x)
+    yr = seq(x)
+    assert torch.allclose(y, yr, atol=1e-5)
+    gy = torch.randn_like(y)
+    g1 = torch.autograd.grad(y, [x] + list(seq.parameters()), gy)
+    g2 = torch.autograd.grad(yr, [x] + list(seq.parameters()), gy)
+    for a, r in zip(g1, g2):
+        assert float((a - r).abs().max()) <= 2e-5 * (float(r.abs().max()) + 1e-9) + 1e-7
