@@ -49,7 +49,12 @@ def ide5(xyz, kappa_inv):
     for _ in range(16):
         re, im = re + [re[-1] * x - im[-1] * y], im + [re[-1] * y + im[-1] * x]
     re, im = torch.cat(re, -1)[..., ms], torch.cat(im, -1)[..., ms]
-    poly = vmz @ mat
+    if vmz.is_cuda and vmz.dim() == 2:     # [n,17] x [17,36]: a dense layer without bias on the HIP kernels (fwd + bwd), not a library GEMM
+        from .autograd import LinearActFn
+        from . import ops
+        poly = LinearActFn.apply(vmz.contiguous(), mat.t().contiguous(), None, ops.ACT_NONE, 0.0)
+    else:
+        poly = vmz @ mat
     att = torch.exp(-sigma * kappa_inv)
     return torch.cat([re * poly * att, im * poly * att], -1)
 

@@ -95,7 +95,11 @@ class TensoFlow(nn.Module):
                                     *self.nis_plane, *self.nis_line)
         else:
             feat = ops.vm_gather(self._field(), xyz_sampled.reshape(-1, 3), level_vol, self.aabb)
-        return self.nis_mat(torch.cat([feat, posenc(xyz_sampled, 3)], -1))
+        h = torch.cat([feat, posenc(xyz_sampled, 3)], -1)
+        if h.is_cuda:                                   # 57-64-16 feature net on the HIP dense-layer kernels (fwd + bwd)
+            from ..autograd import mlp_apply
+            return mlp_apply(self.nis_mat, h.contiguous())
+        return self.nis_mat(h)
 
     def _condition(self, pts, reflections):
         feature = self.tenso_feature(pts)
@@ -122,8 +126,8 @@ class TensoFlow(nn.Module):
 
     def forward(self, pts, reflections, roughness, x, return_jacobian=False, rays_id=None):
         """flow.py:801-831 -> z (, logqx).  Differentiable wrt every parameter of the flow (the NIS loss path):
-        forward and backward are fused HIP kernels (autograd.FlowLogqFn / VmGatherFn); the 57-64-16 feature net is a
-        per-point library GEMM under plain autograd."""
+        forward and backward are fused HIP kernels (autograd.FlowLogqFn / VmGatherFn); the 57-64-16 feature net runs on the
+        HIP dense-layer kernels (autograd.mlp_apply)."""
         cond = self._condition(pts, reflections)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             wb = []

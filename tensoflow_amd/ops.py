@@ -320,14 +320,16 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None):
     rid = None if rays_id is None else rays_id.contiguous()
     L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
                                  _p(g_point), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
-    # fold the hoisted per-point part (three small library GEMMs per net)
+    # fold the hoisted per-point part: the three products of one dense layer c [pn,37] -> [pn,64] (tf_linear_bwd)
     c = cond * 2.0 - 1.0
     g_cond = torch.zeros_like(cond)
     for k in range(2):
         gW1, gb1 = grads[k][0]
-        gW1[:, 7:] += g_point[k].t() @ c
-        gb1 += g_point[k].sum(0)
-        g_cond += 2.0 * (g_point[k] @ _f(weights[k][0][0])[:, 7:])
+        gp = g_point[k].contiguous()
+        gx, gw, gb = linear_bwd(c, _f(weights[k][0][0])[:, 7:].contiguous(), gp, gp, ACT_NONE)
+        gW1[:, 7:] += gw
+        gb1 += gb
+        g_cond += 2.0 * gx
     return grads, g_cond
 
 
