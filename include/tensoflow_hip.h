@@ -219,14 +219,18 @@ int tf_cube_lookup_bwd_dirs(const float* base, int32_t res, const float* dirs, i
  *   "n uniform steps in the aabb slab" when step_size <= 0.  Ray/box slab test and near/far clamp as sample_ray
  *   (shapeRenderer.py:878-884).  Call twice: (1) offsets = NULL -> counts[rn] = live samples per ray;
  *   (2) offsets[rn] = exclusive prefix sum of counts -> t_starts/t_ends/ray_indices [sum counts] written densely.
- *   volume may be NULL (no occupancy culling).
+ *   volume may be NULL (no occupancy culling).  occupancy_mode 0: `volume` is an AlphaGridMask volume [D,H,W] (W <- x), a sample
+ *   lives when the trilinear fetch at its mid-point is > 0; 1: `volume` is an occupancy grid [rx = D, ry = H, rz = W]
+ *   (OccGridEstimator.binaries), a sample lives when the CELL holding its mid-point is set.  t_jitter [rn] or NULL: added to each
+ *   ray's start after the near/far clamp (stratified sampling: U[0,1) * step drawn by the caller).
  * ------------------------------------------------------------------------------------------ */
 int tf_alpha_mask_sample(const uint8_t* volume, int32_t D, int32_t H, int32_t W, const float* aabb_host, const float* pts,
                          int64_t n, uint8_t* alive, tf_stream_t stream);
 int tf_march_uniform(const float* rays_o, const float* rays_d, const float* near, const float* far, int64_t rn,
                      int32_t n_steps, float step_size, const float* aabb_host, const uint8_t* volume, int32_t D, int32_t H,
-                     int32_t W, const float* mask_aabb_host, const int64_t* offsets, int64_t* counts, float* t_starts,
-                     float* t_ends, int64_t* ray_indices, tf_stream_t stream);
+                     int32_t W, const float* mask_aabb_host, int32_t occupancy_mode, const float* t_jitter,
+                     const int64_t* offsets, int64_t* counts, float* t_starts, float* t_ends, int64_t* ray_indices,
+                     tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Env-light prefilter: EnvLight.build_mips (network/light.py:52-64), rebuilt every shape-stage training step

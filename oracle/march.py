@@ -181,7 +181,7 @@ def alpha_mask_sample(volume, aabb, pts):
     return F.grid_sample(vol, g.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
 
 
-def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume=None, mask_aabb=None):
+def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume=None, mask_aabb=None, cells=False, t_jitter=None):
     """Fixed-step sampler of the build (stands in for nerfacc's OccGridEstimator.sampling, which is third-party and
     unpinned): slab test / clamp as sample_ray (shapeRenderer.py:878-884); n_steps uniform intervals of [tmin, tmax]
     (step_size <= 0) or intervals of step_size from tmin while t < tmax; a sample is kept when its mid-point is inside the
@@ -191,6 +191,8 @@ def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume=None, ma
     ra, rb = (aabb[1] - o) / vec, (aabb[0] - o) / vec
     tmin = torch.minimum(ra, rb).amax(-1).clamp(min=near.reshape(-1), max=far.reshape(-1))[:, None]
     tmax = torch.maximum(ra, rb).amin(-1).clamp(min=near.reshape(-1), max=far.reshape(-1))[:, None]
+    if t_jitter is not None:                       # stratified start: added after the near / far clamp
+        tmin = tmin + t_jitter.reshape(-1, 1)
     step = torch.full_like(tmin, step_size) if step_size > 0 else (tmax - tmin) / n_steps
     i = torch.arange(n_steps, dtype=torch.float32)[None]
     t0 = tmin + step * i
@@ -198,8 +200,23 @@ def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume=None, ma
     mid = (t0 + t1) * 0.5
     p = o[:, None] + d[:, None] * mid[..., None]
     alive = (step > 0) & (tmax > tmin) & (t0 < tmax) & ~((aabb[0] > p) | (p > aabb[1])).any(-1)
-    if volume is not None:
+    if volume is not None and cells:               # occupancy grid [rx,ry,rz]: the cell that holds the mid-point
+        mb = aabb if mask_aabb is None else mask_aabb
+        res = torch.tensor(volume.shape[-3:], dtype=torch.float32)
+        u = (p - mb[0]) * (1.0 / (mb[1] - mb[0]) * 2) * 0.5
+        ijk = torch.minimum(torch.floor(u * res).long().clamp(min=0), (res - 1).long())
+        alive = alive & (volume.reshape(*volume.shape[-3:])[ijk[..., 0], ijk[..., 1], ijk[..., 2]] > 0)
+    elif volume is not None:
         a = alpha_mask_sample(volume, aabb if mask_aabb is None else mask_aabb, p.reshape(-1, 3)).reshape(rn, n_steps)
         alive = alive & (a > 0)
     ridx = torch.arange(rn)[:, None].expand(rn, n_steps)
     return t0[alive], t1[alive], ridx[alive]
+
+
+def occ_grid_update(occs, binaries_shape, idx, occ, occ_thre=1e-2, ema_decay=0.95):
+    """One OccGridEstimator._update given the evaluated cells `idx` and their opacities `occ` (nerfacc's published rule; nerfacc
+    itself is absent: PARITY UNPINNED): occs[idx] = max(occs[idx] * ema_decay, occ); binaries = occs > min(mean(occs), occ_thre)."""
+    occs = occs.clone()
+    occs[idx] = torch.maximum(occs[idx] * ema_decay, occ)
+    thre = torch.clamp(occs[occs >= 0].mean(), max=occ_thre)
+    return occs, (occs > thre).view(binaries_shape)

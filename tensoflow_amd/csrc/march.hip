@@ -18,7 +18,17 @@ struct MaskGeom {
   const unsigned char* vol;   // [D,H,W], W <- x
   int D, H, W;
   float lo[3], inv[3];        // normalize_coord: (x - lo) * inv - 1, inv = 1/size*2
+  int cells;                  // 1: `vol` is an occupancy grid [rx = D, ry = H, rz = W] looked up by the CELL that holds the point
 };
+
+// nerfacc-style occupancy grid (OccGridEstimator.binaries, flattened (x * ry + y) * rz + z): the cell containing the point
+__device__ __forceinline__ bool cell_alive(const MaskGeom& M, float px, float py, float pz) {
+  const float ux = (px - M.lo[0]) * M.inv[0] * 0.5f, uy = (py - M.lo[1]) * M.inv[1] * 0.5f, uz = (pz - M.lo[2]) * M.inv[2] * 0.5f;
+  const int ix = min(max((int)floorf(ux * (float)M.D), 0), M.D - 1);
+  const int iy = min(max((int)floorf(uy * (float)M.H), 0), M.H - 1);
+  const int iz = min(max((int)floorf(uz * (float)M.W), 0), M.W - 1);
+  return M.vol[((long long)ix * M.H + iy) * M.W + iz] != 0;
+}
 
 __device__ __forceinline__ bool axis_corners(float g, int n, int& i0, float& w0, float& w1) {
   // grid_sample align_corners=True unnormalisation: ((g + 1) / 2) * (n - 1)
@@ -60,6 +70,7 @@ template <int WRITE>
 __global__ void __launch_bounds__(256) march_uniform_kernel(const float* __restrict__ o, const float* __restrict__ d,
                                                             const float* __restrict__ near, const float* __restrict__ far,
                                                             long long rn, int n_steps, float step_size, MarchBox B, MaskGeom M,
+                                                            const float* __restrict__ t_jitter,
                                                             const long long* __restrict__ offsets, long long* __restrict__ counts,
                                                             float* __restrict__ t0_out, float* __restrict__ t1_out,
                                                             long long* __restrict__ ridx_out) {
@@ -78,6 +89,7 @@ __global__ void __launch_bounds__(256) march_uniform_kernel(const float* __restr
   float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
   tmin = fminf(fmaxf(tmin, nr), fr);
   tmax = fminf(fmaxf(tmax, nr), fr);
+  if (t_jitter) tmin += t_jitter[ray];            // stratified start (OccGridEstimator.sampling(stratified=True): + U[0,1) * step)
   const float step = step_size > 0.f ? step_size : (tmax - tmin) / (float)n_steps;
   long long base_out = WRITE ? offsets[ray] : 0;
   long long cnt = 0;
@@ -91,7 +103,7 @@ __global__ void __launch_bounds__(256) march_uniform_kernel(const float* __restr
         const float mid = (t0 + t1) * 0.5f;
         const float px = ox + dx * mid, py = oy + dy * mid, pz = oz + dz * mid;
         alive = !(B.lo[0] > px || px > B.hi[0] || B.lo[1] > py || py > B.hi[1] || B.lo[2] > pz || pz > B.hi[2]);
-        if (alive && M.vol) alive = mask_alive(M, px, py, pz);
+        if (alive && M.vol) alive = M.cells ? cell_alive(M, px, py, pz) : mask_alive(M, px, py, pz);
       }
       const unsigned long long m = __ballot(alive);
       if (WRITE && alive) {
@@ -106,7 +118,7 @@ __global__ void __launch_bounds__(256) march_uniform_kernel(const float* __restr
 }
 
 static int mask_geom(const unsigned char* vol, int D, int H, int W, const float* aabb_host, MaskGeom* M) {
-  M->vol = vol; M->D = D; M->H = H; M->W = W;
+  M->vol = vol; M->D = D; M->H = H; M->W = W; M->cells = 0;
   for (int k = 0; k < 3; ++k) {
     M->lo[k] = aabb_host[k];
     const float size = aabb_host[3 + k] - aabb_host[k];
@@ -129,8 +141,10 @@ extern "C" int tf_alpha_mask_sample(const uint8_t* volume, int32_t D, int32_t H,
 
 extern "C" int tf_march_uniform(const float* rays_o, const float* rays_d, const float* near, const float* far, int64_t rn,
                                 int32_t n_steps, float step_size, const float* aabb_host, const uint8_t* volume, int32_t D,
-                                int32_t H, int32_t W, const float* mask_aabb_host, const int64_t* offsets, int64_t* counts,
-                                float* t_starts, float* t_ends, int64_t* ray_indices, tf_stream_t stream) {
+                                int32_t H, int32_t W, const float* mask_aabb_host, int32_t occupancy_mode, const float* t_jitter,
+                                const int64_t* offsets, int64_t* counts, float* t_starts, float* t_ends, int64_t* ray_indices,
+                                tf_stream_t stream) {
+  TF_REQUIRE(occupancy_mode == 0 || occupancy_mode == 1, TF_EINVAL, "tf_march_uniform: occupancy_mode %d", occupancy_mode);
   TF_REQUIRE(rn >= 0 && n_steps > 0, TF_ESHAPE, "tf_march_uniform: rn=%lld n_steps=%d", (long long)rn, n_steps);
   if (rn == 0) return TF_OK;
   TF_REQUIRE(rays_o && rays_d && near && far && aabb_host, TF_EINVAL, "tf_march_uniform: null pointer");
@@ -138,15 +152,16 @@ extern "C" int tf_march_uniform(const float* rays_o, const float* rays_d, const 
   MarchBox B;
   for (int k = 0; k < 3; ++k) { B.lo[k] = aabb_host[k]; B.hi[k] = aabb_host[3 + k]; }
   MaskGeom M;
-  if (volume) mask_geom(volume, D, H, W, mask_aabb_host, &M); else { M.vol = nullptr; M.D = M.H = M.W = 2; for (int k = 0; k < 3; ++k) { M.lo[k] = 0; M.inv[k] = 1; } }
+  if (volume) mask_geom(volume, D, H, W, mask_aabb_host, &M); else { M.vol = nullptr; M.D = M.H = M.W = 2; M.cells = 0; for (int k = 0; k < 3; ++k) { M.lo[k] = 0; M.inv[k] = 1; } }
+  if (volume) M.cells = occupancy_mode;
   const unsigned blocks = tf_blocks(rn, 4);
   if (!offsets) {
     TF_REQUIRE(counts, TF_EINVAL, "tf_march_uniform: count pass needs `counts`");
-    march_uniform_kernel<0><<<blocks, 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, near, far, rn, n_steps, step_size, B, M, nullptr,
+    march_uniform_kernel<0><<<blocks, 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, near, far, rn, n_steps, step_size, B, M, t_jitter, nullptr,
                                                                      (long long*)counts, nullptr, nullptr, nullptr);
   } else {
     TF_REQUIRE(t_starts && t_ends && ray_indices, TF_EINVAL, "tf_march_uniform: write pass needs the three outputs");
-    march_uniform_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, near, far, rn, n_steps, step_size, B, M,
+    march_uniform_kernel<1><<<blocks, 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, near, far, rn, n_steps, step_size, B, M, t_jitter,
                                                                      (const long long*)offsets, nullptr, t_starts, t_ends,
                                                                      (long long*)ray_indices);
   }

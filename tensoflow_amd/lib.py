@@ -82,7 +82,7 @@ SIGNATURES = {
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
     "tf_cube_lookup_bwd_dirs": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f, c_f]),
     "tf_alpha_mask_sample": (C.c_int, [c_f, i32, i32, i32, C.c_void_p, c_f, i64, c_f, c_f]),
-    "tf_march_uniform": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, f32, C.c_void_p, c_f, i32, i32, i32, C.c_void_p, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "tf_march_uniform": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, f32, C.c_void_p, c_f, i32, i32, i32, C.c_void_p, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_cubemap_mip_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
     "tf_cubemap_diffuse_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
     "tf_cubemap_diffuse_bwd": (C.c_int, [c_f, i32, c_f, c_f]),

@@ -173,6 +173,83 @@ def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, 
     return AlphaMask(field.aabb, vol), new_aabb
 
 
+class OccGrid:
+    """Occupancy grid of the `use_occ_grid` shape configs (configs/shape/syn/compressor_occ.yaml:21): the role nerfacc.OccGridEstimator
+    plays in the reference (shapeRenderer.py:213-216 construction, :950-959 sampling, :1286-1290 update_every_n_steps, :343-353
+    checkpoint).  nerfacc is third-party and absent (parity unpinned); this class follows its published semantics
+    -- one level, `occs` = EMA of the evaluated opacity per cell, `binaries` = occs > min(mean(occs), occ_thre) -- with the state on
+    the device and the sampling done by tf_march_uniform (cell lookup, stratified start), pinned by the build's own oracle
+    (oracle/march.py:occ_grid_update, march_uniform(cells=True))."""
+
+    def __init__(self, aabb, resolution=128, device="cuda"):
+        res = [int(resolution)] * 3 if isinstance(resolution, int) else [int(r) for r in resolution]
+        self.device = device
+        self.resolution = torch.tensor(res, dtype=torch.int32)
+        self.aabbs = torch.as_tensor(aabb, dtype=torch.float32).reshape(1, 6).to(device)
+        self.n_cells = res[0] * res[1] * res[2]
+        self.occs = torch.zeros(self.n_cells, device=device)
+        self.binaries = torch.zeros(1, *res, dtype=torch.bool, device=device)
+        g = torch.stack(torch.meshgrid(*[torch.arange(r, device=device) for r in res], indexing="ij"), -1).reshape(-1, 3)
+        self.grid_coords = g
+        self.grid_indices = torch.arange(self.n_cells, device=device)
+        self.training = True
+        self.gen = None                      # torch.Generator on the device (tests seed it); None = global RNG
+
+    # ---- nerfacc.OccGridEstimator._update / update_every_n_steps
+    def _cells_to_update(self, step, warmup_steps):
+        if step < warmup_steps:
+            return self.grid_indices
+        n = self.n_cells // 4
+        uniform = torch.randint(self.n_cells, (n,), device=self.device, generator=self.gen)
+        occupied = torch.nonzero(self.binaries.reshape(-1))[:, 0]
+        if occupied.numel() > n:
+            occupied = occupied[torch.randint(occupied.numel(), (n,), device=self.device, generator=self.gen)]
+        return torch.cat([uniform, occupied])
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step, occ_eval_fn, occ_thre=1e-2, ema_decay=0.95, warmup_steps=256, n=16):
+        if not self.training or step % n != 0:
+            return False
+        idx = self._cells_to_update(step, warmup_steps)
+        coords = self.grid_coords[idx].float()
+        u = (coords + torch.rand(coords.shape, device=self.device, generator=self.gen)) / self.resolution.to(self.device).float()
+        lo, hi = self.aabbs[0, :3], self.aabbs[0, 3:]
+        x = lo + u * (hi - lo)
+        occ = occ_eval_fn(x).reshape(-1)
+        self.occs[idx] = torch.maximum(self.occs[idx] * ema_decay, occ)
+        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)
+        return True
+
+    # ---- nerfacc.OccGridEstimator.sampling -> (ray_indices, t_starts, t_ends)
+    @torch.no_grad()
+    def sampling(self, rays_o, rays_d, near_plane=0.0, far_plane=1e10, render_step_size=1e-3, stratified=False, max_steps=1024):
+        rn = rays_o.shape[0]
+        near = torch.full((rn,), float(near_plane), device=rays_o.device)
+        far = torch.full((rn,), float(far_plane), device=rays_o.device)
+        jit = torch.rand(rn, device=rays_o.device, generator=self.gen) * render_step_size if stratified else None
+        aabb = self.aabbs[0].reshape(2, 3).cpu()
+        t0, t1, ridx = ops.march_uniform(rays_o, rays_d, near, far, aabb, max_steps, render_step_size,
+                                         self.binaries[0].to(torch.uint8).contiguous(), aabb, cells=True, t_jitter=jit)
+        return ridx, t0, t1
+
+    # ---- checkpoint: the buffers of nerfacc.OccGridEstimator, by name
+    def state_dict(self):
+        return {"resolution": self.resolution.cpu(), "aabbs": self.aabbs.cpu(), "occs": self.occs.cpu(), "binaries": self.binaries.cpu(),
+                "grid_coords": self.grid_coords.cpu(), "grid_indices": self.grid_indices.cpu()}
+
+    def load_state_dict(self, sd):
+        if tuple(int(v) for v in sd["resolution"]) != tuple(int(v) for v in self.resolution):
+            raise RuntimeError(f"OccGrid: checkpoint resolution {sd['resolution'].tolist()} != {self.resolution.tolist()}")
+        self.aabbs = sd["aabbs"].to(self.device).float().reshape(1, 6)
+        self.occs = sd["occs"].to(self.device).float().reshape(-1)
+        self.binaries = sd["binaries"].to(self.device).bool().reshape(self.binaries.shape)
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+
 @torch.no_grad()
 def march_uniform(field: SdfField, o, d, near, far, n_steps=256, step_size=0.0, mask: AlphaMask = None):
     """Fixed-step sampler with occupancy culling and per-wavefront compaction (tf_march_uniform) -> packed samples."""

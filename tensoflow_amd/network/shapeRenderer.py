@@ -67,15 +67,15 @@ class ShapeRenderer(nn.Module):
         if self.cfg["predict_BG"]:
             raise NotImplementedError("predict_BG (NeRF++ background) raises in the reference's render_core as well (:1109); "
                                       "set predict_BG=False as configs/shape/* do")
-        if self.cfg["use_occ_grid"]:
-            raise NotImplementedError("nerfacc.OccGridEstimator is third-party and unpinned; use march.march_uniform for fixed-step marching")
         self.device = self.cfg["device"]
         aabb = self.cfg["aabb"]
         self.aabb = torch.tensor(aabb.cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb, dtype=torch.float32, device=self.device)
         self.center = self.aabb.mean(0).float().view(1, 1, 3)
         self.radius = (self.aabb[1] - self.center).mean().float()
         self.alphaMask = None
-        self.occ_grid = None
+        # use_occ_grid (configs/shape/syn/compressor_occ.yaml:21; shapeRenderer.py:213-216): the build's own occupancy grid in the
+        # role of nerfacc.OccGridEstimator -- EMA occupancy state on the device, sampling by tf_march_uniform (march.OccGrid)
+        self.occ_grid = march.OccGrid(self.aabb.reshape(-1).cpu(), self.cfg["occ_grid_reso"], self.device) if self.cfg["use_occ_grid"] else None
         self.step_ratio = self.cfg["step_ratio"]
         self.alphaMask_thres = self.cfg["alphaMask_thres"]
         self.marched_weights_thres = self.cfg["marched_weights_thres"]
@@ -119,7 +119,16 @@ class ShapeRenderer(nn.Module):
             vol = self.alphaMask.alpha_volume.bool().cpu().numpy()
             ckpt.update({"alphaMask.shape": vol.shape, "alphaMask.mask": np.packbits(vol.reshape(-1)),
                          "alphaMask.aabb": self.alphaMask.aabb.cpu()})
+        if self.occ_grid is not None:
+            ckpt["occ_grid_state_dict"] = self.occ_grid.state_dict()
         return ckpt
+
+    def update_occ_grid(self, step):
+        """shapeRenderer.py:1286-1290: every 100 steps the occupancy grid takes the EMA of compute_alpha at jittered cell positions
+        (all cells during the first 10 000 steps)."""
+        if self.occ_grid is not None:
+            return self.occ_grid.update_every_n_steps(step=step, occ_eval_fn=lambda x: self.compute_alpha(x), n=100, warmup_steps=10000)
+        return False
 
     def load_ckpt(self, ckpt):
         """shapeRenderer.py:355-362 (strict: every key of a reference checkpoint has a home, incl. the Gaussian-blur buffers)."""
@@ -127,6 +136,8 @@ class ShapeRenderer(nn.Module):
             length = int(np.prod(ckpt["alphaMask.shape"]))
             vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
             self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"], vol.float())
+        if self.occ_grid is not None and "occ_grid_state_dict" in ckpt:
+            self.occ_grid.load_state_dict(ckpt["occ_grid_state_dict"])
         self.load_state_dict(ckpt["network_state_dict"])
 
     def upsample_sdf_grid(self, res_target):
@@ -226,7 +237,11 @@ class ShapeRenderer(nn.Module):
         """shapeRenderer.py:934-963."""
         perturb = self.cfg["perturb"] if perturb_overwrite < 0 else perturb_overwrite
         o, d, dirs, radiis, cos = ray_batch["rays_o"], ray_batch["rays_d"], ray_batch["dirs"], ray_batch["radiis"], ray_batch["rays_cos"]
-        t0, t1, ridx = self.sample_ray(o, dirs, near, far, perturb, radiis=radiis, rays_cos=cos)
+        if self.occ_grid is not None:                     # shapeRenderer.py:950-959
+            ridx, t0, t1 = self.occ_grid.sampling(o, dirs, near_plane=float(near.min()), far_plane=float(far.max()),
+                                                  render_step_size=float(self.stepSize), stratified=is_train)
+        else:
+            t0, t1, ridx = self.sample_ray(o, dirs, near, far, perturb, radiis=radiis, rays_cos=cos)
         return self.render_core(o, d, dirs, radiis, cos, t0, t1, ridx, human_poses, cos_anneal_ratio=cos_anneal_ratio, step=step,
                                 is_train=is_train)
 
@@ -468,6 +483,7 @@ class ShapeRenderer(nn.Module):
                                       "synthetic scene, or call render() with a ray batch / nvs(pose, K, h, w)")
         step = data["step"]
         if "eval" not in data:
+            self.update_occ_grid(step)
             self.color_network.envlight.build_mips()
             return self.train_step(step)
         return self.test_step(data["index"], step=step)

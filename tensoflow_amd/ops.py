@@ -417,8 +417,10 @@ def alpha_mask_sample(volume_u8, aabb, pts):
     return out.bool()
 
 
-def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume_u8=None, mask_aabb=None):
-    """-> t_starts [N], t_ends [N], ray_indices [N] int64 packed by (ray, t).  One host read of N between the two passes."""
+def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume_u8=None, mask_aabb=None, cells=False, t_jitter=None):
+    """-> t_starts [N], t_ends [N], ray_indices [N] int64 packed by (ray, t).  One host read of N between the two passes.
+    cells: volume_u8 is an occupancy grid [rx,ry,rz] looked up per cell (OccGridEstimator.binaries) instead of an AlphaGridMask
+    volume; t_jitter [rn]: per-ray start offset (stratified sampling)."""
     lib = L.load()
     o, d, near, far = _f(o), _f(d), _f(near.reshape(-1)), _f(far.reshape(-1))
     rn = o.shape[0]
@@ -429,8 +431,10 @@ def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume_u8=None,
     vol = _p(None if volume_u8 is None else volume_u8, torch.uint8)
     counts = torch.empty(rn, dtype=torch.int64, device=dev)
     null = C.c_void_p(0)
+    mode = 1 if cells else 0
+    tj = _p(_f(t_jitter.reshape(-1))) if t_jitter is not None else None
     L.check(lib.tf_march_uniform(_p(o), _p(d), _p(near), _p(far), rn, n_steps, float(step_size), C.byref(box), vol, D, H, W,
-                                 C.byref(mbox), null, _p(counts, torch.int64), null, null, null, _stream()), "tf_march_uniform")
+                                 C.byref(mbox), mode, tj, null, _p(counts, torch.int64), null, null, null, _stream()), "tf_march_uniform")
     incl = torch.cumsum(counts, 0)
     offsets = (incl - counts).contiguous()
     n = int(incl[-1]) if rn > 0 else 0
@@ -439,7 +443,7 @@ def march_uniform(o, d, near, far, aabb, n_steps, step_size=0.0, volume_u8=None,
     ridx = torch.empty(n, dtype=torch.int64, device=dev)
     if n > 0:
         L.check(lib.tf_march_uniform(_p(o), _p(d), _p(near), _p(far), rn, n_steps, float(step_size), C.byref(box), vol, D, H, W,
-                                     C.byref(mbox), _p(offsets, torch.int64), null, _p(t0), _p(t1), _p(ridx, torch.int64),
+                                     C.byref(mbox), mode, tj, _p(offsets, torch.int64), null, _p(t0), _p(t1), _p(ridx, torch.int64),
                                      _stream()), "tf_march_uniform")
     return t0, t1, ridx
 

@@ -255,3 +255,66 @@ def test_material_renderer(golden, dev, tmp_path):
     img = m.nvs(pose, K, 32, 32, chunk=300)
     assert img["color"].shape == (32, 32, 3) and np.isfinite(img["color"]).all()
     assert (img["color"][0, 0] == 1).all() and 0.02 < float((img["normal"][..., 2] != 1).mean()) < 0.98
+
+
+def test_occ_grid_marcher_and_state(golden, dev):
+    """use_occ_grid (configs/shape/syn/compressor_occ.yaml:21): cell-lookup marching with a stratified start is bit-exact against
+    the oracle's restatement; one EMA update of the occupancy state equals the oracle's rule on the same cells and opacities; a
+    ShapeRenderer built with use_occ_grid=True trains 20 steps through the grid (updates every 100 steps from step 0 on) and its
+    checkpoint carries `occ_grid_state_dict` through a round trip."""
+    from oracle import march as om
+    from tensoflow_amd import march, ops
+    from tensoflow_amd.synth import pinhole_rays
+    g = golden("march_r32")
+    # ---- marcher: cell lookup + per-ray start jitter
+    o, d, _, _ = [torch.from_numpy(a) for a in pinhole_rays(2000, seed=19)]
+    gen = torch.Generator().manual_seed(4)
+    vol = (torch.rand(20, 24, 28, generator=gen) > 0.6)
+    near, far = torch.full((2000,), 0.05), torch.full((2000,), 6.0)
+    jit = torch.rand(2000, generator=gen) * 0.013
+    rt0, rt1, rr = om.march_uniform(o, d, near, far, AABB, 600, 0.013, vol.to(torch.uint8), AABB, cells=True, t_jitter=jit)
+    t0, t1, ridx = ops.march_uniform(o.to(dev), d.to(dev), near.to(dev), far.to(dev), AABB, 600, 0.013, vol.to(torch.uint8).to(dev), AABB,
+                                     cells=True, t_jitter=jit.to(dev))
+    assert torch.equal(ridx.cpu(), rr) and torch.equal(t0.cpu(), rt0) and torch.equal(t1.cpu(), rt1) and rr.numel() > 20000
+    # ---- renderer with the grid
+    r = _shape_renderer(g, dev, use_occ_grid=True, occ_grid_reso=32)
+    og = r.occ_grid
+    assert isinstance(og, march.OccGrid) and og.binaries.shape == (1, 32, 32, 32) and not bool(og.binaries.any())
+    og.gen = torch.Generator(device=dev).manual_seed(7)
+    state = og.gen.get_state()
+    assert r.update_occ_grid(0) is True and r.update_occ_grid(1) is False
+    # the same update by the oracle's rule: all cells (warm-up), the same jitter, the same opacity function
+    g2 = torch.Generator(device=dev)
+    g2.set_state(state)
+    u = (og.grid_coords.float() + torch.rand(og.grid_coords.shape, device=dev, generator=g2)) / 32.0
+    x = r.aabb[0] + u * (r.aabb[1] - r.aabb[0])
+    occ = r.compute_alpha(x).reshape(-1)
+    occs_ref, bin_ref = om.occ_grid_update(torch.zeros(32 ** 3), (1, 32, 32, 32), torch.arange(32 ** 3), occ.cpu())
+    assert torch.equal(og.occs.cpu(), occs_ref) and torch.equal(og.binaries.cpu(), bin_ref)
+    assert 0.005 < float(og.binaries.float().mean()) < 0.6
+    # ---- 20 training steps through render() with the grid sampler
+    r.train()
+    opt = torch.optim.Adam(r.get_train_opt_params(1e-3, 1e-3, 1e-3), betas=(0.9, 0.99))
+    c = lambda k: g[k].to(dev)
+    batch = {"rays_o": c("rays_o"), "rays_d": c("dirs"), "dirs": c("dirs"), "radiis": c("radiis"), "rays_cos": c("rays_cos")}
+    target = torch.rand(g["rays_o"].shape[0], 3, device=dev)
+    losses = []
+    for step in range(20):
+        r.update_occ_grid(step)
+        opt.zero_grad(set_to_none=True)
+        out = r.render(batch, c("near"), c("far"), None, cos_anneal_ratio=0.5, is_train=True, step=step)
+        loss = ((out["ray_rgb"] - target) ** 2).mean() + 0.1 * out["gradient_error"].mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    ck = r.ckpt_to_save()
+    assert set(ck["occ_grid_state_dict"]) == {"resolution", "aabbs", "occs", "binaries", "grid_coords", "grid_indices"}
+    r2 = _shape_renderer(g, dev, use_occ_grid=True, occ_grid_reso=32)
+    r2.load_ckpt(ck)
+    assert torch.equal(r2.occ_grid.binaries, og.binaries) and torch.equal(r2.occ_grid.occs, og.occs)
+    with torch.no_grad():
+        r.eval(); r2.eval()
+        a = r.render(batch, c("near"), c("far"), None, perturb_overwrite=0, cos_anneal_ratio=1.0, is_train=False, step=100)
+        b = r2.render(batch, c("near"), c("far"), None, perturb_overwrite=0, cos_anneal_ratio=1.0, is_train=False, step=100)
+    assert torch.equal(a["ray_rgb"], b["ray_rgb"])

@@ -63,3 +63,25 @@ def test_refine_hits(golden):
     assert torch.equal(hit, g["hit"].bool()) and 0.05 < hit.float().mean() < 0.95
     assert rel_err(depth, g["depth"]) < 1e-5 and rel_err(inters, g["inters"]) < 1e-5
     assert rel_err(normals, g["normals"]) < 1e-4
+
+
+def test_oracle_occupancy_cell_marcher_and_update():
+    """The oracle's stand-in for nerfacc's occupancy grid (third-party, absent: parity unpinned): cell lookup, stratified start, EMA
+    update rule -- properties the build's kernels are then held to bit for bit (tests/test_gpu_renderers.py)."""
+    from oracle import march as om
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    vol = torch.zeros(4, 4, 4, dtype=torch.uint8)
+    vol[3, 0, 2] = 1                                   # cell x in [0.5,1], y in [-1,-0.5], z in [0,0.5]
+    o = torch.tensor([[-2.0, -0.75, 0.25]])
+    d = torch.tensor([[1.0, 0.0, 0.0]])
+    t0, t1, ridx = om.march_uniform(o, d, torch.zeros(1), torch.full((1,), 10.0), aabb, 400, 0.01, vol, aabb, cells=True)
+    mid = (t0 + t1) * 0.5 - 2.0
+    assert ridx.numel() in (49, 50, 51) and float(mid.min()) >= 0.5 - 1e-6 and float(mid.max()) <= 1.0 + 1e-6
+    tj0, _, _ = om.march_uniform(o, d, torch.zeros(1), torch.full((1,), 10.0), aabb, 400, 0.01, vol, aabb, cells=True,
+                                 t_jitter=torch.tensor([0.004]))
+    assert abs(float(tj0[0] - t0[0]) - 0.004) < 1e-6 or abs(float(tj0[0] - t0[0]) + 0.006) < 1e-6     # the lattice shifts by the jitter
+    occs = torch.zeros(8)
+    occs, b = om.occ_grid_update(occs, (1, 2, 2, 2), torch.tensor([1, 5]), torch.tensor([0.5, 0.001]))
+    assert occs.tolist() == [0, 0.5, 0, 0, 0, 0.0010000000474974513, 0, 0] and b.reshape(-1).tolist() == [False, True] + [False] * 6
+    occs, b = om.occ_grid_update(occs, (1, 2, 2, 2), torch.tensor([1]), torch.tensor([0.0]))
+    assert abs(float(occs[1]) - 0.475) < 1e-7           # decays by 0.95 when the new evaluation is lower
