@@ -42,8 +42,10 @@ def test_shape_renderer_refuses_unbuilt_modes():
         ShapeRenderer(SHAPE_CFG, training=True)                    # dataset side
     with pytest.raises(NotImplementedError):
         ShapeRenderer({**SHAPE_CFG, "predict_BG": True}, training=False)
-    with pytest.raises(NotImplementedError):
-        ShapeRenderer({**SHAPE_CFG, "use_occ_grid": True}, training=False)
+    # use_occ_grid builds the on-device occupancy grid (march.OccGrid) and its state rides in the checkpoint (shapeRenderer.py:343-353)
+    r = ShapeRenderer({**SHAPE_CFG, "use_occ_grid": True, "occ_grid_reso": 16}, training=False)
+    assert r.occ_grid is not None and tuple(r.occ_grid.binaries.shape) == (1, 16, 16, 16)
+    assert "occ_grid_state_dict" in r.ckpt_to_save()
 
 
 def test_shape_renderer_ckpt_layout_and_upsample():
