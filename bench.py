@@ -270,6 +270,7 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
         for p in fl.parameters():
             p.requires_grad = False
     m.train()
+    m.use_flow_diffuse_copy = m.use_flow_specular_copy = True      # as after step 1000: the flow copies do the sampling
     pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=99)]
     w = torch.rand(pn, 3, device=device)
 
@@ -517,7 +518,8 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
     torch.manual_seed(6033)                                                  # identical replicas
     m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, unit)
     tr = MaterialTrainer(m, {"total_step": 100000}, world=world)
-    tr.step_count = 600                                                      # past nis_loss_iter: every trainable tensor gets a gradient
+    tr.step_count = 1200                                                     # past nis_start_iter: flow copies sample, NIS losses on
+    m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
     pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=99 + 1000 * rank)]
     target = torch.rand(pn, 3, device=device)
     tr.train_step(pts, view, nrm, target)

@@ -1,4 +1,6 @@
 """TensoSDF and MCShadingNetwork (reference: network/fields.py:20-317, :618-1595), forward direction, on the HIP kernels."""
+import math
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -197,6 +199,7 @@ class MCShadingNetwork(nn.Module):
         self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
         self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
         self._shader, self._shader_version = None, None
+        self.use_flow_diffuse_copy = self.use_flow_specular_copy = False      # fields.py:752-760: set by update_step at nis_start_iter
 
     def _param_version(self):
         """Every in-place update of a parameter (optimizer.step, load_state_dict, copy_) bumps its _version counter."""
@@ -333,10 +336,141 @@ class MCShadingNetwork(nn.Module):
         outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
         return colors, outputs
 
+    # ---------------------------------------------------------------- training before the flow copies take over the sampling
+    def forward_train_fixed(self, pts, view_dirs, normals, step=None, is_train=True):
+        """shade_mixed with BOTH fixed samplers (fields.py:1075-1335 with the `else` branches: the material stage's first
+        nis_start_iter = 1000 steps, update_step :1050-1065): 512 cosine directions for the diffuse lobe and the roughness-warped
+        GGX set for the specular lobe (sample_diffuse_directions / sample_specular_directions, :824-903).  Unlike the flow pass, the
+        specular DIRECTIONS depend on the predicted roughness, so the colour gradient reaches the material grids through the
+        directions as well: through the BRDF terms, through the environment lookup (dr.texture is differentiable in its
+        coordinates: tf_cube_lookup_bwd_dirs) and through the inner-light net's reflected-direction encoding.  The per-direction
+        algebra is composed from differentiable device ops; visibility (tf_bvh_trace), the cube map, the VM gather and every MLP
+        product (tf_linear_fwd / tf_linear_bwd) are the HIP kernels.  From nis_loss_iter on, the NIS losses fit the trainable
+        flows on these fixed samples (:1253-1330)."""
+        from ..encodings import ide5, posenc
+        EPS, PI = 1e-6, math.pi
+        dev = pts.device
+        pn = pts.shape[0]
+        cfg = self.cfg
+        view_dirs, normals = F.normalize(view_dirs, dim=-1), F.normalize(normals, dim=-1)
+        metallic, roughness, albedo = self.predict_materials(pts)
+        sat = lambda a, b: torch.clamp((a * b).sum(-1, keepdim=True), 0.0, 1.0)
+        if not hasattr(self, "_bvh"):
+            self._bvh = ops.Bvh(self.ray_tracer[0], self.ray_tracer[1], dev)
+            self._fixed = fibonacci_samples(cfg["diffuse_sample_num"]).to(dev)
+        if not hasattr(self, "_fixed_s"):
+            self._fixed_s = fibonacci_samples(cfg["specular_sample_num"]).to(dev)
+        # tangent frame (get_orthogonal_directions, :812-822)
+        z = normals
+        x0 = torch.stack([z[:, 1], -z[:, 0], torch.zeros_like(z[:, 0])], -1)
+        x1 = torch.stack([-z[:, 2], torch.zeros_like(z[:, 0]), z[:, 0]], -1)
+        x = F.normalize(torch.where((x0.norm(dim=-1) > x1.norm(dim=-1))[:, None], x0, x1), dim=-1)
+        y = torch.cross(z, x, dim=-1)
+        X, Y, Z, V = x[:, None], y[:, None], z[:, None], view_dirs[:, None]
+        jitter = is_train and self.training and cfg.get("random_azimuth", True)
+
+        def half_angles(H):
+            cz = (Z * H).sum(-1, keepdim=True).clamp(-1 + EPS, 1 - EPS)
+            phi = (torch.atan2((Y * H).sum(-1, keepdim=True), (X * H).sum(-1, keepdim=True)) + 2 * PI) % (2 * PI)
+            return phi, torch.acos(cz)
+
+        def lights_of(origins, dirs):
+            """get_lights (:951-975), differentiable wrt the map, the inner-light net and `dirs`."""
+            with torch.no_grad():
+                inters, nrm, depth, hit = self._bvh.trace(origins.contiguous(), dirs.detach().contiguous(), 1e-5, 2 * self.unit_size)
+            lights = torch.zeros_like(dirs)
+            miss = ~hit
+            if bool(miss.any()):
+                lights = lights.index_put((miss,), self.outer_light.direct_light(dirs[miss]))
+            if bool(hit.any()):
+                vd = F.normalize(-dirs[hit], dim=-1)
+                nh = F.normalize(nrm[hit], dim=-1)
+                refl = (vd * nh).sum(-1, keepdim=True) * nh * 2 - vd
+                enc = torch.cat([posenc(inters[hit], 8), ide5(refl, torch.zeros(refl.shape[0], 1, device=dev))], -1)
+                lights = lights.index_put((hit,), torch.exp(torch.clamp(_mlp(self.inner_light, enc), max=cfg["inner_light_exp_max"])))
+            return lights * (depth > 1e-5).float()[:, None], hit
+
+        # ---- diffuse lobe: fixed cosine set (no parameter dependence in the directions)
+        az, el = self._fixed[:, 0][None, :, None] * (2 * PI), self._fixed[:, 1][None, :, None]
+        if jitter:
+            az = (az + torch.rand(pn, 1, 1, device=dev) * (2 * PI)) % (2 * PI)
+        el_sqrt = torch.sqrt(el + 1e-7)
+        d_dirs = (el_sqrt * torch.cos(az)) * X + (el_sqrt * torch.sin(az)) * Y + torch.sqrt(1 - el + 1e-7) * Z
+        d_pdf = sat(d_dirs, Z) / PI * (torch.cos((1 - el) * PI / 2) * PI / 2)
+        nd = d_dirs.shape[1]
+        d_lights, _ = lights_of(pts[:, None].expand(pn, nd, 3).reshape(-1, 3), d_dirs.reshape(-1, 3))
+        d_lights = d_lights.view(pn, nd, 3)
+        kd = 1 - metallic[:, None]
+        d_w = albedo[:, None] * kd * (sat(d_dirs, Z) / PI)
+        diffuse = torch.mean(d_w * d_lights / d_pdf.clamp_min(EPS), 1)
+        # ---- specular lobe: GGX half vectors warped by the predicted (squared) roughness
+        azs, els = self._fixed_s[:, 0][None, :, None], self._fixed_s[:, 1][None, :, None]
+        a = roughness[:, None]
+        cos_t = ((1.0 - els) / (1.0 + (a ** 2 - 1.0) * els).clamp_min(EPS)).clamp_min(EPS).sqrt()
+        sin_t = (1 - cos_t ** 2).clamp_min(EPS).sqrt()
+        phi = azs * (2 * PI)
+        if jitter:
+            phi = (phi + torch.rand(pn, 1, 1, device=dev) * (2 * PI)) % (2 * PI)
+        Hs = (torch.cos(phi) * sin_t) * X + (torch.sin(phi) * sin_t) * Y + cos_t * Z
+        VoH = sat(V, Hs)
+        s_dirs = VoH * Hs * 2 - V
+        NoH_s = cos_t.clamp_min(0.0)
+        ggx = lambda noh, r: r ** 2 / (PI * (noh ** 2 * (r ** 2 - 1.0) + 1.0) ** 2).clamp_min(EPS)
+        s_pdf = ggx(NoH_s, a) * NoH_s / (4 * VoH).clamp_min(EPS) * (torch.cos((1 - els) * PI / 2) * PI / 2)
+        angles_H = torch.cat([phi.expand(pn, -1, -1), torch.arcsin(sin_t).expand(pn, -1, -1)], -1)
+        ns = s_dirs.shape[1]
+        smask = (s_dirs * Z).sum(-1) > 0
+        rid = torch.arange(pn, device=dev)[:, None].expand(pn, ns)[smask]
+        sd_, sp_, sah = s_dirs[smask], s_pdf[smask], angles_H[smask]
+        F0 = 0.04 * (1 - metallic) + metallic * albedo
+        Hh = F.normalize(view_dirs[rid] + sd_, dim=-1)
+        HoV_s = torch.clamp((Hh * view_dirs[rid]).sum(-1, keepdim=True), 0.0, 1.0)
+        fres = F0[rid] + (1.0 - F0[rid]) * torch.clamp(1.0 - HoV_s, 0.0, 1.0) ** 5.0
+        NoV = sat(normals, view_dirs)[rid]
+        NoL = sat(normals[rid], sd_)
+        g1 = lambda c, r: c / (c * (1 - r / 2) + r / 2 + 1e-5)
+        if cfg.get("geometry_type", "schlick") != "schlick":
+            raise NotImplementedError("geometry_type='schlick' (every shipped config)")
+        geo = g1(NoV, roughness[rid]) * g1(NoL, roughness[rid])
+        dist = ggx(sat(normals[rid], Hh), roughness[rid])
+        s_lights, s_hit = lights_of(pts[rid], sd_)
+        s_w = dist * fres * geo / (4 * NoV).clamp_min(EPS)
+        specular = torch.zeros(pn, 3, device=dev).index_add(0, rid, s_w * s_lights / sp_.clamp_min(EPS)) / ns
+        colors = self._linear_to_srgb(diffuse + specular)
+        outputs = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (normals + 1) / 2, "specular_mask": smask,
+                   "diffuse_light": torch.clamp(self._linear_to_srgb(d_lights.mean(1)), 0, 1)}
+        zero = torch.zeros((), device=dev)
+        outputs["loss_nis_diffuse"] = outputs["loss_nis_specular"] = zero
+        va = ops.view_angles(normals, view_dirs)
+        if step is not None and step >= cfg.get("nis_loss_iter_diffuse", 500):
+            sdn = cfg["nis_diffuse_sample_num"]
+            Hd = F.normalize(V + d_dirs[:, :sdn], dim=-1)
+            HoV_d = torch.clamp((Hd * V).sum(-1, keepdim=True), 0.0, 1.0)
+            ph, th = half_angles(Hd)
+            xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
+            _, logq = self.flow_diffuse(pts, va, roughness.detach(), xq.detach().contiguous(), return_jacobian=True)
+            logqx = logq - (4 * PI ** 2 * HoV_d * torch.sin(th)).clamp_min(EPS).log()
+            outputs["loss_nis_diffuse"] = -((d_w * d_lights)[:, :sdn] * logqx / d_pdf.expand(pn, nd, 1)[:, :sdn].clamp_min(EPS)).mean()
+        if step is not None and step >= cfg.get("nis_loss_iter_specular", 500):
+            ph, th = sah[:, :1], sah[:, 1:2]
+            xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
+            _, logq = self.flow_specular(pts, va, roughness.detach(), xq.contiguous(), return_jacobian=True, rays_id=rid)
+            logqx = logq - (4 * PI ** 2 * HoV_s * torch.sin(th)).clamp_min(EPS).log()
+            outputs["loss_nis_specular"] = -(s_w * s_lights * logqx / sp_.clamp_min(EPS)).mean()
+        outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
+        return colors, outputs
+
     def forward(self, pts, view_dirs, normals, human_poses=None, step=None, is_train=False):
         """fields.py:1453-1473 with the flow samplers active: -> (colors [pn,3], outputs dict).
         With autograd enabled (training) the differentiable composition is used; otherwise the fused inference path."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            fd, fs = getattr(self, "use_flow_diffuse_copy", False), getattr(self, "use_flow_specular_copy", False)
+            if step is not None and not fd and not fs:
+                # fields.py:1082,1160: until the first copy refresh (nis_start_iter) both lobes draw from the fixed samplers
+                return self.forward_train_fixed(pts, view_dirs, normals, step=step, is_train=is_train)
+            if step is not None and fd != fs:
+                raise NotImplementedError("one lobe on its flow copy and the other on the fixed sampler: set nis_start_iter_diffuse == "
+                                          "nis_start_iter_specular (every shipped config does)")
             return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train)
         return self._forward_eval(pts, view_dirs, normals)
 

@@ -7,6 +7,9 @@ from .. import ops
 
 
 class _CubeLookup(torch.autograd.Function):
+    """exp(bilinear cube fetch): differentiable wrt the map (tf_cube_lookup_bwd) and -- as dr.texture is -- wrt the lookup direction
+    (tf_cube_lookup_bwd_dirs; needed while the material stage still trains on the roughness-warped GGX directions)."""
+
     @staticmethod
     def forward(ctx, base, dirs):
         ctx.save_for_backward(base, dirs)
@@ -15,6 +18,9 @@ class _CubeLookup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         base, dirs = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            g_base, g_dirs = ops.cube_lookup_bwd_dirs(base, dirs, g.contiguous(), apply_exp=True, want_base=ctx.needs_input_grad[0])
+            return g_base, g_dirs.view_as(dirs)
         return ops.cube_lookup_bwd(base, dirs, g.contiguous(), apply_exp=True), None
 
 

@@ -459,6 +459,56 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
+def gen_shading_grad_fixed():
+    """Training direction BEFORE the flow copies take over (use_flow_*_copy False: the first nis_start_iter = 1000 steps of the
+    material stage, fields.py:1050-1065): MCShadingNetwork.forward at step 100 (fixed samplers only) and step 600 (NIS losses
+    fitted on the fixed samples); loss = sum(colors * w) + loss_nis; reference autograd gradients of every trainable tensor --
+    incl. the path through the roughness-warped GGX directions (sample_specular_directions, :858-903)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    # the real `raytracing` extension is a CUDA kernel without a backward: its outputs carry no autograd history.  The brute-force
+    # stand-in is written in torch ops, so its inputs are detached here -- otherwise hit points and depths would pick up a gradient
+    # wrt the (roughness-dependent) specular directions that the reference does not have.
+    trace = lambda o, d: MaterialRenderer.trace(host, (o + 2 * unit * d).detach(), d.detach())
+    torch.manual_seed(4)
+    cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+               nis_specular_sample_num=8)
+    net = MCShadingNetwork(cfg, trace, AABB)
+    g = torch.Generator().manual_seed(3)
+    net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(0.3 * torch.randn(1, 36, R, R, generator=g)) for _ in range(3)])
+    net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(0.5 + 0.3 * torch.randn(1, 36, R, 1, generator=g)) for _ in range(3)])
+    for fl in (net.flow_diffuse, net.flow_specular, net.flow_diffuse_copy, net.flow_specular_copy):
+        perturb_(list(fl.nis_plane) + list(fl.nis_line), 0.1, 3)
+        perturb_([p for n, p in fl.flows.named_parameters() if "weight" in n], 0.05, 5)
+    with torch.no_grad():
+        net.outer_light.base.add_(0.5 * torch.randn(net.outer_light.base.shape, generator=g))
+    base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
+    assert all(torch.equal(v, base[k]) for k, v in net.state_dict().items()), "state differs from shading_grad.npz"
+    assert not net.use_flow_diffuse_copy and not net.use_flow_specular_copy
+    net.eval()
+    pn = 40
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
+    w = torch.rand(pn, 3, generator=g)
+    arr = dict(pts=pts, view_in=view, normals_in=nrm, bwd_w=w, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32))
+    for step in (100, 600):
+        net.zero_grad()
+        colors, outputs = net(pts, view, nrm, None, step, False)
+        loss = (colors * w).sum() + outputs["loss_nis"]
+        loss.backward()
+        arr.update({f"colors_{step}": colors, f"loss_nis_{step}": outputs["loss_nis"], f"loss_nis_diffuse_{step}": outputs["loss_nis_diffuse"],
+                    f"loss_nis_specular_{step}": outputs["loss_nis_specular"]})
+        arr.update({f"grad{step}/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        print(step, "loss_nis", float(outputs["loss_nis"]), "tensors with grad", sum(p.grad is not None for p in net.parameters()))
+    save("shading_grad_fixed", **arr)           # network state and mesh: shading_grad.npz (same seed)
+
+
 def gen_march_grad():
     """Geometry-only training direction of the ray-march: loss over compute_sdf_alpha + nerfacc compositing outputs
     (shapeRenderer.py:995-1025, :1166-1206); gradients of the SDF field, decoder and variance from the reference autograd."""
