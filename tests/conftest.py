@@ -48,9 +48,19 @@ def golden():
 
 
 def rel_err(a, b):
-    """max |a-b| / max(|b|, 1) -- the 'relative fp32' measure used throughout."""
+    """max |a-b| / max(|b|, 1) -- the 'relative fp32' measure used throughout.  For quantities below 1 (colours, alpha, sdf,
+    roughness, weights) this is an ABSOLUTE bound; `true_rel_err` below is the relative one."""
     a, b = a.double(), b.double()
     return float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) if a.numel() else 0.0
+
+
+def true_rel_err(a, b, floor=1e-3):
+    """max |a-b| / max(|b|, floor * max|b|): a genuinely relative measure with a small floor against division by ~0 (a quantity
+    of size 1e-2 held to 1e-4 here is held to 1e-6 absolute)."""
+    a, b = a.double(), b.double()
+    if not a.numel():
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp_min(floor * float(b.abs().max()) + 1e-300)).max())
 
 
 AABB = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])

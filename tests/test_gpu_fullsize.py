@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AABB, rel_err
+from conftest import AABB, rel_err, true_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -178,3 +178,60 @@ def test_compact_mask_ragged_and_unaligned(dev):
     idx, count = ops.compact_mask(mask)
     n = int(count)
     assert n == int(mask.sum(dtype=torch.int64)) and bool(mask[idx[:n]].all()) and idx[:n].unique().numel() == n
+
+
+def test_full_size_state_against_the_oracle(dev):
+    """BASELINE configs[2] at its real sizes -- R = 512 material / flow fields, the 265 k-triangle bench mesh, 128 + 512 + 128
+    secondary rays -- on 64 surface points against the ORACLE (CPU restatement pinned to the reference goldens; the bench mesh is
+    traced by oracle/bvh_cpu.c): hit flags and specular masks bit-exact, per-pixel colour within 1e-4 except points holding an
+    ill-conditioned flow sample (reported: each must show a flow sample displaced by > 1e-4); and configs[1]'s R = 300 field:
+    sdf / gradient / alpha of 4096 samples against the oracle."""
+    from oracle import march as om
+    from oracle import shading as osh
+    from oracle.mesh import BvhRayTracer
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import MCShader
+    from tensoflow_amd.synth import random_mc_state, random_sdf_state, sphere_surface_points, sphere_torus_mesh
+    torch.set_num_threads(16)
+    sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
+    verts, faces = sphere_torus_mesh(224, 448, 256, 128)
+    unit = 2.0 / 511
+    sh = MCShader(sd, verts, faces, AABB, unit, device=dev, n_fixed_diffuse=512)
+    sh.cull_dead_rays = False
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(64, seed=123)]
+    out = sh.shade(pts.to(dev), view.to(dev), nrm.to(dev), 128, 128)
+    tr = osh.MeshTracer(torch.from_numpy(verts)[torch.from_numpy(faces).long()], bvh=BvhRayTracer(verts, faces))
+    with torch.no_grad():
+        ref = osh.shade(sd, tr, unit, AABB, pts, view, nrm, 128, 128, n_fixed_diffuse=512, use_flow=True)
+    assert torch.equal(out["hit"][:, :640].cpu(), ref["diffuse_hit"]) and torch.equal(out["specular_mask"].cpu(), ref["specular_mask"])
+    for k in ("metallic", "roughness", "albedo"):
+        assert rel_err(out[k].cpu(), ref[k]) < 1e-4 and true_rel_err(out[k].cpu(), ref[k]) < 1e-3, k
+    err = (out["colors"].cpu() - ref["colors"]).abs().amax(-1)
+    moved = torch.maximum((out["diffuse_angles"].cpu() - ref["diffuse_flow_angles"]).abs().amax(-1).amax(-1),
+                          (out["specular_angles"].cpu() - ref["specular_flow_angles"]).abs().amax(-1).amax(-1))
+    bad = err > 1e-4
+    print(f"R=512 state, 64 points: max pixel err {float(err.max()):.2e}, {int(bad.sum())} beyond 1e-4; their worst flow-sample move "
+          f"{[f'{float(v):.1e}' for v in moved[bad]]}")
+    assert int(bad.sum()) <= 3 and float(err.max()) < 2e-3
+    assert bool((moved[bad] > 1e-4).all())               # every outlier holds a displaced (ill-conditioned) flow sample
+    # ---- configs[1]: R = 300 SDF field
+    R = 300
+    ssd = random_sdf_state(seed=1, R=R)
+    packed = ops.VmPacked([ssd[f"sdf_plane.{i}"].to(dev) for i in range(3)], [ssd[f"sdf_line.{i}"].to(dev) for i in range(3)], 3)
+    W = [ssd[k].to(dev) for k in ("sdf_mat.0.weight", "sdf_mat.0.bias", "sdf_mat.2.weight", "sdf_mat.2.bias")]
+    gen = torch.Generator().manual_seed(11)
+    n = 4096
+    p = torch.rand(n, 3, generator=gen) * 1.6 - 0.8
+    lv = torch.rand(n, generator=gen) * 2.2 - 0.1
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    dists = torch.full((n,), 2.0 / 256)
+    units = [2.0 / (R - 1)] * 3
+    alpha, grad, feat, sdf, nh = ops.sdf_alpha(packed, *W, p.to(dev), lv.to(dev), dists.to(dev), dirs.to(dev), AABB, units, float(np.exp(3.0)), 1.0)
+    osd = {"sdf_network." + k: v for k, v in ssd.items()}
+    osd["deviation_network.variance"] = torch.tensor(0.3)
+    with torch.no_grad():
+        ra, rg, rf, _, rs, _ = om.sdf_alpha(osd, p, lv[:, None], dists, dirs, 1.0, AABB, [R, R, R], 3, training=False)
+    assert rel_err(alpha.cpu(), ra) < 1e-4 and rel_err(sdf.cpu(), rs) < 1e-4 and rel_err(grad.cpu(), rg) < 1e-4 and rel_err(feat.cpu(), rf) < 1e-4
+    g_rel = float(((grad.cpu() - rg).norm(dim=-1) / rg.norm(dim=-1).clamp_min(1e-3 * float(rg.norm(dim=-1).max()))).max())   # vector-wise
+    print(f"R=300 field: true relative error sdf {true_rel_err(sdf.cpu(), rs):.1e}, grad (per vector) {g_rel:.1e}, alpha {true_rel_err(alpha.cpu(), ra):.1e}")
+    assert true_rel_err(sdf.cpu(), rs) < 2e-3 and g_rel < 2e-3
