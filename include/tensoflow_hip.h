@@ -297,13 +297,17 @@ int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes, const flo
  * integral is exactly zero -- below-horizon samples, fields.py:1156,1209 -- per-wavefront live-sample culling).
  * hit_rows_only != 0: pos / nrm rows are written for rays that hit only (rows of missing rays are left untouched): the
  * integral reads them through the compacted hit list, and 85 % of its rays miss.
- * work_counter: 8 bytes of device scratch (zeroed by the call) that switches on the persistent kernel with dynamic
- * ray fetch (lanes pull new rays as their wave-mates finish); NULL = one statically assigned ray per lane. */
+ * origin_order [m / rays_per_origin] int32 (device) or NULL (used when rays_per_origin >= 64): the ORDER in which origins are handed
+ * to the persistent waves -- the u-th origin traced is origin_order[u]; results stay at each ray's own index.  Passing a
+ * spatially sorted order (Morton code of the origin) lets every XCD work on one contiguous eighth of the scene (its L2 then
+ * holds that part of the tree and triangles).
+ * work_counter: 64 bytes (8 x int64) of device scratch (zeroed by the call) that switches on the persistent kernel with
+ * dynamic ray fetch (lanes pull new rays as their wave-mates finish); NULL = one statically assigned ray per lane. */
 int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const float* frame_host, int64_t n_pairs, const float* o, const float* d,
                  int64_t rays_per_origin, const int32_t* slot_order, float origin_offset0, float origin_offset1,
                  const uint8_t* live, int64_t m,
-                 float* pos, float* nrm, float* depth, uint8_t* hit, int32_t hit_rows_only, int64_t* work_counter,
-                 tf_stream_t stream);
+                 float* pos, float* nrm, float* depth, uint8_t* hit, int32_t hit_rows_only, const int32_t* origin_order,
+                 int64_t* work_counter, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generic small MLP on rows (weight-norm already folded by the caller): used for the inner-light

@@ -360,6 +360,7 @@ struct TraceArgs {
   int n_pairs;
   long long rays_per_origin;   // o holds m / rays_per_origin rows; ray i starts at row i / rays_per_origin
   const int* order;            // [rays_per_origin] or null: the j-th ray traced of a point is its slot order[j]
+  const int* origin_order;     // [n_origins] or null (SPINE): the u-th origin handed out is origin_order[u] (spatially sorted by the caller)
   int hits_only;               // 1: pos / nrm rows are written for rays that hit only (nobody reads a miss's row)
   int unit_parts, unit_size;   // SPINE: an origin's rays_per_origin rays are handed out in unit_parts units of <= unit_size rays
   float spine_radius;          // SPINE: ray origins lie within this distance of their origin row (|off0| + |off1| for unit directions)
@@ -409,6 +410,10 @@ struct TraceArgs {
 #ifndef BVH_UNIT_GROUP
 #define BVH_UNIT_GROUP 1    // units claimed per atomic
 #endif
+#ifndef BVH_XCD_POOLS
+#define BVH_XCD_POOLS 0     // 1: one unit pool per XCD over Morton-sorted origins (origin_order).  Measured 18.0-18.3 ms vs 17.1-17.3: the
+                            // traversal does not respond to L2 locality either (TCC hit rate 60-66 % in every variant)
+#endif
 template <bool DYN, bool SPINE>
 __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) {
   __shared__ int stack[(BVH_LDS_STACK + 1) * 256];   // + one dummy row: the target of predicated-off pushes
@@ -433,6 +438,10 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   long long q_next = 0, q_end = 0;   // wave-uniform: this wave's private chunk of the ray pool
   long long u_next = 0, u_end = 0;   // SPINE: this wave's private range of units
   int ugrab = BVH_UNIT_GROUP;
+#if BVH_XCD_POOLS
+  int my_pool;
+  { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); my_pool = (int)(xcc & 7u); }
+#endif
   int grab = BVH_CHUNK_MAX;
 #ifdef BVH_STATS
   unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0, st_spine = 0, st_spush = 0, st_walks = 0, st_ray = 0, st_max = 0, st_gt100 = 0, st_gt1000 = 0;
@@ -593,6 +602,26 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
             // unit (524 k of them per 201 M rays) held the whole kernel at 6 ms with the traversal switched off.
             const long long n_units = (A.m / A.rays_per_origin) * A.unit_parts;
             if (u_next >= u_end) {
+#if BVH_XCD_POOLS
+              // eight pools, one per XCD: the units (origins in the caller's spatial order) are cut into eight contiguous ranges and
+              // a wave drains the range of the XCD it runs on first -- its XCD's L2 then holds one eighth of the mesh's tree and
+              // triangles instead of all of it -- before helping the others out (placement only steers speed, never results)
+              bool got = false;
+              for (int t = 0; t < 8 && !got; ++t) {
+                const int pool = (my_pool + t) & 7;
+                const long long p_lo = n_units * pool / 8, p_hi = n_units * (pool + 1) / 8;
+                if (lane == 0) base = atomicAdd(A.counter + pool, (unsigned long long)ugrab);
+                base = __shfl(base, 0);
+                if (p_lo + (long long)base < p_hi) {
+                  u_next = p_lo + (long long)base;
+                  u_end = min(u_next + ugrab, p_hi);
+                  got = true;
+                } else if (t == 0) {
+                  my_pool = (my_pool + 1) & 7;        // own range is empty for good: start from the next one from now on
+                }
+              }
+              if (!got) { exhausted = true; break; }
+#else
               if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)ugrab);
               base = __shfl(base, 0);
               if (base >= (unsigned long long)n_units) { exhausted = true; break; }
@@ -600,9 +629,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
               u_end = min(u_next + ugrab, n_units);
               const long long share = (n_units - u_end) / (4LL * gridDim.x * 4);       // guided: shrinks as the pool drains
               ugrab = (int)min((long long)BVH_UNIT_GROUP, max(1LL, share));
+#endif
             }
             base = (unsigned long long)u_next++;
-            const long long oid = (long long)base / A.unit_parts, part = (long long)base - oid * A.unit_parts;
+            const long long ou = (long long)base / A.unit_parts, part = (long long)base - ou * A.unit_parts;
+            const long long oid = A.origin_order ? (long long)A.origin_order[ou] : ou;
             q_next = oid * A.rays_per_origin + part * A.unit_size;
             q_end = min(q_next + A.unit_size, (oid + 1) * A.rays_per_origin);
             build_spine(oid);
@@ -772,7 +803,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const float* frame_host, int64_t n_pairs, const float* o, const float* d,
                             int64_t rays_per_origin, const int32_t* slot_order, float origin_offset0, float origin_offset1, const uint8_t* live,
                             int64_t m, float* pos, float* nrm, float* depth, uint8_t* hit, int32_t hit_rows_only,
-                            int64_t* work_counter, tf_stream_t stream_) {
+                            const int32_t* origin_order, int64_t* work_counter, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(m >= 0 && n_pairs > 0, TF_ESHAPE, "tf_bvh_trace: m < 0 or empty BVH");
   TF_REQUIRE(rays_per_origin >= 1, TF_ESHAPE, "tf_bvh_trace: rays_per_origin must be >= 1");
@@ -783,7 +814,7 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
   A.pairs = reinterpret_cast<const uint4*>(pairs); A.tris = reinterpret_cast<const float4*>(tris12);
   for (int k = 0; k < 3; ++k) { A.org[k] = frame_host[k]; A.scl[k] = frame_host[3 + k]; }
   A.n_pairs = (int)n_pairs;
-  A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order;
+  A.o = o; A.d = d; A.live = live; A.m = m; A.rays_per_origin = rays_per_origin; A.order = slot_order; A.origin_order = origin_order;
 #ifdef BVH_NO_TOP   // dev-only switch: every record from global memory
   A.n_top = 0;
 #else
@@ -793,7 +824,7 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
   A.off0 = origin_offset0; A.off1 = origin_offset1; A.counter = (unsigned long long*)work_counter;
   A.pos = pos; A.nrm = nrm; A.depth = depth; A.hit = hit; A.hits_only = hit_rows_only ? 1 : 0;
   if (work_counter) {
-    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(int64_t), stream);
+    hipError_t e = hipMemsetAsync(work_counter, 0, 8 * sizeof(int64_t), stream);     // work_counter[8]: one pool per XCD
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_bvh_trace: hipMemsetAsync failed: %s", hipGetErrorString(e));
     static int resident = 0;    // blocks per CU the hardware admits (registers / LDS), queried once
     if (!resident) {

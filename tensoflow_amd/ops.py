@@ -518,9 +518,10 @@ class Bvh:
         self.tris = torch.from_numpy(tris12).to(device)
 
     def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True, slot_order=None,
-              hit_rows_only=False):
+              hit_rows_only=False, origin_order=None):
         """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3].
-        hit_rows_only: the pos / nrm rows of rays that miss are left UNINITIALISED (callers that only read hit rows)."""
+        hit_rows_only: the pos / nrm rows of rays that miss are left UNINITIALISED (callers that only read hit rows).
+        origin_order [n_origins] int32: order in which the origins are handed to the persistent waves (see morton_order)."""
         o, d = _f(o.reshape(-1, 3)), _f(d.reshape(-1, 3))
         m = d.shape[0]
         if m == 0:
@@ -537,11 +538,24 @@ class Bvh:
         depth = torch.empty(m, dtype=torch.float32, device=dev)
         hit = torch.empty(m, dtype=torch.uint8, device=dev)
         lv = None if live is None else live.reshape(-1).contiguous()
-        ctr = torch.empty(1, dtype=torch.int64, device=dev) if dynamic else None
+        ctr = torch.empty(8, dtype=torch.int64, device=dev) if dynamic else None
+        if origin_order is not None and (origin_order.dtype != torch.int32 or origin_order.numel() != o.shape[0]):
+            raise RuntimeError("Bvh.trace: origin_order must be an int32 permutation of the origin rows")
         L.check(self.lib.tf_bvh_trace(_p(self.pairs, torch.int32), _p(self.tris), C.byref(self.frame), self.n_pairs, _p(o), _p(d), per_origin, _p(slot_order, torch.int32), float(off0), float(off1),
                                       _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
-                                      int(bool(hit_rows_only)), _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
+                                      int(bool(hit_rows_only)), _p(origin_order, torch.int32), _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
         return pos, nrm, depth, hit.bool()
+
+
+def morton_order(pts, aabb):
+    """int32 permutation sorting points [n,3] along a 30-bit Morton curve over `aabb` (device-side; Bvh.trace origin_order)."""
+    lo, hi = aabb[0].to(pts.device), aabb[1].to(pts.device)
+    q = ((pts - lo) / (hi - lo)).clamp(0, 1).mul(1023).long()
+    code = torch.zeros(pts.shape[0], dtype=torch.long, device=pts.device)
+    for b in range(10):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code).to(torch.int32)
 
 
 class ShapeShade:

@@ -83,9 +83,9 @@ def test_fused_stage_validation(lib):
     assert lib.tf_point_fwd(None, None, None, None, None, None, None, None, None, None, 0, 0.04, None, None, None, None, None, None) == 0
     frame = (C.c_float * 6)()
     assert lib.tf_bvh_trace(None, None, C.byref(frame), 1, None, None, 0, None, 0.0, 0.0, None, 5, None, None, None, None, 0, None,
-                            None) == -2 and b"rays_per_origin" in lib.tf_last_error()
+                            None, None) == -2 and b"rays_per_origin" in lib.tf_last_error()
     assert lib.tf_bvh_trace(None, None, C.byref(frame), 1, None, None, 1, None, 0.0, 0.0, None, 5, None, None, None, None, 0, None,
-                            None) == -1
+                            None, None) == -1
     # unknown precision codes are rejected
     assert lib.tf_sdf_forward(None, None, None, None, None, None, 5, None, None, 7, None, 0, None) != 0
 
