@@ -553,6 +553,29 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
     return res
 
 
+def other_rooflines(summ, timer, hits, args, sh, dom):
+    """The matrix-core kernels of the step when they are not the dominant one (same definitions as `roofline`)."""
+    from tensoflow_amd import ops as _ops
+    out = {}
+    if dom != "inner_light" and "inner_light" in summ and hits:
+        ms, n = summ["inner_light"]
+        terms = {_ops.PREC_F16X3: 3, _ops.PREC_F16X2: 2, _ops.PREC_F16: 1}.get(sh.inner_precision, 3)
+        ach = hits * FLOP_PER_HIT_RAY / (ms * 1e-3) / 1e12
+        out["inner_light2_kernel"] = dict(bound="mfma", achieved=ach, peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F16_MFMA_TFLOPS,
+                                          executed_tflops=hits / 32.0 * 336 * terms * 32768 / (ms * 1e-3) / 1e12, avg_launch_ms=ms / n,
+                                          traffic=pmc_traffic("inner_light2_kernel"),
+                                          per_launch=f"{hits // max(1, n)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop, {terms} f16 MFMA per product term")
+    if dom != "flow_sample" and "flow_sample" in summ:
+        ms, n = summ["flow_sample"]
+        samples = timer.units.get("flow_sample", 0)
+        ach = samples * FLOP_PER_FLOW_SAMPLE / (ms * 1e-3) / 1e12
+        out["flow_kernel"] = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
+                                  avg_launch_ms=ms / n, traffic=pmc_traffic("flow_kernel"),
+                                  per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches); "
+                                             "vector-instruction / dependency bound (spline), fp32-grade f16x3 products")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -661,7 +684,7 @@ def main():
             terms = {_ops.PREC_F16X3: 3, _ops.PREC_F16X2: 2, _ops.PREC_F16: 1}.get(sh.inner_precision, 3)
             executed = hits / 32.0 * 336 * terms * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
             roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
-                        frac=ach / peak, traffic=pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
+                        frac=ach / peak, traffic=pmc_traffic("inner_light2_kernel") or pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         executed_tflops=executed, frac_executed=executed / peak,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
                                    f"({'f16 MFMA operands, fp32 accumulate, ' + str(terms) + ' MFMA per product term; peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
@@ -688,6 +711,7 @@ def main():
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",
                        "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "parallelism": f"points sharded x{world}, no collective"},
             "roofline": roof,
+            "roofline_other": other_rooflines(summ, timer, hits, args, sh, dom),
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         }
         if train_dp is not None:

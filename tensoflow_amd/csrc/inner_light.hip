@@ -7,6 +7,7 @@
 // (mfma_mlp.h); the 688 KB of fragment-ordered weights stream from L2 (256 coalesced bytes per MFMA).
 // Weight-norm is folded by the caller (effective W = g * v / |v|).
 #include <cmath>
+#include <type_traits>
 
 #include "mfma_mlp.h"
 #include "tf_common.h"
@@ -474,21 +475,17 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   const int q_out = 32 * wave + (lane & 31);               // ray of the pass whose radiance this lane stores (lanes 0..31)
   // inputs of the first pass; inside the loop the NEXT pass's index row and input rows are requested a layer or two ahead
   // of their use (two dependent L2 / HBM round trips otherwise open every pass)
-  float in6[6];
+  float in9[9];                                            // pts | nrm | view of the ray this lane encodes
   long long nsrc;
+  auto load_inputs = [&](long long src) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { in9[k] = pts[3 * src + k]; in9[3 + k] = nrm[3 * src + k]; in9[6 + k] = view[3 * src + k]; }
+  };
   {
     long long row = (long long)blockIdx.x * C::R + q_enc;
     if (row >= m) row = m - 1;
     nsrc = idx ? idx[row] : row;
-    if (wave < 2) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) in6[k] = pts[3 * nsrc + k];
-#pragma unroll
-      for (int k = 3; k < 6; ++k) in6[k] = 0.f;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { in6[k] = nrm[3 * nsrc + k]; in6[3 + k] = view[3 * nsrc + k]; }
-    }
+    load_inputs(nsrc);
   }
   Il2Ring<TERMS> ring;
 #ifndef IL2_NO_XPF
@@ -506,15 +503,79 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     asm volatile("" : "+s"(ws));
     IL2_STAMP();
     const tf_h8* W = reinterpret_cast<const tf_h8*>(ws);     // wave-uniform, 16-byte units (kP1 etc. are float offsets)
-    // ---- encodings of the pass's 128 rays: waves 0-1 positional (features 72..122), waves 2-3 IDE (features 0..71)
+    // ---- encodings of the pass's 128 rays, 64 per wave, the work of a ray split over TWO waves so that all four are equally
+    // busy (the whole IDE on one wave pair cost 6.9 k cycles against 5.3 k for the positional encoding on the other):
+    //   waves 0-1: positional encoding (features 72..122) + IDE columns 0..11  (l = 1, 2, 4 and the first two orders of l = 8)
+    //   waves 2-3: IDE columns 12..35 (rest of l = 8, all of l = 16)
+    // Every 4-feature store granule has one owner (12 and 36 + 12 are multiples of 4).
     {
       const int r = q_enc >> 5, j = q_enc & 31;
+      // reflected direction (both wave pairs need it)
+      float n[3] = {in9[3], in9[4], in9[5]};
+      float v[3] = {vsign * in9[6], vsign * in9[7], vsign * in9[8]};
+      float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+      n[0] *= inv; n[1] *= inv; n[2] *= inv;
+      inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+      v[0] *= inv; v[1] *= inv; v[2] *= inv;
+      const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+      const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+      const __attribute__((address_space(4))) float* mat =
+          (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
+      // IDE columns [C0, C1): sph[col] = (rx + i ry)^mm * sum_k mat[k][col] rz^k; Re -> feature col, Im -> feature 36 + col
+      auto ide_cols = [&](auto c0_, auto c1_) {
+        constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value;
+        constexpr int KMAX = C1 <= 12 ? 8 : 16, MMAX = C1 <= 12 ? 4 : 16;
+        float zp[KMAX + 1], cre[MMAX + 1], cim[MMAX + 1];
+        zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
+#pragma unroll
+        for (int k = 1; k <= KMAX; ++k) zp[k] = zp[k - 1] * rz;
+#pragma unroll
+        for (int k = 1; k <= MMAX; ++k) {
+          cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
+          cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
+        }
+        float re[C1 - C0], im[C1 - C0];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+#pragma unroll
+          for (int mm = 0; mm <= (1 << d); ++mm) {
+            const int col = (1 << d) - 1 + d + mm;
+            if (col >= C0 && col < C1) {
+              float poly = 0.f;
+#pragma unroll
+              for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+              re[col - C0] = cre[mm] * poly;
+              im[col - C0] = cim[mm] * poly;
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < (C1 - C0) / 4; ++g) {
+          il2_store4<C::XP>(act8, C0 + 4 * g, r, j, re[4 * g], re[4 * g + 1], re[4 * g + 2], re[4 * g + 3]);
+          il2_store4<C::XP>(act8, 36 + C0 + 4 * g, r, j, im[4 * g], im[4 * g + 1], im[4 * g + 2], im[4 * g + 3]);
+        }
+      };
       if (wave < 2) {
-        const float p[3] = {in6[0], in6[1], in6[2]};
+        const float p[3] = {in9[0], in9[1], in9[2]};
         float enc[56];
 #pragma unroll
         for (int k = 0; k < 3; ++k) enc[k] = p[k];
-        if (__all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f)) {
+        if (TERMS <= 2) {
+          // operands are rounded to f16 (2^-12) on their way into the matrix cores: octaves 1..7 by angle doubling from ONE
+          // accurate sincos per coordinate (error doubles per octave: <= 1.3e-5 at 2^7 p) instead of 24 range-reduced evaluations
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            float sn, cs;
+            if (fabsf(p[k]) < 3.f) tf_sincos_small(p[k], sn, cs); else tf_sincos(p[k], sn, cs);
+            enc[3 + k] = sn; enc[6 + k] = cs;
+#pragma unroll
+            for (int f = 1; f < 8; ++f) {
+              const float s2 = 2.f * sn * cs, c2 = fmaf(-2.f * sn, sn, 1.f);
+              sn = s2; cs = c2;
+              enc[3 + 6 * f + k] = sn; enc[3 + 6 * f + 3 + k] = cs;
+            }
+          }
+        } else if (__all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f)) {
 #pragma unroll
           for (int f = 0; f < 8; ++f)
 #pragma unroll
@@ -529,42 +590,9 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         for (int k = 51; k < 56; ++k) enc[k] = 0.f;
 #pragma unroll
         for (int g = 0; g < 14; ++g) il2_store4<C::XP>(act8, 72 + 4 * g, r, j, enc[4 * g], enc[4 * g + 1], enc[4 * g + 2], enc[4 * g + 3]);
+        ide_cols(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
       } else {
-        float n[3] = {in6[0], in6[1], in6[2]};
-        float v[3] = {vsign * in6[3], vsign * in6[4], vsign * in6[5]};
-        float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
-        n[0] *= inv; n[1] *= inv; n[2] *= inv;
-        inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-        v[0] *= inv; v[1] *= inv; v[2] *= inv;
-        const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
-        const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
-        float zp[17], cre[17], cim[17];
-        zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
-#pragma unroll
-        for (int k = 1; k < 17; ++k) {
-          zp[k] = zp[k - 1] * rz;
-          cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
-          cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
-        }
-        // wave-uniform table through the scalar cache.  (As compile-time literals the 222 coefficients were materialised in
-        // SGPRs, hoisted out of the pass loop as loop invariants and spilled: 175 scalar + 300 vector spills.)
-        const __attribute__((address_space(4))) float* mat =
-            (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
-        float enc[72];
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-#pragma unroll
-          for (int mm = 0; mm <= (1 << d); ++mm) {
-            const int col = (1 << d) - 1 + d + mm;
-            float poly = 0.f;
-#pragma unroll
-            for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
-            enc[col] = cre[mm] * poly;
-            enc[36 + col] = cim[mm] * poly;
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 18; ++g) il2_store4<C::XP>(act8, 4 * g, r, j, enc[4 * g], enc[4 * g + 1], enc[4 * g + 2], enc[4 * g + 3]);
+        ide_cols(std::integral_constant<int, 12>{}, std::integral_constant<int, 36>{});
       }
     }
     // index rows: this pass's output ray, the next pass's input ray
@@ -603,15 +631,7 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     IL2_STAMP();
     // ---- layers 2, 3 (K = 256)
     const float dep = depth ? depth[osrc] : 1.f;
-    if (npass < n_pass) {                                   // next pass's input rows (consumed at the top of the next iteration)
-      if (wave < 2) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) in6[k] = pts[3 * nsrc + k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { in6[k] = nrm[3 * nsrc + k]; in6[3 + k] = view[3 * nsrc + k]; }
-      }
-    }
+    if (npass < n_pass) load_inputs(nsrc);                  // next pass's input rows (consumed at the top of the next iteration)
     tf_h8 a4[16];                                            // layer 4's weight fragments (hi), requested under layer 3's epilogue
 #pragma unroll
     for (int layer = 1; layer < 3; ++layer) {
