@@ -364,7 +364,10 @@ __device__ __forceinline__ void il2_store4(uint2* act8, int k, int r, int j, flo
 // Weight fragments in flight: a ring of PF + 1 k-steps (two unit tiles x AP planes each).  A layer starts with its first PF
 // k-steps already requested (il2_prefetch, issued before the barriers / epilogue of the layer in front of it: an L2 round trip
 // per layer start was otherwise exposed four times per pass).
-constexpr int kIl2Pf = 3;
+#ifndef IL2_PF
+#define IL2_PF 3
+#endif
+constexpr int kIl2Pf = IL2_PF;
 template <int TERMS>
 struct Il2Ring { tf_h8 a[kIl2Pf + 1][2][IL2<TERMS>::AP]; };
 
@@ -394,6 +397,13 @@ __device__ __forceinline__ void il2_layer(const tf_h8* __restrict__ Wl /* wave-u
 #ifdef IL2_NO_XPF
   il2_prefetch<TERMS>(Wl, T0, lane, ring);
 #endif
+  // B fragments (activations) of k-step s + 1 are requested BEFORE the MFMAs of k-step s (register double buffer): read, wait and
+  // multiply in sequence left the matrix pipe idle for an LDS round trip (~200 cycles) in front of every 256 cycles of MFMAs.
+  tf_h8 bq[2][4][C::XP];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int p = 0; p < C::XP; ++p) bq[0][r][p] = actl[((0 * 4 + r) * C::XP + p) * 64];
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
     if (s + PF < K16) {
@@ -402,11 +412,16 @@ __device__ __forceinline__ void il2_layer(const tf_h8* __restrict__ Wl /* wave-u
 #pragma unroll
         for (int p = 0; p < C::AP; ++p) ring.a[(s + PF) % (PF + 1)][t][p] = wp[(unsigned)(((s + PF) * 8 + t) * 128 + p * 64 + lane)];
     }
+    if (s + 1 < K16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int p = 0; p < C::XP; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * 4 + r) * C::XP + p) * 64];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const tf_h8 b_hi = actl[((s * 4 + r) * C::XP) * 64];
-      tf_h8 b_lo = b_hi;
-      if (TERMS == 3) b_lo = actl[((s * 4 + r) * C::XP + 1) * 64];
+      const tf_h8 b_hi = bq[s & 1][r][0];
+      const tf_h8 b_lo = bq[s & 1][r][C::XP - 1];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const tf_h8 a_hi = ring.a[s % (PF + 1)][t][0];
@@ -416,7 +431,7 @@ __device__ __forceinline__ void il2_layer(const tf_h8* __restrict__ Wl /* wave-u
       }
     }
 #ifndef IL2_NO_SB
-    __builtin_amdgcn_sched_barrier(0);      // bounds how far the B-fragment reads of later k-steps are hoisted (registers)
+    __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
 #endif
   }
 }
@@ -542,8 +557,12 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
             const int col = (1 << d) - 1 + d + mm;
             if (col >= C0 && col < C1) {
               float poly = 0.f;
+#ifndef IL2_ABLATE_IDE   // dev-only timing ablation
 #pragma unroll
               for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
+#else
+              poly = zp[1];
+#endif
               re[col - C0] = cre[mm] * poly;
               im[col - C0] = cim[mm] * poly;
             }
