@@ -68,7 +68,10 @@ class MaterialRenderer(nn.Module):
             border = self.cfg.get("split_borderline", 100)
             self.train_ids, test = ids[:border], ids[border:]
             self.test_ids = test[::50] if len(test) > 10 else test[::4]
-        else:
+        else:                                            # get_database_split(split_type='validation'), dataset/database.py:834-839
+            import random
+            ids = list(ids)
+            random.Random(6033).shuffle(ids)             # random.seed(6033); random.shuffle(img_ids)
             self.test_ids, self.train_ids = ids[:1], ids[1:]
         self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
         # the material stage's OWN ray table (materialRenderer.py:452-480): unit directions, no half-pixel offset -- the same

@@ -410,14 +410,32 @@ class ShapeRenderer(nn.Module):
             border = self.cfg.get("split_borderline", 100)
             self.train_ids, test = ids[:border], ids[border:]
             self.test_ids = test[::50] if len(test) > 10 else test[::4]
-        else:
+        else:                                            # get_database_split(split_type='validation'), dataset/database.py:834-839
+            import random
+            ids = list(ids)
+            random.Random(6033).shuffle(ids)             # random.seed(6033); random.shuffle(img_ids)
             self.test_ids, self.train_ids = ids[:1], ids[1:]
         self.train_imgs_info = self.database.imgs_info(self.train_ids)
         self.test_imgs_info = self.database.imgs_info(self.test_ids)
         self.train_num, self.test_num = len(self.train_ids), len(self.test_ids)
         batch, self.tbn, _, _ = construct_ray_batch_nerf(self.train_imgs_info)
+        batch, self.tbn = self.filtering_train_rays(batch)
         self.train_table = RayTable(batch, rank=self.cfg.get("rank", 0), world=self.cfg.get("world", 1),
                                     seed=self.cfg.get("random_seed", 6033), device=self.device)
+
+    @torch.no_grad()
+    def filtering_train_rays(self, batch, chunk=1 << 22):
+        """shapeRenderer.py:539-566: rays whose slab interval with the aabb is empty never enter the training table."""
+        o, d = batch["rays_o"], batch["dirs"]
+        aabb = self.aabb.cpu()
+        keep = []
+        for i in range(0, o.shape[0], chunk):
+            oo, dd = o[i:i + chunk], d[i:i + chunk]
+            vec = torch.where(dd == 0, torch.full_like(dd, 1e-6), dd)
+            ra, rb = (aabb[1] - oo) / vec, (aabb[0] - oo) / vec
+            keep.append(torch.maximum(ra, rb).amin(-1) > torch.minimum(ra, rb).amax(-1))
+        keep = torch.cat(keep) if keep else torch.zeros(0, dtype=torch.bool)
+        return {k: v[keep] for k, v in batch.items()}, int(keep.sum())
 
     def compute_rgb_loss(self, rgb_pr, rgb_gt):
         from ..trainer import rgb_loss
