@@ -143,7 +143,10 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
                                      worst_flow_sample=j, sample_move_hip_vs_oracle32=float(mv[k, j]),
                                      same_sample_move_oracle32_vs_oracle64=float(mv64[k, j]),
                                      max_sample_move_oracle32_vs_oracle64=float(mv64[k].max())))
-            explained = hits_equal and mat_err < 1e-5 and all(o["sample_move_hip_vs_oracle32"] > 1e-4 for o in outliers)
+            # explained: hit flags and materials agree, and the point either holds a flow sample displaced by far more than the ~1e-6 of
+            # a well-conditioned one, or the ORACLE's own fp32 and fp64 colours already differ by half the deviation or more
+            explained = hits_equal and mat_err < 1e-5 and all(
+                o["sample_move_hip_vs_oracle32"] > 5e-5 or o["oracle32_vs_oracle64"] >= 0.5 * o["hip_vs_oracle32"] for o in outliers)
         else:
             explained, hits_equal, mat_err = True, True, 0.0
         psnr = dict(value_db=20 * math.log10(1.0 / math.sqrt(max(mse, 1e-30))), max_rel_err=float(err.max()),
@@ -151,6 +154,7 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
                     points=done, frac_points_within_tolerance=float((err <= 1e-4).float().mean()),
                     against="oracle/shading.py (CPU restatement pinned to the reference goldens) on the same points, same scene",
                     outliers=outliers, outliers_explained=explained,
+                    outliers_where_hip_is_closer_to_oracle64_than_oracle32_is=sum(o["hip_vs_oracle64"] < o["oracle32_vs_oracle64"] for o in outliers),
                     outlier_points_hit_flags_equal=hits_equal, outlier_points_material_max_err=mat_err,
                     note="sRGB colours in [0,1]; max_rel_err = max |a-b| / max(|b|, 1), max_true_rel_err = max |a-b| / max(|b|, "
                          "1e-3 max|b|).  `outliers` (first 32): every point beyond the tolerance re-evaluated by HIP, the fp32 oracle and "
@@ -362,6 +366,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     build_mips_ms = e0.elapsed_time(e1) / 3
     shader = ShapeShader(sd, [s.detach() for s in env.specular], env.diffuse.detach(), synthetic_fg_lut(), device=device)
     inv_s = math.exp(10 * 0.3)
+    march.update_alpha_mask(field, inv_s)              # warm-up (first call allocates the lattice)
     e0.record()
     mask, _ = march.update_alpha_mask(field, inv_s)
     e1.record()
@@ -406,9 +411,16 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
                          f"fused 7-tap sdf+FD+alpha (eval: no hessian term, f16x3 decoder), split-sum shading, compositing (forward)",
                 rays_per_s=n_rays_total / dt, frame_ms=dt * 1e3, live_samples_per_frame=live,
                 live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
-                sdf_alpha_samples_per_s=sps, algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,
-                hbm_frac=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS, tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12,
-                hbm_traffic_per_launch=pmc_traffic("sdf_kernel"),
+                sdf_alpha_samples_per_s=sps, sdf_kernel_avg_launch_ms=sdf_s * 1e3 / max(1, len(sdf_ev) // max(1, steps)),
+                # ALGORITHMIC gather rate: 18 144 B per live sample with no reuse assumed.  The 51 MB field lives in
+                # the Infinity Cache / L2, so this is NOT what crosses the memory fabric -- that is `measured_fabric_*` below.
+                algorithmic_GBps=sps * MARCH_BYTES_PER_SAMPLE / 1e9,
+                algorithmic_frac_of_hbm_peak=sps * MARCH_BYTES_PER_SAMPLE / 1e9 / PEAK_HBM_GBS, tflops=sps * MARCH_FLOP_PER_SAMPLE / 1e12,
+                measured_fabric_bytes_per_launch=pmc_traffic("sdf_kernel"),
+                measured_fabric_GBps=(pmc_traffic("sdf_kernel") / (sdf_s / max(1, len(sdf_ev) // max(1, steps))) / 1e9) if pmc_traffic("sdf_kernel") else None,
+                measured_fabric_frac_of_hbm_peak=(pmc_traffic("sdf_kernel") / (sdf_s / max(1, len(sdf_ev) // max(1, steps))) / 1e9 / PEAK_HBM_GBS) if pmc_traffic("sdf_kernel") else None,
+                bound="vector-instruction issue + gather latency: 45 % of wave time issuing vector instructions, 38 % waiting on the gathers, "
+                      "16 % matrix pipe (profiles/*_pmc_summary.json, sdf_kernel)",
                 envlight_build_mips_ms=build_mips_ms, update_alpha_mask_ms=mask_ms)
 
 
@@ -553,6 +565,17 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
     return res
 
 
+def hit_sensitivity(summ, steps, pn, hit_frac, ms_per_step):
+    """Only the inner-light stage depends on how many secondary rays hit geometry (its time is linear in the hit count); the other
+    stages trace / shade every ray.  -> the step time and rate EXTRAPOLATED to the ~20 % hit fraction SURVEY.md 8(d) sketched."""
+    if "inner_light" not in summ or hit_frac <= 0:
+        return None
+    il = summ["inner_light"][0] / steps
+    ms20 = ms_per_step + il * (0.20 / hit_frac - 1.0)
+    return dict(inner_light_ms_per_step=il, measured_hit_fraction=hit_frac, extrapolated_ms_per_step_at_0p20=ms20,
+                extrapolated_points_per_s_at_0p20=pn / ms20 * 1e3, note="linear extrapolation of the inner-light stage only; not a measurement")
+
+
 def other_rooflines(summ, timer, hits, args, sh, dom):
     """The matrix-core kernels of the step when they are not the dominant one (same definitions as `roofline`)."""
     from tensoflow_amd import ops as _ops
@@ -569,7 +592,8 @@ def other_rooflines(summ, timer, hits, args, sh, dom):
         ms, n = summ["flow_sample"]
         samples = timer.units.get("flow_sample", 0)
         ach = samples * FLOP_PER_FLOW_SAMPLE / (ms * 1e-3) / 1e12
-        out["flow_kernel"] = dict(bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TFLOPS,
+        fpeak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS     # f16x3 products run on the f16 MFMA
+        out["flow_kernel"] = dict(bound="mfma", achieved=ach, peak=fpeak, unit="TFLOP/s", frac=ach / fpeak,
                                   avg_launch_ms=ms / n, traffic=pmc_traffic("flow_kernel"),
                                   per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches); "
                                              "vector-instruction / dependency bound (spline), fp32-grade f16x3 products")
@@ -692,8 +716,9 @@ def main():
             n_launch = summ[dom][1]
             samples = timer.units.get("flow_sample", 0)
             ach = samples * FLOP_PER_FLOW_SAMPLE / (summ[dom][0] * 1e-3) / 1e12
-            roof = dict(kernel="flow_kernel", bound="mfma", achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, avg_launch_ms=summ[dom][0] / n_launch,
+            fpeak = PEAK_F16_MFMA_TFLOPS if args.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+            roof = dict(kernel="flow_kernel", bound="mfma", achieved=ach, peak=fpeak, unit="TFLOP/s",
+                        frac=ach / fpeak, traffic=pmc_traffic("flow_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches)")
         else:
             # BVH traversal / elementwise stages: byte-bound; algorithmic bytes = rays x (24 B in + 29 B out)
@@ -709,7 +734,10 @@ def main():
             "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
                                    f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",
-                       "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "parallelism": f"points sharded x{world}, no collective"},
+                       "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "parallelism": f"points sharded x{world}, no collective",
+                       "hit_rate_sensitivity": hit_sensitivity(summ, args.steps, pn, hit_frac, dt / args.steps * 1e3),
+                       "deviations_from_SURVEY_8d_config3": "2^18 points per step instead of 2^20 (the rate is flat from 2^16 up: see --points); "
+                                                             "this synthetic scene's hit fraction is 0.148, the survey sketched ~0.20"},
             "roofline": roof,
             "roofline_other": other_rooflines(summ, timer, hits, args, sh, dom),
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},

@@ -27,7 +27,7 @@ with torch.no_grad():
 
     def inner():
         ops.inner_light_indexed(sh.inner, inters, d2, nn, idx, count, depth, hl, near_eps=1e-5, exp_max=sh.exp_max,
-                                precision=sh.precision, cache=sh.inner_cache)
+                                precision=sh.inner_precision, cache=sh.inner_cache)
 
     def flow():
         ops.flow_sample(sh.flow_d.nets, cond_d, sh.latent(128), None, precision=sh.precision, cache=sh.flow_d.cache)

@@ -36,7 +36,7 @@ def back(dirs, wgt, tr):
     d2 = dirs.reshape(-1, 3)
     hl = torch.empty_like(d2)
     ops.inner_light_indexed(sh.inner, inters, d2, nn, idx, count, depth, hl, near_eps=1e-5, exp_max=sh.exp_max,
-                            precision=sh.precision, cache=sh.inner_cache)
+                            precision=sh.inner_precision, cache=sh.inner_cache)
     return ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hl, sh.env, S + sh.fixed_d.shape[0], S)[0]
 
 
