@@ -13,7 +13,9 @@
 
 #define BVH_MAX_DIST 10.0f
 #ifndef BVH_LEAF
-#define BVH_LEAF 4
+#define BVH_LEAF 2         // triangles per leaf at most.  Every triangle test is three 16-byte fetches of which most miss the L2 (12.7 MB of
+                           // records on the bench mesh against 4 MB): one more pair step is cheaper than two more triangles
+                           // (201 M rays, 7 waves per SIMD: 1: 17.0, 2: 15.5, 3: 15.9, 4: 16.5, 6: 17.2 ms)
 #endif
 #ifndef BVH_REFILL
 #define BVH_REFILL 32   // idle lanes per wave that trigger a refill from the ray pool (16: 4.92, 24: 4.79, 32: 4.76, 40: 4.77, 48: 4.92 ms per 50 M rays)
@@ -29,7 +31,10 @@
 #define BVH_LDS_STACK 12   // of which in LDS (the rest is a per-lane scratch array, touched by the rare deep pile-ups only)
 #endif
 #ifndef BVH_WAVES
-#define BVH_WAVES 8        // resident 256-thread blocks per CU the kernel is compiled for (register budget)
+#define BVH_WAVES 7        // resident 256-thread blocks per CU the kernel is compiled for (register budget): 72 registers hold the step without
+                           // spilling into the hot loop; at 8 (64 registers, 16 spilled) the spill traffic costs more than the eighth wave hides
+                           // (17.1 vs 16.5 ms).  5 and 6 need -mllvm -disable-promote-alloca-to-vector (the private stack tail is otherwise
+                           // promoted to registers and 118 values spill: 51 ms) and are slower with it too (6: 16.5 vs 15.8 at 7, BVH_LEAF 2)
 #endif
 #ifdef BVH_WIDE
 #define BVH_MAX_DEPTH 25   // deepest node level the builder may create (root = 0): 13 four-wide levels, <= 39 postponed children
@@ -38,6 +43,11 @@
 #endif
 #ifndef BVH_TOP
 #define BVH_TOP 127        // pair records of the top of the tree kept in LDS per workgroup (4 KB; numbered breadth-first by the packer)
+#endif
+#ifndef BVH_LEAF_PAIRED
+#define BVH_LEAF_PAIRED 0  // 1: the two triangle records of a leaf are requested together.  Measured slower at every occupancy (7 waves:
+                           // 19.6 vs 15.8 ms, 25 spilled registers; 6: 17.1 vs 16.5; 5, no spill: 17.9): the second record's registers
+                           // cost more than its overlapped round trip returns
 #endif
 #ifndef BVH_LEAF_W
 #define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
@@ -328,7 +338,7 @@ extern "C" int64_t tf_bvh_pack_host(const TfBvhNode* nodes_host, int64_t n_nodes
 
 // ----------------------------------------------------------------------------- device trace
 #ifdef BVH_STATS
-__device__ unsigned long long g_bvh_stats[8];   // inner lane-steps, leaf lane-steps, wave inner iterations x64, wave leaf iterations x64
+__device__ unsigned long long g_bvh_stats[8];   // inner lane-steps, leaf lane-steps, wave inner iterations x64, wave leaf iterations x64, spine entries, spine pushes, triangles tested, max steps of a ray
 extern "C" void tf_bvh_stats(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_stats), 64); unsigned long long z[8] = {0,0,0,0,0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_stats), z, 64); }
 #endif
 
@@ -394,6 +404,14 @@ struct TraceArgs {
 };
 
 #define BVH_NONE (-1)
+
+#ifdef BVH_CLOCK   // dev-only: where a wave's life goes.  [0] refill (ray fetch, spine, stores) [1] inner steps [2] leaf steps [3] wave lifetime,
+// all in s_memrealtime ticks (100 MHz) summed over waves; [4] waves; [5] earliest wave end, [6] latest wave end, [7] earliest wave start
+// [8] of the refill: result stores of finished rays (+ normal rows) [9] unit claim + spine build [10] ray fetch + spine walk
+__device__ unsigned long long g_bvh_clock[12];
+extern "C" void tf_bvh_clock(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_clock), 96); unsigned long long z[12] = {0,0,0,0,0,~0ULL,0,~0ULL,0,0,0,0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_clock), z, 96); }
+#define BVH_TICK() __builtin_amdgcn_s_memrealtime()
+#endif
 
 // One lane = one ray.  A wave alternates between INNER steps (lanes whose current reference is a pair test both child
 // boxes, descend into the nearer one and push the other on their LDS stack) and LEAF steps (lanes parked at a leaf
@@ -465,7 +483,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #endif
   int grab = BVH_CHUNK_MAX;
 #ifdef BVH_STATS
-  unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0, st_spine = 0, st_spush = 0, st_walks = 0, st_ray = 0, st_max = 0, st_gt100 = 0, st_gt1000 = 0;
+  unsigned st_inner = 0, st_leaf = 0, st_wi = 0, st_wl = 0, st_spine = 0, st_spush = 0, st_walks = 0, st_ray = 0, st_max = 0, st_tris = 0;
 #endif
   auto start_ray = [&](long long seq) {
     // trace order -> ray id: consecutive lanes take the slots of one point in `order` (directions sorted along a
@@ -506,7 +524,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   };
   auto retire = [&]() {
 #ifdef BVH_STATS
-    st_max = max(st_max, st_ray); st_gt100 += st_ray > 100; st_gt1000 += st_ray > 1000; st_ray = 0;
+    st_max = max(st_max, st_ray); st_ray = 0;
 #endif
 #ifdef BVH_ABLATE_STORE   // dev-only timing ablation: results are not written
     if (best == -123.f) A.depth[rid] = best;
@@ -603,8 +621,18 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     if (i < A.m) start_ray(i);
     exhausted = true;
   }
+#ifdef BVH_CLOCK
+  const unsigned long long ck_start = BVH_TICK();
+  unsigned long long ck_refill = 0, ck_inner = 0, ck_leaf = 0, ck_t = ck_start, ck_retire = 0, ck_claim = 0, ck_startray = 0;
+#endif
   while (true) {
+#ifdef BVH_CLOCK
+    ck_t = BVH_TICK();
+#endif
     if (rid >= 0 && cur == BVH_NONE) retire();
+#ifdef BVH_CLOCK
+    { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ck_retire += BVH_TICK() - ck_t; }
+#endif
     if (DYN && !exhausted) {
       // ---- fetch new rays for idle lanes from the wave's private chunk [q_next, q_end); the chunk itself comes from ONE
       // global atomic per BVH_CHUNK_MIN..BVH_CHUNK_MAX rays (a single counter word sustains only ~88 M atomics/s -- one
@@ -616,6 +644,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
         const int nw = __popcll(wb);
         if (nw == 0 || (round > 0 && nw < BVH_REFILL)) break;
         if (q_next >= q_end) {
+#ifdef BVH_CLOCK
+          const unsigned long long ck_c0 = BVH_TICK();
+#endif
           unsigned long long base = 0;
           if (SPINE) {
             // one unit = the rays [part * unit_size, (part + 1) * unit_size) of ONE origin: all rays started from it share a spine.
@@ -668,7 +699,13 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           const long long share = (A.m - q_end) / (4LL * gridDim.x * 4);
           grab = (int)min((long long)BVH_CHUNK_MAX, max((long long)BVH_CHUNK_MIN, share));
           }
+#ifdef BVH_CLOCK
+          ck_claim += BVH_TICK() - ck_c0;
+#endif
         }
+#ifdef BVH_CLOCK
+        const unsigned long long ck_s0 = BVH_TICK();
+#endif
         if (want) {
           const long long id = q_next + __popcll(wb & lt_mask);
           if (id < q_end) {
@@ -678,8 +715,14 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           }
         }
         q_next = min(q_next + nw, q_end);
+#ifdef BVH_CLOCK
+        { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ck_startray += BVH_TICK() - ck_s0; }
+#endif
       }
     }
+#ifdef BVH_CLOCK
+    { const unsigned long long t = BVH_TICK(); ck_refill += t - ck_t; ck_t = t; }
+#endif
     if (__ballot(rid >= 0) == 0ULL) {
       if (exhausted) break;
       continue;
@@ -689,23 +732,21 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
       const int n_inner = __popcll(__ballot(cur >= 0));
       const int n_leaf = __popcll(__ballot(cur < BVH_NONE));
       if (n_inner + n_leaf == 0) break;
+#ifdef BVH_CLOCK
+      const bool ck_is_leaf = n_leaf > 0 && (n_inner == 0 || n_leaf * BVH_LEAF_W >= n_inner);
+#endif
       if (n_leaf > 0 && (n_inner == 0 || n_leaf * BVH_LEAF_W >= n_inner)) {
 #ifdef BVH_STATS
         st_wl++;
 #endif
         if (cur < BVH_NONE) {
 #ifdef BVH_STATS
-          st_leaf++;
+          st_leaf++; st_tris += (~cur) & 7;
 #endif
           const int enc = ~cur;
           const int first = enc >> 3, cnt = enc & 7;
-#ifdef BVH_ABLATE_LEAF    // dev-only timing ablation: no triangle is tested
-          for (int k = 0; k < 0; ++k) {
-#else
-          for (int k = 0; k < cnt; ++k) {
-#endif
-            const float4* T = A.tris + 3LL * (first + k);
-            const float4 t0 = T[0], t1 = T[1], t2 = T[2];
+          // Moeller-Trumbore on a full-precision (a, e1, e2) record, the arithmetic of the brute-force oracle (hits and depths are exact)
+          auto tri_test = [&](const float4 t0, const float4 t1, const float4 t2, int id) {
             const float ax = t0.x, ay = t0.y, az = t0.z;
             const float e1x = t0.w, e1y = t1.x, e1z = t1.y, e2x = t1.z, e2y = t1.w, e2z = t2.x;
             const float rx = ox - ax, ry = oy - ay, rz = oz - az;
@@ -715,8 +756,28 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
             const float u = det * -(qx * e2x + qy * e2y + qz * e2z);
             const float v = det * (qx * e1x + qy * e1y + qz * e1z);
             const float t = det * -(nx * rx + ny * ry + nz * rz);
-            if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) { best = t; best_tri = first + k; }
+            if (u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= 0.f && t < best) { best = t; best_tri = id; }
+          };
+#ifdef BVH_ABLATE_LEAF    // dev-only timing ablation: no triangle is tested
+          const int cnt_t = 0;
+#else
+          const int cnt_t = cnt;
+#endif
+          const float4* T = A.tris + 3LL * first;
+#if BVH_LEAF_PAIRED
+          // leaves hold <= 2 triangles by default: both records are requested before either is tested (one memory round trip per leaf
+          // instead of one per triangle: three quarters of the triangle fetches miss the L2 -- 12.7 MB of records against 4 MB)
+          if (cnt_t > 0) {
+            const float4 a0 = T[0], a1 = T[1], a2 = T[2];
+            float4 b0 = a0, b1 = a1, b2 = a2;
+            if (cnt_t > 1) { b0 = T[3]; b1 = T[4]; b2 = T[5]; }
+            tri_test(a0, a1, a2, first);
+            if (cnt_t > 1) tri_test(b0, b1, b2, first + 1);
           }
+          for (int k = 2; k < cnt_t; ++k) tri_test(T[3 * k], T[3 * k + 1], T[3 * k + 2], first + k);
+#else
+          for (int k = 0; k < cnt_t; ++k) tri_test(T[3 * k], T[3 * k + 1], T[3 * k + 2], first + k);
+#endif
           cur = pop();
         }
       } else {
@@ -810,14 +871,26 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
         }
 #endif
       }
+#ifdef BVH_CLOCK
+      { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t = BVH_TICK(); if (ck_is_leaf) ck_leaf += t - ck_t; else ck_inner += t - ck_t; ck_t = t; }
+#endif
       if (DYN && !exhausted && __popcll(__ballot(cur == BVH_NONE)) >= BVH_REFILL) break;
     }
   }
+#ifdef BVH_CLOCK
+  if (lane == 0) {
+    const unsigned long long t = BVH_TICK();
+    atomicAdd(&g_bvh_clock[0], ck_refill); atomicAdd(&g_bvh_clock[1], ck_inner); atomicAdd(&g_bvh_clock[2], ck_leaf);
+    atomicAdd(&g_bvh_clock[3], t - ck_start); atomicAdd(&g_bvh_clock[4], 1ULL);
+    atomicMin(&g_bvh_clock[5], t); atomicMax(&g_bvh_clock[6], t); atomicMin(&g_bvh_clock[7], ck_start);
+    atomicAdd(&g_bvh_clock[8], ck_retire); atomicAdd(&g_bvh_clock[9], ck_claim); atomicAdd(&g_bvh_clock[10], ck_startray);
+  }
+#endif
 #ifdef BVH_STATS
   atomicAdd(&g_bvh_stats[0], (unsigned long long)st_inner); atomicAdd(&g_bvh_stats[1], (unsigned long long)st_leaf);
   if (lane == 0) { atomicAdd(&g_bvh_stats[2], 64ULL * st_wi); atomicAdd(&g_bvh_stats[3], 64ULL * st_wl); }
   atomicMax(&g_bvh_stats[7], (unsigned long long)st_max); atomicAdd(&g_bvh_stats[6], 0ULL);
-  atomicAdd(&g_bvh_stats[4], (unsigned long long)st_spine); atomicAdd(&g_bvh_stats[5], (unsigned long long)st_spush); atomicAdd(&g_bvh_stats[6], ((unsigned long long)st_gt1000 << 32) | (unsigned long long)st_gt100);
+  atomicAdd(&g_bvh_stats[4], (unsigned long long)st_spine); atomicAdd(&g_bvh_stats[5], (unsigned long long)st_spush); atomicAdd(&g_bvh_stats[6], (unsigned long long)st_tris);
 #endif
 }
 

@@ -28,6 +28,6 @@ try:
     lib.tf_bvh_stats(st)
     m = pn * 768 * 7
     print(f"bvh stats over {m} rays: inner lane-steps/ray {st[0]/m:.1f} leaf {st[1]/m:.2f} wave inner x64/ray {st[2]/m:.1f} wave leaf x64/ray {st[3]/m:.1f} "
-          f"spine entries/ray {st[4]/m:.1f} pushes/ray {st[5]/m:.2f} max steps {st[7]}")
+          f"spine entries/ray {st[4]/m:.1f} pushes/ray {st[5]/m:.2f} triangles tested/ray {st[6]/m:.2f} max steps {st[7]}")
 except AttributeError:
     pass

@@ -24,5 +24,5 @@ lib.tf_bvh_stats(st)
 m = d.shape[0]
 print(f"rays {m}: inner lane-steps/ray {st[0]/m:.1f}  leaf lane-steps/ray {st[1]/m:.2f}  wave inner iters x64 /ray {st[2]/m:.1f}  "
       f"wave leaf iters x64 /ray {st[3]/m:.1f}  inner SIMD eff {st[0]/max(st[2],1):.2f}  leaf SIMD eff {st[1]/max(st[3],1):.2f}  hit frac {hit.float().mean():.3f}")
-print(f"max inner steps of one ray {st[7]}  rays > 100 steps {st[6] & 0xffffffff}  rays > 1000 steps {st[6] >> 32}")
-print(f"spine entries tested/ray {st[4]/m:.1f}  spine pushes/ray {st[5]/m:.2f}  spine walks (wave events) {st[6]}  rays/walk {m/max(st[6],1):.1f}")
+print(f"max inner steps of one ray {st[7]}  triangles tested/ray {st[6]/m:.2f}")
+print(f"spine entries tested/ray {st[4]/m:.1f}  spine pushes/ray {st[5]/m:.2f}")
