@@ -260,19 +260,169 @@ __device__ __forceinline__ void coupling_net(const float* __restrict__ net /*LDS
   else tf_layer<32, 1, 2>(net + kL4 + lane, a, o);
 }
 
+// ---- The two tiles of a 64-row group, software-pipelined by half a layer (f16 operand modes).
+// Measured on the kernel above (coupling_net twice per block): one wave per SIMD 12.4 ms, two 10.8, three 10.4 for the bench's two
+// launches -- a SIMD's time is the SUM of its matrix-core cycles (264 MFMAs x 32) and its vector-issue cycles (~2 750 x 4) whatever
+// the number of waves, because a wave's own stream alternates a block of vector instructions (LeakyReLU + operand split of a whole
+// layer) with a block of dependent MFMAs.  A vector instruction issued BETWEEN two MFMAs of the same wave costs nothing while at most
+// ~6 of them follow each MFMA (tools/mfma_valu_overlap.hip), so the two tiles are interleaved in ONE instruction stream: while the
+// matrix cores run layer k of tile A, the vector unit activates and splits tile B's layer k-1 output, pair by pair, one pair behind
+// each MFMA; scheduling barriers pin that order.  The arithmetic per accumulator is unchanged (same MFMA sequence, same split), so
+// results are bit-identical to coupling_net.
+struct FlowS16 {          // pre-split operands of one tile's 32 layer inputs: pair p = (value 2p, value 2p + 1) as packed halves
+  unsigned hi[16], lo[16];
+};
+
+template <int TERMS, bool LEAKY>
+__device__ __forceinline__ void flow_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  if (LEAKY) { x0 = leaky(x0); x1 = leaky(x1); }
+  // the consumer is an MFMA of a LATER stage (>= 6 MFMAs away): no hazard nop needed behind the asm statement
+  if (TERMS == 3)
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(lo) : "v"(x0), "v"(x1));
+  else
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+}
+
+// One layer of one tile on the matrix cores; `piece(i)` is called behind MFMA i (0 .. K16 * TOUT * TERMS - 1): the other tile's vector work.
+template <int K16, int TOUT, int TERMS, typename Piece>
+__device__ __forceinline__ void flow_mfma_stage(const tf_h8* __restrict__ wf /* + lane */, const FlowS16& S, f32x16 (&out)[TOUT], Piece&& piece) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  tf_h8 fa[TOUT][2], fn[TOUT][2];
+#pragma unroll
+  for (int t = 0; t < TOUT; ++t) { fa[t][0] = wf[t * 128]; if (TERMS == 3) fa[t][1] = wf[t * 128 + 64]; }
+  int slot = 0;
+#pragma unroll
+  for (int s16 = 0; s16 < K16; ++s16) {
+    if (s16 + 1 < K16) {      // next k-step's weight fragments: requested one k-step ahead of their MFMAs
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) { fn[t][0] = wf[((s16 + 1) * TOUT + t) * 128]; if (TERMS == 3) fn[t][1] = wf[((s16 + 1) * TOUT + t) * 128 + 64]; }
+    }
+    u32x4 bh, bl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { bh[q] = S.hi[4 * s16 + q]; bl[q] = S.lo[4 * s16 + q]; }
+    const tf_h8 b_hi = __builtin_bit_cast(tf_h8, bh), b_lo = __builtin_bit_cast(tf_h8, bl);
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) {
+      out[t] = tf_mfma_h(fa[t][0], b_hi, out[t]);
+      piece(slot++); __builtin_amdgcn_sched_barrier(0);
+      if (TERMS == 3) {
+        out[t] = tf_mfma_h(fa[t][0], b_lo, out[t]);
+        piece(slot++); __builtin_amdgcn_sched_barrier(0);
+        out[t] = tf_mfma_h(fa[t][1], b_hi, out[t]);
+        piece(slot++); __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (s16 + 1 < K16) {
+#pragma unroll
+      for (int t = 0; t < TOUT; ++t) { fa[t][0] = fn[t][0]; if (TERMS == 3) fa[t][1] = fn[t][1]; }
+    }
+  }
+}
+
+// pair p of a finished layer: activate, split into S, and re-initialise the two accumulator registers with the NEXT layer's bias
+template <int TERMS>
+__device__ __forceinline__ void flow_post_pair(int p, f32x16 (&acc)[2], FlowS16& S, const float* __restrict__ bias_next /* LDS, or null */, int h) {
+  const int t = p >> 3, j = 2 * (p & 7);
+  flow_pair<TERMS, true>(acc[t][j], acc[t][j + 1], S.hi[p], S.lo[p]);
+  if (bias_next) { acc[t][j] = bias_next[(t * 16 + j) * 2 + h]; acc[t][j + 1] = bias_next[(t * 16 + j + 1) * 2 + h]; }
+}
+
+template <int MODE>
+__device__ __forceinline__ void coupling_pair(const float* __restrict__ net /*LDS*/, const float* __restrict__ ProwA, const float* __restrict__ ProwB,
+                                              float yA, float yB, int lane, f32x16 (&oA)[1], f32x16 (&oB)[1]) {
+  static_assert(MODE != 0, "f16 operand modes only");
+  constexpr int TERMS = MODE == 1 ? 1 : 3;
+  const int h = lane >> 5;
+  const tf_h8* nh = reinterpret_cast<const tf_h8*>(net) + lane;
+  f32x16 aA[2], aB[2];
+  FlowS16 SA, SB;
+  auto embed = [&](float y, FlowS16& S) {     // layer-1 sample part: embed3(y) (7 values + pad, Reshift 2x-1), k = rho(j, h), j = 0..3
+    float emb[8];
+    emb[0] = y;
+    tf_sincos_small(y, emb[1], emb[2]);
+    tf_sincos_small(y * 2.f, emb[3], emb[4]);
+    tf_sincos_small(y * 4.f, emb[5], emb[6]);
+    emb[7] = 0.5f;
+    float in4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) in4[j] = (h ? emb[4 + j] : emb[j]) * 2.f - 1.f;
+    flow_pair<TERMS, false>(in4[0], in4[1], S.hi[0], S.lo[0]);
+    flow_pair<TERMS, false>(in4[2], in4[3], S.hi[1], S.lo[1]);
+    S.hi[2] = S.hi[3] = 0u; S.lo[2] = S.lo[3] = 0u;          // inputs 8..15 of the k-step are padding
+  };
+  auto init_p = [&](const float* Prow, f32x16 (&a)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[t][j] = Prow[32 * t + tf_rho(j, h)];
+  };
+  auto none = [](int) {};
+  // (an asm-written operand that the very next MFMA reads needs its two wait states spelled out: the hazard recogniser does not see
+  // vector writes made inside an asm string)
+  // stage 0: tile A's layer-1 input
+  init_p(ProwA, aA);
+  embed(yA, SA);
+  asm volatile("s_nop 1");
+  // stage 1: L1(A) on the matrix cores | tile B's layer-1 input
+  init_p(ProwB, aB);
+  flow_mfma_stage<1, 2, TERMS>(nh + hL1 / 4, SA, aA, none);
+  embed(yB, SB);
+  asm volatile("s_nop 1");
+  // stage 2: L1(B) | post(A, layer 1) -> SA, aA <- b2
+  flow_mfma_stage<1, 2, TERMS>(nh + hL1 / 4, SB, aB, [&](int i) { flow_post_pair<TERMS>(i, aA, SA, net + hB2, h); });
+#pragma unroll
+  for (int p = 2 * TERMS; p < 16; ++p) flow_post_pair<TERMS>(p, aA, SA, net + hB2, h);
+  asm volatile("s_nop 1");
+  // pieces behind the MFMAs of a 4-k-step layer: TERMS == 3 -> 24 slots, pairs behind two of every three; TERMS == 1 -> 8 slots, two pairs each
+  auto spread = [&](int i, f32x16 (&acc)[2], FlowS16& S, const float* bias) {
+    if (TERMS == 3) { if (i % 3 != 2) flow_post_pair<TERMS>(2 * (i / 3) + i % 3, acc, S, bias, h); }
+    else { flow_post_pair<TERMS>(2 * i, acc, S, bias, h); flow_post_pair<TERMS>(2 * i + 1, acc, S, bias, h); }
+  };
+  // stage 3: L2(A) | post(B, layer 1) -> SB, aB <- b2
+  flow_mfma_stage<4, 2, TERMS>(nh + hL2 / 4, SA, aA, [&](int i) { spread(i, aB, SB, net + hB2); });
+  // stage 4: L2(B) | post(A, layer 2) -> SA, aA <- b3
+  flow_mfma_stage<4, 2, TERMS>(nh + hL2 / 4, SB, aB, [&](int i) { spread(i, aA, SA, net + hB3); });
+  // stage 5: L3(A) | post(B, layer 2) -> SB, aB <- b3
+  flow_mfma_stage<4, 2, TERMS>(nh + hL3 / 4, SA, aA, [&](int i) { spread(i, aB, SB, net + hB3); });
+  // stage 6: L3(B) | post(A, layer 3) -> SA ; oA <- b4
+  flow_mfma_stage<4, 2, TERMS>(nh + hL3 / 4, SB, aB, [&](int i) { spread(i, aA, SA, nullptr); });
+#pragma unroll
+  for (int j = 0; j < 16; ++j) oA[0][j] = net[hB4 + j * 2 + h];
+  // stage 7: L4(A) (4 k-steps x 1 tile) | post(B, layer 3) -> SB ; oB <- b4
+  flow_mfma_stage<4, 1, TERMS>(nh + hL4 / 4, SA, oA, [&](int i) {
+    if (TERMS == 3) { flow_post_pair<TERMS>(i, aB, SB, nullptr, h); }
+    else { flow_post_pair<TERMS>(4 * i, aB, SB, nullptr, h); flow_post_pair<TERMS>(4 * i + 1, aB, SB, nullptr, h);
+           flow_post_pair<TERMS>(4 * i + 2, aB, SB, nullptr, h); flow_post_pair<TERMS>(4 * i + 3, aB, SB, nullptr, h); }
+  });
+  if (TERMS == 3) {
+#pragma unroll
+    for (int p = 12; p < 16; ++p) flow_post_pair<TERMS>(p, aB, SB, nullptr, h);
+  }
+  asm volatile("s_nop 1");
+#pragma unroll
+  for (int j = 0; j < 16; ++j) oB[0][j] = net[hB4 + j * 2 + h];
+  // stage 8: L4(B)
+  flow_mfma_stage<4, 1, TERMS>(nh + hL4 / 4, SB, oB, none);
+}
+
 // Two tiles (A: rows 0..31, B: rows 32..63 of a 64-row group) share one spline pass: lane l evaluates the spline of row l,
 // i.e. lanes 0..31 need all 32 outputs of tile A's column (lane & 31) and lanes 32..63 those of tile B's.  Each lane keeps
 // the 16 outputs it holds of ITS tile and receives the other 16 from its partner lane (l ^ 32), which holds them in the
 // accumulators of the tile it does not need itself.
 __device__ __forceinline__ void gather_outputs(const f32x16 (&oA)[1], const f32x16 (&oB)[1], int h, float (&wv)[32]) {
+  // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second: afterwards the first holds
+  // {A's lanes 0..31 | B's lanes 0..31} -- for every lane the outputs rho(j, 0) of ITS tile -- and the second {A's 32..63 | B's 32..63},
+  // the outputs rho(j, 1).  One instruction per register instead of four selects and a cross-lane read.
+  (void)h;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const float own = h ? oB[0][j] : oA[0][j];
-    const float send = h ? oA[0][j] : oB[0][j];
-    const float recv = __shfl_xor(send, 32);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(oA[0][j]), __float_as_uint(oB[0][j]), false, false);
     const int r0 = (j & 3) + 8 * (j >> 2);
-    wv[r0] = h ? recv : own;
-    wv[r0 + 4] = h ? own : recv;
+    wv[r0] = __uint_as_float(r[0]);
+    wv[r0 + 4] = __uint_as_float(r[1]);
   }
 }
 
@@ -280,6 +430,13 @@ __device__ __forceinline__ void gather_outputs(const f32x16 (&oA)[1], const f32x
 // ~37 % of the time with two waves per SIMD, so the f16 variants are compiled for THREE (768 threads per workgroup, <= 168 VGPRs).
 #ifndef FLOW_WPB_H3
 #define FLOW_WPB_H3 12
+#endif
+#ifndef FLOW_PIPELINED
+#define FLOW_PIPELINED 0   // 1: coupling_pair (the two tiles of a group interleaved in one instruction stream).  Measured, bench's two launches:
+                           // one wave per SIMD 12.4 -> 11.7 ms, two 10.8 -> 10.6, three (default) 10.5 -> 10.7: what the interleave hides
+                           // inside a wave, a second and third wave already hide across waves.  tools/mfma_chain.hip: one wave alone runs a
+                           // 32x32x16 MFMA every 32.8 cycles, 40.7 with 7 vector instructions behind two of every three (18.7 cycles of
+                           // issue, 8 exposed), and waves that share a SIMD take turns by age rather than filling each other's gaps.
 #endif
 template <bool SAMPLE, int MODE>
 __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kernel(const float* __restrict__ netfrag /*[2][kNetFloats]*/,
@@ -300,6 +457,9 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
   // (lane & 31) resp. 32 + (lane & 31) on this lane's MFMA column, so every spline is evaluated once (not once per half)
   const long long n_groups = (m + 63) / 64;
   const int h = lane >> 5, col = lane & 31;
+#ifdef FLOW_STAGGER   // dev-only experiment: waves that share a SIMD (wave, wave + 4, wave + 8) start a third of a group apart
+  for (int d = 0; d < (wave >> 2); ++d) __builtin_amdgcn_s_sleep(FLOW_STAGGER);
+#endif
   for (long long grp = (long long)blockIdx.x * waves_per_block + wave; grp < n_groups;
        grp += (long long)gridDim.x * waves_per_block) {
     asm volatile("" ::: "memory");  // keep the LDS weight fragments out of registers across tiles (LICM)
@@ -323,6 +483,14 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
       x1 = fminf(fmaxf(xin[2 * row + 1], 1e-6f), 1.f - 1e-6f);
       lj = 0.f;
     }
+#ifdef FLOW_STAMPS   // dev-only: shader-clock stamps of one 64-row group of workgroup 0 (its 9th), per wave
+    unsigned long long st[12]; int n_st = 0;
+    const bool st_on = blockIdx.x == 0 && grp == (long long)wave + 8LL * gridDim.x * waves_per_block;
+#define FLOW_STAMP() do { if (st_on && n_st < 12) st[n_st++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FLOW_STAMP() do {} while (0)
+#endif
+    FLOW_STAMP();
     const int ptA = __shfl((int)pt, col), ptB = __shfl((int)pt, 32 + col);   // pn < 2^31 (checked by the launcher)
     float wv[32];
     f32x16 oA[1], oB[1];
@@ -331,15 +499,27 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
     // one coupling block for both tiles: `keep` is the conditioning coordinate of this lane's own row
     auto run_block = [&](const float* net, long long pbase, float keep) {
       const float kA = __shfl(keep, col), kB = __shfl(keep, 32 + col);
+#if FLOW_PIPELINED
+      if (MODE != 0) {
+        coupling_pair<MODE == 0 ? 3 : MODE>(net, P + (pbase + ptA) * 64, P + (pbase + ptB) * 64, kA, kB, lane, oA, oB);
+        FLOW_STAMP(); FLOW_STAMP();
+      } else
+#endif
+      {
       coupling_net<MODE>(net, P + (pbase + ptA) * 64, kA, lane, oA);
+      FLOW_STAMP();
       coupling_net<MODE>(net, P + (pbase + ptB) * 64, kB, lane, oB);
+      FLOW_STAMP();
+      }
       gather_outputs(oA, oB, h, wv);
     };
     if (SAMPLE) {
       run_block(lds, 0, x0);                                             // block 0 keeps x0, moves x1
       pw_inverse(x1, wv, t, l, bin0); x1 = t; lj += l;
+      FLOW_STAMP();
       run_block(lds + NF, pn, x1);                                       // block 1 keeps x1, moves x0
       pw_inverse(x0, wv, t, l, bin1); x0 = t; lj += l;
+      FLOW_STAMP();
     } else {
       run_block(lds + NF, pn, x1);
       pw_forward(x0, wv, t, l, bin1); x0 = t; lj += l;
@@ -352,6 +532,12 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
       out_lj[row] = lj;
       if (bins) reinterpret_cast<int2*>(bins)[row] = make_int2(bin0, bin1);
     }
+#ifdef FLOW_STAMPS
+    FLOW_STAMP();
+    if (SAMPLE && st_on && lane == 0 && n_st == 8)
+      printf("flow<%d> wave %d: net A %llu | net B %llu | gather + spline %llu | net A %llu | net B %llu | gather + spline %llu | store %llu | group %llu ticks\n", MODE, wave,
+             st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[7] - st[0]);
+#endif
   }
 }
 
