@@ -424,6 +424,10 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                   uint8_t* live /* [pn,T] = any(wgt != 0), may be NULL */,
                   float* flow_logjac /* [pn, sd+ss] = log max(4 pi^2 HoV sin(theta), 1e-6) of the flow slots (NIS loss,
                                         fields.py:1275,1312), may be NULL */,
+                  const int32_t* slot_of_pos /* [T] device permutation or NULL: row j of a point's dirs / wgt / live holds slot
+                                                slot_of_pos[j] -- the rays of a point stored in TRAVERSAL order, so that tf_bvh_trace
+                                                (called without slot_order) reads and writes consecutive rows from consecutive
+                                                lanes; spec_mask / flow_logjac stay indexed by sample.  NULL: row = slot */,
                   tf_stream_t stream);
 /* The sampler of the NON-NIS pass of shade_mixed (nis_sample False / flows not yet active; the pass whose colours
  * MCShadingNetwork.forward returns in eval, fields.py:1467-1473): nf fixed cosine directions (sample_diffuse_directions,
@@ -447,7 +451,9 @@ int tf_shade_dirs_bwd(const float* normals, const float* view, const float* meta
  * miss branch is never written or read.  Zero-weight slots are skipped. */
 int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit, const float* hit_lights,
                         const float* env_base, int32_t env_res, float near_eps, int64_t pn, int32_t n_diffuse, int32_t ss,
-                        float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);
+                        float* colors, float* diffuse_lin, float* specular_lin,
+                        const int32_t* slot_of_pos /* as tf_shade_dirs: the lobe of row j is that of slot slot_of_pos[j]; or NULL */,
+                        tf_stream_t stream);
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);

@@ -28,7 +28,7 @@
 #define BVH_STACK 32       // per-ray traversal stack entries; the builder bounds the tree depth to match
 #endif
 #ifndef BVH_LDS_STACK
-#define BVH_LDS_STACK 12   // of which in LDS (the rest is a per-lane scratch array, touched by the rare deep pile-ups only)
+#define BVH_LDS_STACK 10   // of which in LDS (the rest is a per-lane scratch array, touched by the rare deep pile-ups only; 10 vs 12: 15.2 vs 15.4 ms)
 #endif
 #ifndef BVH_WAVES
 #define BVH_WAVES 7        // resident 256-thread blocks per CU the kernel is compiled for (register budget): 72 registers hold the step without
@@ -453,9 +453,21 @@ extern "C" void tf_bvh_clock(unsigned long long* out) { hipMemcpyFromSymbol(out,
 #define BVH_XCD_POOLS 0     // 1: one unit pool per XCD over Morton-sorted origins (origin_order).  Measured 18.0-18.3 ms vs 17.1-17.3: the
                             // traversal does not respond to L2 locality either (TCC hit rate 60-66 % in every variant)
 #endif
-template <bool DYN, bool SPINE>
+#ifndef BVH_STAGE
+#define BVH_STAGE 0         // 1 (dev switch): SPINE, rays of a point contiguous (no slot_order): the direction rows and live flags of the wave's
+                            // next 64 rays are copied into LDS by LDS-DMA one refill AHEAD of their use, so that a refill (600 per wave on
+                            // the bench) does not stall every lane of the wave on a fetch from HBM.  Results identical; measured SLOWER
+                            // (17.3 vs 15.2 ms per 201 M rays): the fetch was not what a refill waits for (its spine walk and start-up
+                            // arithmetic are), and the window re-fetch, 10 more spilled registers and the extra waits cost more
+#endif
+template <bool DYN, bool SPINE, bool STAGED = false>
 __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) {
   __shared__ int stack[(BVH_LDS_STACK + 1) * 256];   // + one dummy row: the target of predicated-off pushes
+  __shared__ float dstage[STAGED ? 4 * 2 * 256 : 1];      // per wave: two windows of 64 direction rows (LDS-DMA of 12 bytes per lane lands at a 16-byte stride)
+  __shared__ unsigned lstage[STAGED ? 4 * 2 * 64 : 1];    // ... and of 64 live flags (one dword each)
+  long long st_base = -1;                            // wave-uniform: first ray of the window staged last
+  int st_buf = 0;
+  float uox = 0.f, uoy = 0.f, uoz = 0.f;             // wave-uniform: origin row of the current unit
   __shared__ uint4 spine[SPINE ? 4 * BVH_SPINE_MAX : 1];
   __shared__ uint4 near_tree[SPINE && BVH_NEAR > 0 ? 4 * 2 * BVH_NEAR : 1];   // per wave: the records of the subtree around the unit's origin
   int spine_n = 0, spine_end = 0;                    // wave-uniform
@@ -503,6 +515,34 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     cur = 0;
     if (A.live && !A.live[id]) cur = BVH_NONE;   // zero weight in the integral: reported as a miss, never traversed
 #ifdef BVH_ABLATE_TRAVERSE   // dev-only timing ablation: ray fetch + scheduling + result stores only
+    cur = BVH_NONE;
+#endif
+  };
+  constexpr bool staged = STAGED;
+  auto stage_issue = [&](long long seq0) {           // window [seq0, seq0 + 64) -> the buffer not read at the moment
+    st_buf ^= 1; st_base = seq0;
+    const long long row = min(seq0 + lane, A.m - 1);
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(dstage + ((tid >> 6) * 2 + st_buf) * 256));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(A.d + 3 * row) : "memory");
+    if (A.live) {
+      const unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned*)(lstage + ((tid >> 6) * 2 + st_buf) * 64));
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_ubyte %1, off" ::"s"(lb), "v"(A.live + row) : "memory");
+    }
+  };
+  auto start_ray_staged = [&](long long seq, int k) {   // ray `seq` = row k of the staged window; its origin row is the unit's
+    rid = seq;
+    const float* dsrc = dstage + ((tid >> 6) * 2 + st_buf) * 256 + 4 * k;
+    dx = dsrc[0]; dy = dsrc[1]; dz = dsrc[2];
+    ox = __fadd_rn(__fadd_rn(uox, __fmul_rn(dx, A.off0)), __fmul_rn(A.off1, dx));
+    oy = __fadd_rn(__fadd_rn(uoy, __fmul_rn(dy, A.off0)), __fmul_rn(A.off1, dy));
+    oz = __fadd_rn(__fadd_rn(uoz, __fmul_rn(dz, A.off0)), __fmul_rn(A.off1, dz));
+    const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz;
+    Ax = A.scl[0] * ix; Ay = A.scl[1] * iy; Az = A.scl[2] * iz;
+    Bx = (A.org[0] - ox) * ix; By = (A.org[1] - oy) * iy; Bz = (A.org[2] - oz) * iz;
+    best = BVH_MAX_DIST; best_tri = -1; sp = 0;
+    cur = 0;
+    if (A.live && !lstage[((tid >> 6) * 2 + st_buf) * 64 + k]) cur = BVH_NONE;
+#ifdef BVH_ABLATE_TRAVERSE
     cur = BVH_NONE;
 #endif
   };
@@ -688,6 +728,13 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
             const long long oid = A.origin_order ? (long long)A.origin_order[ou] : ou;
             q_next = oid * A.rays_per_origin + part * A.unit_size;
             q_end = min(q_next + A.unit_size, (oid + 1) * A.rays_per_origin);
+            if (staged) {
+              stage_issue(q_next);                   // in flight while the spine is walked
+              // one origin row per unit, the same for every lane: kept in scalar registers
+              uox = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(A.o[3 * oid])));
+              uoy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(A.o[3 * oid + 1])));
+              uoz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(A.o[3 * oid + 2])));
+            }
             build_spine(oid);
           } else {
           if (lane == 0) base = atomicAdd(A.counter, (unsigned long long)grab);
@@ -706,6 +753,24 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #ifdef BVH_CLOCK
         const unsigned long long ck_s0 = BVH_TICK();
 #endif
+        if (staged) {
+          // the window [q_next, q_next + 64) was requested at the end of the previous refill (or by the unit claim above, whose
+          // spine build ends in a full wait); a second round of the same refill reads a window requested a moment ago
+          if (st_base != q_next) stage_issue(q_next);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // free when nothing is in flight
+          if (want) {
+            const int k = __popcll(wb & lt_mask);
+            const long long id = q_next + k;
+            if (id < q_end) {
+              start_ray_staged(id, k);
+              if (cur == BVH_NONE) retire();
+              else spine_walk();
+            }
+          }
+          q_next = min(q_next + nw, q_end);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the window has been read before its buffer can be targeted again (two refills on)
+          if (q_next < q_end) stage_issue(q_next);
+        } else {
         if (want) {
           const long long id = q_next + __popcll(wb & lt_mask);
           if (id < q_end) {
@@ -715,6 +780,7 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           }
         }
         q_next = min(q_next + nw, q_end);
+        }
 #ifdef BVH_CLOCK
         { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ck_startray += BVH_TICK() - ck_s0; }
 #endif
@@ -923,7 +989,7 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
     static int resident = 0;    // blocks per CU the hardware admits (registers / LDS), queried once
     if (!resident) {
       int nb = 0;
-      hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true, true>, 256, 0);
+      hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true, true, true>, 256, 0);
       resident = (e2 == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;
     }
     long long blocks = (m + 255) / 256;
@@ -936,7 +1002,8 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
     A.unit_parts = (int)((rays_per_origin + BVH_CHUNK_MAX - 1) / BVH_CHUNK_MAX);
     A.unit_size = (int)((rays_per_origin + A.unit_parts - 1) / A.unit_parts);
     A.spine_radius = (fabsf(origin_offset0) + fabsf(origin_offset1)) * 1.001f + 1e-6f;
-    if (use_spine) bvh_trace_kernel<true, true><<<(unsigned)blocks, 256, 0, stream>>>(A);
+    if (use_spine && BVH_STAGE && !slot_order) bvh_trace_kernel<true, true, true><<<(unsigned)blocks, 256, 0, stream>>>(A);
+    else if (use_spine) bvh_trace_kernel<true, true><<<(unsigned)blocks, 256, 0, stream>>>(A);
     else bvh_trace_kernel<true, false><<<(unsigned)blocks, 256, 0, stream>>>(A);
   } else {
     A.unit_parts = 1; A.unit_size = 1; A.spine_radius = 0.f;

@@ -82,12 +82,15 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ ang_s, const float* __restrict__ logq_s, const float* __restrict__ fixed_s,
     const float* __restrict__ az_jitter_s, int ss, long long pn, float* __restrict__ dirs,
     float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live,
-    float* __restrict__ flow_logjac) {
+    float* __restrict__ flow_logjac, const int* __restrict__ slot_of_pos) {
   const int T = sd + nf + ss;
   long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= pn * T) return;
   const long long pt = e / T;
-  const int slot = (int)(e % T);
+  // row e of dirs / wgt / live is POSITION e % T of its point; the slot (which sample of which direction set) it holds is
+  // slot_of_pos[position] when the caller stores the rays of a point in traversal order (tf_bvh_trace then reads and writes
+  // consecutive rows from consecutive lanes), the position itself otherwise.  spec_mask / flow_logjac stay indexed by sample.
+  const int slot = slot_of_pos ? slot_of_pos[(int)(e % T)] : (int)(e % T);
   Frame F;
   make_frame(normals + 3 * pt, F);
   float v[3] = {view[3 * pt], view[3 * pt + 1], view[3 * pt + 2]};
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
                                                                const float* __restrict__ hit_lights, const float* __restrict__ env,
                                                                int env_res, float near_eps, long long pn, int n_diff, int ss,
                                                                float* __restrict__ colors, float* __restrict__ diffuse_lin,
-                                                               float* __restrict__ specular_lin) {
+                                                               float* __restrict__ specular_lin, const int* __restrict__ slot_of_pos) {
   const int lane = threadIdx.x & 63;
   const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pt >= pn) return;
@@ -323,7 +326,8 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
       }
     }
     const float c0 = w0 * l0, c1 = w1 * l1, c2 = w2 * l2;
-    if (t < n_diff) { d[0] += c0; d[1] += c1; d[2] += c2; } else { s[0] += c0; s[1] += c1; s[2] += c2; }
+    const int slot = slot_of_pos ? slot_of_pos[t] : t;      // rows in traversal order: the lobe a row belongs to follows its slot
+    if (slot < n_diff) { d[0] += c0; d[1] += c1; d[2] += c2; } else { s[0] += c0; s[1] += c1; s[2] += c2; }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k)
@@ -342,13 +346,13 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
 extern "C" int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit,
                                    const float* hit_lights, const float* env_base, int32_t env_res, float near_eps, int64_t pn,
                                    int32_t n_diffuse, int32_t ss, float* colors, float* diffuse_lin, float* specular_lin,
-                                   tf_stream_t stream) {
+                                   const int32_t* slot_of_pos, tf_stream_t stream) {
   TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && env_res > 0, TF_ESHAPE, "tf_shade_reduce_env: negative size / env_res <= 0");
   if (pn == 0) return TF_OK;
   TF_REQUIRE(wgt && dirs && depth && hit && hit_lights && env_base && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
   shade_reduce_env_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, dirs, depth, hit, hit_lights, env_base, env_res,
                                                                             near_eps, pn, n_diffuse, ss, colors, diffuse_lin,
-                                                                            specular_lin);
+                                                                            specular_lin, slot_of_pos);
   TF_LAUNCH_CHECK("tf_shade_reduce_env");
   return TF_OK;
 }
@@ -366,7 +370,7 @@ static int shade_dirs_launch(const float* normals, const float* view, const floa
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, const float* fixed_s,
                              const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
-                             uint8_t* live, float* flow_logjac, tf_stream_t stream, const char* who) {
+                             uint8_t* live, float* flow_logjac, const int32_t* slot_of_pos, tf_stream_t stream, const char* who) {
   TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "%s: negative size", who);
   if (pn == 0 || sd + nf + ss == 0) return TF_OK;
   TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "%s: null pointer", who);
@@ -377,7 +381,7 @@ static int shade_dirs_launch(const float* normals, const float* view, const floa
   shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
                                                                           logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, fixed_s,
                                                                           az_jitter_s, ss, pn, dirs, wgt, spec_mask, live,
-                                                                          fixed_s ? nullptr : flow_logjac);
+                                                                          fixed_s ? nullptr : flow_logjac, slot_of_pos);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -386,9 +390,9 @@ extern "C" int tf_shade_dirs(const float* normals, const float* view, const floa
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
                              int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
-                             tf_stream_t stream) {
+                             const int32_t* slot_of_pos, tf_stream_t stream) {
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
-                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, stream, "tf_shade_dirs");
+                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, stream, "tf_shade_dirs");
 }
 
 extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, const float* metallic, const float* roughness,
@@ -396,7 +400,7 @@ extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, cons
                                    const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
                                    uint8_t* spec_mask, uint8_t* live, tf_stream_t stream) {
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, nullptr, nullptr, 0, fixed_d, az_jitter, nf, nullptr, nullptr,
-                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, stream, "tf_shade_dirs_fixed");
+                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, nullptr, stream, "tf_shade_dirs_fixed");
 }
 
 extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,

@@ -715,7 +715,9 @@ def view_angles(normals, view):
     return va
 
 
-def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False):
+def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False,
+               slot_of_pos=None):
+    """slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order)."""
     lib = L.load()
     pn = normals.shape[0]
     sd = 0 if ang_d is None else ang_d.shape[1]
@@ -733,7 +735,7 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
                               _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
                               _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(g(ang_s)),
                               _p(g(None if logq_s is None else logq_s.reshape(pn, ss))), ss, pn, _p(dirs), _p(wgt),
-                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _stream()), "tf_shade_dirs")
+                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _p(slot_of_pos, torch.int32), _stream()), "tf_shade_dirs")
     if want_logjac:
         return dirs, wgt, mask.bool(), live, logjac
     return dirs, wgt, mask.bool(), live
@@ -780,7 +782,7 @@ def inner_light_encode(pos, dirs, nrm, idx=None, count=None):
     return X
 
 
-def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, ss, near_eps=1e-5):
+def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, ss, near_eps=1e-5, slot_of_pos=None):
     """colors / diffuse / specular sums with the miss branch of get_lights evaluated inside the reduction."""
     lib = L.load()
     pn = wgt.shape[0]
@@ -790,7 +792,8 @@ def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, 
     sl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     env_base = _f(env_base)
     L.check(lib.tf_shade_reduce_env(_p(_f(wgt)), _p(_f(dirs)), _p(_f(depth)), _p(hit_u8, torch.uint8), _p(_f(hit_lights)), _p(env_base),
-                                    env_base.shape[1], float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl), _stream()),
+                                    env_base.shape[1], float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl),
+                                    _p(slot_of_pos, torch.int32), _stream()),
             "tf_shade_reduce_env")
     return colors, dl, sl
 

@@ -104,7 +104,15 @@ class ShadeOutputs(dict):
     sample) has a data-dependent length, so building it forces a device->host sync; it is derived from `specular_mask` on
     first access instead of on every call (the eval integral never reads it)."""
 
+    _PER_RAY = ("dirs", "wgt", "hit", "live", "hit_lights", "depth")
+
     def __missing__(self, key):
+        if key in self._PER_RAY and "_pos_" + key in self:
+            # MCShader.shade keeps a point's rays in TRAVERSAL order (row j = slot slot_of_pos[j]); callers that read a per-ray array
+            # get it in slot order, gathered on first access (the throughput path never asks)
+            v = self["_pos_" + key].index_select(1, self["_pos_of_slot"])
+            self[key] = v
+            return v
         if key == "lights":     # [pn,T,3] light of every ray (fields.py:951-975): hit rows from the inner-light net, the rest env light
             hit = self["hit"]
             pn, T = hit.shape
@@ -213,6 +221,13 @@ class MCShader:
             self._order[key] = torch.from_numpy(np.concatenate(parts).astype(np.int32)).to(self.device)
         return self._order[key]
 
+    def pos_of_slot(self, sn_d, sn_s):
+        """Inverse of slot_order (int64, for index_select): the row of a point's per-ray arrays that holds slot s."""
+        key = ("inv", sn_d, sn_s)
+        if key not in self._order:
+            self._order[key] = torch.argsort(self.slot_order(sn_d, sn_s).long())
+        return self._order[key]
+
     def trace_and_inner(self, pts_rep, dirs, live=None, slot_order=None, origin_order=None):
         """Hit branch of get_lights (fields.py:951-975): BVH visibility + inner-light MLP on the rays that hit.
         -> hit_lights [M,3] (rows of rays that hit; the others are uninitialised), hit [M] bool, depth [M], inters [M,3]."""
@@ -273,8 +288,13 @@ class MCShader:
             ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                           cache=self.flow_s.cache)
         tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
+        # a point's rays are STORED in traversal order (row j holds slot order[j]): the traversal then reads and writes consecutive
+        # rows from consecutive lanes instead of going through the permutation for every ray; only the kernels that need to know
+        # WHICH sample a row is (direction construction, the lobe split of the reduction) take the permutation
+        order = self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None
         with tm.stage("shade_dirs"):
-            dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s)
+            dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
+                                                    slot_of_pos=order)
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built
         # origins are handed to the traversal in Morton order (each XCD then works on one contiguous eighth of the scene); nothing
@@ -282,13 +302,19 @@ class MCShader:
         with tm.stage("point_prep"):
             oorder = ops.morton_order(pts, self.aabb) if self.sort_origins and T >= 64 else None
         hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
-                                                              slot_order=self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None,
                                                               origin_order=oorder)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         with tm.stage("shade_reduce"):
             # environment light of the rays that missed is evaluated inside the reduction (no [pn,T,3] light array)
-            colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, n_diff, sn_specular)
-        return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
-                    specular_mask=smask, hit=hit.reshape(pn, T), live=live, view_angles=va,
-                    diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s, specular_logq=lq_s, dirs=dirs, wgt=wgt,
-                    hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=n_diff)
+            colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, n_diff, sn_specular,
+                                                  slot_of_pos=order)
+        out = ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
+                           specular_mask=smask, view_angles=va, diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s,
+                           specular_logq=lq_s, _env=self.env, n_diffuse=n_diff)
+        per_ray = dict(hit=hit.reshape(pn, T), live=live, dirs=dirs, wgt=wgt, hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T))
+        if order is None:
+            out.update(per_ray)
+        else:
+            out.update({"_pos_" + k: v for k, v in per_ray.items()})
+            out["_pos_of_slot"] = self.pos_of_slot(sn_diffuse, sn_specular)
+        return out

@@ -84,8 +84,9 @@ def test_bvh_full_mesh_paths_agree_and_hits_lie_on_mesh(dev):
 
 def test_shade_full_size_invariances(dev):
     """BASELINE configs[2] shader (R = 512 fields, 128 flow samples per lobe, 512 fixed directions) on 4096 points: colours
-    are finite, unchanged bit for bit by zero-weight ray culling and by the direction-sorted traversal order, and independent
-    of how the points are batched."""
+    are finite, unchanged bit for bit by zero-weight ray culling, unchanged up to the order of the per-pixel sum (2e-6) by storing
+    and tracing a point's rays direction-sorted instead of in slot order (hit flags identical), and independent of how the points
+    are batched."""
     from tensoflow_amd.shading import MCShader
     from tensoflow_amd.synth import random_mc_state, sphere_surface_points, sphere_torus_mesh
     sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
@@ -99,7 +100,8 @@ def test_shade_full_size_invariances(dev):
     sh.cull_dead_rays = False
     assert torch.equal(sh.shade(pts, view, nrm, 128, 128)["colors"], c)
     sh.cull_dead_rays, sh.sort_rays = True, False
-    assert torch.equal(sh.shade(pts, view, nrm, 128, 128)["colors"], c)
+    plain = sh.shade(pts, view, nrm, 128, 128)
+    assert torch.equal(plain["hit"], out["hit"]) and float((plain["colors"] - c).abs().max()) < 2e-6
     sh.sort_rays = True
     half = sh.shade(pts[:2048].contiguous(), view[:2048].contiguous(), nrm[:2048].contiguous(), 128, 128)["colors"]
     assert torch.equal(half, c[:2048])

@@ -353,9 +353,13 @@ def test_shade_golden(golden, dev, tag):
     out2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
     assert torch.equal(out2["hit"][:, :nd].cpu(), ref["diffuse_hit"])
     assert torch.equal(out2["colors"], out["colors"])                                 # culling changes nothing, bit for bit
-    sh.cull_dead_rays, sh.sort_rays = True, False                                     # traversal in slot order instead of direction-sorted
+    sh.cull_dead_rays, sh.sort_rays = True, False                                     # rays stored and traced in slot order instead of direction-sorted
     out3 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
-    assert torch.equal(out3["hit"], out["hit"]) and torch.equal(out3["colors"], out["colors"])
+    # every per-ray quantity is the same bit for bit; the pixel is the same sum taken over the rows in another order
+    for k in ("hit", "dirs", "wgt", "depth"):
+        assert torch.equal(out3[k], out[k]), k
+    assert torch.equal(out3["hit_lights"][out["hit"]], out["hit_lights"][out["hit"]])
+    assert rel_err(out3["colors"].cpu(), out["colors"].cpu()) < 2e-6
     order = sh.slot_order(sn_d, sn_s).cpu().long()
     assert torch.equal(order.sort().values, torch.arange(sn_d + n_fd + sn_s))         # a permutation of the slots
 
