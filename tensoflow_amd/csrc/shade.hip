@@ -312,15 +312,20 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
   float d[3] = {0, 0, 0}, s[3] = {0, 0, 0};
   for (int t = lane; t < T; t += 64) {
     const long long r = pt * T + t, e = r * 3;
+    // all four rows are requested together (85 % of the rays miss and need every one of them).  Measured neutral against fetching
+    // them behind the branches (2.65 ms either way): the kernel is held by the four texel gathers + ~130 vector instructions of the
+    // environment lookup per missing ray, not by the streams
     const F3 w = ld3(wgt + e);
+    const F3 dd = ld3(dirs + e);
+    const unsigned char hr = hit[r];
+    const float dr = depth[r];
     const float w0 = w.x, w1 = w.y, w2 = w.z;
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
-      if (hit[r]) {
+      if (hr) {
         const F3 hl = ld3(hit_lights + e);
         l0 = hl.x; l1 = hl.y; l2 = hl.z;
-      } else if (depth[r] > near_eps) {
-        const F3 dd = ld3(dirs + e);
+      } else if (dr > near_eps) {
         cube_fetch_rgb(env, env_res, dd.x, dd.y, dd.z, l0, l1, l2);
         l0 = fast_exp(l0); l1 = fast_exp(l1); l2 = fast_exp(l2);
       }
