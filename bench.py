@@ -234,8 +234,45 @@ def flow_count_probe(sh, pts, view, nrm, S, steps):
                 rays_per_s=pn * (2 * S + 512) / dt)
 
 
+def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800):
+    """Secondary figure (BASELINE configs[4] at one GPU's share): ONE full 800 x 800 frame -- primary visibility of the 640 000 pinhole
+    rays through the mesh BVH, then the flow-sampled integral with 512 samples per lobe (512 + 512 + 512 = 1 536 secondary rays per
+    surface point) on every pixel that sees the object, plain-f16 operands in the flow nets and the inner-light MLP ('fp16 ... flow';
+    the VM fields stay fp32).  The camera rays are resident in HBM before the timed region; the frame's
+    data-dependent point count costs one host sync per frame, as in MaterialRenderer.nvs."""
+    from tensoflow_amd import ops
+    from tensoflow_amd.synth import pinhole_rays
+    o, d, _, _ = [torch.from_numpy(a).to(device) for a in pinhole_rays(hw * hw, seed=2, h=hw, w=hw)]
+    keep = sh.precision
+    sh.precision = ops.PREC_F16
+
+    def frame():
+        pos, nrm, depth, hit = sh.bvh.trace(o, d)
+        pts, n, v = pos[hit], nrm[hit], -d[hit]
+        img = torch.ones(hw * hw, 3, device=device)
+        cols = [sh.shade(pts[c:c + chunk].contiguous(), v[c:c + chunk].contiguous(), n[c:c + chunk].contiguous(), S, S)["colors"]
+                for c in range(0, pts.shape[0], chunk)]
+        if cols:
+            img[hit] = torch.cat(cols)
+        return img, pts.shape[0]
+
+    try:
+        frame()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            img, n_pts = frame()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        sh.precision = keep
+    return dict(workload=f"{hw}x{hw} frame: {hw * hw} primary rays, {n_pts} surface points x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets "
+                         "and the inner-light MLP, fp32 VM fields", ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
+                secondary_rays_per_s=n_pts * (2 * S + 512) / dt, finite=bool(torch.isfinite(img).all()))
+
+
 def fp16_probe(sh, pts, view, nrm, S, steps, ref_colors):
-    """Secondary figure (BASELINE configs[4]: 'fp16 field + flow'): the headline pass with plain-f16 decoder operands
+    """Secondary figure (the arithmetic of BASELINE configs[4], 'fp16 field + flow', on the headline workload): the headline pass with plain-f16 decoder operands
     (TF_PREC_F16: one MFMA per product term in the flow coupling nets and the inner-light MLP, fp32 accumulate) and its PSNR
     against the fp32-accurate (f16x3) colours of the same points.  Not a parity-grade number: reported, never the headline."""
     from tensoflow_amd import ops
@@ -265,7 +302,7 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
     """Secondary figure: one TRAINING step of the material stage (BASELINE configs[2], train mode): MCShadingNetwork.forward
     with autograd (shade_mixed + both NIS losses, fields.py:1075-1335) + backward over every trainable tensor, on the
     reference's batch of 2048 surface points.  Forward and the HIP backward ops (VM gather / BRDF weights / cube map / flow
-    log-density) run in libtensoflow_hip.so; the inner-light weight gradients are library GEMMs."""
+    log-density) and every dense layer of the step (tf_linear_fwd / tf_linear_bwd, exact fp32 MFMA) run in libtensoflow_hip.so: no library GEMM."""
     from tensoflow_amd.network.fields import MCShadingNetwork
     from tensoflow_amd.synth import sphere_surface_points
     torch.manual_seed(6033)
@@ -300,7 +337,7 @@ def shape_train_probe(device, steps, n_rays=1024):
     C = 36, 3 mips; the reference's batch of 1024 rays): sample_ray (64 + 4 x 16 importance samples), render_core with autograd
     (SdfAlphaFn, differentiable ShapeShadingNetwork, CompositeFn), eikonal / sparse / hessian / TV terms, backward over every
     trainable tensor.  HIP: field gathers and their scatter, the fused 7-tap forward, compositing forward / backward, cube-map
-    lookups and their gradients, EnvLight.build_mips and its adjoints; library GEMMs: decoder and shading-MLP products."""
+    lookups and their gradients, EnvLight.build_mips and its adjoints, and the decoder / shading-MLP products (tf_linear_*): no library GEMM."""
     from tensoflow_amd.network.shapeRenderer import ShapeRenderer
     from tensoflow_amd.synth import pinhole_rays, random_sdf_state, random_shape_shader_state
     R = 300
@@ -766,6 +803,11 @@ def main():
                 line["config3_flow256"] = flow_count_probe(sh, pts, view, nrm, 256, max(2, args.steps))
             except Exception as e:
                 line["config3_flow256"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train and args.precision == "f16x3":
+            try:
+                line["config4_frame512"] = relight_frame_probe(sh, device, 2)
+            except Exception as e:
+                line["config4_frame512"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train:
             try:
                 line["shape_train"] = shape_train_probe(device, max(2, args.steps))
