@@ -4,8 +4,12 @@
 * `TensoSDFSynDatabase`      -- dataset/database.py:479-579: frames of the listed splits; RGB composited over white (or black)
                                 with the alpha channel and quantised to uint8 exactly like the reference; mask = alpha;
                                 K from `camera_angle_x`; `get_pose` halves the translation (scale_factor 0.5).
-                                PNG decoding: PIL (the reference uses skimage.io.imread -- same 8-bit samples).  The test-split
-                                extras (`_normal.png`; `_diffColor.exr` needs an EXR decoder, absent here) are not read.
+                                PNG decoding: PIL (the reference uses skimage.io.imread -- same 8-bit samples).  The test split's
+                                extras are read on request: `_normal.png` -> [-1,1] over a (0,0,1) background (:519-527),
+                                `_diffColor.exr` -> rgb x alpha through hdr_io.read_exr (:530-535; cv2 in the reference).
+* `ORBDatabase`              -- dataset/database.py:723-802 (Stanford-ORB in the Blender layout): one split ('train' or 'test'), RGB(A)
+                                PNGs with the object mask in a SEPARATE file (`<split>_mask/...png`), no pose rescaling.
+* `parse_database_name`      -- :804-823 for the database types this build reads ('tensoSDF/<model>', 'orb/<model>').
 * `construct_ray_batch_nerf` -- shapeRenderer.py:471-518: pinhole rays through pixel centres in the OpenGL camera frame, cone radii
                                 from neighbouring-ray distances, `rays_cos = 1 / |rays_d|`, colours, masks, per-ray pose rows.
 * `RayTable`                 -- `_shuffle_train_batch` / `train_step`'s slicing (:411-415, :778-782) with the data-parallel split of
@@ -20,10 +24,11 @@ import torch.nn.functional as F
 
 
 class TensoSDFSynDatabase:
-    def __init__(self, root, splits=("train", "val"), white_bg=True):
+    def __init__(self, root, splits=("train", "val"), white_bg=True, load_normals=False, load_diff_color=False):
         from PIL import Image
         self.root = root
         self.imgs_all, self.masks_all, self.pose_all = [], [], []
+        self.normals_all, self.diffColor_all = [], []
         meta = None
         for s in splits:
             with open(os.path.join(root, f"transforms_{s}.json")) as fp:
@@ -38,6 +43,16 @@ class TensoSDFSynDatabase:
                 self.imgs_all.append((rgb * 255.0).astype(np.uint8))
                 self.masks_all.append(mask)
                 self.pose_all.append(np.array(fr["transform_matrix"], dtype=np.float64))
+                if load_normals:
+                    nrm = np.asarray(Image.open(os.path.join(root, fr["file_path"] + "_normal.png")))[..., :3] / 255
+                    nrm = (nrm - 0.5) * 2.0
+                    self.normals_all.append(nrm * mask + (1 - mask) * np.array([0, 0, 1]))
+                if load_diff_color:
+                    from .hdr_io import read_exr
+                    dc, names = read_exr(os.path.join(root, fr["file_path"] + "_diffColor.exr"))
+                    if names[:3] != ["R", "G", "B"] or dc.shape[-1] < 4:
+                        raise ValueError(f"{fr['file_path']}_diffColor.exr: RGBA expected, got channels {names}")
+                    self.diffColor_all.append(dc[..., :3] * dc[..., 3:4])
         if not self.imgs_all:
             raise ValueError(f"{root}: no frames in splits {splits}")
         self.H, self.W = self.imgs_all[0].shape[:2]
@@ -45,6 +60,12 @@ class TensoSDFSynDatabase:
         self.K = np.array([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]], dtype=np.float32)
         self.scale_factor = 0.5
         self.img_ids = list(range(len(self.imgs_all)))
+
+    def get_normal(self, i):
+        return self.normals_all[int(i)]
+
+    def get_albedo(self, i):
+        return self.diffColor_all[int(i)]
 
     def get_image(self, i):
         return self.imgs_all[i]
@@ -71,6 +92,50 @@ class TensoSDFSynDatabase:
                 "masks": torch.from_numpy(np.stack([self.get_mask(i) for i in ids]).astype(np.float32))[:, None],
                 "Ks": torch.from_numpy(np.stack([self.get_K(i) for i in ids])),
                 "poses": torch.from_numpy(np.stack([self.get_pose(i) for i in ids]).astype(np.float32))}
+
+
+class ORBDatabase(TensoSDFSynDatabase):
+    """Stanford-ORB scenes in the Blender layout (dataset/database.py:723-802): `transforms_<split>.json`, colour PNGs, the object
+    mask in `<file_path with <split> -> <split>_mask>.png` (one channel), poses used as they are (scale_factor 1)."""
+
+    def __init__(self, root, is_test=False, white_bg=True):
+        from PIL import Image
+        split = "test" if is_test else "train"
+        self.root = root
+        self.imgs_all, self.masks_all, self.pose_all, self.normals_all, self.diffColor_all = [], [], [], [], []
+        with open(os.path.join(root, f"transforms_{split}.json")) as fp:
+            meta = json.load(fp)
+        for fr in meta["frames"]:
+            img = np.asarray(Image.open(os.path.join(root, fr["file_path"] + ".png"))).astype(np.float32) / 255.0
+            m = np.asarray(Image.open(os.path.join(root, fr["file_path"].replace(split, f"{split}_mask") + ".png")))
+            if m.ndim != 2:
+                raise ValueError(f"{fr['file_path']}: the mask PNG must have one channel, got shape {m.shape}")
+            mask = m[..., None].astype(np.float32) / 255.0
+            rgb = img[..., :3] * mask + (1 - mask) if white_bg else img[..., :3] * mask
+            self.imgs_all.append((rgb * 255.0).astype(np.uint8))
+            self.masks_all.append(mask)
+            self.pose_all.append(np.array(fr["transform_matrix"], dtype=np.float64))
+        if not self.imgs_all:
+            raise ValueError(f"{root}: no frames in split {split}")
+        self.H, self.W = self.imgs_all[0].shape[:2]
+        self.focal = 0.5 * self.W / np.tan(0.5 * float(meta["camera_angle_x"]))
+        self.K = np.array([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]], dtype=np.float32)
+        self.scale_factor = 1.0
+        self.img_ids = list(range(len(self.imgs_all)))
+
+
+def parse_database_name(database_name, dataset_dir, is_test=False, white_bg=False):
+    """dataset/database.py:804-823 for the layouts read here: '<type>/<model>' under `dataset_dir`."""
+    if dataset_dir in (None, "None"):
+        raise AssertionError("change your own dataset dir!")
+    kind, model = database_name.split("/")
+    root = os.path.join(dataset_dir, model)
+    if kind == "tensoSDF":
+        return TensoSDFSynDatabase(root, splits=("test",) if is_test else ("train", "val"), white_bg=white_bg,
+                                   load_normals=is_test, load_diff_color=is_test)
+    if kind == "orb":
+        return ORBDatabase(root, is_test=is_test, white_bg=white_bg)
+    raise NotImplementedError(f"database type '{kind}' (this build reads tensoSDF/* and orb/*)")
 
 
 def construct_ray_batch_nerf(imgs_info, device="cpu", is_train=True):

@@ -106,18 +106,42 @@ class _CubeLookupLinear(torch.autograd.Function):
         return ops.cube_lookup_bwd(tex, dirs, g.contiguous(), apply_exp=False), None
 
 
+def latlong_to_cubemap(latlong, res, device="cuda"):
+    """light_utils.latlong_to_cubemap (:34-47): a lat-long map [H,W,C] resampled at the texel-centre directions of a cube map
+    [6,res,res,C] -- u = atan2(x, -z) / 2pi + 1/2, v = acos(y) / pi, bilinear taps with nvdiffrast's default 'wrap' boundary in both
+    axes (texel centres at (i + 1/2) / size).  Set-up code (one call per environment map), plain torch on the device."""
+    img = torch.as_tensor(latlong, dtype=torch.float32, device=device)
+    H, W, C = img.shape
+    v = _texel_centre_dirs(res, device)
+    tu = torch.atan2(v[:, 0], -v[:, 2]) / (2 * np.pi) + 0.5
+    tv = torch.acos(v[:, 1].clamp(-1, 1)) / np.pi
+    x, y = tu * W - 0.5, tv * H - 0.5
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = (x - x0)[:, None], (y - y0)[:, None]
+    x0, y0 = x0.long(), y0.long()
+    tap = lambda yy, xx: img[yy % H, xx % W]
+    out = (tap(y0, x0) * (1 - fx) + tap(y0, x0 + 1) * fx) * (1 - fy) + (tap(y0 + 1, x0) * (1 - fx) + tap(y0 + 1, x0 + 1) * fx) * fy
+    return out.reshape(6, res, res, C).contiguous()
+
+
 class EnvLight(torch.nn.Module):
     def __init__(self, path=None, device=None, scale=1.0, min_res=16, start_res=16, max_res=512, min_roughness=0.08,
                  max_roughness=0.5, trainable=False):
         super().__init__()
-        if path is not None:
-            raise NotImplementedError("loading lat-long HDR files is outside the hot path (light.py:39-49)")
         self.device = device if device is not None else "cuda"
         self.scale, self.min_res, self.max_res = scale, min_res, max_res
         self.min_roughness, self.max_roughness, self.trainable, self.start_res = min_roughness, max_roughness, trainable, start_res
         self.base = torch.nn.Parameter(torch.full((6, max_res, max_res, 3), np.log(0.5), dtype=torch.float32, device=self.device),
                                        requires_grad=trainable)
+        if path is not None:
+            self.load(path)
         self.level = max(0, int(np.log2(max_res / start_res)) + 0.5)
+
+    def load(self, path):
+        """light.py:39-49: a lat-long environment picture (.hdr / .exr / .npy / 8-bit) x scale, resampled onto the cube, becomes `base`."""
+        from ..hdr_io import imread_float
+        image = imread_float(path)[..., :3] * self.scale
+        self.base.data = latlong_to_cubemap(image, self.max_res, self.device)
 
     def upsample(self):
         if self.level > 0:
