@@ -428,6 +428,10 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                                                 slot_of_pos[j] -- the rays of a point stored in TRAVERSAL order, so that tf_bvh_trace
                                                 (called without slot_order) reads and writes consecutive rows from consecutive
                                                 lanes; spec_mask / flow_logjac stay indexed by sample.  NULL: row = slot */,
+                  int32_t row_begin, int32_t row_count /* only rows [row_begin, row_begin + row_count) of every point are built
+                                                          (row_count < 0: all T): the rows of a direction set can be built as soon
+                                                          as ITS samples exist, while the next set is still being sampled; the
+                                                          sample arrays of sets outside the range are not read */,
                   tf_stream_t stream);
 /* The sampler of the NON-NIS pass of shade_mixed (nis_sample False / flows not yet active; the pass whose colours
  * MCShadingNetwork.forward returns in eval, fields.py:1467-1473): nf fixed cosine directions (sample_diffuse_directions,

@@ -82,11 +82,14 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ ang_s, const float* __restrict__ logq_s, const float* __restrict__ fixed_s,
     const float* __restrict__ az_jitter_s, int ss, long long pn, float* __restrict__ dirs,
     float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live,
-    float* __restrict__ flow_logjac, const int* __restrict__ slot_of_pos) {
+    float* __restrict__ flow_logjac, const int* __restrict__ slot_of_pos, int pos0, int npos) {
   const int T = sd + nf + ss;
-  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= pn * T) return;
-  const long long pt = e / T;
+  // rows [pos0, pos0 + npos) of every point (the whole point by default): a caller whose direction sets become ready one after the
+  // other builds the rows of the sets it has while the next set is still being sampled
+  const long long work = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (work >= pn * npos) return;
+  const long long pt = work / npos;
+  const long long e = pt * T + pos0 + (work - pt * npos);
   // row e of dirs / wgt / live is POSITION e % T of its point; the slot (which sample of which direction set) it holds is
   // slot_of_pos[position] when the caller stores the rays of a point in traversal order (tf_bvh_trace then reads and writes
   // consecutive rows from consecutive lanes), the position itself otherwise.  spec_mask / flow_logjac stay indexed by sample.
@@ -375,18 +378,21 @@ static int shade_dirs_launch(const float* normals, const float* view, const floa
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, const float* fixed_s,
                              const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
-                             uint8_t* live, float* flow_logjac, const int32_t* slot_of_pos, tf_stream_t stream, const char* who) {
+                             uint8_t* live, float* flow_logjac, const int32_t* slot_of_pos, int32_t pos0, int32_t npos, tf_stream_t stream,
+                             const char* who) {
   TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "%s: negative size", who);
-  if (pn == 0 || sd + nf + ss == 0) return TF_OK;
+  if (npos < 0) { pos0 = 0; npos = sd + nf + ss; }
+  TF_REQUIRE(pos0 >= 0 && pos0 + npos <= sd + nf + ss, TF_ESHAPE, "%s: row range [%d, %d) outside [0, %d)", who, pos0, pos0 + npos, sd + nf + ss);
+  if (pn == 0 || npos == 0) return TF_OK;
   TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE((sd == 0 || (ang_d && logq_d)) && (nf == 0 || fixed_d) && (ss == 0 || (((ang_s && logq_s) || fixed_s) && spec_mask)),
              TF_EINVAL, "%s: null sample pointer for a non-empty sample set", who);
   TF_REQUIRE(!(fixed_s && ang_s), TF_EINVAL, "%s: the specular set is either flow-sampled (ang_s) or fixed (fixed_s), not both", who);
-  long long work = (long long)pn * (sd + nf + ss);
+  long long work = (long long)pn * npos;
   shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
                                                                           logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, fixed_s,
                                                                           az_jitter_s, ss, pn, dirs, wgt, spec_mask, live,
-                                                                          fixed_s ? nullptr : flow_logjac, slot_of_pos);
+                                                                          fixed_s ? nullptr : flow_logjac, slot_of_pos, pos0, npos);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -395,9 +401,10 @@ extern "C" int tf_shade_dirs(const float* normals, const float* view, const floa
                              const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
                              int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
-                             const int32_t* slot_of_pos, tf_stream_t stream) {
+                             const int32_t* slot_of_pos, int32_t row_begin, int32_t row_count, tf_stream_t stream) {
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
-                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, stream, "tf_shade_dirs");
+                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, row_begin, row_count, stream,
+                           "tf_shade_dirs");
 }
 
 extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, const float* metallic, const float* roughness,
@@ -405,7 +412,7 @@ extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, cons
                                    const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
                                    uint8_t* spec_mask, uint8_t* live, tf_stream_t stream) {
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, nullptr, nullptr, 0, fixed_d, az_jitter, nf, nullptr, nullptr,
-                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, nullptr, stream, "tf_shade_dirs_fixed");
+                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, nullptr, 0, -1, stream, "tf_shade_dirs_fixed");
 }
 
 extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,

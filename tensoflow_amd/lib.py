@@ -104,7 +104,7 @@ SIGNATURES = {
     "tf_point_fwd": (C.c_int, [c_f, P(TfVmDesc), c_f, P(TfVmDesc), c_f, P(TfVmDesc), c_f, P(f32 * 6), c_f, c_f, i64, f32,
                                c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_view_angles": (C.c_int, [c_f, c_f, i64, c_f, c_f]),
-    "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tf_shade_dirs_fixed": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_dirs_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, c_f]),
     "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, c_f, sz, c_f]),

@@ -716,29 +716,42 @@ def view_angles(normals, view):
 
 
 def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False,
-               slot_of_pos=None):
-    """slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order)."""
+               slot_of_pos=None, rows=None, out=None):
+    """slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order).
+    rows = (begin, count): build only these rows of every point, into the arrays `out` = (dirs, wgt, mask, live) of an earlier call
+    (None: allocate); the sample arrays of direction sets outside the range are not read, so a set's rows can be built while the
+    next set is still being sampled (ang_s / logq_s may then be given as shapes: (ss,))."""
     lib = L.load()
     pn = normals.shape[0]
     sd = 0 if ang_d is None else ang_d.shape[1]
     nf = 0 if fixed_d is None else fixed_d.shape[0]
-    ss = 0 if ang_s is None else ang_s.shape[1]
+    ss_only = isinstance(ang_s, tuple)                      # placeholder: the specular samples do not exist yet
+    ss = 0 if ang_s is None else (ang_s[0] if ss_only else ang_s.shape[1])
     T = sd + nf + ss
     dev = normals.device
-    dirs = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
-    wgt = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
-    mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
-    live = torch.empty(pn, T, dtype=torch.uint8, device=dev)
+    if out is None:
+        dirs = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
+        wgt = torch.empty(pn, T, 3, dtype=torch.float32, device=dev)
+        mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
+        live = torch.empty(pn, T, dtype=torch.uint8, device=dev)
+    else:
+        dirs, wgt, mask, live = out
+        mask = mask.view(torch.uint8)
     logjac = torch.empty(pn, sd + ss, dtype=torch.float32, device=dev) if want_logjac else None
     g = lambda t: None if t is None else _f(t)
+    if ss_only:
+        a_s = l_s = dirs                                    # any valid address: never read for rows outside the specular set
+    else:
+        a_s, l_s = g(ang_s), g(None if logq_s is None else logq_s.reshape(pn, ss))
+    r0, rc = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
     L.check(lib.tf_shade_dirs(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
                               _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
-                              _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(g(ang_s)),
-                              _p(g(None if logq_s is None else logq_s.reshape(pn, ss))), ss, pn, _p(dirs), _p(wgt),
-                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _p(slot_of_pos, torch.int32), _stream()), "tf_shade_dirs")
+                              _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(a_s), _p(l_s), ss, pn, _p(dirs), _p(wgt),
+                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _p(slot_of_pos, torch.int32), r0, rc, _stream()),
+            "tf_shade_dirs")
     if want_logjac:
         return dirs, wgt, mask.bool(), live, logjac
-    return dirs, wgt, mask.bool(), live
+    return dirs, wgt, mask.bool() if out is None else mask, live
 
 
 def shade_dirs_fixed(normals, view, metallic, roughness, albedo, fixed_d, fixed_s, az_jitter=None, az_jitter_s=None):

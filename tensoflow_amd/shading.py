@@ -194,6 +194,8 @@ class MCShader:
         self._order = {}
         self.sort_rays = True           # trace each point's rays in direction-sorted order (results unchanged)
         self.sort_origins = False       # hand the points to the traversal in Morton order (results unchanged; measured: no gain, +1 ms of sorting)
+        self.overlap_dirs = True        # build the diffuse / fixed direction rows on a second stream under the specular flow's sampling
+        self._side_stream = None
         self.timer = _NoTimer()
         self.hit_total = None
 
@@ -282,19 +284,43 @@ class MCShader:
             # materials + both flow condition rows: one fused launch (tf_point_fwd) after the view-angle kernel
             va = ops.view_angles(normals, view_dirs)
             metallic, rough, albedo, cond_d, cond_s = self.point_prep(pts, va)
-        with tm.stage("flow_sample"):
-            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d, precision=self.precision,
-                                          cache=self.flow_d.cache)
-            ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
-                                          cache=self.flow_s.cache)
-        tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         # a point's rays are STORED in traversal order (row j holds slot order[j]): the traversal then reads and writes consecutive
         # rows from consecutive lanes instead of going through the permutation for every ray; only the kernels that need to know
         # WHICH sample a row is (direction construction, the lobe split of the reduction) take the permutation
         order = self.slot_order(sn_diffuse, sn_specular) if self.sort_rays else None
-        with tm.stage("shade_dirs"):
-            dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
-                                                    slot_of_pos=order)
+        nf = self.fixed_d.shape[0]
+        with tm.stage("flow_sample"):
+            ang_d, lq_d = ops.flow_sample(self.flow_d.nets, cond_d, self.latent(sn_diffuse), jitter_d, precision=self.precision,
+                                          cache=self.flow_d.cache)
+        if self.overlap_dirs:
+            # the rows of the diffuse flow set and of the fixed set (5/6 of a point's rows: an HBM write stream) are built on a second
+            # HIP stream WHILE the specular flow is being sampled (matrix-core / vector-issue bound, HBM idle); the specular rows follow
+            T = sn_diffuse + nf + sn_specular
+            dev = pts.device
+            bufs = (torch.empty(pn, T, 3, dtype=torch.float32, device=dev), torch.empty(pn, T, 3, dtype=torch.float32, device=dev),
+                    torch.empty(pn, sn_specular, dtype=torch.bool, device=dev), torch.empty(pn, T, dtype=torch.uint8, device=dev))
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream()
+            self._side_stream.wait_stream(cur)
+            with torch.cuda.stream(self._side_stream):
+                ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
+                               slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs)
+            with tm.stage("flow_sample"):
+                ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
+                                              cache=self.flow_s.cache)
+            with tm.stage("shade_dirs"):
+                cur.wait_stream(self._side_stream)
+                dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
+                                                        slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs)
+        else:
+            with tm.stage("flow_sample"):
+                ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
+                                              cache=self.flow_s.cache)
+            with tm.stage("shade_dirs"):
+                dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
+                                                        slot_of_pos=order)
+        tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built
         # origins are handed to the traversal in Morton order (each XCD then works on one contiguous eighth of the scene); nothing
