@@ -778,6 +778,11 @@ def main():
             "roofline": roof,
             "roofline_other": other_rooflines(summ, timer, hits, args, sh, dom),
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "stages_overlapped_ms_per_step": dict(
+                {k: round(v[0] / args.steps, 3) for k, v in timer.summary_overlapped().items()},
+                note="issued on a second HIP stream UNDER the main-stream stages above (the diffuse / fixed direction rows under the specular "
+                     "flow's sampling; the per-pixel reduction of batch k under the per-point stage and flow sampling of batch k + 1): "
+                     "their own durations while sharing the GPU, not part of the stage sum, which still adds up to ms_per_step"),
         }
         if train_dp is not None:
             line["train_dp"] = train_dp

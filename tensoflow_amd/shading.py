@@ -58,11 +58,12 @@ class StageTimer:
 
     def __init__(self):
         self.events = {}
+        self.events_overlapped = {}      # work issued on the side stream under main-stream stages: reported apart, not part of the stage sum
         self.units = {}
 
     class _Ctx:
-        def __init__(self, owner, name):
-            self.o, self.name = owner, name
+        def __init__(self, owner, name, overlapped=False):
+            self.o, self.name, self.ov = owner, name, overlapped
 
         def __enter__(self):
             self.s = torch.cuda.Event(enable_timing=True)
@@ -71,10 +72,11 @@ class StageTimer:
 
         def __exit__(self, *a):
             self.e.record()
-            self.o.events.setdefault(self.name, []).append((self.s, self.e))
+            (self.o.events_overlapped if self.ov else self.o.events).setdefault(self.name, []).append((self.s, self.e))
 
-    def stage(self, name):
-        return StageTimer._Ctx(self, name)
+    def stage(self, name, overlapped=False):
+        """Events are recorded on the CURRENT stream: an overlapped stage is entered inside `with torch.cuda.stream(side)`."""
+        return StageTimer._Ctx(self, name, overlapped)
 
     def add_units(self, name, n):
         self.units[name] = self.units.get(name, 0) + int(n)
@@ -82,6 +84,9 @@ class StageTimer:
     def summary(self):
         """-> {stage: (total_ms, launches)} (call after torch.cuda.synchronize())."""
         return {k: (sum(s.elapsed_time(e) for s, e in v), len(v)) for k, v in self.events.items()}
+
+    def summary_overlapped(self):
+        return {k: (sum(s.elapsed_time(e) for s, e in v), len(v)) for k, v in self.events_overlapped.items()}
 
 
 class _NoTimer:
@@ -92,7 +97,7 @@ class _NoTimer:
         def __exit__(self, *a):
             return False
 
-    def stage(self, name):
+    def stage(self, name, overlapped=False):
         return _NoTimer._C()
 
     def add_units(self, name, n):
@@ -105,6 +110,19 @@ class ShadeOutputs(dict):
     first access instead of on every call (the eval integral never reads it)."""
 
     _PER_RAY = ("dirs", "wgt", "hit", "live", "hit_lights", "depth")
+    _LATE = ("colors", "diffuse_lin", "specular_lin")
+    _pending = None      # the side stream the reduction of this call was issued on (MCShader.overlap_reduce), until its results are first read
+
+    def __getitem__(self, key):
+        if self._pending is not None and key in self._LATE:
+            # the per-pixel sums were issued on the side stream so that the NEXT batch's sampling can start under them: whoever reads
+            # them first makes its stream wait for that work
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._pending)
+            for k in self._LATE:
+                dict.__getitem__(self, k).record_stream(cur)
+            self._pending = None
+        return dict.__getitem__(self, key)
 
     def __missing__(self, key):
         if key in self._PER_RAY and "_pos_" + key in self:
@@ -195,6 +213,9 @@ class MCShader:
         self.sort_rays = True           # trace each point's rays in direction-sorted order (results unchanged)
         self.sort_origins = False       # hand the points to the traversal in Morton order (results unchanged; measured: no gain, +1 ms of sorting)
         self.overlap_dirs = True        # build the diffuse / fixed direction rows on a second stream under the specular flow's sampling
+        self.overlap_reduce = False     # True: issue the per-pixel reduction on the second stream, under the NEXT batch's per-point stage and
+                                        # flow sampling.  Measured slower (41.7 vs 40.7 ms per step): its texel gathers slow the flow kernel by
+                                        # more (+2.1 ms) than the reduction's own 2.7 ms
         self._side_stream = None
         self.timer = _NoTimer()
         self.hit_total = None
@@ -304,8 +325,9 @@ class MCShader:
             cur = torch.cuda.current_stream()
             self._side_stream.wait_stream(cur)
             with torch.cuda.stream(self._side_stream):
-                ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
-                               slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs)
+                with tm.stage("shade_dirs (diffuse + fixed rows)", overlapped=True):
+                    ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
+                                   slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs)
             with tm.stage("flow_sample"):
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
@@ -330,10 +352,26 @@ class MCShader:
         hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
                                                               origin_order=oorder)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
-        with tm.stage("shade_reduce"):
-            # environment light of the rays that missed is evaluated inside the reduction (no [pn,T,3] light array)
-            colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, n_diff, sn_specular,
-                                                  slot_of_pos=order)
+        pending = None
+        if self.overlap_reduce:
+            # the reduction (texel gathers of the environment light: latency bound, matrix cores idle) goes to the side stream: it runs
+            # under the per-point stage and the flow sampling of the NEXT batch unless the caller reads the colours first
+            # (ShadeOutputs.__getitem__ waits).  Its inputs are kept from the allocator until that work is done (record_stream).
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=pts.device)
+            pending = self._side_stream
+            pending.wait_stream(torch.cuda.current_stream())
+            hit_u8 = hit.view(torch.uint8)
+            with torch.cuda.stream(pending):
+                with tm.stage("shade_reduce", overlapped=True):
+                    colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, self.env, n_diff, sn_specular, slot_of_pos=order)
+            for t in (wgt, dirs, depth, hit_u8, hit_lights):
+                t.record_stream(pending)
+        else:
+            with tm.stage("shade_reduce"):
+                # environment light of the rays that missed is evaluated inside the reduction (no [pn,T,3] light array)
+                colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, hit.view(torch.uint8), hit_lights, self.env, n_diff, sn_specular,
+                                                      slot_of_pos=order)
         out = ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                            specular_mask=smask, view_angles=va, diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s,
                            specular_logq=lq_s, _env=self.env, n_diffuse=n_diff)
@@ -343,4 +381,5 @@ class MCShader:
         else:
             out.update({"_pos_" + k: v for k, v in per_ray.items()})
             out["_pos_of_slot"] = self.pos_of_slot(sn_diffuse, sn_specular)
+        out._pending = pending
         return out
