@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ 
   if (n_dev) n = min(n, max(0LL, *n_dev));
   // thread = column j (strided), workgroup = a slab of 256 rows
   const long long r0 = (long long)blockIdx.x * 256, r1 = min(r0 + 256, n);
+  if (r0 >= n) return;      // launched for a capacity: a slab past the device-side row count adds nothing (and used to add 256 atomic zeros)
   for (int j = threadIdx.x; j < N; j += 256) {
     float s = 0.f;
     for (long long r = r0; r < r1; ++r) {
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(256) act_bwd_small_kernel(const float* __restr
                                                             const long long* __restrict__ n_dev) {
   if (n_dev) total = min(total, max(0LL, *n_dev) * N);
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if ((e & ~63LL) >= total) return;             // the whole wave is past the valid elements: nothing to store, nothing to reduce
   float g = 0.f;
   if (e < total) {
     g = gY[e] * act_bwd_from_y(Y[e], act, p);
