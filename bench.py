@@ -633,7 +633,8 @@ def other_rooflines(summ, timer, hits, args, sh, dom):
         out["flow_kernel"] = dict(bound="mfma", achieved=ach, peak=fpeak, unit="TFLOP/s", frac=ach / fpeak,
                                   avg_launch_ms=ms / n, traffic=pmc_traffic("flow_kernel"),
                                   per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches); "
-                                             "vector-instruction / dependency bound (spline), fp32-grade f16x3 products")
+                                             "matrix-core + vector-issue cycles add up per SIMD (DESIGN.md section 3, item 5), fp32-grade f16x3 products; the second launch "
+                                             "shares the GPU with the direction kernel on the side stream (stages_overlapped_ms_per_step): alone the two launches take 10.4 ms")
     return out
 
 
