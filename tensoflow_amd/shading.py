@@ -297,7 +297,10 @@ class MCShader:
 
     @torch.no_grad()
     def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None):
-        """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)"""
+        """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)
+        One call at a time per shader: the kernels' workspaces (packed weights, the flows' per-point rows, the traversal's work
+        counters) are per device, not per call -- two shade() calls in flight on different streams would share them (measured as
+        well: two batches in flight are 2x SLOWER, the persistent traversal kernels of both cannot be resident together)."""
         pts = pts.to(self.device).float().contiguous()
         pn = pts.shape[0]
         tm = self.timer
