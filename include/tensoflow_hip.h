@@ -466,15 +466,19 @@ int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n
  * Dense layers of the training direction.  Replace torch.nn.Linear + activation -- the library GEMMs under the reference's
  * TensoSDF decoder (network/fields.py:78-81), make_predictor_3layer / _4layer (network/other_field.py:50-119: material
  * predictors fields.py:1010-1017, inner-light net :905-911, ShapeShadingNetwork's nets :448-567) -- in forward AND backward.
- * Exact fp32 matrix cores (v_mfma_f32_32x32x2_f32).  X [n,K], W [N,K] (torch layout), b [N] or NULL, Y [n,N] row-major.
+ * precision: TF_PREC_F32 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32; what the training ops use), TF_PREC_F16X3 = f16 operand
+ * split (three v_mfma_f32_32x32x16_f16 per product term, fp32 accumulate) for operands inside the f16 range only -- unscaled
+ * gradients of a mean-reduced loss are not.
+ * X [n,K], W [N,K] (torch layout), b [N] or NULL, Y [n,N] row-major.
  * tf_linear_bwd: Y = the forward OUTPUT (post-activation), gY [n,N]; gZ [n,N] scratch that receives gY * act'(Y);
  * gX [n,K] or NULL; gW [N,K] / gb [N] or NULL are overwritten (zeroed, then accumulated with fp32 atomics over row slabs).
  * n_dev (device pointer, or NULL): only the first min(n, *n_dev) rows are valid -- the row count of a compacted list (hit rays)
  * stays on the device, the launch is sized for the capacity n and surplus workgroups exit (no host sync in a training step). */
 int tf_linear_fwd(const float* X, const float* W, const float* b, int64_t n, int32_t K, int32_t N, int32_t act /* TfActivation */,
-                  float act_param, float* Y, const int64_t* n_dev, tf_stream_t stream);
+                  float act_param, int32_t precision /* TfPrecision */, float* Y, const int64_t* n_dev, tf_stream_t stream);
 int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
-                  float act_param, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev, tf_stream_t stream);
+                  float act_param, int32_t precision, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev,
+                  tf_stream_t stream);
 
 #ifdef __cplusplus
 }

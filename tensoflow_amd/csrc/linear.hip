@@ -1,4 +1,7 @@
-// Dense layers of the training direction: Y = act(X W^T + b) and its three backward products, on the exact-fp32 matrix cores.
+// Dense layers of the training direction: Y = act(X W^T + b) and its three backward products, on the matrix cores: exact fp32
+// (v_mfma_f32_32x32x2_f32, the default) or the f16x3 operand split (three v_mfma_f32_32x32x16_f16 per product term, fp32 accumulate)
+// for operands inside the f16 range -- NOT for raw gradients (1e-7 .. 1e-5 per element under a mean-reduced loss: they flush to zero),
+// and measured no faster on these tall-skinny products (the tile traffic through LDS, not the matrix rate, holds them).
 //
 // The reference trains its small MLPs -- TensoSDF's decoder (network/fields.py:78-81), the material predictors and the inner-light
 // net (network/other_field.py:50-119, fields.py:905-911,1010-1017), ShapeShadingNetwork's three 128-wide nets (fields.py:448-567)
@@ -53,7 +56,7 @@ __device__ __forceinline__ float act_bwd_from_y(float y, int act, float p) {
 }
 
 // A_KFAST / B_NFAST: which index of the operand is contiguous in memory (decides the coalescing of the tile loads)
-template <bool A_KFAST, bool B_NFAST>
+template <bool A_KFAST, bool B_NFAST, bool H3>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs G) {
   __shared__ float As[KC][BM + 4];
   __shared__ float Bs[KC][BN + 4];
@@ -132,12 +135,34 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs G) {
   for (long long k0 = kb; k0 < ke; k0 += KC) {
     const bool more = k0 + KC < ke;
     if (more) fetch(k0 + KC);
-    // ---- wave `wave`: rows [32 wave, 32 wave + 32) x all 64 columns; lane supplies A[i = lane & 31][k = lane >> 5]
+    // ---- wave `wave`: rows [32 wave, 32 wave + 32) x all 64 columns
+    if (H3) {
+      // the chunk is ONE k-step of the f16 instruction: lane half h supplies k = 8 h .. 8 h + 7 of its row (A) / column (B), split on
+      // the fly into hi + lo halves (tf_split8: 12 vector instructions per 8 values); hi.hi + hi.lo + lo.hi, the lo.lo term (2^-22) dropped
+      const int h = lane >> 5, i = lane & 31;
+      float v8[8];
 #pragma unroll
-    for (int s = 0; s < KC / 2; ++s) {
-      const float a = As[2 * s + (lane >> 5)][32 * wave + (lane & 31)];
+      for (int e = 0; e < 8; ++e) v8[e] = As[8 * h + e][32 * wave + i];
+      tf_h8 a_hi, a_lo;
+      tf_split8(v8, a_hi, a_lo);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t] = tf_mfma(a, Bs[2 * s + (lane >> 5)][32 * t + (lane & 31)], acc[t]);
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = Bs[8 * h + e][32 * t + i];
+        tf_h8 b_hi, b_lo;
+        tf_split8(v8, b_hi, b_lo);
+        acc[t] = tf_mfma_h(a_hi, b_hi, acc[t]);
+        acc[t] = tf_mfma_h(a_hi, b_lo, acc[t]);
+        acc[t] = tf_mfma_h(a_lo, b_hi, acc[t]);
+      }
+    } else {
+      // exact fp32: lane supplies A[i = lane & 31][k = lane >> 5] of each pair of k
+#pragma unroll
+      for (int s = 0; s < KC / 2; ++s) {
+        const float a = As[2 * s + (lane >> 5)][32 * wave + (lane & 31)];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = tf_mfma(a, Bs[2 * s + (lane >> 5)][32 * t + (lane & 31)], acc[t]);
+      }
     }
     __syncthreads();
     if (more) {
@@ -163,9 +188,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs G) {
 }
 
 template <bool A_KFAST, bool B_NFAST>
-int launch(const GemmArgs& G, int splits, hipStream_t stream, const char* who) {
+int launch(const GemmArgs& G, int splits, bool h3, hipStream_t stream, const char* who) {
   dim3 grid((unsigned)((G.M + BM - 1) / BM), (unsigned)((G.N + BN - 1) / BN), (unsigned)splits);
-  gemm_kernel<A_KFAST, B_NFAST><<<grid, 256, 0, stream>>>(G);
+  if (h3) gemm_kernel<A_KFAST, B_NFAST, true><<<grid, 256, 0, stream>>>(G);
+  else gemm_kernel<A_KFAST, B_NFAST, false><<<grid, 256, 0, stream>>>(G);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -212,18 +238,23 @@ __global__ void __launch_bounds__(256) act_bwd_small_kernel(const float* __restr
 }  // namespace
 
 extern "C" int tf_linear_fwd(const float* X, const float* W, const float* b, int64_t n, int32_t K, int32_t N, int32_t act, float act_param,
-                             float* Y, const int64_t* n_dev, tf_stream_t stream) {
+                             int32_t precision, float* Y, const int64_t* n_dev, tf_stream_t stream) {
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_fwd: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP, TF_EINVAL, "tf_linear_fwd: unknown activation %d", act);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_fwd: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  const bool h3 = precision == TF_PREC_F16X3;
   if (n == 0) return TF_OK;
   TF_REQUIRE(X && W && Y, TF_EINVAL, "tf_linear_fwd: null pointer");
   GemmArgs G{X, K, 1, W, 1, K, Y, N, b, n, N, K, K, act, act_param, 0, (const long long*)n_dev, 1};
-  return launch<true, false>(G, 1, (hipStream_t)stream, "tf_linear_fwd");
+  return launch<true, false>(G, 1, h3, (hipStream_t)stream, "tf_linear_fwd");
 }
 
 extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
-                             float act_param, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev, tf_stream_t stream_) {
+                             float act_param, int32_t precision, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev,
+                             tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_bwd: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  const bool h3 = precision == TF_PREC_F16X3;
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_bwd: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP, TF_EINVAL, "tf_linear_bwd: unknown activation %d", act);
   TF_REQUIRE(W && (n == 0 || (X && Y && gY && gZ)), TF_EINVAL, "tf_linear_bwd: null pointer");
@@ -235,14 +266,14 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
   if (gX) {   // gX [n,K] = gZ [n,N] . W [N,K]
     GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
-    const int rc = launch<true, true>(G, 1, stream, "tf_linear_bwd(data)");
+    const int rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
     if (rc != TF_OK) return rc;
   }
   if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
     const long long split = 1024;     // rows per workgroup: enough workgroups to fill the chip at n ~ 2e5; each adds a [128 x 64] tile atomically
     const int splits = (int)((n + split - 1) / split);
     GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
-    const int rc = launch<false, true>(G, splits, stream, "tf_linear_bwd(weight)");
+    const int rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
     if (rc != TF_OK) return rc;
   }
   return TF_OK;

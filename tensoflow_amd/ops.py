@@ -235,8 +235,16 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_EXP_CLAMP = 0, 1, 2, 3, 4      # TfActivation
 
 
-def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None):
-    """Y = act(x w^T + b) on the exact-fp32 matrix cores (tf_linear_fwd): x [n,K], w [N,K], b [N] or None -> [n,N].
+LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction's dense layers: exact fp32 MFMA.  PREC_F16X3 exists in the
+                                 # kernel and is NOT the default for two measured reasons: gradients of mean-reduced losses (1e-7 .. 1e-5 per
+                                 # element) fall below the f16 range and flush to zero unscaled (test_mcshading_eval_follows_parameter_updates
+                                 # caught it), and the tall-skinny products are held by their tile traffic, not by the matrix rate (material
+                                 # training step 17.9 vs 18.1 ms)
+
+
+def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None, precision=None):
+    """Y = act(x w^T + b) on the matrix cores (tf_linear_fwd): x [n,K], w [N,K], b [N] or None -> [n,N].
+    precision: PREC_F32 (exact fp32 MFMA; module default LINEAR_PRECISION) or PREC_F16X3 (operands within the f16 range only).
     n_dev: device int64 scalar -- only the first min(n, n_dev) rows are computed (the rest of Y stays uninitialised)."""
     lib = L.load()
     x, w = _f(x), _f(w)
@@ -244,12 +252,13 @@ def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None):
     N = w.shape[0]
     assert w.shape == (N, K)
     y = torch.empty(n, N, device=x.device)
-    L.check(lib.tf_linear_fwd(_p(x), _p(w), _p(_f(b)) if b is not None else None, n, K, N, int(act), float(act_param), _p(y),
+    L.check(lib.tf_linear_fwd(_p(x), _p(w), _p(_f(b)) if b is not None else None, n, K, N, int(act), float(act_param),
+                              int(LINEAR_PRECISION if precision is None else precision), _p(y),
                               _p(n_dev, torch.int64) if n_dev is not None else None, _stream()), "tf_linear_fwd")
     return y
 
 
-def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=True, need_gb=True, n_dev=None):
+def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=True, need_gb=True, n_dev=None, precision=None):
     """-> (gx [n,K] | None, gw [N,K] | None, gb [N] | None) of Y = act(x w^T + b) given the forward output y and gy (tf_linear_bwd)."""
     lib = L.load()
     x, w, y, gy = _f(x), _f(w), _f(y), _f(gy)
@@ -259,7 +268,8 @@ def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=T
     gx = torch.empty(n, K, device=x.device) if need_gx else None
     gw = torch.empty(N, K, device=x.device) if need_gw else None
     gb = torch.empty(N, device=x.device) if need_gb else None
-    L.check(lib.tf_linear_bwd(_p(x), _p(w), _p(y), _p(gy), n, K, N, int(act), float(act_param), _p(gz), _p(gx) if need_gx else None,
+    L.check(lib.tf_linear_bwd(_p(x), _p(w), _p(y), _p(gy), n, K, N, int(act), float(act_param),
+                              int(LINEAR_PRECISION if precision is None else precision), _p(gz), _p(gx) if need_gx else None,
                               _p(gw) if need_gw else None, _p(gb) if need_gb else None,
                               _p(n_dev, torch.int64) if n_dev is not None else None, _stream()), "tf_linear_bwd")
     return gx, gw, gb

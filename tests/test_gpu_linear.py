@@ -12,8 +12,18 @@ def _ref_act(z, act, p):
             ops.ACT_SIGMOID: lambda: torch.sigmoid(z), ops.ACT_EXP_CLAMP: lambda: torch.exp(z.clamp(max=p))}[act]()
 
 
+@pytest.fixture(params=["f16x3", "f32"])
+def linear_precision(request):
+    """Both operand arithmetics of tf_linear_*: the f16x3 split (default) and exact fp32 MFMA -- the same 2e-5 bar for both."""
+    from tensoflow_amd import ops
+    keep = ops.LINEAR_PRECISION
+    ops.LINEAR_PRECISION = ops.PREC_F16X3 if request.param == "f16x3" else ops.PREC_F32
+    yield request.param
+    ops.LINEAR_PRECISION = keep
+
+
 @pytest.mark.parametrize("n,K,N", [(1, 3, 1), (777, 111, 256), (4096, 256, 129), (2048, 108, 128), (300, 128, 3), (5000, 123, 256), (130, 256, 256)])
-def test_linear_fwd_bwd_matches_torch(n, K, N):
+def test_linear_fwd_bwd_matches_torch(n, K, N, linear_precision):
     from tensoflow_amd import ops
     from tensoflow_amd.autograd import LinearActFn
     dev = torch.device("cuda:0")
@@ -35,7 +45,7 @@ def test_linear_fwd_bwd_matches_torch(n, K, N):
             assert float((a.double() - r.double()).abs().max()) / scale < 2e-5, (act, name, n, K, N)
 
 
-def test_linear_device_side_row_count():
+def test_linear_device_side_row_count(linear_precision):
     """n_dev: rows beyond the device-side count are neither computed nor differentiated (compacted hit lists, no host sync)."""
     from tensoflow_amd import ops
     dev = torch.device("cuda:0")
