@@ -340,6 +340,10 @@ int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm,
 /* idx[0 .. *count) = indices i with mask[i] != 0 (unordered); *count is zeroed by the call (replaces the boolean-mask
  * indexing of fields.py:962-971). */
 int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
+/* The same with the mask v[i] < thr of a float array: the hit list straight from tf_bvh_trace's depth (a miss holds TF_MISS_DEPTH),
+ * so that the traversal need not store a flag byte per ray (hit == NULL there). */
+#define TF_MISS_DEPTH 10.0f
+int tf_compact_below(const float* v, float thr, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Split-sum shading of the shape stage in ONE launch: ShapeShadingNetwork.forward (network/fields.py:448-567,
@@ -452,7 +456,7 @@ int tf_shade_dirs_bwd(const float* normals, const float* view, const float* meta
 /* Same reduction with get_lights' miss branch folded in (fields.py:951-975): a slot whose ray hit the mesh (hit[r] != 0)
  * takes hit_lights[r] (tf_inner_light_indexed_fwd's scatter target; other rows are never read), a slot whose ray missed
  * takes exp(cube(env_base, dirs[r])) * (depth[r] > near_eps) evaluated on the fly -- the [pn,T,3] light array of the
- * miss branch is never written or read.  Zero-weight slots are skipped. */
+ * miss branch is never written or read.  Zero-weight slots are skipped.  hit may be NULL: a ray then hit iff depth[r] < TF_MISS_DEPTH. */
 int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit, const float* hit_lights,
                         const float* env_base, int32_t env_res, float near_eps, int64_t pn, int32_t n_diffuse, int32_t ss,
                         float* colors, float* diffuse_lin, float* specular_lin,

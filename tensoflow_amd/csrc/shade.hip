@@ -320,8 +320,8 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
     // environment lookup per missing ray, not by the streams
     const F3 w = ld3(wgt + e);
     const F3 dd = ld3(dirs + e);
-    const unsigned char hr = hit[r];
     const float dr = depth[r];
+    const bool hr = hit ? hit[r] != 0 : dr < TF_MISS_DEPTH;
     const float w0 = w.x, w1 = w.y, w2 = w.z;
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
@@ -357,7 +357,7 @@ extern "C" int tf_shade_reduce_env(const float* wgt, const float* dirs, const fl
                                    const int32_t* slot_of_pos, tf_stream_t stream) {
   TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && env_res > 0, TF_ESHAPE, "tf_shade_reduce_env: negative size / env_res <= 0");
   if (pn == 0) return TF_OK;
-  TF_REQUIRE(wgt && dirs && depth && hit && hit_lights && env_base && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
+  TF_REQUIRE(wgt && dirs && depth && hit_lights && env_base && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
   shade_reduce_env_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, dirs, depth, hit, hit_lights, env_base, env_res,
                                                                             near_eps, pn, n_diffuse, ss, colors, diffuse_lin,
                                                                             specular_lin, slot_of_pos);

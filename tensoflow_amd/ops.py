@@ -366,6 +366,21 @@ def compact_mask(mask_u8):
     return idx, count
 
 
+MISS_DEPTH = 10.0      # TF_MISS_DEPTH: tf_bvh_trace's depth of a ray that hits nothing
+
+
+def compact_below(v, thr):
+    """Indices i with v[i] < thr -> idx [m] int64 (first *count entries valid, unordered), count [1] int64 (tf_compact_below): the hit
+    list straight from the traversal's depth array."""
+    lib = L.load()
+    v = _f(v).reshape(-1)
+    m = v.numel()
+    idx = torch.empty(m, dtype=torch.int64, device=v.device)
+    count = torch.empty(1, dtype=torch.int64, device=v.device)
+    L.check(lib.tf_compact_below(_p(v), float(thr), m, _p(idx, torch.int64), _p(count, torch.int64), _stream()), "tf_compact_below")
+    return idx, count
+
+
 def _mlp4(weights):
     net = L.TfMlp4()
     keep = []
@@ -528,7 +543,7 @@ class Bvh:
         self.tris = torch.from_numpy(tris12).to(device)
 
     def trace(self, o, d, off0=0.0, off1=0.0, want_pos=True, want_nrm=True, live=None, dynamic=True, slot_order=None,
-              hit_rows_only=False, origin_order=None):
+              hit_rows_only=False, origin_order=None, want_hit=True):
         """o [m,3] (one origin per ray) or [m // T, 3] (T consecutive rays share an origin row); d [m,3].
         hit_rows_only: the pos / nrm rows of rays that miss are left UNINITIALISED (callers that only read hit rows).
         origin_order [n_origins] int32: order in which the origins are handed to the persistent waves (see morton_order)."""
@@ -546,7 +561,7 @@ class Bvh:
         pos = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_pos else None
         nrm = torch.empty(m, 3, dtype=torch.float32, device=dev) if want_nrm else None
         depth = torch.empty(m, dtype=torch.float32, device=dev)
-        hit = torch.empty(m, dtype=torch.uint8, device=dev)
+        hit = torch.empty(m, dtype=torch.uint8, device=dev) if want_hit else None       # want_hit=False: a ray hit iff depth < 10 (MISS_DEPTH)
         lv = None if live is None else live.reshape(-1).contiguous()
         ctr = torch.empty(8, dtype=torch.int64, device=dev) if dynamic else None
         if origin_order is not None and (origin_order.dtype != torch.int32 or origin_order.numel() != o.shape[0]):
@@ -554,7 +569,7 @@ class Bvh:
         L.check(self.lib.tf_bvh_trace(_p(self.pairs, torch.int32), _p(self.tris), C.byref(self.frame), self.n_pairs, _p(o), _p(d), per_origin, _p(slot_order, torch.int32), float(off0), float(off1),
                                       _p(lv, torch.uint8), m, _p(pos), _p(nrm), _p(depth), _p(hit, torch.uint8),
                                       int(bool(hit_rows_only)), _p(origin_order, torch.int32), _p(ctr, torch.int64), _stream()), "tf_bvh_trace")
-        return pos, nrm, depth, hit.bool()
+        return pos, nrm, depth, hit.bool() if want_hit else None
 
 
 def morton_order(pts, aabb):
@@ -814,7 +829,8 @@ def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, 
     dl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     sl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     env_base = _f(env_base)
-    L.check(lib.tf_shade_reduce_env(_p(_f(wgt)), _p(_f(dirs)), _p(_f(depth)), _p(hit_u8, torch.uint8), _p(_f(hit_lights)), _p(env_base),
+    L.check(lib.tf_shade_reduce_env(_p(_f(wgt)), _p(_f(dirs)), _p(_f(depth)), _p(hit_u8, torch.uint8) if hit_u8 is not None else None,
+                                    _p(_f(hit_lights)), _p(env_base),
                                     env_base.shape[1], float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl),
                                     _p(slot_of_pos, torch.int32), _stream()),
             "tf_shade_reduce_env")

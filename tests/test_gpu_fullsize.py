@@ -182,6 +182,31 @@ def test_compact_mask_ragged_and_unaligned(dev):
     assert n == int(mask.sum(dtype=torch.int64)) and bool(mask[idx[:n]].all()) and idx[:n].unique().numel() == n
 
 
+def test_compact_below_ragged_and_unaligned(dev):
+    """tf_compact_below (the hit list straight from the traversal's depth array): the index SET equals nonzero(v < thr) for ragged
+    lengths around the 32-element / 8192-element granules and for views that start off a 16-byte boundary; values equal to the
+    threshold (a miss holds exactly TF_MISS_DEPTH) are not kept; NaN is not kept."""
+    from tensoflow_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for m in (1, 31, 32, 33, 255, 8191, 8192, 8193, 100003):
+        for shift in (0, 1, 3):
+            v = torch.where(torch.rand(m + shift, generator=g) < 0.15, torch.rand(m + shift, generator=g) * 9.99, torch.full((m + shift,), 10.0))
+            v[::97] = float("nan")
+            d = v.to(dev)[shift:]
+            idx, count = ops.compact_below(d, ops.MISS_DEPTH)
+            n = int(count)
+            ref = torch.nonzero(d < 10.0).reshape(-1)
+            assert n == ref.numel(), (m, shift)
+            assert torch.equal(torch.sort(idx[:n]).values, ref), (m, shift)
+    idx, count = ops.compact_below(torch.empty(0, device=dev), 10.0)
+    assert int(count) == 0
+    m = 262144 * 768
+    d = torch.where(torch.rand(m, device=dev) < 0.1475, torch.rand(m, device=dev), torch.full((m,), 10.0, device=dev))
+    idx, count = ops.compact_below(d, 10.0)
+    n = int(count)
+    assert n == int((d < 10.0).sum(dtype=torch.int64)) and bool((d[idx[:n]] < 10.0).all()) and idx[:n].unique().numel() == n
+
+
 def test_full_size_state_against_the_oracle(dev):
     """BASELINE configs[2] at its real sizes -- R = 512 material / flow fields, the 265 k-triangle bench mesh, 128 + 512 + 128
     secondary rays -- on 64 surface points against the ORACLE (CPU restatement pinned to the reference goldens; the bench mesh is
