@@ -571,7 +571,11 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     rid = -1;
     return;
 #endif
+#ifdef BVH_ABLATE_MISS_DEPTH   // dev-only timing ablation: depth stored for the rays that hit only
+    if (best < BVH_MAX_DIST) A.depth[rid] = best;
+#else
     A.depth[rid] = best;
+#endif
     if (A.hit) A.hit[rid] = best < BVH_MAX_DIST ? 1 : 0;
     // 85 % of the integral's secondary rays miss; their position / normal rows are never read, and writing them cost 12 %
     // of the kernel (scattered partial-line stores: 4x write amplification at the fabric)
