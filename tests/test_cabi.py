@@ -227,3 +227,21 @@ def test_late_round1_entry_points_validate(lib):
     assert lib.tf_inner_light_fwd(None, None, None, None, 5, 5.0, 2, None, None, 0, None) == -1 and b"null pointer" in lib.tf_last_error()
     assert lib.tf_inner_light_fwd(None, None, None, None, 5, 5.0, 9, None, None, 0, None) == -1 and b"unknown precision" in lib.tf_last_error()
     assert lib.tf_sdf_forward(None, None, None, None, None, None, 5, None, None, 2, None, 0, None) != 0
+
+
+def test_round2_entry_points_validate(lib):
+    """Arguments added in round 2 are checked on the host before any launch: the row range of tf_shade_dirs, the precision of
+    tf_linear_*, the float-threshold compaction, the optional hit flags of tf_shade_reduce_env."""
+    a = C.addressof((C.c_float * 16)())
+    sd = lambda r0, rc: lib.tf_shade_dirs(a, a, a, a, a, a, a, 2, a, None, 3, a, a, 2, 5, a, a, a, None, None, None, r0, rc, None)
+    assert sd(5, 4) == -2 and b"row range" in lib.tf_last_error()              # rows [5, 9) of T = 7
+    assert sd(-1, 2) == -2
+    assert lib.tf_shade_dirs(a, a, a, a, a, a, a, 2, a, None, 3, a, a, 2, 0, a, a, a, None, None, None, 0, -1, None) == 0      # no points: no-op
+    assert lib.tf_linear_fwd(a, a, None, 4, 2, 2, 0, 0.0, 2, a, None, None) == -1 and b"precision" in lib.tf_last_error()      # TF_PREC_F16 is not offered
+    assert lib.tf_linear_bwd(a, a, a, a, 4, 2, 2, 0, 0.0, 7, a, None, None, None, None, None) == -1
+    assert lib.tf_linear_fwd(a, a, None, 0, 2, 2, 0, 0.0, 1, a, None, None) == 0                                              # n = 0 with the f16x3 option
+    assert lib.tf_compact_below(None, 10.0, -1, None, None, None) == -2
+    assert lib.tf_compact_below(None, 10.0, 4, None, None, None) == -1 and b"count is null" in lib.tf_last_error()
+    # hit may be NULL (depth < TF_MISS_DEPTH); the other arrays may not
+    assert lib.tf_shade_reduce_env(a, a, a, None, a, None, 4, 1e-5, 3, 2, 1, a, None, None, None, None) == -1 and b"null pointer" in lib.tf_last_error()
+    assert lib.tf_shade_reduce_env(a, a, a, None, a, a, 0, 1e-5, 3, 2, 1, a, None, None, None, None) == -2
