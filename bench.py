@@ -803,6 +803,18 @@ def main():
                 line["config4_fp16"] = fp16_probe(sh, pts, view, nrm, S, max(2, args.steps), out["colors"])
             except Exception as e:
                 line["config4_fp16"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train and args.precision == "f16x3":
+            # the conservative reading of the headline: the inner-light decoder on the fp32-grade f16x3 split as well (the default runs it
+            # on plain f16 operands, whose per-pixel error stays inside the 1e-4 bar: DESIGN.md section 3, "Operand precision")
+            try:
+                keep_ip = sh.inner_precision
+                sh.inner_precision = _ops.PREC_F16X3
+                line["headline_inner_light_f16x3"] = flow_count_probe(sh, pts, view, nrm, S, max(2, args.steps))
+                line["headline_inner_light_f16x3"]["workload"] += ", inner-light decoder on f16x3 operands like the flow nets"
+            except Exception as e:
+                line["headline_inner_light_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                sh.inner_precision = keep_ip
         if world == 1 and not args.no_train and S == 128:
             # BASELINE configs[3] at one GPU's share: 256 flow samples per lobe (1024 secondary rays per point)
             try:
