@@ -386,13 +386,19 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     const float g = valid ? g_logq[row] : 0.f;
     const long long pt0 = __shfl(pt, 0);
     const bool uniform_pt = __all(pt == pt0) != 0;
-    // ---- forward recompute
-    float in8a[8], in8b[8], wv1[32], wv0[32];
-    f32x16 in1a[1], a1[2], a2[2], a3[2];
-    embed8(x1, in8a);
-    net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);   // net 1 keeps x1, moves x0
+    // ---- forward recompute.  Net 1's activations are NOT kept across net 0's forward and backward (kept, the kernel needed 512
+    // registers and still spilled 517 values into its hot loops): net 1 runs once for z0 and a second time just before its own
+    // backward -- one more small forward per tile instead of the scratch traffic.
+    float in8a[8], in8b[8], wv0[32];
     float z0, lj1;
-    pw_forward_fb(x0, wv1, z0, lj1);
+    {
+      float wv1[32];
+      f32x16 in1a[1], a1[2], a2[2], a3[2];
+      embed8(x1, in8a);
+      net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);   // net 1 keeps x1, moves x0
+      pw_forward_fb(x0, wv1, z0, lj1);
+    }
+    asm volatile("" : "+v"(z0));                   // the first evaluation ends here: nothing of it but z0 stays live
     f32x16 in1b[1], b1[2], b2[2], b3[2];
     embed8(z0, in8b);
     net_fwd_keep(net_lds, P + pt * 64, in8b, lane, in1b, b1, b2, b3, wv0);                        // net 0 keeps z0, moves x1
@@ -410,8 +416,16 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     float* const gB0[4] = {nullptr, sl0 + kGB1, sl0 + kGB2, sl0 + kGB3};
     net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, gW0, gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
     // d(2*emb(z0) - 1)/dz0
-    const float g_z0 = 2.f * (g_in8[0] + g_in8[1] * cosf(z0) - g_in8[2] * sinf(z0) + 2.f * g_in8[3] * cosf(2.f * z0) -
-                              2.f * g_in8[4] * sinf(2.f * z0) + 4.f * g_in8[5] * cosf(4.f * z0) - 4.f * g_in8[6] * sinf(4.f * z0));
+    float g_z0 = 2.f * (g_in8[0] + g_in8[1] * cosf(z0) - g_in8[2] * sinf(z0) + 2.f * g_in8[3] * cosf(2.f * z0) -
+                        2.f * g_in8[4] * sinf(2.f * z0) + 4.f * g_in8[5] * cosf(4.f * z0) - 4.f * g_in8[6] * sinf(4.f * z0));
+    asm volatile("" : "+v"(g_z0));
+    // net 1 again, this time keeping what its backward needs
+    float wv1[32];
+    f32x16 in1a[1], a1[2], a2[2], a3[2];
+    float x1_again = x1;
+    asm volatile("" : "+v"(x1_again));             // a value of its own: otherwise the two evaluations are merged and kept live after all
+    embed8(x1_again, in8a);
+    net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);
     float g_wv1[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
