@@ -154,6 +154,58 @@ __global__ void __launch_bounds__(256) vm_gather_kernel(VmGeom g, const float* _
   }
 }
 
+// Backward of the gather with ONE CHANNEL per lane: the C channels of a texel are C consecutive floats of the channel-last pyramid, so
+// the C lanes of a (point, plane) add to C consecutive words with one atomic instruction per texel -- 16 words per 64-byte atomic
+// request instead of the 4 the float4-chunk mapping of the forward kernel gave (its four per-component atomics each touched every
+// fourth word).  The gradient buffer (51 MB at R = 300) lives behind the L2: the scatter is bound by atomic REQUESTS.
+__global__ void __launch_bounds__(256) vm_scatter_kernel(VmGeom g, const float* __restrict__ packed, const float* __restrict__ xyz,
+                                                         const float* __restrict__ level, long long n, const float* __restrict__ gfeat,
+                                                         float* __restrict__ out) {
+  const int cpp = 3 * g.C;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * cpp) return;
+  const long long pt = e / cpp;
+  const int q = (int)(e % cpp);
+  const int i = q / g.C, c = q % g.C;
+  float p[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = (xyz[pt * 3 + k] - g.aabb_lo[k]) / g.aabb_size[k];
+  const int m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2, vm = 2 - i;
+  const float u = p[m0], v = p[m1], wv = p[vm];
+  int l0, l1;
+  float fl;
+  mip_select(level ? level[pt] : 0.f, g.n_levels, l0, l1, fl);
+  const float gs = gfeat[e];
+  float pv = 0.f, lv = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int li = 0; li < 2; ++li) {
+      const int l = li ? l1 : l0;
+      const float wl = li ? fl : 1.f - fl;
+      if (li && fl == 0.f) break;
+      const int H = vm_dim(g.ph[i], l), W = vm_dim(g.pw[i], l), L = vm_dim(g.ll[i], l);
+      int x0, x1, y0, y1, z0, z1;
+      float fx, fy, fz;
+      axis_taps(u, W, x0, x1, fx);
+      axis_taps(v, H, y0, y1, fy);
+      axis_taps(wv, L, z0, z1, fz);
+      const long long pb = g.poff[i][l], lb = g.loff[i][l];
+      const long long a00 = pb + ((long long)y0 * W + x0) * g.C + c, a10 = pb + ((long long)y0 * W + x1) * g.C + c;
+      const long long a01 = pb + ((long long)y1 * W + x0) * g.C + c, a11 = pb + ((long long)y1 * W + x1) * g.C + c;
+      const long long b0 = lb + (long long)z0 * g.C + c, b1 = lb + (long long)z1 * g.C + c;
+      if (pass == 0) {       // same expressions as the forward kernel's lerp4 (a * (1 - t) + b * t), per channel
+        const float top = packed[a00] * (1.f - fx) + packed[a10] * fx, bot = packed[a01] * (1.f - fx) + packed[a11] * fx;
+        pv += wl * (top * (1.f - fy) + bot * fy);
+        lv += wl * (packed[b0] * (1.f - fz) + packed[b1] * fz);
+      } else {
+        const float gp_ = gs * lv * wl, gl_ = gs * pv * wl;
+        atomicAdd(out + a00, gp_ * ((1.f - fx) * (1.f - fy))); atomicAdd(out + a10, gp_ * (fx * (1.f - fy)));
+        atomicAdd(out + a01, gp_ * ((1.f - fx) * fy)); atomicAdd(out + a11, gp_ * (fx * fy));
+        atomicAdd(out + b0, gl_ * (1.f - fz)); atomicAdd(out + b1, gl_ * fz);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" size_t tf_vm_packed_floats(const TfVmDesc* d) {
   VmGeom g;
@@ -237,8 +289,13 @@ extern "C" int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const fl
   TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_vm_gather_bwd: n < 0");
   if (n == 0) return TF_OK;
   TF_REQUIRE(packed && xyz && gfeat && gpacked, TF_EINVAL, "tf_vm_gather_bwd: null pointer");
+#ifdef VM_SCATTER_CHUNKS      // dev-only switch: the float4-chunk mapping of the forward kernel
   long long work = (long long)n * (3 * g.C / 4);
   vm_gather_kernel<true><<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked);
+#else
+  long long work = (long long)n * (3 * g.C);
+  vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked);
+#endif
   TF_LAUNCH_CHECK("tf_vm_gather_bwd");
   return TF_OK;
 }
