@@ -36,11 +36,13 @@ __global__ void __launch_bounds__(256) cube_lookup_bwd_kernel(const float* __res
                                                               const float* __restrict__ g_out, float* __restrict__ g_base,
                                                               float* __restrict__ g_dirs) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
+  // a lane past the end stays in the wave (the map scatter below exchanges values across lanes) with a harmless direction and no gradient
+  const bool live = i < m;
+  if (!live) i = m - 1;
   const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
   CubeTaps T;
   cube_taps(dx, dy, dz, R, T);
-  float gr = g_out[3 * i], gg = g_out[3 * i + 1], gb = g_out[3 * i + 2];
+  float gr = live ? g_out[3 * i] : 0.f, gg = live ? g_out[3 * i + 1] : 0.f, gb = live ? g_out[3 * i + 2] : 0.f;
   float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -49,14 +51,25 @@ __global__ void __launch_bounds__(256) cube_lookup_bwd_kernel(const float* __res
   }
   if (apply_exp) { gr *= expf(r); gg *= expf(g); gb *= expf(b); }
   if (g_base) {
+    // The map (18.9 MB at 512^2) sits behind the L2, where a scatter is bound by atomic REQUESTS: the three channels of a texel are
+    // three consecutive words, so three NEIGHBOURING lanes add them in one instruction (one request per texel instead of three).
+    // Per tap, four sub-steps of 16 rays: lane 3 r' + c serves channel c of ray 16 s + r' (values fetched across lanes).
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / 3, c = lane - 3 * grp;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (T.w[t] == 0.f) continue;
-      float* p = g_base + 3LL * T.idx[t];
-      atomicAdd(p, T.w[t] * gr); atomicAdd(p + 1, T.w[t] * gg); atomicAdd(p + 2, T.w[t] * gb);
+      const float w0 = T.w[t] * gr, w1 = T.w[t] * gg, w2 = T.w[t] * gb;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const int src = (16 * sub + grp) & 63;
+        const int idx_s = __shfl(T.idx[t], src);
+        const float v0 = __shfl(w0, src), v1 = __shfl(w1, src), v2 = __shfl(w2, src);
+        const float val = c == 0 ? v0 : c == 1 ? v1 : v2;
+        if (lane < 48 && val != 0.f) atomicAdd(g_base + 3LL * idx_s + c, val);
+      }
     }
   }
-  if (g_dirs) {
+  if (g_dirs && live) {
     int face;
     float x, y;
     cube_face_uv(dx, dy, dz, face, x, y);
