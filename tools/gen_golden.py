@@ -282,15 +282,16 @@ def gen_shading_wide():
              sn=np.array([512, 256, cfg.get("nis_diffuse_sample_num", 64), cfg.get("nis_specular_sample_num", 32)], np.int32), **arr)
 
 
-def gen_march():
-    """ShapeRenderer.sample_ray / compute_sdf_alpha / render_core (shapeRenderer.py:871,995,1105)."""
+def _march_renderer(**over):
+    """The R = 32 ShapeRenderer of the `march_r32` fixture (same seeds -> same state_dict), with injected pre-filtered environment
+    maps and FG LUT."""
     from network.shapeRenderer import ShapeRenderer
-    from tensoflow_amd.synth import pinhole_rays
     R = 32
     cfg = dict(gridSize=[R, R, R], max_levels=3, sdf_n_comp=36, sdf_dim=256, app_dim=128, predict_BG=False,
                isBGWhite=True, has_radiance_field=False, clip_sample_variance=False, apply_occ_loss=True,
                occ_loss_step=10000, device="cpu", database_name="tensoSDF/compressor", nerfDataType=True,
                apply_gaussian_loss=False, inv_s_init=0.3)
+    cfg.update(over)
     torch.manual_seed(6033)
     r = ShapeRenderer(cfg, training=False)
     net = r.sdf_network
@@ -305,6 +306,14 @@ def gen_march():
     u = torch.linspace(0, 1, 32)
     lut = torch.stack(torch.meshgrid(u, u, indexing="ij"), -1)
     cn.FG_LUT = torch.stack([0.9 * (1 - lut[..., 1]) * lut[..., 0] + 0.05, 0.1 * (1 - lut[..., 0]) ** 2], -1)[None].contiguous()
+    return r, g, spec, diff
+
+
+def gen_march():
+    """ShapeRenderer.sample_ray / compute_sdf_alpha / render_core (shapeRenderer.py:871,995,1105)."""
+    from tensoflow_amd.synth import pinhole_rays
+    r, g, spec, diff = _march_renderer()
+    net, cn = r.sdf_network, r.color_network
     r.eval()
     rn = 96
     o, d, radii, cos = [torch.from_numpy(a) for a in pinhole_rays(rn, seed=2)]
@@ -339,6 +348,62 @@ def gen_march():
           and "outer_light" not in k}
     save("march_r32", sd=sd, bwd_w=w, fg_lut=cn.FG_LUT, env_diffuse=diff, env_spec0=spec[0], env_spec1=spec[1],
          env_spec2=spec[2], step_size=r.stepSize, base_radii=r.base_radii, **arr, **grads)
+
+
+def gen_march_eval():
+    """The validation branch of ShapeRenderer.render_core (is_train=False, shapeRenderer.py:1246-1275: expected-depth point,
+    re-evaluated normal / materials / lights, get_intersection(sn0=128, sn1=9) of utils/network_utils.py:172-202) on the rays of
+    `march_r32`, and a 24 x 24 ShapeRenderer.nvs frame (:569-668).  The renderer is the one of `march_r32` (same seeds); only the
+    outputs, the camera and a checksum of the state are stored.  nvs is run with cfg perturb = 0 (the reference leaves the training
+    jitter on in nvs -- torch.rand on its device, not reproducible across devices) and torch.set_default_tensor_type made a no-op
+    (the reference switches the default tensor type to CUDA there)."""
+    from tensoflow_amd.synth import pinhole_rays
+    r, g, spec, diff = _march_renderer(perturb=0.0, test_ray_num=200)
+    net = r.sdf_network
+    bump = float(os.environ.get("TF_GOLDEN_BUMP", "0.2"))
+    perturb_(list(net.sdf_plane) + list(net.sdf_line), bump, 11)       # bumpy geometry: reflected rays must hit something
+    with torch.no_grad():
+        # the reference's initial field is sdf ~ |x| (a point at the origin): lower the decoder's sdf bias so that there IS a surface
+        last = [m for m in net.sdf_mat if isinstance(m, torch.nn.Linear)][-1]
+        last.bias[0] -= float(os.environ.get("TF_GOLDEN_RADIUS", "0.35"))
+        r.deviation_network.variance.fill_(float(os.environ.get("TF_GOLDEN_VAR", "0.45")))   # sharp surface: acc -> 1, the depth point sits on it
+    r.eval()
+    rn = 96
+    o, d, radii, cos = [torch.from_numpy(a) for a in pinhole_rays(rn, seed=12, h=64, w=64, focal=213.0)]    # every ray near the object
+    near, far = r.near_far_from_sphere(o, d)
+    arr = {}
+    with torch.no_grad():
+        t0, t1, ridx = r.sample_ray(o, d, near, far, 0, radiis=radii, rays_cos=cos)
+        hp = torch.zeros(rn, 3, 4)
+        out = r.render_core(o, d, d, radii, cos, t0, t1, ridx, hp, cos_anneal_ratio=1.0, step=300000, is_train=False)
+    for k, v in out.items():
+        if isinstance(v, torch.Tensor):
+            arr["val/" + k] = v
+    # 24 x 24 frame: camera on the unit-2 sphere looking at the origin (blender convention: -z forward, y up)
+    h = w = 24
+    eye = torch.tensor([1.1, -1.3, 0.9])
+    eye = eye / eye.norm() * 2.0
+    fwd = -eye / eye.norm()
+    right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+    right = right / right.norm()
+    up = torch.linalg.cross(right, fwd)
+    pose = torch.stack([right, up, -fwd, eye], 1).numpy().astype(np.float32)             # [3,4] camera-to-world
+    f = 0.5 * w / np.tan(0.5 * 0.35)
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+    keep = torch.set_default_tensor_type
+    torch.set_default_tensor_type = lambda *a, **k: None
+    try:
+        frame = r.nvs(pose, K, h, w)
+    finally:
+        torch.set_default_tensor_type = keep
+    for k, v in frame.items():
+        arr["nvs/" + k] = v
+    sd = r.state_dict()
+    chk = np.array([float(sd[k].double().abs().sum()) for k in sorted(sd) if sd[k].is_floating_point() and "FG_LUT" not in k
+                    and "envlight.base" not in k and "gaussian" not in k and "outer_light" not in k], np.float64)
+    over = {k: v for k, v in sd.items() if "sdf_plane" in k or "sdf_line" in k or "deviation_network" in k or "sdf_mat" in k}       # the only tensors that differ from march_r32
+    save("march_eval_r32", sd=over, nvs_pose=pose, nvs_K=K, nvs_hw=np.array([h, w]), state_checksum=chk, rays_o=o, dirs=d, radiis=radii,
+         rays_cos=cos, t_starts=t0, t_ends=t1, ray_indices=ridx, **arr)
 
 
 def gen_march_late():
