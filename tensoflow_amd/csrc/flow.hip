@@ -625,15 +625,16 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
                                                                          nets[1].b[0], cond, pn, P);
   const size_t lds = (size_t)kWsNet * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  int attr_dev;
+  if (tf_once_needed(attr_set, &attr_dev)) {
     hipFuncSetAttribute((const void*)flow_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)flow_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)flow_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)flow_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)flow_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)flow_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    tf_once_done(attr_set, attr_dev);
   }
   TF_REQUIRE(pn < (1LL << 31), TF_ESHAPE, "%s: pn must be < 2^31", who);
   const long long tiles = (m + 63) / 64;   // 64-row groups

@@ -512,11 +512,12 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   flow_point_part_kernel2<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0], nets[1].b[0],
                                                                           cond, pn, P);
   const size_t lds = (size_t)(2 * kNetFloats + 4 * 2 * kTileLds) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  int attr_dev;
+  if (tf_once_needed(attr_set, &attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)flow_logq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
-    attr_set = true;
+    tf_once_done(attr_set, attr_dev);
   }
   const long long tiles = (m + 31) / 32;
   long long blocks = (tiles + 3) / 4;

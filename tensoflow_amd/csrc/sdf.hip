@@ -334,11 +334,12 @@ template <int MODE, bool H3>
 static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
   A.b2 = b2_dev;
   const size_t lds = (size_t)kLdsTotal * sizeof(float);  // weights + W2 streaming double buffer + geometry table
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  int attr_dev;
+  if (tf_once_needed(attr_set, &attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
-    attr_set = true;
+    tf_once_done(attr_set, attr_dev);
   }
   long long blocks = (A.n + 127) / 128;
   if (blocks > 256) blocks = 256;  // one 150 KB-LDS workgroup per CU; waves loop over tile groups

@@ -332,10 +332,10 @@ extern "C" int tf_shape_shade_pack(const TfShapeNets* nets, float* workspace, si
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net[i]->b[1], 128, 4, bb + 128);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net[i]->b[2], nout[i], 1, bb + 256);
   }
-  static float ide_host[17 * 36];
-  static bool ide_ready = false;
-  if (!ide_ready) { shape_ide_tables_host(ide_host); ide_ready = true; }
-  hipError_t e = hipMemcpyAsync(workspace + kSIde, ide_host, sizeof(ide_host), hipMemcpyHostToDevice, stream);
+  // computed once per process (C++11 magic static: thread-safe), read-only afterwards
+  struct IdeTable { float v[17 * 36]; IdeTable() { shape_ide_tables_host(v); } };
+  static const IdeTable ide_table;
+  hipError_t e = hipMemcpyAsync(workspace + kSIde, ide_table.v, sizeof(ide_table.v), hipMemcpyHostToDevice, stream);
   TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_shape_shade_pack: hipMemcpyAsync failed: %s", hipGetErrorString(e));
   TF_LAUNCH_CHECK("tf_shape_shade_pack");
   return TF_OK;

@@ -26,6 +26,20 @@ void tf_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
+// Per-DEVICE one-time set-up (kernel attributes are per device; a process may drive several).  `mask` is a function-local
+// std::atomic<unsigned long long>: returns true exactly when the calling thread should run the set-up for the current device
+// (racing first calls may both run it: the set-up calls are idempotent).  tf_once_done() marks it done.
+#include <atomic>
+static inline bool tf_once_needed(std::atomic<unsigned long long>& mask, int* dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+  *dev_out = dev;
+  return (mask.load(std::memory_order_acquire) & (1ull << dev)) == 0;
+}
+static inline void tf_once_done(std::atomic<unsigned long long>& mask, int dev) {
+  mask.fetch_or(1ull << dev, std::memory_order_release);
+}
+
 static inline unsigned tf_blocks(int64_t n, int per_block) {
   return (unsigned)((n + per_block - 1) / per_block);
 }

@@ -173,7 +173,7 @@ def update_alpha_mask(field: SdfField, inv_s, grid=(128, 128, 128), thres=1e-4, 
     return AlphaMask(field.aabb, vol), new_aabb
 
 
-class OccGrid:
+class OccGrid(torch.nn.Module):
     """Occupancy grid of the `use_occ_grid` shape configs (configs/shape/syn/compressor_occ.yaml:21): the role nerfacc.OccGridEstimator
     plays in the reference (shapeRenderer.py:213-216 construction, :950-959 sampling, :1286-1290 update_every_n_steps, :343-353
     checkpoint).  nerfacc is third-party and absent (parity unpinned); this class follows its published semantics
@@ -182,17 +182,19 @@ class OccGrid:
     (oracle/march.py:occ_grid_update, march_uniform(cells=True))."""
 
     def __init__(self, aabb, resolution=128, device="cuda"):
+        super().__init__()
         res = [int(resolution)] * 3 if isinstance(resolution, int) else [int(r) for r in resolution]
         self.device = device
-        self.resolution = torch.tensor(res, dtype=torch.int32)
-        self.aabbs = torch.as_tensor(aabb, dtype=torch.float32).reshape(1, 6).to(device)
         self.n_cells = res[0] * res[1] * res[2]
-        self.occs = torch.zeros(self.n_cells, device=device)
-        self.binaries = torch.zeros(1, *res, dtype=torch.bool, device=device)
+        # the six registered buffers of nerfacc.OccGridEstimator, by name, dtype and shape: the reference keeps the estimator as a
+        # sub-module of ShapeRenderer, so its state_dict() carries `occ_grid.<buffer>` keys and the strict load expects them
+        self.register_buffer("resolution", torch.tensor(res, dtype=torch.int32, device=device))
+        self.register_buffer("aabbs", torch.as_tensor(aabb, dtype=torch.float32).reshape(1, 6).to(device))
+        self.register_buffer("occs", torch.zeros(self.n_cells, device=device))
+        self.register_buffer("binaries", torch.zeros(1, *res, dtype=torch.bool, device=device))
         g = torch.stack(torch.meshgrid(*[torch.arange(r, device=device) for r in res], indexing="ij"), -1).reshape(-1, 3)
-        self.grid_coords = g
-        self.grid_indices = torch.arange(self.n_cells, device=device)
-        self.training = True
+        self.register_buffer("grid_coords", g)
+        self.register_buffer("grid_indices", torch.arange(self.n_cells, device=device))
         self.gen = None                      # torch.Generator on the device (tests seed it); None = global RNG
 
     # ---- nerfacc.OccGridEstimator._update / update_every_n_steps
@@ -212,7 +214,7 @@ class OccGrid:
             return False
         idx = self._cells_to_update(step, warmup_steps)
         coords = self.grid_coords[idx].float()
-        u = (coords + torch.rand(coords.shape, device=self.device, generator=self.gen)) / self.resolution.to(self.device).float()
+        u = (coords + torch.rand(coords.shape, device=self.device, generator=self.gen)) / self.resolution.float()
         lo, hi = self.aabbs[0, :3], self.aabbs[0, 3:]
         x = lo + u * (hi - lo)
         occ = occ_eval_fn(x).reshape(-1)
@@ -233,21 +235,12 @@ class OccGrid:
                                          self.binaries[0].to(torch.uint8).contiguous(), aabb, cells=True, t_jitter=jit)
         return ridx, t0, t1
 
-    # ---- checkpoint: the buffers of nerfacc.OccGridEstimator, by name
-    def state_dict(self):
-        return {"resolution": self.resolution.cpu(), "aabbs": self.aabbs.cpu(), "occs": self.occs.cpu(), "binaries": self.binaries.cpu(),
-                "grid_coords": self.grid_coords.cpu(), "grid_indices": self.grid_indices.cpu()}
-
-    def load_state_dict(self, sd):
-        if tuple(int(v) for v in sd["resolution"]) != tuple(int(v) for v in self.resolution):
+    # ---- checkpoint: nn.Module.state_dict() / load_state_dict() over the registered buffers (the `occ_grid_state_dict` entry of the
+    # reference's checkpoint, shapeRenderer.py:349-353, and the `occ_grid.*` keys inside its network_state_dict)
+    def load_state_dict(self, sd, strict=True):
+        if "resolution" in sd and tuple(int(v) for v in sd["resolution"]) != tuple(int(v) for v in self.resolution):
             raise RuntimeError(f"OccGrid: checkpoint resolution {sd['resolution'].tolist()} != {self.resolution.tolist()}")
-        self.aabbs = sd["aabbs"].to(self.device).float().reshape(1, 6)
-        self.occs = sd["occs"].to(self.device).float().reshape(-1)
-        self.binaries = sd["binaries"].to(self.device).bool().reshape(self.binaries.shape)
-
-    def train(self, mode=True):
-        self.training = mode
-        return self
+        return super().load_state_dict(sd, strict=strict)
 
 
 @torch.no_grad()

@@ -237,8 +237,7 @@ class MCShadingNetwork(nn.Module):
                 dst.load_state_dict(src.state_dict())
                 for p in dst.parameters():
                     p.requires_grad = False
-                setattr(self, f"use_flow_{name}_copy", True)
-                self._shader = None
+                setattr(self, f"use_flow_{name}_copy", True)      # load_state_dict bumped the copies' parameter versions: shader() re-packs
                 done.append(name)
         return done
 

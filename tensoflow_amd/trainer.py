@@ -111,9 +111,14 @@ class MaterialTrainer:
         replicas' Adam states stay in lockstep with a single-process run: the two trainable flows are only reached through the
         NIS losses, which start at nis_loss_iter (fields.py:1257,1296); before that their .grad stays None and Adam skips them."""
         ps = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
-        if step is not None and step < self.cfg["nis_loss_iter"]:
-            flow = {id(p) for fl in (self.net.flow_diffuse, self.net.flow_specular) for p in fl.parameters()}
-            ps = [p for p in ps if id(p) not in flow]
+        if step is not None:
+            # the thresholds are the NETWORK's (a shader_cfg may set them per lobe; the trainer cfg key only seeds them above): a flow
+            # whose loss has not started is left out, one whose loss has started is exchanged -- per flow, not for both at once
+            skip = set()
+            for name in ("diffuse", "specular"):
+                if step < self.net.cfg[f"nis_loss_iter_{name}"]:
+                    skip |= {id(p) for p in getattr(self.net, f"flow_{name}").parameters()}
+            ps = [p for p in ps if id(p) not in skip]
         return ps
 
     def refresh_flow_copies(self, step):

@@ -25,7 +25,7 @@ def _shape_renderer(g, dev, **over):
     cfg.update(over)
     r = ShapeRenderer(cfg, training=False)
     missing, unexpected = r.load_state_dict(g.sd, strict=False)
-    assert not unexpected and all("FG_LUT" in k or "envlight.base" in k or "outer_light" in k or "gaussian" in k for k in missing), (missing, unexpected)
+    assert not unexpected and all("FG_LUT" in k or "envlight.base" in k or "outer_light" in k or "gaussian" in k or k.startswith("occ_grid.") for k in missing), (missing, unexpected)
     cn = r.color_network
     cn.envlight.specular = [g[f"env_spec{i}"].to(dev) for i in range(3)]       # injected pre-filtered stack, as the generator did
     cn.envlight.diffuse = g["env_diffuse"].to(dev)
@@ -334,7 +334,10 @@ def test_occ_grid_marcher_and_state(golden, dev):
     assert isinstance(og, march.OccGrid) and og.binaries.shape == (1, 32, 32, 32) and not bool(og.binaries.any())
     og.gen = torch.Generator(device=dev).manual_seed(7)
     state = og.gen.get_state()
+    assert r.update_occ_grid(0) is False            # eval mode: the estimator only updates while training (a sub-module like nerfacc's)
+    r.train()
     assert r.update_occ_grid(0) is True and r.update_occ_grid(1) is False
+    r.eval()
     # the same update by the oracle's rule: all cells (warm-up), the same jitter, the same opacity function
     g2 = torch.Generator(device=dev)
     g2.set_state(state)

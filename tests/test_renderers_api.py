@@ -45,7 +45,22 @@ def test_shape_renderer_refuses_unbuilt_modes():
     # use_occ_grid builds the on-device occupancy grid (march.OccGrid) and its state rides in the checkpoint (shapeRenderer.py:343-353)
     r = ShapeRenderer({**SHAPE_CFG, "use_occ_grid": True, "occ_grid_reso": 16}, training=False)
     assert r.occ_grid is not None and tuple(r.occ_grid.binaries.shape) == (1, 16, 16, 16)
-    assert "occ_grid_state_dict" in r.ckpt_to_save()
+    ck = r.ckpt_to_save()
+    assert "occ_grid_state_dict" in ck
+    # nerfacc.OccGridEstimator is an nn.Module inside the reference's ShapeRenderer: its six buffers ride in network_state_dict
+    # under `occ_grid.` (and again in occ_grid_state_dict); a checkpoint written there must pass the strict load here and vice versa
+    ref_keys = {"occ_grid." + k for k in ("resolution", "aabbs", "occs", "binaries", "grid_coords", "grid_indices")}
+    assert ref_keys <= set(ck["network_state_dict"])
+    sd = {k: v.clone() for k, v in ck["network_state_dict"].items()}
+    assert sd["occ_grid.resolution"].dtype == torch.int32 and sd["occ_grid.binaries"].dtype == torch.bool
+    assert sd["occ_grid.grid_coords"].shape == (16 ** 3, 3) and sd["occ_grid.aabbs"].shape == (1, 6) and sd["occ_grid.occs"].shape == (16 ** 3,)
+    sd["occ_grid.occs"] = torch.rand(16 ** 3)
+    sd["occ_grid.binaries"] = (sd["occ_grid.occs"] > 0.5).reshape(1, 16, 16, 16)
+    r2 = ShapeRenderer({**SHAPE_CFG, "use_occ_grid": True, "occ_grid_reso": 16}, training=False)
+    r2.load_ckpt({"kwargs": ck["kwargs"], "network_state_dict": sd, "occ_grid_state_dict": {k[9:]: v for k, v in sd.items() if k.startswith("occ_grid.")}})
+    assert torch.equal(r2.occ_grid.occs, sd["occ_grid.occs"]) and torch.equal(r2.occ_grid.binaries, sd["occ_grid.binaries"])
+    with pytest.raises(RuntimeError):                 # a renderer built WITHOUT the grid refuses those keys, as the reference's strict load does
+        ShapeRenderer(SHAPE_CFG, training=False).load_ckpt({"network_state_dict": sd})
 
 
 def test_shape_renderer_ckpt_layout_and_upsample():
