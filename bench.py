@@ -243,8 +243,8 @@ def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800):
     from tensoflow_amd import ops
     from tensoflow_amd.synth import pinhole_rays
     o, d, _, _ = [torch.from_numpy(a).to(device) for a in pinhole_rays(hw * hw, seed=2, h=hw, w=hw)]
-    keep = sh.precision
-    sh.precision = ops.PREC_F16
+    keep, keep_ip = sh.precision, sh.inner_precision
+    sh.precision = sh.inner_precision = ops.PREC_F16
 
     def frame():
         pos, nrm, depth, hit = sh.bvh.trace(o, d)
@@ -265,7 +265,7 @@ def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     finally:
-        sh.precision = keep
+        sh.precision, sh.inner_precision = keep, keep_ip
     return dict(workload=f"{hw}x{hw} frame: {hw * hw} primary rays, {n_pts} surface points x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets "
                          "and the inner-light MLP, fp32 VM fields", ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
                 secondary_rays_per_s=n_pts * (2 * S + 512) / dt, finite=bool(torch.isfinite(img).all()))
@@ -276,8 +276,8 @@ def fp16_probe(sh, pts, view, nrm, S, steps, ref_colors):
     (TF_PREC_F16: one MFMA per product term in the flow coupling nets and the inner-light MLP, fp32 accumulate) and its PSNR
     against the fp32-accurate (f16x3) colours of the same points.  Not a parity-grade number: reported, never the headline."""
     from tensoflow_amd import ops
-    keep = sh.precision
-    sh.precision = ops.PREC_F16
+    keep, keep_ip = sh.precision, sh.inner_precision
+    sh.precision = sh.inner_precision = ops.PREC_F16
     try:
         for _ in range(2):
             out = sh.shade(pts, view, nrm, S, S)
@@ -291,7 +291,7 @@ def fp16_probe(sh, pts, view, nrm, S, steps, ref_colors):
         mse = float(((got - ref_colors) ** 2).mean())
         rel = float(((got - ref_colors).abs() / ref_colors.abs().clamp_min(1.0)).max())
     finally:
-        sh.precision = keep
+        sh.precision, sh.inner_precision = keep, keep_ip
     pn = pts.shape[0]
     return dict(workload=f"{pn} points x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets and the inner-light MLP",
                 ms_per_step=dt * 1e3, points_per_s=pn / dt, psnr_db_vs_f16x3=20 * math.log10(1.0 / math.sqrt(max(mse, 1e-30))),
@@ -591,7 +591,9 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
     n_par = sum(p.numel() for p in tr.trainable())
     res = dict(workload=f"BASELINE configs[3]: MCShadingNetwork train step, {pn} points per GPU x ({S} + 512 + {S}) rays, NIS losses, "
                         f"fwd + bwd + gradient averaging + Adam", ms_per_step=dt * 1e3, points_per_s=world * pn / dt,
-               trainable_parameters=n_par, gradient_bytes=4 * n_par, ranks=world)
+               trainable_parameters=n_par, gradient_bytes=4 * n_par, ranks=world,
+               ranks_reported_by_backend=(dist.get_world_size() if world > 1 else 1),
+               exchange=("none (one rank: same step without the collective)" if world == 1 else "reduce-scatter + all-gather of every trainable gradient"))
     ev = tr.comm_stats.get("events", [])
     if ev:
         ms = sum(a.elapsed_time(b) for a, b in ev) / steps
@@ -600,6 +602,31 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
                                 mode=tr.comm_stats.get("mode"), algbw_GBps=nbytes / ms / 1e6,
                                 busbw_GBps=nbytes / ms / 1e6 * 2 * (world - 1) / world, backend=dist.get_backend(), ranks=world)
     return res
+
+
+def bvh_roofline(summ, dom, traced, issued):
+    """Traversal / elementwise stages.  The byte figure of a BVH traversal is its ray I/O only -- 24 B in + 29 B out per TRACED ray
+    (zero-weight rays are retired at the fetch: 24 B in, one depth word out; node and triangle traffic is data-dependent, not
+    algorithmic).  A latency-bound traversal sits on neither roof: what one can act on is reported beside it --
+    rays/s, and from the instrumented build / PMC passes committed under profiles/ the pair steps, triangle tests and fabric
+    bytes per traced ray."""
+    ms = summ[dom][0]
+    ach = (traced * 53 + (issued - traced) * 17) / (ms * 1e-3) / 1e9
+    roof = dict(kernel="bvh_trace_kernel" if dom == "bvh_trace" else dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic("bvh_trace_kernel" if dom == "bvh_trace" else dom),
+                avg_launch_ms=ms / summ[dom][1], traced_rays_per_s=traced / (ms * 1e-3), issued_rays_per_s=issued / (ms * 1e-3),
+                per_launch=f"{traced // max(1, summ[dom][1])} traced rays x 53 B + {(issued - traced) // max(1, summ[dom][1])} zero-weight rays x 17 B "
+                           "(BVH node / triangle traffic is data-dependent, not algorithmic)")
+    st = os.path.join(REPO, "profiles", "bvh_stats.json")
+    if dom == "bvh_trace" and os.path.exists(st):
+        try:
+            with open(st) as f:
+                roof["per_traced_ray"] = json.load(f)
+        except Exception:
+            pass
+    if roof["traffic"]:
+        roof["fabric_bytes_per_traced_ray"] = roof["traffic"] / max(1, traced // max(1, summ[dom][1]))
+    return roof
 
 
 def hit_sensitivity(summ, steps, pn, hit_frac, ms_per_step):
@@ -643,7 +670,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=262144, help="surface points per GPU per step (SURVEY.md 8(d) config 3 shades 2^20 points; the rate is flat from 2^16 up: +3 % at 2^18)")
+    ap.add_argument("--points", type=int, default=1048576, help="surface points per GPU per step (SURVEY.md 8(d) config 3: 2^20), shaded in --chunk sized calls")
+    ap.add_argument("--chunk", type=int, default=262144, help="points per MCShader.shade call inside a step (805 M rays of a 2^20-point step would index past "
+                                                               "2^31 floats in one array; the reference chunks its frames the same way)")
     ap.add_argument("--flow-samples", type=int, default=128)
     ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
@@ -670,6 +699,9 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_on = world > 1
+    # N ranks share one host: each keeps its share of the cores (the host-side BVH build, the oracle legs and torch's intra-op pool
+    # would otherwise oversubscribe them N-fold)
+    torch.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, world)))
     if dist_on:
         import torch.distributed as dist
         backend = os.environ.get("TENSOFLOW_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only for 1-GPU dry runs
@@ -698,11 +730,20 @@ def main():
         order = torch.argsort(code)
         pts, nrm, view = pts[order].contiguous(), nrm[order].contiguous(), view[order].contiguous()
 
-    def step():
-        return sh.shade(pts, view, nrm, S, S)
+    chunk = max(1, min(args.chunk, pn))
+    live_rays = torch.zeros((), dtype=torch.int64, device=device)       # device-side tally of the rays the traversal is handed (weight != 0)
+
+    def step(count=False):
+        o = None
+        for c0 in range(0, pn, chunk):
+            o = sh.shade(pts[c0:c0 + chunk], view[c0:c0 + chunk], nrm[c0:c0 + chunk], S, S)
+            if count:
+                live_rays.add_(o["_pos_live" if "_pos_live" in o else "live"].sum(dtype=torch.int64))
+        return o
 
     for _ in range(args.warmup):
         step()
+    step(count=True)                                  # untimed: counts the live rays of one step (identical every step)
     timer = StageTimer()
     sh.timer = timer
     sh.hit_total = None
@@ -721,9 +762,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     value = world * pn * args.steps / dt
+    # the secondary probes below run on the first chunk of the point stream
+    pts_p, view_p, nrm_p = pts[:chunk].contiguous(), view[:chunk].contiguous(), nrm[:chunk].contiguous()
 
     train_dp = None
-    if dist_on and not args.no_train:
+    if not args.no_train:                             # world == 1 included: the same leg without an exchange, so that N = 1 can be compared with N > 1
         from tensoflow_amd.shading import _NoTimer as _NT
         sh.timer = _NT()
         try:
@@ -738,6 +781,8 @@ def main():
         dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
         hits = int(sh.hit_total.item()) if sh.hit_total is not None else 0
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
+        traced_per_step = int(live_rays.item())
+        live_frac = traced_per_step / max(1, pn * (2 * S + 512))
         if dom == "inner_light":
             n_launch = summ[dom][1]
             ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
@@ -759,23 +804,22 @@ def main():
                         frac=ach / fpeak, traffic=pmc_traffic("flow_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches)")
         else:
-            # BVH traversal / elementwise stages: byte-bound; algorithmic bytes = rays x (24 B in + 29 B out)
-            rays = pn * (2 * S + 512) * args.steps
-            ach = rays * 53 / (summ[dom][0] * 1e-3) / 1e9
-            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
-                        traffic=pmc_traffic("bvh_trace_kernel" if dom == "bvh_trace" else dom), avg_launch_ms=summ[dom][0] / summ[dom][1],
-                        per_launch=f"{rays // args.steps} rays x 53 B of ray in/out (BVH node traffic is data-dependent, not algorithmic)")
+            roof = bvh_roofline(summ, dom, traced_per_step * args.steps, pn * (2 * S + 512) * args.steps)
         line = {
             "metric": "shaded surface points/s @128 flow samples", "value": value, "unit": "points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (matrix products on the f16 MFMA with fp32 accumulate: f16x3 operand split in the flow nets, f16 operands in the inner-light decoder; per-pixel parity 1e-4 in tests/)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
                                    f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
+                       "arithmetic": "fp32 end to end at the ABI; every decoder product (flow coupling nets, inner-light MLP, per-point nets) is fp32-grade: "
+                                     + ("exact fp32 MFMA" if args.precision == "f32" else "f16x3 operand split (x = hi + lo, three f16 MFMAs per product term, fp32 accumulate: 22 significant bits per operand) in EVERY decoder, none on plain f16 operands"),
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",
-                       "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "parallelism": f"points sharded x{world}, no collective",
-                       "hit_rate_sensitivity": hit_sensitivity(summ, args.steps, pn, hit_frac, dt / args.steps * 1e3),
-                       "deviations_from_SURVEY_8d_config3": "2^18 points per step instead of 2^20 (the rate is flat from 2^16 up: see --points); "
-                                                             "this synthetic scene's hit fraction is 0.148, the survey sketched ~0.20"},
+                       "points_per_shade_call": chunk,
+                       "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "live_ray_fraction": live_frac,
+                       "traced_rays_per_step": traced_per_step, "hit_rays_per_step": hits // max(1, args.steps),
+                       "parallelism": f"points sharded x{world}, no collective",
+                       "deviations_from_SURVEY_8d_config3": "surface points on the sphere only: hit fraction 0.148 where the survey sketched ~0.20; the "
+                                                             "`scene_points` probe shades points over sphere AND torus (measured hit fraction there)"},
             "roofline": roof,
             "roofline_other": other_rooflines(summ, timer, hits, args, sh, dom),
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
@@ -791,7 +835,7 @@ def main():
         sh.timer = _NoTimer()                     # the secondary probes below are not part of the timed region
         if world == 1 and not args.no_train:
             try:
-                line["flow_only"] = flow_only_probe(device, sd, verts, faces, aabb, unit, S, max(2, args.steps), pn)
+                line["flow_only"] = flow_only_probe(device, sd, verts, faces, aabb, unit, S, max(2, args.steps), chunk)
             except Exception as e:
                 line["flow_only"] = {"error": f"{type(e).__name__}: {e}"}
             try:
@@ -800,25 +844,39 @@ def main():
                 line["train"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":
             try:
-                line["config4_fp16"] = fp16_probe(sh, pts, view, nrm, S, max(2, args.steps), out["colors"])
+                ref_p = sh.shade(pts_p, view_p, nrm_p, S, S)["colors"]
+                line["config4_fp16"] = fp16_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps), ref_p)
             except Exception as e:
                 line["config4_fp16"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":
-            # the conservative reading of the headline: the inner-light decoder on the fp32-grade f16x3 split as well (the default runs it
-            # on plain f16 operands, whose per-pixel error stays inside the 1e-4 bar: DESIGN.md section 3, "Operand precision")
+            # NOT parity-grade arithmetic, reported only: the headline pass with the inner-light decoder alone on plain f16 operands
+            # (one MFMA per product term; the flow nets stay f16x3).  Per-pixel error stays inside 1e-4 on the reference goldens
+            # (tests/test_gpu_parity.py::test_inner_light_operand_modes_on_trained_like_net) -- never the headline `value`.
             try:
                 keep_ip = sh.inner_precision
-                sh.inner_precision = _ops.PREC_F16X3
-                line["headline_inner_light_f16x3"] = flow_count_probe(sh, pts, view, nrm, S, max(2, args.steps))
-                line["headline_inner_light_f16x3"]["workload"] += ", inner-light decoder on f16x3 operands like the flow nets"
+                sh.inner_precision = _ops.PREC_F16
+                line["inner_light_f16_operands"] = flow_count_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps))
+                line["inner_light_f16_operands"]["workload"] += ", inner-light decoder on plain f16 operands (narrower than the reference's fp32: reported, not credited)"
             except Exception as e:
-                line["headline_inner_light_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+                line["inner_light_f16_operands"] = {"error": f"{type(e).__name__}: {e}"}
             finally:
                 sh.inner_precision = keep_ip
+        if world == 1 and not args.no_train:
+            # SURVEY.md 8(d) config 3 sketches points over sphere AND torus with ~20 % of the secondary rays hitting: measured, not extrapolated
+            try:
+                from tensoflow_amd.synth import scene_surface_points
+                p2, n2, v2 = [torch.from_numpy(a).to(device) for a in scene_surface_points(chunk, seed=16)]
+                sh.hit_total = None
+                line["scene_points"] = flow_count_probe(sh, p2, v2, n2, S, max(2, args.steps))
+                n_calls = 2 + max(2, args.steps)
+                line["scene_points"]["hit_fraction"] = int(sh.hit_total.item()) / (n_calls * chunk * (2 * S + 512))
+                line["scene_points"]["workload"] += ", surface points area-uniform over sphere and torus"
+            except Exception as e:
+                line["scene_points"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and S == 128:
             # BASELINE configs[3] at one GPU's share: 256 flow samples per lobe (1024 secondary rays per point)
             try:
-                line["config3_flow256"] = flow_count_probe(sh, pts, view, nrm, 256, max(2, args.steps))
+                line["config3_flow256"] = flow_count_probe(sh, pts_p, view_p, nrm_p, 256, max(2, args.steps))
             except Exception as e:
                 line["config3_flow256"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":

@@ -80,6 +80,35 @@ def sphere_surface_points(n, seed=6, radius=0.5, cam_dist=2.0, n_cams=8):
     return pts.astype(np.float32), d.astype(np.float32), view.astype(np.float32)
 
 
+def torus_surface_points(n, seed=6, R=0.75, r=0.12, cam_dist=2.0, n_cams=8):
+    """Points on the torus of `sphere_torus_mesh` (area-uniform: rejection on the (R + r cos w) area element) with analytic normals
+    and view dirs toward the camera the normal faces best. -> pts, normals, view_dirs  (f32 [n,3])."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(0, 2 * np.pi, size=3 * n + 64)
+    w = rng.uniform(0, 2 * np.pi, size=3 * n + 64)
+    keep = rng.uniform(0, R + r, size=u.shape) < R + r * np.cos(w)
+    u, w = u[keep][:n], w[keep][:n]
+    assert len(u) == n
+    nrm = np.stack([np.cos(w) * np.cos(u), np.cos(w) * np.sin(u), np.sin(w)], -1)
+    pts = np.stack([R * np.cos(u), R * np.sin(u), np.zeros_like(u)], -1) + r * nrm
+    k = np.arange(n_cams)
+    cams = np.stack([np.cos(2 * np.pi * k / n_cams) * math.cos(0.5), np.sin(2 * np.pi * k / n_cams) * math.cos(0.5),
+                     np.full(n_cams, math.sin(0.5))], -1) * cam_dist
+    pick = np.argmax(nrm @ cams.T + rng.uniform(0, 0.3, size=(n, n_cams)), axis=-1)
+    view = cams[pick] - pts
+    view /= np.linalg.norm(view, axis=-1, keepdims=True)
+    return pts.astype(np.float32), nrm.astype(np.float32), view.astype(np.float32)
+
+
+def scene_surface_points(n, seed=6):
+    """Points over the WHOLE bench scene (sphere and torus, split by surface area: 47 % / 53 %), shuffled."""
+    a_s, a_t = 4 * math.pi * 0.25, 4 * math.pi ** 2 * 0.75 * 0.12
+    n_s = int(round(n * a_s / (a_s + a_t)))
+    parts = [sphere_surface_points(n_s, seed=seed), torus_surface_points(n - n_s, seed=seed + 1)]
+    perm = np.random.default_rng(seed + 2).permutation(n)
+    return tuple(np.concatenate([a[i] for a in parts], 0)[perm] for i in range(3))
+
+
 def pinhole_rays(n, seed=2, h=800, w=800, focal=1111.1, cam_dist=2.0, az=0.7, el=0.5):
     """n random pixels of an h x w pinhole looking at the origin.
     -> rays_o, rays_d (unit), radiis [n,1], rays_cos [n,1]  (shapeRenderer.py:479-486,510 style)."""
