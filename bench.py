@@ -234,11 +234,11 @@ def flow_count_probe(sh, pts, view, nrm, S, steps):
                 rays_per_s=pn * (2 * S + 512) / dt)
 
 
-def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800):
+def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800, field_note="fp32 VM fields"):
     """Secondary figure (BASELINE configs[4] at one GPU's share): ONE full 800 x 800 frame -- primary visibility of the 640 000 pinhole
     rays through the mesh BVH, then the flow-sampled integral with 512 samples per lobe (512 + 512 + 512 = 1 536 secondary rays per
-    surface point) on every pixel that sees the object, plain-f16 operands in the flow nets and the inner-light MLP ('fp16 ... flow';
-    the VM fields stay fp32).  The camera rays are resident in HBM before the timed region; the frame's
+    surface point) on every pixel that sees the object, plain-f16 operands in the flow nets and the inner-light MLP ('fp16 ... flow');
+    with an MCShader built with field_f16=True the material / flow VM pyramids hold halves as well ('fp16 field').  The camera rays are resident in HBM before the timed region; the frame's
     data-dependent point count costs one host sync per frame, as in MaterialRenderer.nvs."""
     from tensoflow_amd import ops
     from tensoflow_amd.synth import pinhole_rays
@@ -267,7 +267,7 @@ def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800):
     finally:
         sh.precision, sh.inner_precision = keep, keep_ip
     return dict(workload=f"{hw}x{hw} frame: {hw * hw} primary rays, {n_pts} surface points x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets "
-                         "and the inner-light MLP, fp32 VM fields", ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
+                         f"and the inner-light MLP, {field_note}", ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
                 secondary_rays_per_s=n_pts * (2 * S + 512) / dt, finite=bool(torch.isfinite(img).all()))
 
 
@@ -375,7 +375,7 @@ def shape_train_probe(device, steps, n_rays=1024):
                 ms_per_step=dt * 1e3, rays_per_s=n_rays / dt, trainable_parameters=n_par)
 
 
-def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
+def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256, field_f16=False):
     """Secondary figure (BASELINE configs[1]): one full 800x800 frame of the shape stage -- fixed-step sampler with occupancy
     culling (tf_march_uniform), fused 7-tap sdf/FD/alpha kernel, split-sum shading, compositing.  Reports rays/s, live
     samples/s and the gather roofline of the sdf kernel (18 144 B and 466 944 flop per live sample, level >= ... one mip)."""
@@ -386,7 +386,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     R = 300
     sd = {"sdf_network." + k: v for k, v in random_sdf_state(seed=1, R=R).items()}
     sd.update(random_shape_shader_state(seed=8))
-    field = march.SdfField(sd, [[-1.0, -1, -1], [1, 1, 1]], [R, R, R], 3, device=device)
+    field = march.SdfField(sd, [[-1.0, -1, -1], [1, 1, 1]], [R, R, R], 3, device=device, field_f16=field_f16)
     env = EnvLight(trainable=False, max_res=128, device=device)
     env.base.data = sd["color_network.envlight.base"].to(device)
     t_env = time.perf_counter()
@@ -444,7 +444,7 @@ def march_probe(device, steps, n_rays_total=640000, chunk=65536, n_steps=256):
     dt = (time.perf_counter() - t0) / steps
     sdf_s = sum(s.elapsed_time(e) for s, e in sdf_ev) * 1e-3 / steps
     sps = live / sdf_s
-    return dict(workload=f"TensoSDF R=300 C=36 3 mips, {n_rays_total} rays x {n_steps} fixed steps, 128^3 occupancy culling, "
+    return dict(workload=f"TensoSDF R=300 C=36 3 mips{' (HALF texels: 72-byte texel segments)' if field_f16 else ''}, {n_rays_total} rays x {n_steps} fixed steps, 128^3 occupancy culling, "
                          f"fused 7-tap sdf+FD+alpha (eval: no hessian term, f16x3 decoder), split-sum shading, compositing (forward)",
                 rays_per_s=n_rays_total / dt, frame_ms=dt * 1e3, live_samples_per_frame=live,
                 live_fraction=live / (n_rays_total * n_steps), sdf_alpha_ms_per_frame=sdf_s * 1e3,
@@ -882,6 +882,10 @@ def main():
         if world == 1 and not args.no_train and args.precision == "f16x3":
             try:
                 line["config4_frame512"] = relight_frame_probe(sh, device, 2)
+                from tensoflow_amd.shading import MCShader as _MC
+                sh16 = _MC(sd, verts, faces, aabb, unit, device=device, n_fixed_diffuse=512, bvh=sh.bvh, field_f16=True)
+                line["config4_frame512_f16_field"] = relight_frame_probe(sh16, device, 2, field_note="HALF-texel material / flow VM pyramids (fp16 field + flow: BASELINE configs[4] as written)")
+                del sh16
             except Exception as e:
                 line["config4_frame512"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train:
@@ -894,6 +898,12 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()              # the probes above leave ~20 GB of cached blocks behind
             line["march"] = march_probe(device, max(2, args.steps))
+            try:      # A/B of the half-texel pyramid (BASELINE configs[4]'s "fp16 field") on the same frame
+                mh = march_probe(device, max(2, args.steps), field_f16=True)
+                line["march"]["f16_field"] = {k: mh[k] for k in ("workload", "rays_per_s", "frame_ms", "live_samples_per_frame", "sdf_alpha_ms_per_frame",
+                                                                 "sdf_alpha_samples_per_s")}
+            except Exception as e:
+                line["march"]["f16_field"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], line["psnr"] = cpu_baseline(sd, verts, faces, aabb, unit, 16384, S, sh=sh)
             if "march" in line:

@@ -76,9 +76,18 @@ typedef struct TfVmDesc {
   int32_t ph[3];    /* plane heights at level 0 (v axis) */
   int32_t pw[3];    /* plane widths  at level 0 (u axis) */
   int32_t ll[3];    /* line lengths  at level 0 */
+  int32_t texel_f16; /* 0: the pyramid holds fp32 texels.  1: IEEE half texels (BASELINE configs[4] "fp16 field"): `packed` arguments
+                      * of the gather / decoder entry points then point at tf_vm_packed_floats() HALVES (same element offsets, half the
+                      * bytes: a C = 36 texel is 72 B instead of 144 B); taps are widened to fp32 on load, blends and products stay fp32.
+                      * Inference only (the gather / pack adjoints take fp32 pyramids).  Not parity-grade: opt-in. */
 } TfVmDesc;
 
 size_t tf_vm_packed_floats(const TfVmDesc* d);
+
+/* The half pyramid of an fp32 pyramid built by tf_vm_pack_fwd: packed16[e] = round-to-nearest-even(packed[e]) for all
+ * tf_vm_packed_floats(d) elements (mips are averaged in fp32 first, rounded once).  Replaces the `.half()` of the field tensors
+ * in an fp16 evaluation of network/fields.py:276-288,790-802 and network/flow.py:723-735. */
+int tf_vm_pack_to_f16(const TfVmDesc* d, const float* packed, void* packed16, tf_stream_t stream);
 
 /* planes[i]: [C,H,W] (the reference's nn.Parameter [1,C,H,W]); lines[i]: [C,L] ([1,C,L,1]). */
 int tf_vm_pack_fwd(const TfVmDesc* d, const float* const planes[3], const float* const lines[3],

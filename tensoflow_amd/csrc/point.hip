@@ -75,14 +75,14 @@ __device__ __forceinline__ void gather_rows(const VmGeom& g, const float* __rest
     axis_taps(u, W, x0, x1, fx);
     axis_taps(v, H, y0, y1, fy);
     axis_taps(w, L, z0, z1, fz);
-    const float* pb = packed + g.poff[i][0] + 4 * j;
-    const float* lb = packed + g.loff[i][0] + 4 * j;
-    const float4 t00 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x0) * C);
-    const float4 t10 = *reinterpret_cast<const float4*>(pb + ((long long)y0 * W + x1) * C);
-    const float4 t01 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x0) * C);
-    const float4 t11 = *reinterpret_cast<const float4*>(pb + ((long long)y1 * W + x1) * C);
-    const float4 s0 = *reinterpret_cast<const float4*>(lb + (long long)z0 * C);
-    const float4 s1 = *reinterpret_cast<const float4*>(lb + (long long)z1 * C);
+    const long long pb = g.poff[i][0] + 4 * j, lb = g.loff[i][0] + 4 * j;
+    const int f16 = g.texel_f16;                       // wave-uniform: half pyramid (TfVmDesc.texel_f16), widened on load
+    const float4 t00 = vm_texel4(packed, pb + ((long long)y0 * W + x0) * C, f16);
+    const float4 t10 = vm_texel4(packed, pb + ((long long)y0 * W + x1) * C, f16);
+    const float4 t01 = vm_texel4(packed, pb + ((long long)y1 * W + x0) * C, f16);
+    const float4 t11 = vm_texel4(packed, pb + ((long long)y1 * W + x1) * C, f16);
+    const float4 s0 = vm_texel4(packed, lb + (long long)z0 * C, f16);
+    const float4 s1 = vm_texel4(packed, lb + (long long)z1 * C, f16);
     const float4 pl = pt_lerp4(pt_lerp4(t00, t10, fx), pt_lerp4(t01, t11, fx), fy), ln = pt_lerp4(s0, s1, fz);
     float* x = X + r * KP + 4 * q;
     x[0] = pl.x * ln.x; x[1] = pl.y * ln.y; x[2] = pl.z * ln.z; x[3] = pl.w * ln.w;

@@ -74,6 +74,7 @@ struct ChunkRaw {
 // Per (plane, level) geometry lives in LDS as 8 ints {H, W, L, plane offset, line offset, -, -, -}: the plane index
 // of a chunk differs between the two lane halves and the level differs per lane, so the lookup is a per-lane LDS
 // read instead of select chains over kernel arguments.
+template <bool TEX16>
 __device__ __forceinline__ void load_chunk(const int* __restrict__ geo, const float* __restrict__ packed, const float (&p)[3],
                                            int l, int q, ChunkRaw& r) {
   const int i = q / (SDF_C / 4), j = q % (SDF_C / 4);
@@ -85,14 +86,13 @@ __device__ __forceinline__ void load_chunk(const int* __restrict__ geo, const fl
   axis_taps(u, W, x0, x1, r.fx);
   axis_taps(v, H, y0, y1, r.fy);
   axis_taps(w, L, z0, z1, r.fz);
-  const float* pb = packed + (unsigned)(ga.w + 4 * j);
-  const float* lb = packed + (unsigned)(loff + 4 * j);
-  r.t00 = *reinterpret_cast<const float4*>(pb + (unsigned)((y0 * W + x0) * SDF_C));
-  r.t10 = *reinterpret_cast<const float4*>(pb + (unsigned)((y0 * W + x1) * SDF_C));
-  r.t01 = *reinterpret_cast<const float4*>(pb + (unsigned)((y1 * W + x0) * SDF_C));
-  r.t11 = *reinterpret_cast<const float4*>(pb + (unsigned)((y1 * W + x1) * SDF_C));
-  r.s0 = *reinterpret_cast<const float4*>(lb + (unsigned)(z0 * SDF_C));
-  r.s1 = *reinterpret_cast<const float4*>(lb + (unsigned)(z1 * SDF_C));
+  const unsigned pb = (unsigned)(ga.w + 4 * j), lb = (unsigned)(loff + 4 * j);      // element offsets (the same in a half pyramid)
+  r.t00 = vm_texel4<TEX16>(packed, pb + (unsigned)((y0 * W + x0) * SDF_C));
+  r.t10 = vm_texel4<TEX16>(packed, pb + (unsigned)((y0 * W + x1) * SDF_C));
+  r.t01 = vm_texel4<TEX16>(packed, pb + (unsigned)((y1 * W + x0) * SDF_C));
+  r.t11 = vm_texel4<TEX16>(packed, pb + (unsigned)((y1 * W + x1) * SDF_C));
+  r.s0 = vm_texel4<TEX16>(packed, lb + (unsigned)(z0 * SDF_C));
+  r.s1 = vm_texel4<TEX16>(packed, lb + (unsigned)(z1 * SDF_C));
 }
 
 template <int NL>
@@ -113,7 +113,7 @@ __device__ __forceinline__ float4 blend_chunk(const ChunkRaw (&r)[NL], float fl)
 // NL = number of mip levels fetched (1 when no lane of the wave has a fractional LOD, else 2).
 // Layer 1 runs as 7 feature groups of 2 chunks (8 k-steps x 8 unit tiles = 64 MFMAs each): while group g's MFMAs
 // execute, the 12*NL texel loads of group g+1 are already in flight.
-template <int NL, bool H3>
+template <int NL, bool H3, bool TEX16>
 __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
                                                int l1, float fl, int lane, f32x16 (&acc)[8]) {
   // Make the LDS base opaque per call: every LDS operand of this function (W1 fragments, biases, the sdf row of
@@ -140,8 +140,8 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
     for (int c = 0; c < 2; ++c) {
       int q = 4 * g + 2 * c + h;        // this lane's chunks of group g: q = 2*(2g+c) + h
       if (q > 26) q = 26;               // lane half 1 of the last group carries (x,y,z,0) instead: dummy fetch
-      load_chunk(geo, A.packed, p, l0, q, raw[c][0]);
-      if (NL == 2) load_chunk(geo, A.packed, p, l1, q, raw[c][NL - 1]);
+      load_chunk<TEX16>(geo, A.packed, p, l0, q, raw[c][0]);
+      if (NL == 2) load_chunk<TEX16>(geo, A.packed, p, l1, q, raw[c][NL - 1]);
     }
   };
   issue(0);
@@ -203,15 +203,15 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
   return part + A.b2[0];
 }
 
-template <bool H3>
+template <bool H3, bool TEX16>
 __device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
                                             int l1, float fl, int lane, f32x16 (&acc)[8]) {
   // wave-uniform choice: one mip level is enough when no lane has a fractional LOD
-  if (__any(fl != 0.f)) return sdf_hidden_nl<2, H3>(A, lds, x, l0, l1, fl, lane, acc);
-  return sdf_hidden_nl<1, H3>(A, lds, x, l0, l1, fl, lane, acc);
+  if (__any(fl != 0.f)) return sdf_hidden_nl<2, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc);
+  return sdf_hidden_nl<1, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc);
 }
 
-template <int MODE, bool H3>  // MODE 0: sdf + feat, 1: sdf only, 2: alpha (7 taps); H3: f16x3 matrix arithmetic
+template <int MODE, bool H3, bool TEX16 = false>  // MODE 0: sdf + feat, 1: sdf only, 2: alpha (7 taps); H3: f16x3 matrix arithmetic; TEX16: half pyramid
 __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
     float fl;
     mip_select(A.level ? A.level[row] : 0.f, A.g.n_levels, l0, l1, fl);
     f32x16 acc[8];
-    const float s_c = sdf_hidden<H3>(A, lds, x, l0, l1, fl, lane, acc);
+    const float s_c = sdf_hidden<H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc);
     if (MODE != 1 && A.feat) {
       // appearance features: [128 x 256] * H^T, W2 fragments streamed from L2
       f32x16 o[4];
@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
     for (int ax = 0; ax < 3; ++ax) {
       float xt[3] = {x[0], x[1], x[2]};
       xt[ax] = x[ax] + A.units[ax];
-      sp[ax] = sdf_hidden<H3>(A, lds, xt, l0, l1, fl, lane, acc);
+      sp[ax] = sdf_hidden<H3, TEX16>(A, lds, xt, l0, l1, fl, lane, acc);
       xt[ax] = x[ax] - A.units[ax];
-      sn[ax] = sdf_hidden<H3>(A, lds, xt, l0, l1, fl, lane, acc);
+      sn[ax] = sdf_hidden<H3, TEX16>(A, lds, xt, l0, l1, fl, lane, acc);
     }
     if (valid && h == 0) {
       float g[3], hs[3];
@@ -306,6 +306,7 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   TF_REQUIRE(rc != -1, TF_EINVAL, "%s: bad TfVmDesc", who);
   TF_REQUIRE(rc != -2, TF_ESHAPE, "%s: plane/line sizes > 1 must be divisible by 2^(n_levels-1)", who);
   TF_REQUIRE(A->g.total < (1LL << 31), TF_ESHAPE, "%s: packed field exceeds 2^31 floats", who);
+  TF_REQUIRE(!A->g.texel_f16 || precision == TF_PREC_F16X3, TF_EINVAL, "%s: a half pyramid (texel_f16) runs with the TF_PREC_F16X3 decoder only", who);
   TF_REQUIRE(workspace_floats >= (size_t)kSdfWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kSdfWsFloats);
   TF_REQUIRE(mlp->w1 && mlp->b1 && mlp->w2 && mlp->b2, TF_EINVAL, "%s: null weight pointer", who);
@@ -330,20 +331,20 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   return TF_OK;
 }
 
-template <int MODE, bool H3>
+template <int MODE, bool H3, bool TEX16 = false>
 static int sdf_launch(SdfArgs& A, const float* b2_dev, hipStream_t stream, const char* who) {
   A.b2 = b2_dev;
   const size_t lds = (size_t)kLdsTotal * sizeof(float);  // weights + W2 streaming double buffer + geometry table
   static std::atomic<unsigned long long> attr_set{0};
   int attr_dev;
   if (tf_once_needed(attr_set, &attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE, H3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)sdf_kernel<MODE, H3, TEX16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e));
     tf_once_done(attr_set, attr_dev);
   }
   long long blocks = (A.n + 127) / 128;
   if (blocks > 256) blocks = 256;  // one 150 KB-LDS workgroup per CU; waves loop over tile groups
-  sdf_kernel<MODE, H3><<<(unsigned)blocks, 256, lds, stream>>>(A);
+  sdf_kernel<MODE, H3, TEX16><<<(unsigned)blocks, 256, lds, stream>>>(A);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -358,6 +359,8 @@ extern "C" int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSd
   SdfArgs A = {};
   if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, precision, stream, "tf_sdf_forward")) return rc;
   A.packed = packed; A.pts = xyz; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
+  if (A.g.texel_f16)
+    return feat ? sdf_launch<0, true, true>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1, true, true>(A, mlp->b2, stream, "tf_sdf_forward");
   if (precision == TF_PREC_F16X3)
     return feat ? sdf_launch<0, true>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1, true>(A, mlp->b2, stream, "tf_sdf_forward");
   return feat ? sdf_launch<0, false>(A, mlp->b2, stream, "tf_sdf_forward") : sdf_launch<1, false>(A, mlp->b2, stream, "tf_sdf_forward");
@@ -378,6 +381,7 @@ extern "C" int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const Tf
   A.dists = dists; A.dirs = dirs; A.inv_s = inv_s; A.cos_anneal = cos_anneal;
   for (int k = 0; k < 3; ++k) A.units[k] = units_host[k];
   A.alpha = alpha; A.grad = grad; A.nhess = nhess;
+  if (A.g.texel_f16) return sdf_launch<2, true, true>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
   return precision == TF_PREC_F16X3 ? sdf_launch<2, true>(A, mlp->b2, stream, "tf_sdf_alpha_fwd")
                                     : sdf_launch<2, false>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
 }

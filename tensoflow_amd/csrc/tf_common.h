@@ -54,6 +54,7 @@ struct VmGeom {
   long long total;
   float aabb_lo[3], aabb_inv[3];  // contraction: (x - lo) * inv  -- see note in vm_field.hip
   float aabb_size[3];
+  int texel_f16;                  // 1: `packed` holds halves (TfVmDesc.texel_f16)
 };
 
 static inline int vm_geom_init(const TfVmDesc* d, const float* aabb_host, VmGeom* g) {
@@ -61,6 +62,7 @@ static inline int vm_geom_init(const TfVmDesc* d, const float* aabb_host, VmGeom
   if (d->C <= 0 || d->C % 4 != 0 || d->n_levels < 1 || d->n_levels > 4) return -1;
   g->C = d->C;
   g->n_levels = d->n_levels;
+  g->texel_f16 = d->texel_f16 ? 1 : 0;
   long long off = 0;
   const int m = (1 << (d->n_levels - 1)) - 1;
   for (int i = 0; i < 3; ++i) {
@@ -102,6 +104,21 @@ static inline int vm_geom_init(const TfVmDesc* d, const float* aabb_host, VmGeom
 
 #ifdef __HIPCC__
 __device__ __forceinline__ int vm_dim(int n, int l) { int v = n >> l; return v < 1 ? 1 : v; }
+
+// Four consecutive channels of a texel at ELEMENT offset `off` of the packed pyramid (off % 4 == 0): 16 bytes of an fp32 pyramid,
+// 8 bytes of a half pyramid widened to fp32 (the half pyramid keeps the element offsets of the fp32 one).
+template <bool F16>
+__device__ __forceinline__ float4 vm_texel4(const float* __restrict__ packed, long long off) {
+  if (F16) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(packed) + off);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *reinterpret_cast<const float4*>(packed + off);
+}
+__device__ __forceinline__ float4 vm_texel4(const float* __restrict__ packed, long long off, int f16) {
+  return f16 ? vm_texel4<true>(packed, off) : vm_texel4<false>(packed, off);
+}
 
 // Bilinear tap set on one axis of size n (texel-centre addressing, clamp): i0, i1, frac.
 __device__ __forceinline__ void axis_taps(float t01, int n, int& i0, int& i1, float& f) {

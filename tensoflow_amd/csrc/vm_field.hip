@@ -130,9 +130,10 @@ __global__ void __launch_bounds__(256) vm_gather_kernel(VmGeom g, const float* _
       const long long a01 = pb + ((long long)y1 * W + x0) * g.C + 4 * j, a11 = pb + ((long long)y1 * W + x1) * g.C + 4 * j;
       const long long b0 = lb + (long long)z0 * g.C + 4 * j, b1 = lb + (long long)z1 * g.C + 4 * j;
       if (pass == 0) {
-        float4 t00 = *reinterpret_cast<const float4*>(packed + a00), t10 = *reinterpret_cast<const float4*>(packed + a10);
-        float4 t01 = *reinterpret_cast<const float4*>(packed + a01), t11 = *reinterpret_cast<const float4*>(packed + a11);
-        float4 s0 = *reinterpret_cast<const float4*>(packed + b0), s1 = *reinterpret_cast<const float4*>(packed + b1);
+        const int f16 = BWD ? 0 : g.texel_f16;          // wave-uniform
+        float4 t00 = vm_texel4(packed, a00, f16), t10 = vm_texel4(packed, a10, f16);
+        float4 t01 = vm_texel4(packed, a01, f16), t11 = vm_texel4(packed, a11, f16);
+        float4 s0 = vm_texel4(packed, b0, f16), s1 = vm_texel4(packed, b1, f16);
         float4 top = lerp4(t00, t10, fx), bot = lerp4(t01, t11, fx);
         float4 pl = lerp4(top, bot, fy), ln = lerp4(s0, s1, fz);
         pv.x += wl * pl.x; pv.y += wl * pl.y; pv.z += wl * pl.z; pv.w += wl * pl.w;
@@ -206,6 +207,18 @@ __global__ void __launch_bounds__(256) vm_scatter_kernel(VmGeom g, const float* 
   }
 }
 
+__global__ void __launch_bounds__(256) vm_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n) {
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(src + e);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 o; o[0] = (_Float16)v.x; o[1] = (_Float16)v.y; o[2] = (_Float16)v.z; o[3] = (_Float16)v.w;
+    *reinterpret_cast<h4*>(dst + e) = o;
+  } else {
+    for (long long k = e; k < n; ++k) dst[k] = (_Float16)src[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" size_t tf_vm_packed_floats(const TfVmDesc* d) {
   VmGeom g;
@@ -244,6 +257,16 @@ extern "C" int tf_vm_pack_fwd(const TfVmDesc* d, const float* const planes[3], c
     }
   }
   TF_LAUNCH_CHECK("tf_vm_pack_fwd");
+  return TF_OK;
+}
+
+extern "C" int tf_vm_pack_to_f16(const TfVmDesc* d, const float* packed, void* packed16, tf_stream_t stream_) {
+  VmGeom g;
+  if (int rc = check_geom(d, nullptr, &g, "tf_vm_pack_to_f16")) return rc;
+  TF_REQUIRE(packed && packed16, TF_EINVAL, "tf_vm_pack_to_f16: null pointer");
+  TF_REQUIRE((((uintptr_t)packed | (uintptr_t)packed16) & 15) == 0, TF_EINVAL, "tf_vm_pack_to_f16: buffers must be 16-byte aligned");
+  vm_to_f16_kernel<<<tf_blocks((g.total + 3) / 4, 256), 256, 0, (hipStream_t)stream_>>>(packed, (_Float16*)packed16, g.total);
+  TF_LAUNCH_CHECK("tf_vm_pack_to_f16");
   return TF_OK;
 }
 
@@ -286,6 +309,7 @@ extern "C" int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const fl
   VmGeom g;
   TF_REQUIRE(aabb_host, TF_EINVAL, "tf_vm_gather_bwd: aabb_host is null");
   if (int rc = check_geom(d, aabb_host, &g, "tf_vm_gather_bwd")) return rc;
+  TF_REQUIRE(!g.texel_f16, TF_EINVAL, "tf_vm_gather_bwd: the adjoint takes an fp32 pyramid (texel_f16 is an inference-only format)");
   TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_vm_gather_bwd: n < 0");
   if (n == 0) return TF_OK;
   TF_REQUIRE(packed && xyz && gfeat && gpacked, TF_EINVAL, "tf_vm_gather_bwd: null pointer");

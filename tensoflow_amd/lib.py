@@ -15,7 +15,7 @@ i32, i64, f32, sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
 
 class TfVmDesc(C.Structure):
-    _fields_ = [("C", i32), ("n_levels", i32), ("ph", i32 * 3), ("pw", i32 * 3), ("ll", i32 * 3)]
+    _fields_ = [("C", i32), ("n_levels", i32), ("ph", i32 * 3), ("pw", i32 * 3), ("ll", i32 * 3), ("texel_f16", i32)]
 
 
 class TfSdfMlp(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "tf_last_error": (C.c_char_p, []),
     "tf_vm_packed_floats": (sz, [P(TfVmDesc)]),
     "tf_vm_pack_fwd": (C.c_int, [P(TfVmDesc), P(F3), P(F3), c_f, c_f]),
+    "tf_vm_pack_to_f16": (C.c_int, [P(TfVmDesc), c_f, c_f, c_f]),
     "tf_vm_pack_bwd": (C.c_int, [P(TfVmDesc), c_f, P(F3), P(F3), c_f]),
     "tf_vm_gather_fwd": (C.c_int, [P(TfVmDesc), c_f, c_f, c_f, P(f32 * 6), i64, c_f, c_f]),
     "tf_vm_gather_bwd": (C.c_int, [P(TfVmDesc), c_f, c_f, c_f, P(f32 * 6), i64, c_f, c_f, c_f]),

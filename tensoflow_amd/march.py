@@ -29,7 +29,7 @@ def ball_radii(t, radii, cos):
 class SdfField:
     """TensoSDF parameters resident on the device + packed pyramid (rebuilt by `refresh()` after an optimizer step)."""
 
-    def __init__(self, sd, aabb, grid_size, n_levels, device="cuda", prefix="sdf_network."):
+    def __init__(self, sd, aabb, grid_size, n_levels, device="cuda", prefix="sdf_network.", field_f16=False):
         g = lambda k: sd[prefix + k].to(device).float().contiguous()
         self.planes = [g(f"sdf_plane.{i}") for i in range(3)]
         self.lines = [g(f"sdf_line.{i}") for i in range(3)]
@@ -40,7 +40,7 @@ class SdfField:
         self.units = ((self.aabb[1] - self.aabb[0]) / (self.grid_size - 1)).tolist()
         self.n_levels = n_levels
         self.device = device
-        self.packed = ops.VmPacked(self.planes, self.lines, n_levels)
+        self.packed = ops.VmPacked(self.planes, self.lines, n_levels, texel_f16=field_f16)     # field_f16: half texels (configs[4])
 
     def refresh(self):
         self.packed.repack(self.planes, self.lines)

@@ -44,11 +44,16 @@ def _f(t):
 class VmPacked:
     """Channel-last packed mip pyramid of a VM field (built by tf_vm_pack_fwd)."""
 
-    def __init__(self, planes, lines, n_levels):
+    def __init__(self, planes, lines, n_levels, texel_f16=False):
+        """texel_f16: BASELINE configs[4]'s "fp16 field" -- the pyramid the kernels read holds IEEE halves (tf_vm_pack_to_f16 of the
+        fp32 pyramid: mips averaged in fp32, rounded once; half the bytes per texel), taps widened to fp32 on load.  Inference only,
+        opt-in, not parity-grade."""
         self.lib = L.load()
         C_ = planes[0].shape[1]
         d = L.TfVmDesc()
         d.C, d.n_levels = C_, n_levels
+        d.texel_f16 = 1 if texel_f16 else 0
+        self.texel_f16 = bool(texel_f16)
         for i in range(3):
             assert planes[i].shape[0] == 1 and lines[i].shape[0] == 1 and lines[i].shape[3] == 1
             assert planes[i].shape[1] == C_ and lines[i].shape[1] == C_
@@ -61,15 +66,25 @@ class VmPacked:
         self.C = C_
         self.n_levels = n_levels
         self.data = torch.empty(n, dtype=torch.float32, device=planes[0].device)
+        self.data16 = torch.empty(n, dtype=torch.float16, device=planes[0].device) if texel_f16 else None
         self.repack(planes, lines)
+        if texel_f16:
+            self.data = None                    # only the half pyramid stays resident
+
+    def ptr(self):
+        """Device pointer of the pyramid the kernels gather from (fp32, or halves when desc.texel_f16)."""
+        return _p(self.data16, torch.float16) if self.texel_f16 else _p(self.data)
 
     def repack(self, planes, lines):
         pl = [_f(p.detach()) for p in planes]
         ln = [_f(l.detach()) for l in lines]
         pa = (C.c_void_p * 3)(*[p.data_ptr() for p in pl])
         la = (C.c_void_p * 3)(*[l.data_ptr() for l in ln])
-        L.check(self.lib.tf_vm_pack_fwd(C.byref(self.desc), C.byref(pa), C.byref(la), _p(self.data), _stream()),
+        data = self.data if self.data is not None else torch.empty(self.n_floats, dtype=torch.float32, device=self.data16.device)
+        L.check(self.lib.tf_vm_pack_fwd(C.byref(self.desc), C.byref(pa), C.byref(la), _p(data), _stream()),
                 "tf_vm_pack_fwd")
+        if self.texel_f16:
+            L.check(self.lib.tf_vm_pack_to_f16(C.byref(self.desc), _p(data), _p(self.data16, torch.float16), _stream()), "tf_vm_pack_to_f16")
 
     def unpack_grad(self, gpacked, planes, lines):
         gp = [torch.empty_like(p, memory_format=torch.contiguous_format) for p in planes]
@@ -86,7 +101,7 @@ def vm_gather(packed: VmPacked, xyz, level, aabb):
     n = xyz.shape[0]
     feat = torch.empty(n, 3 * packed.C, dtype=torch.float32, device=xyz.device)
     lv = None if level is None else _f(level.reshape(-1))
-    L.check(packed.lib.tf_vm_gather_fwd(C.byref(packed.desc), _p(packed.data), _p(xyz), _p(lv), C.byref(_aabb6(aabb)), n,
+    L.check(packed.lib.tf_vm_gather_fwd(C.byref(packed.desc), packed.ptr(), _p(xyz), _p(lv), C.byref(_aabb6(aabb)), n,
                                         _p(feat), _stream()), "tf_vm_gather_fwd")
     return feat
 
@@ -94,6 +109,8 @@ def vm_gather(packed: VmPacked, xyz, level, aabb):
 def vm_gather_bwd(packed: VmPacked, xyz, level, aabb, gfeat):
     xyz = _f(xyz)
     gfeat = _f(gfeat)
+    if packed.texel_f16:
+        raise RuntimeError("vm_gather_bwd: a half pyramid (texel_f16) is an inference-only format")
     gpacked = torch.zeros_like(packed.data)
     lv = None if level is None else _f(level.reshape(-1))
     L.check(packed.lib.tf_vm_gather_bwd(C.byref(packed.desc), _p(packed.data), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
@@ -131,7 +148,7 @@ def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=Tr
     feat = torch.empty(n, w2.shape[0] - 1, dtype=torch.float32, device=xyz.device) if want_feat else None
     ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), xyz.device)
     lv = None if level is None else _f(level.reshape(-1))
-    L.check(lib.tf_sdf_forward(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
+    L.check(lib.tf_sdf_forward(C.byref(packed.desc), packed.ptr(), C.byref(mlp), _p(xyz), _p(lv), C.byref(_aabb6(aabb)),
                                n, _p(sdf), _p(feat), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_forward")
     return sdf, feat
 
@@ -156,7 +173,7 @@ def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, u
     ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), dev)
     lv = None if level is None else _f(level.reshape(-1))
     un = (C.c_float * 3)(*[float(u) for u in units])
-    L.check(lib.tf_sdf_alpha_fwd(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
+    L.check(lib.tf_sdf_alpha_fwd(C.byref(packed.desc), packed.ptr(), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
                                  C.byref(_aabb6(aabb)), C.byref(un), float(inv_s), float(cos_anneal), n, _p(alpha), _p(grad),
                                  _p(feat), _p(sdf), _p(nh), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
     return alpha, grad, feat, sdf, nh
@@ -646,7 +663,7 @@ class PointPrep:
         self.fields = (mat_packed, flow_d_packed, flow_s_packed)
         self.aabb6 = _aabb6(aabb)
         self.rough_min = float(rough_min)
-        dev = mat_packed.data.device
+        dev = (mat_packed.data16 if mat_packed.texel_f16 else mat_packed.data).device
         self.ws = torch.empty(int(self.lib.tf_point_workspace_floats()), dtype=torch.float32, device=dev)
         self.repack(mat_nets, nis_nets)
 
@@ -681,8 +698,8 @@ class PointPrep:
         cd = torch.empty(pn, 37, dtype=torch.float32, device=dev)
         cs = torch.empty(pn, 37, dtype=torch.float32, device=dev)
         m, fd, fs = self.fields
-        L.check(self.lib.tf_point_fwd(_p(self.ws), C.byref(m.desc), _p(m.data), C.byref(fd.desc), _p(fd.data), C.byref(fs.desc),
-                                      _p(fs.data), C.byref(self.aabb6), _p(pts), _p(va), pn, self.rough_min, _p(met), _p(rough),
+        L.check(self.lib.tf_point_fwd(_p(self.ws), C.byref(m.desc), m.ptr(), C.byref(fd.desc), fd.ptr(), C.byref(fs.desc),
+                                      fs.ptr(), C.byref(self.aabb6), _p(pts), _p(va), pn, self.rough_min, _p(met), _p(rough),
                                       _p(alb), _p(cd), _p(cs), _stream()), "tf_point_fwd")
         return met, rough, alb, cd, cs
 

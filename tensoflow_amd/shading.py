@@ -169,11 +169,11 @@ def aux_outputs(out):
 class FlowParams:
     """One TensoFlow (nis planes/lines + nis_mat + 2 coupling nets) resident on the device."""
 
-    def __init__(self, sd, prefix, device, n_levels=3):
+    def __init__(self, sd, prefix, device, n_levels=3, field_f16=False):
         g = lambda k: sd[prefix + k].to(device).float().contiguous()
         self.planes = [g(f"nis_plane.{i}") for i in range(3)]
         self.lines = [g(f"nis_line.{i}") for i in range(3)]
-        self.packed = ops.VmPacked(self.planes, self.lines, n_levels)
+        self.packed = ops.VmPacked(self.planes, self.lines, n_levels, texel_f16=field_f16)
         self.mat = [(g("nis_mat.0.weight"), g("nis_mat.0.bias")), (g("nis_mat.2.weight"), g("nis_mat.2.bias"))]
         self.nets = [[(g(f"flows.{b}.nn.{l}.weight"), g(f"flows.{b}.nn.{l}.bias")) for l in (1, 3, 5, 7)] for b in range(2)]
         self.cache = ops.PackCache()     # packed coupling-net fragments survive across calls while the weights are unchanged
@@ -183,7 +183,7 @@ class MCShader:
     """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
-                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None):
+                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         # Inner-light decoder (123-256-256-256-3): fp32-grade f16x3 operand split like every other decoder.  ops.PREC_F16 (plain f16
@@ -198,14 +198,16 @@ class MCShader:
         g = lambda k: sd[k].to(device).float().contiguous()
         self.mat_planes = [g(f"mat_plane.{i}") for i in range(3)]
         self.mat_lines = [g(f"mat_line.{i}") for i in range(3)]
-        self.mat_packed = ops.VmPacked(self.mat_planes, self.mat_lines, 3)
+        # field_f16: BASELINE configs[4] ("fp16 field + flow") -- the material and flow VM pyramids hold halves (ops.VmPacked)
+        self.field_f16 = bool(field_f16)
+        self.mat_packed = ops.VmPacked(self.mat_planes, self.mat_lines, 3, texel_f16=field_f16)
         sdd = {k: v.to(device).float() for k, v in sd.items() if v.is_floating_point() and ("predictor" in k or "inner_light" in k)}
         self.pred = {name: [(wn_weight(sdd, f"{name}_predictor.{i}").contiguous(), sdd[f"{name}_predictor.{i}.bias"]) for i in (0, 2)]
                      for name in ("metallic", "roughness", "albedo")}
         self.inner = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
         self.env = g("outer_light.base")
-        self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device)
-        self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device)
+        self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device, field_f16=field_f16)
+        self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device, field_f16=field_f16)
         self.inner_cache = ops.PackCache()
         self.bvh = bvh if bvh is not None else ops.Bvh(vertices, triangles, device)   # `bvh`: reuse an uploaded tree (same mesh)
         self.point_prep = ops.PointPrep(self.mat_packed, self.flow_d.packed, self.flow_s.packed, self.pred,

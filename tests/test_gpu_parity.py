@@ -532,3 +532,42 @@ def test_f16_mode_is_close_but_not_parity_grade(golden, dev):
         f = SdfField(golden("march_r32").sd, AABB, [32, 32, 32], 3, device=dev)
         f.sdf_alpha(torch.zeros(4, 3, device=dev), None, torch.zeros(4, device=dev), torch.zeros(4, 3, device=dev), 1.0, 0.0,
                     precision=ops.PREC_F16)
+
+
+@pytest.mark.gpu
+def test_half_texel_pyramid_is_the_fp32_path_on_the_rounded_field(golden, dev):
+    """TfVmDesc.texel_f16 (BASELINE configs[4] 'fp16 field'): tf_vm_pack_to_f16 rounds the fp32 pyramid to nearest-even halves, and
+    every consumer -- the standalone gather, the fused sdf / 7-tap alpha kernel, the per-point stage -- returns BIT-identical results
+    to its fp32-texel path run on a pyramid that holds those rounded values: the format changes the bytes fetched, never the arithmetic."""
+    from tensoflow_amd import ops
+    g = golden("tensosdf_r32_l3")
+    sd = {k: v.to(dev) for k, v in g.sd.items()}
+    planes = [sd[f"sdf_plane.{i}"] for i in range(3)]
+    lines = [sd[f"sdf_line.{i}"] for i in range(3)]
+    p32 = ops.VmPacked(planes, lines, 3)
+    p16 = ops.VmPacked(planes, lines, 3, texel_f16=True)
+    assert p16.data is None and p16.data16.dtype == torch.float16 and torch.equal(p16.data16, p32.data.half())
+    prnd = ops.VmPacked(planes, lines, 3)
+    prnd.data.copy_(p32.data.half().float())                         # fp32 pyramid holding the rounded texels
+    gen = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(5000, 3, generator=gen) * 2.2 - 1.1).to(dev)    # incl. out-of-aabb points (clamped taps)
+    lv = (torch.rand(5000, generator=gen) * 4 - 1).to(dev)
+    for level in (None, lv):
+        assert torch.equal(ops.vm_gather(p16, xyz, level, AABB), ops.vm_gather(prnd, xyz, level, AABB))
+    W = [sd["sdf_mat.0.weight"], sd["sdf_mat.0.bias"], sd["sdf_mat.2.weight"], sd["sdf_mat.2.bias"]]
+    a = ops.sdf_forward(p16, *W, xyz, lv, AABB, want_feat=True)
+    b = ops.sdf_forward(prnd, *W, xyz, lv, AABB, want_feat=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    full = ops.sdf_forward(p32, *W, xyz, lv, AABB, want_feat=True)
+    assert 0 < float((a[0] - full[0]).abs().max()) < 5e-3             # the half field IS a different (rounded) field
+    dists = torch.full((5000,), 0.01, device=dev)
+    dirs = torch.nn.functional.normalize(torch.randn(5000, 3, generator=gen), dim=-1).to(dev)
+    units = [2.0 / 31] * 3
+    oa = ops.sdf_alpha(p16, *W, xyz, lv, dists, dirs, AABB, units, 20.0, 0.5, want_hess=False)
+    ob = ops.sdf_alpha(prnd, *W, xyz, lv, dists, dirs, AABB, units, 20.0, 0.5, want_hess=False)
+    for x, y in zip(oa, ob):
+        assert (x is None and y is None) or torch.equal(x, y)
+    with pytest.raises(RuntimeError):                                  # the exact-fp32 decoder does not take a half pyramid
+        ops.sdf_forward(p16, *W, xyz, lv, AABB, want_feat=False, precision=ops.PREC_F32)
+    with pytest.raises(RuntimeError):                                  # inference-only format
+        ops.vm_gather_bwd(p16, xyz, lv, AABB, torch.ones(5000, 108, device=dev))

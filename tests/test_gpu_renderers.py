@@ -408,15 +408,24 @@ def test_config5_frame_crop_512_flow_samples_f16_mode(golden, dev):
     assert 0.2 < float(hit.float().mean()) < 0.95
     pts, normals, view = inters[hit].contiguous(), nrm[hit].contiguous(), (-d.to(dev))[hit].contiguous()
 
-    def frame(prec):
-        sh.precision = prec
+    def frame(prec, shader=sh):
+        shader.precision = shader.inner_precision = prec              # flow nets AND inner-light decoder
         img = torch.ones(64 * 64, 3, device=dev)                       # white background
-        img[hit] = sh.shade(pts, view, normals, 512, 512)["colors"]
+        img[hit] = shader.shade(pts, view, normals, 512, 512)["colors"]
         return img.cpu()
 
     f32g, f16 = frame(ops.PREC_F16X3), frame(ops.PREC_F16)
     psnr = lambda a, b: 20 * math.log10(1.0 / math.sqrt(max(float(((a - b) ** 2).mean()), 1e-30)))
     p16 = psnr(f16, f32g)
+    # "fp16 field + flow": the material / flow VM pyramids hold halves as well (ops.VmPacked texel_f16), same tree
+    sh16 = MCShader(g.sd, g["verts"].numpy(), g["faces"].numpy(), AABB, float(g["unit_size"]), device=dev, n_fixed_diffuse=n_fd,
+                    bvh=sh.bvh, field_f16=True)
+    assert sh16.mat_packed.texel_f16 and sh16.flow_d.packed.texel_f16 and sh16.mat_packed.data16.dtype == torch.float16
+    f16f = frame(ops.PREC_F16, sh16)
+    p16f = psnr(f16f, f32g)
+    field_only = frame(ops.PREC_F16X3, sh16)                            # half field, fp32-grade products: the field's own share
+    print(f"config-5 crop, fp16 field + flow: PSNR vs fp32-grade frame {p16f:.1f} dB (half field alone: {psnr(field_only, f32g):.1f} dB)")
+    assert p16f > 55.0 and not torch.equal(f16f, f16) and psnr(field_only, f32g) > 60.0
     # oracle frame on the same crop (the small golden mesh: brute-force tracing)
     tr = osh.MeshTracer(g["verts"][g["faces"].long()])
     sel = torch.nonzero(hit.cpu())[:, 0][::7][:96]
