@@ -790,8 +790,8 @@ def main():
             # executed matrix-core flop: 336 v_mfma_f32_32x32x16_f16 per 32-ray tile and product term (K padded to 128 / 256)
             terms = {_ops.PREC_F16X3: 3, _ops.PREC_F16X2: 2, _ops.PREC_F16: 1}.get(sh.inner_precision, 3)
             executed = hits / 32.0 * 336 * terms * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
-            roof = dict(kernel="inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
-                        frac=ach / peak, traffic=pmc_traffic("inner_light2_kernel") or pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
+            roof = dict(kernel="inner_light3_kernel" if (args.precision == "f16x3" and sh.inner_precision == _ops.PREC_F16X3) else "inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
+                        frac=ach / peak, traffic=pmc_traffic("inner_light3_kernel") or pmc_traffic("inner_light2_kernel") or pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         executed_tflops=executed, frac_executed=executed / peak,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
                                    f"({'f16 MFMA operands, fp32 accumulate, ' + str(terms) + ' MFMA per product term; peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")

@@ -946,6 +946,9 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   auto row_src = [&](int it, int ln, const long long* ix) {
     long long row = pass_of(it) * 64 + ln;
     if (row >= m) row = m - 1;
+#ifdef IL3_ABLATE_GATHER   // dev-only timing ablation: input rows read in order (coalesced), not through the hit list
+    return row;
+#endif
     return ix ? ix[row] : row;
   };
   auto load_inputs = [&](long long src) {

@@ -13,7 +13,7 @@ if st:
 
 
 def short(name):
-    for key in ("inner_light2_kernel", "inner_light_kernel", "bvh_trace_kernel", "flow_kernel", "sdf_kernel", "shape_shade_kernel", "point_prep_kernel",
+    for key in ("inner_light3_kernel", "inner_light2_kernel", "inner_light_kernel", "bvh_trace_kernel", "flow_kernel", "sdf_kernel", "shape_shade_kernel", "point_prep_kernel",
                 "cube_lookup_fwd_kernel", "shade_dirs_kernel", "shade_reduce_kernel", "compact_mask_kernel", "composite_fwd_kernel",
                 "march_uniform_kernel", "vm_gather_kernel", "cube_filter_kernel"):
         if key in name:
