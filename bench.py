@@ -58,11 +58,11 @@ def pmc_traffic(kernel):
         return None
 
 
-def build_scene(device, seed, mesh_res):
+def build_scene(device, seed, mesh_res, torus_r=0.12):
     from tensoflow_amd.shading import MCShader
     from tensoflow_amd.synth import random_mc_state, sphere_torus_mesh
     sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
-    verts, faces = sphere_torus_mesh(*mesh_res)
+    verts, faces = sphere_torus_mesh(*mesh_res, torus_r=torus_r)
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     unit = 2.0 / 511
     sh = MCShader(sd, verts, faces, aabb, unit, device=device, n_fixed_diffuse=512)
@@ -873,6 +873,21 @@ def main():
                 line["scene_points"]["workload"] += ", surface points area-uniform over sphere and torus"
             except Exception as e:
                 line["scene_points"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train:
+            # ... and a scene whose secondary rays hit about as often as SURVEY.md 8(d) sketched (~0.20): the same sphere inside a FAT torus
+            # (tube radius 0.2 instead of 0.12), same triangle count, same network state -- measured, not extrapolated
+            try:
+                from tensoflow_amd.shading import MCShader as _MC2
+                from tensoflow_amd.synth import sphere_torus_mesh as _stm
+                v2, f2 = _stm(*mesh_res, torus_r=0.2)
+                sh2 = _MC2(sd, v2, f2, aabb, unit, device=device, n_fixed_diffuse=512)
+                sh2.hit_total = None
+                line["fat_torus_scene"] = flow_count_probe(sh2, pts_p, view_p, nrm_p, S, max(2, args.steps))
+                line["fat_torus_scene"]["hit_fraction"] = int(sh2.hit_total.item()) / ((2 + max(2, args.steps)) * chunk * (2 * S + 512))
+                line["fat_torus_scene"]["workload"] += ", sphere r = 0.5 inside a torus R = 0.75, r = 0.2 (headline scene: r = 0.12)"
+                del sh2
+            except Exception as e:
+                line["fat_torus_scene"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and S == 128:
             # BASELINE configs[3] at one GPU's share: 256 flow samples per lobe (1024 secondary rays per point)
             try:

@@ -56,10 +56,10 @@ def torus(R=0.75, r=0.12, n_major=48, n_minor=16, center=(0.0, 0.0, 0.0)):
     return v, np.asarray(faces, np.int32)
 
 
-def sphere_torus_mesh(n_lat=16, n_lon=32, n_major=48, n_minor=16):
+def sphere_torus_mesh(n_lat=16, n_lon=32, n_major=48, n_minor=16, torus_r=0.12):
     """-> vertices [V,3] f32, triangles [T,3] i32 (outward-facing winding)."""
     v0, f0 = uv_sphere(0.5, n_lat, n_lon)
-    v1, f1 = torus(0.75, 0.12, n_major, n_minor)
+    v1, f1 = torus(0.75, torus_r, n_major, n_minor)
     return np.concatenate([v0, v1], 0), np.concatenate([f0, f1 + len(v0)], 0)
 
 
