@@ -126,8 +126,9 @@ def env_lookup(levels, d, rough=None, diffuse=None, min_r=0.08, max_r=0.5):
     return torch.exp(val)
 
 
-def shape_shade(sd, env, fg_lut, pts, normals, view, feat):
-    """ShapeShadingNetwork.forward (no radiance field, no human light) -> color, occ_prob, roughness, reflective."""
+def shape_shade(sd, env, fg_lut, pts, normals, view, feat, inter_results=False):
+    """ShapeShadingNetwork.forward (no radiance field, no human light) -> color, occ_prob, roughness, reflective
+    (+ the `inter_results` dictionary of fields.py:541-560 when asked)."""
     P = "color_network."
     normals = F.normalize(normals, dim=-1).clone()
     normals[normals[:, :2].sum(-1) == 0.0] = torch.tensor([0.0, 1e-6, 1.0])
@@ -150,6 +151,14 @@ def shape_shade(sd, env, fg_lut, pts, normals, view, feat):
     fg = tex.bilinear_2d(fg_lut[0], uv, "clamp")
     spec = (spec_alb * fg[:, 0:1] + fg[:, 1:2]) * light
     color = linear_to_srgb(diffuse + spec).clamp(0.0, 1.0)
+    if inter_results:
+        c01 = lambda t: t.clamp(0.0, 1.0)
+        diff_light = env_lookup(None, normals, diffuse=env["diffuse"])
+        inter = dict(specular_albedo=spec_alb, specular_ref=c01(spec_alb * fg[:, 0:1] + fg[:, 1:2]), specular_direct_light=direct,
+                     specular_light=c01(linear_to_srgb(light)), specular_color=c01(linear_to_srgb(spec)), diffuse_albedo=(1 - metal) * albedo,
+                     diffuse_light=c01(linear_to_srgb(diff_light)), diffuse_color=c01(linear_to_srgb(diffuse)), metallic=metal, roughness=rough,
+                     albedo=albedo, occ_prob=occ_c, indirect_light=indirect * occ_c)      # fields.py:438: the indirect light is returned weighted
+        return color, occ, rough, refl, inter
     return color, occ, rough, refl
 
 
@@ -171,6 +180,63 @@ def render_core(sd, env, fg_lut, o, d, radiis, rays_cos, t0, t1, ridx, aabb, gri
     return dict(ray_rgb=rgb, acc=acc, normal=nrm, gradient_error=(grad.norm(dim=-1) - 1.0) ** 2,
                 std=torch.mean(1 / inv_s), loss_sparse=torch.exp(-20.0 * sdf.abs()).mean(),
                 loss_hessian=nh.abs().mean(), alpha=alpha, weights=w, color=color, sdf=sdf, grad=grad)
+
+
+def _neus_weights(sd, inv_s, z, p, d, aabb, n_levels):
+    """get_weights (utils/network_utils.py:149-170): NeuS weights of the sections of z along (p, d); field level None (sdf_inter_fun)."""
+    pn, sn = z.shape
+    pts = z[..., None] * d[:, None, :] + p[:, None, :]
+    sdf = sdf_forward(sd, pts.reshape(-1, 3), None, aabb, n_levels, "sdf_network.")[:, 0].reshape(pn, sn)
+    prev_sdf, next_sdf = sdf[:, :-1], sdf[:, 1:]
+    prev_z, next_z = z[:, :-1], z[:, 1:]
+    mid_sdf = (prev_sdf + next_sdf) * 0.5
+    cos_val = (next_sdf - prev_sdf) / (next_z - prev_z + 1e-5)
+    surface = cos_val < 0
+    cos_val = cos_val.clamp(max=0)
+    dist = next_z - prev_z
+    prev_cdf = torch.sigmoid((mid_sdf - cos_val * dist * 0.5) * inv_s)
+    next_cdf = torch.sigmoid((mid_sdf + cos_val * dist * 0.5) * inv_s)
+    alpha = (prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5) * surface.float()
+    return alpha * torch.cumprod(torch.cat([torch.ones(pn, 1), 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
+
+
+def traced_occlusion(sd, pts, dirs, aabb, n_levels, sn0=128, sn1=9):
+    """get_intersection (utils/network_utils.py:172-202) -> sum of the hit weights along (pts, dirs) up to the unit sphere [pn,1]
+    (0 for points outside r = 0.999): the `occ_prob_gt` of render_core's validation branch (shapeRenderer.py:1268-1270)."""
+    occ = torch.zeros(pts.shape[0], 1)
+    inside = pts.norm(dim=-1) < 0.999
+    if bool(inside.any()):
+        p, d = pts[inside], dirs[inside]
+        dtx, xtx = (p * d).sum(-1, keepdim=True), (p ** 2).sum(-1, keepdim=True)
+        max_dist = -dtx + torch.sqrt((dtx ** 2 - xtx + 1).clamp(min=0) + 1e-6)           # get_sphere_intersection (network_utils.py:93-103)
+        inv_s = torch.exp(sd["deviation_network.variance"] * 10.0).clip(1e-6, 1e6)
+        z = max_dist * torch.linspace(0, 1, sn0)[None]
+        w = _neus_weights(sd, inv_s, z, p, d, aabb, n_levels)
+        z_new = sample_pdf_det(z, w, sn1)[0]
+        occ[inside] = _neus_weights(sd, inv_s, z_new, p, d, aabb, n_levels).sum(-1, keepdim=True)
+    return occ
+
+
+def render_core_validation(sd, env, fg_lut, o, d, radiis, rays_cos, t0, t1, ridx, aabb, grid_size, n_levels, base_radii, cos_anneal=1.0):
+    """Validation branch of ShapeRenderer.render_core (is_train=False, nerfDataType, shapeRenderer.py:1246-1275) on top of the train
+    branch's composite: expected depth -> surface point -> re-evaluated finite-difference normal, materials / split-sum lights there
+    (the shading net's inter_results, masked to the aabb), traced occlusion along the reflected direction."""
+    out = render_core(sd, env, fg_lut, o, d, radiis, rays_cos, t0, t1, ridx, aabb, grid_size, n_levels, base_radii, cos_anneal)
+    rn = o.shape[0]
+    mid = (t0 + t1) * 0.5
+    acc = out["acc"]
+    t_depth = accumulate_along_rays(out["weights"], mid[:, None], ridx, rn)
+    pts = t_depth * d + o
+    level = torch.log2(ball_radii(t_depth, radiis, rays_cos) / base_radii)
+    grad, _ = sdf_gradient(sd, pts, level, aabb, n_levels, grid_size, training=False, prefix="sdf_network.")
+    normals = F.normalize(grad, dim=-1)
+    inner = ~((aabb[0] > pts) | (pts > aabb[1])).any(-1)[:, None]
+    feat = sdf_forward(sd, pts, level, aabb, n_levels, "sdf_network.")[:, 1:]
+    _, occ, rough, refl, inter = shape_shade(sd, env, fg_lut, pts, normals, -d, feat, inter_results=True)
+    val = dict(ray_rgb=out["ray_rgb"], acc=acc, normal=out["normal"], normal_vis=((out["normal"] + 1.0) * 0.5) * acc + (1.0 - acc),
+               depth=t_depth * rays_cos, occ_prob_gt=traced_occlusion(sd, pts, refl, aabb, n_levels, 128, 9))
+    val.update({k: v * inner for k, v in inter.items()})
+    return val
 
 
 def alpha_mask_sample(volume, aabb, pts):

@@ -53,6 +53,22 @@ def test_render_core(golden):
     assert rel_err(out["loss_hessian"], g["rc/loss_hessian"]) < 1e-4
 
 
+def test_render_core_validation_branch(golden):
+    """oracle/march.py:render_core_validation against the imported reference's render_core(is_train=False) (golden march_eval_r32:
+    bumpy field, sharp surface, smooth pre-filtered maps): every validation key, incl. the traced occlusion."""
+    g, ge = golden("march_r32"), golden("march_eval_r32")
+    sd = dict(g.sd)
+    sd.update(ge.sd)
+    env = {"specular": [ge[f"env_spec{i}"] for i in range(3)], "diffuse": ge["env_diffuse"]}
+    val = om.render_core_validation(sd, env, g["fg_lut"], ge["rays_o"], ge["dirs"], ge["radiis"], ge["rays_cos"], ge["t_starts"], ge["t_ends"],
+                                    ge["ray_indices"], AABB, GS, 3, float(g["base_radii"]), 1.0)
+    assert int((ge["val/occ_prob_gt"] > 1e-3).sum()) > 40
+    for k, v in val.items():
+        ref = ge["val/" + k]
+        assert rel_err(v.reshape(ref.shape), ref) < 2e-5, (k, rel_err(v.reshape(ref.shape), ref))
+    assert {"depth", "occ_prob_gt", "normal_vis", "specular_direct_light", "indirect_light", "occ_prob", "albedo"} <= set(val)
+
+
 def test_refine_hits(golden):
     """SDF refinement of mesh hits vs MaterialRenderer.trace_sdf_with_mesh run on the imported reference."""
     from oracle import refine, shading as osh
