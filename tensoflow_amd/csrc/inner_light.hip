@@ -917,6 +917,9 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) float lbias[3 * 512];             // [layer][lane half][tile * 16 + reg]
   __shared__ __attribute__((aligned(16))) float w4a[3 * 512];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
   __shared__ float part[2 * 4 * 6 * 32];                                    // [team][wave][ray tile * 3 + output][ray]
+  __shared__ __attribute__((aligned(16))) float stage[2 * (3 * 64 * 4 + 64)];   // [team]: hit point | normal | direction rows of the NEXT pass's 64 rays (16 bytes per
+                                                                                // ray and array: where a 12-byte LDS-DMA lands) and their depths
+  __shared__ long long stage_src[2 * 64];                                       // ... and their source indices
   __shared__ __attribute__((aligned(16))) float idem[36 * 20];              // IDE polynomial coefficients [column][power (17, padded to 20)]: read as
                                                                             // broadcast ds_read_b128 (through the scalar cache the 222 coefficients
                                                                             // of a ray went through v_mov copies into packed-FMA operands: 43 spills)
@@ -935,13 +938,16 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   uint2* act8 = reinterpret_cast<uint2*>(actt);
   float* partt = part + team * (4 * 6 * 32);
   auto pass_of = [&](int it) { return ((long long)it * gridDim.x + blockIdx.x) * 2 + team; };
-  // lane l of every wave of a team stands for ray l of the team's pass (the four waves split a ray's FEATURES)
-  // the input row of the lane's ray as three 3-vectors, each the destination TUPLE of one global_load_dwordx3 and carried as a tuple
-  // through the pass loop: as nine scalars the register allocator re-homed two components right behind each load -- an
-  // `s_waitcnt vmcnt(2)` in the step that issues the gathers, i.e. a whole HBM round trip exposed (P1 took 4-8 k cycles instead of 2 k)
-  typedef float il3_f3 __attribute__((ext_vector_type(3)));
-  il3_f3 in_p = {0.f, 0.f, 0.f}, in_n = {0.f, 0.f, 1.f}, in_v = {0.f, 0.f, 1.f};
-  long long src_cur = 0, src_nxt = 0, src_nn = 0, src_out = 0;   // index rows: pass in flight, next pass (its inputs are in in9), the one after, pass being stored
+  // lane l of every wave of a team stands for ray l of the team's pass (the four waves split a ray's FEATURES).
+  // Input rows: every wave needs all of its ray's inputs, but they are GATHERED once per team and never pass through registers: in the
+  // gather step wave 0 / 1 / 2 sends the hit-point / normal / direction row of ray `lane` of the NEXT pass straight into the team's
+  // LDS stage by LDS-DMA (one instruction per wave), wave 3 the depth and the source index; the encodings read their ray's rows from
+  // there one pass later.  (Gathered by every wave into registers the rows cost four times the random requests and 19 registers held
+  // across the matrix steps.)
+  float* staget = stage + team * (3 * 64 * 4 + 64);
+  long long* stage_srct = stage_src + team * 64;
+  long long src_nxt = 0;                   // source index of ray `lane` of the next pass to gather
+  long long src_cur = 0, src_out = 0;      // ... of the pass in flight / of the pass being stored
   float dep_out = 1.f, dep_cur = 1.f;
   auto row_src = [&](int it, int ln, const long long* ix) {
     long long row = pass_of(it) * 64 + ln;
@@ -951,14 +957,28 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #endif
     return ix ? ix[row] : row;
   };
-  auto load_inputs = [&](long long src) {
-    in_p = *reinterpret_cast<const il3_f3*>(pts + 3 * src);      // 12-byte rows: 4-byte aligned dwordx3
-    in_n = *reinterpret_cast<const il3_f3*>(nrm + 3 * src);
-    in_v = *reinterpret_cast<const il3_f3*>(view + 3 * src);
+  // wave-uniform role: which array this wave sends (w < 3) -- or depth + index (w == 3)
+  auto gather_dma = [&](long long src) {
+    if (w < 3) {
+      // (three uniform branches: a select over the three pointers is lowered to a table in scratch memory)
+      const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + w * 256));
+      if (w == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(pts + 3 * src) : "memory");     // lands at 16 bytes per lane
+      else if (w == 1) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(nrm + 3 * src) : "memory");
+      else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(view + 3 * src) : "memory");
+    } else {
+      if (depth) {
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + 768));
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(la), "v"(depth + src) : "memory");       // 4 bytes per lane
+      } else {
+        staget[768 + lane] = 1.f;
+      }
+      stage_srct[lane] = src;
+    }
   };
   src_nxt = row_src(0, lane, idx);
-  load_inputs(src_nxt);
-  src_nn = n_iter > 1 ? row_src(1, lane, idx) : 0;
+  gather_dma(src_nxt);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  src_nxt = n_iter > 1 ? row_src(1, lane, idx) : 0;
   Il3Ring ring;
   f32x16 acc[2][2];
   const float b4[3] = {ws_arg[kIB4 + 0], ws_arg[kIB4 + 2], ws_arg[kIB4 + 4]};     // packed order: [n * 2 + half], unit n = reg for n < 4
@@ -1030,12 +1050,15 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     //   wave 0: IDE columns 0..15      wave 1: 20..23, 32..35      wave 2: 16..19, 28..31 + the zero granule      wave 3: 24..27 + p
     // Every 4-column store granule has one owner.
     {
-      // this pass's input row (requested in step P1 of the previous pass) -> locals
-      const float p[3] = {in_p[0], in_p[1], in_p[2]};
-      float n[3] = {in_n[0], in_n[1], in_n[2]};
-      float v[3] = {vsign_o * in_v[0], vsign_o * in_v[1], vsign_o * in_v[2]};
+      // this pass's input rows of the lane's ray: from the team's stage (sent there by LDS-DMA during the previous pass)
+      const float4 rp = *reinterpret_cast<const float4*>(staget + 4 * lane_o), rn = *reinterpret_cast<const float4*>(staget + 256 + 4 * lane_o),
+                   rv = *reinterpret_cast<const float4*>(staget + 512 + 4 * lane_o);
+      const float p[3] = {rp.x, rp.y, rp.z};
+      float n[3] = {rn.x, rn.y, rn.z};
+      float v[3] = {vsign_o * rv.x, vsign_o * rv.y, vsign_o * rv.z};
       dep_out = dep_cur;
-      src_cur = src_nxt;
+      dep_cur = staget[768 + lane_o];
+      src_cur = stage_srct[lane_o];
       if (live) {
         // this ray's slot in the team image, made opaque per pass: the 64 store addresses of a pass are this + compile-time constants
         // (immediate offsets); as loop invariants of the pass loop they were each materialised in a register and kept across the
@@ -1153,16 +1176,12 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
     for (int layer = 1; layer < 3; ++layer) {
       il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);   // lands while this wave publishes and waits for its partner
-      if (layer == 1) {
-        // ALL gathers of a pass are requested here, BEHIND layer 2's weight prefetch and a publish + barrier wait (>= 6 k cycles) ahead of
-        // the first wait that has to see them retired (k-step 3 of layer 2): the next pass's input rows, the index row after it, this
-        // pass's depth.  vmcnt retires in order: a random-row gather (an HBM round trip) in front of a matrix phase's weight loads, or
-        // in front of a spill reload inside the encodings, stalls that wait for the whole round trip (M1 took 8 k cycles for 96 MFMAs
-        // behind the radiance stores, M3 8.4 k behind the input gathers, the encodings 8.5 k with the gathers at their top).
-        dep_cur = depth ? depth[src_cur] : 1.f;
-        if (it + 1 < n_iter) load_inputs(src_nn);
-        src_nxt = src_nn;
-        if (it + 2 < n_iter) src_nn = row_src(it + 2, lane_o, idx_o);
+      if (layer == 1 && it + 1 < n_iter) {
+        // the gather step: BEHIND layer 2's weight prefetch and a publish + barrier wait ahead of the first wait that has to see it
+        // retired (vmcnt retires in order: a random-row gather -- an HBM round trip -- in front of a matrix phase's weight loads stalls
+        // that phase's first counted wait for the whole round trip)
+        gather_dma(src_nxt);
+        if (it + 2 < n_iter) src_nxt = row_src(it + 2, lane_o, idx_o);
       }
 #ifndef IL3_ABLATE_P    // dev-only timing ablation: nothing is published
       il3_publish(actt + lane, T0, acc);
