@@ -5,10 +5,14 @@
                               bound_max], values outside the unit sphere replaced by `outside_val`; evaluated on the device by
                               tf_sdf_forward through TensoSDF.sdf, slab by slab.
 * `iso_surface`            -- extract_geometry (:224-231).  The reference hands the lattice to PyMCubes (third-party, absent here,
-                              unpinned): this module extracts the same iso-surface with marching TETRAHEDRA on the Kuhn 6-split of
-                              every cell (tables generated below, no 256-case table), in tensor ops on the lattice's device.  Same
-                              surface to O(h^2), watertight, consistently wound; NOT PyMCubes' triangulation (about twice the
-                              triangle count).  Winding follows PyMCubes: face normals point towards DEcreasing lattice values,
+                              unpinned): this module extracts the same iso-surface with MARCHING CUBES (method="cubes", the
+                              default: one vertex per sign-changing lattice edge, placed by linear interpolation exactly as
+                              PyMCubes places it; the 256-case table is GENERATED below by linking the iso-segments of the six
+                              cell faces into loops, with one rule for ambiguous faces, so neighbouring cells always agree and the
+                              surface is watertight -- the classic table is not on ambiguous faces; loops are fan-triangulated,
+                              so the triangle LIST differs from PyMCubes' while vertices and surface coincide) or with marching
+                              TETRAHEDRA on the Kuhn 6-split of every cell (method="tetrahedra": about twice the triangles).
+                              Both run in tensor ops on the lattice's device.  Winding follows PyMCubes: face normals point towards DEcreasing lattice values,
                               i.e. into the object for a positive-outside SDF -- the orientation MaterialRenderer.trace undoes
                               with its `-normals` (materialRenderer.py:256-259).  Vertices map to world units like :228-230.
 * `write_ply` / `read_ply` -- the file extract_mesh.py:43-47 exports through trimesh (binary little-endian PLY: float x, y, z;
@@ -47,6 +51,69 @@ def _tet_case_table():
 _CASE_TAB, _CASE_CNT = _tet_case_table()
 
 
+def _cube_case_table():
+    """Marching-cubes table: case (bit c = corner c inside, corner c = (c & 1, c >> 1 & 1, c >> 2 & 1)) -> triangles, each three cell
+    edges (a, b) with a inside / b outside, wound so that the normal points from the inside corners to the outside ones.
+    Construction: on every cell face (corners in counter-clockwise order seen from outside) each boundary edge whose corners differ
+    carries a vertex; walking the boundary, an inside -> outside crossing starts an iso-segment that ends at the NEXT outside -> inside
+    crossing (on a face with four crossings this separates the two outside corners -- the same choice on both cells that share the
+    face, because it only looks at the face).  Every crossed cell edge starts one segment (in one of its two faces) and ends one (in
+    the other), so the segments chain into closed loops; each loop becomes a triangle fan."""
+    corner = np.array([[c & 1, c >> 1 & 1, c >> 2 & 1] for c in range(8)])
+    faces = []
+    for a in range(3):
+        b, c = (a + 1) % 3, (a + 2) % 3
+        for side in (0, 1):
+            quad = []
+            for (ub, uc) in ((0, 0), (1, 0), (1, 1), (0, 1)):           # counter-clockwise seen from +a
+                xyz = [0, 0, 0]
+                xyz[a], xyz[b], xyz[c] = side, ub, uc
+                quad.append(xyz[0] | xyz[1] << 1 | xyz[2] << 2)
+            faces.append(quad if side == 1 else quad[::-1])             # seen from -a the same cycle runs clockwise: reverse it
+    max_t = 0
+    rows = []
+    for case in range(256):
+        ins = [(case >> c) & 1 for c in range(8)]
+        nxt = {}
+        for quad in faces:
+            exits = [i for i in range(4) if ins[quad[i]] and not ins[quad[(i + 1) % 4]]]
+            for i in exits:
+                j = (i + 1) % 4
+                while not (not ins[quad[j]] and ins[quad[(j + 1) % 4]]):   # the next outside -> inside crossing
+                    j = (j + 1) % 4
+                start = (quad[i], quad[(i + 1) % 4])                    # (inside corner, outside corner)
+                end = (quad[(j + 1) % 4], quad[j])
+                nxt[start] = end
+        tris, seen = [], set()
+        for e0 in list(nxt):
+            if e0 in seen:
+                continue
+            loop, e = [], e0
+            while e not in seen:
+                seen.add(e)
+                loop.append(e)
+                e = nxt[e]
+            # orientation: the loop's area vector against (centroid of its outside corners - centroid of its inside corners)
+            mid = np.array([(corner[a_] + corner[b_]) * 0.5 for a_, b_ in loop])
+            area = sum(np.cross(mid[k] - mid[0], mid[k + 1] - mid[0]) for k in range(1, len(loop) - 1))
+            grad = np.mean([corner[b_] for _, b_ in loop], 0) - np.mean([corner[a_] for a_, _ in loop], 0)
+            if float(np.dot(area, grad)) < 0:
+                loop = loop[::-1]
+            tris += [(loop[0], loop[k], loop[k + 1]) for k in range(1, len(loop) - 1)]
+        rows.append(tris)
+        max_t = max(max_t, len(tris))
+    tab = np.zeros((256, max_t, 3, 2), np.int64)
+    cnt = np.zeros(256, np.int64)
+    for case, tris in enumerate(rows):
+        cnt[case] = len(tris)
+        for t, tri in enumerate(tris):
+            tab[case, t] = tri
+    return tab, cnt
+
+
+_CUBE_TAB, _CUBE_CNT = _cube_case_table()
+
+
 @torch.no_grad()
 def sdf_lattice(sdf_fn, bound_min, bound_max, resolution, outside_val=1.0, device="cuda", slab=16):
     """-> u [res, res, res] float32 on `device`; sdf_fn(pts [n,3]) -> [n] or [n,1]."""
@@ -63,9 +130,12 @@ def sdf_lattice(sdf_fn, bound_min, bound_max, resolution, outside_val=1.0, devic
 
 
 @torch.no_grad()
-def iso_surface(u, threshold=0.0, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), slab=32, normals_to_lower=True):
+def iso_surface(u, threshold=0.0, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 1.0, 1.0), slab=32, normals_to_lower=True, method="cubes"):
     """u [nx, ny, nz] -> vertices [V,3] float32 (world units), triangles [F,3] int64 (both on u's device).
-    normals_to_lower: face normals towards decreasing u (PyMCubes' winding); False: towards increasing u."""
+    normals_to_lower: face normals towards decreasing u (PyMCubes' winding); False: towards increasing u.
+    method: "cubes" (marching cubes, what the reference's PyMCubes call does) or "tetrahedra"."""
+    if method not in ("cubes", "tetrahedra"):
+        raise ValueError(f"iso_surface: method {method!r}")
     dev = u.device
     nx, ny, nz = u.shape
     v = u.float() - threshold
@@ -84,6 +154,22 @@ def iso_surface(u, threshold=0.0, bound_min=(-1.0, -1.0, -1.0), bound_max=(1.0, 
         if not bool(mixed.any()):
             continue
         base, cval, inside = base[mixed], cval[mixed], inside[mixed]
+        if method == "cubes":
+            ctab, ccnt = torch.from_numpy(_CUBE_TAB).to(dev), torch.from_numpy(_CUBE_CNT).to(dev)
+            case = (inside.long() << torch.arange(8, device=dev)).sum(-1)
+            for t in range(ctab.shape[1]):
+                sel = ccnt[case] > t
+                if not bool(sel.any()):
+                    break
+                edges = ctab[case[sel], t]                                    # [m,3,2] cell-local corners (inside, outside)
+                bs = base[sel]
+                pa = bs[:, None, :] + corner[edges[..., 0]]                   # [m,3,3] lattice coordinates
+                pb = bs[:, None, :] + corner[edges[..., 1]]
+                flips.append(torch.full((bs.shape[0],), bool(normals_to_lower), device=dev))   # the table's loops face the outside corners
+                ida = (pa[..., 0] * ny + pa[..., 1]) * nz + pa[..., 2]
+                idb = (pb[..., 0] * ny + pb[..., 1]) * nz + pb[..., 2]
+                keys_a.append(torch.minimum(ida, idb)); keys_b.append(torch.maximum(ida, idb))
+            continue
         for tet in _TETS:
             tv = cval[:, tet]                                               # [n,4]
             case = (inside[:, tet].long() << torch.arange(4, device=dev)).sum(-1)
@@ -214,7 +300,7 @@ def extract_mesh(renderer, resolution=512, path=None, threshold=0.0):
     dev = renderer.aabb.device
     fn = lambda x: renderer.sdf_network.sdf(x, torch.full((x.shape[0],), ratio, device=x.device))
     u = sdf_lattice(fn, (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), resolution, device=dev)
-    v, f = iso_surface(u, threshold)
+    v, f = iso_surface(u, threshold)                     # marching cubes, like the reference's mcubes.marching_cubes
     v, f = v.cpu().numpy().astype(np.float32), f.cpu().numpy().astype(np.int32)
     if path is not None:
         write_ply(path, v, f)
