@@ -888,6 +888,24 @@ def main():
                 del sh2
             except Exception as e:
                 line["fat_torus_scene"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train and args.precision == "f16x3":
+            # outer_light_version='direction' (configs/mat/syn/{lego,armadillo,horse}.yaml; no BASELINE config uses it): the rays that
+            # MISS -- 85 % of them -- are answered by a 72-256-256-256-3 net on the IDE of the direction instead of the cube map
+            try:
+                import math as _m
+                from tensoflow_amd.shading import MCShader as _MC3
+                from tensoflow_amd.synth import _wn_linear
+                sd3 = {k: v for k, v in sd.items() if k != "outer_light.base"}
+                gen3 = torch.Generator().manual_seed(31)
+                for l, (fi, fo) in zip((0, 2, 4, 6), [(72, 256), (256, 256), (256, 256), (256, 3)]):
+                    _wn_linear(gen3, fi, fo, sd3, f"outer_light.{l}", bias_fill=_m.log(0.5) if l == 6 else None)
+                sh3 = _MC3(sd3, verts, faces, aabb, unit, device=device, n_fixed_diffuse=512, bvh=sh.bvh)
+                n3 = min(65536, chunk)
+                line["outer_light_direction"] = flow_count_probe(sh3, pts_p[:n3].contiguous(), view_p[:n3].contiguous(), nrm_p[:n3].contiguous(), S, max(2, args.steps))
+                line["outer_light_direction"]["workload"] += ", outer light = the direction-encoded net on every ray that misses (not a BASELINE config)"
+                del sh3
+            except Exception as e:
+                line["outer_light_direction"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and S == 128:
             # BASELINE configs[3] at one GPU's share: 256 flow samples per lobe (1024 secondary rays per point)
             try:

@@ -340,6 +340,16 @@ int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, const float*
                                const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
                                float near_eps, float exp_max, int32_t precision, float* lights, float* workspace,
                                size_t workspace_floats, tf_stream_t stream);
+/* MCShadingNetwork.predict_outer_lights with outer_light_version = 'direction' (network/fields.py:913-916, the net built at
+ * :716-718: make_predictor_4layer(72, 3, 'exp', light_exp_max); configs/mat/syn/{lego,armadillo,horse}.yaml) for the rays that MISSED
+ * the mesh (get_lights :962-968): lights[i] = exp(min(net(IDE5(dirs[i], roughness 0)), exp_max)) for i = idx[r], r < *count_dev.
+ * net->w[0] is the [256,72] first layer; the other layers as TfMlp4.  The direction rows are encoded as they are (the reference
+ * does not normalise them).  precision: TF_PREC_F16X3 (| TF_WEIGHTS_PACKED) only -- the net runs on the staggered fp32-grade kernel of
+ * the inner light; `workspace` as tf_inner_light_workspace_floats(), one workspace PER NET.  A missing ray's depth is TF_MISS_DEPTH, so
+ * get_lights' near mask (:973) is 1 on every row written here. */
+int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, const int64_t* idx, const int64_t* count_dev,
+                               int64_t capacity, float exp_max, int32_t precision, float* lights, float* workspace,
+                               size_t workspace_floats, tf_stream_t stream);
 /* Input encoding of the inner-light net alone: X [capacity,123] = cat[pos_enc8(pos[i]), IDE5(reflect(-dirs[i], nrm[i]))] for
  * i = idx[r] (r < *count_dev), or i = r when idx is NULL (then view = dirs).  Used by the training backward, whose
  * weight-gradient products are plain library GEMMs on X. */
@@ -465,7 +475,9 @@ int tf_shade_dirs_bwd(const float* normals, const float* view, const float* meta
 /* Same reduction with get_lights' miss branch folded in (fields.py:951-975): a slot whose ray hit the mesh (hit[r] != 0)
  * takes hit_lights[r] (tf_inner_light_indexed_fwd's scatter target; other rows are never read), a slot whose ray missed
  * takes exp(cube(env_base, dirs[r])) * (depth[r] > near_eps) evaluated on the fly -- the [pn,T,3] light array of the
- * miss branch is never written or read.  Zero-weight slots are skipped.  hit may be NULL: a ray then hit iff depth[r] < TF_MISS_DEPTH. */
+ * miss branch is never written or read.  Zero-weight slots are skipped.  hit may be NULL: a ray then hit iff depth[r] < TF_MISS_DEPTH.
+ * env_base may be NULL (outer_light_version = 'direction'): then every slot with a non-zero weight takes hit_lights[r] -- the rows of
+ * the rays that missed were written by tf_outer_light_indexed_fwd. */
 int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth, const uint8_t* hit, const float* hit_lights,
                         const float* env_base, int32_t env_res, float near_eps, int64_t pn, int32_t n_diffuse, int32_t ss,
                         float* colors, float* diffuse_lin, float* specular_lin,

@@ -14,7 +14,7 @@ def segment_coo(src, index, out=None, dim_size=None, reduce="sum"):
     assert reduce == "sum"
     if out is None:
         out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
-    return out.index_add(0, index, src)
+    return out.index_add(0, index, src.to(out.dtype))
 
 
 def render_weight_from_alpha(alphas, ray_indices=None, n_rays=None, packed_info=None):

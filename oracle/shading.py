@@ -3,7 +3,7 @@
 Follows network/fields.py (MCShadingNetwork):
   tenso_feature :776-810, get_orthogonal_directions :812-822,
   sample_diffuse_directions :824-856, sample_specular_directions :858-903,
-  get_inner_lights :905-911, predict_outer_lights('envlight') :929-930,
+  get_inner_lights :905-911, predict_outer_lights('envlight') :929-930 / ('direction') :913-916,
   get_lights :951-975, GGX terms :977-1033, predict_materials :1010-1017,
   direction_to_angle :1035-1048, shade_mixed :1075-1335, forward :1453-1473;
 network/light.py:125-162 (EnvLight.direct_light); network/materialRenderer.py:221-223,253-263
@@ -124,8 +124,15 @@ class MeshTracer:
         return pos, nrm, t[:, None], (t < MAX_DIST)
 
 
-def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0):
-    """fields.py:951-975 with outer_light_version='envlight', human_lights=False.
+def outer_light_direction(sd, dirs, light_exp_max=5.0):
+    """predict_outer_lights, outer_light_version='direction' (fields.py:913-916; the net: :716-718): the 4-layer predictor on
+    sph_enc(directions, 0) -- the rows as they are."""
+    return mlp(sd, "outer_light", (0, 2, 4, 6), ide5(dirs, 0), F.relu, lambda t: torch.exp(t.clamp(max=light_exp_max)))
+
+
+def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0):
+    """fields.py:951-975, human_lights=False; outer_light_version follows the state dict ('envlight': `outer_light.base`,
+    'direction': `outer_light.0.*`).
     pts, dirs [M,3] -> lights [M,3], hit [M] bool, inters [M,3]."""
     eps = 1e-5
     o = pts + dirs * eps
@@ -133,7 +140,8 @@ def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0):
     lights = torch.zeros_like(pts)
     miss = ~hit
     if miss.any():
-        lights[miss] = env_direct_light(sd["outer_light.base"], dirs[miss])
+        lights[miss] = (env_direct_light(sd["outer_light.base"], dirs[miss]) if "outer_light.base" in sd
+                        else outer_light_direction(sd, dirs[miss], light_exp_max))
     if hit.any():
         lights[hit] = inner_light(sd, inters[hit], -dirs[hit], nrm[hit], exp_max)
     lights = lights * (depth > eps).to(lights.dtype)

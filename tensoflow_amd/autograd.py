@@ -142,46 +142,69 @@ class ShadeWeightsFn(torch.autograd.Function):
 
 
 class LightsFn(torch.autograd.Function):
-    """lights [M,3] of MCShadingNetwork.get_lights (fields.py:951-975): BVH visibility, cube-map light on a miss, inner-light MLP
-    on a hit, near mask -- forward entirely in the HIP kernels.  Backward: the cube-map gradient is tf_cube_lookup_bwd (scatter);
-    the inner-light weight gradients come from tf_linear_fwd / tf_linear_bwd on the [hits,123] encoding of tf_inner_light_encode."""
+    """lights [M,3] of MCShadingNetwork.get_lights (fields.py:951-975): BVH visibility, outer light on a miss (the cube map, or -- with
+    env_base None, outer_light_version='direction' -- the 72-256-256-256-3 net on the IDE of the direction), inner-light MLP on a hit,
+    near mask -- forward entirely in the HIP kernels.  Backward: the cube-map gradient is tf_cube_lookup_bwd (scatter); the weight
+    gradients of the nets come from tf_linear_fwd / tf_linear_bwd on the [hits,123] encoding of tf_inner_light_encode (the [misses,72]
+    IDE rows of the outer net).  wb: the inner net's 4 (weight, bias) pairs, followed by the outer net's when env_base is None."""
 
     @staticmethod
-    def forward(ctx, env_base, pts_rep, dirs, live, bvh, unit, exp_max, precision, *inner_wb):
+    def forward(ctx, env_base, pts_rep, dirs, live, bvh, unit, exp_max, precision, outer_exp_max, *wb):
         inters, nrm, depth, hit = bvh.trace(pts_rep, dirs, 1e-5, 2 * unit, live=live)
-        lights = ops.cube_lookup(env_base.detach(), dirs, apply_exp=True, depth=depth, near_eps=1e-5)
+        inner_wb, outer_wb = wb[:8], wb[8:]
+        idx_m = count_m = None
+        if env_base is not None:
+            lights = ops.cube_lookup(env_base.detach(), dirs, apply_exp=True, depth=depth, near_eps=1e-5)
+        else:
+            lights = torch.zeros_like(dirs)
+            idx_m, count_m = ops.compact_mask((~hit).view(torch.uint8))
+            ow = [(outer_wb[2 * l].detach().contiguous(), outer_wb[2 * l + 1].detach().contiguous()) for l in range(4)]
+            ops.outer_light_indexed(ow, dirs, idx_m, count_m, lights, exp_max=outer_exp_max)      # near mask of a miss: 1
         idx, count = ops.compact_mask(hit.view(torch.uint8))
         weights = [(inner_wb[2 * l].detach(), inner_wb[2 * l + 1].detach()) for l in range(4)]
         ops.inner_light_indexed(weights, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=exp_max, precision=precision)
-        ctx.save_for_backward(env_base, dirs, inters, nrm, depth, hit, idx, count, *inner_wb)
-        ctx.exp_max = exp_max
+        ctx.has_env = env_base is not None
+        ctx.save_for_backward(env_base if ctx.has_env else idx_m, dirs, inters, nrm, depth, hit, idx, count, count_m if not ctx.has_env else count, *wb)
+        ctx.exp_max, ctx.outer_exp_max = exp_max, outer_exp_max
         ctx.mark_non_differentiable(hit)
         return lights, hit
 
     @staticmethod
-    def backward(ctx, g_lights, _g_hit):
-        env_base, dirs, inters, nrm, depth, hit, idx, count, *inner_wb = ctx.saved_tensors
-        near = (depth > 1e-5).float()[:, None]
-        g = (g_lights * near).contiguous()
-        g_base = ops.cube_lookup_bwd(env_base.detach(), dirs, g * (~hit).float()[:, None], apply_exp=True)
-        # inner-light net on the hit rows: recompute the four layers and differentiate them with the HIP dense-layer kernels.  The
-        # number of hit rays stays on the device (`count`): launches are sized for the capacity and clamp to it in-kernel, so a
-        # training step has no host sync here.
-        cap = idx.numel()
-        X = ops.inner_light_encode(inters, dirs, nrm, idx, count)                 # [cap, 123], rows >= count unspecified
-        gsel = g.index_select(0, idx.clamp(0, g.shape[0] - 1))                    # [cap, 3]
-        ws = [t.detach() for t in inner_wb]
+    def _net_bwd(X, gsel, ws, count, exp_max):
+        """Recompute the four layers on X and differentiate them (HIP dense-layer kernels): -> 8 gradients (weight, bias per layer).
+        The row count stays on the device (`count`): launches are sized for the capacity and clamp to it in-kernel -- no host sync."""
         acts = [ops.ACT_RELU, ops.ACT_RELU, ops.ACT_RELU, ops.ACT_EXP_CLAMP]
         hs = [X]
         for l in range(4):
-            hs.append(ops.linear_fwd(hs[-1], ws[2 * l], ws[2 * l + 1], acts[l], ctx.exp_max, n_dev=count))
+            hs.append(ops.linear_fwd(hs[-1], ws[2 * l], ws[2 * l + 1], acts[l], exp_max, n_dev=count))
         grads = [None] * 8
         gy = gsel
         for l in (3, 2, 1, 0):
-            gx, gw, gb = ops.linear_bwd(hs[l], ws[2 * l], hs[l + 1], gy, acts[l], ctx.exp_max, need_gx=l > 0, n_dev=count)
+            gx, gw, gb = ops.linear_bwd(hs[l], ws[2 * l], hs[l + 1], gy, acts[l], exp_max, need_gx=l > 0, n_dev=count)
             grads[2 * l], grads[2 * l + 1] = gw, gb
             gy = gx
-        return (g_base, None, None, None, None, None, None, None, *grads)
+        return grads
+
+    @staticmethod
+    def backward(ctx, g_lights, _g_hit):
+        first, dirs, inters, nrm, depth, hit, idx, count, count_m, *wb = ctx.saved_tensors
+        near = (depth > 1e-5).float()[:, None]
+        g = (g_lights * near).contiguous()
+        ws = [t.detach().contiguous() for t in wb]
+        g_base, g_outer = None, []
+        if ctx.has_env:
+            g_base = ops.cube_lookup_bwd(first.detach(), dirs, g * (~hit).float()[:, None], apply_exp=True)
+        else:
+            from .encodings import ide5
+            idx_m = first.clamp(0, g.shape[0] - 1)                                # rows >= count_m are unspecified: any valid row
+            d_m = dirs.index_select(0, idx_m)
+            X = ide5(d_m, torch.zeros(d_m.shape[0], 1, device=d_m.device), wide=True).contiguous()      # [cap, 72]
+            g_outer = LightsFn._net_bwd(X, g.index_select(0, idx_m), ws[8:], count_m, ctx.outer_exp_max)
+        # inner-light net on the hit rows
+        X = ops.inner_light_encode(inters, dirs, nrm, idx, count)                 # [cap, 123], rows >= count unspecified
+        gsel = g.index_select(0, idx.clamp(0, g.shape[0] - 1))                    # [cap, 3]
+        grads = LightsFn._net_bwd(X, gsel, ws[:8], count, ctx.exp_max)
+        return (g_base, None, None, None, None, None, None, None, None, *grads, *g_outer)
 
 
 class CompositeFn(torch.autograd.Function):

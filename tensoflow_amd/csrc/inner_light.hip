@@ -753,11 +753,16 @@ __host__ __device__ __forceinline__ int il3_orig_col(int k) {
   }
   return k < 123 ? k - 120 : -1;
 }
-static __global__ void __launch_bounds__(256) inner_light_cols3_kernel(const float* __restrict__ W /*[256,123]*/, float* __restrict__ Wp /*[256,128]*/) {
+// in_cols = 123: the inner-light net's first layer; in_cols = 72: the outer-light net's ('direction': IDE columns only, the positional
+// columns of the image are zero)
+static __global__ void __launch_bounds__(256) inner_light_cols3_kernel(const float* __restrict__ W /*[256,in_cols]*/, int in_cols,
+                                                                       float* __restrict__ Wp /*[256,128]*/) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= 256 * 128) return;
-  const int row = e >> 7, k = e & 127, c = il3_orig_col(k);
-  Wp[e] = c >= 0 ? W[row * 123 + c] : 0.f;
+  const int row = e >> 7, k = e & 127;
+  int c = il3_orig_col(k);
+  if (in_cols == 72) c = c >= 51 ? c - 51 : -1;
+  Wp[e] = c >= 0 ? W[row * in_cols + c] : 0.f;
 }
 
 #ifdef IL3_STAMPS
@@ -905,6 +910,10 @@ __device__ __forceinline__ void il3_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// OUTER: the same network shape fed with the IDE of the ray DIRECTION itself (MCShadingNetwork.predict_outer_lights, 'direction':
+// network/fields.py:913-916 -- sph_enc(directions, 0), no reflection, no normalisation, no positional columns: their weights are zero
+// in the image and `pts` / `nrm` alias `view`)
+template <bool OUTER>
 __global__ void __launch_bounds__(512, 1)
 inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
                     const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
@@ -1010,7 +1019,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     const long long* idx_o = idx;
     asm volatile("" : "+s"(idx_o));
     const int hh_o = lane_o >> 5;
-    const float vsign_o = idx_o ? -1.f : 1.f;
+    const float vsign_o = (idx_o && !OUTER) ? -1.f : 1.f;
     IL3_STAMP(0);
     // ================= step FE
     // ---- F: the 256 -> 3 layer of the pass whose layer 3 this wave has just finished (its accumulators)
@@ -1070,7 +1079,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
         v[0] *= inv; v[1] *= inv; v[2] *= inv;
         const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
-        const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
+        const float rx = OUTER ? rv.x : vn * n[0] * 2.f - v[0], ry = OUTER ? rv.y : vn * n[1] * 2.f - v[1], rz = OUTER ? rv.z : vn * n[2] * 2.f - v[2];
 #ifndef IL3_ABLATE_E
         // IDE columns [C0, C1) (+ [D0, D1)): sph[col] = (rx + i ry)^mm * sum_q mat[q][col] rz^q; Re -> column col, Im -> 36 + col
         auto ide_cols = [&](auto c0_, auto c1_, auto d0_, auto d1_) {
@@ -1217,7 +1226,7 @@ static __global__ void __launch_bounds__(256) inner_light_cols_kernel(const floa
 static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
                               const int64_t* idx, const int64_t* count_dev, const float* depth, float near_eps, float exp_max,
                               int32_t precision, float* out, float* workspace, size_t workspace_floats, hipStream_t stream,
-                              const char* who) {
+                              const char* who, bool outer = false) {
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
@@ -1226,6 +1235,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16 || precision == TF_PREC_F16X2, TF_EINVAL,
              "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
+  TF_REQUIRE(!outer || (precision == TF_PREC_F16X3 && !ring), TF_EINVAL, "%s: the direction-encoded outer light runs on the fp32-grade "
+             "staggered kernel only (precision TF_PREC_F16X3)", who);
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kInnerWsFloats);
@@ -1238,13 +1249,16 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
       tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
     } else {
       _Float16* hw = reinterpret_cast<_Float16*>(workspace);
-      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
+      if (!outer)      // (the first-layer images of the other kernels read a [256,123] matrix: the outer net's is [256,72])
+        tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
-      inner_light_cols_kernel<<<tf_blocks(256 * 123, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);
-      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kP1);
-      inner_light_cols3_kernel<<<tf_blocks(256 * 128, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);     // same stream: after the pack above has read kWp
+      if (!outer) {
+        inner_light_cols_kernel<<<tf_blocks(256 * 123, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);
+        tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kP1);
+      }
+      inner_light_cols3_kernel<<<tf_blocks(256 * 128, 256), 256, 0, stream>>>(net->w[0], outer ? 72 : 123, workspace + kWp);     // same stream: after the pack above has read kWp
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 128, 0, 128, 8, 8, hw + 2 * (size_t)kQ1);
     }
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
@@ -1272,7 +1286,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     // staggered two-team kernel: one 512-thread workgroup per CU, two 64-ray passes in flight
     long long blocks = ((m + 63) / 64 + 1) / 2;
     if (blocks > 256) blocks = 256;
-    inner_light3_kernel<<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    if (outer) inner_light3_kernel<true><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    else inner_light3_kernel<false><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
     return TF_OK;
   }
@@ -1316,6 +1331,14 @@ extern "C" int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, c
   TF_REQUIRE(capacity == 0 || (idx && count_dev), TF_EINVAL, "tf_inner_light_indexed_fwd: idx / count_dev is null");
   return inner_light_launch(net, pos, dirs, nrm, capacity, idx, count_dev, depth, near_eps, exp_max, precision, lights, workspace,
                             workspace_floats, (hipStream_t)stream, "tf_inner_light_indexed_fwd");
+}
+
+extern "C" int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, const int64_t* idx, const int64_t* count_dev,
+                                         int64_t capacity, float exp_max, int32_t precision, float* lights, float* workspace,
+                                         size_t workspace_floats, tf_stream_t stream) {
+  TF_REQUIRE(capacity == 0 || (idx && count_dev), TF_EINVAL, "tf_outer_light_indexed_fwd: idx / count_dev is null");
+  return inner_light_launch(net, dirs, dirs, dirs, capacity, idx, count_dev, nullptr, 0.f, exp_max, precision, lights, workspace,
+                            workspace_floats, (hipStream_t)stream, "tf_outer_light_indexed_fwd", true);
 }
 
 // ---------------------------------------------------------------- input encoding only (training: the weight-gradient

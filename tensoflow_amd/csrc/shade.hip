@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
     const float w0 = w.x, w1 = w.y, w2 = w.z;
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     if (w0 != 0.f || w1 != 0.f || w2 != 0.f) {
-      if (hr) {
+      if (hr || !env) {      // env == NULL: the miss rows hold the outer-light net's answer (tf_outer_light_indexed_fwd)
         const F3 hl = ld3(hit_lights + e);
         l0 = hl.x; l1 = hl.y; l2 = hl.z;
       } else if (dr > near_eps) {
@@ -355,9 +355,9 @@ extern "C" int tf_shade_reduce_env(const float* wgt, const float* dirs, const fl
                                    const float* hit_lights, const float* env_base, int32_t env_res, float near_eps, int64_t pn,
                                    int32_t n_diffuse, int32_t ss, float* colors, float* diffuse_lin, float* specular_lin,
                                    const int32_t* slot_of_pos, tf_stream_t stream) {
-  TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && env_res > 0, TF_ESHAPE, "tf_shade_reduce_env: negative size / env_res <= 0");
+  TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && (env_res > 0 || !env_base), TF_ESHAPE, "tf_shade_reduce_env: negative size / env_res <= 0");
   if (pn == 0) return TF_OK;
-  TF_REQUIRE(wgt && dirs && depth && hit_lights && env_base && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
+  TF_REQUIRE(wgt && dirs && depth && hit_lights && colors, TF_EINVAL, "tf_shade_reduce_env: null pointer");
   shade_reduce_env_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, dirs, depth, hit, hit_lights, env_base, env_res,
                                                                             near_eps, pn, n_diffuse, ss, colors, diffuse_lin,
                                                                             specular_lin, slot_of_pos);

@@ -36,8 +36,15 @@ def _ide_tables():
 _IDE = {}
 
 
-def ide5(xyz, kappa_inv):
-    """xyz [..., 3] unit directions, kappa_inv [..., 1] -> [..., 72]."""
+def ide5(xyz, kappa_inv, wide=False):
+    """xyz [..., 3] unit directions, kappa_inv [..., 1] -> [..., 72].
+    wide: evaluate in fp64 (Horner on the fp32-ROUNDED coefficient table, which is part of the reference function) and return fp32.
+    The degree-16 columns cancel catastrophically in fp32 -- the reference's own fp32 values are good to ~6e-4, their derivative wrt
+    the direction to ~2e-3 (tools/gen_golden.py:gen_shading_direction measures both against an fp64 run) -- so where the training
+    direction differentiates THROUGH the encoding (the 'direction' outer light under the roughness-warped fixed samplers) the wide
+    form keeps this implementation's noise below the reference's instead of adding a second, independent copy of it."""
+    if wide:
+        return _ide5_wide(xyz, kappa_inv)
     dev = xyz.device
     if dev not in _IDE:
         mat, ms, ls = _ide_tables()
@@ -57,6 +64,27 @@ def ide5(xyz, kappa_inv):
         poly = vmz @ mat
     att = torch.exp(-sigma * kappa_inv)
     return torch.cat([re * poly * att, im * poly * att], -1)
+
+
+def _ide5_wide(xyz, kappa_inv):
+    dev = xyz.device
+    key = (dev, "wide")
+    if key not in _IDE:
+        mat, ms, ls = _ide_tables()
+        _IDE[key] = (torch.from_numpy(mat.astype(np.float64)).to(dev), torch.from_numpy(ms).to(dev), torch.from_numpy(0.5 * ls * (ls + 1)).double().to(dev))
+    mat, ms, sigma = _IDE[key]
+    q = xyz.double()
+    x, y, z = q[..., 0:1], q[..., 1:2], q[..., 2:3]
+    poly = mat[16].expand(*z.shape[:-1], 36)
+    for k in range(15, -1, -1):                 # Horner, all 36 columns at once (element-wise kernels: no library GEMM)
+        poly = poly * z + mat[k]
+    re, im = [torch.ones_like(x)], [torch.zeros_like(x)]
+    for _ in range(16):
+        re, im = re + [re[-1] * x - im[-1] * y], im + [re[-1] * y + im[-1] * x]
+    re, im = torch.cat(re, -1)[..., ms], torch.cat(im, -1)[..., ms]
+    kap = kappa_inv.double() if torch.is_tensor(kappa_inv) else torch.as_tensor(float(kappa_inv), dtype=torch.float64, device=dev)
+    att = torch.exp(-sigma * kap)
+    return torch.cat([re * poly * att, im * poly * att], -1).float()
 
 
 def linear_to_srgb(lin):

@@ -182,8 +182,9 @@ class MCShadingNetwork(nn.Module):
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        if self.cfg["outer_light_version"] != "envlight" or self.cfg["human_lights"]:
-            raise NotImplementedError("round 1 covers outer_light_version='envlight', human_lights=False (configs/mat/syn/*.yaml)")
+        if self.cfg["outer_light_version"] not in ("envlight", "direction") or self.cfg["human_lights"]:
+            raise NotImplementedError("outer_light_version 'envlight' or 'direction', human_lights=False (every configs/mat/syn/*.yaml and "
+                                      "configs/mat/orb/*.yaml); 'sphere_direction' + human lights (configs/mat/custom) are not built")
         self.aabb, self.unit_size, self.ray_tracer = aabb, float(unit_size), ray_tracer
         R, C = self.cfg["mat_grid"], 36
         self.mat_plane = nn.ParameterList([nn.Parameter(1e-4 * (2 * torch.rand(1, C, R, R) - 1)) for _ in range(3)]).cuda()
@@ -194,7 +195,13 @@ class MCShadingNetwork(nn.Module):
         self.inner_light = nn.Sequential(wn(nn.Linear(123, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
                                          nn.ReLU(), wn(nn.Linear(256, 3)), nn.Identity()).cuda()
         nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))
-        self.outer_light = EnvLight(trainable=True, max_res=self.cfg["light_reso"])
+        if self.cfg["outer_light_version"] == "envlight":
+            self.outer_light = EnvLight(trainable=True, max_res=self.cfg["light_reso"])
+        else:
+            # fields.py:716-718: make_predictor_4layer(72, 3, activation='exp', exp_max=light_exp_max) on the IDE of the ray direction
+            self.outer_light = nn.Sequential(wn(nn.Linear(72, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
+                                             nn.ReLU(), wn(nn.Linear(256, 3)), nn.Identity()).cuda()
+            nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
         mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda")
         self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
         self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
@@ -217,7 +224,7 @@ class MCShadingNetwork(nn.Module):
         old = self._shader
         self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
                                 exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"],
-                                bvh=old.bvh if old is not None else None)
+                                bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"])
         self._shader_version = ver
         return self._shader
 
@@ -257,13 +264,23 @@ class MCShadingNetwork(nn.Module):
             reg = reg + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0))
         return reg.reshape(1)
 
+    def _outer_mlp(self, dirs):
+        """predict_outer_lights('direction') (fields.py:913-916) as a differentiable composition: IDE of the rows as they are, the
+        net's products on tf_linear_fwd / tf_linear_bwd."""
+        from ..encodings import ide5
+        enc = ide5(dirs, torch.zeros(dirs.shape[0], 1, device=dirs.device), wide=True)
+        return torch.exp(torch.clamp(_mlp(self.outer_light, enc), max=self.cfg["light_exp_max"]))
+
     def predict_outer_lights_pts(self, pts):
+        """fields.py:1512-1520."""
+        if self.cfg["outer_light_version"] == "direction":
+            return self._outer_mlp(pts)
         return self.outer_light.direct_light(pts)
 
     def env_light(self, h, w, gamma=True, no_grad=True):
         """fields.py:1475-1510: lat-long image [h,w,3] of the learned environment light."""
         from ..encodings import linear_to_srgb
-        dev = self.outer_light.base.device
+        dev = self.mat_line[0].device
         azs = torch.linspace(1.0, 0.0, w, device=dev) * np.pi * 2 - np.pi / 2
         els = torch.linspace(1.0, -1.0, h, device=dev) * np.pi / 2
         els, azs = torch.meshgrid(els, azs, indexing="ij")
@@ -310,8 +327,15 @@ class MCShadingNetwork(nn.Module):
         inner_wb = []
         for i in (0, 2, 4, 6):
             inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)
-        lights, hit = LightsFn.apply(self.outer_light.base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
-                                     self.cfg["inner_light_exp_max"], self.cfg.get("precision", ops.PREC_F16X3), *inner_wb)
+        if self.cfg["outer_light_version"] == "direction":
+            env_base = None
+            for i in (0, 2, 4, 6):
+                inner_wb += [self.outer_light[i].weight, self.outer_light[i].bias]
+        else:
+            env_base = self.outer_light.base
+        lights, hit = LightsFn.apply(env_base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
+                                     self.cfg["inner_light_exp_max"], self.cfg.get("precision", ops.PREC_F16X3), self.cfg["light_exp_max"],
+                                     *inner_wb)
         lights = lights.view(pn, T, 3)
         contrib = wgt * lights
         diffuse_lin, specular_lin = contrib[:, :nd].sum(1), contrib[:, nd:].sum(1)
@@ -380,7 +404,8 @@ class MCShadingNetwork(nn.Module):
             lights = torch.zeros_like(dirs)
             miss = ~hit
             if bool(miss.any()):
-                lights = lights.index_put((miss,), self.outer_light.direct_light(dirs[miss]))
+                outer = self._outer_mlp(dirs[miss]) if cfg["outer_light_version"] == "direction" else self.outer_light.direct_light(dirs[miss])
+                lights = lights.index_put((miss,), outer)
             if bool(hit.any()):
                 vd = F.normalize(-dirs[hit], dim=-1)
                 nh = F.normalize(nrm[hit], dim=-1)

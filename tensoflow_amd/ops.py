@@ -398,10 +398,10 @@ def compact_below(v, thr):
     return idx, count
 
 
-def _mlp4(weights):
+def _mlp4(weights, in_dim=123):
     net = L.TfMlp4()
     keep = []
-    expect = [(256, 123), (256, 256), (256, 256), (3, 256)]
+    expect = [(256, in_dim), (256, 256), (256, 256), (3, 256)]
     for l in range(4):
         W, b = _f(weights[l][0]), _f(weights[l][1])
         if tuple(W.shape) != expect[l]:
@@ -423,6 +423,22 @@ def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near
     L.check(lib.tf_inner_light_indexed_fwd(C.byref(net), _p(pos), _p(dirs), _p(nrm), _p(idx, torch.int64), _p(count, torch.int64),
                                            idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision) | flag, _p(lights),
                                            _p(ws), ws.numel(), _stream()), "tf_inner_light_indexed_fwd")
+    return lights
+
+
+def outer_light_indexed(weights, dirs, idx, count, lights, exp_max=5.0, precision=PREC_F16X3, cache=None):
+    """In place: lights[i] = exp(min(outer_light(IDE5(dirs[i])), exp_max)) for i in idx[:count] -- predict_outer_lights('direction') on
+    the rays that missed (tf_outer_light_indexed_fwd).  weights: 4 (W_eff, b) pairs, 72-256-256-256-3."""
+    lib = L.load()
+    net, keep = _mlp4(weights, in_dim=72)
+    if cache is None:
+        ws, flag = _workspace("outer", lib.tf_inner_light_workspace_floats(), dirs.device), 0
+    else:
+        ws = cache.workspace(lib.tf_inner_light_workspace_floats(), dirs.device)
+        flag = cache.flag(keep, precision)
+    L.check(lib.tf_outer_light_indexed_fwd(C.byref(net), _p(dirs), _p(idx, torch.int64), _p(count, torch.int64), idx.numel(),
+                                           float(exp_max), int(precision) | flag, _p(lights), _p(ws), ws.numel(), _stream()),
+            "tf_outer_light_indexed_fwd")
     return lights
 
 
@@ -845,10 +861,10 @@ def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, 
     colors = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     dl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     sl = torch.empty(pn, 3, dtype=torch.float32, device=dev)
-    env_base = _f(env_base)
+    env_base = _f(env_base) if env_base is not None else None       # None: every light is in hit_lights (outer_light_version='direction')
     L.check(lib.tf_shade_reduce_env(_p(_f(wgt)), _p(_f(dirs)), _p(_f(depth)), _p(hit_u8, torch.uint8) if hit_u8 is not None else None,
-                                    _p(_f(hit_lights)), _p(env_base),
-                                    env_base.shape[1], float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl),
+                                    _p(_f(hit_lights)), _p(env_base) if env_base is not None else None,
+                                    env_base.shape[1] if env_base is not None else 0, float(near_eps), pn, n_diffuse, ss, _p(colors), _p(dl), _p(sl),
                                     _p(slot_of_pos, torch.int32), _stream()),
             "tf_shade_reduce_env")
     return colors, dl, sl

@@ -138,6 +138,9 @@ class ShadeOutputs(dict):
         if key == "lights":     # [pn,T,3] light of every ray (fields.py:951-975): hit rows from the inner-light net, the rest env light
             hit = self["hit"]
             pn, T = hit.shape
+            if self["_env"] is None:      # outer_light_version='direction': the outer net wrote the rows of the rays that missed
+                self[key] = self["hit_lights"]
+                return self[key]
             env = ops.cube_lookup(self["_env"], self["dirs"].reshape(-1, 3), apply_exp=True, depth=self["depth"].reshape(-1), near_eps=1e-5)
             lights = torch.where(hit.reshape(-1, 1), self["hit_lights"].reshape(-1, 3), env).reshape(pn, T, 3)
             self[key] = lights
@@ -180,10 +183,14 @@ class FlowParams:
 
 
 class MCShader:
-    """Eval-mode MCShadingNetwork with outer_light_version='envlight', human lights off."""
+    """Eval-mode MCShadingNetwork, human lights off.  outer_light_version follows the state dict: `outer_light.base` = 'envlight' (the
+    cube map, looked up inside the reduction), `outer_light.0.*` = 'direction' (fields.py:716-718, 913-916: a 72-256-256-256-3 net on
+    the IDE of the ray direction, evaluated on the rays that missed by tf_outer_light_indexed_fwd; configs/mat/syn/{lego,armadillo,
+    horse}.yaml)."""
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
-                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False):
+                 exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False,
+                 light_exp_max=5.0):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         # Inner-light decoder (123-256-256-256-3): fp32-grade f16x3 operand split like every other decoder.  ops.PREC_F16 (plain f16
@@ -201,11 +208,21 @@ class MCShader:
         # field_f16: BASELINE configs[4] ("fp16 field + flow") -- the material and flow VM pyramids hold halves (ops.VmPacked)
         self.field_f16 = bool(field_f16)
         self.mat_packed = ops.VmPacked(self.mat_planes, self.mat_lines, 3, texel_f16=field_f16)
-        sdd = {k: v.to(device).float() for k, v in sd.items() if v.is_floating_point() and ("predictor" in k or "inner_light" in k)}
+        sdd = {k: v.to(device).float() for k, v in sd.items() if v.is_floating_point() and ("predictor" in k or "inner_light" in k or
+                                                                                          k.startswith("outer_light."))}
         self.pred = {name: [(wn_weight(sdd, f"{name}_predictor.{i}").contiguous(), sdd[f"{name}_predictor.{i}.bias"]) for i in (0, 2)]
                      for name in ("metallic", "roughness", "albedo")}
         self.inner = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
-        self.env = g("outer_light.base")
+        if "outer_light.base" in sd:
+            self.env, self.outer = g("outer_light.base"), None
+        elif "outer_light.0.bias" in sd and tuple(wn_weight(sdd, "outer_light.0").shape) == (256, 72):
+            self.env = None
+            self.outer = [(wn_weight(sdd, f"outer_light.{i}").contiguous(), sdd[f"outer_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
+            self.outer_cache = ops.PackCache()
+            self.light_exp_max = float(light_exp_max)
+        else:
+            raise NotImplementedError("outer light: a cube map (`outer_light.base`, outer_light_version='envlight') or the 72-input net of "
+                                      "outer_light_version='direction'; 'sphere_direction' (144 inputs, configs/mat/custom) is not built")
         self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device, field_f16=field_f16)
         self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device, field_f16=field_f16)
         self.inner_cache = ops.PackCache()
@@ -269,10 +286,20 @@ class MCShader:
         with T.stage("hit_compaction"):
             idx, count = ops.compact_below(depth, ops.MISS_DEPTH)
         with T.stage("inner_light"):
-            hit_lights = torch.empty_like(dirs)
+            # 'direction': rows of culled rays are read by nobody but `lights` consumers (aux maps): zero, not uninitialised
+            hit_lights = torch.empty_like(dirs) if self.outer is None else torch.zeros_like(dirs)
             ops.inner_light_indexed(self.inner, inters, dirs, nrm, idx, count, depth, hit_lights, near_eps=1e-5,
                                     exp_max=self.exp_max, precision=self.inner_precision if self.precision != ops.PREC_F32 else ops.PREC_F32,
                                     cache=self.inner_cache)
+        if self.outer is not None:
+            with T.stage("outer_light"):
+                # miss branch of get_lights (fields.py:962-968) with predict_outer_lights('direction'): the same staggered kernel on the
+                # (live) rays that missed; their near mask is 1 (depth = the traversal's miss value)
+                miss = (depth >= ops.MISS_DEPTH).to(torch.uint8)
+                if live is not None:
+                    miss &= live.reshape(-1).to(torch.uint8)
+                idx_m, count_m = ops.compact_mask(miss)
+                ops.outer_light_indexed(self.outer, dirs, idx_m, count_m, hit_lights, exp_max=self.light_exp_max, cache=self.outer_cache)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return hit_lights, hit, depth, inters
 
@@ -282,6 +309,8 @@ class MCShader:
         evaluated inside the reduction, tf_shade_reduce_env.)"""
         hit_lights, _, depth, inters = self.trace_and_inner(pts_rep, dirs, live=live, slot_order=slot_order)
         hit = depth < ops.MISS_DEPTH
+        if self.outer is not None:
+            return hit_lights, hit, inters
         lights = ops.cube_lookup(self.env, dirs, apply_exp=True, depth=depth, near_eps=1e-5)
         lights = torch.where(hit[:, None], hit_lights, lights)
         return lights, hit, inters

@@ -55,7 +55,8 @@ def material_param_groups(net, lr_xyz, lr_net, lr_env):
     groups = [
         {"params": list(net.mat_line), "lr": lr_xyz},
         {"params": list(net.mat_plane), "lr": lr_xyz},
-        {"params": list(net.outer_light.parameters()), "lr": lr_env},
+        # fields.py:1584: the cube map takes the environment-light rate, the direction-encoded net the network rate
+        {"params": list(net.outer_light.parameters()), "lr": lr_env if net.cfg["outer_light_version"] == "envlight" else lr_net},
         {"params": list(net.albedo_predictor.parameters()) + list(net.metallic_predictor.parameters())
                    + list(net.roughness_predictor.parameters()) + list(net.inner_light.parameters()), "lr": lr_net},
     ]

@@ -243,5 +243,10 @@ def test_round2_entry_points_validate(lib):
     assert lib.tf_compact_below(None, 10.0, -1, None, None, None) == -2
     assert lib.tf_compact_below(None, 10.0, 4, None, None, None) == -1 and b"count is null" in lib.tf_last_error()
     # hit may be NULL (depth < TF_MISS_DEPTH); the other arrays may not
-    assert lib.tf_shade_reduce_env(a, a, a, None, a, None, 4, 1e-5, 3, 2, 1, a, None, None, None, None) == -1 and b"null pointer" in lib.tf_last_error()
+    # (env_base may be NULL as well since round 3 -- outer_light_version='direction': every light is read from hit_lights)
+    assert lib.tf_shade_reduce_env(a, a, a, None, None, a, 4, 1e-5, 3, 2, 1, a, None, None, None, None) == -1 and b"null pointer" in lib.tf_last_error()
+    # the direction-encoded outer light runs on the fp32-grade kernel only; idx / count are required
+    assert lib.tf_outer_light_indexed_fwd(None, a, None, None, 4, 5.0, 1, a, a, 0, None) == -1 and b"idx / count_dev" in lib.tf_last_error()
+    assert lib.tf_outer_light_indexed_fwd(None, a, a, a, 4, 5.0, 2, a, a, 0, None) == -1 and b"TF_PREC_F16X3" in lib.tf_last_error()
+    assert lib.tf_outer_light_indexed_fwd(None, a, a, a, 0, 5.0, 1, a, a, 0, None) == 0
     assert lib.tf_shade_reduce_env(a, a, a, None, a, a, 0, 1e-5, 3, 2, 1, a, None, None, None, None) == -2

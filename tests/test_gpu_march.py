@@ -390,6 +390,114 @@ def test_mcshading_training_step_before_flow_copies_golden(golden, dev, step):
     assert with_grad >= set(grads), sorted(set(grads) - with_grad)[:5]
 
 
+def _direction_net(golden, dev):
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    g, base = golden("shading_direction"), golden("shading_grad")
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
+               nis_specular_sample_num=sn_s, outer_light_version="direction")
+    m = MCShadingNetwork(cfg, (base["verts"].numpy(), base["faces"].numpy()), AABB, float(g["unit_size"]))
+    sd = {k: v for k, v in base.sd.items() if not k.startswith("outer_light.")}
+    sd.update(g.sd)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not [k for k in unexpected if k.startswith("outer_light.")]     # the reference's keys of the 'direction' net, all of them
+    for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
+        for p in fl.parameters():
+            p.requires_grad = False
+    m.eval()
+    return g, base, sd, m
+
+
+def test_direction_outer_light_eval_golden(golden, dev):
+    """outer_light_version='direction' (configs/mat/syn/{lego,armadillo,horse}.yaml; fields.py:716-718, 913-916): get_lights,
+    predict_outer_lights_pts and the eval forward (fixed pass + flow pass) against the reference run on the same state."""
+    from tensoflow_amd.shading import MCShader
+    g, base, sd, m = _direction_net(golden, dev)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    sh = MCShader(sd, base["verts"].numpy(), base["faces"].numpy(), AABB, float(g["unit_size"]), device=dev, n_fixed_diffuse=n_fd,
+                  n_fixed_specular=n_fs)
+    assert sh.env is None and sh.outer is not None
+    pts16 = g["pts"].repeat_interleave(16, 0).to(dev)
+    lights, hit, _ = sh.lights(pts16, g["gl_dirs"].to(dev).contiguous())
+    assert torch.equal(hit.cpu(), g["gl_hit"].bool())
+    # Per RAY the reference's own fp32 answer is only good to ~6e-4 on this (trained) net: the IDE's degree-16 polynomials cancel
+    # catastrophically in fp32 (oracle in fp32 vs the same oracle in fp64).  The HIP path is held to the fp64 answer within twice
+    # the reference's own distance from it -- and to the reference within 1e-4 per PIXEL below, where the integral averages the noise.
+    from oracle import shading as osh
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = osh.outer_light_direction(sd64, g["gl_dirs"].double())
+    rel = lambda a: float(((a.double() - ref64).abs() / ref64.abs().clamp_min(1e-2)).max())
+    with torch.no_grad():
+        env = m.predict_outer_lights_pts(g["gl_dirs"].to(dev))                    # the differentiable composition (exact-fp32 products)
+    miss = ~hit.cpu()
+    e_ref, e_kernel, e_comp = rel(g["outer_pts"]), rel(torch.where(miss[:, None], lights.cpu(), ref64.float())), rel(env.cpu())
+    print(f"direction outer light, per-ray error against the fp64 oracle: reference {e_ref:.2e}, staggered kernel {e_kernel:.2e}, "
+          f"composed {e_comp:.2e} ({int(miss.sum())} missing + {int(hit.sum())} hit rays)")
+    assert e_kernel < max(TOL, 2 * e_ref) and e_comp < max(TOL, 2 * e_ref)
+    hl = lights.cpu()[~miss]
+    assert float(((hl - g["gl_lights"][~miss]).abs() / g["gl_lights"][~miss].abs().clamp_min(1e-2)).max()) < 1e-3     # inner light on the hits
+    with torch.no_grad():
+        colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
+    assert rel_err(colors.cpu(), g["colors"]) < TOL
+    for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light", "rgb_pr_nis",
+              "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis", "specular_light_nis"):
+        assert rel_err(out[k].cpu(), g.out[k]) < TOL, k
+    # the throughput path (zero-weight rays culled: their rows are never evaluated) gives the same colours
+    sh.cull_dead_rays = True
+    o2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
+    assert rel_err(o2["colors"].cpu(), g.out["rgb_pr_nis"]) < TOL
+    # lat-long image of the learned light (fields.py:1475-1510) goes through the same net
+    img = m.env_light(8, 16)
+    assert img.shape == (8, 16, 3) and torch.isfinite(img).all()
+
+
+@pytest.mark.parametrize("step", [100, 1200])
+def test_direction_outer_light_training_golden(golden, dev, step):
+    """Training direction of the 'direction' outer light: the fixed-sampler pass (step 100: the colour gradient reaches the
+    material grids through the roughness-warped directions AND the IDE of the outer net's input) and the flow pass (step 1200)
+    against the reference's autograd."""
+    g, base, sd, m = _direction_net(golden, dev)
+    if step >= 1000:
+        m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
+    colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, step, False)
+    assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    if step >= 1000:
+        assert abs(float(out["loss_nis"]) - float(g["loss_nis_1200"])) < 1e-4 * max(1, abs(float(g["loss_nis_1200"])))
+    ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
+    grads = {k[len(f"grad{step}/"):]: v for k, v in g.a.items() if k.startswith(f"grad{step}/")}
+    checked, bad, vs64 = 0, [], []
+    for name, p in m.named_parameters():
+        if name in grads and p.requires_grad:
+            assert p.grad is not None, name
+            ref = grads[name]
+            scale = float(ref.abs().max()) + 1e-12
+            err = float((p.grad.cpu() - ref).abs().max()) / scale
+            l2 = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-20))
+            key64 = f"grad{step}_f64/{name}"
+            if key64 in g.a:
+                # the reference's own fp32 gradient is 1e-3 away from the same pass run in fp64 (the colour gradient reaches the grids
+                # through d IDE / d direction: degree-16 polynomials that cancel badly in fp32; tools/gen_golden.py stores both): the
+                # HIP path is held to the fp64 answer within 2.5x the reference's own distance from it
+                r64 = g[key64]
+                d_ref = float((ref.double() - r64).abs().max() / r64.abs().max()), float((ref.double() - r64).norm() / r64.norm())
+                d_hip = float((p.grad.cpu().double() - r64).abs().max() / r64.abs().max()), float((p.grad.cpu().double() - r64).norm() / r64.norm())
+                ok = d_hip[0] < max(1e-3, 2.5 * d_ref[0]) and d_hip[1] < max(1e-3, 2.5 * d_ref[1])
+                vs64.append((name.split(".parametrizations")[0], "ref %.1e/%.1e" % d_ref, "hip %.1e/%.1e" % d_hip))
+            elif "inner_light" in name or "outer_light" in name:
+                ok = l2 < 2e-2 and err < 6e-2       # ReLU flips on a few hundred rays (see test_mcshading_training_step_golden)
+            else:
+                # step 100: through the outer net's input gradient (see above; the reference's fp32 noise there is 1.6e-3); step 1200: no
+                # gradient flows through the directions
+                ok = (err < 5e-3 and l2 < 5e-3) if step < 1000 else (err < 1e-3 and l2 < 1e-3)
+            if not ok:
+                bad.append((name, round(err, 5), round(l2, 5)))
+            checked += 1
+    print("checked", checked, "against the fp64 reference (max / l2):", vs64)
+    assert not bad, bad
+    assert checked >= 40 and sum(n.startswith("outer_light.") for n in grads) == 12 and (step >= 1000 or len(vs64) >= 6)
+    assert all(m.get_parameter(n).grad is not None for n in grads if n.startswith("outer_light."))
+
+
 def test_sdf_alpha_training_golden(golden, dev):
     """Shape-stage training direction (geometry): loss over compute_sdf_alpha + compositing; gradients of the SDF planes, lines,
     decoder and variance vs the reference autograd."""

@@ -51,6 +51,36 @@ def test_env_and_lights(golden):
     assert rel_err(inters, g["gl_inters"]) < 1e-6
 
 
+def _direction_state(golden):
+    """shading_direction.npz holds the outer-light net only; the rest of the state and the mesh are shading_grad's."""
+    g, base = golden("shading_direction"), golden("shading_grad")
+    sd = {k: v for k, v in base.sd.items() if not k.startswith("outer_light.")}
+    sd.update(g.sd)
+    return g, base, sd
+
+
+def test_direction_outer_light(golden):
+    """outer_light_version='direction' (fields.py:716-718, 913-916; configs/mat/syn/{lego,armadillo,horse}.yaml): the oracle's
+    miss branch against the reference's get_lights / predict_outer_lights_pts / eval forward."""
+    g, base, sd = _direction_state(golden)
+    assert rel_err(osh.outer_light_direction(sd, g["gl_dirs"]), g["outer_pts"]) < 2e-6
+    tr = _tracer(base)
+    unit = float(g["unit_size"])
+    lights, hit, _ = osh.get_lights(sd, tr, unit, g["pts"].repeat_interleave(16, 0), g["gl_dirs"])
+    assert torch.equal(hit, g["gl_hit"].bool()) and 0.2 < hit.float().mean() < 0.8
+    assert rel_err(lights, g["gl_lights"]) < 1e-5
+    assert float(g["gl_lights"][~hit].log().std()) > 0.5            # the net answers with a spread of radiances, not its bias
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    fixed = osh.shade(sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs,
+                      use_flow=False)
+    assert rel_err(fixed["colors"], g["colors"]) < 2e-5
+    assert rel_err(fixed["diffuse_light"], g.out["diffuse_light"]) < 2e-5
+    flow = osh.shade(sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs,
+                     use_flow=True)
+    assert rel_err(flow["colors"], g.out["rgb_pr_nis"]) < 5e-5
+    assert rel_err(flow["diffuse_light"], g.out["diffuse_light_nis"]) < 5e-5
+
+
 def test_cpu_bvh_equals_brute_force():
     """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
     unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along

@@ -585,6 +585,118 @@ def gen_shading_grad_fixed():
     save("shading_grad_fixed", **arr)           # network state and mesh: shading_grad.npz (same seed)
 
 
+def gen_shading_direction():
+    """outer_light_version='direction' (configs/mat/syn/{lego,armadillo,horse}.yaml; fields.py:716-718, 913-916): the network of
+    `shading_grad` (same seed, same sizes) with the outer light a 72-256-256-256-3 net on the IDE of the ray direction, made
+    TRAINED (400 Adam steps on a synthetic sky, through the reference's own module).  Stored: only the tensors that differ from
+    shading_grad.npz (`outer_light.*`); eval forward (fixed + flow pass), get_lights on random rays, and the reference's autograd
+    gradients of the flow pass (step 1200, copies active) and of the fixed-sampler pass (step 100)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, (o + 2 * unit * d).detach(), d.detach())      # (as gen_shading_grad_fixed)
+    torch.manual_seed(4)
+    cfg = dict(outer_light_version="direction", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+               nis_specular_sample_num=8)
+    net = MCShadingNetwork(cfg, trace, AABB)
+    base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
+    # every tensor shading_grad.npz holds is loaded (the construction order of the two variants differs, so the seeds do not line up)
+    net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(base[f"mat_plane.{i}"].clone()) for i in range(3)])     # (32^2 planes, as there)
+    net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(base[f"mat_line.{i}"].clone()) for i in range(3)])
+    own = net.state_dict()
+    own.update({k: v for k, v in base.items() if k in own})
+    net.load_state_dict(own)
+    g = torch.Generator().manual_seed(13)
+    # a TRAINED outer net instead of a freshly initialised one (which answers its bias, log 0.5, in every direction): 400 Adam steps
+    # on a synthetic sky -- a sun lobe over a vertical gradient, log-radiance between about -1.6 and 1.2 -- through the reference's
+    # own module and encoding
+    sun = torch.nn.functional.normalize(torch.tensor([0.5, -0.3, 0.8]), dim=0)
+    sky = lambda d: -1.0 + 2.2 * torch.exp(-6.0 * (1.0 - d @ sun))[:, None] + 0.6 * d[:, 2:3] * torch.tensor([1.0, 0.9, 0.7])
+    prm = list(net.outer_light.parameters())
+    m1, m2 = [torch.zeros_like(p) for p in prm], [torch.zeros_like(p) for p in prm]
+    for it in range(400):          # Adam written out (torch.optim pulls in modules the import shim cannot inspect)
+        d = torch.nn.functional.normalize(torch.randn(2048, 3, generator=g), dim=-1)
+        loss = ((net.predict_outer_lights_pts(d).log() - sky(d)) ** 2).mean()
+        grads = torch.autograd.grad(loss, prm)
+        with torch.no_grad():
+            for p_, g_, a_, b_ in zip(prm, grads, m1, m2):
+                a_.mul_(0.9).add_(g_, alpha=0.1)
+                b_.mul_(0.999).addcmul_(g_, g_, value=0.001)
+                p_.sub_(2e-3 * (a_ / (1 - 0.9 ** (it + 1))) / ((b_ / (1 - 0.999 ** (it + 1))).sqrt() + 1e-8))
+    print("outer net fitted: log-radiance mse %.4f" % float(loss))
+    net.zero_grad()
+    changed = {k: v for k, v in net.state_dict().items() if k not in base}
+    assert all(k.startswith("outer_light.") for k in changed) and "outer_light.base" not in changed, list(changed)
+    net.eval()
+    pn = 40
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
+    w = torch.rand(pn, 3, generator=g)
+    arr = dict(pts=pts, view_in=view, normals_in=nrm, bwd_w=w, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32))
+    with torch.no_grad():
+        colors, outputs = net(pts, view, nrm, None, None, False)
+        dirs = torch.nn.functional.normalize(torch.randn(pn * 16, 3, generator=g), dim=-1)
+        lights, _, inters, lnrm, hit = net.get_lights(pts.repeat_interleave(16, 0)[:, None], dirs[:, None], None)
+        env = net.predict_outer_lights_pts(dirs)
+    ml = lights[:, 0][~hit[:, 0]]
+    print("miss rays", int((~hit).sum()), "log-radiance: mean %.3f std %.3f min %.3f max %.3f" % (
+        float(ml.log().mean()), float(ml.log().std()), float(ml.log().min()), float(ml.log().max())))
+    keep = ("albedo", "roughness", "metallic", "diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility",
+            "indirect_light", "rgb_pr_nis", "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis",
+            "diffuse_light_nis", "specular_light_nis")
+    arr.update({"out/" + k: outputs[k] for k in keep})
+    arr.update(colors=colors, gl_dirs=dirs, gl_lights=lights[:, 0], gl_hit=hit[:, 0], outer_pts=env)
+    # training direction, fixed samplers (copies not active yet)
+    assert not net.use_flow_diffuse_copy and not net.use_flow_specular_copy
+    net.zero_grad()
+    c, o = net(pts, view, nrm, None, 100, False)
+    ((c * w).sum() + o["loss_nis"]).backward()
+    arr.update({"colors_100": c})
+    # (the flows' own gradients are pinned by shading_grad / shading_grad_fixed: not stored again)
+    arr.update({"grad100/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and not k.startswith("flow_")})
+    # the same pass in fp64 (the reference's module, default dtype switched): how far the reference's own fp32 gradients are from
+    # the exact ones -- the colour gradient reaches the material grids through d IDE / d direction, degree-16 polynomials that
+    # cancel badly in fp32 -- is the yardstick the parity test holds the HIP path to
+    torch.set_default_dtype(torch.float64)
+    cells = [c for c in net.sph_enc.__closure__ if torch.is_tensor(c.cell_contents)]     # the IDE closure's fp32 tables (the fp32-ROUNDED
+    kept = [c.cell_contents for c in cells]                                              # coefficients are part of the function: kept, widened)
+    try:
+        for c in cells:
+            c.cell_contents = c.cell_contents.double()
+        net.double()
+        net.zero_grad()
+        c64, o64 = net(pts.double(), view.double(), nrm.double(), None, 100, False)
+        ((c64 * w.double()).sum() + o64["loss_nis"]).backward()
+        arr.update({"grad100_f64/" + k: p.grad.clone() for k, p in net.named_parameters()
+                    if p.grad is not None and (k.startswith("mat_line") or k.startswith("outer_light.0") or k.startswith("roughness_predictor.2"))})
+        arr["colors_100_f64"] = c64
+    finally:
+        torch.set_default_dtype(torch.float32)
+        for c, v in zip(cells, kept):
+            c.cell_contents = v
+        net.float()
+    for k in ("mat_line.0", "outer_light.0.parametrizations.weight.original1"):
+        a32, a64 = arr["grad100/" + k].double(), arr["grad100_f64/" + k]
+        print("fp32 reference vs fp64 reference, grad of", k, ": max %.2e l2 %.2e" % (float((a32 - a64).abs().max() / a64.abs().max()), float((a32 - a64).norm() / a64.norm())))
+    # ... and with the flow copies sampling
+    for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
+        for p in fl.parameters():
+            p.requires_grad = False
+    net.use_flow_diffuse_copy = net.use_flow_specular_copy = True
+    net.zero_grad()
+    c, o = net(pts, view, nrm, None, 1200, False)
+    ((c * w).sum() + o["loss_nis"]).backward()
+    arr.update({"colors_1200": c, "loss_nis_1200": o["loss_nis"]})
+    arr.update({"grad1200/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and not k.startswith("flow_")})
+    print("grads:", sum(k.startswith("grad100/") for k in arr), sum(k.startswith("grad1200/") for k in arr))
+    save("shading_direction", sd=changed, **arr)       # the rest of the state and the mesh: shading_grad.npz
+
+
 def gen_march_grad():
     """Geometry-only training direction of the ray-march: loss over compute_sdf_alpha + nerfacc compositing outputs
     (shapeRenderer.py:995-1025, :1166-1206); gradients of the SDF field, decoder and variance from the reference autograd."""
