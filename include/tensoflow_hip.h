@@ -354,8 +354,9 @@ int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, const int64
  * i = idx[r] (r < *count_dev), or i = r when idx is NULL (then view = dirs).  Used by the training backward, whose
  * weight-gradient products are plain library GEMMs on X. */
 int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm, const int64_t* idx,
-                          const int64_t* count_dev, int64_t capacity, float* X, float* workspace,
-                          size_t workspace_floats, tf_stream_t stream);
+                          const int64_t* count_dev, int64_t capacity, float* X, int32_t ld /* row stride of X in floats, >= 123:
+                          columns [123, ld) are written as zeros (ld = 128: rows aligned for the dense-layer kernels' DMA path) */,
+                          float* workspace, size_t workspace_floats, tf_stream_t stream);
 /* idx[0 .. *count) = indices i with mask[i] != 0 (unordered); *count is zeroed by the call (replaces the boolean-mask
  * indexing of fields.py:962-971). */
 int tf_compact_mask(const uint8_t* mask, int64_t m, int64_t* idx, int64_t* count, tf_stream_t stream);

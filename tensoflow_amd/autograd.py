@@ -201,9 +201,13 @@ class LightsFn(torch.autograd.Function):
             X = ide5(d_m, torch.zeros(d_m.shape[0], 1, device=d_m.device), wide=True).contiguous()      # [cap, 72]
             g_outer = LightsFn._net_bwd(X, g.index_select(0, idx_m), ws[8:], count_m, ctx.outer_exp_max)
         # inner-light net on the hit rows
-        X = ops.inner_light_encode(inters, dirs, nrm, idx, count)                 # [cap, 123], rows >= count unspecified
+        # rows of 128 floats (5 zero columns, the first layer's weight padded to match): aligned for the dense layers' DMA kernels
+        X = ops.inner_light_encode(inters, dirs, nrm, idx, count, ld=128)         # [cap, 128], rows >= count unspecified
         gsel = g.index_select(0, idx.clamp(0, g.shape[0] - 1))                    # [cap, 3]
-        grads = LightsFn._net_bwd(X, gsel, ws[:8], count, ctx.exp_max)
+        wi = list(ws[:8])
+        wi[0] = torch.nn.functional.pad(wi[0], (0, 5))
+        grads = LightsFn._net_bwd(X, gsel, wi, count, ctx.exp_max)
+        grads[0] = grads[0][:, :123].contiguous()
         return (g_base, None, None, None, None, None, None, None, None, *grads, *g_outer)
 
 

@@ -1346,14 +1346,15 @@ extern "C" int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, 
 __global__ void __launch_bounds__(256) inner_light_encode_kernel(const float* __restrict__ mat, const float* __restrict__ pts,
                                                                  const float* __restrict__ view, const float* __restrict__ nrm,
                                                                  long long m_arg, const long long* __restrict__ idx,
-                                                                 const long long* __restrict__ count_dev, float* __restrict__ X) {
+                                                                 const long long* __restrict__ count_dev, float* __restrict__ X, int ld) {
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   if (row >= m) return;
   const long long src = idx ? idx[row] : row;
   const float vsign = idx ? -1.f : 1.f;
-  float* x = X + row * 123;
+  float* x = X + row * ld;
+  for (int k = 123; k < ld; ++k) x[k] = 0.f;
   const float p[3] = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
   for (int k = 0; k < 3; ++k) x[k] = p[k];
   for (int f = 0; f < 8; ++f)
@@ -1390,17 +1391,17 @@ __global__ void __launch_bounds__(256) inner_light_encode_kernel(const float* __
 }
 
 extern "C" int tf_inner_light_encode(const float* pos, const float* dirs, const float* nrm, const int64_t* idx,
-                                     const int64_t* count_dev, int64_t capacity, float* X, float* workspace, size_t workspace_floats,
-                                     tf_stream_t stream_) {
+                                     const int64_t* count_dev, int64_t capacity, float* X, int32_t ld, float* workspace,
+                                     size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TF_REQUIRE(capacity >= 0, TF_ESHAPE, "tf_inner_light_encode: capacity < 0");
+  TF_REQUIRE(capacity >= 0 && ld >= 123, TF_ESHAPE, "tf_inner_light_encode: capacity < 0 or ld < 123");
   if (capacity == 0) return TF_OK;
   TF_REQUIRE(pos && dirs && nrm && X && workspace, TF_EINVAL, "tf_inner_light_encode: null pointer");
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "tf_inner_light_encode: workspace too small");
   hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_tables_cached(), 17 * 36 * sizeof(float), hipMemcpyHostToDevice, stream);
   TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_inner_light_encode: hipMemcpyAsync failed: %s", hipGetErrorString(e));
   inner_light_encode_kernel<<<tf_blocks(capacity, 256), 256, 0, stream>>>(workspace + kIdeMat, pos, dirs, nrm, capacity,
-                                                                         (const long long*)idx, (const long long*)count_dev, X);
+                                                                         (const long long*)idx, (const long long*)count_dev, X, ld);
   TF_LAUNCH_CHECK("tf_inner_light_encode");
   return TF_OK;
 }

@@ -15,6 +15,11 @@
 #include "mfma_mlp.h"
 #include "tf_common.h"
 
+#ifndef TF_GEMM2
+#define TF_GEMM2 1      // 0 (dev switch): every product on the register-staged kernel
+#endif
+#include <stdint.h>
+
 namespace {
 constexpr int BM = 128, BN = 64, KC = 16;
 
@@ -196,6 +201,249 @@ int launch(const GemmArgs& G, int splits, bool h3, hipStream_t stream, const cha
   return TF_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------
+// The same three products for ALIGNED operands (every leading stride a multiple of four floats: all 128- and 256-wide layers), as a
+// software pipeline that keeps the matrix cores fed.  What held the kernel above at 44 TF/s of 157 (measured, 236 k x 256 x 256): its
+// tile loads pass through registers one 16-deep chunk ahead, i.e. 1 024 cycles of MFMAs per wave stand against an HBM / L2 round trip of
+// 2-4 k cycles, and its 88-126 registers leave 3 waves per SIMD to cover the difference.  Here:
+//   * tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), THREE stages deep: the loads of
+//     chunk c + 2 are issued before the MFMAs of chunk c, one s_barrier per chunk;
+//   * a workgroup owns 128 x 128 of C, a wave 64 x 64 (2 x 2 MFMA tiles): every operand fragment read from LDS feeds two MFMAs, 32 MFMAs
+//     (2 048 cycles) per wave and chunk;
+//   * operand images in LDS follow the operand's contiguous index.  "Reduction-fast" (X [m][k], W [n][k], gZ [m][n] as the A operand
+//     of the data gradient): a row's 16 reduction elements are four 16-byte quads, stored at slot 4 r + (q ^ ((r >> 1) & 3)) of its
+//     16-row block, so that a lane's `ds_read_b128` of quad q (rows r = 0..31 across the lanes) is conflict free; lane half h takes quads
+//     2h, 2h + 1 = reduction elements 8h .. 8h + 7, element t of them in MFMA t (the pairing of the two k of v_mfma_f32_32x32x2_f32 is
+//     free as long as A and B agree).  "Output-fast" (W [n][k] as B of the data gradient, gZ and X in the weight gradient): image
+//     [16 reduction rows][128 outputs], conflict-free `ds_read_b32`, the same element -> MFMA pairing.
+//   * out-of-range quads (reduction tail, rows past a device-side count) are fetched from a 16-byte zero word instead of being
+//     predicated: every lane always issues its DMA, the vmcnt arithmetic stays uniform.
+constexpr int G2_NST = 3;
+__device__ __attribute__((aligned(16))) float g2_zero[4];
+
+struct Gemm2Args {
+  const float* A; long long sA;            // reduction-fast: A(row, red) = A[row sA + red]; output-fast: A(red, row) = A[red sA + row]
+  const float* B; long long sB;            // likewise with (col, red)
+  float* C; long long sC;
+  const float* bias;
+  long long M, N, K, k_split;
+  int act; float act_param; int atomic;
+  const long long* n_dev; int rows_are_m;
+};
+
+template <bool A_RF, bool B_RF>
+__global__ void __launch_bounds__(256, 3) gemm2_kernel(Gemm2Args G) {
+  __shared__ __attribute__((aligned(16))) float lds[G2_NST][2][128 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, i = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  if (G.n_dev) {
+    const long long nv = max(0LL, *G.n_dev);
+    if (G.rows_are_m) G.M = min(G.M, nv); else G.K = min(G.K, nv);
+  }
+  const long long m0 = (long long)blockIdx.x * 128, n0 = (long long)blockIdx.y * 128;
+  const long long kb = (long long)blockIdx.z * G.k_split, ke = min(kb + G.k_split, G.K);
+  if (m0 >= G.M || kb >= ke) return;                       // workgroup-uniform
+  const int nchunk = (int)((ke - kb + 15) / 16);
+  typedef const __attribute__((address_space(1))) float* gp_t;
+  const gp_t zero = (gp_t)g2_zero;
+  // ---- this lane's two DMA sources per operand and chunk (blocks 2 wave, 2 wave + 1 of the operand's eight 1 KB blocks)
+  auto issue = [&](int c, int st) {
+    const long long k0 = kb + 16LL * c;
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const bool rf = op == 0 ? A_RF : B_RF;
+      const float* base = op == 0 ? G.A : G.B;
+      const long long stride = op == 0 ? G.sA : G.sB, o0 = op == 0 ? m0 : n0, bound = op == 0 ? G.M : G.N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int blk = 2 * wave + j;
+        gp_t src;
+        if (rf) {
+          const int rl = lane >> 2, q = (lane & 3) ^ ((rl >> 1) & 3);
+          const long long row = min(o0 + 16 * blk + rl, bound - 1), red = k0 + 4 * q;
+          src = red < ke ? (gp_t)(base + row * stride + red) : zero;
+        } else {
+          const long long red = k0 + 2 * blk + (lane >> 5), out = o0 + 4 * (lane & 31);
+          src = (red < ke && out < bound) ? (gp_t)(base + red * stride + out) : zero;
+        }
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(&lds[st][op][blk * 256]));
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(src) : "memory");
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  issue(0, 0);
+  if (nchunk > 1) issue(1, 1);
+  for (int c = 0; c < nchunk; ++c) {
+    const int st = c % G2_NST;
+    if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // chunk c has landed (chunk c + 1 may still be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                // ... for every wave; and every wave is done reading chunk c - 1
+    asm volatile("" ::: "memory");
+    if (c + 2 < nchunk) issue(c + 2, (c + 2) % G2_NST);
+    float fa[2][8], fb[2][8];
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      const bool rf = op == 0 ? A_RF : B_RF;
+      const float* img = lds[st][op];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int r = (op == 0 ? 64 * wm : 64 * wn) + 32 * t2 + i;
+        float* dst = op == 0 ? fa[t2] : fb[t2];
+        if (rf) {
+          const int blk = r >> 4, rl = r & 15;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const float4 v = *reinterpret_cast<const float4*>(img + blk * 256 + 4 * (4 * rl + ((2 * h + qq) ^ ((rl >> 1) & 3))));
+            dst[4 * qq] = v.x; dst[4 * qq + 1] = v.y; dst[4 * qq + 2] = v.z; dst[4 * qq + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) dst[t] = img[(8 * h + t) * 128 + r];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = tf_mfma(fa[a][t], fb[b][t], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long long n = n0 + 64 * wn + 32 * b + i;
+      if (n >= G.N) continue;
+      const float bv = G.bias ? G.bias[n] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long long m = m0 + 64 * wm + 32 * a + tf_rho(reg, h);
+        if (m >= G.M) continue;
+        float* dst = G.C + m * G.sC + n;
+        if (G.atomic) atomicAdd(dst, acc[a][b][reg]);
+        else *dst = act_fwd(acc[a][b][reg] + bv, G.act, G.act_param);
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Layers with at most four outputs (the 256 -> 3 radiance layers, the 128 -> 1 / 128 -> 3 material heads): 61 of 64 tile columns of a
+// matrix-core kernel would be padding (measured: 0.77 ms for the backward of 236 k x 256 -> 3, 25 x the time its bytes need).  Three
+// streaming kernels instead, one row per wave / per thread group, fp32 fma:
+//   forward      y[r][j]  = act(sum_k x[r][k] w[j][k] + b[j])    a lane owns four k of every 256, wave reduction
+//   data         gx[r][k] = sum_j gz[r][j] w[j][k]               a lane owns four k
+//   weight       gw[j][k] += sum_r gz[r][j] x[r][k]              a thread owns four k, a workgroup 1 024 rows, one atomic per (j, k) and workgroup
+template <int NOUT>
+__global__ void __launch_bounds__(256) thin_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
+                                                       long long n, int K, int act, float p, float* __restrict__ Y,
+                                                       const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, max(0LL, *n_dev));
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  float bj[NOUT];
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) bj[j] = b ? b[j] : 0.f;
+  for (long long r = wave; r < n; r += n_waves) {
+    float s[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) s[j] = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(X + r * K + k);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const float4 w = *reinterpret_cast<const float4*>(W + j * K + k);       // 1-4 KB in all: served by the vector L1
+        s[j] = fmaf(x.w, w.w, fmaf(x.z, w.z, fmaf(x.y, w.y, fmaf(x.x, w.x, s[j]))));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o);
+    if (lane < NOUT) {
+      float v = s[0];
+#pragma unroll
+      for (int j = 1; j < NOUT; ++j) v = lane == j ? s[j] : v;
+      float bb = bj[0];
+#pragma unroll
+      for (int j = 1; j < NOUT; ++j) bb = lane == j ? bj[j] : bb;
+      Y[r * NOUT + lane] = act_fwd(v + bb, act, p);
+    }
+  }
+}
+
+template <int NOUT>
+__global__ void __launch_bounds__(256) thin_data_kernel(const float* __restrict__ gZ, const float* __restrict__ W, long long n, int K,
+                                                        float* __restrict__ gX, const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, max(0LL, *n_dev));
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;       // one quad of four k
+  const int kq = K / 4;
+  const long long r = q / kq;
+  if (r >= n) return;
+  const int k = 4 * (int)(q - r * kq);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) {
+    const float g = gZ[r * NOUT + j];
+    const float4 w = *reinterpret_cast<const float4*>(W + j * K + k);
+    o.x = fmaf(g, w.x, o.x); o.y = fmaf(g, w.y, o.y); o.z = fmaf(g, w.z, o.z); o.w = fmaf(g, w.w, o.w);
+  }
+  *reinterpret_cast<float4*>(gX + r * K + k) = o;
+}
+
+template <int NOUT>
+__global__ void __launch_bounds__(256) thin_weight_kernel(const float* __restrict__ gZ, const float* __restrict__ X, long long n, int K,
+                                                          float* __restrict__ gW, const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, max(0LL, *n_dev));
+  const int kq = K / 4, rp = 256 / kq;                 // rp rows in flight per workgroup pass (K <= 1024)
+  const int t = threadIdx.x, sub = t / kq, k = 4 * (t - sub * kq);
+  const long long r0 = (long long)blockIdx.x * 1024, r1 = min(r0 + 1024, n);
+  if (r0 >= n) return;                                 // workgroup-uniform
+  __shared__ float part[NOUT * 1024];                  // [j][k]: the row groups of the workgroup meet here, then one atomic per (j, k)
+  for (int e = t; e < NOUT * K; e += 256) part[e] = 0.f;
+  __syncthreads();
+  if (sub < rp) {
+    float4 a[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + sub; r < r1; r += rp) {
+      const float4 x = *reinterpret_cast<const float4*>(X + r * K + k);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const float g = gZ[r * NOUT + j];
+        a[j].x = fmaf(g, x.x, a[j].x); a[j].y = fmaf(g, x.y, a[j].y); a[j].z = fmaf(g, x.z, a[j].z); a[j].w = fmaf(g, x.w, a[j].w);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+      atomicAdd(&part[j * K + k], a[j].x); atomicAdd(&part[j * K + k + 1], a[j].y);
+      atomicAdd(&part[j * K + k + 2], a[j].z); atomicAdd(&part[j * K + k + 3], a[j].w);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < NOUT * K; e += 256) atomicAdd(gW + e, part[e]);
+}
+inline bool thin_ok(int K, int N) { return TF_GEMM2 && N >= 1 && N <= 4 && K % 4 == 0 && K >= 4 && K <= 1024; }
+
+template <bool A_RF, bool B_RF>
+int launch2(const Gemm2Args& G, int splits, hipStream_t stream, const char* who) {
+  dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)splits);
+  gemm2_kernel<A_RF, B_RF><<<grid, 256, 0, stream>>>(G);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// 128-wide column blocks against the 64-wide ones of the register-staged kernel: not when the last block would be mostly padding
+// (TensoSDF's 129-wide output layer: 256 column slots instead of 192)
+inline bool wide_cols_pay(long long n_cols) { return ((n_cols + 127) / 128) * 128 * 4 <= ((n_cols + 63) / 64) * 64 * 5; }
+
 // gZ = gY * act'(Y); gb[j] += sum over rows (one partial per workgroup, atomics)
 __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ Y, long long n, int N, int act,
                                                       float p, float* __restrict__ gZ, float* __restrict__ gb, const long long* __restrict__ n_dev) {
@@ -213,27 +461,39 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ 
     if (gb) atomicAdd(gb + j, s);
   }
 }
-// N < 64 columns: one thread per element; the bias gradient is reduced over the wave before the atomic (one atomic per wave and
-// column instead of one per element: with N = 1 .. 3 every element of the matrix hit the same few words)
+// N < 64 columns: a workgroup owns 4 096 consecutive elements; the bias gradient is summed in LDS and leaves the workgroup as ONE
+// atomic per column (one atomic per WAVE and column -- 33 k atomics on three words for 236 k x 3 -- cost 0.4 ms: a single word
+// sustains ~88 M atomics/s)
 __global__ void __launch_bounds__(256) act_bwd_small_kernel(const float* __restrict__ gY, const float* __restrict__ Y, long long total, int N,
                                                             int act, float p, float* __restrict__ gZ, float* __restrict__ gb,
                                                             const long long* __restrict__ n_dev) {
   if (n_dev) total = min(total, max(0LL, *n_dev) * N);
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if ((e & ~63LL) >= total) return;             // the whole wave is past the valid elements: nothing to store, nothing to reduce
-  float g = 0.f;
-  if (e < total) {
-    g = gY[e] * act_bwd_from_y(Y[e], act, p);
-    gZ[e] = g;
-  }
-  if (!gb) return;
-  const int col = (int)(e % N);                 // lanes of a wave cycle through the N columns
-  for (int c = 0; c < N; ++c) {
-    float s = (col == c && e < total) ? g : 0.f;
+  __shared__ float sgb[64];
+  const long long e0 = (long long)blockIdx.x * 4096;
+  if (e0 >= total) return;                      // workgroup-uniform
+  if (threadIdx.x < 64) sgb[threadIdx.x] = 0.f;
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const long long e = e0 + it * 256 + threadIdx.x;
+    if ((e & ~63LL) >= total) break;              // the whole wave is past the valid elements
+    float g = 0.f;
+    if (e < total) {
+      g = gY[e] * act_bwd_from_y(Y[e], act, p);
+      gZ[e] = g;
+    }
+    if (gb) {
+      const int col = (int)(e % N);               // lanes of a wave cycle through the N columns: a shuffle tree per column, then LDS
+      for (int c = 0; c < N; ++c) {
+        float sc = (col == c && e < total) ? g : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(gb + c, s);
+        for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o);
+        if ((threadIdx.x & 63) == 0 && sc != 0.f) atomicAdd(&sgb[c], sc);
+      }
+    }
   }
+  __syncthreads();
+  if (gb && threadIdx.x < N) atomicAdd(gb + threadIdx.x, sgb[threadIdx.x]);
 }
 }  // namespace
 
@@ -245,6 +505,21 @@ extern "C" int tf_linear_fwd(const float* X, const float* W, const float* b, int
   const bool h3 = precision == TF_PREC_F16X3;
   if (n == 0) return TF_OK;
   TF_REQUIRE(X && W && Y, TF_EINVAL, "tf_linear_fwd: null pointer");
+  if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W)) {
+    const unsigned blocks = (unsigned)min((long long)tf_blocks(n, 4), 8192LL);
+    const long long* nd = (const long long*)n_dev;
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 1) thin_fwd_kernel<1><<<blocks, 256, 0, st>>>(X, W, b, n, K, act, act_param, Y, nd);
+    else if (N == 2) thin_fwd_kernel<2><<<blocks, 256, 0, st>>>(X, W, b, n, K, act, act_param, Y, nd);
+    else if (N == 3) thin_fwd_kernel<3><<<blocks, 256, 0, st>>>(X, W, b, n, K, act, act_param, Y, nd);
+    else thin_fwd_kernel<4><<<blocks, 256, 0, st>>>(X, W, b, n, K, act, act_param, Y, nd);
+    TF_LAUNCH_CHECK("tf_linear_fwd(thin)");
+    return TF_OK;
+  }
+  if (!h3 && TF_GEMM2 && K % 4 == 0 && N >= 32 && wide_cols_pay(N) && aligned16(X) && aligned16(W)) {
+    Gemm2Args G2{X, K, W, K, Y, N, b, n, N, K, K, act, act_param, 0, (const long long*)n_dev, 1};
+    return launch2<true, true>(G2, 1, (hipStream_t)stream, "tf_linear_fwd");
+  }
   GemmArgs G{X, K, 1, W, 1, K, Y, N, b, n, N, K, K, act, act_param, 0, (const long long*)n_dev, 1};
   return launch<true, false>(G, 1, h3, (hipStream_t)stream, "tf_linear_fwd");
 }
@@ -262,18 +537,44 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   if (gb) { hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd: memset failed"); }
   if (n == 0) return TF_OK;
   if (N >= 64) act_bwd_kernel<<<tf_blocks(n, 256), 256, 0, stream>>>(gY, Y, n, N, act, act_param, gZ, gb, (const long long*)n_dev);
-  else act_bwd_small_kernel<<<tf_blocks(n * N, 256), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
+  else act_bwd_small_kernel<<<tf_blocks(n * N, 4096), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
+  if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
+    const long long* nd = (const long long*)n_dev;
+#define TF_THIN(NO)                                                                                                                  \
+    do {                                                                                                                              \
+      if (gX) thin_data_kernel<NO><<<tf_blocks(n * (K / 4), 256), 256, 0, stream>>>(gZ, W, n, K, gX, nd);                             \
+      if (gW) thin_weight_kernel<NO><<<tf_blocks(n, 1024), 256, 0, stream>>>(gZ, X, n, K, gW, nd);                                     \
+    } while (0)
+    if (N == 1) TF_THIN(1); else if (N == 2) TF_THIN(2); else if (N == 3) TF_THIN(3); else TF_THIN(4);
+#undef TF_THIN
+    TF_LAUNCH_CHECK("tf_linear_bwd(thin)");
+    return TF_OK;
+  }
+  const bool g2 = !h3 && TF_GEMM2 && K % 4 == 0 && N % 4 == 0 && N >= 32 && K >= 32 && wide_cols_pay(N) && wide_cols_pay(K) &&
+                  aligned16(X) && aligned16(W) && aligned16(gZ);
   if (gX) {   // gX [n,K] = gZ [n,N] . W [N,K]
-    GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
-    const int rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
+    int rc;
+    if (g2) {
+      Gemm2Args G2{gZ, N, W, K, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
+      rc = launch2<true, false>(G2, 1, stream, "tf_linear_bwd(data)");
+    } else {
+      GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
+      rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
+    }
     if (rc != TF_OK) return rc;
   }
   if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
-    const long long split = 1024;     // rows per workgroup: enough workgroups to fill the chip at n ~ 2e5; each adds a [128 x 64] tile atomically
+    const long long split = 1024;     // rows per workgroup: enough workgroups to fill the chip at n ~ 2e5; each adds its tile atomically
     const int splits = (int)((n + split - 1) / split);
-    GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
-    const int rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
+    int rc;
+    if (g2) {
+      Gemm2Args G2{gZ, N, X, K, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
+      rc = launch2<false, false>(G2, splits, stream, "tf_linear_bwd(weight)");
+    } else {
+      GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
+      rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
+    }
     if (rc != TF_OK) return rc;
   }
   return TF_OK;

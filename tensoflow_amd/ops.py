@@ -842,13 +842,13 @@ def shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt,
     return g_alb, g_met, g_rough
 
 
-def inner_light_encode(pos, dirs, nrm, idx=None, count=None):
-    """-> X [capacity,123] (rows >= *count are undefined)."""
+def inner_light_encode(pos, dirs, nrm, idx=None, count=None, ld=123):
+    """-> X [capacity,ld] (rows >= *count are undefined; columns >= 123 zero)."""
     lib = L.load()
     cap = pos.shape[0] if idx is None else idx.numel()
-    X = torch.empty(cap, 123, dtype=torch.float32, device=pos.device)
+    X = torch.empty(cap, ld, dtype=torch.float32, device=pos.device)
     ws = _workspace("inner", lib.tf_inner_light_workspace_floats(), pos.device)
-    L.check(lib.tf_inner_light_encode(_p(_f(pos)), _p(_f(dirs)), _p(_f(nrm)), _p(idx, torch.int64), _p(count, torch.int64), cap, _p(X),
+    L.check(lib.tf_inner_light_encode(_p(_f(pos)), _p(_f(dirs)), _p(_f(nrm)), _p(idx, torch.int64), _p(count, torch.int64), cap, _p(X), int(ld),
                                       _p(ws), ws.numel(), _stream()), "tf_inner_light_encode")
     return X
 

@@ -22,7 +22,11 @@ def linear_precision(request):
     ops.LINEAR_PRECISION = keep
 
 
-@pytest.mark.parametrize("n,K,N", [(1, 3, 1), (777, 111, 256), (4096, 256, 129), (2048, 108, 128), (300, 128, 3), (5000, 123, 256), (130, 256, 256)])
+# shapes of every kernel family behind tf_linear_*: the register-staged tiles (odd strides: 111, 123, 129 columns), the LDS-DMA pipeline
+# (strides that are multiples of four: ragged row counts, a ragged reduction of 108, two column blocks), the streaming kernels of layers
+# with <= 4 outputs
+@pytest.mark.parametrize("n,K,N", [(1, 3, 1), (777, 111, 256), (4096, 256, 129), (2048, 108, 128), (300, 128, 3), (5000, 123, 256), (130, 256, 256),
+                                   (3333, 256, 256), (5000, 128, 128), (1029, 72, 256), (5000, 256, 3), (2048, 108, 1), (999, 128, 4), (1500, 64, 2)])
 def test_linear_fwd_bwd_matches_torch(n, K, N, linear_precision):
     from tensoflow_amd import ops
     from tensoflow_amd.autograd import LinearActFn
@@ -42,6 +46,8 @@ def test_linear_fwd_bwd_matches_torch(n, K, N, linear_precision):
         ref = (yr.detach(), x.grad, w.grad, b.grad)
         for name, a, r in zip(("y", "gx", "gw", "gb"), got, ref):
             scale = float(r.abs().max()) + 1e-12
+            if name == "gb":      # a column sum of n signed terms can cancel to almost nothing (N = 1: there is no other column to set the scale)
+                scale = max(scale, 1e-3 * float(gy.abs().sum(0).max()))
             assert float((a.double() - r.double()).abs().max()) / scale < 2e-5, (act, name, n, K, N)
 
 
@@ -62,6 +68,29 @@ def test_linear_device_side_row_count(linear_precision):
     gz = gy[:nv] * (yfull[:nv] > 0)
     assert torch.allclose(gw, gz.t() @ x[:nv], atol=2e-3, rtol=1e-4) and torch.allclose(gb, gz.sum(0), atol=1e-3)
     assert torch.allclose(gx[:nv], gz @ w, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,N", [(256, 256), (256, 3), (128, 128)])
+def test_linear_device_side_row_count_aligned_kernels(K, N):
+    """The same contract on the LDS-DMA pipeline and on the streaming kernels (exact fp32)."""
+    from tensoflow_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    n, nv = 3000, 1437
+    x, w, b = torch.randn(n, K, device=dev), torch.randn(N, K, device=dev) / K ** 0.5, torch.randn(N, device=dev)
+    cnt = torch.tensor([nv], dtype=torch.int64, device=dev)
+    y = torch.full((n, N), 7.0, device=dev)
+    y = ops.linear_fwd(x, w, b, ops.ACT_RELU, n_dev=cnt)
+    assert torch.allclose(y[:nv], torch.relu(F.linear(x[:nv], w, b)), atol=1e-4)
+    gy = torch.randn(n, N, device=dev)
+    yfull = torch.relu(F.linear(x, w, b))
+    gx, gw, gb = ops.linear_bwd(x, w, yfull, gy, ops.ACT_RELU, n_dev=cnt)
+    gz = gy[:nv] * (yfull[:nv] > 0)
+    assert torch.allclose(gw, gz.t() @ x[:nv], atol=2e-3, rtol=1e-4) and torch.allclose(gb, gz.sum(0), atol=1e-3)
+    assert torch.allclose(gx[:nv], gz @ w, atol=1e-4)
+    zero = torch.zeros(1, dtype=torch.int64, device=dev)
+    _, gw0, gb0 = ops.linear_bwd(x, w, yfull, gy, ops.ACT_RELU, n_dev=zero)
+    assert float(gw0.abs().max()) == 0.0 and float(gb0.abs().max()) == 0.0
 
 
 def test_mlp_apply_walks_weight_normed_sequentials():
