@@ -257,7 +257,8 @@ def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, i
     P = (pts[None] + offs[:, None]).reshape(-1, 3).contiguous()
     lv = None if level is None else level.reshape(-1).repeat(7).contiguous()
     feat = VmGatherFn.apply(P, lv, aabb, n_levels, *planes, *lines)
-    h = LinearActFn.apply(torch.cat([feat, P], -1), W1, b1, ops.ACT_SOFTPLUS, 100.0)
+    # 108 + 3 inputs, one zero column (and a zero weight column) added: rows of 112 floats are aligned for the dense layers' DMA kernels
+    h = LinearActFn.apply(torch.cat([feat, P, torch.zeros_like(P[:, :1])], -1), F.pad(W1, (0, 1)), b1, ops.ACT_SOFTPLUS, 100.0)
     s = LinearActFn.apply(h, W2[:1].contiguous(), b2[:1].contiguous(), ops.ACT_NONE, 0.0)[:, 0].view(7, N)
     app = LinearActFn.apply(h[:N].contiguous(), W2[1:].contiguous(), b2[1:].contiguous(), ops.ACT_NONE, 0.0)
     sdf = s[0]
