@@ -446,10 +446,12 @@ inline bool wide_cols_pay(long long n_cols) { return ((n_cols + 127) / 128) * 12
 
 // gZ = gY * act'(Y); gb[j] += sum over rows (one partial per workgroup, atomics)
 __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ gY, const float* __restrict__ Y, long long n, int N, int act,
-                                                      float p, float* __restrict__ gZ, float* __restrict__ gb, const long long* __restrict__ n_dev) {
+                                                      float p, float* __restrict__ gZ, float* __restrict__ gb, const long long* __restrict__ n_dev,
+                                                      int slab) {
   if (n_dev) n = min(n, max(0LL, *n_dev));
-  // thread = column j (strided), workgroup = a slab of 256 rows
-  const long long r0 = (long long)blockIdx.x * 256, r1 = min(r0 + 256, n);
+  // thread = column j (strided), workgroup = a slab of `slab` rows (256 for long matrices; a 2 048-row layer cut into 256-row slabs
+  // was 8 workgroups walking 256 dependent rows each: 64 us for 2 MB)
+  const long long r0 = (long long)blockIdx.x * slab, r1 = min(r0 + slab, n);
   if (r0 >= n) return;      // launched for a capacity: a slab past the device-side row count adds nothing (and used to add 256 atomic zeros)
   for (int j = threadIdx.x; j < N; j += 256) {
     float s = 0.f;
@@ -536,7 +538,11 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   if (gW) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd: memset failed"); }
   if (gb) { hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd: memset failed"); }
   if (n == 0) return TF_OK;
-  if (N >= 64) act_bwd_kernel<<<tf_blocks(n, 256), 256, 0, stream>>>(gY, Y, n, N, act, act_param, gZ, gb, (const long long*)n_dev);
+  if (N >= 64) {
+    int slab = 256;
+    while (slab > 8 && n / slab < 1024) slab >>= 1;       // >= 1 024 workgroups where the matrix has the rows for it
+    act_bwd_kernel<<<tf_blocks(n, slab), 256, 0, stream>>>(gY, Y, n, N, act, act_param, gZ, gb, (const long long*)n_dev, slab);
+  }
   else act_bwd_small_kernel<<<tf_blocks(n * N, 4096), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
   if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
