@@ -206,8 +206,8 @@ int launch(const GemmArgs& G, int splits, bool h3, hipStream_t stream, const cha
 // software pipeline that keeps the matrix cores fed.  What held the kernel above at 44 TF/s of 157 (measured, 236 k x 256 x 256): its
 // tile loads pass through registers one 16-deep chunk ahead, i.e. 1 024 cycles of MFMAs per wave stand against an HBM / L2 round trip of
 // 2-4 k cycles, and its 88-126 registers leave 3 waves per SIMD to cover the difference.  Here:
-//   * tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), THREE stages deep: the loads of
-//     chunk c + 2 are issued before the MFMAs of chunk c, one s_barrier per chunk;
+//   * tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), double buffered: the loads of
+//     chunk c + 1 are issued before the MFMAs of chunk c, one s_barrier per chunk, four workgroups resident per CU;
 //   * a workgroup owns 128 x 128 of C, a wave 64 x 64 (2 x 2 MFMA tiles): every operand fragment read from LDS feeds two MFMAs, 32 MFMAs
 //     (2 048 cycles) per wave and chunk;
 //   * operand images in LDS follow the operand's contiguous index.  "Reduction-fast" (X [m][k], W [n][k], gZ [m][n] as the A operand
@@ -218,7 +218,13 @@ int launch(const GemmArgs& G, int splits, bool h3, hipStream_t stream, const cha
 //     [16 reduction rows][128 outputs], conflict-free `ds_read_b32`, the same element -> MFMA pairing.
 //   * out-of-range quads (reduction tail, rows past a device-side count) are fetched from a 16-byte zero word instead of being
 //     predicated: every lane always issues its DMA, the vmcnt arithmetic stays uniform.
-constexpr int G2_NST = 3;
+#ifndef TF_G2_NST
+#define TF_G2_NST 2     // LDS stages.  Measured (236 k x 256 x 256 forward / 128 x 128): 2 stages 78.9 / 68.8 TF/s, 3 stages 75.4 / 57.9,
+                        // 4 stages 63.9 / 47.0 (two waves per SIMD) -- more resident workgroups beat a deeper prefetch; reading the next
+                        // chunk's fragments under the current chunk's MFMAs (a second register set) changed nothing (73-75): a workgroup's
+                        // life is 16 chunks, what is left is its prologue round trip and its epilogue's scattered stores
+#endif
+constexpr int G2_NST = TF_G2_NST;
 __device__ __attribute__((aligned(16))) float g2_zero[4];
 
 struct Gemm2Args {
@@ -232,7 +238,7 @@ struct Gemm2Args {
 };
 
 template <bool A_RF, bool B_RF>
-__global__ void __launch_bounds__(256, 3) gemm2_kernel(Gemm2Args G) {
+__global__ void __launch_bounds__(256, 4) gemm2_kernel(Gemm2Args G) {
   __shared__ __attribute__((aligned(16))) float lds[G2_NST][2][128 * 16];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -278,15 +284,19 @@ __global__ void __launch_bounds__(256, 3) gemm2_kernel(Gemm2Args G) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  issue(0, 0);
-  if (nchunk > 1) issue(1, 1);
+#pragma unroll
+  for (int p = 0; p < G2_NST - 1; ++p)
+    if (p < nchunk) issue(p, p);
   for (int c = 0; c < nchunk; ++c) {
     const int st = c % G2_NST;
-    if (c + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // chunk c has landed (chunk c + 1 may still be in flight)
+    // chunk c has landed (the G2_NST - 2 chunks behind it may still be in flight: four DMAs per wave and chunk)
+    const int behind = min(nchunk - 1 - c, G2_NST - 2);
+    if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                // ... for every wave; and every wave is done reading chunk c - 1
     asm volatile("" ::: "memory");
-    if (c + 2 < nchunk) issue(c + 2, (c + 2) % G2_NST);
+    if (c + G2_NST - 1 < nchunk) issue(c + G2_NST - 1, (c + G2_NST - 1) % G2_NST);
     float fa[2][8], fb[2][8];
 #pragma unroll
     for (int op = 0; op < 2; ++op) {

@@ -5,7 +5,12 @@ import time
 
 import torch
 
+import os
+
 sys.path.insert(0, ".")
+from tensoflow_amd import lib as L  # noqa: E402
+if os.environ.get("TF_LIB"):          # dev: an alternative build (tools/build_variant.sh)
+    L.LIB_PATH = os.path.abspath(os.environ["TF_LIB"])
 from tensoflow_amd import ops  # noqa: E402
 
 
