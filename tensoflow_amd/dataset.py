@@ -9,7 +9,9 @@
                                 `_diffColor.exr` -> rgb x alpha through hdr_io.read_exr (:530-535; cv2 in the reference).
 * `ORBDatabase`              -- dataset/database.py:723-802 (Stanford-ORB in the Blender layout): one split ('train' or 'test'), RGB(A)
                                 PNGs with the object mask in a SEPARATE file (`<split>_mask/...png`), no pose rescaling.
-* `parse_database_name`      -- :804-823 for the database types this build reads ('tensoSDF/<model>', 'orb/<model>').
+* `TensoIRDatabase`          -- dataset/database.py:376-477 (TensoIR synthetic: the lego / armadillo / horse configs): a directory per frame
+                                with `metadata.json` + `rgba_<light>_<rotation>.png`; `NeRFSynDatabase` -- :288-374 (Blender layout, no rescaling).
+* `parse_database_name`      -- :804-823 for the database types this build reads ('tensoSDF/', 'tensoIR/', 'nerf/', 'orb/<model>').
 * `construct_ray_batch_nerf` -- shapeRenderer.py:471-518: pinhole rays through pixel centres in the OpenGL camera frame, cone radii
                                 from neighbouring-ray distances, `rays_cos = 1 / |rays_d|`, colours, masks, per-ray pose rows.
 * `RayTable`                 -- `_shuffle_train_batch` / `train_step`'s slicing (:411-415, :778-782) with the data-parallel split of
@@ -124,18 +126,71 @@ class ORBDatabase(TensoSDFSynDatabase):
         self.img_ids = list(range(len(self.imgs_all)))
 
 
+class NeRFSynDatabase(TensoSDFSynDatabase):
+    """NeRF-synthetic (Blender) scenes (dataset/database.py:288-374): splits train + test (test alone when is_test), RGBA PNGs, the test
+    split's `_normal.png` on request, poses used as they are (scale_factor 1)."""
+
+    def __init__(self, root, is_test=False, white_bg=True):
+        super().__init__(root, splits=("test",) if is_test else ("train", "test"), white_bg=white_bg, load_normals=is_test)
+        self.scale_factor = 1.0
+
+
+class TensoIRDatabase(TensoSDFSynDatabase):
+    """TensoIR synthetic scenes (dataset/database.py:376-477; configs/{shape,mat}/syn/{lego,armadillo,...}.yaml): one DIRECTORY per frame
+    (`train_000`, `val_012`, `test_003` ...) holding `metadata.json` (`cam_transform_mat`: 16 comma-separated numbers, `cam_angle_x`,
+    `imh`, `imw`), `rgba_<light>_<rotation>.png` and -- test split -- `normal.png`, `albedo.png` (both RGBA: value x alpha; the normal
+    over a (0,0,1) background).  Frames sorted by directory name; translation halved (scale_factor 0.5)."""
+
+    def __init__(self, root, is_test=False, white_bg=True, light_name="sunset", light_rotation="000"):
+        from PIL import Image
+        self.root = root
+        self.imgs_all, self.masks_all, self.pose_all, self.normals_all, self.diffColor_all = [], [], [], [], []
+        meta = None
+        for s in (("test",) if is_test else ("train", "val")):
+            for item in sorted(d for d in os.listdir(root) if d.startswith(s) and os.path.isdir(os.path.join(root, d))):
+                with open(os.path.join(root, item, "metadata.json")) as fp:
+                    meta = json.load(fp)
+                im = Image.open(os.path.join(root, item, f"rgba_{light_name}_{light_rotation}.png"))
+                if im.mode != "RGBA":
+                    raise ValueError(f"{item}/rgba_{light_name}_{light_rotation}.png: RGBA expected, got {im.mode}")
+                img = np.asarray(im).astype(np.float32) / 255.0
+                mask = img[..., -1:]
+                rgb = img[..., :3] * mask + (1 - mask) if white_bg else img[..., :3] * mask
+                self.imgs_all.append((rgb * 255.0).astype(np.uint8))
+                self.masks_all.append(mask)
+                self.pose_all.append(np.array([float(v) for v in meta["cam_transform_mat"].split(",")], dtype=np.float64).reshape(4, 4))
+                if is_test:
+                    nim = np.asarray(Image.open(os.path.join(root, item, "normal.png")))
+                    na = nim[..., [-1]] / 255
+                    self.normals_all.append((nim[..., :3] / 255 - 0.5) * 2.0 * na + (1 - na) * np.array([0, 0, 1]))
+                    aim = np.asarray(Image.open(os.path.join(root, item, "albedo.png")))
+                    self.diffColor_all.append(aim[..., :3] / 255 * (aim[..., [-1]] / 255))
+        if not self.imgs_all:
+            raise ValueError(f"{root}: no frame directories for the requested splits")
+        self.H, self.W = float(meta["imh"]), float(meta["imw"])                 # (floats, as the reference keeps them)
+        self.focal = 0.5 * self.W / np.tan(0.5 * float(meta["cam_angle_x"]))
+        self.K = np.array([[self.focal, 0, 0.5 * self.W], [0, self.focal, 0.5 * self.H], [0, 0, 1]], dtype=np.float32)
+        self.scale_factor = 0.5
+        self.img_ids = list(range(len(self.imgs_all)))
+
+
 def parse_database_name(database_name, dataset_dir, is_test=False, white_bg=False):
     """dataset/database.py:804-823 for the layouts read here: '<type>/<model>' under `dataset_dir`."""
     if dataset_dir in (None, "None"):
         raise AssertionError("change your own dataset dir!")
     kind, model = database_name.split("/")
     root = os.path.join(dataset_dir, model)
+    if kind == "tensoIR":
+        return TensoIRDatabase(root, is_test=is_test, white_bg=white_bg)
+    if kind == "nerf":
+        return NeRFSynDatabase(root, is_test=is_test, white_bg=white_bg)
     if kind == "tensoSDF":
         return TensoSDFSynDatabase(root, splits=("test",) if is_test else ("train", "val"), white_bg=white_bg,
                                    load_normals=is_test, load_diff_color=is_test)
     if kind == "orb":
         return ORBDatabase(root, is_test=is_test, white_bg=white_bg)
-    raise NotImplementedError(f"database type '{kind}' (this build reads tensoSDF/* and orb/*)")
+    raise NotImplementedError(f"database type '{kind}' (this build reads tensoSDF/*, tensoIR/*, nerf/* and orb/*; the Glossy and "
+                              f"custom-COLMAP layouts are not read)")
 
 
 def construct_ray_batch_nerf(imgs_info, device="cpu", is_train=True):

@@ -77,6 +77,56 @@ def test_database_and_ray_table(tmp_path):
     assert seen.shape[0] == 191
 
 
+def test_tensoir_and_nerf_synthetic_layouts(tmp_path):
+    """TensoIR (a directory per frame: the lego / armadillo / horse configs) and NeRF-synthetic (Blender) layouts,
+    dataset/database.py:288-477, through parse_database_name."""
+    from PIL import Image
+    from tensoflow_amd.dataset import NeRFSynDatabase, TensoIRDatabase, construct_ray_batch_nerf, parse_database_name
+    rng = np.random.default_rng(5)
+    root = tmp_path / "data" / "lego"
+    poses = {}
+    for split, n in (("train", 3), ("val", 2), ("test", 2)):
+        for k in reversed(range(n)):                                  # written out of order: the reader sorts by directory name
+            d = root / f"{split}_{k:03d}"
+            os.makedirs(d)
+            T = np.eye(4)
+            T[:3, 3] = [0.1 * k, -0.2, 4.0 + k]
+            poses[(split, k)] = T
+            json.dump({"cam_transform_mat": ",".join(repr(float(v)) for v in T.reshape(-1)), "cam_angle_x": 0.6911, "imh": 5, "imw": 7},
+                      open(d / "metadata.json", "w"))
+            img = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+            img[0, 0, 3] = 0
+            Image.fromarray(img, "RGBA").save(d / "rgba_sunset_000.png")
+            if split == "test":
+                nrm = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+                nrm[0, 0, 3] = 0
+                Image.fromarray(nrm, "RGBA").save(d / "normal.png")
+                Image.fromarray(rng.integers(0, 256, (5, 7, 4), dtype=np.uint8), "RGBA").save(d / "albedo.png")
+                poses[("test_nrm", k)] = nrm
+    db = parse_database_name("tensoIR/lego", str(tmp_path / "data"), is_test=False, white_bg=True)
+    assert isinstance(db, TensoIRDatabase) and len(db.img_ids) == 5 and (db.H, db.W) == (5.0, 7.0) and db.scale_factor == 0.5
+    assert np.allclose(db.pose_all[1], poses[("train", 1)]) and np.allclose(db.pose_all[3], poses[("val", 0)])       # train_000..002, val_000..001
+    assert np.allclose(db.get_pose(2)[:3, 3], 0.5 * poses[("train", 2)][:3, 3]) and (db.get_image(0)[0, 0] == 255).all()
+    assert db.focal == pytest.approx(0.5 * 7 / math.tan(0.5 * 0.6911))
+    batch, rn, h, w = construct_ray_batch_nerf(db.imgs_info())
+    assert rn == 5 * 35 and (h, w) == (5, 7)
+    te = parse_database_name("tensoIR/lego", str(tmp_path / "data"), is_test=True, white_bg=False)
+    assert len(te.img_ids) == 2 and (te.get_image(0)[0, 0] == 0).all()
+    n0 = poses[("test_nrm", 0)]
+    assert np.allclose(te.get_normal(0)[0, 0], [0, 0, 1]) and np.allclose(te.get_normal(0)[2, 3], (n0[2, 3, :3] / 255 - 0.5) * 2 * (n0[2, 3, 3] / 255)
+                                                                          + (1 - n0[2, 3, 3] / 255) * np.array([0, 0, 1]))
+    assert te.get_albedo(1).shape == (5, 7, 3) and float(te.get_albedo(1).max()) <= 1.0
+    # Blender layout: the TensoSDF reader with train + test splits and unscaled poses
+    broot = str(tmp_path / "data" / "chair")
+    raw, frames = _write_scene(broot)
+    json.dump(json.load(open(os.path.join(broot, "transforms_val.json"))), open(os.path.join(broot, "transforms_test.json"), "w"))
+    nb = parse_database_name("nerf/chair", str(tmp_path / "data"), is_test=False, white_bg=True)
+    assert isinstance(nb, NeRFSynDatabase) and len(nb.img_ids) == 4 and nb.scale_factor == 1.0
+    assert np.allclose(nb.get_pose(1)[:3, 3], np.array(frames[1]["transform_matrix"])[:3, 3])
+    with pytest.raises(NotImplementedError, match="custom"):
+        parse_database_name("custom/shoe", str(tmp_path / "data"))
+
+
 def test_database_refuses_rgb_files(tmp_path):
     from PIL import Image
     from tensoflow_amd.dataset import TensoSDFSynDatabase
