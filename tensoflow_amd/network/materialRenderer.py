@@ -35,9 +35,9 @@ class MaterialRenderer(nn.Module):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
         with_data = training or not nvs
-        if with_data and not (self.cfg["nerfDataType"] and str(self.cfg.get("database_name", "")).startswith("tensoSDF/")):
-            raise NotImplementedError("the dataset side of MaterialRenderer (_init_dataset / train_step) reads the TensoSDF synthetic "
-                                      "layout only (database_name 'tensoSDF/<scene>', nerfDataType=True): for anything else "
+        if with_data and not (self.cfg["nerfDataType"] and str(self.cfg.get("database_name", "")).split("/")[0] in ("tensoSDF", "tensoIR", "nerf", "orb")):
+            raise NotImplementedError("the dataset side of MaterialRenderer (_init_dataset / train_step) reads the Blender-convention "
+                                      "layouts (database_name 'tensoSDF/', 'tensoIR/', 'nerf/' or 'orb/<scene>', nerfDataType=True): for anything else "
                                       "construct with training=False, nvs=True and pass surface points to shade()")
         self.device = self.cfg["device"]
         self._init_geometry()
@@ -60,9 +60,8 @@ class MaterialRenderer(nn.Module):
         """materialRenderer.py:345-382 + filtering_train_rays (:384-417): database, split, per-pixel ray table, every training ray
         traced against the mesh and refined on the SDF on the device (chunks of 512^2 rays, no CPU round trip per chunk); rays that
         miss are dropped; the table of surface points is shuffled.  cfg['rank'] / cfg['world']: this process's stride of a batch."""
-        from ..dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf_material
-        scene = self.cfg["database_name"].split("/")[1]
-        self.database = TensoSDFSynDatabase(os.path.join(self.cfg["dataset_dir"], scene), white_bg=self.cfg.get("isBGWhite", True))
+        from ..dataset import RayTable, construct_ray_batch_nerf_material, parse_database_name
+        self.database = parse_database_name(self.cfg["database_name"], self.cfg["dataset_dir"], white_bg=self.cfg.get("isBGWhite", True))
         ids = self.database.get_img_ids()
         if self.cfg.get("split_manul", False):
             border = self.cfg.get("split_borderline", 100)

@@ -60,9 +60,9 @@ class ShapeRenderer(nn.Module):
     def __init__(self, cfg, training=True):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        if training and not (self.cfg["nerfDataType"] and str(self.cfg.get("database_name", "")).startswith("tensoSDF/")):
-            raise NotImplementedError("the dataset side of ShapeRenderer (_init_dataset / train_step) reads the TensoSDF synthetic "
-                                      "layout only (database_name 'tensoSDF/<scene>', nerfDataType=True): for anything else "
+        if training and not (self.cfg["nerfDataType"] and str(self.cfg.get("database_name", "")).split("/")[0] in ("tensoSDF", "tensoIR", "nerf", "orb")):
+            raise NotImplementedError("the dataset side of ShapeRenderer (_init_dataset / train_step) reads the Blender-convention "
+                                      "layouts (database_name 'tensoSDF/', 'tensoIR/', 'nerf/' or 'orb/<scene>', nerfDataType=True): for anything else "
                                       "construct with training=False and pass ray batches to render()")
         if self.cfg["predict_BG"]:
             raise NotImplementedError("predict_BG (NeRF++ background) raises in the reference's render_core as well (:1109); "
@@ -402,9 +402,8 @@ class ShapeRenderer(nn.Module):
         """shapeRenderer.py:383-409: database, manual split (first 100 images train, the rest thinned for validation,
         dataset/database.py:824-833), CPU-resident ray table of every training pixel, shuffled.  cfg['rank'] / cfg['world'] select
         this process's stride of each batch."""
-        from ..dataset import RayTable, TensoSDFSynDatabase, construct_ray_batch_nerf
-        scene = self.cfg["database_name"].split("/")[1]
-        self.database = TensoSDFSynDatabase(os.path.join(self.cfg["dataset_dir"], scene), white_bg=self.cfg["isBGWhite"])
+        from ..dataset import RayTable, construct_ray_batch_nerf, parse_database_name
+        self.database = parse_database_name(self.cfg["database_name"], self.cfg["dataset_dir"], white_bg=self.cfg["isBGWhite"])
         ids = self.database.get_img_ids()
         if self.cfg.get("split_manul", False):
             border = self.cfg.get("split_borderline", 100)

@@ -149,7 +149,7 @@ class ShadeOutputs(dict):
             raise KeyError(key)
         smask = self["specular_mask"]
         pn, ss = smask.shape
-        rid = torch.arange(pn, device=smask.device)[:, None].expand(pn, ss)[smask]
+        rid = torch.arange(pn, device=smask.device)[:, None].expand(pn, ss)[smask.bool()]      # (the kernel writes the mask as bytes)
         self[key] = rid
         return rid
 

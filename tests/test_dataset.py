@@ -166,7 +166,21 @@ def test_shape_renderer_dataset_side(tmp_path):
     # gt of the downsampled image = 2x2 box average of the file's composited pixels
     want = torch.from_numpy(r.database.get_image(r.test_ids[0]).astype(np.float32) / 255).reshape(8, 2, 8, 2, 3).mean((1, 3))
     assert torch.allclose(ev["gt_rgb"].cpu(), want, atol=1e-6)
+    # the other Blender-convention layouts go through the same door (configs/shape/syn/lego.yaml: tensoIR/lego, split_manul)
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    for k in range(4):
+        d = tmp_path / "data" / "lego" / f"train_{k:03d}"
+        os.makedirs(d)
+        T = np.eye(4)
+        T[:3, 3] = [0.0, 0.0, 4.0]
+        json.dump({"cam_transform_mat": ",".join(repr(float(v)) for v in T.reshape(-1)), "cam_angle_x": 0.6911, "imh": 16, "imw": 16}, open(d / "metadata.json", "w"))
+        Image.fromarray(rng.integers(0, 256, (16, 16, 4), dtype=np.uint8), "RGBA").save(d / "rgba_sunset_000.png")
+    r2 = ShapeRenderer({**cfg, "database_name": "tensoIR/lego", "split_manul": True, "split_borderline": 3}, training=True).cuda()
+    assert r2.train_num == 3 and r2.test_num == 1
+    r2.train()
+    assert torch.isfinite(r2({"step": 3})["loss_rgb"]).all()
     with pytest.raises(NotImplementedError):
-        ShapeRenderer({**cfg, "database_name": "nerf_synthetic/lego"}, training=True)
+        ShapeRenderer({**cfg, "database_name": "custom/shoe"}, training=True)
     with pytest.raises(NotImplementedError):
         ShapeRenderer(cfg, training=False)({"step": 0})
