@@ -187,7 +187,9 @@ __device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32],
 #pragma clang fp contract(fast)
 
 // forward net keeping the hidden activations; P-row + sample embed -> wv[32]
-__device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, const float* __restrict__ Prow, const float (&in8)[8],
+// `net`: the biases in LDS; `netg`: the fragment image in global memory, from which every layer's weights are streamed (their room in
+// the LDS image holds the workgroup's weight-gradient accumulators instead).
+__device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, const float* __restrict__ netg, const float* __restrict__ Prow, const float (&in8)[8],
                                              int lane, f32x16 (&in1)[1], f32x16 (&h1)[2], f32x16 (&h2)[2], f32x16 (&h3)[2],
                                              float (&wv)[32]) {
   const int h = lane >> 5;
@@ -199,17 +201,17 @@ __device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, cons
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) h1[t][j] = Prow[32 * t + tf_rho(j, h)];
-  tf_layer<4, 2, 1>(net + kL1 + lane, in1, h1);
+  tf_layer<4, 2, 1>(netg + kL1 + lane, in1, h1);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) { h1[t][j] = leaky(h1[t][j]); h2[t][j] = net[kB2 + (t * 16 + j) * 2 + h]; }
-  tf_layer<32, 2, 2>(net + kL2 + lane, h1, h2);
+  tf_layer_sb<32, 2, 2, 16>(netg + kL2 + lane, h1, h2);
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) { h2[t][j] = leaky(h2[t][j]); h3[t][j] = net[kB3 + (t * 16 + j) * 2 + h]; }
-  tf_layer<32, 2, 2>(net + kL3 + lane, h2, h3);
+  tf_layer_sb<32, 2, 2, 16>(netg + kL3 + lane, h2, h3);
   f32x16 o[1];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -217,7 +219,7 @@ __device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, cons
     for (int j = 0; j < 16; ++j) h3[t][j] = leaky(h3[t][j]);
 #pragma unroll
   for (int j = 0; j < 16; ++j) o[0][j] = net[kB4 + j * 2 + h];
-  tf_layer<32, 1, 2>(net + kL4 + lane, h3, o);
+  tf_layer_sb<32, 1, 2, 16>(netg + kL4 + lane, h3, o);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const float mine = o[0][j], other = __shfl_xor(mine, 32);
@@ -238,7 +240,9 @@ __device__ __forceinline__ void tile_to_lds(const f32x16 (&x)[TT], float* __rest
 }
 
 // g_W[out, col0 + in] += delta * hin^T over the 32 rows of the tile; tiles come from the LDS transposes.
-template <int TO, int TI>
+// ACC_LDS: gW is the workgroup's accumulator block in LDS (the two 64 x 64 layers: ds_add_f32, flushed once per workgroup);
+// otherwise the workgroup's slice in global memory (float atomics at the L2).
+template <int TO, int TI, bool ACC_LDS = false>
 __device__ __forceinline__ void accum_dw(const float* __restrict__ ld_, const float* __restrict__ lh_, float* __restrict__ gW, int ld,
                                          int nout, int nin, int lane) {
   const int i = lane & 31, kh = lane >> 5;
@@ -256,7 +260,16 @@ __device__ __forceinline__ void accum_dw(const float* __restrict__ ld_, const fl
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = 32 * to + tf_rho(j, kh);
-        if (row < nout && col < nin) atomicAdd(gW + (long long)row * ld + col, acc[j]);
+#ifdef FLOW_BWD_ABLATE_DW_ATOMICS   // dev-only timing ablation: the weight-gradient blocks are computed and dropped
+        if (row < nout && col < nin && acc[j] == 123.456f) gW[(long long)row * ld + col] = acc[j];
+#else
+        if (ACC_LDS) {
+          typedef __attribute__((address_space(3))) float* lp_t;
+          if (row < nout && col < nin) __hip_atomic_fetch_add((lp_t)gW + row * ld + col, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (row < nout && col < nin) {
+          atomicAdd(gW + (long long)row * ld + col, acc[j]);
+        }
+#endif
       }
     }
 }
@@ -282,7 +295,7 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
   tile_to_lds<1>(d4, lds_d, lane);
   tile_to_lds<2>(h3, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<1, 2>(lds_d, lds_h, gW[3], 64, 21, 64, lane);
+  accum_dw<1, 2, true>(lds_d, lds_h, gW[3], 64, 21, 64, lane);
   if (lane < 21) atomicAdd(gB[3] + lane, row_sum(lds_d, lane));
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -298,7 +311,7 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
   tile_to_lds<2>(d3, lds_d, lane);
   tile_to_lds<2>(h2, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 2>(lds_d, lds_h, gW[2], 64, 64, 64, lane);
+  accum_dw<2, 2, true>(lds_d, lds_h, gW[2], 64, 64, 64, lane);
   if (lane < 32) { atomicAdd(gB[2] + lane, row_sum(lds_d, lane)); atomicAdd(gB[2] + 32 + lane, row_sum(lds_d, 32 + lane)); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -314,7 +327,7 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
   tile_to_lds<2>(d2, lds_d, lane);
   tile_to_lds<2>(h1, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 2>(lds_d, lds_h, gW[1], 64, 64, 64, lane);
+  accum_dw<2, 2, true>(lds_d, lds_h, gW[1], 64, 64, 64, lane);
   if (lane < 32) { atomicAdd(gB[1] + lane, row_sum(lds_d, lane)); atomicAdd(gB[1] + 32 + lane, row_sum(lds_d, 32 + lane)); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -330,7 +343,7 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
   tile_to_lds<2>(d1, lds_d, lane);
   tile_to_lds<1>(in1, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 1>(lds_d, lds_h, gW[0], 44, 64, 7, lane);
+  accum_dw<2, 1, true>(lds_d, lds_h, gW[0], 8, 64, 7, lane);
   if (uniform_pt) {
     if (lane < 32) { atomicAdd(gP_pt + lane, row_sum(lds_d, lane)); atomicAdd(gP_pt + 32 + lane, row_sum(lds_d, 32 + lane)); }
   } else {
@@ -365,7 +378,15 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
                                                             long long m, int sn, long long pn, const float* __restrict__ g_logq,
                                                             FlowGrads G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  for (int i = threadIdx.x; i < 2 * kNetFloats; i += 256) lds[i] = ws_arg[i];
+  // LDS image: of the forward fragment image only the biases are kept; every layer's weights are streamed from L2, and the room of
+  // layer l's fragments holds this workgroup's accumulator of layer l's weight gradient, row-major: kL1 [64][8] (the 7 sample columns),
+  // kL2 [64][64], kL3 [64][64], kL4 [32][64] (21 rows used).  Adding every tile's blocks to the workgroup's GLOBAL slice with float
+  // atomics cost 0.67 ms of a 2.0 ms call, and not by their bytes: a wave's vector-memory operations retire in order, so every weight
+  // load of the next layer waited behind the 32-64 atomics issued just before it.
+  for (int i = threadIdx.x; i < 2 * kNetFloats; i += 256) {
+    const int r = i % kNetFloats;
+    lds[i] = r < kB2 ? 0.f : ws_arg[i];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* lds_d = lds + 2 * kNetFloats + wave * 2 * kTileLds;
@@ -395,13 +416,13 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
       float wv1[32];
       f32x16 in1a[1], a1[2], a2[2], a3[2];
       embed8(x1, in8a);
-      net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);   // net 1 keeps x1, moves x0
+      net_fwd_keep(net_lds + kNetFloats, ws + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);   // net 1 keeps x1, moves x0
       pw_forward_fb(x0, wv1, z0, lj1);
     }
     asm volatile("" : "+v"(z0));                   // the first evaluation ends here: nothing of it but z0 stays live
     f32x16 in1b[1], b1[2], b2[2], b3[2];
     embed8(z0, in8b);
-    net_fwd_keep(net_lds, P + pt * 64, in8b, lane, in1b, b1, b2, b3, wv0);                        // net 0 keeps z0, moves x1
+    net_fwd_keep(net_lds, ws, P + pt * 64, in8b, lane, in1b, b1, b2, b3, wv0);                    // net 0 keeps z0, moves x1
     float z1, lj0;
     pw_forward_fb(x1, wv0, z1, lj0);
     // ---- reverse
@@ -412,7 +433,7 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);
     float g_in8[8];
     float* const sl0 = G.slices + (size_t)blockIdx.x * kGradFloats;
-    float* const gW0[4] = {sl0 + kGW0, sl0 + kGW1, sl0 + kGW2, sl0 + kGW3};
+    float* const gW0[4] = {lds + kL1, lds + kL2, lds + kL3, lds + kL4};
     float* const gB0[4] = {nullptr, sl0 + kGB1, sl0 + kGB2, sl0 + kGB3};
     net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, gW0, gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
     // d(2*emb(z0) - 1)/dz0
@@ -425,16 +446,28 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     float x1_again = x1;
     asm volatile("" : "+v"(x1_again));             // a value of its own: otherwise the two evaluations are merged and kept live after all
     embed8(x1_again, in8a);
-    net_fwd_keep(net_lds + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);
+    net_fwd_keep(net_lds + kNetFloats, ws + kNetFloats, P + (pn + pt) * 64, in8a, lane, in1a, a1, a2, a3, wv1);
     float g_wv1[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
     pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
     float* const sl1 = sl0 + kGNet;
-    float* const gW1[4] = {sl1 + kGW0, sl1 + kGW1, sl1 + kGW2, sl1 + kGW3};
+    float* const gW1[4] = {lds + kNetFloats + kL1, lds + kNetFloats + kL2, lds + kNetFloats + kL3, lds + kNetFloats + kL4};
     float* const gB1[4] = {nullptr, sl1 + kGB1, sl1 + kGB2, sl1 + kGB3};
     net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, gW1, gB1, G.gP + (pn + pt) * 64, uniform_pt, lane,
             g_in8);
+  }
+  // the accumulators leave the workgroup once (kGW1 | kGW2 are adjacent in the slice, kL2 | kL3 in the image)
+  __syncthreads();
+  float* const sl = G.slices + (size_t)blockIdx.x * kGradFloats;
+#pragma unroll
+  for (int net = 0; net < 2; ++net) {
+    const float* img = lds + net * kNetFloats;
+    float* dst = sl + net * kGNet;
+    for (int i = threadIdx.x; i < 2 * 4096; i += 256) dst[kGW1 + i] = img[kL2 + i];
+    for (int i = threadIdx.x; i < 21 * 64; i += 256) dst[kGW3 + i] = img[kL4 + i];
+    for (int i = threadIdx.x; i < 64 * 8; i += 256)
+      if ((i & 7) < 7) dst[kGW0 + (i >> 3) * 44 + (i & 7)] = img[kL1 + i];
   }
 }
 
