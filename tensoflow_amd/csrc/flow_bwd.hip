@@ -5,9 +5,11 @@
 //   1. forward recompute (fp32 MFMA, weights in LDS) keeping the three hidden activations of each net in registers;
 //   2. closed-form reverse pass through the two piecewise-quadratic splines and the prior term;
 //   3. delta propagation W^T * delta on the MFMA (transposed fragments streamed from L2);
-//   4. weight gradients delta * h^T on the MFMA: both tiles are transposed through a per-wave LDS scratch so that the
-//      32 rows of the tile become the MFMA k dimension; the resulting 32x32 blocks are added to global memory with
-//      float atomics shaped as two 128-byte segments per wave instruction;
+//   4. weight gradients delta * h^T on the MFMA: both tiles are transposed through a per-wave LDS scratch so that the rows of
+//      the tile become the MFMA k dimension; every wave OWNS three of a net's twelve 32x32 gradient blocks, accumulates them over
+//      the four tiles of its workgroup (128 rows per step, two workgroup barriers per layer) in registers across the whole kernel
+//      and stores them once (round 3; per-tile float atomics into the workgroup's slice cost a third of the kernel, LDS float
+//      atomics a fifth: 1.99 -> 1.15 ms per 262 k rows);
 //   5. bias / per-point (hoisted layer-1) gradients reduced over the tile's rows in LDS, one atomic per unit.
 #include "mfma_mlp.h"
 #include "tf_common.h"
@@ -187,12 +189,14 @@ __device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32],
 #pragma clang fp contract(fast)
 
 // forward net keeping the hidden activations; P-row + sample embed -> wv[32]
-// `net`: the biases in LDS; `netg`: the fragment image in global memory, from which every layer's weights are streamed (their room in
-// the LDS image holds the workgroup's weight-gradient accumulators instead).
+// `net`: the fragment image in LDS; `netg`: the same image in global memory (dev switch FLOW_BWD_FWD_STREAM reads the weights from there).
 __device__ __forceinline__ void net_fwd_keep(const float* __restrict__ net, const float* __restrict__ netg, const float* __restrict__ Prow, const float (&in8)[8],
                                              int lane, f32x16 (&in1)[1], f32x16 (&h1)[2], f32x16 (&h2)[2], f32x16 (&h3)[2],
                                              float (&wv)[32]) {
   const int h = lane >> 5;
+#ifndef FLOW_BWD_FWD_STREAM    // dev switch: forward fragments streamed from L2 instead of read from the LDS image (measured: 1.47 vs 1.15 ms)
+  netg = net;
+#endif
 #pragma unroll
   for (int j = 0; j < 16; ++j) in1[0][j] = 0.f;
 #pragma unroll
@@ -239,39 +243,20 @@ __device__ __forceinline__ void tile_to_lds(const f32x16 (&x)[TT], float* __rest
     for (int j = 0; j < 16; ++j) l[(32 * t + tf_rho(j, h)) * 33 + r] = x[t][j];
 }
 
-// g_W[out, col0 + in] += delta * hin^T over the 32 rows of the tile; tiles come from the LDS transposes.
-// ACC_LDS: gW is the workgroup's accumulator block in LDS (the two 64 x 64 layers: ds_add_f32, flushed once per workgroup);
-// otherwise the workgroup's slice in global memory (float atomics at the L2).
-template <int TO, int TI, bool ACC_LDS = false>
-__device__ __forceinline__ void accum_dw(const float* __restrict__ ld_, const float* __restrict__ lh_, float* __restrict__ gW, int ld,
-                                         int nout, int nin, int lane) {
+// One OWNED 32 x 32 block of delta * hin^T over the four tiles of the workgroup (128 rows): the operands come from every wave's LDS
+// transposes, the block stays in this wave's registers across the whole tile loop and is stored once at the end of the kernel.
+// (Per-tile adds of every block -- float atomics into the workgroup's global slice, then ds_add_f32 into LDS accumulators -- cost
+// 0.67 resp. 0.42 ms of a 2.0 ms call: an LDS float atomic retires about one lane per clock.)
+__device__ __forceinline__ void accum_block(const float* __restrict__ scr0 /* wave 0's delta transpose */, int to, int ti, int lane,
+                                            f32x16& acc) {
   const int i = lane & 31, kh = lane >> 5;
 #pragma unroll
-  for (int to = 0; to < TO; ++to)
+  for (int wv = 0; wv < 4; ++wv) {
+    const float* ld_ = scr0 + wv * 2 * kTileLds + (32 * to + i) * 33 + kh;
+    const float* lh_ = scr0 + wv * 2 * kTileLds + kTileLds + (32 * ti + i) * 33 + kh;
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti) {
-      f32x16 acc;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        acc = tf_mfma(ld_[(32 * to + i) * 33 + 2 * s + kh], lh_[(32 * ti + i) * 33 + 2 * s + kh], acc);
-      const int col = 32 * ti + i;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int row = 32 * to + tf_rho(j, kh);
-#ifdef FLOW_BWD_ABLATE_DW_ATOMICS   // dev-only timing ablation: the weight-gradient blocks are computed and dropped
-        if (row < nout && col < nin && acc[j] == 123.456f) gW[(long long)row * ld + col] = acc[j];
-#else
-        if (ACC_LDS) {
-          typedef __attribute__((address_space(3))) float* lp_t;
-          if (row < nout && col < nin) __hip_atomic_fetch_add((lp_t)gW + row * ld + col, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else if (row < nout && col < nin) {
-          atomicAdd(gW + (long long)row * ld + col, acc[j]);
-        }
-#endif
-      }
-    }
+    for (int s = 0; s < 16; ++s) acc = tf_mfma(ld_[2 * s], lh_[2 * s], acc);
+  }
 }
 
 // sum over the tile's 32 rows of an LDS [unit][row] tile: lanes 0..31 take unit 32*t + lane
@@ -285,17 +270,22 @@ __device__ __forceinline__ float row_sum(const float* __restrict__ l, int unit) 
 // backward through one net given delta4 (accumulator layout, 21 valid units); returns g of the 8 sample inputs (in8 order)
 __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f32x16 (&in1)[1], const f32x16 (&h1)[2],
                                         const f32x16 (&h2)[2], const f32x16 (&h3)[2], const float (&g_wv)[32],
-                                        float* __restrict__ lds_d, float* __restrict__ lds_h, float* const (&gW)[4],
+                                        float* __restrict__ lds_d, float* __restrict__ lds_h, const float* __restrict__ scr0, int wave,
+                                        f32x16 (&accW)[3] /* this wave's blocks: dW3 (wave>>1, wave&1) | dW2 (same) | dW4 (0, wave) for wave < 2, dW1 (wave-2, 0) otherwise */,
                                         float* const (&gB)[4], float* __restrict__ gP_pt, bool uniform_pt, int lane, float (&g_in8)[8]) {
   const int h = lane >> 5, i = lane & 31;
   f32x16 d4[1], d3[2], d2[2], d1[2], d0[1];
 #pragma unroll
   for (int j = 0; j < 16; ++j) { const int r0 = (j & 3) + 8 * (j >> 2); d4[0][j] = h ? g_wv[r0 + 4] : g_wv[r0]; }
   // ---- layer 4: dW4 = d4 * h3^T, db4, d3 = (W4^T d4) * lrelu'(h3)
+  // (two workgroup barriers per layer: every wave has read the transposes of the previous layer before they are overwritten; every
+  // wave's transposes are in LDS before any wave accumulates its block over all four tiles)
+  __syncthreads();
   tile_to_lds<1>(d4, lds_d, lane);
   tile_to_lds<2>(h3, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<1, 2, true>(lds_d, lds_h, gW[3], 64, 21, 64, lane);
+  __syncthreads();
+  if (wave < 2) accum_block(scr0, 0, wave, lane, accW[2]);
   if (lane < 21) atomicAdd(gB[3] + lane, row_sum(lds_d, lane));
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -308,10 +298,12 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
     for (int j = 0; j < 16; ++j) d3[t][j] *= dleaky(h3[t][j]);
   // ---- layer 3
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
   tile_to_lds<2>(d3, lds_d, lane);
   tile_to_lds<2>(h2, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 2, true>(lds_d, lds_h, gW[2], 64, 64, 64, lane);
+  __syncthreads();
+  accum_block(scr0, wave >> 1, wave & 1, lane, accW[0]);
   if (lane < 32) { atomicAdd(gB[2] + lane, row_sum(lds_d, lane)); atomicAdd(gB[2] + 32 + lane, row_sum(lds_d, 32 + lane)); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -324,10 +316,12 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
     for (int j = 0; j < 16; ++j) d2[t][j] *= dleaky(h2[t][j]);
   // ---- layer 2
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
   tile_to_lds<2>(d2, lds_d, lane);
   tile_to_lds<2>(h1, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 2, true>(lds_d, lds_h, gW[1], 64, 64, 64, lane);
+  __syncthreads();
+  accum_block(scr0, wave >> 1, wave & 1, lane, accW[1]);
   if (lane < 32) { atomicAdd(gB[1] + lane, row_sum(lds_d, lane)); atomicAdd(gB[1] + 32 + lane, row_sum(lds_d, 32 + lane)); }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -340,10 +334,12 @@ __device__ __forceinline__ void net_bwd(const float* __restrict__ tfrag, const f
     for (int j = 0; j < 16; ++j) d1[t][j] *= dleaky(h1[t][j]);
   // ---- layer 1 (sample part 64 x 8) + hoisted per-point part
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
   tile_to_lds<2>(d1, lds_d, lane);
   tile_to_lds<1>(in1, lds_h, lane);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  accum_dw<2, 1, true>(lds_d, lds_h, gW[0], 8, 64, 7, lane);
+  __syncthreads();
+  if (wave >= 2) accum_block(scr0, wave - 2, 0, lane, accW[2]);
   if (uniform_pt) {
     if (lane < 32) { atomicAdd(gP_pt + lane, row_sum(lds_d, lane)); atomicAdd(gP_pt + 32 + lane, row_sum(lds_d, 32 + lane)); }
   } else {
@@ -378,21 +374,30 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
                                                             long long m, int sn, long long pn, const float* __restrict__ g_logq,
                                                             FlowGrads G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // LDS image: of the forward fragment image only the biases are kept; every layer's weights are streamed from L2, and the room of
-  // layer l's fragments holds this workgroup's accumulator of layer l's weight gradient, row-major: kL1 [64][8] (the 7 sample columns),
-  // kL2 [64][64], kL3 [64][64], kL4 [32][64] (21 rows used).  Adding every tile's blocks to the workgroup's GLOBAL slice with float
-  // atomics cost 0.67 ms of a 2.0 ms call, and not by their bytes: a wave's vector-memory operations retire in order, so every weight
-  // load of the next layer waited behind the 32-64 atomics issued just before it.
+  // LDS image: the forward fragments and biases of both nets.
   for (int i = threadIdx.x; i < 2 * kNetFloats; i += 256) {
     const int r = i % kNetFloats;
-    lds[i] = r < kB2 ? 0.f : ws_arg[i];
+    lds[i] = ws_arg[i];
+    (void)r;
   }
   __syncthreads();
+  // this wave's weight-gradient blocks of the two nets (net_bwd): in registers for the whole kernel
+  f32x16 accW[2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) accW[a][b][j] = 0.f;
+  const float* scr0 = lds + 2 * kNetFloats;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* lds_d = lds + 2 * kNetFloats + wave * 2 * kTileLds;
   float* lds_h = lds_d + kTileLds;
   const long long n_tiles = (m + 31) / 32;
-  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < n_tiles; tile += (long long)gridDim.x * 4) {
+  // the four waves of the workgroup walk the tiles in lock step (net_bwd holds workgroup barriers): a wave past the last tile runs an
+  // all-invalid tile (g = 0: it adds exact zeros)
+  for (long long tile0 = (long long)blockIdx.x * 4; tile0 < n_tiles; tile0 += (long long)gridDim.x * 4) {
+    const long long tile = tile0 + wave;
     const float* ws = ws_arg;
     asm volatile("" : "+s"(ws));                 // keep the transposed-fragment addresses out of LICM's reach
     int opaque = 0;
@@ -433,9 +438,8 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);
     float g_in8[8];
     float* const sl0 = G.slices + (size_t)blockIdx.x * kGradFloats;
-    float* const gW0[4] = {lds + kL1, lds + kL2, lds + kL3, lds + kL4};
     float* const gB0[4] = {nullptr, sl0 + kGB1, sl0 + kGB2, sl0 + kGB3};
-    net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, gW0, gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
+    net_bwd(ws + 2 * kNetFloats, in1b, b1, b2, b3, g_wv0, lds_d, lds_h, scr0, wave, accW[0], gB0, G.gP + pt * 64, uniform_pt, lane, g_in8);
     // d(2*emb(z0) - 1)/dz0
     float g_z0 = 2.f * (g_in8[0] + g_in8[1] * cosf(z0) - g_in8[2] * sinf(z0) + 2.f * g_in8[3] * cosf(2.f * z0) -
                         2.f * g_in8[4] * sinf(2.f * z0) + 4.f * g_in8[5] * cosf(4.f * z0) - 4.f * g_in8[6] * sinf(4.f * z0));
@@ -452,22 +456,27 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
     pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
     float* const sl1 = sl0 + kGNet;
-    float* const gW1[4] = {lds + kNetFloats + kL1, lds + kNetFloats + kL2, lds + kNetFloats + kL3, lds + kNetFloats + kL4};
     float* const gB1[4] = {nullptr, sl1 + kGB1, sl1 + kGB2, sl1 + kGB3};
-    net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, gW1, gB1, G.gP + (pn + pt) * 64, uniform_pt, lane,
-            g_in8);
+    net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, scr0, wave, accW[1], gB1, G.gP + (pn + pt) * 64, uniform_pt,
+            lane, g_in8);
   }
-  // the accumulators leave the workgroup once (kGW1 | kGW2 are adjacent in the slice, kL2 | kL3 in the image)
-  __syncthreads();
+  // every wave stores the blocks it owns into the workgroup's slice (plain stores: a block has one owner)
   float* const sl = G.slices + (size_t)blockIdx.x * kGradFloats;
+  auto store_block = [&](float* dst, int ld, int nout, int nin, int to, int ti, const f32x16& a) {
+    const int col = 32 * ti + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = 32 * to + tf_rho(j, lane >> 5);
+      if (row < nout && col < nin) dst[row * ld + col] = a[j];
+    }
+  };
 #pragma unroll
   for (int net = 0; net < 2; ++net) {
-    const float* img = lds + net * kNetFloats;
     float* dst = sl + net * kGNet;
-    for (int i = threadIdx.x; i < 2 * 4096; i += 256) dst[kGW1 + i] = img[kL2 + i];
-    for (int i = threadIdx.x; i < 21 * 64; i += 256) dst[kGW3 + i] = img[kL4 + i];
-    for (int i = threadIdx.x; i < 64 * 8; i += 256)
-      if ((i & 7) < 7) dst[kGW0 + (i >> 3) * 44 + (i & 7)] = img[kL1 + i];
+    store_block(dst + kGW2, 64, 64, 64, wave >> 1, wave & 1, accW[net][0]);
+    store_block(dst + kGW1, 64, 64, 64, wave >> 1, wave & 1, accW[net][1]);
+    if (wave < 2) store_block(dst + kGW3, 64, 21, 64, 0, wave, accW[net][2]);
+    else store_block(dst + kGW0, 44, 64, 7, wave - 2, 0, accW[net][2]);
   }
 }
 
