@@ -581,7 +581,14 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
     if (rc != TF_OK) return rc;
   }
   if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
-    const long long split = 1024;     // rows per workgroup: enough workgroups to fill the chip at n ~ 2e5; each adds its tile atomically
+#ifndef TF_WGRAD_SPLIT
+#define TF_WGRAD_SPLIT 1024
+#endif
+    // rows per workgroup: 1 024 for long matrices (enough workgroups to fill the chip at n ~ 2e5; larger slabs measured no faster);
+    // a 2 048-row layer cut that way was two slabs of 64 dependent chunks each -- 85 us for a 2 MB product: short matrices get
+    // slabs of n / 256 rows (>= 64).  Each workgroup adds its tile atomically.
+    long long split = TF_WGRAD_SPLIT;
+    if (n / 256 < split) split = ((n / 256 + 15) / 16) * 16 < 64 ? 64 : ((n / 256 + 15) / 16) * 16;
     const int splits = (int)((n + split - 1) / split);
     int rc;
     if (g2) {
