@@ -193,7 +193,10 @@ int tf_pwquad_eval(const float* wv, const float* y, int64_t m, int32_t inverse, 
  * sum_r g_logq[r]*logq[r] wrt the 16 net tensors (accumulated with float atomics: zero them first) and wrt the
  * hoisted per-point layer-1 pre-activation, g_point [2,pn,64] (zero first).  The caller folds g_point into
  * d W1[:, 7:44] = g_point^T (2 cond - 1), d b1 = sum_pt g_point, d cond = 2 g_point W1[:, 7:44]  (three small GEMMs).
- * d W1[:, 0:7] (the sample-embedding columns) is written by the kernel into gnets[k].w[0] ([64,44], cols 0..6). */
+ * d W1[:, 0:7] (the sample-embedding columns) is written by the kernel into gnets[k].w[0] ([64,44], cols 0..6).
+ * g_x [m,2] or NULL: gradient wrt the sample coordinates x themselves (asked for between nis_loss_iter and nis_start_iter, where the
+ * NIS loss is fitted on the fixed GGX half angles and those depend on the predicted roughness: fields.py:1296-1318 with
+ * sample_specular_directions :858-903) -- closed form through both splines and the kept coordinate's embedding. */
 typedef struct TfCouplingNetGrad {
   float* w[4];
   float* b[4];
@@ -201,7 +204,7 @@ typedef struct TfCouplingNetGrad {
 size_t tf_flow_bwd_workspace_floats(int64_t pn);
 int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id,
                      int64_t m, int32_t sn, int64_t pn, const float* g_logq, const TfCouplingNetGrad gnets[2],
-                     float* g_point, float* workspace, size_t workspace_floats, tf_stream_t stream);
+                     float* g_point, float* g_x, float* workspace, size_t workspace_floats, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Environment light: EnvLight.direct_light (network/light.py:125-162) = exp(bilinear cube lookup

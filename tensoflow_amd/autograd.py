@@ -96,27 +96,18 @@ class FlowLogqFn(torch.autograd.Function):
     def backward(ctx, g_z, g_logq):
         cond, x, *wb = ctx.saved_tensors
         weights = [[(wb[8 * k + 2 * l], wb[8 * k + 2 * l + 1]) for l in range(4)] for k in range(2)]
-        grads, g_cond = ops.flow_logq_bwd(weights, cond.detach(), x, g_logq.contiguous(), rays_id=ctx.rays_id)
+        # d logq / d x is only asked for between nis_loss_iter and nis_start_iter, where the NIS loss is fitted on the fixed GGX half
+        # angles and those depend on the predicted roughness (fields.py:1296-1318 with sample_specular_directions): closed form in the
+        # same kernel (round 3; central differences of the forward -- round 2 -- were exact in the median and off by more than the
+        # gradient itself on the 0.03 % of samples whose stencil straddled a knot of a narrow spline bin: tools/exp_flow_dx.py)
+        want_gx = ctx.needs_input_grad[1]
+        res = ops.flow_logq_bwd(weights, cond.detach(), x, g_logq.contiguous(), rays_id=ctx.rays_id, want_gx=want_gx)
+        grads, g_cond = res[0], res[1]
+        g_x = res[2] if want_gx else None
         flat = []
         for k in range(2):
             for l in range(4):
                 flat += [grads[k][l][0], grads[k][l][1]]
-        g_x = None
-        if ctx.needs_input_grad[1]:
-            # d logq / d x: only asked for between nis_loss_iter and nis_start_iter, where the NIS loss is fitted on the fixed GGX
-            # half angles and those depend on the predicted roughness (fields.py:1296-1318 with sample_specular_directions).  Taken by
-            # central differences of the HIP forward (4 launches): the density is piecewise smooth in x, h = 1e-3 keeps the fp32
-            # difference quotient good to ~1e-4 -- and this term enters the objective with NISLoss's weight of 1e-4.
-            h = 1e-3
-            cols = []
-            for c in range(2):
-                e = torch.zeros_like(x)
-                e[..., c] = h
-                xp, xm = (x + e).clamp(1e-6, 1 - 1e-6), (x - e).clamp(1e-6, 1 - 1e-6)
-                lp = ops.flow_logq(weights, cond.detach(), xp.contiguous(), rays_id=ctx.rays_id, precision=ops.PREC_F32)[1]
-                lm = ops.flow_logq(weights, cond.detach(), xm.contiguous(), rays_id=ctx.rays_id, precision=ops.PREC_F32)[1]
-                cols.append((lp - lm).reshape(g_logq.shape) / (xp[..., c] - xm[..., c]).reshape(g_logq.shape))
-            g_x = torch.stack([g_logq * cols[0], g_logq * cols[1]], -1).reshape(x.shape)
         return (g_cond, g_x, None, *flat)
 
 

@@ -108,7 +108,8 @@ __device__ __forceinline__ void pw_forward_fb(float xin, const float (&wv)[32], 
   logj = logf(lerp);
 }
 
-__device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32], float g_out, float g_logj, float (&g_wv)[32]) {
+// -> gradient wrt the transformed coordinate xin itself (d out / d xin = lerp = exp(logj), d logj / d xin = dv / (w lerp): both through al)
+__device__ __forceinline__ float pw_forward_bwd(float xin, const float (&wv)[32], float g_out, float g_logj, float (&g_wv)[32]) {
   PwT T;
   pw_tables_fwd(wv, T);
   int cnt = 0;
@@ -135,6 +136,7 @@ __device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32],
   const float g_vwm = go;
   if (!(araw >= 0.f && araw <= 1.f)) g_al = 0.f;
   const float g_wssm = -g_al / wm;
+  const float g_xin = g_al / wm;
   g_wm += -g_al * araw / wm;
   // scatter the picked gradients back into per-index arrays
   float g_v[FLOW_NB + 1], g_w[FLOW_NB];
@@ -185,6 +187,7 @@ __device__ __forceinline__ void pw_forward_bwd(float xin, const float (&wv)[32],
     const float ge = g_e[i] + g_S;
     g_wv[11 + i] += (T.e[i] > 1e-6f) ? ge * T.e[i] : 0.f;
   }
+  return g_xin;
 }
 #pragma clang fp contract(fast)
 
@@ -372,7 +375,7 @@ __device__ __forceinline__ void embed8(float y, float (&in8)[8]) {
 __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restrict__ ws_arg, const float* __restrict__ P,
                                                             const float* __restrict__ xin, const long long* __restrict__ rays_id,
                                                             long long m, int sn, long long pn, const float* __restrict__ g_logq,
-                                                            FlowGrads G) {
+                                                            FlowGrads G, float* __restrict__ g_x) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // LDS image: the forward fragments and biases of both nets.
   for (int i = threadIdx.x; i < 2 * kNetFloats; i += 256) {
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     float g_wv0[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) g_wv0[k] = 0.f;
-    pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);
+    float g_x1 = pw_forward_bwd(x1, wv0, g_z1, g, g_wv0);        // x1 as the coordinate block 0 moves
     float g_in8[8];
     float* const sl0 = G.slices + (size_t)blockIdx.x * kGradFloats;
     float* const gB0[4] = {nullptr, sl0 + kGB1, sl0 + kGB2, sl0 + kGB3};
@@ -454,11 +457,17 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
     float g_wv1[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) g_wv1[k] = 0.f;
-    pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
+    const float g_x0 = pw_forward_bwd(x0, wv1, g_z0, g, g_wv1);
     float* const sl1 = sl0 + kGNet;
     float* const gB1[4] = {nullptr, sl1 + kGB1, sl1 + kGB2, sl1 + kGB3};
     net_bwd(ws + 2 * kNetFloats + kTNet, in1a, a1, a2, a3, g_wv1, lds_d, lds_h, scr0, wave, accW[1], gB1, G.gP + (pn + pt) * 64, uniform_pt,
             lane, g_in8);
+    if (g_x) {
+      // ... and x1 as the coordinate block 1 keeps: through its embedding into net 1 (d(2 emb(x1) - 1) / d x1, as for z0 above)
+      g_x1 += 2.f * (g_in8[0] + g_in8[1] * cosf(x1) - g_in8[2] * sinf(x1) + 2.f * g_in8[3] * cosf(2.f * x1) -
+                     2.f * g_in8[4] * sinf(2.f * x1) + 4.f * g_in8[5] * cosf(4.f * x1) - 4.f * g_in8[6] * sinf(4.f * x1));
+      if (valid && lane < 32) { g_x[2 * row] = g_x0; g_x[2 * row + 1] = g_x1; }
+    }
   }
   // every wave stores the blocks it owns into the workgroup's slice (plain stores: a block has one owner)
   float* const sl = G.slices + (size_t)blockIdx.x * kGradFloats;
@@ -518,7 +527,7 @@ __global__ void __launch_bounds__(256) flow_point_part_kernel2(const float* __re
 
 extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id, int64_t m,
                                 int32_t sn, int64_t pn, const float* g_logq, const TfCouplingNetGrad gnets[2], float* g_point,
-                                float* workspace, size_t workspace_floats, tf_stream_t stream_) {
+                                float* g_x, float* workspace, size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "tf_flow_logq_bwd";
   TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
@@ -567,7 +576,7 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   G.slices = workspace + kBwdWs + (size_t)2 * 64 * (size_t)pn;
   hipError_t e2 = hipMemsetAsync(G.slices, 0, (size_t)blocks * kGradFloats * sizeof(float), stream);
   TF_REQUIRE(e2 == hipSuccess, TF_EHIP, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e2));
-  flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G);
+  flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G, g_x);
   flow_grad_fold_kernel<<<tf_blocks(kGradFloats, 256), 256, 0, stream>>>(G, (int)blocks);
   TF_LAUNCH_CHECK(who);
   return TF_OK;

@@ -326,9 +326,9 @@ def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
     return (z, lq, bins) if want_bins else (z, lq)
 
 
-def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None):
-    """Backward of flow_logq wrt the 16 net tensors and cond.
-    -> (grads: 2 lists of 4 (gW, gb) pairs in torch layout, g_cond [pn,37])."""
+def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False):
+    """Backward of flow_logq wrt the 16 net tensors and cond (want_gx: and wrt the sample coordinates x, closed form in the kernel).
+    -> (grads: 2 lists of 4 (gW, gb) pairs in torch layout, g_cond [pn,37]) (, g_x like x)."""
     lib = L.load()
     cond, x, g_logq = _f(cond), _f(x), _f(g_logq.reshape(-1))
     pn = cond.shape[0]
@@ -345,8 +345,9 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None):
     g_point = torch.zeros(2, pn, 64, dtype=torch.float32, device=dev)
     ws = _workspace("flow_bwd", lib.tf_flow_bwd_workspace_floats(pn), dev)
     rid = None if rays_id is None else rays_id.contiguous()
+    g_x = torch.zeros_like(x) if want_gx else None
     L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
-                                 _p(g_point), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
+                                 _p(g_point), _p(g_x), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
     # fold the hoisted per-point part: the three products of one dense layer c [pn,37] -> [pn,64] (tf_linear_bwd)
     c = cond * 2.0 - 1.0
     g_cond = torch.zeros_like(cond)
@@ -357,7 +358,7 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None):
         gW1[:, 7:] += gw
         gb1 += gb
         g_cond += 2.0 * gx
-    return grads, g_cond
+    return (grads, g_cond, g_x) if want_gx else (grads, g_cond)
 
 
 # ------------------------------------------------------------------------------ light / mesh / shading

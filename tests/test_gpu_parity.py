@@ -210,6 +210,40 @@ def test_pwquad_spline_on_reference_vectors(golden, dev):
     assert float(err.max()) < 2e-2
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_flow_logq_gradient_wrt_samples_matches_oracle_autograd(golden, dev, masked):
+    """d logq / d x (asked for between nis_loss_iter and nis_start_iter: the fixed GGX half angles depend on the predicted roughness)
+    from the fused backward kernel -- closed form through both splines and the kept coordinate's embedding -- against autograd of the
+    oracle flow in fp64, on samples that include knots of narrow spline bins (slopes of 2e3)."""
+    from oracle import flow as ofl
+    from tensoflow_amd.network.flow import TensoFlow
+    g = golden("tensoflow_r32")
+    m = TensoFlow(2, AABB, device=dev, gridSize=[32, 32, 32])
+    m.load_state_dict(g.sd)
+    pts, va, rough = g["pts"], g["view_angles"], g["roughness"]
+    pn, sn = pts.shape[0], 64
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(pn, sn, 2, generator=gen).clamp(1e-3, 1 - 1e-3)
+    w = torch.randn(pn, sn, 1, generator=gen)
+    rid = None
+    if masked:                                   # the specular lobe's form: a ragged subset of the samples with their point ids
+        keep = torch.rand(pn, sn, generator=gen) < 0.6
+        rid = torch.arange(pn)[:, None].expand(pn, sn)[keep]
+        x, w = x[keep], w[keep]
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in g.sd.items()}
+    x64 = x.double().requires_grad_(True)
+    _, lq = ofl.flow_logq(sd64, pts.double(), va.double(), rough.double(), x64, AABB.double(), rays_id=rid)
+    (lq * w.double()).sum().backward()
+    ref = x64.grad
+    xd = x.to(dev).requires_grad_(True)
+    _, lq2 = m(pts.to(dev), va.to(dev), rough.to(dev), xd, return_jacobian=True, rays_id=None if rid is None else rid.to(dev))
+    (lq2 * w.to(dev)).sum().backward()
+    err = (xd.grad.cpu().double() - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"d logq / d x: max |g| {scale:.1f}, max err {float(err.max()):.2e}, median {float(err.median()):.2e}")
+    assert scale > 100 and float(err.max()) < 1e-3 * scale and float(err.median()) < 1e-5 * scale
+
+
 def test_flow_roundtrip_full_size(dev, golden):
     """size-independent property at BASELINE size (128 samples, 4096 points): logq(sample) == -logj."""
     from oracle import flow as oflow
