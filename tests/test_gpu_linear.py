@@ -26,7 +26,8 @@ def linear_precision(request):
 # (strides that are multiples of four: ragged row counts, a ragged reduction of 108, two column blocks), the streaming kernels of layers
 # with <= 4 outputs
 @pytest.mark.parametrize("n,K,N", [(1, 3, 1), (777, 111, 256), (4096, 256, 129), (2048, 108, 128), (300, 128, 3), (5000, 123, 256), (130, 256, 256),
-                                   (3333, 256, 256), (5000, 128, 128), (1029, 72, 256), (5000, 256, 3), (2048, 108, 1), (999, 128, 4), (1500, 64, 2)])
+                                   (3333, 256, 256), (5000, 128, 128), (1029, 72, 256), (5000, 256, 3), (2048, 108, 1), (999, 128, 4), (1500, 64, 2),
+                                   (500, 32, 32), (64, 128, 128), (20000, 36, 128), (77, 4, 3), (1, 1024, 2)])
 def test_linear_fwd_bwd_matches_torch(n, K, N, linear_precision):
     from tensoflow_amd import ops
     from tensoflow_amd.autograd import LinearActFn
