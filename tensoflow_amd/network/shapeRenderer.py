@@ -332,7 +332,7 @@ class ShapeRenderer(nn.Module):
         if idx.numel() == 0:
             return zero
         gt = self._traced_occlusion(points[idx].detach(), occ_info["reflective"][idx].detach(), 64, 16)
-        return F.l1_loss(occ_info["occ_prob"][idx], gt)
+        return F.l1_loss(occ_info["occ_prob"].index_select(0, idx), gt)      # (index_select: its backward is an atomic index_add, not the sort of x[idx])
 
     @torch.no_grad()
     def _validation_outputs(self, rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step):
