@@ -130,9 +130,39 @@ def outer_light_direction(sd, dirs, light_exp_max=5.0):
     return mlp(sd, "outer_light", (0, 2, 4, 6), ide5(dirs, 0), F.relu, lambda t: torch.exp(t.clamp(max=light_exp_max)))
 
 
-def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0):
-    """fields.py:951-975, human_lights=False; outer_light_version follows the state dict ('envlight': `outer_light.base`,
-    'direction': `outer_light.0.*`).
+def outer_light_sphere_direction(sd, pts, dirs, light_exp_max=5.0):
+    """predict_outer_lights, 'sphere_direction' (fields.py:917-928): IDE of the direction | IDE of the point where the ray leaves the unit
+    sphere (get_sphere_intersection, utils/network_utils.py:108-114; points outside 0.999 are pulled in first)."""
+    p = pts.clone()
+    far = p.norm(dim=-1) > 0.999
+    p[far] = p[far] * 0.999
+    dtx = (p * dirs).sum(-1, keepdim=True)
+    dist = -dtx + torch.sqrt(dtx ** 2 - (p ** 2).sum(-1, keepdim=True) + 1 + 1e-6)
+    enc = torch.cat([ide5(dirs, 0), ide5(p + dirs * dist, 0)], -1)
+    return mlp(sd, "outer_light", (0, 2, 4, 6), enc, F.relu, lambda t: torch.exp(t.clamp(max=light_exp_max)))
+
+
+def human_light(sd, pts, dirs, poses):
+    """get_human_light (fields.py:935-949) with get_camera_plane_intersection (utils/network_utils.py:69-88) and IPE(mean, 0, 0, 6)
+    (:56-61: sin of [2^k mean | 2^k mean + pi/2]) -> (human_lights [n,3], human_weights [n,1])."""
+    R, t = poses[:, :, :3], poses[:, :, 3:]
+    p_ = (R @ pts[:, :, None] + t)[..., 0]
+    d_ = (R @ dirs[:, :, None])[..., 0].clone()
+    hits = d_[:, 2].abs() > 1e-4
+    d_[~hits, 2] = 1e-4                                   # the reference writes through a view of dirs_
+    dist = -p_[:, 2] / d_[:, 2]
+    mean = (p_ + dist[:, None] * d_)[:, :2] * 0.3
+    hits = (hits & (mean.norm(dim=-1) < 1.5) & (dist > 0)).to(pts.dtype)[:, None]
+    mean = mean * hits
+    scaled = (mean[:, None, :] * (2.0 ** torch.arange(6, dtype=pts.dtype))[:, None]).reshape(-1, 12)
+    pe = torch.sin(torch.cat([scaled, scaled + 0.5 * np.pi], -1))
+    h = mlp(sd, "human_light", (0, 2, 4, 6), pe, F.relu, lambda t: torch.exp(t.clamp(max=0.0))) * hits
+    return h[:, :3], h[:, 3:].clamp(0.0, 1.0)
+
+
+def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0, poses=None):
+    """fields.py:951-975; the variant follows the state dict: 'envlight' (`outer_light.base`), 'direction' / 'sphere_direction'
+    (`outer_light.0.*` with 72 / 144 inputs), human lights (`human_light.*`; poses [M,3,4]).
     pts, dirs [M,3] -> lights [M,3], hit [M] bool, inters [M,3]."""
     eps = 1e-5
     o = pts + dirs * eps
@@ -140,8 +170,16 @@ def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0)
     lights = torch.zeros_like(pts)
     miss = ~hit
     if miss.any():
-        lights[miss] = (env_direct_light(sd["outer_light.base"], dirs[miss]) if "outer_light.base" in sd
-                        else outer_light_direction(sd, dirs[miss], light_exp_max))
+        if "outer_light.base" in sd:
+            outer = env_direct_light(sd["outer_light.base"], dirs[miss])
+        elif sd["outer_light.0.parametrizations.weight.original1"].shape[1] == 144:
+            outer = outer_light_sphere_direction(sd, pts[miss], dirs[miss], light_exp_max)
+        else:
+            outer = outer_light_direction(sd, dirs[miss], light_exp_max)
+        if "human_light.0.bias" in sd:
+            hl, hw = human_light(sd, pts[miss], dirs[miss], poses[miss])
+            outer = outer * (1 - hw) + hl * hw
+        lights[miss] = outer
     if hit.any():
         lights[hit] = inner_light(sd, inters[hit], -dirs[hit], nrm[hit], exp_max)
     lights = lights * (depth > eps).to(lights.dtype)
@@ -189,8 +227,8 @@ def fixed_specular_dirs(n, x, y, view, rough, samples):
 
 
 def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, n_fixed_diffuse=512,
-          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy"):
-    """MCShadingNetwork.forward -> shade_mixed, eval, human_lights off, envlight outer light.
+          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None):
+    """MCShadingNetwork.forward -> shade_mixed, eval; outer-light variant and human lights follow the state dict (get_lights).
     Returns dict(colors, diffuse_colors(lin), specular_colors(lin), metallic, roughness, albedo,
                  specular_rays_id, specular_mask, visibility, ...)."""
     view = F.normalize(view, dim=-1)
@@ -216,7 +254,8 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     dn = ddirs.shape[1]
     kd = 1 - metallic[:, None]
     dl, dhit, _ = get_lights(sd, tracer, unit_size, pts[:, None].expand(pn, dn, 3).reshape(-1, 3),
-                             ddirs.reshape(-1, 3), exp_max)
+                             ddirs.reshape(-1, 3), exp_max,
+                             poses=human_poses[:, None].expand(pn, dn, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None)
     dl = dl.reshape(pn, dn, 3)
     dw = albedo[:, None] * kd * (sat_dot(ddirs, nrm[:, None]) / np.pi)
     diffuse = torch.mean(dw * dl / dpdf.clamp_min(EPS), 1)
@@ -243,7 +282,7 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     geo = schlick_g1(NoV, rough[rid]) * schlick_g1(NoL, rough[rid])
     NoH = sat_dot(nrm[rid], Hs)
     dist = ggx_d(NoH, rough[rid])
-    sl, shit, sinter = get_lights(sd, tracer, unit_size, pts[rid], sd_, exp_max)
+    sl, shit, sinter = get_lights(sd, tracer, unit_size, pts[rid], sd_, exp_max, poses=human_poses[rid] if human_poses is not None else None)
     sw = dist * fres * geo / (4 * NoV).clamp_min(EPS)
     specular = segment_coo(sw * sl / sp_.clamp_min(EPS), rid, torch.zeros(pn, 3)) / sn
     colors = linear_to_srgb(diffuse + specular)

@@ -182,9 +182,10 @@ class MCShadingNetwork(nn.Module):
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        if self.cfg["outer_light_version"] not in ("envlight", "direction") or self.cfg["human_lights"]:
-            raise NotImplementedError("outer_light_version 'envlight' or 'direction', human_lights=False (every configs/mat/syn/*.yaml and "
-                                      "configs/mat/orb/*.yaml); 'sphere_direction' + human lights (configs/mat/custom) are not built")
+        if self.cfg["outer_light_version"] not in ("envlight", "direction", "sphere_direction"):
+            raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
+        if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":
+            raise NotImplementedError("human_lights with the cube-map outer light (no shipped config combines them)")
         self.aabb, self.unit_size, self.ray_tracer = aabb, float(unit_size), ray_tracer
         R, C = self.cfg["mat_grid"], 36
         self.mat_plane = nn.ParameterList([nn.Parameter(1e-4 * (2 * torch.rand(1, C, R, R) - 1)) for _ in range(3)]).cuda()
@@ -198,10 +199,18 @@ class MCShadingNetwork(nn.Module):
         if self.cfg["outer_light_version"] == "envlight":
             self.outer_light = EnvLight(trainable=True, max_res=self.cfg["light_reso"])
         else:
-            # fields.py:716-718: make_predictor_4layer(72, 3, activation='exp', exp_max=light_exp_max) on the IDE of the ray direction
-            self.outer_light = nn.Sequential(wn(nn.Linear(72, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
+            # fields.py:716-721: make_predictor_4layer(72 | 72 * 2, 3, activation='exp', exp_max=light_exp_max) on the IDE of the ray
+            # direction ('sphere_direction': and of the point where the ray leaves the unit sphere)
+            n_in = 72 if self.cfg["outer_light_version"] == "direction" else 144
+            self.outer_light = nn.Sequential(wn(nn.Linear(n_in, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
                                              nn.ReLU(), wn(nn.Linear(256, 3)), nn.Identity()).cuda()
             nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
+        if self.cfg["human_lights"]:
+            # fields.py:727-729: make_predictor_4layer(2 * 2 * 6, 4, activation='exp') -- exp(min(x, 0)) -- on the capturer's plane
+            self.human_light = nn.Sequential(wn(nn.Linear(24, 256)), nn.ReLU(), wn(nn.Linear(256, 256)), nn.ReLU(), wn(nn.Linear(256, 256)),
+                                             nn.ReLU(), wn(nn.Linear(256, 4)), nn.Identity()).cuda()
+            nn.init.constant_(self.human_light[-2].bias, np.log(0.02))
+        self._composed_lights = self.cfg["outer_light_version"] == "sphere_direction" or self.cfg["human_lights"]
         mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda")
         self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
         self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
@@ -225,6 +234,8 @@ class MCShadingNetwork(nn.Module):
         self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
                                 exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"],
                                 bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"])
+        if self._composed_lights:
+            self._shader.overlap_dirs = False      # (the composed miss branch allocates between the streams' kernels: keep one stream)
         self._shader_version = ver
         return self._shader
 
@@ -264,12 +275,42 @@ class MCShadingNetwork(nn.Module):
             reg = reg + torch.sum(torch.clamp(metallic - 0.98, min=0)) + torch.sum(torch.clamp(0.02 - metallic, min=0))
         return reg.reshape(1)
 
-    def _outer_mlp(self, dirs):
-        """predict_outer_lights('direction') (fields.py:913-916) as a differentiable composition: IDE of the rows as they are, the
-        net's products on tf_linear_fwd / tf_linear_bwd."""
+    def _outer_mlp(self, dirs, origins=None):
+        """predict_outer_lights('direction' | 'sphere_direction') (fields.py:913-928) as a differentiable composition: IDE of the rows
+        as they are (and of the point where the ray leaves the unit sphere), the net's products on tf_linear_fwd / tf_linear_bwd."""
         from ..encodings import ide5
-        enc = ide5(dirs, torch.zeros(dirs.shape[0], 1, device=dirs.device), wide=True)
+        zero = torch.zeros(dirs.shape[0], 1, device=dirs.device)
+        enc = ide5(dirs, zero, wide=True)
+        if self.cfg["outer_light_version"] == "sphere_direction":
+            o = origins if origins is not None else dirs                    # predict_outer_lights_pts feeds the direction twice (:1516)
+            if origins is not None:
+                far = (o.norm(dim=-1) > 0.999)[:, None]
+                o = torch.where(far, o * 0.999, o)
+                dtx = (o * dirs).sum(-1, keepdim=True)
+                o = o + dirs * (-dtx + torch.sqrt(dtx ** 2 - (o ** 2).sum(-1, keepdim=True) + 1 + 1e-6))
+            enc = torch.cat([enc, ide5(o, zero, wide=True)], -1)
         return torch.exp(torch.clamp(_mlp(self.outer_light, enc), max=self.cfg["light_exp_max"]))
+
+    def _miss_lights(self, origins, dirs, poses):
+        """Outer light of the rays that missed, blended with the capturer's reflection when human_lights is on (fields.py:962-968)
+        -> (lights [n,3], human_lights * human_weights [n,3] or None)."""
+        outer = self._outer_mlp(dirs, origins)
+        if not self.cfg["human_lights"]:
+            return outer, None
+        R, t = poses[:, :, :3], poses[:, :, 3]
+        p_ = torch.einsum("nij,nj->ni", R, origins) + t
+        d_ = torch.einsum("nij,nj->ni", R, dirs)
+        hits = d_[:, 2].abs() > 1e-4
+        dz = torch.where(hits, d_[:, 2], torch.full_like(d_[:, 2], 1e-4))
+        dist = -p_[:, 2] / dz
+        mean = (p_[:, :2] + dist[:, None] * d_[:, :2]) * 0.3
+        hits = (hits & (mean.norm(dim=-1) < 1.5) & (dist > 0)).float()[:, None]
+        mean = mean * hits
+        scaled = (mean[:, None, :] * (2.0 ** torch.arange(6, device=mean.device))[:, None]).reshape(-1, 12)         # IPE(mean, 0, 0, 6)
+        pe = torch.sin(torch.cat([scaled, scaled + 0.5 * math.pi], -1))
+        h = torch.exp(torch.clamp(_mlp(self.human_light, pe), max=0.0)) * hits
+        hl, hw = h[:, :3], h[:, 3:].clamp(0.0, 1.0)
+        return outer * (1 - hw) + hl * hw, hl * hw
 
     def predict_outer_lights_pts(self, pts):
         """fields.py:1512-1520."""
@@ -299,7 +340,32 @@ class MCShadingNetwork(nn.Module):
         eps = torch.finfo(torch.float32).eps
         return torch.where(lin <= 0.0031308, 323 / 25 * lin, (211 * lin.clamp(min=eps) ** (5 / 12) - 11) / 200)
 
-    def forward_train(self, pts, view_dirs, normals, step=None, is_train=True):
+    def _lights_of(self, origins, dirs, poses=None):
+        """get_lights (fields.py:951-975) as a differentiable composition: visibility by tf_bvh_trace (no gradient, like the reference's
+        ray tracer), the outer light of the rays that miss (cube map or net; human lights blended in), the inner-light net on the hits;
+        differentiable wrt the map / nets and wrt `dirs`.  -> (lights [n,3], hit [n], human_lights * human_weights of the misses or None)."""
+        from ..encodings import ide5, posenc
+        dev = dirs.device
+        with torch.no_grad():
+            inters, nrm, depth, hit = self._bvh.trace(origins.contiguous(), dirs.detach().contiguous(), 1e-5, 2 * self.unit_size)
+        lights = torch.zeros_like(dirs)
+        miss = ~hit
+        hl = None
+        if bool(miss.any()):
+            if self.cfg["outer_light_version"] == "envlight":
+                outer = self.outer_light.direct_light(dirs[miss])
+            else:
+                outer, hl = self._miss_lights(origins[miss], dirs[miss], poses[miss] if poses is not None else None)
+            lights = lights.index_put((miss,), outer)
+        if bool(hit.any()):
+            vd = F.normalize(-dirs[hit], dim=-1)
+            nh = F.normalize(nrm[hit], dim=-1)
+            refl = (vd * nh).sum(-1, keepdim=True) * nh * 2 - vd
+            enc = torch.cat([posenc(inters[hit], 8), ide5(refl, torch.zeros(refl.shape[0], 1, device=dev))], -1)
+            lights = lights.index_put((hit,), torch.exp(torch.clamp(_mlp(self.inner_light, enc), max=self.cfg["inner_light_exp_max"])))
+        return lights * (depth > 1e-5).float()[:, None], hit, hl
+
+    def forward_train(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None):
         """Differentiable forward of shade_mixed with the flow samplers (fields.py:1075-1335): every per-sample stage runs in
         the HIP kernels through autograd Functions whose backward is HIP as well (VM gather, BRDF weights, cube map, flow
         log-density) or a library GEMM (inner-light weight gradients); the per-point material MLPs are torch modules."""
@@ -327,15 +393,20 @@ class MCShadingNetwork(nn.Module):
         inner_wb = []
         for i in (0, 2, 4, 6):
             inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)
-        if self.cfg["outer_light_version"] == "direction":
-            env_base = None
-            for i in (0, 2, 4, 6):
-                inner_wb += [self.outer_light[i].weight, self.outer_light[i].bias]
+        if self._composed_lights:
+            # 'sphere_direction' / human lights (configs/mat/custom): the composed get_lights of the fixed-sampler pass
+            poses_rep = human_poses[:, None].expand(pn, T, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None
+            lights, hit, _ = self._lights_of(pts_rep[:, None].expand(pn, T, 3).reshape(-1, 3), dirs.reshape(-1, 3), poses_rep)
         else:
-            env_base = self.outer_light.base
-        lights, hit = LightsFn.apply(env_base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
-                                     self.cfg["inner_light_exp_max"], self.cfg.get("precision", ops.PREC_F16X3), self.cfg["light_exp_max"],
-                                     *inner_wb)
+            if self.cfg["outer_light_version"] == "direction":
+                env_base = None
+                for i in (0, 2, 4, 6):
+                    inner_wb += [self.outer_light[i].weight, self.outer_light[i].bias]
+            else:
+                env_base = self.outer_light.base
+            lights, hit = LightsFn.apply(env_base, pts_rep, dirs.reshape(-1, 3), live.reshape(-1), self._bvh, self.unit_size,
+                                         self.cfg["inner_light_exp_max"], self.cfg.get("precision", ops.PREC_F16X3), self.cfg["light_exp_max"],
+                                         *inner_wb)
         lights = lights.view(pn, T, 3)
         contrib = wgt * lights
         diffuse_lin, specular_lin = contrib[:, :nd].sum(1), contrib[:, nd:].sum(1)
@@ -360,7 +431,7 @@ class MCShadingNetwork(nn.Module):
         return colors, outputs
 
     # ---------------------------------------------------------------- training before the flow copies take over the sampling
-    def forward_train_fixed(self, pts, view_dirs, normals, step=None, is_train=True):
+    def forward_train_fixed(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None):
         """shade_mixed with BOTH fixed samplers (fields.py:1075-1335 with the `else` branches: the material stage's first
         nis_start_iter = 1000 steps, update_step :1050-1065): 512 cosine directions for the diffuse lobe and the roughness-warped
         GGX set for the specular lobe (sample_diffuse_directions / sample_specular_directions, :824-903).  Unlike the flow pass, the
@@ -397,22 +468,9 @@ class MCShadingNetwork(nn.Module):
             phi = (torch.atan2((Y * H).sum(-1, keepdim=True), (X * H).sum(-1, keepdim=True)) + 2 * PI) % (2 * PI)
             return phi, torch.acos(cz)
 
-        def lights_of(origins, dirs):
-            """get_lights (:951-975), differentiable wrt the map, the inner-light net and `dirs`."""
-            with torch.no_grad():
-                inters, nrm, depth, hit = self._bvh.trace(origins.contiguous(), dirs.detach().contiguous(), 1e-5, 2 * self.unit_size)
-            lights = torch.zeros_like(dirs)
-            miss = ~hit
-            if bool(miss.any()):
-                outer = self._outer_mlp(dirs[miss]) if cfg["outer_light_version"] == "direction" else self.outer_light.direct_light(dirs[miss])
-                lights = lights.index_put((miss,), outer)
-            if bool(hit.any()):
-                vd = F.normalize(-dirs[hit], dim=-1)
-                nh = F.normalize(nrm[hit], dim=-1)
-                refl = (vd * nh).sum(-1, keepdim=True) * nh * 2 - vd
-                enc = torch.cat([posenc(inters[hit], 8), ide5(refl, torch.zeros(refl.shape[0], 1, device=dev))], -1)
-                lights = lights.index_put((hit,), torch.exp(torch.clamp(_mlp(self.inner_light, enc), max=cfg["inner_light_exp_max"])))
-            return lights * (depth > 1e-5).float()[:, None], hit
+        def lights_of(origins, dirs, poses=None):
+            l, h, _ = self._lights_of(origins, dirs, poses)
+            return l, h
 
         # ---- diffuse lobe: fixed cosine set (no parameter dependence in the directions)
         az, el = self._fixed[:, 0][None, :, None] * (2 * PI), self._fixed[:, 1][None, :, None]
@@ -422,7 +480,8 @@ class MCShadingNetwork(nn.Module):
         d_dirs = (el_sqrt * torch.cos(az)) * X + (el_sqrt * torch.sin(az)) * Y + torch.sqrt(1 - el + 1e-7) * Z
         d_pdf = sat(d_dirs, Z) / PI * (torch.cos((1 - el) * PI / 2) * PI / 2)
         nd = d_dirs.shape[1]
-        d_lights, _ = lights_of(pts[:, None].expand(pn, nd, 3).reshape(-1, 3), d_dirs.reshape(-1, 3))
+        d_lights, _ = lights_of(pts[:, None].expand(pn, nd, 3).reshape(-1, 3), d_dirs.reshape(-1, 3),
+                                human_poses[:, None].expand(pn, nd, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None)
         d_lights = d_lights.view(pn, nd, 3)
         kd = 1 - metallic[:, None]
         d_w = albedo[:, None] * kd * (sat(d_dirs, Z) / PI)
@@ -457,7 +516,7 @@ class MCShadingNetwork(nn.Module):
             raise NotImplementedError("geometry_type='schlick' (every shipped config)")
         geo = g1(NoV, roughness[rid]) * g1(NoL, roughness[rid])
         dist = ggx(sat(normals[rid], Hh), roughness[rid])
-        s_lights, s_hit = lights_of(pts[rid], sd_)
+        s_lights, s_hit = lights_of(pts[rid], sd_, human_poses[rid] if human_poses is not None else None)
         s_w = dist * fres * geo / (4 * NoV).clamp_min(EPS)
         specular = torch.zeros(pn, 3, device=dev).index_add(0, rid, s_w * s_lights / sp_.clamp_min(EPS)) / ns
         colors = self._linear_to_srgb(diffuse + specular)
@@ -487,19 +546,21 @@ class MCShadingNetwork(nn.Module):
     def forward(self, pts, view_dirs, normals, human_poses=None, step=None, is_train=False):
         """fields.py:1453-1473 with the flow samplers active: -> (colors [pn,3], outputs dict).
         With autograd enabled (training) the differentiable composition is used; otherwise the fused inference path."""
+        if self.cfg["human_lights"] and human_poses is None:
+            raise ValueError("human_lights=True: forward() needs the per-point human_poses [pn,3,4]")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             fd, fs = getattr(self, "use_flow_diffuse_copy", False), getattr(self, "use_flow_specular_copy", False)
             if step is not None and not fd and not fs:
                 # fields.py:1082,1160: until the first copy refresh (nis_start_iter) both lobes draw from the fixed samplers
-                return self.forward_train_fixed(pts, view_dirs, normals, step=step, is_train=is_train)
+                return self.forward_train_fixed(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
             if step is not None and fd != fs:
                 raise NotImplementedError("one lobe on its flow copy and the other on the fixed sampler: set nis_start_iter_diffuse == "
                                           "nis_start_iter_specular (every shipped config does)")
-            return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train)
-        return self._forward_eval(pts, view_dirs, normals)
+            return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
+        return self._forward_eval(pts, view_dirs, normals, human_poses)
 
     @torch.no_grad()
-    def _forward_eval(self, pts, view_dirs, normals):
+    def _forward_eval(self, pts, view_dirs, normals, human_poses=None):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
         from ..shading import aux_outputs
@@ -508,9 +569,10 @@ class MCShadingNetwork(nn.Module):
         # the unweighted light maps (diffuse_light, visibility ...) average over EVERY ray, incl. those whose BRDF weight is zero:
         # the zero-weight culling of the throughput path is switched off here
         sh.cull_dead_rays = False
-        fx = sh.shade_fixed(pts, view_dirs, normals)
+        hp = human_poses.float().contiguous() if (human_poses is not None and self.cfg["human_lights"]) else None
+        fx = sh.shade_fixed(pts, view_dirs, normals, human_poses=hp)
         outputs = {"albedo": fx["albedo"], "roughness": fx["roughness"], "metallic": fx["metallic"], "normal": nrm, **aux_outputs(fx)}
-        nis = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"])
+        nis = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"], human_poses=hp)
         outputs.update({k + "_nis": v for k, v in {"albedo": nis["albedo"], "roughness": nis["roughness"], "metallic": nis["metallic"],
                                                   "normal": nrm, "rgb_pr": nis["colors"], **aux_outputs(nis)}.items()})
         outputs["specular_rays_id_nis"] = nis["specular_rays_id"]

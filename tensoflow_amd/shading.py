@@ -209,20 +209,30 @@ class MCShader:
         self.field_f16 = bool(field_f16)
         self.mat_packed = ops.VmPacked(self.mat_planes, self.mat_lines, 3, texel_f16=field_f16)
         sdd = {k: v.to(device).float() for k, v in sd.items() if v.is_floating_point() and ("predictor" in k or "inner_light" in k or
-                                                                                          k.startswith("outer_light."))}
+                                                                                          k.startswith("outer_light.") or k.startswith("human_light."))}
         self.pred = {name: [(wn_weight(sdd, f"{name}_predictor.{i}").contiguous(), sdd[f"{name}_predictor.{i}.bias"]) for i in (0, 2)]
                      for name in ("metallic", "roughness", "albedo")}
         self.inner = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
+        self.light_exp_max = float(light_exp_max)
+        self.outer_sphere, self.human = False, None
         if "outer_light.base" in sd:
             self.env, self.outer = g("outer_light.base"), None
-        elif "outer_light.0.bias" in sd and tuple(wn_weight(sdd, "outer_light.0").shape) == (256, 72):
+        elif "outer_light.0.bias" in sd and tuple(wn_weight(sdd, "outer_light.0").shape) in ((256, 72), (256, 144)):
             self.env = None
             self.outer = [(wn_weight(sdd, f"outer_light.{i}").contiguous(), sdd[f"outer_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
             self.outer_cache = ops.PackCache()
-            self.light_exp_max = float(light_exp_max)
+            # 144 inputs = 'sphere_direction' (fields.py:917-928: IDE of the direction | IDE of the point where the ray leaves the unit
+            # sphere; configs/mat/custom/*): evaluated as a composition (encodings in torch, dense layers on tf_linear_fwd), not fused
+            self.outer_sphere = self.outer[0][0].shape[1] == 144
         else:
-            raise NotImplementedError("outer light: a cube map (`outer_light.base`, outer_light_version='envlight') or the 72-input net of "
-                                      "outer_light_version='direction'; 'sphere_direction' (144 inputs, configs/mat/custom) is not built")
+            raise NotImplementedError("outer light: a cube map (`outer_light.base`, 'envlight') or the 72- / 144-input net of 'direction' / "
+                                      "'sphere_direction'")
+        if "human_light.0.bias" in sd:
+            # human_lights (fields.py:727-729, 935-949; configs/mat/custom/*): light reflected off the photo capturer, a 24-256-256-256-4
+            # net on the positional encoding of where a missing ray meets the capturer's plane; blended into the outer light
+            self.human = [(wn_weight(sdd, f"human_light.{i}").contiguous(), sdd[f"human_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
+            if self.outer is None:
+                raise NotImplementedError("human_lights with the cube-map outer light: no shipped config combines them")
         self.flow_d = FlowParams(sd, f"flow_diffuse{flow_suffix}.", device, field_f16=field_f16)
         self.flow_s = FlowParams(sd, f"flow_specular{flow_suffix}.", device, field_f16=field_f16)
         self.inner_cache = ops.PackCache()
@@ -274,7 +284,46 @@ class MCShader:
             self._order[key] = torch.argsort(self.slot_order(sn_d, sn_s).long())
         return self._order[key]
 
-    def trace_and_inner(self, pts_rep, dirs, live=None, slot_order=None, origin_order=None):
+    @staticmethod
+    def _net4(weights, x, exp_max):
+        """A 4-layer predictor (ReLU x 3, exp(min(., exp_max))) on the dense-layer kernels."""
+        for l, (W, b) in enumerate(weights):
+            x = ops.linear_fwd(x, W, b, ops.ACT_RELU if l < 3 else ops.ACT_EXP_CLAMP, exp_max)
+        return x
+
+    def miss_lights_composed(self, origins, dirs, poses):
+        """predict_outer_lights('sphere_direction') / get_human_light + their blend (fields.py:913-949, 962-968) for rays that missed:
+        origins, dirs [n,3], poses [n,3,4] or None -> lights [n,3]."""
+        from .encodings import ide5
+        zero = torch.zeros(dirs.shape[0], 1, device=dirs.device)
+        enc = ide5(dirs, zero, wide=True)
+        if self.outer_sphere:
+            o = origins.clone()
+            far = o.norm(dim=-1) > 0.999
+            o[far] = o[far] * 0.999                                        # (shrink this point a little bit, :922-924)
+            dtx = (o * dirs).sum(-1, keepdim=True)
+            dist = -dtx + torch.sqrt(dtx ** 2 - (o ** 2).sum(-1, keepdim=True) + 1 + 1e-6)       # get_sphere_intersection
+            enc = torch.cat([enc, ide5(o + dirs * dist, zero, wide=True)], -1)
+        outer = self._net4(self.outer, enc.contiguous(), self.light_exp_max)
+        if self.human is None or poses is None:        # (no poses: the outer net alone -- MCShader.lights() on bare rays)
+            return outer
+        R, t = poses[:, :, :3], poses[:, :, 3]
+        p_ = torch.einsum("nij,nj->ni", R, origins) + t
+        d_ = torch.einsum("nij,nj->ni", R, dirs)
+        hits = d_[:, 2].abs() > 1e-4
+        dz = torch.where(hits, d_[:, 2], torch.full_like(d_[:, 2], 1e-4))
+        d_ = torch.cat([d_[:, :2], dz[:, None]], -1)                       # (the reference overwrites the z of the view it divides by)
+        dist = -p_[:, 2] / dz
+        mean = (p_ + dist[:, None] * d_)[:, :2] * 0.3
+        hits = (hits & (mean.norm(dim=-1) < 1.5) & (dist > 0)).float()[:, None]
+        mean = mean * hits
+        scaled = (mean[:, None, :] * (2.0 ** torch.arange(6, device=mean.device))[:, None]).reshape(-1, 12)       # IPE(mean, 0, 0, 6)
+        pe = torch.sin(torch.cat([scaled, scaled + 0.5 * math.pi], -1))
+        h = self._net4(self.human, pe.contiguous(), 0.0) * hits            # ExpActivation(max_light = 0): at most 1
+        hl, hw = h[:, :3], h[:, 3:].clamp(0.0, 1.0)
+        return outer * (1 - hw) + hl * hw
+
+    def trace_and_inner(self, pts_rep, dirs, live=None, slot_order=None, origin_order=None, poses=None):
         """Hit branch of get_lights (fields.py:951-975): BVH visibility + inner-light MLP on the rays that hit.
         -> hit_lights [M,3] (rows of rays that hit; the others are uninitialised), hit = None (a ray hit iff depth < ops.MISS_DEPTH:
         the traversal stores no separate flag byte -- 0.6 ms of scattered one-byte stores per 201 M rays), depth [M], inters [M,3]."""
@@ -299,7 +348,15 @@ class MCShader:
                 if live is not None:
                     miss &= live.reshape(-1).to(torch.uint8)
                 idx_m, count_m = ops.compact_mask(miss)
-                ops.outer_light_indexed(self.outer, dirs, idx_m, count_m, hit_lights, exp_max=self.light_exp_max, cache=self.outer_cache)
+                if not self.outer_sphere and self.human is None:
+                    ops.outer_light_indexed(self.outer, dirs, idx_m, count_m, hit_lights, exp_max=self.light_exp_max, cache=self.outer_cache)
+                else:
+                    # composed variants (configs/mat/custom): one host sync for the count, slices of 2^21 rays to bound the encodings
+                    n, T = int(count_m), dirs.shape[0] // pts_rep.shape[0]
+                    for c0 in range(0, n, 1 << 21):
+                        ids = idx_m[c0:min(c0 + (1 << 21), n)]
+                        org = ids // T if T > 1 else ids
+                        hit_lights[ids] = self.miss_lights_composed(pts_rep[org], dirs[ids], poses[org] if poses is not None else None)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return hit_lights, hit, depth, inters
 
@@ -316,7 +373,7 @@ class MCShader:
         return lights, hit, inters
 
     @torch.no_grad()
-    def shade_fixed(self, pts, view_dirs, normals):
+    def shade_fixed(self, pts, view_dirs, normals, human_poses=None):
         """The non-NIS pass of shade_mixed (nis_sample=False, fields.py:1075-1235 with the `else` samplers): the fixed cosine set
         for the diffuse lobe and the fixed GGX-warped set for the specular lobe (sample_diffuse_directions /
         sample_specular_directions, :824-903).  Same output dict as `shade` (without the flow arrays)."""
@@ -326,14 +383,14 @@ class MCShader:
         metallic, rough, albedo, _, _ = self.point_prep(pts, va)
         dirs, wgt, smask, live = ops.shade_dirs_fixed(normals, view_dirs, metallic, rough, albedo, self.fixed_d, self.fixed_s)
         T, nd, ns = dirs.shape[1], self.fixed_d.shape[0], self.fixed_s.shape[0]
-        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None)
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None, poses=human_poses)
         colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, None, hit_lights, self.env, nd, ns)
         return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                             specular_mask=smask, live=live, view_angles=va, dirs=dirs, wgt=wgt,
                             hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=nd)
 
     @torch.no_grad()
-    def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None):
+    def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None, human_poses=None):
         """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)
         One call at a time per shader: the kernels' workspaces (packed weights, the flows' per-point rows, the traversal's work
         counters) are per device, not per call -- two shade() calls in flight on different streams would share them (measured as
@@ -390,7 +447,7 @@ class MCShader:
         with tm.stage("point_prep"):
             oorder = ops.morton_order(pts, self.aabb) if self.sort_origins and T >= 64 else None
         hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
-                                                              origin_order=oorder)
+                                                              origin_order=oorder, poses=human_poses)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         pending = None
         if self.overlap_reduce:

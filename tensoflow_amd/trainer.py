@@ -59,6 +59,7 @@ def material_param_groups(net, lr_xyz, lr_net, lr_env):
         {"params": list(net.outer_light.parameters()), "lr": lr_env if net.cfg["outer_light_version"] == "envlight" else lr_net},
         {"params": list(net.albedo_predictor.parameters()) + list(net.metallic_predictor.parameters())
                    + list(net.roughness_predictor.parameters()) + list(net.inner_light.parameters()), "lr": lr_net},
+        # (the reference's groups do not list `human_light`: with human_lights=True that net keeps its initial weights, fields.py:1580-1586)
     ]
     groups += net.flow_diffuse.get_optparam_groups(lr_xyz, lr_net)
     groups += net.flow_specular.get_optparam_groups(lr_xyz, lr_net)
@@ -126,14 +127,15 @@ class MaterialTrainer:
         """MCShadingNetwork.update_step (fields.py:1056-1065)."""
         return self.net.update_step(step)
 
-    def train_step(self, pts, view_dirs, normals, target_rgb):
+    def train_step(self, pts, view_dirs, normals, target_rgb, human_poses=None):
         """One iteration of the loop at trainer_inv.py:181-252 on a batch of surface points, with the reference's objective:
-        sum of the means of loss_rgb (charbonier), loss_mat_reg, loss_diffuse_light and 1e-4 loss_nis."""
+        sum of the means of loss_rgb (charbonier), loss_mat_reg, loss_diffuse_light and 1e-4 loss_nis.
+        human_poses [pn,3,4]: the capturer's pose per point (shader_cfg.human_lights, configs/mat/custom)."""
         step = self.step_count
         self.net.train()
         self.optimizer.zero_grad(set_to_none=True)
         self.refresh_flow_copies(step)                                    # MaterialRenderer.train_step calls update_step first (:549)
-        colors, outputs = self.net(pts, view_dirs, normals, None, step, True)
+        colors, outputs = self.net(pts, view_dirs, normals, human_poses, step, True)
         mat_reg = None
         if self.cfg["reg_mat"]:
             mat_reg = self.net.material_regularization(pts, normals, outputs["metallic"], outputs["roughness"], outputs["albedo"], step)

@@ -81,6 +81,29 @@ def test_direction_outer_light(golden):
     assert rel_err(flow["diffuse_light"], g.out["diffuse_light_nis"]) < 5e-5
 
 
+def test_sphere_direction_outer_light_and_human_lights(golden):
+    """The real-capture variant (configs/mat/custom/*.yaml): outer_light_version='sphere_direction' + human_lights=True -- the oracle's
+    miss branch (unit-sphere exit point, capturer-plane intersection, IPE, the blend) against the reference's get_lights / eval forward."""
+    g, base = golden("shading_custom"), golden("shading_grad")
+    sd = {k: v for k, v in base.sd.items() if not k.startswith("outer_light.")}
+    sd.update(g.sd)
+    tr = _tracer(base)
+    unit = float(g["unit_size"])
+    poses = g["human_poses"]
+    lights, hit, _ = osh.get_lights(sd, tr, unit, g["pts"].repeat_interleave(16, 0), g["gl_dirs"], poses=poses.repeat_interleave(16, 0))
+    assert torch.equal(hit, g["gl_hit"].bool())
+    assert rel_err(lights, g["gl_lights"]) < 2e-5
+    hl, hw = osh.human_light(sd, g["pts"].repeat_interleave(16, 0)[~hit], g["gl_dirs"][~hit], poses.repeat_interleave(16, 0)[~hit])
+    assert rel_err(hl * hw, g["gl_human"]) < 1e-5 and int((g["gl_human"].norm(dim=-1) > 0).sum()) > 30      # the capturer is seen
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    fixed = osh.shade(sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs,
+                      use_flow=False, human_poses=poses)
+    assert rel_err(fixed["colors"], g["colors"]) < 2e-5
+    flow = osh.shade(sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs,
+                     use_flow=True, human_poses=poses)
+    assert rel_err(flow["colors"], g.out["rgb_pr_nis"]) < 5e-5
+
+
 def test_cpu_bvh_equals_brute_force():
     """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
     unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along

@@ -697,6 +697,105 @@ def gen_shading_direction():
     save("shading_direction", sd=changed, **arr)       # the rest of the state and the mesh: shading_grad.npz
 
 
+def gen_shading_custom():
+    """The real-capture variant of the material shader (configs/mat/custom/*.yaml): outer_light_version='sphere_direction' (144-input
+    net: IDE of the direction | IDE of the unit-sphere exit point) + human_lights=True (the capturer's reflection, blended into the
+    outer light of the rays that miss).  Network of `shading_grad` (same sizes); the two light nets trained for 300 Adam steps on
+    synthetic targets so that they answer with a spread of values; per-point human poses = random rigid transforms that put the
+    capturer's plane in front of the object.  Stored: the tensors that differ from shading_grad.npz, the poses, eval forward (fixed +
+    flow pass), get_lights on random rays, gradients of the fixed pass (step 100) and of the flow pass (step 1200)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, (o + 2 * unit * d).detach(), d.detach())
+    torch.manual_seed(4)
+    cfg = dict(outer_light_version="sphere_direction", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=True,
+               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+               nis_specular_sample_num=8)
+    net = MCShadingNetwork(cfg, trace, AABB)
+    base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
+    net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(base[f"mat_plane.{i}"].clone()) for i in range(3)])
+    net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(base[f"mat_line.{i}"].clone()) for i in range(3)])
+    own = net.state_dict()
+    own.update({k: v for k, v in base.items() if k in own})
+    net.load_state_dict(own)
+    g = torch.Generator().manual_seed(17)
+    pn = 40
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
+    # human poses [pn,3,4]: x_h = R x + t; the capturer's plane z_h = 0 sits 2.5 units from the origin, looking at it
+    def rand_pose(n):
+        q = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)                  # direction to the capturer
+        up = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+        xa = torch.nn.functional.normalize(torch.cross(up, q, dim=-1), dim=-1)
+        ya = torch.cross(q, xa, dim=-1)
+        Rm = torch.stack([xa, ya, q], 1)                                                            # rows: the capturer's axes
+        t = -(Rm @ (2.5 * q)[:, :, None])[..., 0]
+        return torch.cat([Rm, t[:, :, None]], -1)
+    poses = rand_pose(pn)
+    sun = torch.nn.functional.normalize(torch.tensor([0.5, -0.3, 0.8]), dim=0)
+    sky = lambda d: -1.0 + 2.2 * torch.exp(-6.0 * (1.0 - d @ sun))[:, None] + 0.6 * d[:, 2:3] * torch.tensor([1.0, 0.9, 0.7])
+    prm = list(net.outer_light.parameters()) + list(net.human_light.parameters())
+    m1, m2 = [torch.zeros_like(p) for p in prm], [torch.zeros_like(p) for p in prm]
+    for it in range(300):          # Adam written out (see gen_shading_direction)
+        d = torch.nn.functional.normalize(torch.randn(1024, 3, generator=g), dim=-1)
+        o = 0.6 * torch.nn.functional.normalize(torch.randn(1024, 3, generator=g), dim=-1)
+        ps = rand_pose(1024)
+        outer = net.predict_outer_lights(o, d)
+        hl, hw = net.get_human_light(o, d, ps)
+        # targets: the sky for the outer net; a bright disc (weight 0.8 inside radius 0.5 of the plane's centre) for the capturer
+        inter = (ps[:, :, :3] @ o[:, :, None] + ps[:, :, 3:])[..., 0]
+        loss = ((outer.log() - sky(d)) ** 2).mean() + ((net.human_light(torch.zeros(1, 24))[:, 3:] - 0.6) ** 2).mean()
+        loss = loss + ((hl - 0.5 * hw.detach()) ** 2).mean() + 0.0 * inter.sum()
+        grads = torch.autograd.grad(loss, prm, allow_unused=True)
+        with torch.no_grad():
+            for p_, g_, a_, b_ in zip(prm, grads, m1, m2):
+                if g_ is None:
+                    continue
+                a_.mul_(0.9).add_(g_, alpha=0.1)
+                b_.mul_(0.999).addcmul_(g_, g_, value=0.001)
+                p_.sub_(2e-3 * (a_ / (1 - 0.9 ** (it + 1))) / ((b_ / (1 - 0.999 ** (it + 1))).sqrt() + 1e-8))
+    net.zero_grad()
+    changed = {k: v for k, v in net.state_dict().items() if k not in base}
+    assert all(k.startswith("outer_light.") or k.startswith("human_light.") for k in changed), list(changed)
+    net.eval()
+    w = torch.rand(pn, 3, generator=g)
+    arr = dict(pts=pts, view_in=view, normals_in=nrm, bwd_w=w, human_poses=poses, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32))
+    with torch.no_grad():
+        colors, outputs = net(pts, view, nrm, poses, None, False)
+        dirs = torch.nn.functional.normalize(torch.randn(pn * 16, 3, generator=g), dim=-1)
+        lights, hlw, inters, lnrm, hit = net.get_lights(pts.repeat_interleave(16, 0), dirs, poses.repeat_interleave(16, 0))
+    miss = ~hit
+    hlw_n = hlw.norm(dim=-1)
+    print("miss rays", int(miss.sum()), "of", hit.numel(), "; capturer seen by", int((hlw_n > 0).sum()), "of them; human term mean %.4f max %.4f" % (
+        float(hlw_n.mean()), float(hlw_n.max())), "; log-radiance of misses: std %.3f" % float(lights[miss].log().std()))
+    keep = ("albedo", "roughness", "metallic", "diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility",
+            "indirect_light", "rgb_pr_nis", "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis",
+            "diffuse_light_nis", "specular_light_nis")
+    arr.update({"out/" + k: outputs[k] for k in keep})
+    arr.update(colors=colors, gl_dirs=dirs, gl_lights=lights, gl_hit=hit, gl_human=hlw)
+    net.zero_grad()
+    c, o = net(pts, view, nrm, poses, 100, False)
+    ((c * w).sum() + o["loss_nis"]).backward()
+    arr.update({"colors_100": c})
+    arr.update({"grad100/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and (k.startswith("outer_light") or k.startswith("human_light") or k.startswith("mat_line") or k.startswith("roughness_predictor.2"))})
+    for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
+        for p in fl.parameters():
+            p.requires_grad = False
+    net.use_flow_diffuse_copy = net.use_flow_specular_copy = True
+    net.zero_grad()
+    c, o = net(pts, view, nrm, poses, 1200, False)
+    ((c * w).sum() + o["loss_nis"]).backward()
+    arr.update({"colors_1200": c, "loss_nis_1200": o["loss_nis"]})
+    arr.update({"grad1200/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and (k.startswith("outer_light") or k.startswith("human_light") or k.startswith("mat_line"))})
+    print("grads:", sum(k.startswith("grad100/") for k in arr), sum(k.startswith("grad1200/") for k in arr))
+    save("shading_custom", sd=changed, **arr)
+
+
 def gen_march_grad():
     """Geometry-only training direction of the ray-march: loss over compute_sdf_alpha + nerfacc compositing outputs
     (shapeRenderer.py:995-1025, :1166-1206); gradients of the SDF field, decoder and variance from the reference autograd."""
