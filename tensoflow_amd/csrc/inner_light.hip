@@ -1162,7 +1162,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     if (live) {
       il3_bias(lbias + hh * 256, T0, acc);
 #ifndef IL3_ABLATE_M    // dev-only timing ablation: no matrix products
-      il3_layer<8>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
+      // (the direction-encoded outer net has 72 input columns: five k-steps, the rest of its image is zero)
+      il3_layer<OUTER ? 5 : 8>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
 #endif
     }
     if (it >= 1 && w < 2 && hh_o == w) {
