@@ -222,8 +222,8 @@ class CompositeFn(torch.autograd.Function):
     def backward(ctx, g_w, g_acc, g_out):
         alpha, values, w, ridx = ctx.saved_tensors
         # gradient arriving directly on the per-sample weights is folded in as an extra value channel of ones
-        if g_w is not None and bool((g_w != 0).any()):
-            raise RuntimeError("CompositeFn: gradients wrt the per-sample weights are not supported; use acc / out")
+        if g_w is not None:          # (checked on the device: no host sync in the training step)
+            torch._assert_async((g_w == 0).all(), "CompositeFn: gradients wrt the per-sample weights are not supported; use acc / out")
         a, v = alpha.detach(), values.detach()
         ga, gvs = None, []
         for c0 in range(0, v.shape[1], 8):

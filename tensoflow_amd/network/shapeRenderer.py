@@ -72,6 +72,8 @@ class ShapeRenderer(nn.Module):
         self.aabb = torch.tensor(aabb.cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb, dtype=torch.float32, device=self.device)
         self.center = self.aabb.mean(0).float().view(1, 1, 3)
         self.radius = (self.aabb[1] - self.center).mean().float()
+        # host copies of the scalars the kernels take by value: read once here, not by a device sync in every step
+        self._aabb_cpu, self._radius_f = self.aabb.cpu(), float(self.radius)
         self.alphaMask = None
         # use_occ_grid (configs/shape/syn/compressor_occ.yaml:21; shapeRenderer.py:213-216): the build's own occupancy grid in the
         # role of nerfacc.OccGridEstimator -- EMA occupancy state on the device, sampling by tf_march_uniform (march.OccGrid)
@@ -104,6 +106,7 @@ class ShapeRenderer(nn.Module):
         self.units = self.aabbSize / (self.gridSize - 1)
         self.stepSize = torch.mean(self.units) * self.step_ratio
         self.base_radii = self.aabbSize[0] / 2.0 / self.gridSize[0]
+        self._units_f, self._base_radii_f = [float(u) for u in self.units], float(self.base_radii)
         self.nSamples = self.cfg["n_samples"] + self.cfg["n_importance"]
 
     def get_kwargs(self):
@@ -160,10 +163,10 @@ class ShapeRenderer(nn.Module):
         f = march.SdfField.__new__(march.SdfField)
         f.planes, f.lines = [p.detach() for p in net.sdf_plane], [p.detach() for p in net.sdf_line]
         f.W = [w.detach() for w in net._w()]
-        f.aabb = self.aabb.cpu()
+        f.aabb = self._aabb_cpu
         f.aabb_dev = self.aabb
         f.grid_size = self.gridSize.float().cpu()
-        f.units = [float(u) for u in self.units]
+        f.units = list(self._units_f)
         f.n_levels = self.max_levels
         f.device = self.device
         f.packed = net._field()
@@ -173,7 +176,7 @@ class ShapeRenderer(nn.Module):
         return self.deviation_network.inv_s().clip(1e-6, 1e6)
 
     def near_far_from_sphere(self, rays_o, dirs):
-        return march.near_far_from_sphere(rays_o, dirs, float(self.radius))
+        return march.near_far_from_sphere(rays_o, dirs, self._radius_f)
 
     @staticmethod
     def compute_ball_radii(distance, radiis, cos):
@@ -208,7 +211,7 @@ class ShapeRenderer(nn.Module):
         clip_sample_variance: the up-sampling sharpness 64 * 2^i is capped by the learned inv_s (:905-907)."""
         t_rand = (torch.rand(rays_o.shape[0], 1, device=rays_o.device) - 0.5) if perturb > 0 else None
         cap = float(self._inv_s()) if self.cfg["clip_sample_variance"] else None
-        return march.sample_ray(self._field(), rays_o, dirs, near, far, radiis, rays_cos, float(self.base_radii),
+        return march.sample_ray(self._field(), rays_o, dirs, near, far, radiis, rays_cos, self._base_radii_f,
                                 n_samples=self.cfg["n_samples"], n_importance=self.cfg["n_importance"],
                                 up_steps=self.cfg["up_sample_steps"], t_rand=t_rand, inv_s_cap=cap)
 
@@ -223,14 +226,14 @@ class ShapeRenderer(nn.Module):
         if self.cfg["freeze_inv_s_step"] is not None and step is not None and step < self.cfg["freeze_inv_s_step"]:
             inv_s = inv_s.detach()
         lv = None if level is None else level.reshape(-1).contiguous()
-        units = [float(u) for u in self.units]
+        units = list(self._units_f)
         if torch.is_grad_enabled() and any(p.requires_grad for p in list(net.parameters()) + [self.deviation_network.variance]):
             alpha, grad, feat, sdf, nh = SdfAlphaFn.apply(points.contiguous(), lv, dists.contiguous(), dirs.contiguous(), inv_s,
-                                                          float(cos_anneal_ratio), self.aabb.cpu(), units, self.max_levels,
+                                                          float(cos_anneal_ratio), self._aabb_cpu, units, self.max_levels,
                                                           *net.sdf_plane, *net.sdf_line, *net._w())
         else:
             alpha, grad, feat, sdf, nh = ops.sdf_alpha(net._field(), *[w.detach() for w in net._w()], points, lv, dists, dirs,
-                                                       self.aabb.cpu(), units, float(inv_s), float(cos_anneal_ratio), want_hess=is_train)
+                                                       self._aabb_cpu, units, float(inv_s), float(cos_anneal_ratio), want_hess=is_train)
         return alpha, grad, feat, inv_s.expand(N), sdf, (nh if is_train else None)
 
     def render(self, ray_batch, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True, step=None):

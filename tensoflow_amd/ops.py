@@ -31,8 +31,21 @@ def _p(t, dtype=torch.float32, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
+_AABB_HOST = {}
+
+
 def _aabb6(aabb):
-    a = torch.as_tensor(aabb, dtype=torch.float32).reshape(-1).cpu().tolist()
+    """The box as six host floats (a kernel argument by value).  A box that lives on the device is read back ONCE per (storage, version):
+    every call used to be a device sync -- 14 of them in a shape-stage training step."""
+    if torch.is_tensor(aabb) and aabb.is_cuda:
+        key = (aabb.data_ptr(), aabb._version, aabb.device.index)
+        a = _AABB_HOST.get(key)
+        if a is None:
+            if len(_AABB_HOST) > 64:
+                _AABB_HOST.clear()
+            a = _AABB_HOST[key] = aabb.detach().float().reshape(-1).cpu().tolist()
+    else:
+        a = torch.as_tensor(aabb, dtype=torch.float32).reshape(-1).tolist()
     return (C.c_float * 6)(*a)
 
 
