@@ -620,6 +620,8 @@ def gen_shading_direction():
     sky = lambda d: -1.0 + 2.2 * torch.exp(-6.0 * (1.0 - d @ sun))[:, None] + 0.6 * d[:, 2:3] * torch.tensor([1.0, 0.9, 0.7])
     prm = list(net.outer_light.parameters())
     m1, m2 = [torch.zeros_like(p) for p in prm], [torch.zeros_like(p) for p in prm]
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(1)       # the fit on ONE thread: a multi-threaded reduction order would make the trained weights differ from run to run
     for it in range(400):          # Adam written out (torch.optim pulls in modules the import shim cannot inspect)
         d = torch.nn.functional.normalize(torch.randn(2048, 3, generator=g), dim=-1)
         loss = ((net.predict_outer_lights_pts(d).log() - sky(d)) ** 2).mean()
@@ -629,6 +631,7 @@ def gen_shading_direction():
                 a_.mul_(0.9).add_(g_, alpha=0.1)
                 b_.mul_(0.999).addcmul_(g_, g_, value=0.001)
                 p_.sub_(2e-3 * (a_ / (1 - 0.9 ** (it + 1))) / ((b_ / (1 - 0.999 ** (it + 1))).sqrt() + 1e-8))
+    torch.set_num_threads(n_thr)
     print("outer net fitted: log-radiance mse %.4f" % float(loss))
     net.zero_grad()
     changed = {k: v for k, v in net.state_dict().items() if k not in base}
@@ -741,6 +744,8 @@ def gen_shading_custom():
     sky = lambda d: -1.0 + 2.2 * torch.exp(-6.0 * (1.0 - d @ sun))[:, None] + 0.6 * d[:, 2:3] * torch.tensor([1.0, 0.9, 0.7])
     prm = list(net.outer_light.parameters()) + list(net.human_light.parameters())
     m1, m2 = [torch.zeros_like(p) for p in prm], [torch.zeros_like(p) for p in prm]
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(1)       # (one thread: reproducible weights, see gen_shading_direction)
     for it in range(300):          # Adam written out (see gen_shading_direction)
         d = torch.nn.functional.normalize(torch.randn(1024, 3, generator=g), dim=-1)
         o = 0.6 * torch.nn.functional.normalize(torch.randn(1024, 3, generator=g), dim=-1)
@@ -759,6 +764,7 @@ def gen_shading_custom():
                 a_.mul_(0.9).add_(g_, alpha=0.1)
                 b_.mul_(0.999).addcmul_(g_, g_, value=0.001)
                 p_.sub_(2e-3 * (a_ / (1 - 0.9 ** (it + 1))) / ((b_ / (1 - 0.999 ** (it + 1))).sqrt() + 1e-8))
+    torch.set_num_threads(n_thr)
     net.zero_grad()
     changed = {k: v for k, v in net.state_dict().items() if k not in base}
     assert all(k.startswith("outer_light.") or k.startswith("human_light.") for k in changed), list(changed)
