@@ -965,7 +965,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["tensosdf", "pwquad", "flow", "encodings", "shading", "march", "refine", "shading_grad", "march_grad", "march_late"]
+    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
