@@ -42,6 +42,98 @@ MARCH_BYTES_PER_SAMPLE = 18_144   # 7 evals x 18 texels x 36 ch 
 MARCH_FLOP_PER_SAMPLE = 466_944
 
 
+def _sanitise(x, digits=6):
+    """Strict-JSON values: non-finite floats -> None, floats rounded to `digits` significant digits, numpy / torch scalars -> Python."""
+    if isinstance(x, dict):
+        return {str(k): _sanitise(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sanitise(v, digits) for v in x]
+    if isinstance(x, (bool, str)) or x is None:
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if not math.isfinite(x):
+            return None
+        return float(f"{x:.{digits}g}")
+    if hasattr(x, "item"):
+        return _sanitise(x.item(), digits)
+    return str(x)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+COMPACT_LIMIT = 3072
+
+
+def compact_line(line):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline` + a few headline secondaries, strict JSON,
+    under COMPACT_LIMIT bytes.  Everything else (per-stage times, probes, the per-outlier re-evaluation) goes to the detail
+    object (stderr + gpurun_out/bench_detail.json), never to this line: round 3's 21 KB line did not reach the driver's record."""
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    cfg = line.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "points_per_gpu_per_step", "points_per_shade_call", "mesh_triangles", "hit_fraction",
+                                "live_ray_fraction", "aux_outputs", "parallelism"))
+    if isinstance(out["config"].get("workload"), str):
+        out["config"]["workload"] = out["config"]["workload"][:200]
+    if isinstance(line.get("roofline"), dict):
+        out["roofline"] = _pick(line["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                                   "executed_tflops", "frac_executed"))
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(out["cpu_baseline"].get("sample"), str):
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:200]
+    ps = line.get("psnr")
+    if isinstance(ps, dict):
+        out["psnr"] = _pick(ps, ("value_db", "points", "tolerance", "frac_points_within_tolerance", "max_rel_err", "outliers_explained"))
+    sec = {}
+    for key, fields in (("flow_only", ("points_per_s",)), ("train", ("ms_per_step",)), ("train_dp", ("ms_per_step", "ranks")),
+                        ("shape_train", ("ms_per_step",)), ("march", ("rays_per_s", "sdf_alpha_samples_per_s", "algorithmic_frac_of_hbm_peak")),
+                        ("config3_flow256", ("points_per_s",)), ("config4_frame512", ("ms_per_frame",))):
+        v = line.get(key)
+        if isinstance(v, dict):
+            got = _pick(v, fields + ("error",))
+            if "error" in got:
+                got["error"] = str(got["error"])[:80]
+            if got:
+                sec[key] = got
+    if sec:
+        out["secondary"] = sec
+    st = line.get("stages_ms_per_step")
+    if isinstance(st, dict):
+        out["stages_ms_per_step"] = dict(list(st.items())[:6])
+    out["detail"] = "stderr + gpurun_out/bench_detail.json"
+    out = _sanitise(out)
+    text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    for drop in ("stages_ms_per_step", "secondary", "psnr"):          # never over the limit, whatever the probes returned
+        if len(text) < COMPACT_LIMIT:
+            break
+        out.pop(drop, None)
+        text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def emit(line):
+    """Detail object -> stderr and gpurun_out/bench_detail.json; the compact line -> stdout, last, flushed, nothing after it."""
+    detail = json.dumps(_sanitise(line, digits=9), allow_nan=False)
+    try:
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    sys.stderr.write("BENCH_DETAIL " + detail + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(compact_line(line) + "\n")
+    sys.stdout.flush()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
     are collected in separate --pmc runs of this same command, tools/collect_profiles.sh; FETCH_SIZE doubled as
@@ -941,7 +1033,7 @@ def main():
             line["cpu_baseline"], line["psnr"] = cpu_baseline(sd, verts, faces, aabb, unit, 16384, S, sh=sh)
             if "march" in line:
                 line["march"]["cpu_baseline"] = march_cpu_baseline()
-        print(json.dumps(line))
+        emit(line)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,65 @@
+"""The driver parses ONE stdout line of bench.py; round 3's 21 KB line did not reach its record (BENCH_r03.parsed = null).
+The final line is built by bench.compact_line from the detail object: strict JSON, < 3 KB, whatever the probes returned."""
+import json
+import math
+import os
+
+import bench
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _canned():
+    with open(os.path.join(REPO, "profiles", "r3d_bench_line.json")) as f:
+        return json.load(f)
+
+
+def _strict(text):
+    def bad(c):
+        raise ValueError(c)
+    return json.loads(text, parse_constant=bad)
+
+
+def test_compact_line_is_short_strict_json_with_the_contract_keys():
+    line = _canned()
+    assert len(json.dumps(line)) > 10000                      # the canned detail object is the 21 KB one
+    text = bench.compact_line(line)
+    assert "\n" not in text and len(text) < 3072
+    got = _strict(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert "workload" in got["config"] and "model" not in got["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in got["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert abs(got["value"] - line["value"]) <= 1e-5 * line["value"]
+    assert abs(got["roofline"]["frac"] - got["roofline"]["achieved"] / got["roofline"]["peak"]) < 1e-4
+
+
+def test_compact_line_survives_non_finite_values_and_failed_probes():
+    line = _canned()
+    line["roofline"]["traffic"] = float("nan")
+    line["psnr"]["value_db"] = float("inf")
+    line["train"] = {"error": "RuntimeError: " + "x" * 5000}
+    line["config"]["workload"] = "w" * 5000
+    line["cpu_baseline"]["sample"] = "s" * 5000
+    line["stages_ms_per_step"] = {f"stage{i}": float(i) for i in range(400)}
+    text = bench.compact_line(line)
+    assert len(text) < 3072
+    got = _strict(text)
+    assert got["roofline"]["traffic"] is None and got["psnr"]["value_db"] is None
+    assert math.isfinite(got["value"])
+
+
+def test_emit_prints_exactly_one_stdout_line(capsys, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    bench.emit(_canned())
+    cap = capsys.readouterr()
+    lines = cap.out.splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 3072
+    assert _strict(lines[0])["metric"].startswith("shaded surface points/s")
+    assert cap.err.startswith("BENCH_DETAIL ")
+    _strict(cap.err[len("BENCH_DETAIL "):])
+    _strict(open(tmp_path / "gpurun_out" / "bench_detail.json").read())
