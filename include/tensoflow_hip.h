@@ -487,6 +487,19 @@ int tf_shade_reduce_env(const float* wgt, const float* dirs, const float* depth,
                         float* colors, float* diffuse_lin, float* specular_lin,
                         const int32_t* slot_of_pos /* as tf_shade_dirs: the lobe of row j is that of slot slot_of_pos[j]; or NULL */,
                         tf_stream_t stream);
+/* The same reduction plus the per-point statistics behind the REST of shade_mixed's output dict (fields.py:1232-1256, :1288-1291):
+ * aux [pn,16] = { sum of the diffuse rays' lights [3] (-> diffuse_light :1242, approximate_light :1248), sum of the unmasked specular
+ * rays' lights [3] (-> specular_light :1230/:1243), the same over rays that hit the mesh [3] and their count (-> indirect_light :1229,
+ * visibility :1228), then count / mean / sum of squared deviations of g = mean_c(fx_c) / max(p, 1e-6) over the unmasked specular rays
+ * (-> variance :1289, variance_specular_vis :1291) and mean / sum of squared deviations of g over the n_diffuse diffuse rays
+ * (-> variance_diffuse_vis :1256), one pad }.  EVERY ray's light enters (zero weight or not): call it on rays traced without the
+ * zero-weight culling.  `lights` [pn,T,3] non-NULL: the light of every ray is given (training composition) and hit / depth only
+ * supply the hit flags; NULL: as tf_shade_reduce_env.  spec_mask [pn,ss] = tf_shade_dirs' mask.  colors / diffuse_lin /
+ * specular_lin may be NULL. */
+int tf_shade_reduce_aux(const float* wgt, const float* lights, const float* dirs, const float* depth, const uint8_t* hit,
+                        const float* hit_lights, const float* env_base, int32_t env_res, float near_eps, const uint8_t* spec_mask,
+                        int64_t pn, int32_t n_diffuse, int32_t ss, float* colors, float* diffuse_lin, float* specular_lin,
+                        float* aux, const int32_t* slot_of_pos, tf_stream_t stream);
 /* n_diffuse = sd + nf.  diffuse_lin / specular_lin [pn,3] may be NULL. */
 int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);

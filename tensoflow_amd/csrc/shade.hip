@@ -365,6 +365,123 @@ extern "C" int tf_shade_reduce_env(const float* wgt, const float* dirs, const fl
   return TF_OK;
 }
 
+// The reduction WITH the auxiliary per-point statistics of shade_mixed's output dict (fields.py:1232-1256, :1288-1291): besides the
+// colour sums, per point
+//   aux[0..2]  sum of the lights of the n_diff diffuse rays                     -> diffuse_light, approximate_light
+//   aux[3..5]  sum of the lights of the UNMASKED specular rays                  -> specular_light
+//   aux[6..8]  the same restricted to rays that hit the mesh, aux[9] their count -> indirect_light, visibility
+//   aux[10..12] count, mean, M2 (sum of squared deviations) of g = mean_c(fx_c) / p over the unmasked specular rays
+//   aux[13..14] mean, M2 of g over the n_diff diffuse rays                      -> variance, variance_{diffuse,specular}_vis
+// (Welford per lane, Chan's merge across the wave: the reference's E[g^2] - E[g]^2 cancels in fp32, this does not.)  Every ray's
+// light is evaluated, zero weight or not: the unweighted maps average over all of them.  `lights` [pn,T,3] non-NULL: the light
+// array is given (training composition); NULL: hit rows from hit_lights, missing rays from the cube map as in shade_reduce_env.
+__device__ __forceinline__ void welford_add(float& n, float& mean, float& m2, float g) {
+  n += 1.f;
+  const float dl = g - mean;
+  mean += dl / n;
+  m2 += dl * (g - mean);
+}
+__device__ __forceinline__ void welford_merge_wave(float& n, float& mean, float& m2) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), qb = __shfl_xor(m2, o);
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float dl = mb - mean;
+      mean += dl * (nb / nt);
+      m2 += qb + dl * dl * (n * nb / nt);
+    }
+    n = nt;
+  }
+}
+
+__global__ void __launch_bounds__(256) shade_reduce_aux_kernel(const float* __restrict__ wgt, const float* __restrict__ lights,
+                                                               const float* __restrict__ dirs, const float* __restrict__ depth,
+                                                               const unsigned char* __restrict__ hit, const float* __restrict__ hit_lights,
+                                                               const float* __restrict__ env, int env_res, float near_eps,
+                                                               const unsigned char* __restrict__ spec_mask, long long pn, int n_diff, int ss,
+                                                               float* __restrict__ colors, float* __restrict__ diffuse_lin,
+                                                               float* __restrict__ specular_lin, float* __restrict__ aux,
+                                                               const int* __restrict__ slot_of_pos) {
+  const int lane = threadIdx.x & 63;
+  const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= pn) return;
+  const int T = n_diff + ss;
+  float d[3] = {0, 0, 0}, s[3] = {0, 0, 0}, sd_[3] = {0, 0, 0}, ss_[3] = {0, 0, 0}, si_[3] = {0, 0, 0};
+  float nhit = 0.f, n_s = 0.f, mean_s = 0.f, m2_s = 0.f, n_d = 0.f, mean_d = 0.f, m2_d = 0.f;
+  const float gd = (float)n_diff / 3.f, gs = (float)ss / 3.f;      // wgt = (fx / p) / count per channel: g = mean over channels x count
+  for (int t = lane; t < T; t += 64) {
+    const long long r = pt * T + t, e = r * 3;
+    const F3 w = ld3(wgt + e);
+    const float dr = depth ? depth[r] : 0.f;
+    const bool hr = hit ? hit[r] != 0 : dr < TF_MISS_DEPTH;
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    if (lights) {
+      const F3 l = ld3(lights + e);
+      l0 = l.x; l1 = l.y; l2 = l.z;
+    } else if (hr || !env) {
+      const F3 hl = ld3(hit_lights + e);
+      l0 = hl.x; l1 = hl.y; l2 = hl.z;
+    } else if (dr > near_eps) {
+      const F3 dd = ld3(dirs + e);
+      cube_fetch_rgb(env, env_res, dd.x, dd.y, dd.z, l0, l1, l2);
+      l0 = fast_exp(l0); l1 = fast_exp(l1); l2 = fast_exp(l2);
+    }
+    const float c0 = w.x * l0, c1 = w.y * l1, c2 = w.z * l2;
+    const int slot = slot_of_pos ? slot_of_pos[t] : t;
+    if (slot < n_diff) {
+      d[0] += c0; d[1] += c1; d[2] += c2;
+      sd_[0] += l0; sd_[1] += l1; sd_[2] += l2;
+      welford_add(n_d, mean_d, m2_d, (c0 + c1 + c2) * gd);
+    } else {
+      s[0] += c0; s[1] += c1; s[2] += c2;
+      if (spec_mask[pt * ss + (slot - n_diff)]) {
+        ss_[0] += l0; ss_[1] += l1; ss_[2] += l2;
+        if (hr) { si_[0] += l0; si_[1] += l1; si_[2] += l2; nhit += 1.f; }
+        welford_add(n_s, mean_s, m2_s, (c0 + c1 + c2) * gs);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      d[k] += __shfl_xor(d[k], o); s[k] += __shfl_xor(s[k], o);
+      sd_[k] += __shfl_xor(sd_[k], o); ss_[k] += __shfl_xor(ss_[k], o); si_[k] += __shfl_xor(si_[k], o);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nhit += __shfl_xor(nhit, o);
+  welford_merge_wave(n_s, mean_s, m2_s);
+  welford_merge_wave(n_d, mean_d, m2_d);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (colors) colors[3 * pt + k] = srgb(d[k] + s[k]);
+      if (diffuse_lin) diffuse_lin[3 * pt + k] = d[k];
+      if (specular_lin) specular_lin[3 * pt + k] = s[k];
+      aux[16 * pt + k] = sd_[k]; aux[16 * pt + 3 + k] = ss_[k]; aux[16 * pt + 6 + k] = si_[k];
+    }
+    aux[16 * pt + 9] = nhit; aux[16 * pt + 10] = n_s; aux[16 * pt + 11] = mean_s; aux[16 * pt + 12] = m2_s;
+    aux[16 * pt + 13] = mean_d; aux[16 * pt + 14] = m2_d; aux[16 * pt + 15] = 0.f;
+  }
+}
+
+extern "C" int tf_shade_reduce_aux(const float* wgt, const float* lights, const float* dirs, const float* depth, const uint8_t* hit,
+                                   const float* hit_lights, const float* env_base, int32_t env_res, float near_eps,
+                                   const uint8_t* spec_mask, int64_t pn, int32_t n_diffuse, int32_t ss, float* colors,
+                                   float* diffuse_lin, float* specular_lin, float* aux, const int32_t* slot_of_pos, tf_stream_t stream) {
+  TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0 && (env_res > 0 || !env_base), TF_ESHAPE, "tf_shade_reduce_aux: negative size / env_res <= 0");
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(wgt && aux && (ss == 0 || spec_mask), TF_EINVAL, "tf_shade_reduce_aux: null pointer");
+  TF_REQUIRE(lights || (dirs && depth && hit_lights), TF_EINVAL, "tf_shade_reduce_aux: either `lights` or (dirs, depth, hit_lights)");
+  TF_REQUIRE(!lights || hit || depth, TF_EINVAL, "tf_shade_reduce_aux: with `lights`, the hit flags come from `hit` or `depth`");
+  shade_reduce_aux_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(wgt, lights, dirs, depth, hit, hit_lights, env_base, env_res,
+                                                                            near_eps, spec_mask, pn, n_diffuse, ss, colors, diffuse_lin,
+                                                                            specular_lin, aux, slot_of_pos);
+  TF_LAUNCH_CHECK("tf_shade_reduce_aux");
+  return TF_OK;
+}
+
 extern "C" int tf_view_angles(const float* normals, const float* view, int64_t pn, float* view_angles, tf_stream_t stream) {
   TF_REQUIRE(pn >= 0, TF_ESHAPE, "tf_view_angles: pn < 0");
   if (pn == 0) return TF_OK;

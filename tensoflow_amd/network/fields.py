@@ -314,7 +314,7 @@ class MCShadingNetwork(nn.Module):
 
     def predict_outer_lights_pts(self, pts):
         """fields.py:1512-1520."""
-        if self.cfg["outer_light_version"] == "direction":
+        if self.cfg["outer_light_version"] != "envlight":          # 'sphere_direction' feeds the direction's IDE twice (:1515-1516)
             return self._outer_mlp(pts)
         return self.outer_light.direct_light(pts)
 

@@ -115,7 +115,7 @@ class MaterialRenderer(nn.Module):
     def test_step(self, index):
         """materialRenderer.py:568-640, reduced to what the validation metrics read: the rendered and the ground-truth image."""
         i = self.test_ids[index]
-        h, w = self.database.H, self.database.W
+        h, w = self.database.get_image(i).shape[:2]       # as the reference (materialRenderer.py:583): TensoIRDatabase keeps H / W as floats
         img = self.nvs(self.database.get_pose(i)[:3], self.database.get_K(i), h, w)
         return {"rgb_pr": torch.from_numpy(img["color"]), "rgb_gt": torch.from_numpy(self.database.get_image(i).astype(np.float32) / 255.0),
                 "gt_mask": torch.from_numpy(self.database.get_mask(i) > 0)[..., None], **{k: torch.from_numpy(v) for k, v in img.items() if k != "color"}}

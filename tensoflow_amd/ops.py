@@ -35,15 +35,17 @@ _AABB_HOST = {}
 
 
 def _aabb6(aabb):
-    """The box as six host floats (a kernel argument by value).  A box that lives on the device is read back ONCE per (storage, version):
-    every call used to be a device sync -- 14 of them in a shape-stage training step."""
+    """The box as six host floats (a kernel argument by value).  A box that lives on the device is read back ONCE per tensor OBJECT and
+    version: every call used to be a device sync -- 14 of them in a shape-stage training step.  The cache entry holds the tensor itself
+    (its storage stays alive, so the allocator cannot hand the same address to another box) and is valid only for that very object at
+    that version; a raw (data_ptr, version) key does not identify a tensor (advisor, round 3)."""
     if torch.is_tensor(aabb) and aabb.is_cuda:
-        key = (aabb.data_ptr(), aabb._version, aabb.device.index)
-        a = _AABB_HOST.get(key)
-        if a is None:
+        ent = _AABB_HOST.get(id(aabb))
+        if ent is None or ent[0] is not aabb or ent[1] != aabb._version:
             if len(_AABB_HOST) > 64:
                 _AABB_HOST.clear()
-            a = _AABB_HOST[key] = aabb.detach().float().reshape(-1).cpu().tolist()
+            ent = _AABB_HOST[id(aabb)] = (aabb, aabb._version, aabb.detach().float().reshape(-1).cpu().tolist())
+        a = ent[2]
     else:
         a = torch.as_tensor(aabb, dtype=torch.float32).reshape(-1).tolist()
     return (C.c_float * 6)(*a)
@@ -882,6 +884,29 @@ def shade_reduce_env(wgt, dirs, depth, hit_u8, hit_lights, env_base, n_diffuse, 
                                     _p(slot_of_pos, torch.int32), _stream()),
             "tf_shade_reduce_env")
     return colors, dl, sl
+
+
+def shade_reduce_aux(wgt, spec_mask, n_diffuse, ss, lights=None, dirs=None, depth=None, hit_u8=None, hit_lights=None, env_base=None,
+                     near_eps=1e-5, slot_of_pos=None, want_colors=True):
+    """tf_shade_reduce_aux: the reduction plus the per-point statistics behind the rest of shade_mixed's output dict
+    -> (colors, diffuse_lin, specular_lin, aux [pn,16]).  Either `lights` [pn,T,3] (and hit flags from hit_u8 / depth) or the
+    (dirs, depth, hit_lights, env_base) set of shade_reduce_env."""
+    lib = L.load()
+    pn = wgt.shape[0]
+    dev = wgt.device
+    colors = torch.empty(pn, 3, dtype=torch.float32, device=dev) if want_colors else None
+    dl = torch.empty(pn, 3, dtype=torch.float32, device=dev) if want_colors else None
+    sl = torch.empty(pn, 3, dtype=torch.float32, device=dev) if want_colors else None
+    aux = torch.empty(pn, 16, dtype=torch.float32, device=dev)
+    env_base = _f(env_base) if env_base is not None else None
+    sm = spec_mask.view(torch.uint8) if spec_mask.dtype == torch.bool else spec_mask
+    L.check(lib.tf_shade_reduce_aux(_p(_f(wgt)), _p(_f(lights)) if lights is not None else None, _p(_f(dirs)) if dirs is not None else None,
+                                    _p(_f(depth)) if depth is not None else None, _p(hit_u8, torch.uint8) if hit_u8 is not None else None,
+                                    _p(_f(hit_lights)) if hit_lights is not None else None, _p(env_base) if env_base is not None else None,
+                                    env_base.shape[1] if env_base is not None else 0, float(near_eps), _p(sm.contiguous(), torch.uint8), pn,
+                                    n_diffuse, ss, _p(colors), _p(dl), _p(sl), _p(aux), _p(slot_of_pos, torch.int32), _stream()),
+            "tf_shade_reduce_aux")
+    return colors, dl, sl, aux
 
 
 def shade_reduce(wgt, lights, n_diffuse, ss):

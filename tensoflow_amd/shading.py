@@ -109,7 +109,7 @@ class ShadeOutputs(dict):
     sample) has a data-dependent length, so building it forces a device->host sync; it is derived from `specular_mask` on
     first access instead of on every call (the eval integral never reads it)."""
 
-    _PER_RAY = ("dirs", "wgt", "hit", "live", "hit_lights", "depth")
+    _PER_RAY = ("dirs", "wgt", "hit", "live", "hit_lights", "depth", "inters", "human_hw")
     _LATE = ("colors", "diffuse_lin", "specular_lin")
     _pending = None      # the side stream the reduction of this call was issued on (MCShader.overlap_reduce), until its results are first read
 
@@ -145,6 +145,18 @@ class ShadeOutputs(dict):
             lights = torch.where(hit.reshape(-1, 1), self["hit_lights"].reshape(-1, 3), env).reshape(pn, T, 3)
             self[key] = lights
             return lights
+        if key == "inter":      # fields.py:1226,1251: get_lights' intersection rows of the unmasked specular rays [M,3] (hit rows only are
+            nd = self["n_diffuse"]                     # meaningful: what the third-party tracer leaves in a missing ray's row is unpinned)
+            v = self["inters"][:, nd:][self["specular_mask"].bool()]
+            self[key] = v
+            return v
+        if key == "human_lights":       # fields.py:1226,1241: human_lights * human_weights of the unmasked specular rays that MISSED [n,3]
+            nd = self["n_diffuse"]
+            sel = self["specular_mask"].bool() & ~self["hit"][:, nd:]
+            v = self["human_hw"][:, nd:][sel] if ("human_hw" in self or "_pos_human_hw" in self) else \
+                torch.zeros(int(sel.sum()), 3, device=sel.device)
+            self[key] = v
+            return v
         if key != "specular_rays_id":
             raise KeyError(key)
         smask = self["specular_mask"]
@@ -154,19 +166,81 @@ class ShadeOutputs(dict):
         return rid
 
 
-def aux_outputs(out):
-    """The auxiliary per-point outputs of shade_mixed (fields.py:1232-1251) from a ShadeOutputs dict: diffuse / specular light and
-    colour maps, visibility and indirect light of the unmasked specular rays.  Device-resident torch reductions over [pn,T,3]
-    (evaluation images only; the throughput path never asks for them)."""
+class LazyOutputs(dict):
+    """An output dict whose data-dependent-length entries (`inter`, `human_lights`: fields.py:1241,1251 -- nothing outside
+    shade_mixed reads them) are built on first access: building them costs a device -> host sync per call."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = {}
+
+    def set_lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            v = self._lazy.pop(key)()
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._lazy)
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def items(self):
+        for k in list(self._lazy):
+            self[k]
+        return dict.items(self)
+
+    def values(self):
+        for k in list(self._lazy):
+            self[k]
+        return dict.values(self)
+
+
+def aux_from_stats(aux, nd, ns, metallic, specular_lin, diffuse_lin, diffuse_sample_num):
+    """The auxiliary outputs of shade_mixed (fields.py:1228-1256, :1288-1291) from tf_shade_reduce_aux's per-point statistics
+    `aux` [pn,16]: light / colour maps, approximate_light, visibility, indirect light and the three variance figures."""
     from .encodings import linear_to_srgb
-    lights, hit, smask, nd = out["lights"], out["hit"], out["specular_mask"], out["n_diffuse"]
-    ns = smask.shape[1]
-    m = smask[..., None].float()
-    spec_l, spec_hit = lights[:, nd:], hit[:, nd:, None].float()
     c01 = lambda t: t.clamp(0, 1)
-    return {"diffuse_light": c01(linear_to_srgb(lights[:, :nd].mean(1))), "specular_light": c01(linear_to_srgb((spec_l * m).sum(1) / ns)),
-            "diffuse_color": c01(linear_to_srgb(out["diffuse_lin"])), "specular_color": c01(linear_to_srgb(out["specular_lin"])),
-            "visibility": 1 - (spec_hit * m).sum(1) / ns, "indirect_light": (spec_l * spec_hit * m).sum(1) / ns}
+    dmean = aux[:, 0:3] / nd
+    spec_color = c01(linear_to_srgb(specular_lin))
+    n, mean, m2 = aux[:, 10:11], aux[:, 11:12], aux[:, 12:13]
+    sg, sg2 = n * mean, m2 + n * mean * mean                       # sum g, sum g^2 over the unmasked specular rays
+    n64, mean64, m264 = n.double(), mean.double(), m2.double()
+    N = n64.sum()
+    mu = (n64 * mean64).sum() / N.clamp_min(1.0)
+    var_all = ((m264.sum() + (n64 * (mean64 - mu) ** 2).sum()) / (N - 1.0)).float()     # torch.var(unbiased) over all M unmasked rays (:1289)
+    return {"diffuse_light": c01(linear_to_srgb(dmean)), "specular_light": c01(linear_to_srgb(aux[:, 3:6] / ns)),
+            "diffuse_color": c01(linear_to_srgb(diffuse_lin)), "specular_color": spec_color,
+            # (:1248 adds the ALREADY sRGB-encoded, clamped specular colour to the linear diffuse term: reproduced as written)
+            "approximate_light": c01(linear_to_srgb((1 - metallic) * dmean + spec_color)),
+            "visibility": 1 - aux[:, 9:10] / ns, "indirect_light": aux[:, 6:9] / ns,
+            "variance": var_all,
+            "variance_diffuse_vis": aux[:, 14:15] / max(nd - 1, 1) / diffuse_sample_num,
+            "variance_specular_vis": (sg2 / ns - (sg / ns) ** 2) / ns}
+
+
+def aux_outputs(out, diffuse_sample_num=512):
+    """The auxiliary per-point outputs of shade_mixed (fields.py:1232-1256) from a ShadeOutputs dict built with aux=True (the
+    statistics come out of the reduction kernel: no [pn,T,3] light array is materialised)."""
+    return aux_from_stats(out["_aux"], out["n_diffuse"], out["specular_mask"].shape[1], out["metallic"], out["specular_lin"],
+                          out["diffuse_lin"], diffuse_sample_num)
 
 
 class FlowParams:
@@ -252,6 +326,7 @@ class MCShader:
         self._side_stream = None
         self.timer = _NoTimer()
         self.hit_total = None
+        self.human_hw = None
 
     def latent(self, sn):
         if sn not in self._latent:
@@ -305,6 +380,7 @@ class MCShader:
             dist = -dtx + torch.sqrt(dtx ** 2 - (o ** 2).sum(-1, keepdim=True) + 1 + 1e-6)       # get_sphere_intersection
             enc = torch.cat([enc, ide5(o + dirs * dist, zero, wide=True)], -1)
         outer = self._net4(self.outer, enc.contiguous(), self.light_exp_max)
+        self._last_hlhw = None
         if self.human is None or poses is None:        # (no poses: the outer net alone -- MCShader.lights() on bare rays)
             return outer
         R, t = poses[:, :, :3], poses[:, :, 3]
@@ -321,6 +397,7 @@ class MCShader:
         pe = torch.sin(torch.cat([scaled, scaled + 0.5 * math.pi], -1))
         h = self._net4(self.human, pe.contiguous(), 0.0) * hits            # ExpActivation(max_light = 0): at most 1
         hl, hw = h[:, :3], h[:, 3:].clamp(0.0, 1.0)
+        self._last_hlhw = hl * hw
         return outer * (1 - hw) + hl * hw
 
     def trace_and_inner(self, pts_rep, dirs, live=None, slot_order=None, origin_order=None, poses=None):
@@ -353,10 +430,16 @@ class MCShader:
                 else:
                     # composed variants (configs/mat/custom): one host sync for the count, slices of 2^21 rays to bound the encodings
                     n, T = int(count_m), dirs.shape[0] // pts_rep.shape[0]
+                    # ray r belongs to origin r // T: `dirs` is [pn, T] row-major whatever `origin_order` says (that argument only
+                    # changes the order in which the traversal's waves CLAIM the origins; no row moves)
+                    assert dirs.shape[0] == pts_rep.shape[0] * T, (dirs.shape, pts_rep.shape)
+                    self.human_hw = torch.zeros_like(dirs) if (self.human is not None and poses is not None) else None
                     for c0 in range(0, n, 1 << 21):
                         ids = idx_m[c0:min(c0 + (1 << 21), n)]
                         org = ids // T if T > 1 else ids
                         hit_lights[ids] = self.miss_lights_composed(pts_rep[org], dirs[ids], poses[org] if poses is not None else None)
+                        if self.human_hw is not None and self._last_hlhw is not None:
+                            self.human_hw[ids] = self._last_hlhw           # human_lights * human_weights (get_lights' 2nd value, :975)
         self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
         return hit_lights, hit, depth, inters
 
@@ -373,7 +456,7 @@ class MCShader:
         return lights, hit, inters
 
     @torch.no_grad()
-    def shade_fixed(self, pts, view_dirs, normals, human_poses=None):
+    def shade_fixed(self, pts, view_dirs, normals, human_poses=None, aux=False):
         """The non-NIS pass of shade_mixed (nis_sample=False, fields.py:1075-1235 with the `else` samplers): the fixed cosine set
         for the diffuse lobe and the fixed GGX-warped set for the specular lobe (sample_diffuse_directions /
         sample_specular_directions, :824-903).  Same output dict as `shade` (without the flow arrays)."""
@@ -383,14 +466,24 @@ class MCShader:
         metallic, rough, albedo, _, _ = self.point_prep(pts, va)
         dirs, wgt, smask, live = ops.shade_dirs_fixed(normals, view_dirs, metallic, rough, albedo, self.fixed_d, self.fixed_s)
         T, nd, ns = dirs.shape[1], self.fixed_d.shape[0], self.fixed_s.shape[0]
-        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None, poses=human_poses)
-        colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, None, hit_lights, self.env, nd, ns)
-        return ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
-                            specular_mask=smask, live=live, view_angles=va, dirs=dirs, wgt=wgt,
-                            hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=nd)
+        # aux: the unweighted maps average over EVERY ray (zero weight or not), so nothing is culled for such a call
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if (self.cull_dead_rays and not aux) else None,
+                                                              poses=human_poses)
+        if aux:
+            colors, dl, sl, stats = ops.shade_reduce_aux(wgt, smask, nd, ns, dirs=dirs, depth=depth, hit_lights=hit_lights, env_base=self.env)
+        else:
+            colors, dl, sl = ops.shade_reduce_env(wgt, dirs, depth, None, hit_lights, self.env, nd, ns)
+        out = ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
+                           specular_mask=smask, live=live, view_angles=va, dirs=dirs, wgt=wgt, inters=inters.reshape(pn, T, 3),
+                           hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T), _env=self.env, n_diffuse=nd)
+        if aux:
+            out["_aux"] = stats
+        if self.human_hw is not None and human_poses is not None:
+            out["human_hw"] = self.human_hw.reshape(pn, T, 3)
+        return out
 
     @torch.no_grad()
-    def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None, human_poses=None):
+    def shade(self, pts, view_dirs, normals, sn_diffuse, sn_specular, jitter_d=None, jitter_s=None, human_poses=None, aux=False):
         """-> dict(colors [pn,3], specular_mask, specular_rays_id, diffuse_lin, specular_lin, materials...)
         One call at a time per shader: the kernels' workspaces (packed weights, the flows' per-point rows, the traversal's work
         counters) are per device, not per call -- two shade() calls in flight on different streams would share them (measured as
@@ -446,11 +539,18 @@ class MCShader:
         # is moved: only the order in which the persistent waves claim the points changes
         with tm.stage("point_prep"):
             oorder = ops.morton_order(pts, self.aabb) if self.sort_origins and T >= 64 else None
-        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if self.cull_dead_rays else None,
+        # aux=True (the rest of shade_mixed's output dict, fields.py:1232-1256): every ray's light enters the unweighted maps, so the
+        # zero-weight culling is off for such a call and the reduction is tf_shade_reduce_aux
+        hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if (self.cull_dead_rays and not aux) else None,
                                                               origin_order=oorder, poses=human_poses)
         n_diff = sn_diffuse + self.fixed_d.shape[0]
         pending = None
-        if self.overlap_reduce:
+        stats = None
+        if aux:
+            with tm.stage("shade_reduce"):
+                colors, dl, sl, stats = ops.shade_reduce_aux(wgt, smask, n_diff, sn_specular, dirs=dirs, depth=depth, hit_lights=hit_lights,
+                                                             env_base=self.env, slot_of_pos=order)
+        elif self.overlap_reduce:
             # the reduction (texel gathers of the environment light: latency bound, matrix cores idle) goes to the side stream: it runs
             # under the per-point stage and the flow sampling of the NEXT batch unless the caller reads the colours first
             # (ShadeOutputs.__getitem__ waits).  Its inputs are kept from the allocator until that work is done (record_stream).
@@ -470,7 +570,12 @@ class MCShader:
         out = ShadeOutputs(colors=colors, diffuse_lin=dl, specular_lin=sl, metallic=metallic, roughness=rough, albedo=albedo,
                            specular_mask=smask, view_angles=va, diffuse_angles=ang_d, diffuse_logq=lq_d, specular_angles=ang_s,
                            specular_logq=lq_s, _env=self.env, n_diffuse=n_diff)
-        per_ray = dict(live=live, dirs=dirs, wgt=wgt, hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T))
+        per_ray = dict(live=live, dirs=dirs, wgt=wgt, hit_lights=hit_lights.reshape(pn, T, 3), depth=depth.reshape(pn, T),
+                       inters=inters.reshape(pn, T, 3))
+        if self.human_hw is not None and human_poses is not None:
+            per_ray["human_hw"] = self.human_hw.reshape(pn, T, 3)
+        if stats is not None:
+            out["_aux"] = stats
         if order is None:
             out.update(per_ray)
         else:
