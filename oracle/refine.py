@@ -59,3 +59,45 @@ def refine_hits(sd, tracer, o, d, aabb, grid_size, n_levels, inv_s, unit_size, s
         n = torch.where(flip[:, None], -n, n)
         normals[hit] = n
     return inters, normals, depth, hit[:, None]
+
+
+def material_nvs(shader_sd, sdf_sd, tracer, pose, K, h, w, aabb, grid_size, n_levels, inv_s, unit_size, sn_fixed, sn_flow,
+                 n_fixed_specular):
+    """MaterialRenderer.nvs (materialRenderer.py:641-752) with nerfDataType rays (:647-672): pixel grid -> camera rays (no half-pixel
+    offset, unit directions) -> trace_sdf_with_mesh(32, 9) -> MCShadingNetwork.forward(step=None) on the pixels that see the object
+    (the un-suffixed maps come from the fixed-sampler pass) -> 15 maps [h,w,C]: white background (:743), normal (0,0,1) on pixels that
+    miss in 512-ray chunks with a hit (:725), sqrt of the squared roughness (:739), the four variance maps left at zero (their assignments are commented out,
+    :732-735).  sn_fixed = cfg diffuse_sample_num, sn_flow = (nis_diffuse_sample_num, nis_specular_sample_num)."""
+    from . import shading as osh
+    pose = torch.as_tensor(pose, dtype=torch.float32)
+    K = torch.as_tensor(K, dtype=torch.float32)
+    i, j = torch.meshgrid(torch.linspace(0, w - 1, w), torch.linspace(0, h - 1, h), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)
+    rays_d = F.normalize((pose[:3, :3] @ dirs.t()).t(), dim=-1)
+    rays_o = pose[:3, 3].expand(h * w, 3)
+    inters, normals, depth, hit = refine_hits(sdf_sd, tracer, rays_o, rays_d, aabb, grid_size, n_levels, inv_s, unit_size)
+    hit = hit[:, 0]
+    rn = h * w
+    out = {k: torch.zeros(rn, c) for k, c in (("color", 3), ("normal", 3), ("spec_light", 3), ("diff_light", 3), ("indirect_light", 3),
+                                              ("spec_color", 3), ("diff_color", 3), ("albedo", 3), ("roughness", 1), ("metallic", 1),
+                                              ("occ_trace", 1), ("variance_diffuse_vis", 1), ("variance_specular_vis", 1),
+                                              ("variance_diffuse_vis_nis", 1), ("variance_specular_vis_nis", 1))}
+    out["color"][:] = 1.0
+    # (:725 sits inside `if torch.sum(hit_mask) > 0` of the 512-ray chunk loop: pixels that miss get the normal (0,0,1) only in chunks
+    # that contain at least one hit; in a chunk without any they stay zero)
+    for c0 in range(0, rn, 512):
+        if hit[c0:c0 + 512].any():
+            out["normal"][c0:c0 + 512, 2] = 1.0
+    if hit.any():
+        sh = osh.shade(shader_sd, tracer, unit_size, aabb, inters[hit], -rays_d[hit], normals[hit], sn_flow[0], sn_flow[1],
+                       n_fixed_diffuse=sn_fixed, n_fixed_specular=n_fixed_specular, use_flow=False)
+        c01 = lambda t: torch.clamp(osh.linear_to_srgb(t), 0, 1)
+        out["color"][hit] = sh["colors"]
+        out["normal"][hit] = normals[hit]
+        out["spec_light"][hit], out["diff_light"][hit] = sh["specular_light"], sh["diffuse_light"]
+        out["indirect_light"][hit], out["occ_trace"][hit] = sh["indirect_light"], sh["visibility"]
+        out["spec_color"][hit], out["diff_color"][hit] = c01(sh["specular_lin"]), c01(sh["diffuse_lin"])
+        out["albedo"][hit], out["metallic"][hit] = sh["albedo"], sh["metallic"]
+        out["roughness"][hit] = torch.sqrt(sh["roughness"])
+    return {k: v.reshape(h, w, -1) for k, v in out.items()}, (inters, normals, depth, hit)

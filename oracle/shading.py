@@ -160,7 +160,7 @@ def human_light(sd, pts, dirs, poses):
     return h[:, :3], h[:, 3:].clamp(0.0, 1.0)
 
 
-def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0, poses=None):
+def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0, poses=None, return_human=False):
     """fields.py:951-975; the variant follows the state dict: 'envlight' (`outer_light.base`), 'direction' / 'sphere_direction'
     (`outer_light.0.*` with 72 / 144 inputs), human lights (`human_light.*`; poses [M,3,4]).
     pts, dirs [M,3] -> lights [M,3], hit [M] bool, inters [M,3]."""
@@ -169,6 +169,7 @@ def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0,
     inters, nrm, depth, hit = tracer(o + 2 * unit_size * dirs, dirs)
     lights = torch.zeros_like(pts)
     miss = ~hit
+    hlw = torch.zeros(int(miss.sum()), 3, dtype=pts.dtype) if miss.any() else torch.zeros(1, 3, dtype=pts.dtype)     # (:960,966)
     if miss.any():
         if "outer_light.base" in sd:
             outer = env_direct_light(sd["outer_light.base"], dirs[miss])
@@ -179,10 +180,13 @@ def get_lights(sd, tracer, unit_size, pts, dirs, exp_max=5.0, light_exp_max=5.0,
         if "human_light.0.bias" in sd:
             hl, hw = human_light(sd, pts[miss], dirs[miss], poses[miss])
             outer = outer * (1 - hw) + hl * hw
+            hlw = hl * hw
         lights[miss] = outer
     if hit.any():
         lights[hit] = inner_light(sd, inters[hit], -dirs[hit], nrm[hit], exp_max)
     lights = lights * (depth > eps).to(lights.dtype)
+    if return_human:
+        return lights, hit, inters, hlw
     return lights, hit, inters
 
 
@@ -282,7 +286,8 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     geo = schlick_g1(NoV, rough[rid]) * schlick_g1(NoL, rough[rid])
     NoH = sat_dot(nrm[rid], Hs)
     dist = ggx_d(NoH, rough[rid])
-    sl, shit, sinter = get_lights(sd, tracer, unit_size, pts[rid], sd_, exp_max, poses=human_poses[rid] if human_poses is not None else None)
+    sl, shit, sinter, shlw = get_lights(sd, tracer, unit_size, pts[rid], sd_, exp_max, poses=human_poses[rid] if human_poses is not None else None,
+                                        return_human=True)
     sw = dist * fres * geo / (4 * NoV).clamp_min(EPS)
     specular = segment_coo(sw * sl / sp_.clamp_min(EPS), rid, torch.zeros(pn, 3)) / sn
     colors = linear_to_srgb(diffuse + specular)
@@ -294,4 +299,14 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
                diffuse_light=torch.clamp(linear_to_srgb(dl.mean(1)), 0, 1),
                specular_light=torch.clamp(linear_to_srgb(segment_coo(sl, rid, torch.zeros(pn, 3)) / sn), 0, 1),
                diffuse_dirs=ddirs, diffuse_pdf=dpdf, specular_dirs=sdirs, specular_pdf=spdf)
+    # the rest of the reference's dict (fields.py:1241-1256, :1288-1291).  approximate_light adds the ALREADY sRGB-encoded, clamped
+    # specular colour to the linear diffuse term (:1246-1248: `specular_colors` was reassigned two lines earlier); `variance` is the
+    # specular one (:1289 overwrites :1255); variance_diffuse_vis divides by cfg diffuse_sample_num, not by the ray count (:1256)
+    gd = (dw * dl).mean(-1, keepdim=True) / dpdf.clamp_min(EPS)
+    gs = (sw * sl).mean(-1, keepdim=True) / sp_.clamp_min(EPS)
+    spec_srgb = torch.clamp(linear_to_srgb(specular), 0, 1)
+    out.update(human_lights=shlw.reshape(-1, 3), inter=sinter,
+               approximate_light=torch.clamp(linear_to_srgb(torch.mean(kd * dl, 1) + spec_srgb), 0, 1),
+               variance=torch.var(gs), variance_diffuse_vis=torch.var(gd, dim=1, unbiased=True) / n_fixed_diffuse,
+               variance_specular_vis=(segment_coo(gs ** 2, rid, torch.zeros(pn, 1)) / sn - (segment_coo(gs, rid, torch.zeros(pn, 1)) / sn) ** 2) / sn)
     return out

@@ -393,10 +393,18 @@ class MCShadingNetwork(nn.Module):
         inner_wb = []
         for i in (0, 2, 4, 6):
             inner_wb += [self.inner_light[i].weight, self.inner_light[i].bias]     # weight = g*v/|v| (parametrization, autograd)
+        hl_all = None
+        # zero-weight rays (diffuse samples under the horizon) are TRACED like any other: their light enters diffuse_light, which the
+        # diffuse-light regulariser differentiates (materialRenderer.py:562-563), and the unweighted maps.  cfg cull_zero_weight_rays=True
+        # skips them (their colour contribution is exactly zero) at the price of those maps.
+        if not self.cfg.get("cull_zero_weight_rays", False):
+            live = torch.ones_like(live)
         if self._composed_lights:
             # 'sphere_direction' / human lights (configs/mat/custom): the composed get_lights of the fixed-sampler pass
             poses_rep = human_poses[:, None].expand(pn, T, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None
-            lights, hit, _ = self._lights_of(pts_rep[:, None].expand(pn, T, 3).reshape(-1, 3), dirs.reshape(-1, 3), poses_rep)
+            lights, hit, hl_miss = self._lights_of(pts_rep[:, None].expand(pn, T, 3).reshape(-1, 3), dirs.reshape(-1, 3), poses_rep)
+            if hl_miss is not None:                      # human_lights * human_weights of the rays that missed, back on the ray grid
+                hl_all = torch.zeros(pn * T, 3, device=dev).index_put((~hit,), hl_miss.detach())
         else:
             if self.cfg["outer_light_version"] == "direction":
                 env_base = None
@@ -411,8 +419,21 @@ class MCShadingNetwork(nn.Module):
         contrib = wgt * lights
         diffuse_lin, specular_lin = contrib[:, :nd].sum(1), contrib[:, nd:].sum(1)
         colors = self._linear_to_srgb(diffuse_lin + specular_lin)
-        outputs = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (F.normalize(normals, dim=-1) + 1) / 2,
-                   "diffuse_light": torch.clamp(self._linear_to_srgb(lights[:, :nd].mean(1)), 0, 1), "specular_mask": smask}
+        from ..shading import LazyOutputs, aux_from_stats
+        outputs = LazyOutputs({"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (F.normalize(normals, dim=-1) + 1) / 2,
+                               "specular_mask": smask})
+        with torch.no_grad():
+            # the rest of the reference's dict (fields.py:1232-1256, :1288-1291; `variance` is what trainer_inv.py:299 prints): one
+            # launch on the detached arrays.  (The reference's maps carry gradients nobody uses; only diffuse_light feeds a loss.)
+            hit_u8 = hit.reshape(-1).view(torch.uint8) if hit.dtype == torch.bool else hit.reshape(-1).to(torch.uint8)
+            _, _, _, stats = ops.shade_reduce_aux(wgt.detach(), smask, nd, ss, lights=lights.detach(), hit_u8=hit_u8, want_colors=False)
+            outputs.update(aux_from_stats(stats, nd, ss, metallic.detach(), specular_lin.detach(), diffuse_lin.detach(), self.cfg["diffuse_sample_num"]))
+        outputs["diffuse_light"] = torch.clamp(self._linear_to_srgb(lights[:, :nd].mean(1)), 0, 1)        # differentiable (diffuse-light regulariser)
+        spec_sel = lambda: smask.bool()
+        outputs.set_lazy("human_lights", lambda: (lambda sel: (hl_all.view(pn, T, 3)[:, nd:][sel] if hl_all is not None else
+                                                               torch.zeros(int(sel.sum()), 3, device=dev)))(spec_sel() & ~hit.view(pn, T)[:, nd:].bool()))
+        outputs.set_lazy("inter", lambda: self._bvh.trace(pts_rep[:, None].expand(pn, ss, 3)[spec_sel()].contiguous(),
+                                                           dirs.detach()[:, nd:][spec_sel()].contiguous(), 1e-5, 2 * self.unit_size)[0])
         zero = torch.zeros((), device=dev)
         outputs["loss_nis_diffuse"] = outputs["loss_nis_specular"] = zero
         if step is not None and step >= self.cfg.get("nis_loss_iter_diffuse", 500):
@@ -516,12 +537,29 @@ class MCShadingNetwork(nn.Module):
             raise NotImplementedError("geometry_type='schlick' (every shipped config)")
         geo = g1(NoV, roughness[rid]) * g1(NoL, roughness[rid])
         dist = ggx(sat(normals[rid], Hh), roughness[rid])
-        s_lights, s_hit = lights_of(pts[rid], sd_, human_poses[rid] if human_poses is not None else None)
+        s_lights, s_hit, s_hl = self._lights_of(pts[rid], sd_, human_poses[rid] if human_poses is not None else None)
         s_w = dist * fres * geo / (4 * NoV).clamp_min(EPS)
         specular = torch.zeros(pn, 3, device=dev).index_add(0, rid, s_w * s_lights / sp_.clamp_min(EPS)) / ns
         colors = self._linear_to_srgb(diffuse + specular)
-        outputs = {"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (normals + 1) / 2, "specular_mask": smask,
-                   "diffuse_light": torch.clamp(self._linear_to_srgb(d_lights.mean(1)), 0, 1)}
+        from ..shading import LazyOutputs
+        outputs = LazyOutputs({"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (normals + 1) / 2, "specular_mask": smask,
+                               "diffuse_light": torch.clamp(self._linear_to_srgb(d_lights.mean(1)), 0, 1)})
+        with torch.no_grad():                                   # the rest of the dict (fields.py:1232-1256, :1288-1291), as written there
+            c01 = lambda t: torch.clamp(self._linear_to_srgb(t), 0, 1)
+            seg = lambda v: torch.zeros(pn, v.shape[-1], device=dev).index_add(0, rid, v)
+            sh_f = s_hit.float()[:, None]
+            outputs["specular_light"] = c01(seg(s_lights) / ns)
+            outputs["diffuse_color"], outputs["specular_color"] = c01(diffuse), c01(specular)
+            outputs["approximate_light"] = c01(torch.mean(kd * d_lights, 1) + outputs["specular_color"])
+            outputs["visibility"] = 1 - seg(sh_f) / ns
+            outputs["indirect_light"] = seg(s_lights * sh_f) / ns
+            gd_ = (d_w * d_lights).mean(-1, keepdim=True) / d_pdf.clamp_min(EPS)
+            outputs["variance_diffuse_vis"] = torch.var(gd_, dim=1, unbiased=True) / cfg["diffuse_sample_num"]
+            gs_ = (s_w * s_lights).mean(-1, keepdim=True) / sp_.clamp_min(EPS)
+            outputs["variance"] = torch.var(gs_)
+            outputs["variance_specular_vis"] = (seg(gs_ ** 2) / ns - (seg(gs_) / ns) ** 2) / ns
+        outputs.set_lazy("human_lights", lambda: s_hl if s_hl is not None else torch.zeros(int((~s_hit).sum()), 3, device=dev))
+        outputs.set_lazy("inter", lambda: self._bvh.trace(pts[rid].contiguous(), sd_.detach().contiguous(), 1e-5, 2 * self.unit_size)[0])
         zero = torch.zeros((), device=dev)
         outputs["loss_nis_diffuse"] = outputs["loss_nis_specular"] = zero
         va = ops.view_angles(normals, view_dirs)
@@ -563,19 +601,27 @@ class MCShadingNetwork(nn.Module):
     def _forward_eval(self, pts, view_dirs, normals, human_poses=None):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
-        from ..shading import aux_outputs
+        from ..shading import LazyOutputs, aux_outputs
         sh = self.shader()
         nrm = (F.normalize(normals, dim=-1) + 1) / 2
         # the unweighted light maps (diffuse_light, visibility ...) average over EVERY ray, incl. those whose BRDF weight is zero:
-        # the zero-weight culling of the throughput path is switched off here
-        sh.cull_dead_rays = False
+        # aux=True switches the zero-weight culling of the throughput path off and takes the statistics from tf_shade_reduce_aux
         hp = human_poses.float().contiguous() if (human_poses is not None and self.cfg["human_lights"]) else None
-        fx = sh.shade_fixed(pts, view_dirs, normals, human_poses=hp)
-        outputs = {"albedo": fx["albedo"], "roughness": fx["roughness"], "metallic": fx["metallic"], "normal": nrm, **aux_outputs(fx)}
-        nis = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"], human_poses=hp)
+        dsn = self.cfg["diffuse_sample_num"]
+        fx = sh.shade_fixed(pts, view_dirs, normals, human_poses=hp, aux=True)
+        outputs = LazyOutputs({"albedo": fx["albedo"], "roughness": fx["roughness"], "metallic": fx["metallic"], "normal": nrm,
+                               **aux_outputs(fx, dsn)})
+        nis = sh.shade(pts, view_dirs, normals, self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"], human_poses=hp, aux=True)
         outputs.update({k + "_nis": v for k, v in {"albedo": nis["albedo"], "roughness": nis["roughness"], "metallic": nis["metallic"],
-                                                  "normal": nrm, "rgb_pr": nis["colors"], **aux_outputs(nis)}.items()})
-        outputs["specular_rays_id_nis"] = nis["specular_rays_id"]
+                                                  "normal": nrm, "rgb_pr": nis["colors"], **aux_outputs(nis, dsn)}.items()})
+        zero = torch.zeros((), device=pts.device)
+        for sfx in ("", "_nis"):                               # step is None: no NIS loss (fields.py:1285,1329-1330)
+            outputs["loss_nis_diffuse" + sfx] = outputs["loss_nis_specular" + sfx] = outputs["loss_nis" + sfx] = zero
+        # data-dependent lengths (one host sync each): built when somebody reads them -- nothing outside shade_mixed does
+        for sfx, o in (("", fx), ("_nis", nis)):
+            outputs.set_lazy("inter" + sfx, lambda o=o: o["inter"])
+            outputs.set_lazy("human_lights" + sfx, lambda o=o: o["human_lights"])
+        outputs.set_lazy("specular_rays_id_nis", lambda: nis["specular_rays_id"])
         return fx["colors"], outputs
 
 

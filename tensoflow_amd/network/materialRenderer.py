@@ -232,32 +232,52 @@ class MaterialRenderer(nn.Module):
 
     @torch.no_grad()
     def nvs(self, pose, K, h, w, chunk=65536):
-        """materialRenderer.py:641-752 (nerfDataType rays): primary rays -> BVH -> SDF refinement -> flow-sampled shading.
-        -> dict of [h,w,C] numpy arrays (color, normal, albedo, roughness, metallic).  The reference shades 512 rays per pass."""
+        """materialRenderer.py:641-752 (nerfDataType rays, :647-672): primary rays -> BVH -> SDF refinement (32 + 9 evaluations) ->
+        MCShadingNetwork.forward(step=None) on the pixels that see the object -> dict of 15 [h,w,C] numpy maps under the reference's
+        keys (:707): colour (white background, :743), normal, specular / diffuse / indirect light, specular / diffuse colour, albedo,
+        roughness (sqrt of the squared prediction, :739), metallic, occ_trace (= visibility) and the four variance maps, which the
+        reference leaves at zero (their assignments are commented out, :732-735).  The reference shades 512 rays per pass; `chunk`
+        only sizes the launches here -- except for ONE thing its chunk loop decides: a pixel that misses gets the normal (0,0,1)
+        inside `if sum(hit) > 0` (:713,725), i.e. only in 512-ray chunks that contain a hit; reproduced below."""
         dev = self.device
         K = torch.from_numpy(np.asarray(K, np.float32)).to(dev)
         pose = torch.from_numpy(np.asarray(pose, np.float32)).to(dev)
+        h, w = int(h), int(w)
         i, j = torch.meshgrid(torch.linspace(0, w - 1, w, device=dev), torch.linspace(0, h - 1, h, device=dev), indexing="ij")
         i, j = i.t(), j.t()
         dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)
         rays_d = F.normalize(dirs @ pose[:3, :3].t(), dim=-1).contiguous()
         rays_o = pose[:3, 3].expand(h * w, 3).contiguous()
         rn = h * w
-        out = {"color": torch.ones(rn, 3, device=dev), "normal": torch.zeros(rn, 3, device=dev), "albedo": torch.zeros(rn, 3, device=dev),
-               "roughness": torch.zeros(rn, 1, device=dev), "metallic": torch.zeros(rn, 1, device=dev)}
-        out["normal"][:, 2] = 1.0
+        human = self.shader_network.cfg["human_lights"]
+        if human:
+            from ..dataset import human_coordinate_poses
+            hp_all = human_coordinate_poses(pose[None, :3], self.cfg.get("fixed_camera", False))[0]
+        keys = {"color": 3, "normal": 3, "spec_light": 3, "diff_light": 3, "indirect_light": 3, "spec_color": 3, "diff_color": 3, "albedo": 3,
+                "roughness": 1, "metallic": 1, "occ_trace": 1, "variance_diffuse_vis": 1, "variance_specular_vis": 1,
+                "variance_diffuse_vis_nis": 1, "variance_specular_vis_nis": 1}
+        out = {k: torch.zeros(rn, c, device=dev) for k, c in keys.items()}
+        out["color"][:] = 1.0
+        hit_all = torch.zeros(rn, dtype=torch.bool, device=dev)
+        src = {"color": "rgb_pr", "spec_light": "specular_light", "diff_light": "diffuse_light", "indirect_light": "indirect_light",
+               "occ_trace": "visibility", "spec_color": "specular_color", "diff_color": "diffuse_color", "albedo": "albedo", "metallic": "metallic"}
         for s in range(0, rn, chunk):
             o, d = rays_o[s:s + chunk], rays_d[s:s + chunk]
             inters, nrm, depth, hit = self.trace_sdf_with_mesh(o, d) if self.sdf_network is not None else self.trace(o, d)
+            hit_all[s:s + chunk] = hit[:, 0]
             idx = torch.nonzero(hit[:, 0], as_tuple=False)[:, 0]
             if idx.numel() == 0:
                 continue
-            sh = self.shade(inters[idx].contiguous(), (-d[idx]).contiguous(), nrm[idx].contiguous(), None, False)
-            out["color"][s + idx] = sh["rgb_pr"]
+            hp = hp_all[None].expand(idx.numel(), 3, 4).contiguous() if human else None
+            sh = self.shade(inters[idx].contiguous(), (-d[idx]).contiguous(), nrm[idx].contiguous(), hp, False)
+            for k, sk in src.items():
+                out[k][s + idx] = sh[sk]
             out["normal"][s + idx] = nrm[idx]
-            out["albedo"][s + idx] = sh["albedo"]
-            out["roughness"][s + idx] = torch.sqrt(sh["roughness"])      # predictions are squared roughness (:743)
-            out["metallic"][s + idx] = sh["metallic"]
+            out["roughness"][s + idx] = torch.sqrt(sh["roughness"])      # predictions are squared roughness (:739)
+        # normal of the pixels that miss: (0,0,1) where the reference's 512-ray chunk holds a hit, zero elsewhere (:713,725)
+        pad = (-rn) % 512
+        blk = torch.cat([hit_all, hit_all.new_zeros(pad)]).view(-1, 512).any(1).repeat_interleave(512)[:rn]
+        out["normal"][:, 2] = torch.where(~hit_all & blk, torch.ones_like(out["normal"][:, 2]), out["normal"][:, 2])
         return {k: v.reshape(h, w, -1).cpu().numpy() for k, v in out.items()}
 
     @torch.no_grad()

@@ -78,5 +78,25 @@ def test_shape_stage_to_material_stage(tmp_path):
     md.eval()
     ev = md({"eval": True, "index": 0})
     assert ev["rgb_pr"].shape == (24, 24, 3) and ev["rgb_gt"].shape == (24, 24, 3) and torch.isfinite(ev["rgb_pr"]).all()
+    # the TensoIR layout (configs/mat/syn/{lego,armadillo,horse}.yaml) keeps H / W as FLOATS, like the reference's database class:
+    # test_step takes the frame size from the image (materialRenderer.py:583), not from them (advisor, round 3)
+    import json
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        dd = tmp_path / "data" / "lego" / f"train_{k:03d}"
+        os.makedirs(dd)
+        T = np.eye(4)
+        T[:3, 3] = [0.0, 0.0, 4.0]
+        json.dump({"cam_transform_mat": ",".join(repr(float(x)) for x in T.reshape(-1)), "cam_angle_x": 0.6911, "imh": 12, "imw": 12}, open(dd / "metadata.json", "w"))
+        Image.fromarray(rng.integers(0, 256, (12, 12, 4), dtype=np.uint8), "RGBA").save(dd / "rgba_sunset_000.png")
+    mi = MaterialRenderer({"mesh": ply, "geo_model_path": ckpt, "shader_cfg": shader_cfg, "nerfDataType": True, "database_name": "tensoIR/lego",
+                           "dataset_dir": str(tmp_path / "data"), "train_ray_num": 64, "split_manul": True, "split_borderline": 2}, training=True)
+    assert isinstance(mi.database.H, float) and mi.test_num >= 1
+    mi.eval()
+    ev2 = mi({"eval": True, "index": 0})
+    assert ev2["rgb_pr"].shape == (12, 12, 3) and ev2["rgb_gt"].shape == (12, 12, 3) and torch.isfinite(ev2["rgb_pr"]).all()
+    assert {"spec_light", "diff_light", "occ_trace", "indirect_light"} <= set(ev2)
     mats = mat.extract_materials(str(tmp_path / "materials"))
     assert np.load(str(tmp_path / "materials" / "albedo.npy")).shape == (v.shape[0], 3) and np.isfinite(mats["roughness"]).all()

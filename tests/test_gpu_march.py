@@ -17,6 +17,31 @@ def dev():
     return torch.device("cuda:0")
 
 
+AUX_MAPS = ("approximate_light",)
+AUX_VARS = ("variance", "variance_diffuse_vis", "variance_specular_vis")
+
+
+def check_aux(out, ref, sfx="", human_expected=False, tol=TOL):
+    """The rest of shade_mixed's output dict (fields.py:1241-1256, :1288-1291) against the reference run: `ref(key)` -> golden tensor.
+    The variance figures are second moments of importance-sampling weights (the reference's per-point form is E[g^2] - E[g]^2 in
+    fp32): held relative to each array's scale (true_rel_err, floor 1e-3 of its maximum) at 10x the pixel tolerance."""
+    from conftest import true_rel_err
+    for k in AUX_MAPS:
+        assert rel_err(out[k + sfx].detach().cpu(), ref(k + sfx)) < tol, k + sfx
+    for k in AUX_VARS:
+        got, want = out[k + sfx].detach().cpu(), ref(k + sfx)
+        assert got.shape == want.shape, (k + sfx, got.shape, want.shape)
+        assert true_rel_err(got, want) < 10 * tol, (k + sfx, true_rel_err(got, want))
+    hl, hl_ref = out["human_lights" + sfx].cpu(), ref("human_lights" + sfx)
+    assert hl.shape == hl_ref.shape, (hl.shape, hl_ref.shape)                # one row per unmasked specular ray that misses
+    assert rel_err(hl, hl_ref) < tol
+    assert (float(hl_ref.abs().max()) > 0.1) == human_expected
+    inter, inter_ref = out["inter" + sfx].cpu(), ref("inter" + sfx)
+    assert inter.shape == inter_ref.shape
+    hit = inter_ref.norm(dim=-1) < 5.0         # a missing ray's row is whatever the tracer leaves there (third party, unpinned): o + 10 d here
+    assert 0 < int(hit.sum()) < hit.numel() and rel_err(inter[hit], inter_ref[hit]) < tol
+
+
 def _field(g, dev):
     from tensoflow_amd.march import SdfField
     return SdfField(g.sd, AABB, [32, 32, 32], 3, device=dev)
@@ -170,6 +195,11 @@ def test_module_mcshading(golden, dev):
         assert rel_err(outputs[k].cpu(), g.out[k]) < TOL, k
         if k + "_nis" in g.out:
             assert rel_err(outputs[k + "_nis"].cpu(), g.out[k + "_nis"]) < TOL, k + "_nis"
+    for sfx in ("", "_nis"):
+        check_aux(outputs, lambda k: g.out[k], sfx)
+        assert float(outputs["loss_nis" + sfx]) == 0.0
+    ref_keys = {k for k in g.out}
+    assert ref_keys <= set(outputs.keys()) | {"rgb_pr_nis"}, sorted(ref_keys - set(outputs.keys()))
     img = m.env_light(16, 32)
     assert img.shape == (16, 32, 3) and torch.isfinite(img).all() and not img.requires_grad
     reg = m.material_regularization(g["pts"].to(dev), None, outputs["metallic"], outputs["roughness"], outputs["albedo"], 100)
@@ -320,6 +350,9 @@ def test_mcshading_training_step_golden(golden, dev):
     assert rel_err(colors.detach().cpu(), g["colors"]) < TOL
     assert abs(float(out["loss_nis_diffuse"]) - float(g["loss_nis_diffuse"])) < 1e-4 * max(1, abs(float(g["loss_nis_diffuse"])))
     assert abs(float(out["loss_nis_specular"]) - float(g["loss_nis_specular"])) < 1e-4 * max(1, abs(float(g["loss_nis_specular"])))
+    for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light"):
+        assert rel_err(out[k].detach().cpu(), g["out600/" + k]) < TOL, k
+    check_aux(out, lambda k: g["out600/" + k])             # `variance` is what the reference trainer's progress line reads (trainer_inv.py:299)
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     worst, checked = 0.0, 0
     for name, p in m.named_parameters():
@@ -363,6 +396,9 @@ def test_mcshading_training_step_before_flow_copies_golden(golden, dev, step):
     for k in ("loss_nis_diffuse", "loss_nis_specular"):
         ref = float(g[f"{k}_{step}"])
         assert abs(float(out[k]) - ref) < 1e-4 * max(1, abs(ref)), (k, float(out[k]), ref)
+    for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light"):
+        assert rel_err(out[k].detach().cpu(), g[f"out{step}/" + k]) < TOL, k
+    check_aux(out, lambda k: g[f"out{step}/" + k])
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     grads = {k[len(f"grad{step}/"):]: v for k, v in g.a.items() if k.startswith(f"grad{step}/")}
     checked, bad = 0, []
@@ -461,6 +497,7 @@ def test_direction_outer_light_training_golden(golden, dev, step):
         m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, step, False)
     assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    check_aux(out, lambda k: g[f"out{step}/" + k])
     if step >= 1000:
         assert abs(float(out["loss_nis"]) - float(g["loss_nis_1200"])) < 1e-4 * max(1, abs(float(g["loss_nis_1200"])))
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
@@ -527,6 +564,10 @@ def test_sphere_direction_and_human_lights_eval_golden(golden, dev):
     for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light", "rgb_pr_nis",
               "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis", "specular_light_nis"):
         assert rel_err(out[k].cpu(), g.out[k]) < TOL, k
+    for sfx in ("", "_nis"):
+        check_aux(out, lambda k: g.out[k], sfx, human_expected=True)       # human_lights * human_weights of the missing specular rays
+    img = m.env_light(8, 16)                          # predict_outer_lights_pts('sphere_direction') feeds the direction's IDE twice (:1515-1516)
+    assert img.shape == (8, 16, 3) and torch.isfinite(img).all() and float(img.std()) > 0
     sh = m.shader()
     lights, hit, _ = sh.lights(g["pts"].repeat_interleave(16, 0).to(dev), g["gl_dirs"].to(dev).contiguous())       # no poses: outer net alone
     assert torch.equal(hit.cpu(), g["gl_hit"].bool())
@@ -541,6 +582,7 @@ def test_sphere_direction_and_human_lights_training_golden(golden, dev, step):
         m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), g["human_poses"].to(dev), step, False)
     assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    check_aux(out, lambda k: g[f"out{step}/" + k], human_expected=True)
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     grads = {k[len(f"grad{step}/"):]: v for k, v in g.a.items() if k.startswith(f"grad{step}/")}
     checked, bad = 0, []

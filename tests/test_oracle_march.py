@@ -81,6 +81,33 @@ def test_refine_hits(golden):
     assert rel_err(normals, g["normals"]) < 1e-4
 
 
+def test_material_nvs_frame(golden):
+    """The oracle's MaterialRenderer.nvs composition (ray constructor, SDF-refined mesh hits, both shading passes, the frame's
+    conventions) against a 24 x 24 frame rendered by the imported reference (golden material_nvs_r32; materialRenderer.py:641-752)."""
+    from oracle import refine, shading as osh
+    g, geo, small = golden("material_nvs_r32"), golden("refine_r32"), golden("shading_small")
+    tr = osh.MeshTracer(g["verts"][g["faces"].long()])
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in small["sn"]]
+    h, w = [int(v) for v in g["nvs_hw"]]
+    frame, (inters, normals, depth, hit) = refine.material_nvs(small.sd, geo.sd, tr, g["nvs_pose"], g["nvs_K"], h, w, AABB, GS, 3,
+                                                               float(geo["inv_s"]), float(g["unit_size"]), n_fd, (sn_d, sn_s), n_fs)
+    assert torch.equal(hit, g["hit"].bool()) and 0.2 < hit.float().mean() < 0.8
+    assert rel_err(inters[hit], g["inters"][hit]) < 1e-5 and rel_err(normals[hit], g["normals"][hit]) < 1e-4
+    nvs = {k[4:]: v for k, v in g.a.items() if k.startswith("nvs/")}
+    assert set(frame) == set(nvs) and len(nvs) == 15
+    for k, ref in nvs.items():
+        assert frame[k].shape == ref.shape, k
+        assert rel_err(frame[k], ref) < 5e-5, (k, rel_err(frame[k], ref))
+    assert float(nvs["occ_trace"][hit.reshape(h, w)].min()) < 0.9                  # the ring is seen by the secondary rays
+    miss = ~hit
+    assert (nvs["color"].reshape(-1, 3)[miss] == 1).all()
+    # the reference assigns the (0,0,1) normal of a missing pixel inside `if sum(hit) > 0` of its 512-ray chunk loop: the frame's last
+    # 64 rays (a chunk without a hit) keep zeros
+    assert (nvs["normal"].reshape(-1, 3)[:512][miss[:512]] == torch.tensor([0.0, 0, 1])).all() and not hit[512:].any()
+    assert float(nvs["normal"].reshape(-1, 3)[512:].abs().max()) == 0.0
+    assert float(nvs["variance_diffuse_vis"].abs().max()) == 0.0
+
+
 def test_oracle_occupancy_cell_marcher_and_update():
     """The oracle's stand-in for nerfacc's occupancy grid (third-party, absent: parity unpinned): cell lookup, stratified start, EMA
     update rule -- properties the build's kernels are then held to bit for bit (tests/test_gpu_renderers.py)."""

@@ -36,6 +36,15 @@ def test_shade_fixed_and_flow(golden, tag):
     assert rel_err(flow["diffuse_light"], g.out["diffuse_light_nis"]) < 5e-5
     assert rel_err(torch.clamp(osh.linear_to_srgb(flow["diffuse_lin"]), 0, 1), g.out["diffuse_color_nis"]) < 5e-5
     assert rel_err(torch.clamp(osh.linear_to_srgb(flow["specular_lin"]), 0, 1), g.out["specular_color_nis"]) < 5e-5
+    # the rest of shade_mixed's dict (fields.py:1241-1256, :1288-1291), both passes
+    for o, sfx, tol in ((fixed, "", 2e-5), (flow, "_nis", 1e-4)):
+        assert rel_err(o["approximate_light"], g.out["approximate_light" + sfx]) < tol
+        assert o["human_lights"].shape == g.out["human_lights" + sfx].shape and float(o["human_lights"].abs().max()) == 0.0     # human_lights off: zeros, one row per missing unmasked specular ray
+        hit = o["specular_hit"]
+        assert o["inter"].shape == g.out["inter" + sfx].shape and rel_err(o["inter"][hit], g.out["inter" + sfx][hit]) < 1e-5
+        for k in ("variance", "variance_diffuse_vis", "variance_specular_vis"):
+            assert o[k].shape == g.out[k + sfx].shape, k
+            assert rel_err(o[k], g.out[k + sfx]) < 5 * tol, (k, sfx)
 
 
 def test_env_and_lights(golden):
@@ -102,6 +111,10 @@ def test_sphere_direction_outer_light_and_human_lights(golden):
     flow = osh.shade(sd, tr, unit, AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, n_fixed_diffuse=n_fd, n_fixed_specular=n_fs,
                      use_flow=True, human_poses=poses)
     assert rel_err(flow["colors"], g.out["rgb_pr_nis"]) < 5e-5
+    for o, sfx in ((fixed, ""), (flow, "_nis")):          # human_lights * human_weights of the unmasked specular rays that miss (:1226,1241)
+        assert o["human_lights"].shape == g.out["human_lights" + sfx].shape and float(g.out["human_lights" + sfx].abs().max()) > 0.1
+        assert rel_err(o["human_lights"], g.out["human_lights" + sfx]) < 5e-5
+        assert rel_err(o["variance"], g.out["variance" + sfx]) < 5e-4 and rel_err(o["approximate_light"], g.out["approximate_light" + sfx]) < 1e-4
 
 
 def test_cpu_bvh_equals_brute_force():

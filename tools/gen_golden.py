@@ -161,6 +161,20 @@ def gen_encodings():
     save("encodings", **arr)
 
 
+# the part of shade_mixed's output dict (fields.py:1232-1256, :1288-1291) that rounds 1-3 did not store: `variance` is read by the
+# trainer's progress line (train/trainer_inv.py:299), the rest only inside the reference
+AUX_KEYS = ("human_lights", "approximate_light", "inter", "variance", "variance_diffuse_vis", "variance_specular_vis")
+
+
+def aux_arrays(outputs, prefix="out/"):
+    arr = {}
+    for k in AUX_KEYS:
+        for sfx in ("", "_nis"):
+            if k + sfx in outputs:
+                arr[prefix + k + sfx] = outputs[k + sfx]
+    return arr
+
+
 def small_mesh():
     from tensoflow_amd.synth import sphere_torus_mesh
     return sphere_torus_mesh(n_lat=8, n_lon=12, n_major=16, n_minor=8)
@@ -211,6 +225,7 @@ def gen_shading():
                 "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis",
                 "specular_light_nis")
         arr = {"out/" + k: outputs[k] for k in keep}
+        arr.update(aux_arrays(outputs))
         save(f"shading_{tag}", sd=net.state_dict(), pts=pts, view_in=view_in, normals_in=nrm_in, colors=colors,
              verts=verts, faces=faces, unit_size=np.float32(unit), env_dirs=dirs, env_direct=direct,
              gl_lights=lights[:, 0], gl_hit=hit[:, 0], gl_inters=inters[:, 0],
@@ -492,6 +507,89 @@ def gen_refine():
          inv_s=dev_net(torch.zeros(1, 3))[0, 0], unit_size=np.float32(2.0 / (R - 1)))
 
 
+def gen_material_nvs():
+    """A 24 x 24 MaterialRenderer.nvs frame (materialRenderer.py:641-752: NeRF-type ray constructor :647-672, 512-ray chunk loop
+    :705-745, _get_trace_ray_batch_info -> trace_sdf_with_mesh(32, 9), shade with step=None, sqrt of the squared roughness :739,
+    white background :743, normal (0,0,1) on pixels that miss :725) -- BASELINE configs[4]'s path, run on the imported reference.
+    Geometry: the sphere of `refine_r32` (mesh r = 0.2 + the circle-initialised TensoSDF of the same seeds) inside a torus ring that
+    the camera does not see (it sits on the ring's axis, the frame covers +-0.15 rad) but the secondary rays do: visibility,
+    indirect light and the inner-light net are exercised.  Shader network: the one of `shading_small` (same seeds; asserted).
+    Stored: mesh, camera, the 15 output maps, the refined surface points of the frame's rays.  set_default_tensor_type is made a
+    no-op (the reference switches the default tensor type to CUDA in nvs)."""
+    from network.fields import MCShadingNetwork, TensoSDF
+    from network.materialRenderer import MaterialRenderer
+    from network.other_field import SingleVarianceNetwork
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import torus, uv_sphere
+    R = 32
+    unit = float(2.0 / (R - 1))
+    # ---- geometry: gen_refine's SDF (same seeds) + sphere mesh, plus the ring
+    torch.manual_seed(6033)
+    gs = torch.tensor([R, R, R])
+    sdf = TensoSDF(gs, AABB, device="cpu", sdf_n_comp=36, sdf_dim=256, app_dim=128, init_n_levels=3, sdf_multires=0)
+    perturb_(list(sdf.sdf_plane) + list(sdf.sdf_line), 0.01, 1)
+    sdf.eval()
+    ref_sd = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "refine_r32.npz")).items() if k.startswith("sd/")}
+    assert all(torch.equal(v, ref_sd["sdf_network." + k]) for k, v in sdf.state_dict().items() if "gaussian" not in k), "SDF state differs from refine_r32.npz"
+    dev_net = SingleVarianceNetwork(init_val=0.3, activation="exp")
+    v0, f0 = uv_sphere(0.2, 12, 24)
+    v1, f1 = torus(0.75, 0.12, 16, 8)
+    verts, faces = np.concatenate([v0, v1], 0), np.concatenate([f0, f1 + len(v0)], 0)
+    mr = MaterialRenderer.__new__(MaterialRenderer)
+    torch.nn.Module.__init__(mr)
+    shader_cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False, gridSize=[R, R, R],
+                      light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16, nis_specular_sample_num=8)
+    mr.cfg = {**MaterialRenderer.default_cfg, "nerfDataType": True, "device": "cpu", "database_name": "syn/golden", "shader_cfg": shader_cfg}
+    mr.warned_normal, mr.device = True, "cpu"
+    mr.ray_tracer = BruteForceRayTracer(verts, faces)
+    mr.aabb, mr.gridSize = AABB, gs
+    mr.center = torch.mean(AABB, 0).float().view(1, 1, 3)
+    mr.radius = (AABB[1] - mr.center).mean().float()
+    mr.unit_size = torch.mean((AABB[1] - AABB[0]) / (gs - 1), dim=-1)
+    mr.sdf_network, mr.deviation_net = sdf, dev_net
+    mr.sdf_inter_fun = lambda x: sdf.sdf(x, None)
+    # ---- shader: gen_shading('small') (same seeds, same perturbations)
+    torch.manual_seed(4)
+    mr._init_shader()
+    net = mr.shader_network
+    g = torch.Generator().manual_seed(3)
+    net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(0.3 * torch.randn(1, 36, R, R, generator=g)) for _ in range(3)])
+    net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(0.5 + 0.3 * torch.randn(1, 36, R, 1, generator=g)) for _ in range(3)])
+    for fl in (net.flow_diffuse, net.flow_specular, net.flow_diffuse_copy, net.flow_specular_copy):
+        perturb_(list(fl.nis_plane) + list(fl.nis_line), 0.1, 3)
+        perturb_([p for n, p in fl.flows.named_parameters() if "weight" in n], 0.05, 5)
+    with torch.no_grad():
+        net.outer_light.base.add_(0.5 * torch.randn(net.outer_light.base.shape, generator=g))
+    small = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_small.npz")).items() if k.startswith("sd/")}
+    assert all(torch.equal(v, small[k]) for k, v in net.state_dict().items()), "shader state differs from shading_small.npz"
+    mr.eval()
+    # ---- camera on the ring's axis (blender convention: -z forward, y up), 24 x 24, the sphere fills about two thirds of the frame
+    h = w = 24
+    pose = np.array([[1.0, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 2.0]], np.float32)
+    f = 0.5 * w / np.tan(0.15)
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]], np.float32)
+    keep = torch.set_default_tensor_type
+    torch.set_default_tensor_type = lambda *a, **k: None
+    try:
+        with torch.no_grad():
+            frame = mr.nvs(pose, K, h, w)
+    finally:
+        torch.set_default_tensor_type = keep
+    arr = {"nvs/" + k: v for k, v in frame.items()}
+    # the surface points of the frame's rays (what the chunk loop shades), from the same reference methods
+    i, j = torch.meshgrid(torch.linspace(0, w - 1, w), torch.linspace(0, h - 1, h), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)
+    rays_d = torch.nn.functional.normalize(dirs @ torch.from_numpy(pose[:, :3]).t(), dim=-1)
+    rays_o = torch.from_numpy(pose[:, 3]).expand(h * w, 3)
+    with torch.no_grad():
+        info = mr._get_trace_ray_batch_info({"rays_o": rays_o.clone(), "rays_d": rays_d.clone()}, is_train=False)
+    hit = info["hit_mask"]
+    print("material nvs: pixels on the object", int(hit.sum()), "of", h * w, "; mean visibility on them %.3f" % float(frame["occ_trace"].reshape(-1)[hit.numpy()].mean()))
+    save("material_nvs_r32", verts=verts, faces=faces, nvs_pose=pose, nvs_K=K, nvs_hw=np.array([h, w]), unit_size=np.float32(unit),
+         rays_o=rays_o, rays_d=rays_d, inters=info["inters"], normals=info["normals"], depth=info["depth"], hit=hit, **arr)
+
+
 def gen_shading_grad():
     """Training-direction golden: MCShadingNetwork.forward(step=600) with the flow samplers active (use_flow_*_copy), loss =
     sum(colors*w) + loss_nis; gradients of every trainable tensor from the reference's autograd."""
@@ -530,6 +628,8 @@ def gen_shading_grad():
     loss = (colors * w).sum() + outputs["loss_nis"]
     loss.backward()
     grads = {"grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    grads.update(aux_arrays(outputs, "out600/"))
+    grads.update({"out600/" + k: outputs[k] for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light")})
     save("shading_grad", sd=net.state_dict(), pts=pts, view_in=view, normals_in=nrm, colors=colors, bwd_w=w,
          loss_nis=outputs["loss_nis"], loss_nis_diffuse=outputs["loss_nis_diffuse"], loss_nis_specular=outputs["loss_nis_specular"],
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
@@ -581,6 +681,8 @@ def gen_shading_grad_fixed():
         arr.update({f"colors_{step}": colors, f"loss_nis_{step}": outputs["loss_nis"], f"loss_nis_diffuse_{step}": outputs["loss_nis_diffuse"],
                     f"loss_nis_specular_{step}": outputs["loss_nis_specular"]})
         arr.update({f"grad{step}/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        arr.update(aux_arrays(outputs, f"out{step}/"))
+        arr.update({f"out{step}/" + k: outputs[k] for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light")})
         print(step, "loss_nis", float(outputs["loss_nis"]), "tensors with grad", sum(p.grad is not None for p in net.parameters()))
     save("shading_grad_fixed", **arr)           # network state and mesh: shading_grad.npz (same seed)
 
@@ -660,6 +762,7 @@ def gen_shading_direction():
     c, o = net(pts, view, nrm, None, 100, False)
     ((c * w).sum() + o["loss_nis"]).backward()
     arr.update({"colors_100": c})
+    arr.update(aux_arrays(o, "out100/"))
     # (the flows' own gradients are pinned by shading_grad / shading_grad_fixed: not stored again)
     arr.update({"grad100/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and not k.startswith("flow_")})
     # the same pass in fp64 (the reference's module, default dtype switched): how far the reference's own fp32 gradients are from
@@ -695,6 +798,7 @@ def gen_shading_direction():
     c, o = net(pts, view, nrm, None, 1200, False)
     ((c * w).sum() + o["loss_nis"]).backward()
     arr.update({"colors_1200": c, "loss_nis_1200": o["loss_nis"]})
+    arr.update(aux_arrays(o, "out1200/"))
     arr.update({"grad1200/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and not k.startswith("flow_")})
     print("grads:", sum(k.startswith("grad100/") for k in arr), sum(k.startswith("grad1200/") for k in arr))
     save("shading_direction", sd=changed, **arr)       # the rest of the state and the mesh: shading_grad.npz
@@ -783,11 +887,13 @@ def gen_shading_custom():
             "indirect_light", "rgb_pr_nis", "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis",
             "diffuse_light_nis", "specular_light_nis")
     arr.update({"out/" + k: outputs[k] for k in keep})
+    arr.update(aux_arrays(outputs))
     arr.update(colors=colors, gl_dirs=dirs, gl_lights=lights, gl_hit=hit, gl_human=hlw)
     net.zero_grad()
     c, o = net(pts, view, nrm, poses, 100, False)
     ((c * w).sum() + o["loss_nis"]).backward()
     arr.update({"colors_100": c})
+    arr.update(aux_arrays(o, "out100/"))
     arr.update({"grad100/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and (k.startswith("outer_light") or k.startswith("human_light") or k.startswith("mat_line") or k.startswith("roughness_predictor.2"))})
     for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
         for p in fl.parameters():
@@ -797,6 +903,7 @@ def gen_shading_custom():
     c, o = net(pts, view, nrm, poses, 1200, False)
     ((c * w).sum() + o["loss_nis"]).backward()
     arr.update({"colors_1200": c, "loss_nis_1200": o["loss_nis"]})
+    arr.update(aux_arrays(o, "out1200/"))
     arr.update({"grad1200/" + k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None and (k.startswith("outer_light") or k.startswith("human_light") or k.startswith("mat_line"))})
     print("grads:", sum(k.startswith("grad100/") for k in arr), sum(k.startswith("grad1200/") for k in arr))
     save("shading_custom", sd=changed, **arr)
@@ -965,7 +1072,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
