@@ -133,12 +133,30 @@ int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, 
 
 /* ShapeRenderer.compute_sdf_alpha (shapeRenderer.py:995-1025) = forward + 6-tap central
  * differences (fields.py:227-260) + NeuS alpha.  units_host[3] = aabbSize/(R-1).
- * Outputs: alpha[n], grad[n,3], feat[n,A] (may be NULL), sdf[n], nhess[n] (normal_hessian; may be NULL). */
+ * Outputs: alpha[n], grad[n,3], feat[n,A] (may be NULL), sdf[n], nhess[n] (normal_hessian; may be NULL), taps[n,6] (may be NULL:
+ * the six finite-difference sdf values x+, x-, y+, y-, z+, z- of fields.py:236-249, kept for tf_sdf_alpha_bwd). */
 int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
                      const float* level, const float* dists, const float* dirs, const float* aabb_host,
                      const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha,
-                     float* grad, float* feat, float* sdf, float* nhess, int32_t precision, float* workspace,
+                     float* grad, float* feat, float* sdf, float* nhess, float* taps, int32_t precision, float* workspace,
                      size_t workspace_floats, tf_stream_t stream);
+
+/* Backward of compute_sdf_alpha -- what autograd does to shapeRenderer.py:995-1025 over fields.py:227-260 (central differences,
+ * normal_hessian), :262-299 (7 x gather + decoder) and other_field.py:193-207 (inv_s) in the reference -- as ONE entry point: the
+ * closed-form adjoint of alpha / cos annealing / finite differences / hessian term per sample, one recompute of the hidden layer per
+ * tap (same arithmetic as the forward: `precision`), the decoder's three products on the exact-fp32 matrix cores and the 7-tap
+ * scatter into the pyramid gradient.  Inputs as tf_sdf_alpha_fwd plus its outputs sdf [n] and taps [n,6] and the upstream gradients
+ * g_alpha [n], g_grad [n,3], g_feat [n,A], g_sdf [n], g_nhess [n] (each may be NULL = zero).
+ * Outputs: gpacked (pyramid-shaped, += with fp32 atomics: zero it first; tf_vm_pack_bwd folds it back to planes / lines),
+ * g_w1 [Hd, 3C+3], g_b1 [Hd], g_w2 [1+A, Hd], g_b2 [1+A] (overwritten), g_inv_s (one device float, overwritten; may be NULL).
+ * workspace: tf_sdf_alpha_bwd_workspace_floats(n) floats (bounded: samples are processed in chunks of 2^18). */
+size_t tf_sdf_alpha_bwd_workspace_floats(int64_t n);
+int tf_sdf_alpha_bwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts, const float* level,
+                     const float* dists, const float* dirs, const float* aabb_host, const float* units_host, float inv_s,
+                     float cos_anneal, int64_t n, const float* sdf, const float* taps, const float* g_alpha, const float* g_grad,
+                     const float* g_feat, const float* g_sdf, const float* g_nhess, float* gpacked, float* g_w1, float* g_b1,
+                     float* g_w2, float* g_b2, float* g_inv_s, int32_t precision, float* workspace, size_t workspace_floats,
+                     tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Packed-ray compositing: nerfacc.render_weight_from_alpha + accumulate_along_rays

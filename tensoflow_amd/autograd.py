@@ -265,31 +265,43 @@ def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, i
 
 
 class SdfAlphaFn(torch.autograd.Function):
-    """ShapeRenderer.compute_sdf_alpha: forward = the fused HIP kernel (tf_sdf_alpha_fwd).  Backward recomputes through
-    `sdf_alpha_composed` -- HIP gather/scatter for the field, HIP dense-layer kernels for the decoder -- and returns gradients for
-    planes, lines, W1, b1, W2, b2 and inv_s."""
+    """ShapeRenderer.compute_sdf_alpha: forward = the fused HIP kernel (tf_sdf_alpha_fwd, which also keeps the six finite-difference
+    sdf values), backward = tf_sdf_alpha_bwd: ONE entry point (closed-form adjoint of alpha / cos annealing / finite differences /
+    hessian term, one recompute of the hidden layer per tap, the decoder's products on the exact-fp32 matrix cores, the 7-tap
+    scatter) + tf_vm_pack_bwd; gradients for planes, lines, W1, b1, W2, b2 and inv_s.  `sdf_alpha_composed` (the torch composition of
+    rounds 1-3, ~160 launches) is kept as the checker of tests/test_gpu_sdf_bwd.py and behind TENSOFLOW_SDF_BWD=composed."""
 
     @staticmethod
     def forward(ctx, pts, level, dists, dirs, inv_s, cos_anneal, aabb, units, n_levels, *params):
         planes, lines = list(params[:3]), list(params[3:6])
         W1, b1, W2, b2 = params[6:10]
         packed = ops.VmPacked(planes, lines, n_levels)
-        alpha, grad, feat, sdf, nh = ops.sdf_alpha(packed, W1.detach(), b1.detach(), W2.detach(), b2.detach(), pts, level, dists, dirs,
-                                                   aabb, units, float(inv_s), cos_anneal)
-        ctx.save_for_backward(pts, level if level is not None else torch.empty(0, device=pts.device), dists, dirs, inv_s, *params)
+        inv_host = float(inv_s)
+        alpha, grad, feat, sdf, nh, taps = ops.sdf_alpha(packed, W1.detach(), b1.detach(), W2.detach(), b2.detach(), pts, level, dists, dirs,
+                                                         aabb, units, inv_host, cos_anneal, want_taps=True)
+        ctx.save_for_backward(pts, level if level is not None else torch.empty(0, device=pts.device), dists, dirs, inv_s, sdf, taps, *params)
         ctx.cfg = (cos_anneal, aabb, units, n_levels, level is not None)
+        ctx.packed = packed
+        ctx.inv_s_host = inv_host                    # (the forward already read it back for the kernel argument: no second sync in backward)
         return alpha, grad, feat, sdf, nh
 
     @staticmethod
     def backward(ctx, g_alpha, g_grad, g_feat, g_sdf, g_nh):
-        pts, level, dists, dirs, inv_s, *params = ctx.saved_tensors
+        import os
+        pts, level, dists, dirs, inv_s, sdf, taps, *params = ctx.saved_tensors
         cos_anneal, aabb, units, n_levels, has_level = ctx.cfg
-        with torch.enable_grad():
-            leaf = [p.detach().requires_grad_(True) for p in params]
-            inv = inv_s.detach().requires_grad_(True)
-            outs = sdf_alpha_composed(leaf[:3], leaf[3:6], leaf[6], leaf[7], leaf[8], leaf[9], pts, level if has_level else None,
-                                      dists, dirs, inv, cos_anneal, aabb, units, n_levels)
-            gs = [g_alpha, g_grad, g_feat, g_sdf, g_nh]
-            pairs = [(o, g) for o, g in zip(outs, gs) if g is not None]
-            grads = torch.autograd.grad([o for o, _ in pairs], leaf + [inv], [g for _, g in pairs], allow_unused=True)
-        return (None, None, None, None, grads[-1], None, None, None, None, *grads[:-1])
+        if os.environ.get("TENSOFLOW_SDF_BWD") == "composed":         # dev switch: the torch composition
+            with torch.enable_grad():
+                leaf = [p.detach().requires_grad_(True) for p in params]
+                inv = inv_s.detach().requires_grad_(True)
+                outs = sdf_alpha_composed(leaf[:3], leaf[3:6], leaf[6], leaf[7], leaf[8], leaf[9], pts, level if has_level else None,
+                                          dists, dirs, inv, cos_anneal, aabb, units, n_levels)
+                gs = [g_alpha, g_grad, g_feat, g_sdf, g_nh]
+                pairs = [(o, g) for o, g in zip(outs, gs) if g is not None]
+                grads = torch.autograd.grad([o for o, _ in pairs], leaf + [inv], [g for _, g in pairs], allow_unused=True)
+            return (None, None, None, None, grads[-1], None, None, None, None, *grads[:-1])
+        W1, b1, W2, b2 = [p.detach() for p in params[6:10]]
+        gp, g_w1, g_b1, g_w2, g_b2, g_inv = ops.sdf_alpha_bwd(ctx.packed, W1, b1, W2, b2, pts, level if has_level else None, dists, dirs, aabb,
+                                                              units, ctx.inv_s_host, cos_anneal, sdf, taps, g_alpha, g_grad, g_feat, g_sdf, g_nh)
+        gplanes, glines = ctx.packed.unpack_grad(gp, params[:3], params[3:6])
+        return (None, None, None, None, g_inv.reshape(inv_s.shape), None, None, None, None, *gplanes, *glines, g_w1, g_b1, g_w2, g_b2)

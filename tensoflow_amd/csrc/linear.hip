@@ -14,6 +14,7 @@
 // chunks of 16 through LDS ([k][m] / [k][n] images: a lane's MFMA operand is one dword, consecutive lanes consecutive addresses).
 #include "mfma_mlp.h"
 #include "tf_common.h"
+#include "tf_internal.h"
 
 #ifndef TF_GEMM2
 #define TF_GEMM2 1      // 0 (dev switch): every product on the register-staged kernel
@@ -509,6 +510,61 @@ __global__ void __launch_bounds__(256) act_bwd_small_kernel(const float* __restr
 }
 }  // namespace
 
+// The two backward products of a dense layer given gZ = d loss / d (pre-activation) [n,N]: gX [n,K] = gZ . W (overwritten) and
+// gW [N,K] += gZ^T . X (ATOMIC accumulation into whatever gW holds: tf_linear_bwd zeroes it first; tf_sdf_alpha_bwd accumulates over
+// sample chunks).  Internal to the library (tf_internal.h): no activation pass, no bias gradient.
+int tf_linear_products(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
+                       const long long* n_dev, hipStream_t stream) {
+  const bool h3 = precision == TF_PREC_F16X3;
+  if (n == 0) return TF_OK;
+  if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
+    const long long* nd = n_dev;
+#define TF_THIN(NO)                                                                                                                  \
+    do {                                                                                                                              \
+      if (gX) thin_data_kernel<NO><<<tf_blocks(n * (K / 4), 256), 256, 0, stream>>>(gZ, W, n, K, gX, nd);                             \
+      if (gW) thin_weight_kernel<NO><<<tf_blocks(n, 1024), 256, 0, stream>>>(gZ, X, n, K, gW, nd);                                     \
+    } while (0)
+    if (N == 1) TF_THIN(1); else if (N == 2) TF_THIN(2); else if (N == 3) TF_THIN(3); else TF_THIN(4);
+#undef TF_THIN
+    TF_LAUNCH_CHECK("tf_linear_bwd(thin)");
+    return TF_OK;
+  }
+  const bool g2 = !h3 && TF_GEMM2 && K % 4 == 0 && N % 4 == 0 && N >= 32 && K >= 32 && wide_cols_pay(N) && wide_cols_pay(K) &&
+                  aligned16(X) && aligned16(W) && aligned16(gZ);
+  if (gX) {   // gX [n,K] = gZ [n,N] . W [N,K]
+    int rc;
+    if (g2) {
+      Gemm2Args G2{gZ, N, W, K, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
+      rc = launch2<true, false>(G2, 1, stream, "tf_linear_bwd(data)");
+    } else {
+      GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
+      rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
+    }
+    if (rc != TF_OK) return rc;
+  }
+  if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
+#ifndef TF_WGRAD_SPLIT
+#define TF_WGRAD_SPLIT 1024
+#endif
+    // rows per workgroup: 1 024 for long matrices (enough workgroups to fill the chip at n ~ 2e5; larger slabs measured no faster);
+    // a 2 048-row layer cut that way was two slabs of 64 dependent chunks each -- 85 us for a 2 MB product: short matrices get
+    // slabs of n / 256 rows (>= 64).  Each workgroup adds its tile atomically.
+    long long split = TF_WGRAD_SPLIT;
+    if (n / 256 < split) split = ((n / 256 + 15) / 16) * 16 < 64 ? 64 : ((n / 256 + 15) / 16) * 16;
+    const int splits = (int)((n + split - 1) / split);
+    int rc;
+    if (g2) {
+      Gemm2Args G2{gZ, N, X, K, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, n_dev, 0};
+      rc = launch2<false, false>(G2, splits, stream, "tf_linear_bwd(weight)");
+    } else {
+      GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, n_dev, 0};
+      rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
+    }
+    if (rc != TF_OK) return rc;
+  }
+  return TF_OK;
+}
+
 extern "C" int tf_linear_fwd(const float* X, const float* W, const float* b, int64_t n, int32_t K, int32_t N, int32_t act, float act_param,
                              int32_t precision, float* Y, const int64_t* n_dev, tf_stream_t stream) {
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_fwd: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
@@ -555,50 +611,5 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   }
   else act_bwd_small_kernel<<<tf_blocks(n * N, 4096), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
-  if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
-    const long long* nd = (const long long*)n_dev;
-#define TF_THIN(NO)                                                                                                                  \
-    do {                                                                                                                              \
-      if (gX) thin_data_kernel<NO><<<tf_blocks(n * (K / 4), 256), 256, 0, stream>>>(gZ, W, n, K, gX, nd);                             \
-      if (gW) thin_weight_kernel<NO><<<tf_blocks(n, 1024), 256, 0, stream>>>(gZ, X, n, K, gW, nd);                                     \
-    } while (0)
-    if (N == 1) TF_THIN(1); else if (N == 2) TF_THIN(2); else if (N == 3) TF_THIN(3); else TF_THIN(4);
-#undef TF_THIN
-    TF_LAUNCH_CHECK("tf_linear_bwd(thin)");
-    return TF_OK;
-  }
-  const bool g2 = !h3 && TF_GEMM2 && K % 4 == 0 && N % 4 == 0 && N >= 32 && K >= 32 && wide_cols_pay(N) && wide_cols_pay(K) &&
-                  aligned16(X) && aligned16(W) && aligned16(gZ);
-  if (gX) {   // gX [n,K] = gZ [n,N] . W [N,K]
-    int rc;
-    if (g2) {
-      Gemm2Args G2{gZ, N, W, K, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
-      rc = launch2<true, false>(G2, 1, stream, "tf_linear_bwd(data)");
-    } else {
-      GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, (const long long*)n_dev, 1};
-      rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
-    }
-    if (rc != TF_OK) return rc;
-  }
-  if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
-#ifndef TF_WGRAD_SPLIT
-#define TF_WGRAD_SPLIT 1024
-#endif
-    // rows per workgroup: 1 024 for long matrices (enough workgroups to fill the chip at n ~ 2e5; larger slabs measured no faster);
-    // a 2 048-row layer cut that way was two slabs of 64 dependent chunks each -- 85 us for a 2 MB product: short matrices get
-    // slabs of n / 256 rows (>= 64).  Each workgroup adds its tile atomically.
-    long long split = TF_WGRAD_SPLIT;
-    if (n / 256 < split) split = ((n / 256 + 15) / 16) * 16 < 64 ? 64 : ((n / 256 + 15) / 16) * 16;
-    const int splits = (int)((n + split - 1) / split);
-    int rc;
-    if (g2) {
-      Gemm2Args G2{gZ, N, X, K, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
-      rc = launch2<false, false>(G2, splits, stream, "tf_linear_bwd(weight)");
-    } else {
-      GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, (const long long*)n_dev, 0};
-      rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
-    }
-    if (rc != TF_OK) return rc;
-  }
-  return TF_OK;
+  return tf_linear_products(X, W, gZ, n, K, N, h3 ? TF_PREC_F16X3 : TF_PREC_F32, gX, gW, (const long long*)n_dev, stream);
 }

@@ -16,8 +16,11 @@
 //   * the field (51 MB at R=300 incl. mips) is served from L2 / Infinity Cache after first touch.
 // Algorithmic gather traffic: 7 x (3 planes x 4 texels + 3 lines x 2 texels) x C x 4 B = 18 144 B per live
 // sample and mip level (C = 36); flops: 122 880 + 6 x 57 344 = 466 944 per sample (fp32 MFMA).
+#include <type_traits>
+
 #include "mfma_mlp.h"
 #include "tf_common.h"
+#include "tf_internal.h"
 
 #define SDF_C 36
 #define SDF_HID 256
@@ -57,6 +60,7 @@ struct SdfArgs {
   float* alpha;
   float* grad;
   float* nhess;
+  float* taps;          // [n,6] or null: the six finite-difference sdf values (x+, x-, y+, y-, z+, z-), kept for tf_sdf_alpha_bwd
 };
 
 __device__ __forceinline__ float4 f4_lerp(float4 a, float4 b, float t) {
@@ -115,7 +119,7 @@ __device__ __forceinline__ float4 blend_chunk(const ChunkRaw (&r)[NL], float fl)
 // execute, the 12*NL texel loads of group g+1 are already in flight.
 template <int NL, bool H3, bool TEX16>
 __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
-                                               int l1, float fl, int lane, f32x16 (&acc)[8]) {
+                                               int l1, float fl, int lane, f32x16 (&acc)[8], float* xrow = nullptr) {
   // Make the LDS base opaque per call: every LDS operand of this function (W1 fragments, biases, the sdf row of
   // W2: ~700 values per lane) is loop-invariant across tiles and taps, and the compiler otherwise hoists them all
   // out of the tile loop, spills them, and reloads each one from scratch behind an s_waitcnt vmcnt(0).
@@ -152,6 +156,9 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
     for (int c = 0; c < 2; ++c) {
       float4 f = blend_chunk<NL>(raw[c], fl);
       if (g == 6 && c == 1) f = h ? make_float4(x[0], x[1], x[2], 0.f) : f;   // raw xyz (fields.py:265,298)
+      // backward pass (tf_sdf_alpha_bwd): the decoder's input row [108 features | xyz | 1] goes to memory as it is assembled -- the
+      // 112th column holds 1 so that the weight-gradient product of the first layer returns the bias gradient in its last column
+      if (xrow) *reinterpret_cast<float4*>(xrow + 4 * (4 * g + 2 * c + h)) = (g == 6 && c == 1 && h) ? make_float4(f.x, f.y, f.z, 1.f) : f;
       f8[4 * c + 0] = f.x; f8[4 * c + 1] = f.y; f8[4 * c + 2] = f.z; f8[4 * c + 3] = f.w;
     }
     if (g + 1 < 7) issue(g + 1);
@@ -205,10 +212,10 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
 
 template <bool H3, bool TEX16>
 __device__ __forceinline__ float sdf_hidden(const SdfArgs& A, const float* lds, const float (&x)[3], int l0,
-                                            int l1, float fl, int lane, f32x16 (&acc)[8]) {
+                                            int l1, float fl, int lane, f32x16 (&acc)[8], float* xrow = nullptr) {
   // wave-uniform choice: one mip level is enough when no lane has a fractional LOD
-  if (__any(fl != 0.f)) return sdf_hidden_nl<2, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc);
-  return sdf_hidden_nl<1, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc);
+  if (__any(fl != 0.f)) return sdf_hidden_nl<2, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc, xrow);
+  return sdf_hidden_nl<1, H3, TEX16>(A, lds, x, l0, l1, fl, lane, acc, xrow);
 }
 
 template <int MODE, bool H3, bool TEX16 = false>  // MODE 0: sdf + feat, 1: sdf only, 2: alpha (7 taps); H3: f16x3 matrix arithmetic; TEX16: half pyramid
@@ -291,6 +298,10 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
       A.grad[3 * row] = g[0]; A.grad[3 * row + 1] = g[1]; A.grad[3 * row + 2] = g[2];
       A.sdf[row] = s_c;
       if (A.nhess) A.nhess[row] = (g[0] * hs[0] + g[1] * hs[1] + g[2] * hs[2]) / (g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + 1e-5f);
+      if (A.taps) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { A.taps[6 * row + 2 * ax] = sp[ax]; A.taps[6 * row + 2 * ax + 1] = sn[ax]; }
+      }
     }
   }
 }
@@ -369,7 +380,7 @@ extern "C" int tf_sdf_forward(const TfVmDesc* d, const float* packed, const TfSd
 extern "C" int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts,
                                 const float* level, const float* dists, const float* dirs, const float* aabb_host,
                                 const float* units_host, float inv_s, float cos_anneal, int64_t n, float* alpha, float* grad,
-                                float* feat, float* sdf, float* nhess, int32_t precision, float* workspace,
+                                float* feat, float* sdf, float* nhess, float* taps, int32_t precision, float* workspace,
                                 size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_alpha_fwd: n < 0");
@@ -380,8 +391,294 @@ extern "C" int tf_sdf_alpha_fwd(const TfVmDesc* d, const float* packed, const Tf
   A.packed = packed; A.pts = pts; A.level = level; A.n = n; A.sdf = sdf; A.feat = feat;
   A.dists = dists; A.dirs = dirs; A.inv_s = inv_s; A.cos_anneal = cos_anneal;
   for (int k = 0; k < 3; ++k) A.units[k] = units_host[k];
-  A.alpha = alpha; A.grad = grad; A.nhess = nhess;
+  A.alpha = alpha; A.grad = grad; A.nhess = nhess; A.taps = taps;
   if (A.g.texel_f16) return sdf_launch<2, true, true>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
   return precision == TF_PREC_F16X3 ? sdf_launch<2, true>(A, mlp->b2, stream, "tf_sdf_alpha_fwd")
                                     : sdf_launch<2, false>(A, mlp->b2, stream, "tf_sdf_alpha_fwd");
+}
+
+
+// =====================================================================================================================
+// Backward of ShapeRenderer.compute_sdf_alpha (shapeRenderer.py:995-1025 over fields.py:227-260, :262-299) as ONE entry point.
+// The reference differentiates 7 x (6 dr.texture + concat + 2 GEMMs) with autograd; rounds 1-3 here re-ran a torch composition
+// (~160 launches, two 939 MB tensors added to each other).  tf_sdf_alpha_bwd is a fixed pipeline of seven launches:
+//   1. dh_app [n,256] = g_feat . W2[1:]                                   (exact-fp32 matrix cores, linear.hip)
+//   2. sdf_bwd_kernel: per sample the closed-form adjoint of alpha / cos / finite differences / normal-hessian -> d s_t for the 7 taps
+//      (from the tap values the forward kept); then per tap the SAME recompute as the forward kernel (gather -> features -> layer 1 ->
+//      Softplus, W1 fragments in LDS) -> h_t; dz_t = (d s_t w2[0] + [t = 0] dh_app) * (1 - exp(-100 h_t)) in the accumulator
+//      registers; rows h_t, dz_t, [features | xyz | 1] go to the workspace, tap-major
+//   3. din [7n,112] = dz . W1,  dW1|db1 [256,112] += dz^T . [X | 1]          (one column of ones: the bias gradient rides along)
+//   4. dW2[0] += ds^T . h (thin kernel),  dW2[1:] += g_feat^T . h_0,  db2 = column sums
+//   5. the 7-tap scatter of din into the pyramid gradient (request-coalesced lane mapping of tf_vm_gather_bwd)
+// Samples are processed in chunks of kBwdChunk so that the workspace stays bounded.
+static constexpr long long kBwdChunk = 1LL << 18;
+static constexpr int kXld = 112;
+
+struct SdfBwdArgs {
+  const float* sdf;      // [n]   forward outputs kept by the caller
+  const float* taps;     // [n,6]
+  const float* g_alpha;  // [n] or null
+  const float* g_grad;   // [n,3] or null
+  const float* g_sdf;    // [n] or null
+  const float* g_nh;     // [n] or null
+  const float* dh_app;   // [n,256] or null (g_feat . W2[1:])
+  float* dz;             // [7n,256]
+  float* hh;             // [7n,256]
+  float* X;              // [7n,112]
+  float* ds;             // [7n]
+  float* scal;           // [2]: d inv_s, sum of ds (= d b2[0])
+};
+
+template <bool H3>
+__global__ void __launch_bounds__(256) sdf_bwd_kernel(SdfArgs A, SdfBwdArgs B) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = A.ws[i];
+  if (threadIdx.x == 0) {
+    int* geo = reinterpret_cast<int*>(lds + kGeo);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        int* e = geo + (i * 4 + l) * 8;
+        e[0] = vm_dim(A.g.ph[i], l); e[1] = vm_dim(A.g.pw[i], l); e[2] = vm_dim(A.g.ll[i], l);
+        e[3] = (int)A.g.poff[i][l]; e[4] = (int)A.g.loff[i][l]; e[5] = e[6] = e[7] = 0;
+      }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long long n_groups = (A.n + 127) / 128;
+  float acc_inv = 0.f, acc_ds = 0.f;
+  for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
+    const long long tile = tg * 4 + wave;
+    asm volatile("" ::: "memory");
+    long long row = tile * 32 + (lane & 31);
+    const bool valid = row < A.n;
+    if (!valid) row = A.n - 1;
+    const float x[3] = {A.pts[3 * row], A.pts[3 * row + 1], A.pts[3 * row + 2]};
+    int l0, l1;
+    float fl;
+    mip_select(A.level ? A.level[row] : 0.f, A.g.n_levels, l0, l1, fl);
+    // ---- closed-form adjoint of everything behind the seven sdf values (both lane halves of a sample compute the same numbers)
+    float ds[7];
+    {
+      const float s0 = B.sdf[row];
+      float sp[3], sn[3], g[3], hs[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        sp[ax] = B.taps[6 * row + 2 * ax]; sn[ax] = B.taps[6 * row + 2 * ax + 1];
+        g[ax] = (sp[ax] - sn[ax]) / (2.f * A.units[ax]);
+        hs[ax] = (sp[ax] + sn[ax] - 2.f * s0) / (A.units[ax] * A.units[ax]);
+      }
+      const float d[3] = {A.dirs[3 * row], A.dirs[3 * row + 1], A.dirs[3 * row + 2]};
+      const float tc = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+      const float ra = -tc * 0.5f + 0.5f, rb = -tc;
+      const float ic = -(fmaxf(ra, 0.f) * (1.f - A.cos_anneal) + fmaxf(rb, 0.f) * A.cos_anneal);
+      const float dist = A.dists[row];
+      const float e = ic * dist * 0.5f;
+      const float pc = sigmoidf_((s0 - e) * A.inv_s), nc = sigmoidf_((s0 + e) * A.inv_s);
+      const float D = pc + 1e-5f, Aq = (pc - nc + 1e-5f) / D;
+      const float ga = B.g_alpha ? B.g_alpha[row] : 0.f;
+      const float dA = (Aq >= 0.f && Aq <= 1.f) ? ga : 0.f;                     // clip passes its gradient on [0, 1] inclusive
+      const float dpc = dA * (1.f - Aq) / D * (pc * (1.f - pc)), dnc = -dA / D * (nc * (1.f - nc));      // adjoints of the two sigmoid ARGUMENTS
+      float ds0 = (dpc + dnc) * A.inv_s;
+      const float de = (dnc - dpc) * A.inv_s;
+      const float dinv = dpc * (s0 - e) + dnc * (s0 + e);
+      const float dic = de * dist * 0.5f;
+      const float dtc = (ra > 0.f ? 0.5f * dic * (1.f - A.cos_anneal) : 0.f) + (rb > 0.f ? dic * A.cos_anneal : 0.f);
+      const float gn = B.g_nh ? B.g_nh[row] : 0.f;
+      const float G2 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + 1e-5f, NUM = g[0] * hs[0] + g[1] * hs[1] + g[2] * hs[2];
+      const float dNUM = gn / G2, dG2 = -gn * NUM / (G2 * G2);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float dg = dtc * d[ax] + (B.g_grad ? B.g_grad[3 * row + ax] : 0.f) + dNUM * hs[ax] + 2.f * dG2 * g[ax];
+        const float dh = dNUM * g[ax] / (A.units[ax] * A.units[ax]);
+        ds[1 + 2 * ax] = dg / (2.f * A.units[ax]) + dh;
+        ds[2 + 2 * ax] = -dg / (2.f * A.units[ax]) + dh;
+        ds0 -= 2.f * dh;
+      }
+      ds[0] = ds0 + (B.g_sdf ? B.g_sdf[row] : 0.f);
+      if (!valid) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) ds[t] = 0.f;
+      }
+      if (valid && h == 0) {
+        acc_inv += dinv;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { acc_ds += ds[t]; B.ds[(long long)t * A.n + row] = ds[t]; }
+      }
+    }
+    // ---- per tap: recompute the hidden layer, form dz in the accumulator registers, write h | dz | input row
+    f32x16 acc[8];
+    // rows of lanes past the end go to the TRASH row 7 n of every buffer: no divergent store paths (the first version -- `if (valid)`
+    // around 64 float4 stores, a per-store `if (centre tap)` -- spilled 513 scalar and 224 vector registers)
+    auto tap = [&](int t, auto app_tag) __attribute__((always_inline)) {
+      constexpr bool APP = decltype(app_tag)::value;
+      const int ax = (t + 1) / 2 - 1;                         // -1: the centre tap
+      const float sgn = (t & 1) ? 1.f : -1.f;
+      float xt[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xt[k] = (k == ax) ? x[k] + sgn * A.units[k] : x[k];        // x + u / x + (-u): the forward's x + u / x - u
+      float dst = ds[0];
+#pragma unroll
+      for (int k = 1; k < 7; ++k) dst = (t == k) ? ds[k] : dst;
+      long long rt = valid ? (long long)t * A.n + row : 7 * A.n;
+      asm volatile("" : "+v"(rt));                            // per-tap row offset: not a loop invariant to hoist and spill
+      sdf_hidden<H3, false>(A, lds, xt, l0, l1, fl, lane, acc, B.X + rt * kXld);
+      float* hrow = B.hh + rt * SDF_HID + 4 * h;
+      float* zrow = B.dz + rt * SDF_HID + 4 * h;
+      const float* arow = APP ? B.dh_app + row * SDF_HID + 4 * h : nullptr;
+      const float* w2r = lds + kW2r0 + h;
+      {
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        w2r += opaque;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (APP) a4 = *reinterpret_cast<const float4*>(arow + 32 * tt + 8 * jj);
+          const float ap[4] = {a4.x, a4.y, a4.z, a4.w};
+          float hv[4], zv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float hval = acc[tt][4 * jj + k];
+            const float dh = dst * w2r[(tt * 16 + 4 * jj + k) * 2] + ap[k];
+            // Softplus'(z) = sigmoid(100 z) = 1 - exp(-100 h); the linear branch (100 z > 20, i.e. h = z > 0.2) has derivative 1
+            const float sg = hval > 0.2f ? 1.f : 1.f - __builtin_amdgcn_exp2f(-144.269504088896341f * hval);
+            hv[k] = hval; zv[k] = dh * sg;
+          }
+          *reinterpret_cast<float4*>(hrow + 32 * tt + 8 * jj) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+          *reinterpret_cast<float4*>(zrow + 32 * tt + 8 * jj) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // the centre tap (which alone carries the appearance features' gradient) is peeled; the six finite-difference taps share ONE copy
+    // of the gather + layer-1 body (seven inlined copies -- the forward kernel's shape -- made every tap's row addresses loop
+    // invariants of the tile loop)
+    if (B.dh_app) tap(0, std::true_type{});
+    else tap(0, std::false_type{});
+#pragma unroll 1
+    for (int t = 1; t < 7; ++t) tap(t, std::false_type{});
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { acc_inv += __shfl_xor(acc_inv, o); acc_ds += __shfl_xor(acc_ds, o); }
+  if (lane == 0) { atomicAdd(B.scal, acc_inv); atomicAdd(B.scal + 1, acc_ds); }
+}
+
+namespace {
+__global__ void __launch_bounds__(256) sdf_pad_w1_kernel(const float* __restrict__ w1, float* __restrict__ w1p) {
+  const int e = blockIdx.x * 256 + threadIdx.x;             // [256, 112] <- [256, 111] | 0
+  if (e >= SDF_HID * kXld) return;
+  const int r = e / kXld, c = e % kXld;
+  w1p[e] = c < 3 * SDF_C + 3 ? w1[r * (3 * SDF_C + 3) + c] : 0.f;
+}
+__global__ void __launch_bounds__(256) sdf_unpad_gw1_kernel(const float* __restrict__ gp, float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= SDF_HID * kXld) return;
+  const int r = e / kXld, c = e % kXld;
+  if (c < 3 * SDF_C + 3) { if (g_w1) g_w1[r * (3 * SDF_C + 3) + c] = gp[e]; }
+  else if (g_b1) g_b1[r] = gp[e];                           // the column of ones: d b1
+}
+// column sums of X [n, N] (N <= 256), added to out[N]
+__global__ void __launch_bounds__(256) sdf_colsum_kernel(const float* __restrict__ X, long long n, int N, float* __restrict__ out) {
+  const long long r0 = (long long)blockIdx.x * 512, r1 = min(r0 + 512, n);
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += X[r * N + j];
+    atomicAdd(out + j, s);
+  }
+}
+__global__ void sdf_finish_scalars_kernel(const float* __restrict__ scal, float* __restrict__ g_inv_s, float* __restrict__ g_b2) {
+  if (threadIdx.x == 0) {
+    if (g_inv_s) g_inv_s[0] = scal[0];
+    if (g_b2) g_b2[0] = scal[1];
+  }
+}
+}  // namespace
+
+extern "C" size_t tf_sdf_alpha_bwd_workspace_floats(int64_t n) {
+  const long long c = n < kBwdChunk ? (n < 1 ? 1 : n) : kBwdChunk;
+  // fragment workspace | scalars + padded W1 + its gradient | dh_app [c,256] | dz, h [7c+1,256] | X, din [7c+1,112] | ds [7c]
+  // (+1: the trash row that lanes past the end write to)
+  return (size_t)kSdfWsFloats + 64 + 2 * SDF_HID * kXld + (size_t)c * SDF_HID + 2 * (size_t)(7 * c + 1) * SDF_HID + 2 * (size_t)(7 * c + 1) * kXld + (size_t)7 * c + 64;
+}
+
+extern "C" int tf_sdf_alpha_bwd(const TfVmDesc* d, const float* packed, const TfSdfMlp* mlp, const float* pts, const float* level,
+                                const float* dists, const float* dirs, const float* aabb_host, const float* units_host, float inv_s,
+                                float cos_anneal, int64_t n, const float* sdf, const float* taps, const float* g_alpha,
+                                const float* g_grad, const float* g_feat, const float* g_sdf, const float* g_nhess, float* gpacked,
+                                float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_inv_s, int32_t precision, float* workspace,
+                                size_t workspace_floats, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_sdf_alpha_bwd: n < 0");
+  TF_REQUIRE(d && mlp && pts && dists && dirs && units_host && aabb_host && workspace, TF_EINVAL, "tf_sdf_alpha_bwd: null pointer");
+  TF_REQUIRE(n == 0 || (sdf && taps && packed), TF_EINVAL, "tf_sdf_alpha_bwd: the forward's sdf / taps outputs and the pyramid are required");
+  TF_REQUIRE(gpacked && g_w1 && g_b1 && g_w2 && g_b2, TF_EINVAL, "tf_sdf_alpha_bwd: null gradient pointer");
+  TF_REQUIRE(!d->texel_f16, TF_EINVAL, "tf_sdf_alpha_bwd: the adjoint takes an fp32 pyramid (texel_f16 is an inference-only format)");
+  TF_REQUIRE(workspace_floats >= tf_sdf_alpha_bwd_workspace_floats(n), TF_ESHAPE, "tf_sdf_alpha_bwd: workspace too small (%zu < %zu floats)",
+             workspace_floats, tf_sdf_alpha_bwd_workspace_floats(n));
+  SdfArgs A = {};
+  if (int rc = sdf_prepare(d, mlp, aabb_host, workspace, workspace_floats, &A, precision, stream, "tf_sdf_alpha_bwd")) return rc;
+  const int K1 = 3 * SDF_C + 3;
+  // gradients of the decoder are overwritten (accumulated over the chunks below)
+  hipError_t e = hipMemsetAsync(g_w2, 0, sizeof(float) * (size_t)(1 + SDF_APP) * SDF_HID, stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_sdf_alpha_bwd: memset failed");
+  e = hipMemsetAsync(g_b2, 0, sizeof(float) * (1 + SDF_APP), stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_sdf_alpha_bwd: memset failed");
+  float* scal = workspace + kSdfWsFloats;                 // [64]
+  float* w1p = scal + 64;                                 // [256,112]
+  float* gw1p = w1p + SDF_HID * kXld;                     // [256,112]
+  e = hipMemsetAsync(scal, 0, sizeof(float) * (64 + 2 * SDF_HID * kXld), stream);
+  TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_sdf_alpha_bwd: memset failed");
+  sdf_pad_w1_kernel<<<tf_blocks(SDF_HID * kXld, 256), 256, 0, stream>>>(mlp->w1, w1p);
+  const long long c_max = n < kBwdChunk ? (n < 1 ? 1 : n) : kBwdChunk;
+  float* dh_app = gw1p + SDF_HID * kXld;
+  float* dz = dh_app + c_max * SDF_HID;
+  float* hh = dz + (7 * c_max + 1) * SDF_HID;
+  float* X = hh + (7 * c_max + 1) * SDF_HID;
+  float* din = X + (7 * c_max + 1) * kXld;
+  float* dsb = din + (7 * c_max + 1) * kXld;
+  const size_t lds = (size_t)kLdsTotal * sizeof(float);
+  static std::atomic<unsigned long long> attr_set{0};
+  int attr_dev;
+  if (tf_once_needed(attr_set, &attr_dev)) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)sdf_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)sdf_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TF_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, TF_EHIP, "tf_sdf_alpha_bwd: hipFuncSetAttribute failed");
+    tf_once_done(attr_set, attr_dev);
+  }
+  A.packed = packed; A.b2 = mlp->b2; A.inv_s = inv_s; A.cos_anneal = cos_anneal;
+  for (int k = 0; k < 3; ++k) A.units[k] = units_host[k];
+  for (long long c0 = 0; c0 < n; c0 += kBwdChunk) {
+    const long long c = (n - c0) < kBwdChunk ? (n - c0) : kBwdChunk;
+    const float* gf = g_feat ? g_feat + c0 * SDF_APP : nullptr;
+    if (gf) {     // dh_app = g_feat . W2[1:]   (gZ [c,128], W [128,256])
+      if (int rc = tf_linear_products(nullptr, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_F32, dh_app, nullptr, nullptr, stream)) return rc;
+    }
+    A.pts = pts + 3 * c0; A.level = level ? level + c0 : nullptr; A.n = c; A.dists = dists + c0; A.dirs = dirs + 3 * c0;
+    SdfBwdArgs B = {sdf + c0, taps + 6 * c0, g_alpha ? g_alpha + c0 : nullptr, g_grad ? g_grad + 3 * c0 : nullptr,
+                    g_sdf ? g_sdf + c0 : nullptr, g_nhess ? g_nhess + c0 : nullptr, gf ? dh_app : nullptr, dz, hh, X, dsb, scal};
+    long long blocks = (c + 127) / 128;
+    if (blocks > 256) blocks = 256;
+    if (precision == TF_PREC_F16X3) sdf_bwd_kernel<true><<<(unsigned)blocks, 256, lds, stream>>>(A, B);
+    else sdf_bwd_kernel<false><<<(unsigned)blocks, 256, lds, stream>>>(A, B);
+    TF_LAUNCH_CHECK("tf_sdf_alpha_bwd(recompute)");
+    // first layer: din = dz . W1p, [dW1 | db1] += dz^T . [X | 1]
+    if (int rc = tf_linear_products(X, w1p, dz, 7 * c, kXld, SDF_HID, TF_PREC_F32, din, gw1p, nullptr, stream)) return rc;
+    // second layer: row 0 (the sdf) over all taps, rows 1.. (appearance features) on the centre tap (rows [0, c) of h)
+    if (int rc = tf_linear_products(hh, mlp->w2, dsb, 7 * c, SDF_HID, 1, TF_PREC_F32, nullptr, g_w2, nullptr, stream)) return rc;
+    if (gf) {
+      if (int rc = tf_linear_products(hh, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_F32, nullptr, g_w2 + SDF_HID, nullptr, stream)) return rc;
+      sdf_colsum_kernel<<<tf_blocks(c, 512), 256, 0, stream>>>(gf, c, SDF_APP, g_b2 + 1);
+    }
+    if (int rc = tf_vm_scatter_taps(A.g, packed, A.pts, A.level, c, A.units, din, kXld, gpacked, stream)) return rc;
+  }
+  sdf_unpad_gw1_kernel<<<tf_blocks(SDF_HID * kXld, 256), 256, 0, stream>>>(gw1p, g_w1, g_b1);
+  sdf_finish_scalars_kernel<<<1, 64, 0, stream>>>(scal, g_inv_s, g_b2);
+  TF_LAUNCH_CHECK("tf_sdf_alpha_bwd");
+  (void)K1;
+  return TF_OK;
 }

@@ -6,6 +6,7 @@
 // optimizer step.  Gather: one lane per (point, 16-byte channel chunk): the 3*C/4 lanes of a point
 // read each touched texel as one contiguous C*4-byte segment.
 #include "tf_common.h"
+#include "tf_internal.h"
 
 // ------------------------------------------------------------------------------------ pack fwd
 // level 0: [C,H,W] -> [H,W,C].  One thread per pixel per pass over channels; transposed through LDS
@@ -159,24 +160,33 @@ __global__ void __launch_bounds__(256) vm_gather_kernel(VmGeom g, const float* _
 // the C lanes of a (point, plane) add to C consecutive words with one atomic instruction per texel -- 16 words per 64-byte atomic
 // request instead of the 4 the float4-chunk mapping of the forward kernel gave (its four per-component atomics each touched every
 // fourth word).  The gradient buffer (51 MB at R = 300) lives behind the L2: the scatter is bound by atomic REQUESTS.
+// Rows beyond the first n_pts are FINITE-DIFFERENCE TAPS of the same points (tf_sdf_alpha_bwd): row r belongs to point r % n_pts and
+// tap r / n_pts (0: the point itself; 1 + 2 ax / 2 + 2 ax: +- tap_units[ax] along axis ax, fields.py:234-256); gfeat rows have stride ld.
+struct VmTaps { long long n_pts; int ld; float units[3]; };
 __global__ void __launch_bounds__(256) vm_scatter_kernel(VmGeom g, const float* __restrict__ packed, const float* __restrict__ xyz,
                                                          const float* __restrict__ level, long long n, const float* __restrict__ gfeat,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, VmTaps T) {
   const int cpp = 3 * g.C;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= n * cpp) return;
-  const long long pt = e / cpp;
+  const long long row = e / cpp;
+  const long long pt = row % T.n_pts;
+  const int tap = (int)(row / T.n_pts);
   const int q = (int)(e % cpp);
   const int i = q / g.C, c = q % g.C;
   float p[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) p[k] = (xyz[pt * 3 + k] - g.aabb_lo[k]) / g.aabb_size[k];
+  for (int k = 0; k < 3; ++k) {
+    float xk = xyz[pt * 3 + k];
+    if (tap > 0 && (tap - 1) / 2 == k) xk += (tap & 1) ? T.units[k] : -T.units[k];      // x + u, x - u exactly as the forward kernel forms them
+    p[k] = (xk - g.aabb_lo[k]) / g.aabb_size[k];
+  }
   const int m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2, vm = 2 - i;
   const float u = p[m0], v = p[m1], wv = p[vm];
   int l0, l1;
   float fl;
   mip_select(level ? level[pt] : 0.f, g.n_levels, l0, l1, fl);
-  const float gs = gfeat[e];
+  const float gs = gfeat[row * T.ld + q];
   float pv = 0.f, lv = 0.f;
   for (int pass = 0; pass < 2; ++pass) {
     for (int li = 0; li < 2; ++li) {
@@ -318,8 +328,22 @@ extern "C" int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const fl
   vm_gather_kernel<true><<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked);
 #else
   long long work = (long long)n * (3 * g.C);
-  vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked);
+  VmTaps T{n, 3 * g.C, {0.f, 0.f, 0.f}};
+  vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(g, packed, xyz, level, n, gfeat, gpacked, T);
 #endif
   TF_LAUNCH_CHECK("tf_vm_gather_bwd");
+  return TF_OK;
+}
+
+
+// Internal (tf_internal.h): the scatter of tf_vm_gather_bwd for the 7 finite-difference taps of n_pts points in one launch --
+// gfeat [7 n_pts, ld] (row = tap * n_pts + point, the first 3C columns are read), gpacked += .
+int tf_vm_scatter_taps(const VmGeom& g, const float* packed, const float* pts, const float* level, long long n_pts, const float* units,
+                       const float* gfeat, int ld, float* gpacked, hipStream_t stream) {
+  if (n_pts == 0) return TF_OK;
+  const long long rows = 7 * n_pts, work = rows * (3 * g.C);
+  VmTaps T{n_pts, ld, {units[0], units[1], units[2]}};
+  vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, stream>>>(g, packed, pts, level, rows, gfeat, gpacked, T);
+  TF_LAUNCH_CHECK("tf_vm_scatter_taps");
   return TF_OK;
 }

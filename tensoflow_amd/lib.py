@@ -67,7 +67,10 @@ SIGNATURES = {
     "tf_sdf_workspace_floats": (sz, []),
     "tf_sdf_forward": (C.c_int, [P(TfVmDesc), c_f, P(TfSdfMlp), c_f, c_f, P(f32 * 6), i64, c_f, c_f, i32, c_f, sz, c_f]),
     "tf_sdf_alpha_fwd": (C.c_int, [P(TfVmDesc), c_f, P(TfSdfMlp), c_f, c_f, c_f, c_f, P(f32 * 6), P(f32 * 3), f32, f32,
-                                   i64, c_f, c_f, c_f, c_f, c_f, i32, c_f, sz, c_f]),
+                                   i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, sz, c_f]),
+    "tf_sdf_alpha_bwd_workspace_floats": (sz, [i64]),
+    "tf_sdf_alpha_bwd": (C.c_int, [P(TfVmDesc), c_f, P(TfSdfMlp), c_f, c_f, c_f, c_f, P(f32 * 6), P(f32 * 3), f32, f32, i64,
+                                   c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, sz, c_f]),
     "tf_composite_fwd": (C.c_int, [c_f, c_f, c_f, i64, i64, i32, c_f, c_f, c_f, c_f]),
     "tf_composite_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, i64, i64, i32, c_f, c_f, c_f]),
     "tf_flow_workspace_floats": (sz, [i64]),

@@ -169,7 +169,7 @@ def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=Tr
 
 
 def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, units, inv_s, cos_anneal,
-              want_feat=True, want_hess=True, precision=None):
+              want_feat=True, want_hess=True, precision=None, want_taps=False):
     """ShapeRenderer.compute_sdf_alpha -> alpha, grad, feat, sdf, normal_hessian.
     precision: PREC_F16X3 (default) / PREC_F32.  (The hessian term's second difference divides rounding noise by eps^2;
     against the reference it measures 1.1e-3 with either decoder -- the reference's own fp32 rounding dominates.)"""
@@ -185,13 +185,43 @@ def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, u
     sdf = torch.empty(n, dtype=torch.float32, device=dev)
     feat = torch.empty(n, w2.shape[0] - 1, dtype=torch.float32, device=dev) if want_feat else None
     nh = torch.empty(n, dtype=torch.float32, device=dev) if want_hess else None
+    taps = torch.empty(n, 6, dtype=torch.float32, device=dev) if want_taps else None      # the six FD sdf values, kept for sdf_alpha_bwd
     ws = _workspace("sdf", lib.tf_sdf_workspace_floats(), dev)
     lv = None if level is None else _f(level.reshape(-1))
     un = (C.c_float * 3)(*[float(u) for u in units])
     L.check(lib.tf_sdf_alpha_fwd(C.byref(packed.desc), packed.ptr(), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
                                  C.byref(_aabb6(aabb)), C.byref(un), float(inv_s), float(cos_anneal), n, _p(alpha), _p(grad),
-                                 _p(feat), _p(sdf), _p(nh), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
+                                 _p(feat), _p(sdf), _p(nh), _p(taps), int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_fwd")
+    if want_taps:
+        return alpha, grad, feat, sdf, nh, taps
     return alpha, grad, feat, sdf, nh
+
+
+def sdf_alpha_bwd(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, units, inv_s, cos_anneal, sdf, taps,
+                  g_alpha=None, g_grad=None, g_feat=None, g_sdf=None, g_nh=None, precision=None):
+    """tf_sdf_alpha_bwd: backward of compute_sdf_alpha in one entry point -> (gpacked [pyramid], g_w1, g_b1, g_w2, g_b2, g_inv_s [1])."""
+    if precision is None:
+        precision = PREC_F16X3
+    if packed.texel_f16:
+        raise RuntimeError("sdf_alpha_bwd: a half pyramid (texel_f16) is an inference-only format")
+    lib = packed.lib
+    pts, dists, dirs = _f(pts), _f(dists.reshape(-1)), _f(dirs)
+    n = pts.shape[0]
+    dev = pts.device
+    mlp, keep = _sdf_mlp(w1, b1, w2, b2)
+    gpacked = torch.zeros_like(packed.data)
+    g_w1, g_b1, g_w2, g_b2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)
+    g_inv = torch.zeros(1, dtype=torch.float32, device=dev)
+    ws = _workspace("sdf_bwd", lib.tf_sdf_alpha_bwd_workspace_floats(n), dev)
+    lv = None if level is None else _f(level.reshape(-1))
+    un = (C.c_float * 3)(*[float(u) for u in units])
+    g = lambda t, shape: None if t is None else _f(t).reshape(shape)
+    ga, gg, gf, gs, gn = g(g_alpha, (n,)), g(g_grad, (n, 3)), g(g_feat, (n, w2.shape[0] - 1)), g(g_sdf, (n,)), g(g_nh, (n,))
+    L.check(lib.tf_sdf_alpha_bwd(C.byref(packed.desc), _p(packed.data), C.byref(mlp), _p(pts), _p(lv), _p(dists), _p(dirs),
+                                 C.byref(_aabb6(aabb)), C.byref(un), float(inv_s), float(cos_anneal), n, _p(_f(sdf)), _p(_f(taps)),
+                                 _p(ga), _p(gg), _p(gf), _p(gs), _p(gn), _p(gpacked), _p(g_w1), _p(g_b1), _p(g_w2), _p(g_b2), _p(g_inv),
+                                 int(precision), _p(ws), ws.numel(), _stream()), "tf_sdf_alpha_bwd")
+    return gpacked, g_w1, g_b1, g_w2, g_b2, g_inv
 
 
 # ------------------------------------------------------------------------------ compositing
