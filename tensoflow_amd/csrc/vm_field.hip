@@ -217,6 +217,149 @@ __global__ void __launch_bounds__(256) vm_scatter_kernel(VmGeom g, const float* 
   }
 }
 
+// ---- the 7-tap scatter with the taps of a point MERGED before they leave the lane.  The finite-difference taps sit one texel pitch
+// apart (units = aabbSize / (R - 1), texel pitch aabbSize / R: 1.003 texels at level 0, half of that per mip level), so their
+// bilinear footprints overlap: on plane i the taps along the LINE axis share the centre's four texels outright, the taps along an
+// in-plane axis land inside a window of six texels around the centre's pair, and on the line the five taps that do not move along it
+// share the centre's two texels.  One lane = (point, plane, channel): it accumulates the seven taps' contributions per UNIQUE texel in
+// registers (windows indexed relative to the centre's floor index) and issues one atomic per texel that received anything: ~16
+// atomic instructions per level instead of 42 -- the scatter is bound by atomic REQUESTS behind the L2.
+struct AxisTap { int i; float f; };      // UNCLAMPED floor index and fraction (axis_taps clamps i, i + 1 into [0, n - 1])
+__device__ __forceinline__ AxisTap axis_tap_raw(float t01, int n) {
+  const float u = t01 * (float)n - 0.5f;
+  const float fl = floorf(u);
+  AxisTap a; a.i = (int)fl; a.f = u - fl;
+  return a;
+}
+__device__ __forceinline__ int clampi(int v, int n) { return min(max(v, 0), n - 1); }
+__device__ __forceinline__ float pick6(const float (&a)[6], int r) {
+  float v = a[0];
+#pragma unroll
+  for (int k = 1; k < 6; ++k) v = (r == k) ? a[k] : v;
+  return v;
+}
+__device__ __forceinline__ void add6(float (&a)[6], int r, float v) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a[k] += (r == k) ? v : 0.f;
+}
+
+__global__ void __launch_bounds__(256) vm_scatter7_kernel(VmGeom g, const float* __restrict__ packed, const float* __restrict__ xyz,
+                                                          const float* __restrict__ level, long long n_pts, const float* __restrict__ gfeat,
+                                                          float* __restrict__ out, VmTaps T) {
+  const int cpp = 3 * g.C;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_pts * cpp) return;
+  const long long pt = e / cpp;
+  const int q = (int)(e % cpp);
+  const int i = q / g.C, c = q % g.C;
+  const int m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2, vm = 2 - i;       // world axes of the plane's x, y and of the line
+  // normalised coordinates of the centre and of the +- taps per axis, formed exactly as the forward kernel forms them ((x +- u) - lo) / size
+  float pc[3], pp[3], pm[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float xk = xyz[pt * 3 + k];
+    pc[k] = (xk - g.aabb_lo[k]) / g.aabb_size[k];
+    pp[k] = ((xk + T.units[k]) - g.aabb_lo[k]) / g.aabb_size[k];
+    pm[k] = ((xk - T.units[k]) - g.aabb_lo[k]) / g.aabb_size[k];
+  }
+  int l0, l1;
+  float fl;
+  mip_select(level ? level[pt] : 0.f, g.n_levels, l0, l1, fl);
+  // upstream gradients of this (plane, channel) for the seven taps: tap 0 centre, 1 + 2 k / 2 + 2 k = +- along world axis k
+  float gs[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) gs[t] = gfeat[((long long)t * n_pts + pt) * T.ld + q];
+  // taps of this plane by ROLE: 0 centre, 1 / 2 = + / - along the plane's x, 3 / 4 = + / - along its y, 5 / 6 = + / - along the line
+  const float gr[7] = {gs[0], gs[1 + 2 * m0], gs[2 + 2 * m0], gs[1 + 2 * m1], gs[2 + 2 * m1], gs[1 + 2 * vm], gs[2 + 2 * vm]};
+  float pv[7] = {0, 0, 0, 0, 0, 0, 0}, lv[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int li = 0; li < 2; ++li) {
+      if (li && fl == 0.f) break;
+      const int l = li ? l1 : l0;
+      const float wl = li ? fl : 1.f - fl;
+      const int H = vm_dim(g.ph[i], l), W = vm_dim(g.pw[i], l), L = vm_dim(g.ll[i], l);
+      const long long pb = g.poff[i][l] + c, lb = g.loff[i][l] + c;
+      const AxisTap xc = axis_tap_raw(pc[m0], W), xp = axis_tap_raw(pp[m0], W), xm = axis_tap_raw(pm[m0], W);
+      const AxisTap yc = axis_tap_raw(pc[m1], H), yp = axis_tap_raw(pp[m1], H), ym = axis_tap_raw(pm[m1], H);
+      const AxisTap zc = axis_tap_raw(pc[vm], L), zp = axis_tap_raw(pp[vm], L), zm = axis_tap_raw(pm[vm], L);
+      // window slots: index - (centre index - 2) in [0, 5]; a tap further than two texels from the centre (cannot happen while
+      // units = size / (R - 1)) is clamped into the window's edge -- caught by the host-side check of tf_vm_scatter_taps
+      const int rxp = min(max(xp.i - xc.i + 2, 0), 4), rxm = min(max(xm.i - xc.i + 2, 0), 4);
+      const int ryp = min(max(yp.i - yc.i + 2, 0), 4), rym = min(max(ym.i - yc.i + 2, 0), 4);
+      const int rzp = min(max(zp.i - zc.i + 2, 0), 4), rzm = min(max(zm.i - zc.i + 2, 0), 4);
+      const int y0 = clampi(yc.i, H), y1 = clampi(yc.i + 1, H), x0 = clampi(xc.i, W), x1 = clampi(xc.i + 1, W);
+      if (pass == 0) {
+        // texel values of the three windows (rows y0 / y1 over six columns; columns x0 / x1 over six rows; six line texels)
+        float PX0[6], PX1[6], PY0[6], PY1[6], LZ[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int xr = clampi(xc.i - 2 + r, W), yr = clampi(yc.i - 2 + r, H), zr = clampi(zc.i - 2 + r, L);
+          PX0[r] = packed[pb + ((long long)y0 * W + xr) * g.C];
+          PX1[r] = packed[pb + ((long long)y1 * W + xr) * g.C];
+          PY0[r] = packed[pb + ((long long)yr * W + x0) * g.C];
+          PY1[r] = packed[pb + ((long long)yr * W + x1) * g.C];
+          LZ[r] = packed[lb + (long long)zr * g.C];
+        }
+        auto bil_x = [&](int r, float fx) {      // plane value of a tap displaced along x: columns r, r + 1 of both rows, the centre's fy
+          const float top = pick6(PX0, r) * (1.f - fx) + pick6(PX0, r + 1) * fx, bot = pick6(PX1, r) * (1.f - fx) + pick6(PX1, r + 1) * fx;
+          return top * (1.f - yc.f) + bot * yc.f;
+        };
+        auto bil_y = [&](int r, float fy) {      // displaced along y: rows r, r + 1 of both columns, the centre's fx
+          const float top = pick6(PY0, r) * (1.f - xc.f) + pick6(PY1, r) * xc.f, bot = pick6(PY0, r + 1) * (1.f - xc.f) + pick6(PY1, r + 1) * xc.f;
+          return top * (1.f - fy) + bot * fy;
+        };
+        auto lin_z = [&](int r, float fz) { return pick6(LZ, r) * (1.f - fz) + pick6(LZ, r + 1) * fz; };
+        const float pcv = bil_x(2, xc.f), lcv = lin_z(2, zc.f);
+        pv[0] += wl * pcv; lv[0] += wl * lcv;
+        pv[1] += wl * bil_x(rxp, xp.f); lv[1] += wl * lcv;
+        pv[2] += wl * bil_x(rxm, xm.f); lv[2] += wl * lcv;
+        pv[3] += wl * bil_y(ryp, yp.f); lv[3] += wl * lcv;
+        pv[4] += wl * bil_y(rym, ym.f); lv[4] += wl * lcv;
+        pv[5] += wl * pcv; lv[5] += wl * lin_z(rzp, zp.f);
+        pv[6] += wl * pcv; lv[6] += wl * lin_z(rzm, zm.f);
+      } else {
+        float AX0[6] = {0, 0, 0, 0, 0, 0}, AX1[6] = {0, 0, 0, 0, 0, 0}, AY0[6] = {0, 0, 0, 0, 0, 0}, AY1[6] = {0, 0, 0, 0, 0, 0},
+              AZ[6] = {0, 0, 0, 0, 0, 0};
+        // plane adjoints gP_t = g_t lv_t wl, line adjoints gL_t = g_t pv_t wl
+        float gP[7], gL[7];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) { gP[t] = gr[t] * lv[t] * wl; gL[t] = gr[t] * pv[t] * wl; }
+        // centre and the two taps along the line: the centre's four texels (x window slots 2, 3; rows y0, y1)
+        const float gc = gP[0] + gP[5] + gP[6];
+        AX0[2] += gc * ((1.f - xc.f) * (1.f - yc.f)); AX0[3] += gc * (xc.f * (1.f - yc.f));
+        AX1[2] += gc * ((1.f - xc.f) * yc.f); AX1[3] += gc * (xc.f * yc.f);
+        // taps along x: columns r, r + 1 of rows y0, y1
+        add6(AX0, rxp, gP[1] * ((1.f - xp.f) * (1.f - yc.f))); add6(AX0, rxp + 1, gP[1] * (xp.f * (1.f - yc.f)));
+        add6(AX1, rxp, gP[1] * ((1.f - xp.f) * yc.f)); add6(AX1, rxp + 1, gP[1] * (xp.f * yc.f));
+        add6(AX0, rxm, gP[2] * ((1.f - xm.f) * (1.f - yc.f))); add6(AX0, rxm + 1, gP[2] * (xm.f * (1.f - yc.f)));
+        add6(AX1, rxm, gP[2] * ((1.f - xm.f) * yc.f)); add6(AX1, rxm + 1, gP[2] * (xm.f * yc.f));
+        // taps along y: rows r, r + 1 of columns x0, x1
+        add6(AY0, ryp, gP[3] * ((1.f - xc.f) * (1.f - yp.f))); add6(AY0, ryp + 1, gP[3] * ((1.f - xc.f) * yp.f));
+        add6(AY1, ryp, gP[3] * (xc.f * (1.f - yp.f))); add6(AY1, ryp + 1, gP[3] * (xc.f * yp.f));
+        add6(AY0, rym, gP[4] * ((1.f - xc.f) * (1.f - ym.f))); add6(AY0, rym + 1, gP[4] * ((1.f - xc.f) * ym.f));
+        add6(AY1, rym, gP[4] * (xc.f * (1.f - ym.f))); add6(AY1, rym + 1, gP[4] * (xc.f * ym.f));
+        // the y window's rows 2, 3 ARE the centre's rows y0, y1: fold them into the x window's columns 2, 3
+        AX0[2] += AY0[2]; AX1[2] += AY0[3]; AX0[3] += AY1[2]; AX1[3] += AY1[3];
+        AY0[2] = AY0[3] = AY1[2] = AY1[3] = 0.f;
+        // line: the five taps that do not move along it share the centre's two texels
+        const float glc = gL[0] + gL[1] + gL[2] + gL[3] + gL[4];
+        AZ[2] += glc * (1.f - zc.f); AZ[3] += glc * zc.f;
+        add6(AZ, rzp, gL[5] * (1.f - zp.f)); add6(AZ, rzp + 1, gL[5] * zp.f);
+        add6(AZ, rzm, gL[6] * (1.f - zm.f)); add6(AZ, rzm + 1, gL[6] * zm.f);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const int xr = clampi(xc.i - 2 + r, W), yr = clampi(yc.i - 2 + r, H), zr = clampi(zc.i - 2 + r, L);
+          if (AX0[r] != 0.f) atomicAdd(out + pb + ((long long)y0 * W + xr) * g.C, AX0[r]);
+          if (AX1[r] != 0.f) atomicAdd(out + pb + ((long long)y1 * W + xr) * g.C, AX1[r]);
+          if (AY0[r] != 0.f) atomicAdd(out + pb + ((long long)yr * W + x0) * g.C, AY0[r]);
+          if (AY1[r] != 0.f) atomicAdd(out + pb + ((long long)yr * W + x1) * g.C, AY1[r]);
+          if (AZ[r] != 0.f) atomicAdd(out + lb + (long long)zr * g.C, AZ[r]);
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) vm_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long long n) {
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (e + 3 < n) {
@@ -341,9 +484,25 @@ extern "C" int tf_vm_gather_bwd(const TfVmDesc* d, const float* packed, const fl
 int tf_vm_scatter_taps(const VmGeom& g, const float* packed, const float* pts, const float* level, long long n_pts, const float* units,
                        const float* gfeat, int ld, float* gpacked, hipStream_t stream) {
   if (n_pts == 0) return TF_OK;
-  const long long rows = 7 * n_pts, work = rows * (3 * g.C);
   VmTaps T{n_pts, ld, {units[0], units[1], units[2]}};
-  vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, stream>>>(g, packed, pts, level, rows, gfeat, gpacked, T);
+  // the merged kernel's six-texel windows hold taps at most two texels from the centre: units[k] <= 1.5 texel pitches of the level-0 grid
+  // along axis k (the reference's units are size / (R - 1) = R / (R - 1) pitches).  Anything else takes the tap-per-lane kernel.
+  bool merged = true;
+  for (int i = 0; i < 3; ++i) {
+    const int m0 = i == 2 ? 1 : 0, m1 = i == 0 ? 1 : 2, vm = 2 - i;
+    merged = merged && units[m0] * g.pw[i] <= 1.5f * g.aabb_size[m0] && units[m1] * g.ph[i] <= 1.5f * g.aabb_size[m1] &&
+             units[vm] * g.ll[i] <= 1.5f * g.aabb_size[vm] && units[m0] > 0.f && units[m1] > 0.f && units[vm] > 0.f;
+  }
+#ifdef VM_SCATTER_TAP_PER_LANE      // dev-only switch (A/B): round 4's first form, one lane per (tap, point, plane, channel)
+  merged = false;
+#endif
+  if (merged) {
+    const long long work = n_pts * (3 * g.C);
+    vm_scatter7_kernel<<<tf_blocks(work, 256), 256, 0, stream>>>(g, packed, pts, level, n_pts, gfeat, gpacked, T);
+  } else {
+    const long long rows = 7 * n_pts, work = rows * (3 * g.C);
+    vm_scatter_kernel<<<tf_blocks(work, 256), 256, 0, stream>>>(g, packed, pts, level, rows, gfeat, gpacked, T);
+  }
   TF_LAUNCH_CHECK("tf_vm_scatter_taps");
   return TF_OK;
 }

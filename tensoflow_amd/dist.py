@@ -108,6 +108,149 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, average=True,
     return n_coll
 
 
+class GradientExchange:
+    """The per-step gradient exchange with (a) ONE persistent flat buffer per bucket -- every parameter's `.grad` is a VIEW into it, so
+    backward accumulates straight into the bucket: no `torch.cat` of ~190 MB per step and no copy back (the first thing an 8-rank run
+    of `allreduce_gradients` would have shown) -- and (b) every bucket's collective launched from an autograd hook as soon as its LAST
+    gradient has been written (`register_post_accumulate_grad_hook`), asynchronously, under the rest of the backward pass.
+
+    Buckets are filled in REVERSE parameter order (gradients become ready roughly in reverse order of use).  The mean is taken by
+    scaling the bucket by 1 / world before the sum, so that reduce-scatter and all-gather ("rs_ag", the default on RCCL: each rank
+    reduces 1 / world of the bucket over the 7 direct xGMI links) can both be queued from the hook, back to back.
+
+        ex = GradientExchange(params, world)
+        ex.zero_grad()            # instead of optimizer.zero_grad(set_to_none=True): zeroes the buckets, re-attaches the views
+        loss.backward()           # hooks fire; complete buckets are already on the wire
+        ex.finish(expected)       # buckets whose hooks did not all fire are sent now; waits; parameters outside `expected`
+                                  # that received nothing get grad = None again (the optimizer must not step them)
+    A parameter that receives no gradient on THIS rank but does on another still takes part as zeros, as in allreduce_gradients."""
+
+    def __init__(self, params, world=None, bucket_bytes=64 << 20, mode="auto", stats=None):
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.world = int(world)
+        self.stats = stats
+        self.params = [p for p in params if p.requires_grad]
+        if mode == "auto":
+            mode = "rs_ag" if (self.world > 1 and dist.get_backend() == "nccl") else "allreduce"
+        self.mode = mode
+        self.buckets = []          # dicts: params, flat, views, shard, pending (hooks still to fire), work
+        cur, size = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self._close(cur)
+        self._bucket_of = {}
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for si, p in enumerate(b["params"]):
+                self._bucket_of[id(p)] = (bi, si)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._fired = set()
+        self.launched_in_backward = 0          # collectives queued from hooks during the last backward (tests / bench line)
+        self._in_backward = False
+
+    def _close(self, plist):
+        n = sum(p.numel() for p in plist)
+        pad = (-n) % max(self.world, 1)
+        flat = torch.zeros(n + pad, dtype=plist[0].dtype, device=plist[0].device)
+        views, off = [], 0
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        shard = torch.empty(flat.numel() // max(self.world, 1), dtype=flat.dtype, device=flat.device) if self.mode == "rs_ag" else None
+        self.buckets.append(dict(params=plist, flat=flat, views=views, shard=shard, pending=len(plist), work=[], sent=False, events=None))
+
+    def same_params(self, params):
+        want = [p for p in params if p.requires_grad]
+        return len(want) == len(self.params) and all(a is b for a, b in zip(want, self.params))
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def zero_grad(self):
+        """Zero every bucket and point every parameter's .grad at its slice of the bucket."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"], b["work"], b["sent"], b["events"] = len(b["params"]), [], False, None
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+        self._fired = set()
+        self.launched_in_backward = 0
+        self._in_backward = True
+
+    def _send(self, b):
+        if b["sent"] or self.world == 1:
+            b["sent"] = True
+            return
+        flat = b["flat"]
+        if self.stats is not None and flat.is_cuda:
+            b["events"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            b["events"][0].record()
+        flat.mul_(1.0 / self.world)
+        if self.mode == "rs_ag":
+            b["work"].append(dist.reduce_scatter_tensor(b["shard"], flat, op=dist.ReduceOp.SUM, async_op=True))
+            b["work"].append(dist.all_gather_into_tensor(flat, b["shard"], async_op=True))
+        elif flat.is_cuda and dist.get_backend() == "gloo":       # 1-GPU dry runs of the N-rank path: staged through the host at finish()
+            b["work"] = None
+        else:
+            b["work"].append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        b["sent"] = True
+        if self._in_backward:
+            self.launched_in_backward += 2 if self.mode == "rs_ag" else 1
+        if self.stats is not None:
+            self.stats["bytes"] = self.stats.get("bytes", 0) + flat.numel() * flat.element_size()
+            self.stats["collectives"] = self.stats.get("collectives", 0) + (2 if self.mode == "rs_ag" else 1)
+            self.stats["mode"] = self.mode
+
+    def _on_grad(self, p):
+        slot = self._bucket_of.get(id(p))
+        if slot is None or id(p) in self._fired:
+            return
+        self._fired.add(id(p))
+        b = self.buckets[slot[0]]
+        v = b["views"][slot[1]]
+        if p.grad is not v:
+            # autograd replaced the view (first accumulation into an undefined / non-writable grad): put the numbers where they belong
+            v.copy_(p.grad)
+            p.grad = v
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._send(b)
+
+    def finish(self, expected=None):
+        """After backward: send the buckets that are still waiting for a gradient (their missing slices are zeros), wait for
+        every collective, and give parameters outside `expected` that received nothing their None grad back."""
+        self._in_backward = False
+        for b in self.buckets:
+            if not b["sent"]:
+                self._send(b)
+        for b in self.buckets:
+            if b["work"] is None:                                  # gloo with device tensors: host staging
+                host = b["flat"].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                b["flat"].copy_(host)
+            else:
+                for w in b["work"]:
+                    w.wait()
+            if b["events"] is not None:
+                b["events"][1].record()
+                self.stats.setdefault("events", []).append(b["events"])
+        if expected is not None:
+            keep = {id(p) for p in expected}
+            for p in self.params:
+                if id(p) not in keep and id(p) not in self._fired:
+                    p.grad = None
+        return sum(1 for b in self.buckets if b["sent"])
+
+
 def gather_rows(local_rows, n_total, rank, world):
     """Inference: all-gather per-rank row blocks (image tiles) back into [n_total, k] on every rank."""
     if world == 1:

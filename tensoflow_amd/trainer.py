@@ -123,6 +123,19 @@ class MaterialTrainer:
             ps = [p for p in ps if id(p) not in skip]
         return ps
 
+    def _exchange(self):
+        """world > 1: the hooked gradient exchange over every parameter the optimizer holds (dist.GradientExchange: persistent flat
+        buckets, collectives launched during backward); rebuilt when the optimizer's parameter set changes."""
+        if self.world <= 1:
+            return None
+        ps = self.trainable()
+        ex = getattr(self, "_ex", None)
+        if ex is None or not ex.same_params(ps):
+            if ex is not None:
+                ex.remove()
+            ex = self._ex = tdist.GradientExchange(ps, self.world)
+        return ex
+
     def refresh_flow_copies(self, step):
         """MCShadingNetwork.update_step (fields.py:1056-1065)."""
         return self.net.update_step(step)
@@ -133,7 +146,11 @@ class MaterialTrainer:
         human_poses [pn,3,4]: the capturer's pose per point (shader_cfg.human_lights, configs/mat/custom)."""
         step = self.step_count
         self.net.train()
-        self.optimizer.zero_grad(set_to_none=True)
+        ex = self._exchange()
+        if ex is not None:
+            ex.zero_grad()                                                # gradients accumulate into the persistent exchange buckets
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         self.refresh_flow_copies(step)                                    # MaterialRenderer.train_step calls update_step first (:549)
         colors, outputs = self.net(pts, view_dirs, normals, human_poses, step, True)
         mat_reg = None
@@ -141,9 +158,10 @@ class MaterialTrainer:
             mat_reg = self.net.material_regularization(pts, normals, outputs["metallic"], outputs["roughness"], outputs["albedo"], step)
         terms = material_loss_terms(self.cfg, colors, outputs, target_rgb, mat_reg, step)
         loss = sum(v.mean() for v in terms.values())
-        loss.backward()
-        if self.world > 1:
-            tdist.allreduce_gradients(self.trainable(step), world=self.world, stats=getattr(self, "comm_stats", None))
+        loss.backward()                                                   # every bucket's collective is queued as its last gradient lands
+        if ex is not None:
+            ex.stats = getattr(self, "comm_stats", None)
+            ex.finish(expected=self.trainable(step))
         self.optimizer.step()
         # learning-rate bookkeeping, in the reference's order (:247-252)
         for g in self.optimizer.param_groups:
@@ -318,15 +336,19 @@ class ShapeTrainer:
         """batch: rays_o, rays_d, dirs [rn,3], radiis, rays_cos [rn,1], rgbs [rn,3] (, masks [rn] or [rn,1])."""
         step, net, c = self.step_count, self.net, self.cfg
         net.train()
-        self.optimizer.zero_grad(set_to_none=True)
+        ex = MaterialTrainer._exchange(self)                                           # (same rule: world > 1, rebuilt after a grid upsample)
+        if ex is not None:
+            ex.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         net.color_network.envlight.build_mips()
         near, far = net.near_far_from_sphere(batch["rays_o"], batch["dirs"])
         out = net.render(batch, near, far, batch.get("human_poses"), -1, net.get_anneal_val(step), is_train=True, step=step)
         terms = shape_loss_terms(c, out, batch, step)
         loss = sum(v.mean() for v in terms.values())
         loss.backward()
-        if self.world > 1:
-            tdist.allreduce_gradients(self.trainable(), world=self.world)
+        if ex is not None:
+            ex.finish(expected=self.trainable())
         self.optimizer.step()
         for g in self.optimizer.param_groups:                                           # :247-252
             g["lr"] *= self.lr_factor

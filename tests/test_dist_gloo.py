@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tensoflow_amd.dist import allreduce_gradients, gather_rows, shard_batch, shard_range
+from tensoflow_amd.dist import GradientExchange, allreduce_gradients, gather_rows, shard_batch, shard_range
 
 
 def test_shard_range_partition():
@@ -63,6 +63,75 @@ def test_allreduce_and_gather_two_ranks():
         p.join(timeout=30)
     assert all(ok for _, ok, _ in res), res
     assert all(n >= 2 for _, _, n in res)
+
+
+def _hooked_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        w1 = torch.nn.Parameter(torch.randn(37, 16))
+        w2 = torch.nn.Parameter(torch.randn(16, 5))
+        b = torch.nn.Parameter(torch.randn(5))
+        side = torch.nn.Parameter(torch.randn(16))          # receives a gradient on rank 0 only (a data-dependent branch)
+        later = torch.nn.Parameter(torch.randn(4))          # not trained at this step: outside `expected`, no gradient anywhere
+        params = [w1, w2, b, side, later]
+        ex = GradientExchange(params, world, bucket_bytes=256)      # tiny buckets: several collectives, most of them complete mid-backward
+        ptrs = [bk["flat"].data_ptr() for bk in ex.buckets]
+        x = torch.arange(40 * 37, dtype=torch.float32).reshape(40, 37) / 1000.0
+        lo, hi = shard_range(40, rank, world)
+        ok, launched = True, []
+        for step in range(3):
+            ex.zero_grad()
+            h = torch.tanh(x[lo:hi] @ w1 + (side if rank == 0 else 0.0))
+            loss = (h @ w2 + b).pow(2).mean()
+            loss.backward()
+            launched.append(ex.launched_in_backward)       # collectives already queued when backward returns
+            ex.finish(expected=[w1, w2, b, side])
+            # reference: both shards on one process, mean of the two per-rank losses; `side` only in rank 0's term
+            r = [p.detach().clone().requires_grad_(True) for p in (w1, w2, b, side)]
+            tot = 0
+            for rr in range(world):
+                l2, h2 = shard_range(40, rr, world)
+                hh = torch.tanh(x[l2:h2] @ r[0] + (r[3] if rr == 0 else 0.0))
+                tot = tot + (hh @ r[1] + r[2]).pow(2).mean() / world
+            tot.backward()
+            for p, q_ in zip((w1, w2, b, side), r):
+                ok = ok and p.grad is not None and torch.allclose(p.grad, q_.grad, atol=1e-5)
+            ok = ok and later.grad is None                  # outside `expected`: the optimizer must not step it
+            bk = [bk for bk in ex.buckets if any(p_ is w1 for p_ in bk["params"])][0]            # .grad IS a view into the bucket
+            ok = ok and bk["flat"].data_ptr() <= w1.grad.data_ptr() < bk["flat"].data_ptr() + bk["flat"].numel() * 4
+            with torch.no_grad():
+                for p in (w1, w2, b, side):
+                    p -= 0.1 * p.grad                       # replicas stay identical: same averaged gradient everywhere
+        ok = ok and ptrs == [bk["flat"].data_ptr() for bk in ex.buckets]       # ONE persistent buffer per bucket across steps
+        chk = torch.cat([p.detach().reshape(-1) for p in (w1, w2, b, side)])
+        both = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        ok = ok and torch.equal(both[0], both[1])
+        q.put((rank, bool(ok), launched, len(ex.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_hooked_gradient_exchange_two_ranks():
+    """dist.GradientExchange: gradients accumulate into persistent flat buckets (views), every bucket's collective is queued from
+    an autograd hook when its last gradient lands -- i.e. DURING backward --, a parameter without a gradient on one rank takes
+    part as zeros, a parameter outside `expected` keeps grad = None, and the replicas stay bit-identical over three steps."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_hooked_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(ok for _, ok, _, _ in res), res
+    for _, _, launched, n_buckets in res:
+        assert n_buckets >= 3 and all(n >= 1 for n in launched), res          # overlap: something was on the wire before backward ended
 
 
 @pytest.mark.timeout(300)
