@@ -29,9 +29,9 @@
 
 // workspace layout (floats)
 static constexpr int kW1f = 0;                                   // [8][56][64]
-static constexpr int kB1a = kW1f + 8 * SDF_KSTEPS * 64;          // [8][16][2]
-static constexpr int kW2r0 = kB1a + 256;                         // sdf row of W2, accumulator order [8][16][2]
-static constexpr int kB2a = kW2r0 + 256;                         // b2[1:], accumulator order [4][16][2]
+static constexpr int kB1a = kW1f + 8 * SDF_KSTEPS * 64;          // accumulator order, lane half major: [2][8][16] (a lane's 128 values are contiguous: ds_read_b128)
+static constexpr int kW2r0 = kB1a + 256;                         // sdf row of W2, [2][8][16]
+static constexpr int kB2a = kW2r0 + 256;                         // b2[1:], [2][4][16]
 static constexpr int kLdsFloats = kB2a + 128;                    // everything above is copied to LDS
 static constexpr int kStream = kLdsFloats;                       // 2 x 4096 floats: W2 streaming double buffer
 static constexpr int kGeo = kStream + 2 * 4096;                  // 12 x 8 ints: per (plane, level) geometry
@@ -40,6 +40,17 @@ static constexpr int kW2f = kLdsFloats;                          // [4][128][64]
 static constexpr int kSdfWsFloats = kW2f + 4 * 128 * 64;
 
 extern "C" size_t tf_sdf_workspace_floats(void) { return kSdfWsFloats; }
+
+// A vector [n] in accumulator order, LANE-HALF MAJOR: dst[h * (tout_tiles * 16) + tout * 16 + reg] = b[32 tout + rho(reg, h)] -- the
+// 16 * tout_tiles values of a lane are contiguous (the [..][2] interleave of tf_pack_bias_kernel made every one of them its own
+// ds_read_b32: 256 of them per field evaluation for the bias and the sdf row of W2).
+static __global__ void __launch_bounds__(256) sdf_pack_acc_kernel(const float* __restrict__ b, int n, int tout_tiles, float* __restrict__ dst) {
+  const int e = threadIdx.x;
+  if (e >= tout_tiles * 32) return;
+  const int h = e / (tout_tiles * 16), r = e % (tout_tiles * 16), tout = r >> 4, reg = r & 15;
+  const int row = 32 * tout + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+  dst[e] = row < n ? b[row] : 0.f;
+}
 
 struct SdfArgs {
   VmGeom g;
@@ -137,7 +148,10 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[t][j] = lds[kB1a + (t * 16 + j) * 2 + h];
+    for (int jj = 0; jj < 4; ++jj) {      // explicit 16-byte reads (the opaque base above hides the array's alignment from the compiler)
+      const float4 b4 = *reinterpret_cast<const float4*>(lds + kB1a + h * 128 + t * 16 + 4 * jj);
+      acc[t][4 * jj] = b4.x; acc[t][4 * jj + 1] = b4.y; acc[t][4 * jj + 2] = b4.z; acc[t][4 * jj + 3] = b4.w;
+    }
   ChunkRaw raw[2][NL];
   auto issue = [&](int g) {
 #pragma unroll
@@ -202,9 +216,14 @@ __device__ __forceinline__ float sdf_hidden_nl(const SdfArgs& A, const float* ld
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      acc[t][j] = softplus100(acc[t][j]);
-      part += acc[t][j] * lds[kW2r0 + (t * 16 + j) * 2 + h];
+    for (int jj = 0; jj < 4; ++jj) {
+      const float4 w4 = *reinterpret_cast<const float4*>(lds + kW2r0 + h * 128 + t * 16 + 4 * jj);
+      const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[t][4 * jj + k] = softplus100(acc[t][4 * jj + k]);
+        part += acc[t][4 * jj + k] * wv[k];
+      }
     }
   part += __shfl_xor(part, 32);
   return part + A.b2[0];
@@ -254,7 +273,10 @@ __global__ void __launch_bounds__(256) sdf_kernel(SdfArgs A) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) o[t][j] = lds[kB2a + (t * 16 + j) * 2 + h];
+        for (int jj = 0; jj < 4; ++jj) {
+          const float4 b4 = *reinterpret_cast<const float4*>(lds + kB2a + h * 64 + t * 16 + 4 * jj);
+          o[t][4 * jj] = b4.x; o[t][4 * jj + 1] = b4.y; o[t][4 * jj + 2] = b4.z; o[t][4 * jj + 3] = b4.w;
+        }
       if (H3) tf_layer_stream_h3<16, 4, 8, 2, 2>(reinterpret_cast<const _Float16*>(A.ws + kW2f), lds + kStream, threadIdx.x, lane, acc, o);
       else tf_layer_stream<128, 4, 8, 16>(A.ws + kW2f, lds + kStream, threadIdx.x, lane, acc, o);
       if (valid) {
@@ -329,9 +351,9 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   else
     tf_pack_wfrag_kernel<<<tf_blocks(8 * SDF_KSTEPS * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS,
                                                                                   workspace + kW1f);
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b1, SDF_HID, 8, workspace + kB1a);
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
-  tf_pack_bias_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
+  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->b1, SDF_HID, 8, workspace + kB1a);
+  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
+  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
   if (precision == TF_PREC_F16X3)
     tf_pack_wfrag_h3_kernel<<<tf_blocks(4 * 16 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4, 16,
                                                                              reinterpret_cast<_Float16*>(workspace + kW2f));
@@ -527,7 +549,7 @@ __global__ void __launch_bounds__(256) sdf_bwd_kernel(SdfArgs A, SdfBwdArgs B) {
       float* hrow = B.hh + rt * SDF_HID + 4 * h;
       float* zrow = B.dz + rt * SDF_HID + 4 * h;
       const float* arow = APP ? B.dh_app + row * SDF_HID + 4 * h : nullptr;
-      const float* w2r = lds + kW2r0 + h;
+      const float* w2r = lds + kW2r0 + h * 128;
       {
         int opaque = 0;
         asm volatile("" : "+v"(opaque));
@@ -541,10 +563,12 @@ __global__ void __launch_bounds__(256) sdf_bwd_kernel(SdfArgs A, SdfBwdArgs B) {
           if (APP) a4 = *reinterpret_cast<const float4*>(arow + 32 * tt + 8 * jj);
           const float ap[4] = {a4.x, a4.y, a4.z, a4.w};
           float hv[4], zv[4];
+          const float4 w4 = *reinterpret_cast<const float4*>(w2r + tt * 16 + 4 * jj);
+          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float hval = acc[tt][4 * jj + k];
-            const float dh = dst * w2r[(tt * 16 + 4 * jj + k) * 2] + ap[k];
+            const float dh = dst * wv[k] + ap[k];
             // Softplus'(z) = sigmoid(100 z) = 1 - exp(-100 h); the linear branch (100 z > 20, i.e. h = z > 0.2) has derivative 1
             const float sg = hval > 0.2f ? 1.f : 1.f - __builtin_amdgcn_exp2f(-144.269504088896341f * hval);
             hv[k] = hval; zv[k] = dh * sg;

@@ -141,18 +141,22 @@ __device__ __forceinline__ void mip_select(float level, int n_levels, int& l0, i
 }
 
 __device__ __forceinline__ float softplus100(float x) {
-  // torch.nn.Softplus(beta=100, threshold=20): log1p(exp(100 x)) / 100.
-  // Raw hardware exp2 / log2 / rcp (v_exp_f32, v_log_f32, v_rcp_f32: ~1 ulp each, no denormal fix-up sequences) + the
-  // classic log1p correction  log1p(t) = log(u) * t / (u - 1), u = fl(1 + t), which cancels the rounding of 1 + t.
-  // 13 instructions per activation instead of the ~35 of __expf / __logf / IEEE division (the decoder applies it to 128
-  // activations per lane per field evaluation: it was 60 % of the march kernel's vector instructions); relative error
-  // 2e-6 at most for 100 x in [-20, 20] (argument rounding of the exponent), far inside the 1e-4 parity bound.
-  const float bx = 100.f * x;
-  const float t = __builtin_amdgcn_exp2f(bx * 1.44269504088896341f);
-  const float u = 1.f + t;
-  const float d = u - 1.f;
-  const float l = (d == 0.f) ? t : (__builtin_amdgcn_logf(u) * 0.69314718055994531f) * (t * __builtin_amdgcn_rcpf(d));
-  return bx > 20.f ? x : l * 0.01f;
+  // torch.nn.Softplus(beta=100, threshold=20): log1p(exp(100 x)) / 100, and x itself where 100 x > 20.
+  // Round 4: SEVEN instructions with TWO transcendentals -- v_mul, v_min, v_exp (2^a), v_add, v_log (log2), v_mul, v_med3:
+  //     h = max(x, log2(1 + 2^min(100 x log2 e, 126)) ln 2 / 100).
+  // The decoder applies it to 128 activations per lane per field evaluation, and a transcendental issues at a quarter of the vector
+  // rate: rounds 1-3 spent 13 instructions with three of them (exp, log, rcp) on the classic log1p correction
+  // log1p(t) = log(u) t / (u - 1), which keeps the RELATIVE error of tiny outputs -- of no use here: what the next layer needs is
+  // the ABSOLUTE error of h, and rounding 1 + t costs 6e-8 in the logarithm's argument, i.e. <= 6e-10 in h (1 + t = 1 below
+  // t = 6e-8 returns 0 for a true value under 6e-10).  max(x, .): softplus(x) >= x, the clamped exponent makes the formula fall
+  // BELOW x once 100 x > 87 (no overflow to inf), and above the threshold x + log1p(e^-20) / 100 = x + 2e-11 rounds to x: the
+  // branch of the reference comes out of the maximum.  One v_med3 with an opaque upper bound instead of v_max: an MFMA result is
+  // not a known-canonical float to the compiler, which would canonicalise it first (see tf_relu).
+  const float a = fminf(x * 144.269504088896341f, 126.f);
+  const float l = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(a)) * 0.0069314718055994531f;
+  float big = 3.0e38f;
+  asm("" : "+s"(big));
+  return __builtin_amdgcn_fmed3f(x, l, big);
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 #endif
