@@ -560,35 +560,39 @@ __global__ void __launch_bounds__(256) flow_point_part_kernel(const float* __res
 }
 
 static int pack_nets_h3(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
+  TfPackBatch PB(stream);           // both coupling nets in ONE launch (was 14)
   for (int b = 0; b < 2; ++b) {
     float* base = netfrag + (size_t)b * hNetFloats;
     for (int l = 0; l < 4; ++l)
       TF_REQUIRE(nets[b].w[l] && nets[b].b[l], TF_EINVAL, "tf_flow: null weight pointer (block %d layer %d)", b, l);
     _Float16* hb = reinterpret_cast<_Float16*>(base);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 1 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 1, hb + 2 * (size_t)hL1);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL2);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL3);
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 4, hb + 2 * (size_t)hL4);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + hB2);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + hB3);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + hB4);
+    PB.wfrag_h3(nets[b].w[0], 64, 44, 0, 7, 2, 1, hb + 2 * (size_t)hL1);
+    PB.wfrag_h3(nets[b].w[1], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL2);
+    PB.wfrag_h3(nets[b].w[2], 64, 64, 0, 64, 2, 4, hb + 2 * (size_t)hL3);
+    PB.wfrag_h3(nets[b].w[3], 21, 64, 0, 64, 1, 4, hb + 2 * (size_t)hL4);
+    PB.bias(nets[b].b[1], 64, 2, base + hB2);
+    PB.bias(nets[b].b[2], 64, 2, base + hB3);
+    PB.bias(nets[b].b[3], 21, 1, base + hB4);
   }
+  PB.flush();
   return TF_OK;
 }
 
 static int pack_nets(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
+  TfPackBatch PB(stream);
   for (int b = 0; b < 2; ++b) {
     float* base = netfrag + (size_t)b * kNetFloats;
     for (int l = 0; l < 4; ++l)
       TF_REQUIRE(nets[b].w[l] && nets[b].b[l], TF_EINVAL, "tf_flow: null weight pointer (block %d layer %d)", b, l);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
-    tf_pack_wfrag_kernel<<<tf_blocks(32 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + kB2);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + kB3);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + kB4);
+    PB.wfrag(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
+    PB.wfrag(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
+    PB.wfrag(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
+    PB.wfrag(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
+    PB.bias(nets[b].b[1], 64, 2, base + kB2);
+    PB.bias(nets[b].b[2], 64, 2, base + kB3);
+    PB.bias(nets[b].b[3], 21, 1, base + kB4);
   }
+  PB.flush();
   return TF_OK;
 }
 

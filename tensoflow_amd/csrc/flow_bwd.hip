@@ -543,22 +543,24 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
       G.b[b][l] = gnets[b].b[l];
     }
   G.gP = g_point;
+  TfPackBatch PB(stream);           // fragments and transposed fragments of both coupling nets: ONE launch (was 22)
   for (int b = 0; b < 2; ++b) {
     float* base = workspace + (size_t)b * kNetFloats;
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 4 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
-    tf_pack_wfrag_kernel<<<tf_blocks(32 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[1], 64, 2, base + kB2);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[2], 64, 2, base + kB3);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets[b].b[3], 21, 1, base + kB4);
+    PB.wfrag(nets[b].w[0], 64, 44, 0, 7, 2, 4, base + kL1);
+    PB.wfrag(nets[b].w[1], 64, 64, 0, 64, 2, 32, base + kL2);
+    PB.wfrag(nets[b].w[2], 64, 64, 0, 64, 2, 32, base + kL3);
+    PB.wfrag(nets[b].w[3], 21, 64, 0, 64, 1, 32, base + kL4);
+    PB.bias(nets[b].b[1], 64, 2, base + kB2);
+    PB.bias(nets[b].b[2], 64, 2, base + kB3);
+    PB.bias(nets[b].b[3], 21, 1, base + kB4);
     float* tb = workspace + 2 * kNetFloats + (size_t)b * kTNet;
     // transposed fragments: logical matrix = W^T  (rows = layer inputs, cols = layer outputs)
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 16 * 64, 256), 256, 0, stream>>>(nets[b].w[3], 64, 64, 0, 21, 2, 16, tb + kT4, 0, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[2], 64, 64, 0, 64, 2, 32, tb + kT3, 0, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[1], 64, 64, 0, 64, 2, 32, tb + kT2, 0, 1);
-    tf_pack_wfrag_kernel<<<tf_blocks(1 * 32 * 64, 256), 256, 0, stream>>>(nets[b].w[0], 7, 44, 0, 64, 1, 32, tb + kT1, 0, 1);
+    PB.wfrag(nets[b].w[3], 64, 64, 0, 21, 2, 16, tb + kT4, 0, 1);
+    PB.wfrag(nets[b].w[2], 64, 64, 0, 64, 2, 32, tb + kT3, 0, 1);
+    PB.wfrag(nets[b].w[1], 64, 64, 0, 64, 2, 32, tb + kT2, 0, 1);
+    PB.wfrag(nets[b].w[0], 7, 44, 0, 64, 1, 32, tb + kT1, 0, 1);
   }
+  PB.flush();
   float* P = workspace + kBwdWs;
   flow_point_part_kernel2<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0], nets[1].b[0],
                                                                           cond, pn, P);

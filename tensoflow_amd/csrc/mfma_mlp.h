@@ -351,6 +351,88 @@ static __global__ void __launch_bounds__(256) tf_pack_wfrag_h3_kernel(const floa
   }
 }
 
+// ---- batched packing.  A training step re-packs every network it touches (the weights have just been updated): the flow nets alone
+// were 7 launches per coupling net in the forward and 11 in the backward entry point -- 107 tiny launches per material training step.
+// TfPackBatch collects the jobs of an entry point and runs them as ONE launch (blockIdx.y = job, blockIdx.x over its elements).
+struct TfPackJob {
+  const float* src;
+  void* dst;
+  int kind;                       // 0: tf_pack_wfrag_kernel, 1: tf_pack_wfrag_h3_kernel, 2: tf_pack_bias_kernel, 3: accumulator order, lane-half major
+  int nout, ld, col0, kin, tout_tiles, ksteps, s_major, transpose;
+};
+#define TF_PACK_MAX_JOBS 24
+struct TfPackJobs { TfPackJob j[TF_PACK_MAX_JOBS]; int n; };
+
+static __global__ void __launch_bounds__(256) tf_pack_batch_kernel(TfPackJobs J) {
+  const TfPackJob& q = J.j[blockIdx.y];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (q.kind == 2) {
+    if (e >= q.tout_tiles * 32) return;
+    const int h = e & 1, reg = (e >> 1) & 15, tout = e >> 5;
+    const int row = 32 * tout + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    reinterpret_cast<float*>(q.dst)[e] = row < q.nout ? q.src[row] : 0.f;
+    return;
+  }
+  if (q.kind == 3) {              // dst[h * (tout_tiles * 16) + tout * 16 + reg] = src[32 tout + rho(reg, h)]  (sdf.hip: ds_read_b128 per lane)
+    if (e >= q.tout_tiles * 32) return;
+    const int h = e / (q.tout_tiles * 16), r = e % (q.tout_tiles * 16), tout = r >> 4, reg = r & 15;
+    const int row = 32 * tout + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    reinterpret_cast<float*>(q.dst)[e] = row < q.nout ? q.src[row] : 0.f;
+    return;
+  }
+  const int total = q.tout_tiles * q.ksteps * 64;
+  if (e >= total) return;
+  const int lane = e & 63;
+  if (q.kind == 0) {
+    int s, tout;
+    if (q.s_major) { tout = (e >> 6) % q.tout_tiles; s = (e >> 6) / q.tout_tiles; }
+    else { s = (e >> 6) % q.ksteps; tout = (e >> 6) / q.ksteps; }
+    const int row = 32 * tout + (lane & 31), k = tf_kmap(s, lane >> 5);
+    float v = 0.f;
+    if (row < q.nout && k < q.kin) v = q.transpose ? q.src[(long long)k * q.ld + q.col0 + row] : q.src[(long long)row * q.ld + q.col0 + k];
+    reinterpret_cast<float*>(q.dst)[e] = v;
+  } else {
+    const int tout = (e >> 6) % q.tout_tiles, s16 = (e >> 6) / q.tout_tiles;
+    const int row = 32 * tout + (lane & 31);
+    _Float16* base = reinterpret_cast<_Float16*>(q.dst) + ((long long)(s16 * q.tout_tiles + tout) * 2) * 64 * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int k = tf_kmap16(s16, lane >> 5, c);
+      const float w = (row < q.nout && k < q.kin) ? q.src[(long long)row * q.ld + q.col0 + k] : 0.f;
+      const _Float16 hi = (_Float16)w;
+      base[lane * 8 + c] = hi;
+      base[64 * 8 + lane * 8 + c] = (_Float16)(w - (float)hi);
+    }
+  }
+}
+
+struct TfPackBatch {
+  TfPackJobs J;
+  int max_elems;
+  hipStream_t stream;
+  explicit TfPackBatch(hipStream_t s) : max_elems(0), stream(s) { J.n = 0; }
+  void add(const TfPackJob& q, int elems) {
+    if (J.n == TF_PACK_MAX_JOBS) flush();
+    J.j[J.n++] = q;
+    max_elems = elems > max_elems ? elems : max_elems;
+  }
+  // the argument lists of the single-job kernels above
+  void wfrag(const float* W, int nout, int ld, int col0, int kin, int tout_tiles, int ksteps, float* dst, int s_major = 0, int transpose = 0) {
+    add(TfPackJob{W, dst, 0, nout, ld, col0, kin, tout_tiles, ksteps, s_major, transpose}, tout_tiles * ksteps * 64);
+  }
+  void wfrag_h3(const float* W, int nout, int ld, int col0, int kin, int tout_tiles, int ksteps16, _Float16* dst) {
+    add(TfPackJob{W, dst, 1, nout, ld, col0, kin, tout_tiles, ksteps16, 0, 0}, tout_tiles * ksteps16 * 64);
+  }
+  void bias(const float* b, int n, int tout_tiles, float* dst) { add(TfPackJob{b, dst, 2, n, 0, 0, 0, tout_tiles, 0, 0, 0}, tout_tiles * 32); }
+  void acc_major(const float* b, int n, int tout_tiles, float* dst) { add(TfPackJob{b, dst, 3, n, 0, 0, 0, tout_tiles, 0, 0, 0}, tout_tiles * 32); }
+  void flush() {
+    if (J.n == 0) return;
+    tf_pack_batch_kernel<<<dim3((unsigned)((max_elems + 255) / 256), (unsigned)J.n), 256, 0, stream>>>(J);
+    J.n = 0;
+    max_elems = 0;
+  }
+};
+
 // Dense layer, f16x3, weights streamed through LDS in 16 KB slabs of SL16 k-steps (SL16*TOUT*2 KB == 16 KB).
 template <int K16, int TOUT, int TIN, int SL16, int NBUF = 3>
 __device__ __forceinline__ void tf_layer_stream_h3(const _Float16* __restrict__ wslab, float* __restrict__ lds, int tid, int lane,

@@ -202,24 +202,26 @@ extern "C" int tf_point_pack(const TfPointNets* nets, float* workspace, size_t w
   TF_REQUIRE(workspace_floats >= (size_t)kPointWsFloats, TF_ESHAPE, "tf_point_pack: workspace too small (%zu < %d floats)",
              workspace_floats, kPointWsFloats);
   static const int mat_out[3] = {1, 1, 3};
+  TfPackBatch PB(stream);           // the 20 packs of the five per-point nets: ONE launch
   for (int n = 0; n < 3; ++n) {
     TF_REQUIRE(nets->mat_w1[n] && nets->mat_b1[n] && nets->mat_w2[n] && nets->mat_b2[n], TF_EINVAL,
                "tf_point_pack: null material weight pointer (net %d)", n);
     float* ws = workspace + n * kPmSize;
-    tf_pack_wfrag_kernel<<<tf_blocks(4 * PT_MAT_KS * 64, 256), 256, 0, stream>>>(nets->mat_w1[n], 128, 108, 0, 108, 4, PT_MAT_KS, ws + kPmW1);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets->mat_b1[n], 128, 4, ws + kPmB1);
-    tf_pack_wfrag_kernel<<<tf_blocks(64 * 64, 256), 256, 0, stream>>>(nets->mat_w2[n], mat_out[n], 128, 0, 128, 1, 64, ws + kPmW2);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets->mat_b2[n], mat_out[n], 1, ws + kPmB2);
+    PB.wfrag(nets->mat_w1[n], 128, 108, 0, 108, 4, PT_MAT_KS, ws + kPmW1);
+    PB.bias(nets->mat_b1[n], 128, 4, ws + kPmB1);
+    PB.wfrag(nets->mat_w2[n], mat_out[n], 128, 0, 128, 1, 64, ws + kPmW2);
+    PB.bias(nets->mat_b2[n], mat_out[n], 1, ws + kPmB2);
   }
   for (int f = 0; f < 2; ++f) {
     TF_REQUIRE(nets->nis_w1[f] && nets->nis_b1[f] && nets->nis_w2[f] && nets->nis_b2[f], TF_EINVAL,
                "tf_point_pack: null flow feature-net weight pointer (flow %d)", f);
     float* ws = workspace + 3 * kPmSize + f * kPnSize;
-    tf_pack_wfrag_kernel<<<tf_blocks(2 * PT_NIS_KS * 64, 256), 256, 0, stream>>>(nets->nis_w1[f], 64, 57, 0, 57, 2, PT_NIS_KS, ws + kPnW1);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets->nis_b1[f], 64, 2, ws + kPnB1);
-    tf_pack_wfrag_kernel<<<tf_blocks(32 * 64, 256), 256, 0, stream>>>(nets->nis_w2[f], 16, 64, 0, 64, 1, 32, ws + kPnW2);
-    tf_pack_bias_kernel<<<1, 256, 0, stream>>>(nets->nis_b2[f], 16, 1, ws + kPnB2);
+    PB.wfrag(nets->nis_w1[f], 64, 57, 0, 57, 2, PT_NIS_KS, ws + kPnW1);
+    PB.bias(nets->nis_b1[f], 64, 2, ws + kPnB1);
+    PB.wfrag(nets->nis_w2[f], 16, 64, 0, 64, 1, 32, ws + kPnW2);
+    PB.bias(nets->nis_b2[f], 16, 1, ws + kPnB2);
   }
+  PB.flush();
   TF_LAUNCH_CHECK("tf_point_pack");
   return TF_OK;
 }

@@ -41,16 +41,8 @@ static constexpr int kSdfWsFloats = kW2f + 4 * 128 * 64;
 
 extern "C" size_t tf_sdf_workspace_floats(void) { return kSdfWsFloats; }
 
-// A vector [n] in accumulator order, LANE-HALF MAJOR: dst[h * (tout_tiles * 16) + tout * 16 + reg] = b[32 tout + rho(reg, h)] -- the
-// 16 * tout_tiles values of a lane are contiguous (the [..][2] interleave of tf_pack_bias_kernel made every one of them its own
-// ds_read_b32: 256 of them per field evaluation for the bias and the sdf row of W2).
-static __global__ void __launch_bounds__(256) sdf_pack_acc_kernel(const float* __restrict__ b, int n, int tout_tiles, float* __restrict__ dst) {
-  const int e = threadIdx.x;
-  if (e >= tout_tiles * 32) return;
-  const int h = e / (tout_tiles * 16), r = e % (tout_tiles * 16), tout = r >> 4, reg = r & 15;
-  const int row = 32 * tout + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-  dst[e] = row < n ? b[row] : 0.f;
-}
+// (the bias b1, the sdf row of W2 and b2[1:] are stored in accumulator order, LANE-HALF MAJOR -- TfPackBatch::acc_major: the 16 * tiles
+// values of a lane are contiguous, one ds_read_b128 per four; the [..][2] interleave of tf_pack_bias_kernel made each its own ds_read_b32)
 
 struct SdfArgs {
   VmGeom g;
@@ -358,21 +350,15 @@ static int sdf_prepare(const TfVmDesc* d, const TfSdfMlp* mlp, const float* aabb
   TF_REQUIRE(mlp->w1 && mlp->b1 && mlp->w2 && mlp->b2, TF_EINVAL, "%s: null weight pointer", who);
   const int K = 3 * SDF_C + 3;
   // the f16x3 images have the same size as the fp32 fragment images they replace (hi + lo halves = 4 bytes per weight)
-  if (precision == TF_PREC_F16X3)
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 7 * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, 7,
-                                                                            reinterpret_cast<_Float16*>(workspace + kW1f));
-  else
-    tf_pack_wfrag_kernel<<<tf_blocks(8 * SDF_KSTEPS * 64, 256), 256, 0, stream>>>(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS,
-                                                                                  workspace + kW1f);
-  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->b1, SDF_HID, 8, workspace + kB1a);
-  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
-  sdf_pack_acc_kernel<<<1, 256, 0, stream>>>(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
-  if (precision == TF_PREC_F16X3)
-    tf_pack_wfrag_h3_kernel<<<tf_blocks(4 * 16 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4, 16,
-                                                                             reinterpret_cast<_Float16*>(workspace + kW2f));
-  else
-    tf_pack_wfrag_kernel<<<tf_blocks(4 * 128 * 64, 256), 256, 0, stream>>>(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4,
-                                                                           128, workspace + kW2f, 1);
+  TfPackBatch PB(stream);           // the five packs of the decoder: ONE launch
+  if (precision == TF_PREC_F16X3) PB.wfrag_h3(mlp->w1, SDF_HID, K, 0, K, 8, 7, reinterpret_cast<_Float16*>(workspace + kW1f));
+  else PB.wfrag(mlp->w1, SDF_HID, K, 0, K, 8, SDF_KSTEPS, workspace + kW1f);
+  PB.acc_major(mlp->b1, SDF_HID, 8, workspace + kB1a);
+  PB.acc_major(mlp->w2, SDF_HID, 8, workspace + kW2r0);           // row 0 of W2
+  PB.acc_major(mlp->b2 + 1, SDF_APP, 4, workspace + kB2a);
+  if (precision == TF_PREC_F16X3) PB.wfrag_h3(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4, 16, reinterpret_cast<_Float16*>(workspace + kW2f));
+  else PB.wfrag(mlp->w2 + SDF_HID, SDF_APP, SDF_HID, 0, SDF_HID, 4, 128, workspace + kW2f, 1);
+  PB.flush();
   A->ws = workspace;
   return TF_OK;
 }

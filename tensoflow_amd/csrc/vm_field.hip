@@ -5,6 +5,8 @@
 // Data layout: channel-last packed pyramid (one texel = C*4 contiguous bytes), built once per
 // optimizer step.  Gather: one lane per (point, 16-byte channel chunk): the 3*C/4 lanes of a point
 // read each touched texel as one contiguous C*4-byte segment.
+#include <algorithm>
+
 #include "tf_common.h"
 #include "tf_internal.h"
 
@@ -82,6 +84,84 @@ __global__ void __launch_bounds__(256) vm_unpack_kernel(const float* __restrict_
   __syncthreads();
   if (p0 + t < npix)
     for (int c = 0; c < C; ++c) dst[(long long)c * npix + p0 + t] = tile[t * stride + c];
+}
+
+// ---- the same three kernels over ALL six arrays of a field (3 planes + 3 lines) in one launch: blockIdx.y = array.  A pyramid was 18
+// launches to pack (6 x (level 0 + 2 mips)) and 6 to unpack; a training step packs 3-4 pyramids and unpacks as many.
+struct VmArr { const float* src; float* dst; long long npix; int hs, ws, hd, wd, H, W; long long off[4]; };
+struct VmArrs { VmArr a[6]; };
+
+__global__ void __launch_bounds__(256) vm_pack_level0_multi_kernel(VmArrs A, int C) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [256][C+1]
+  const VmArr& q = A.a[blockIdx.y];
+  const long long p0 = (long long)blockIdx.x * 256;
+  if (p0 >= q.npix) return;                                   // workgroup-uniform
+  const int t = threadIdx.x;
+  const int stride = C + 1;
+  if (p0 + t < q.npix)
+    for (int c = 0; c < C; ++c) tile[t * stride + c] = q.src[(long long)c * q.npix + p0 + t];
+  __syncthreads();
+  const long long nvalid = min((long long)256, q.npix - p0);
+  for (long long e = t; e < nvalid * C; e += 256) {
+    int pix = (int)(e / C), c = (int)(e % C);
+    q.dst[p0 * C + e] = tile[pix * stride + c];
+  }
+}
+
+__global__ void __launch_bounds__(256) vm_pack_down_multi_kernel(VmArrs A, int C) {
+  const VmArr& q = A.a[blockIdx.y];
+  const float* __restrict__ src = q.src;
+  const int hs = q.hs, ws = q.ws, hd = q.hd, wd = q.wd;
+  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)hd * wd * C;
+  if (e >= total) return;
+  int c = (int)(e % C);
+  long long pix = e / C;
+  int x = (int)(pix % wd), y = (int)(pix / wd);
+  int sy = hs > 1 ? 2 : 1, sx = ws > 1 ? 2 : 1;
+  float acc = 0.f;
+  // same association as the oracle (and as vm_pack_down_kernel): average over H first, then over W
+  if (sy == 2 && sx == 2) {
+    float a = 0.5f * (src[((long long)(2 * y) * ws + 2 * x) * C + c] + src[((long long)(2 * y + 1) * ws + 2 * x) * C + c]);
+    float b = 0.5f * (src[((long long)(2 * y) * ws + 2 * x + 1) * C + c] + src[((long long)(2 * y + 1) * ws + 2 * x + 1) * C + c]);
+    acc = 0.5f * (a + b);
+  } else if (sy == 2) {
+    acc = 0.5f * (src[((long long)(2 * y) * ws + x) * C + c] + src[((long long)(2 * y + 1) * ws + x) * C + c]);
+  } else if (sx == 2) {
+    acc = 0.5f * (src[((long long)y * ws + 2 * x) * C + c] + src[((long long)y * ws + 2 * x + 1) * C + c]);
+  } else {
+    acc = src[((long long)y * ws + x) * C + c];
+  }
+  q.dst[e] = acc;
+}
+
+__global__ void __launch_bounds__(256) vm_unpack_multi_kernel(VmArrs A, const float* __restrict__ gp, int C, int n_levels) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [256][C+1]
+  const VmArr& q = A.a[blockIdx.y];
+  const int H = q.H, W = q.W;
+  const long long npix = (long long)H * W;
+  const long long p0 = (long long)blockIdx.x * 256;
+  if (p0 >= npix) return;                                     // workgroup-uniform
+  const int t = threadIdx.x;
+  const int stride = C + 1;
+  const long long nvalid = min((long long)256, npix - p0);
+  for (long long e = t; e < nvalid * C; e += 256) {
+    int pix = (int)(e / C), c = (int)(e % C);
+    long long p = p0 + pix;
+    int y = (int)(p / W), x = (int)(p % W);
+    float acc = 0.f, scale = 1.f;
+    int h = H, w = W;
+    for (int l = 0; l < n_levels; ++l) {
+      int yl = H > 1 ? (y >> l) : 0, xl = W > 1 ? (x >> l) : 0;
+      acc += scale * gp[q.off[l] + ((long long)yl * w + xl) * C + c];
+      if (h > 1) { h >>= 1; scale *= 0.5f; }
+      if (w > 1) { w >>= 1; scale *= 0.5f; }
+    }
+    tile[pix * stride + c] = acc;
+  }
+  __syncthreads();
+  if (p0 + t < npix)
+    for (int c = 0; c < C; ++c) q.dst[(long long)c * npix + p0 + t] = tile[t * stride + c];
 }
 
 // ------------------------------------------------------------------------------------ gather
@@ -393,21 +473,30 @@ extern "C" int tf_vm_pack_fwd(const TfVmDesc* d, const float* const planes[3], c
   if (int rc = check_geom(d, nullptr, &g, "tf_vm_pack_fwd")) return rc;
   TF_REQUIRE(planes && lines && packed, TF_EINVAL, "tf_vm_pack_fwd: null pointer");
   const size_t lds = 256 * (g.C + 1) * sizeof(float);
+  // level 0 of all six arrays in one launch, then one launch per mip level (level l reads level l - 1): n_levels launches instead of
+  // 6 n_levels
+  VmArrs A = {};
+  long long max_pix = 0;
   for (int i = 0; i < 3; ++i) {
     TF_REQUIRE(planes[i] && lines[i], TF_EINVAL, "tf_vm_pack_fwd: null plane/line %d", i);
-    long long npix = (long long)g.ph[i] * g.pw[i];
-    vm_pack_level0_kernel<<<tf_blocks(npix, 256), 256, lds, stream>>>(planes[i], packed + g.poff[i][0], g.C, npix);
-    vm_pack_level0_kernel<<<tf_blocks(g.ll[i], 256), 256, lds, stream>>>(lines[i], packed + g.loff[i][0], g.C, g.ll[i]);
-    for (int l = 1; l < g.n_levels; ++l) {
+    A.a[2 * i] = VmArr{planes[i], packed + g.poff[i][0], (long long)g.ph[i] * g.pw[i]};
+    A.a[2 * i + 1] = VmArr{lines[i], packed + g.loff[i][0], (long long)g.ll[i]};
+    max_pix = std::max(max_pix, std::max(A.a[2 * i].npix, A.a[2 * i + 1].npix));
+  }
+  vm_pack_level0_multi_kernel<<<dim3(tf_blocks(max_pix, 256), 6), 256, lds, stream>>>(A, g.C);
+  for (int l = 1; l < g.n_levels; ++l) {
+    VmArrs D = {};
+    long long max_el = 0;
+    for (int i = 0; i < 3; ++i) {
       int hs = g.ph[i] >> (l - 1), ws = g.pw[i] >> (l - 1), hd = g.ph[i] >> l, wd = g.pw[i] >> l;
       hs = hs < 1 ? 1 : hs; ws = ws < 1 ? 1 : ws; hd = hd < 1 ? 1 : hd; wd = wd < 1 ? 1 : wd;
-      vm_pack_down_kernel<<<tf_blocks((long long)hd * wd * g.C, 256), 256, 0, stream>>>(
-          packed + g.poff[i][l - 1], packed + g.poff[i][l], g.C, hs, ws, hd, wd);
+      D.a[2 * i] = VmArr{packed + g.poff[i][l - 1], packed + g.poff[i][l], 0, hs, ws, hd, wd};
       int ls = g.ll[i] >> (l - 1), ld = g.ll[i] >> l;
       ls = ls < 1 ? 1 : ls; ld = ld < 1 ? 1 : ld;
-      vm_pack_down_kernel<<<tf_blocks((long long)ld * g.C, 256), 256, 0, stream>>>(
-          packed + g.loff[i][l - 1], packed + g.loff[i][l], g.C, ls, 1, ld, 1);
+      D.a[2 * i + 1] = VmArr{packed + g.loff[i][l - 1], packed + g.loff[i][l], 0, ls, 1, ld, 1};
+      max_el = std::max(max_el, std::max((long long)hd * wd * g.C, (long long)ld * g.C));
     }
+    vm_pack_down_multi_kernel<<<dim3(tf_blocks(max_el, 256), 6), 256, 0, stream>>>(D, g.C);
   }
   TF_LAUNCH_CHECK("tf_vm_pack_fwd");
   return TF_OK;
@@ -430,14 +519,15 @@ extern "C" int tf_vm_pack_bwd(const TfVmDesc* d, const float* gpacked, float* co
   if (int rc = check_geom(d, nullptr, &g, "tf_vm_pack_bwd")) return rc;
   TF_REQUIRE(gpacked && gplanes && glines, TF_EINVAL, "tf_vm_pack_bwd: null pointer");
   const size_t lds = 256 * (g.C + 1) * sizeof(float);
+  VmArrs A = {};
+  long long max_pix = 0;
   for (int i = 0; i < 3; ++i) {
     TF_REQUIRE(gplanes[i] && glines[i], TF_EINVAL, "tf_vm_pack_bwd: null plane/line %d", i);
-    long long npix = (long long)g.ph[i] * g.pw[i];
-    vm_unpack_kernel<<<tf_blocks(npix, 256), 256, lds, stream>>>(gpacked, gplanes[i], g.C, g.ph[i], g.pw[i], g.n_levels,
-                                                                g.poff[i][0], g.poff[i][1], g.poff[i][2], g.poff[i][3]);
-    vm_unpack_kernel<<<tf_blocks(g.ll[i], 256), 256, lds, stream>>>(gpacked, glines[i], g.C, g.ll[i], 1, g.n_levels,
-                                                                   g.loff[i][0], g.loff[i][1], g.loff[i][2], g.loff[i][3]);
+    A.a[2 * i] = VmArr{nullptr, gplanes[i], 0, 0, 0, 0, 0, g.ph[i], g.pw[i], {g.poff[i][0], g.poff[i][1], g.poff[i][2], g.poff[i][3]}};
+    A.a[2 * i + 1] = VmArr{nullptr, glines[i], 0, 0, 0, 0, 0, g.ll[i], 1, {g.loff[i][0], g.loff[i][1], g.loff[i][2], g.loff[i][3]}};
+    max_pix = std::max(max_pix, std::max((long long)g.ph[i] * g.pw[i], (long long)g.ll[i]));
   }
+  vm_unpack_multi_kernel<<<dim3(tf_blocks(max_pix, 256), 6), 256, lds, stream>>>(A, gpacked, g.C, g.n_levels);
   TF_LAUNCH_CHECK("tf_vm_pack_bwd");
   return TF_OK;
 }
