@@ -94,7 +94,8 @@ def compact_line(line):
     sec = {}
     for key, fields in (("flow_only", ("points_per_s",)), ("train", ("ms_per_step",)), ("train_dp", ("ms_per_step", "ranks")),
                         ("shape_train", ("ms_per_step",)), ("march", ("rays_per_s", "sdf_alpha_samples_per_s", "algorithmic_frac_of_hbm_peak")),
-                        ("config3_flow256", ("points_per_s",)), ("config4_frame512", ("ms_per_frame",))):
+                        ("config3_flow256", ("points_per_s",)), ("config4_frame512", ("ms_per_frame",)),
+                        ("eval_with_aux_maps", ("points_per_s",))):
         v = line.get(key)
         if isinstance(v, dict):
             got = _pick(v, fields + ("error",))
@@ -237,8 +238,11 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
                                      max_sample_move_oracle32_vs_oracle64=float(mv64[k].max())))
             # explained: hit flags and materials agree, and the point either holds a flow sample displaced by far more than the ~1e-6 of
             # a well-conditioned one, or the ORACLE's own fp32 and fp64 colours already differ by half the deviation or more
+            # ... or the HIP colour is inside the tolerance of the fp64 evaluation of the reference's formula (the fp32 oracle is the
+            # one that is off at that point)
             explained = hits_equal and mat_err < 1e-5 and all(
-                o["sample_move_hip_vs_oracle32"] > 5e-5 or o["oracle32_vs_oracle64"] >= 0.5 * o["hip_vs_oracle32"] for o in outliers)
+                o["sample_move_hip_vs_oracle32"] > 5e-5 or o["oracle32_vs_oracle64"] >= 0.5 * o["hip_vs_oracle32"]
+                or o["hip_vs_oracle64"] <= 1e-4 for o in outliers)
         else:
             explained, hits_equal, mat_err = True, True, 0.0
         psnr = dict(value_db=20 * math.log10(1.0 / math.sqrt(max(mse, 1e-30))), max_rel_err=float(err.max()),
@@ -910,6 +914,9 @@ def main():
                        "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "live_ray_fraction": live_frac,
                        "traced_rays_per_step": traced_per_step, "hit_rays_per_step": hits // max(1, args.steps),
                        "parallelism": f"points sharded x{world}, no collective",
+                       "aux_outputs": "not in the timed region: a step returns `colors` (and the per-ray arrays); the rest of shade_mixed's dict "
+                                      "(light / colour maps, visibility, variances: fields.py:1232-1256) needs EVERY ray traced -- the zero-weight "
+                                      "culling off -- and tf_shade_reduce_aux: measured as `eval_with_aux_maps`",
                        "deviations_from_SURVEY_8d_config3": "surface points on the sphere only: hit fraction 0.148 where the survey sketched ~0.20; the "
                                                              "`scene_points` probe shades points over sphere AND torus (measured hit fraction there)"},
             "roofline": roof,
@@ -934,6 +941,25 @@ def main():
                 line["train"] = train_probe(device, verts, faces, aabb, unit, S, max(2, args.steps))
             except Exception as e:      # the probe is informative only: never lose the headline line over it
                 line["train"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train:
+            # the eval pass that ALSO builds the unweighted maps of the reference's output dict (verdict r3, weak 3): nothing culled, the
+            # statistics kernel instead of the plain reduction
+            try:
+                from tensoflow_amd.shading import aux_outputs as _aux
+                for _ in range(2):
+                    _aux(sh.shade(pts_p, view_p, nrm_p, S, S, aux=True))
+                torch.cuda.synchronize()
+                t0a = time.perf_counter()
+                na = max(2, args.steps)
+                for _ in range(na):
+                    ao = _aux(sh.shade(pts_p, view_p, nrm_p, S, S, aux=True))
+                torch.cuda.synchronize()
+                dta = (time.perf_counter() - t0a) / na
+                line["eval_with_aux_maps"] = dict(workload=f"{chunk} points x ({S} + 512 + {S}) rays, every ray traced, colours + the 10 auxiliary "
+                                                           f"outputs of shade_mixed (tf_shade_reduce_aux)", ms_per_step=dta * 1e3,
+                                                  points_per_s=chunk / dta, keys=sorted(ao.keys()))
+            except Exception as e:
+                line["eval_with_aux_maps"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":
             try:
                 ref_p = sh.shade(pts_p, view_p, nrm_p, S, S)["colors"]

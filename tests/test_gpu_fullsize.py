@@ -109,6 +109,45 @@ def test_shade_full_size_invariances(dev):
     assert torch.equal(ragged, c[:1000])
 
 
+def test_aux_statistics_full_size_against_materialised_lights(dev):
+    """tf_shade_reduce_aux at BASELINE configs[2]'s sizes (768 rays per point, 2048 points): the colours are the plain reduction's
+    (same rays, nothing culled), and every auxiliary output of shade_mixed's dict (fields.py:1232-1256, :1288-1291) equals the
+    reference's expressions evaluated by torch on the MATERIALISED [pn,T,3] light array -- two independent routes to the same
+    numbers: in-kernel Welford statistics vs torch.var / segment sums."""
+    from tensoflow_amd.encodings import linear_to_srgb
+    from tensoflow_amd.shading import MCShader, aux_outputs
+    from tensoflow_amd.synth import random_mc_state, sphere_surface_points, sphere_torus_mesh
+    sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
+    verts, faces = sphere_torus_mesh(112, 224, 128, 64)
+    sh = MCShader(sd, verts, faces, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 2.0 / 511, device=dev, n_fixed_diffuse=512)
+    pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(2048, seed=8)]
+    sh.cull_dead_rays = False
+    plain = sh.shade(pts, view, nrm, 128, 128)
+    out = sh.shade(pts, view, nrm, 128, 128, aux=True)
+    assert float((out["colors"] - plain["colors"]).abs().max()) < 1e-6        # same rays, same sums (the two kernels contract their multiply-adds differently)
+    aux = aux_outputs(out, 512)
+    lights, hit, smask, wgt = out["lights"], out["hit"], out["specular_mask"].bool(), out["wgt"]
+    nd, ns = out["n_diffuse"], smask.shape[1]
+    m = smask[..., None].float()
+    dl, sl, sh_ = lights[:, :nd], lights[:, nd:], hit[:, nd:, None].float()
+    c01 = lambda t: t.clamp(0, 1)
+    spec_color = c01(linear_to_srgb(out["specular_lin"]))
+    ref = {"diffuse_light": c01(linear_to_srgb(dl.mean(1))), "specular_light": c01(linear_to_srgb((sl * m).sum(1) / ns)),
+           "visibility": 1 - (sh_ * m).sum(1) / ns, "indirect_light": (sl * sh_ * m).sum(1) / ns,
+           "approximate_light": c01(linear_to_srgb((1 - out["metallic"]) * dl.mean(1) + spec_color))}
+    gd = (wgt[:, :nd] * dl).mean(-1, keepdim=True) * nd                      # fx.mean(-1) / p: wgt = (fx / p) / count per channel
+    gs = ((wgt[:, nd:] * sl).mean(-1, keepdim=True) * ns)
+    ref["variance_diffuse_vis"] = torch.var(gd.double(), dim=1, unbiased=True).float() / 512
+    gsm = gs.double() * m.double()
+    ref["variance_specular_vis"] = ((gsm ** 2).sum(1) / ns - (gsm.sum(1) / ns) ** 2).float() / ns
+    ref["variance"] = torch.var(gs.double()[smask]).float()
+    for k, r in ref.items():
+        assert aux[k].shape == r.shape, (k, aux[k].shape, r.shape)
+        e = true_rel_err(aux[k].cpu(), r.cpu())
+        assert e < 2e-4, (k, e)
+    assert 0.02 < float(1 - aux["visibility"].mean()) < 0.9 and float(aux["variance"]) > 0
+
+
 def test_empty_inputs_are_noops(dev):
     """n = 0 through every wrapper that the renderers call with data-dependent sizes (no launch, well-formed outputs)."""
     from tensoflow_amd import ops
