@@ -687,7 +687,8 @@ class ShapeShadingNetwork(nn.Module):
         from ..synth import synthetic_fg_lut
         self.cfg = {**self.default_cfg, **cfg}
         if self.cfg["human_light"] or self.cfg["sphere_direction"] or self.cfg["mat_pos_multires"] >= 0:
-            raise NotImplementedError("round 1 covers human_light=False, sphere_direction=False, mat_pos_multires=-1 (configs/shape/syn)")
+            raise NotImplementedError("ShapeShadingNetwork: human_light=False, sphere_direction=False, mat_pos_multires=-1 (what every shipped configs/shape file sets); "
+                                      "the material stage builds the human-light / sphere_direction variants (MCShadingNetwork)")
         fd, em = self.cfg["app_feats_dim"], self.cfg["light_exp_max"]
         if self.cfg["has_radiance_field"]:
             self.rad_mlp = _predictor3(fd + 3 + 27 + 3, 3, nn.Sigmoid())      # pos_multires=0 (raw xyz), dir_multires=4
