@@ -49,6 +49,11 @@
                            // 19.6 vs 15.8 ms, 25 spilled registers; 6: 17.1 vs 16.5; 5, no spill: 17.9): the second record's registers
                            // cost more than its overlapped round trip returns
 #endif
+#ifndef BVH_LEAF_TOUCH
+#define BVH_LEAF_TOUCH 0   // 1 (round 4, measured, not adopted): a lane arriving at a leaf touches its triangle records at once, iterations before
+                           // the batched leaf step reads them.  16.9 vs 14.5 ms per 201 M rays: vector-memory results return IN ORDER, so the
+                           // L2-missing touch sits in front of the next pair fetch of every lane of the wave, and its register costs 10 spills
+#endif
 #ifndef BVH_LEAF_W
 #define BVH_LEAF_W 2       // a wave runs a leaf step once (lanes at a leaf) * BVH_LEAF_W >= (lanes at an inner node)
 #endif
@@ -489,6 +494,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, best = BVH_MAX_DIST;
   float Ax = 0, Ay = 0, Az = 0, Bx = 0, By = 0, Bz = 0;   // slab-test constants of the current ray
   bool exhausted = false;
+#if BVH_LEAF_TOUCH
+  float touch = 0.f;
+#endif
   long long q_next = 0, q_end = 0;   // wave-uniform: this wave's private chunk of the ray pool
   long long u_next = 0, u_end = 0;   // SPINE: this wave's private range of units
   int ugrab = BVH_UNIT_GROUP;
@@ -918,6 +926,15 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
           } else {
             cur = pop();
           }
+#if BVH_LEAF_TOUCH
+          // dev experiment (round 4): a lane that has just arrived at a leaf requests the first dword of its triangle records NOW -- the
+          // leaf step proper runs iterations later, when enough lanes wait at leaves, and three quarters of the record fetches miss the L2
+          if (cur < BVH_NONE) {
+            const int enc_t = ~cur;
+            const float* tp = reinterpret_cast<const float*>(A.tris + 3LL * (enc_t >> 3));
+            touch += tp[0] * 0.f + tp[11 + 12 * (((enc_t & 7) > 1) ? 1 : 0)] * 0.f;
+          }
+#endif
 #else
           // dev-only experiment (-DBVH_PREDICATED): the four cases as selects, the push an unconditional LDS write (to a dummy row
           // when predicated off), the pop an unconditional LDS read, one rare wave-uniform branch for the scratch tail.  Results
@@ -950,6 +967,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
       if (DYN && !exhausted && __popcll(__ballot(cur == BVH_NONE)) >= BVH_REFILL) break;
     }
   }
+#if BVH_LEAF_TOUCH
+  if (touch == 123.456f) A.depth[0] = touch;      // (never true: keeps the touch loads alive)
+#endif
 #ifdef BVH_CLOCK
   if (lane == 0) {
     const unsigned long long t = BVH_TICK();
