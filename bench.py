@@ -757,7 +757,10 @@ def other_rooflines(summ, timer, hits, args, sh, dom):
                                   avg_launch_ms=ms / n, traffic=pmc_traffic("flow_kernel"),
                                   per_launch=f"{samples // max(1, args.steps)} flow samples x {FLOP_PER_FLOW_SAMPLE} flop per step (2 launches); "
                                              "matrix-core + vector-issue cycles add up per SIMD (DESIGN.md section 3, item 5), fp32-grade f16x3 products; the second launch "
-                                             "shares the GPU with the direction kernel on the side stream (stages_overlapped_ms_per_step): alone the two launches take 10.4 ms")
+                                             "shares the GPU with the direction kernel on the side stream (stages_overlapped_ms_per_step): alone the two launches take 10.4 ms",
+                                  at_floor="AT ITS INSTRUCTION FLOOR within 7 %: of the 2 750 vector instructions per 64 rows, 1 344 are LeakyReLU + f16 operand split at "
+                                           "3.5 per value (v_mul, v_med3, half a v_cvt_pk_f16_f32, v_fma_mix); gfx950 has no packed fp32 max, so the floor is 3 per value "
+                                           "(-192 instructions); the spline passes are 2 x 700.  Unchanged since round 1; no further work planned (DESIGN.md section 3, round-3 item 7)")
     return out
 
 
