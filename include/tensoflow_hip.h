@@ -262,6 +262,25 @@ int tf_march_uniform(const float* rays_o, const float* rays_d, const float* near
                      const int64_t* offsets, int64_t* counts, float* t_starts, float* t_ends, int64_t* ray_indices,
                      tf_stream_t stream);
 
+/* ShapeRenderer.sample_ray (network/shapeRenderer.py:871-932) with upsample / cat_z_vals (:820-869) and sample_pdf
+ * (utils/network_utils.py:117-147, det=True), three kernels around the field evaluations (tf_sdf_forward) of each round:
+ * tf_sample_ray_init: aabb slab test clamped to [near, far] (:878-884), z [rn, n_samples] = tmin + (tmax - tmin) * lin[k]
+ *   (+ t_rand[r] * 2 / n_samples, the per-ray stratification offset of perturb > 0, or NULL), the sample points [rn n_samples, 3]
+ *   and their mip levels log2(ball_radius / base_radii) (:966-970).  lin [n_samples] = torch.linspace(0, 1, n_samples) on the device.
+ * tf_sample_ray_upsample: one NeuS up-sampling round on the sorted rows z / sdf [rn, n_cur] (n_cur <= 128) with sharpness inv_s:
+ *   new_t [rn, n_imp] (ascending), their points / levels (new_pts may be NULL: last round).  u_lin [n_imp] =
+ *   torch.linspace(0.5 / n_imp, 1 - 0.5 / n_imp, n_imp).
+ * tf_sample_ray_merge: z_out [rn, n_cur + n_imp] = the stable sort of cat(z, new_t) (old samples first on ties), sdf_out the
+ *   gather of cat(sdf, new_sdf) in the same order (sdf_out may be NULL: last round). */
+int tf_sample_ray_init(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* radiis,
+                       const float* rays_cos, const float* aabb_host, const float* lin, const float* t_rand, int64_t rn,
+                       int32_t n_samples, float base_radii, float* z, float* pts, float* level, tf_stream_t stream);
+int tf_sample_ray_upsample(const float* rays_o, const float* rays_d, const float* radiis, const float* rays_cos, const float* z,
+                           const float* sdf, int64_t rn, int32_t n_cur, int32_t n_imp, float inv_s, const float* u_lin,
+                           float base_radii, float* new_t, float* new_pts, float* new_level, tf_stream_t stream);
+int tf_sample_ray_merge(const float* z, const float* sdf, const float* new_t, const float* new_sdf, int64_t rn, int32_t n_cur,
+                        int32_t n_imp, float* z_out, float* sdf_out, tf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Env-light prefilter: EnvLight.build_mips (network/light.py:52-64), rebuilt every shape-stage training step
  * (network/shapeRenderer.py:1291).  Replaces light_utils.cubemap_mip (network/light_utils.py:66-70) and the renderutils

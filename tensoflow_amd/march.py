@@ -93,7 +93,37 @@ def _upsample(o, d, z, sdf, n_imp, inv_s):
 def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n_samples=64, n_importance=64, up_steps=4,
                t_rand=None, inv_s_cap=None):
     """ShapeRenderer.sample_ray -> packed t_starts, t_ends, ray_indices (int64).  t_rand [rn,1] in [-0.5, 0.5): the per-ray
-    stratification offset of perturb > 0 (shapeRenderer.py:888-890); inv_s_cap: clip_sample_variance (:905-907)."""
+    stratification offset of perturb > 0 (shapeRenderer.py:888-890); inv_s_cap: clip_sample_variance (:905-907).
+    Round 4: the slab test + uniform samples, every up-sampling round (NeuS weights, inverse-CDF resampling) and the stable merge
+    are HIP kernels (tf_sample_ray_init / _upsample / _merge: ~30 launches instead of ~420); `sample_ray_torch` is the torch
+    composition of rounds 1-3, kept as the checker of tests/test_gpu_march.py."""
+    n_imp = n_importance // max(up_steps, 1)
+    if not (o.is_cuda and 2 <= n_samples and n_samples + n_imp * max(up_steps - 1, 0) <= 128 and 1 <= n_imp <= 32):
+        return sample_ray_torch(field, o, d, near, far, radiis, rays_cos, base_radii, n_samples, n_importance, up_steps, t_rand, inv_s_cap)
+    rn = o.shape[0]
+    t, pts, lv = ops.sample_ray_init(o, d, near, far, radiis, rays_cos, field.aabb, n_samples, base_radii, t_rand)
+    sdf = field.sdf(pts, lv).reshape(rn, n_samples)
+    for i in range(up_steps):
+        inv_s = float(64 * 2 ** i if inv_s_cap is None else min(inv_s_cap, 64 * 2 ** i))
+        last = i + 1 == up_steps
+        new_t, npts, nlv = ops.sample_ray_upsample(o, d, radiis, rays_cos, t, sdf, n_imp, inv_s, base_radii, want_pts=not last)
+        nsdf = None if last else field.sdf(npts, nlv).reshape(rn, n_imp)
+        t, sdf2 = ops.sample_ray_merge(t, sdf, new_t, nsdf)
+        sdf = sdf2 if sdf2 is not None else sdf
+    aabb = field.aabb_dev
+    dists = t[:, 1:] - t[:, :-1]
+    dists = torch.cat([dists, dists[:, -1:]], -1)
+    mid = t + dists * 0.5
+    ridx = torch.arange(rn, device=o.device)[:, None].expand(rn, t.shape[1])
+    p = o[:, None] + d[:, None] * mid[..., None]
+    inner = ~((aabb[0] > p) | (p > aabb[1])).any(-1)
+    return t[inner], (t + dists)[inner], ridx[inner]
+
+
+@torch.no_grad()
+def sample_ray_torch(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n_samples=64, n_importance=64, up_steps=4,
+                     t_rand=None, inv_s_cap=None):
+    """The torch composition of sample_ray (rounds 1-3): same function, ~420 launches; the checker of the kernels above."""
     rn = o.shape[0]
     dev = o.device
     aabb = field.aabb_dev

@@ -224,6 +224,61 @@ def sdf_alpha_bwd(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aab
     return gpacked, g_w1, g_b1, g_w2, g_b2, g_inv
 
 
+# ------------------------------------------------------------------------------ sample_ray (shapeRenderer.py:871-932)
+_LIN_CACHE = {}
+
+
+def _lin(key, fn, device):
+    t = _LIN_CACHE.get((key, str(device)))
+    if t is None:
+        t = _LIN_CACHE[(key, str(device))] = fn().to(device).contiguous()
+    return t
+
+
+def sample_ray_init(o, d, near, far, radiis, rays_cos, aabb, n_samples, base_radii, t_rand=None):
+    """tf_sample_ray_init -> z [rn,S], pts [rn*S,3], level [rn*S]."""
+    lib = L.load()
+    o, d = _f(o), _f(d)
+    rn, dev = o.shape[0], o.device
+    z = torch.empty(rn, n_samples, dtype=torch.float32, device=dev)
+    pts = torch.empty(rn * n_samples, 3, dtype=torch.float32, device=dev)
+    lv = torch.empty(rn * n_samples, dtype=torch.float32, device=dev)
+    lin = _lin(("lin01", n_samples), lambda: torch.linspace(0.0, 1.0, n_samples), dev)
+    L.check(lib.tf_sample_ray_init(_p(o), _p(d), _p(_f(near.reshape(-1))), _p(_f(far.reshape(-1))), _p(_f(radiis.reshape(-1))),
+                                   _p(_f(rays_cos.reshape(-1))), C.byref(_aabb6(aabb)), _p(lin),
+                                   _p(_f(t_rand.reshape(-1))) if t_rand is not None else None, rn, int(n_samples), float(base_radii),
+                                   _p(z), _p(pts), _p(lv), _stream()), "tf_sample_ray_init")
+    return z, pts, lv
+
+
+def sample_ray_upsample(o, d, radiis, rays_cos, z, sdf, n_imp, inv_s, base_radii, want_pts=True):
+    """tf_sample_ray_upsample -> new_t [rn,n_imp] (, pts [rn*n_imp,3], level [rn*n_imp])."""
+    lib = L.load()
+    rn, S = z.shape
+    dev = z.device
+    new_t = torch.empty(rn, n_imp, dtype=torch.float32, device=dev)
+    npts = torch.empty(rn * n_imp, 3, dtype=torch.float32, device=dev) if want_pts else None
+    nlv = torch.empty(rn * n_imp, dtype=torch.float32, device=dev) if want_pts else None
+    u = _lin(("u", n_imp), lambda: torch.linspace(0.5 / n_imp, 1.0 - 0.5 / n_imp, steps=n_imp), dev)
+    L.check(lib.tf_sample_ray_upsample(_p(_f(o)), _p(_f(d)), _p(_f(radiis.reshape(-1))), _p(_f(rays_cos.reshape(-1))), _p(_f(z)), _p(_f(sdf)),
+                                       rn, S, int(n_imp), float(inv_s), _p(u), float(base_radii), _p(new_t), _p(npts), _p(nlv), _stream()),
+            "tf_sample_ray_upsample")
+    return new_t, npts, nlv
+
+
+def sample_ray_merge(z, sdf, new_t, new_sdf=None):
+    """tf_sample_ray_merge -> z_out [rn, S + n_imp] (, sdf_out)."""
+    lib = L.load()
+    rn, S = z.shape
+    n_imp = new_t.shape[1]
+    z_out = torch.empty(rn, S + n_imp, dtype=torch.float32, device=z.device)
+    sdf_out = torch.empty_like(z_out) if new_sdf is not None else None
+    L.check(lib.tf_sample_ray_merge(_p(_f(z)), _p(_f(sdf)) if new_sdf is not None else None, _p(_f(new_t)),
+                                    _p(_f(new_sdf)) if new_sdf is not None else None, rn, S, n_imp, _p(z_out), _p(sdf_out), _stream()),
+            "tf_sample_ray_merge")
+    return z_out, sdf_out
+
+
 # ------------------------------------------------------------------------------ compositing
 def composite(alpha, ray_indices, values, n_rays):
     lib = L.load()

@@ -28,6 +28,18 @@ def main():
     batch = {"rays_o": o, "rays_d": d, "dirs": d, "radiis": radii, "rays_cos": cos}
     target = torch.rand(n_rays, 3, device=device)
 
+    # finer sections: wrap sample_ray, the colour network and the sdf-alpha call of the renderer
+    def wrap(obj, name, label):
+        fn = getattr(obj, name)
+        def inner(*a, **k):
+            with record_function(label):
+                return fn(*a, **k)
+        setattr(obj, name, inner)
+    wrap(r, "sample_ray", "SEC2 sample_ray")
+    wrap(r, "compute_sdf_alpha", "SEC2 compute_sdf_alpha (fwd)")
+    wrap(r.color_network, "forward", "SEC2 color_network (fwd)")
+    wrap(r.sdf_network, "TV_loss_sdf", "SEC2 TV_loss_sdf (fwd)")
+
     def step(tag=False):
         rf = record_function if tag else (lambda name: __import__("contextlib").nullcontext())
         r.zero_grad(set_to_none=True)
@@ -80,6 +92,19 @@ def main():
                 if best is None or (s.time_range.end - s.time_range.start) < (best.time_range.end - best.time_range.start):
                     best = s
         node_n[best.name if best is not None else "(forward / no autograd node)"] += n
+    secs2 = [e for e in cpu if e.name.startswith("SEC2 ")]
+    sec2_n, sec2_t = collections.Counter(), collections.Counter()
+    for e in cpu:
+        if not e.kernels:
+            continue
+        for s2 in secs2:
+            if s2.time_range.start <= e.time_range.start and e.time_range.end <= s2.time_range.end:
+                sec2_n[s2.name] += len(e.kernels)
+                sec2_t[s2.name] += sum(k.duration for k in e.kernels)
+                break
+    print("\nforward sub-sections (launches, device ms):")
+    for k, v in sec2_n.most_common():
+        print(f"  {v:5d}  {sec2_t[k] / 1e3:8.3f} ms  {k}")
     print("\nlaunches per section:")
     for k, v in sec_n.most_common():
         print(f"  {v:5d}  {k}")
