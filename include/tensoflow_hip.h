@@ -559,6 +559,20 @@ int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* g
                   float act_param, int32_t precision, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev,
                   tf_stream_t stream);
 
+/* -----------------------------------------------------------------------------------
+ * Encodings of the TRAINING direction (the inference kernels evaluate the same functions in registers).
+ * tf_ide5_fwd: generate_ide_fn(5) (utils/ref_utils.py:53-117) -> out [n,72] = [Re(36) | Im(36)] of (x + i y)^m P_{l,m}(z)
+ *   exp(-l (l + 1) / 2 kappa_inv) over (l, m) = (1, 0..1), (2, 0..2), (4, 0..4), (8, 0..8), (16, 0..16); xyz [n,3], kappa_inv [n] or
+ *   NULL (= 0); coef [17,36] = the reference's fp32 coefficient table (coefficient of z^k in column (l, m)), supplied by the caller.
+ *   Polynomials in fp64 Horner form on that table, results rounded to fp32.
+ * tf_ide5_bwd: g_xyz [n,3] and g_kappa [n] (may be NULL) from g_out [n,72], closed form.
+ * tf_posenc_fwd: get_embedder (utils/network_utils.py:38-50): out [n, d (1 + 2 n_freq)] = [x, sin(2^k x), cos(2^k x)]_k.
+ * ----------------------------------------------------------------------------------- */
+int tf_ide5_fwd(const float* xyz, const float* kappa_inv, const float* coef, int64_t n, float* out, tf_stream_t stream);
+int tf_ide5_bwd(const float* xyz, const float* kappa_inv, const float* coef, const float* g_out, int64_t n, float* g_xyz,
+                float* g_kappa, tf_stream_t stream);
+int tf_posenc_fwd(const float* x, int64_t n, int32_t d, int32_t n_freq, float* out, tf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

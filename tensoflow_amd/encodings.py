@@ -13,6 +13,9 @@ import torch
 
 
 def posenc(x, n_freq):
+    if x.is_cuda and x.dim() == 2 and not (torch.is_grad_enabled() and x.requires_grad) and x.dtype == torch.float32:
+        from . import ops
+        return ops.posenc_fwd(x, n_freq)                 # one launch (tf_posenc_fwd) instead of 2 n_freq + 1 + a concatenation
     out = [x]
     for k in range(n_freq):
         out += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
@@ -43,6 +46,10 @@ def ide5(xyz, kappa_inv, wide=False):
     the direction to ~2e-3 (tools/gen_golden.py:gen_shading_direction measures both against an fp64 run) -- so where the training
     direction differentiates THROUGH the encoding (the 'direction' outer light under the roughness-warped fixed samplers) the wide
     form keeps this implementation's noise below the reference's instead of adding a second, independent copy of it."""
+    if xyz.is_cuda and xyz.dim() == 2 and xyz.dtype == torch.float32 and (torch.is_tensor(kappa_inv) or kappa_inv == 0):
+        # round 4: one kernel forward, one backward (tf_ide5_fwd / tf_ide5_bwd: fp64 Horner on the fp32-rounded table, i.e. the `wide`
+        # evaluation for every caller) instead of ~120 element-wise launches and autograd's ~250
+        return Ide5Fn.apply(xyz, kappa_inv if torch.is_tensor(kappa_inv) else None)
     if wide:
         return _ide5_wide(xyz, kappa_inv)
     dev = xyz.device
@@ -64,6 +71,35 @@ def ide5(xyz, kappa_inv, wide=False):
         poly = vmz @ mat
     att = torch.exp(-sigma * kappa_inv)
     return torch.cat([re * poly * att, im * poly * att], -1)
+
+
+class Ide5Fn(torch.autograd.Function):
+    """ide5 on the device: forward tf_ide5_fwd, backward tf_ide5_bwd (closed form wrt the direction and kappa_inv)."""
+
+    @staticmethod
+    def _coef(dev):
+        key = (dev, "coef")
+        if key not in _IDE:
+            _IDE[key] = torch.from_numpy(_ide_tables()[0]).to(dev).contiguous()
+        return _IDE[key]
+
+    @staticmethod
+    def forward(ctx, xyz, kappa_inv):
+        from . import ops
+        xyz = xyz.contiguous()
+        kap = None if kappa_inv is None else kappa_inv.reshape(-1).contiguous()
+        ctx.save_for_backward(xyz, kap if kap is not None else torch.empty(0, device=xyz.device))
+        ctx.has_kap = kap is not None
+        ctx.kshape = None if kappa_inv is None else kappa_inv.shape
+        return ops.ide5_fwd(xyz, kap, Ide5Fn._coef(xyz.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        xyz, kap = ctx.saved_tensors
+        want_k = ctx.has_kap and ctx.needs_input_grad[1]
+        g_xyz, g_k = ops.ide5_bwd(xyz, kap if ctx.has_kap else None, Ide5Fn._coef(xyz.device), g.contiguous(), want_kappa=want_k)
+        return (g_xyz if ctx.needs_input_grad[0] else None), (g_k.reshape(ctx.kshape) if (want_k and g_k is not None) else None)
 
 
 def _ide5_wide(xyz, kappa_inv):

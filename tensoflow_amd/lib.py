@@ -117,6 +117,9 @@ SIGNATURES = {
     "tf_shade_dirs_fixed": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_dirs_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, c_f]),
     "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, i32, c_f, sz, c_f]),
+    "tf_ide5_fwd": (C.c_int, [c_f, c_f, c_f, i64, c_f, c_f]),
+    "tf_ide5_bwd": (C.c_int, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f]),
+    "tf_posenc_fwd": (C.c_int, [c_f, i64, i32, i32, c_f, c_f]),
     "tf_shade_reduce": (C.c_int, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),
     "tf_shade_reduce_aux": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_reduce_env": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, i64, i32, i32, c_f, c_f, c_f, c_f, c_f]),

@@ -279,6 +279,35 @@ def sample_ray_merge(z, sdf, new_t, new_sdf=None):
     return z_out, sdf_out
 
 
+# ------------------------------------------------------------------------------ encodings of the training direction
+def ide5_fwd(xyz, kappa_inv, coef):
+    """tf_ide5_fwd: xyz [n,3], kappa_inv [n] or None, coef [17,36] -> [n,72]."""
+    n = xyz.shape[0]
+    out = torch.empty(n, 72, dtype=torch.float32, device=xyz.device)
+    L.check(L.load().tf_ide5_fwd(_p(_f(xyz)), _p(_f(kappa_inv.reshape(-1))) if kappa_inv is not None else None, _p(coef), n, _p(out), _stream()),
+            "tf_ide5_fwd")
+    return out
+
+
+def ide5_bwd(xyz, kappa_inv, coef, g_out, want_kappa=True):
+    """tf_ide5_bwd -> (g_xyz [n,3], g_kappa [n] or None)."""
+    n = xyz.shape[0]
+    g_xyz = torch.empty(n, 3, dtype=torch.float32, device=xyz.device)
+    g_k = torch.empty(n, dtype=torch.float32, device=xyz.device) if (want_kappa and kappa_inv is not None) else None
+    L.check(L.load().tf_ide5_bwd(_p(_f(xyz)), _p(_f(kappa_inv.reshape(-1))) if kappa_inv is not None else None, _p(coef), _p(_f(g_out)), n,
+                                 _p(g_xyz), _p(g_k), _stream()), "tf_ide5_bwd")
+    return g_xyz, g_k
+
+
+def posenc_fwd(x, n_freq):
+    """tf_posenc_fwd: x [n,d] -> [n, d (1 + 2 n_freq)]."""
+    x = _f(x)
+    n, d = x.shape
+    out = torch.empty(n, d * (1 + 2 * n_freq), dtype=torch.float32, device=x.device)
+    L.check(L.load().tf_posenc_fwd(_p(x), n, d, int(n_freq), _p(out), _stream()), "tf_posenc_fwd")
+    return out
+
+
 # ------------------------------------------------------------------------------ compositing
 def composite(alpha, ray_indices, values, n_rays):
     lib = L.load()

@@ -1,0 +1,65 @@
+"""tf_ide5_fwd / tf_ide5_bwd / tf_posenc_fwd (round 4) against the torch compositions they replace: the integrated directional
+encoding of utils/ref_utils.py:53-117 evaluated in fp64 Horner form on the reference's fp32 coefficient table
+(encodings._ide5_wide) and its autograd gradient wrt the direction and kappa_inv; the positional encoding of
+utils/network_utils.py:38-50.  (Both compositions are pinned to the reference by tests/golden/encodings.npz on CPU.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test collected but no GPU is visible")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("n,with_kappa", [(5000, True), (777, False), (1, True)])
+def test_ide5_kernel_forward_and_backward(dev, n, with_kappa):
+    from tensoflow_amd import encodings as E
+    g = torch.Generator().manual_seed(n)
+    xyz = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    xyz[: min(n, 3)] = torch.tensor([[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])[: min(n, 3)]      # poles and axes
+    kap = torch.rand(n, 1, generator=g) * 0.9 + 0.05 if with_kappa else torch.zeros(n, 1)
+    w = torch.randn(n, 72, generator=g)
+    x1 = xyz.to(dev).requires_grad_(True)
+    k1 = kap.to(dev).requires_grad_(with_kappa)
+    out = E.ide5(x1, k1)                                           # the kernel pair (CUDA, 2-D)
+    assert out.shape == (n, 72) and out.dtype == torch.float32
+    gx, = torch.autograd.grad((out * w.to(dev)).sum(), [x1], retain_graph=with_kappa)
+    x2 = xyz.double().requires_grad_(True)
+    k2 = kap.double().requires_grad_(with_kappa)
+    # fp64 reference: the same Horner evaluation in torch (CPU, double end to end)
+    mat, ms, ls = E._ide_tables()
+    mat64 = torch.from_numpy(mat.astype("float64"))
+    X, Y, Z = x2[:, 0:1], x2[:, 1:2], x2[:, 2:3]
+    poly = mat64[16].expand(n, 36)
+    for kk in range(15, -1, -1):
+        poly = poly * Z + mat64[kk]
+    re, im = [torch.ones_like(X)], [torch.zeros_like(X)]
+    for _ in range(16):
+        re, im = re + [re[-1] * X - im[-1] * Y], im + [re[-1] * Y + im[-1] * X]
+    msl = torch.from_numpy(ms)
+    re, im = torch.cat(re, -1)[:, msl], torch.cat(im, -1)[:, msl]
+    att = torch.exp(-torch.from_numpy(0.5 * ls * (ls + 1)).double() * k2)
+    ref = torch.cat([re * poly * att, im * poly * att], -1)
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    grads = torch.autograd.grad((ref * w.double()).sum(), [x2] + ([k2] if with_kappa else []))
+    scale = float(grads[0].abs().max())
+    assert float((gx.cpu().double() - grads[0]).abs().max()) < 2e-6 * scale
+    if with_kappa:
+        gk, = torch.autograd.grad((out * w.to(dev)).sum(), [k1])
+        assert gk.shape == k1.shape
+        assert float((gk.cpu().double() - grads[1]).abs().max()) < 2e-6 * float(grads[1].abs().max())
+
+
+def test_posenc_kernel(dev):
+    from tensoflow_amd import encodings as E
+    x = (torch.rand(4097, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1)
+    for nf in (0, 4, 6, 8):
+        got = E.posenc(x.to(dev), nf)                              # kernel (CUDA, no grad)
+        ref = E.posenc(x.double(), nf)                             # torch composition, double
+        assert got.shape == ref.shape and float((got.cpu().double() - ref).abs().max()) < 2e-5      # sin / cos of arguments up to 128 in fp32
+    xg = x.to(dev).requires_grad_(True)
+    assert E.posenc(xg, 2).requires_grad                           # differentiable inputs keep the torch composition
