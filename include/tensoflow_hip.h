@@ -573,6 +573,16 @@ int tf_ide5_bwd(const float* xyz, const float* kappa_inv, const float* coef, con
                 float* g_kappa, tf_stream_t stream);
 int tf_posenc_fwd(const float* x, int64_t n, int32_t d, int32_t n_freq, float* out, tf_stream_t stream);
 
+/* TVLoss.forward (network/other_field.py:170-191) on one [C,H,W] grid (B = 1: TensoSDF.TV_loss_sdf, fields.py:133-138).
+ * tf_tv_fwd: partial [tf_tv_partials()] = per-block (sum of squared differences along H, along W), interleaved; the loss is
+ *   weight * 2 * (sum_h / (C (H-1) W) + sum_w / (C H (W-1))) (a term whose count is 0 is left out), summed by the caller in a fixed order.
+ * tf_tv_bwd: g_x [C,H,W] = g_dev[0] * (coef_h * d sum_h / dx + coef_w * d sum_w / dx) (overwritten); g_dev: the upstream gradient
+ *   of the loss, one float on the device; coef_h = weight * 2 / count_h (0 if count_h == 0), coef_w likewise. */
+int32_t tf_tv_partials(void);
+int tf_tv_fwd(const float* x, int32_t C, int32_t H, int32_t W, float* partial, tf_stream_t stream);
+int tf_tv_bwd(const float* x, int32_t C, int32_t H, int32_t W, const float* g_dev, float coef_h, float coef_w, float* g_x,
+              tf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

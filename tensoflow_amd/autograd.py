@@ -305,3 +305,32 @@ class SdfAlphaFn(torch.autograd.Function):
                                                               units, ctx.inv_s_host, cos_anneal, sdf, taps, g_alpha, g_grad, g_feat, g_sdf, g_nh)
         gplanes, glines = ctx.packed.unpack_grad(gp, params[:3], params[3:6])
         return (None, None, None, None, g_inv.reshape(inv_s.shape), None, None, None, None, *gplanes, *glines, g_w1, g_b1, g_w2, g_b2)
+
+
+class TvLossFn(torch.autograd.Function):
+    """TVLoss.forward (other_field.py:170-191) of one [1,C,H,W] grid: tf_tv_fwd (+ a fixed-order sum of its 1 024 partials) and
+    tf_tv_bwd -- two launches forward, one backward, instead of ~12 + autograd's slice backwards on a plane-sized tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import lib as L
+        lib = L.load()
+        b, c, h, w = x.shape
+        assert b == 1 and x.is_contiguous()
+        part = torch.empty(lib.tf_tv_partials(), dtype=torch.float32, device=x.device)
+        L.check(lib.tf_tv_fwd(ops._p(x), c, h, w, ops._p(part), ops._stream()), "tf_tv_fwd")
+        s = part.view(-1, 2).sum(0)
+        count_h, count_w = c * (h - 1) * w, c * h * (w - 1)
+        ctx.coef = (float(weight) * 2.0 / count_h if count_h else 0.0, float(weight) * 2.0 / count_w if count_w else 0.0)
+        ctx.save_for_backward(x)
+        return s[0] * ctx.coef[0] + s[1] * ctx.coef[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import lib as L
+        (x,) = ctx.saved_tensors
+        _, c, h, w = x.shape
+        gx = torch.empty_like(x)
+        L.check(L.load().tf_tv_bwd(ops._p(x), c, h, w, ops._p(g.reshape(1).contiguous().float()), ctx.coef[0], ctx.coef[1], ops._p(gx),
+                                   ops._stream()), "tf_tv_bwd")
+        return gx, None

@@ -40,8 +40,19 @@ def ndf_cutoff(roughness, cutoff=0.99, n=1000000):
 _NDF_CUTOFF = {}
 
 
+_CENTRE_DIRS = {}
+
+
 def _texel_centre_dirs(res, device):
-    """Directions of the texel centres as light_utils.py:72-80 builds them (torch.linspace grid + safe_normalize)."""
+    """Directions of the texel centres as light_utils.py:72-80 builds them (torch.linspace grid + safe_normalize).  Cached per
+    (resolution, device): rebuilding them in every _CubeMip.backward was 75 launches per shape-stage training step."""
+    key = (int(res), str(device))
+    if key not in _CENTRE_DIRS:
+        _CENTRE_DIRS[key] = _texel_centre_dirs_build(res, device)
+    return _CENTRE_DIRS[key]
+
+
+def _texel_centre_dirs_build(res, device):
     lin = torch.linspace(-1.0 + 1.0 / res, 1.0 - 1.0 / res, res, device=device)
     gy, gx = torch.meshgrid(lin, lin, indexing="ij")
     one = torch.ones_like(gx)

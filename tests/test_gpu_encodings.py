@@ -63,3 +63,26 @@ def test_posenc_kernel(dev):
         assert got.shape == ref.shape and float((got.cpu().double() - ref).abs().max()) < 2e-5      # sin / cos of arguments up to 128 in fp32
     xg = x.to(dev).requires_grad_(True)
     assert E.posenc(xg, 2).requires_grad                           # differentiable inputs keep the torch composition
+
+
+@pytest.mark.parametrize("shape", [(1, 36, 32, 32), (1, 36, 300, 1), (1, 4, 7, 13), (1, 1, 1, 5)])
+def test_tv_loss_kernels(dev, shape):
+    """tf_tv_fwd / tf_tv_bwd against TVLoss.forward (other_field.py:170-191) written out in torch (double) and its autograd gradient."""
+    from tensoflow_amd.network.fields import TVLoss
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape)))
+    xd = x.to(dev).requires_grad_(True)
+    got = TVLoss(0.7)(xd)
+    (g,) = torch.autograd.grad(got * 3.0, [xd])
+    x64 = x.double().requires_grad_(True)
+    b, c, h, w = shape
+    tot = 0.0
+    if c * (h - 1) * w:
+        tot = tot + torch.pow(x64[:, :, 1:, :] - x64[:, :, :h - 1, :], 2).sum() / (c * (h - 1) * w)
+    if c * h * (w - 1):
+        tot = tot + torch.pow(x64[:, :, :, 1:] - x64[:, :, :, :w - 1], 2).sum() / (c * h * (w - 1))
+    ref = 0.7 * 2 * tot / b
+    (gr,) = torch.autograd.grad(ref * 3.0, [x64])
+    assert abs(float(got) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert float((g.cpu().double() - gr).abs().max()) < 1e-5 * max(1e-6, float(gr.abs().max()))
+    again = TVLoss(0.7)(xd)
+    assert float(again) == float(got)                       # fixed-order reduction: identical bits run to run
