@@ -446,11 +446,13 @@ class MCShadingNetwork(nn.Module):
             logqx = logq[..., 0] - logjac[:, :sd]
             outputs["loss_nis_diffuse"] = -(contrib[:, :sd] * float(nd) * logqx[..., None]).mean()
         if step is not None and step >= self.cfg.get("nis_loss_iter_specular", 500):
-            rid = torch.arange(pn, device=dev)[:, None].expand(pn, ss)[smask]
-            x = ang_s[smask].clamp(1e-6, 1 - 1e-6).contiguous()
+            # ONE compaction of the specular mask (a boolean index is a nonzero -- eight launches and a host sync -- each time)
+            sel = torch.nonzero(smask.reshape(-1))[:, 0]
+            rid = sel // ss
+            x = ang_s.reshape(-1, ang_s.shape[-1]).index_select(0, sel).clamp(1e-6, 1 - 1e-6).contiguous()
             _, logq = self.flow_specular(pts, va, roughness.detach(), x, return_jacobian=True, rays_id=rid)
-            logqx = logq[:, 0] - logjac[:, sd:][smask]
-            outputs["loss_nis_specular"] = -(contrib[:, nd:][smask] * float(ss) * logqx[:, None]).mean()
+            logqx = logq[:, 0] - logjac[:, sd:].reshape(-1).index_select(0, sel)
+            outputs["loss_nis_specular"] = -(contrib[:, nd:].reshape(-1, 3).index_select(0, sel) * float(ss) * logqx[:, None]).mean()
         outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
         return colors, outputs
 

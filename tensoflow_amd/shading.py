@@ -17,10 +17,9 @@ from . import ops
 
 
 def posenc(x, n_freq):
-    out = [x]
-    for k in range(n_freq):
-        out += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
-    return torch.cat(out, -1)
+    """get_embedder (utils/network_utils.py:38-50); on the device and outside a graph: one launch (encodings.posenc -> tf_posenc_fwd)."""
+    from .encodings import posenc as _pe
+    return _pe(x, n_freq)
 
 
 def wn_weight(sd, prefix):
