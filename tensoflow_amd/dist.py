@@ -152,6 +152,7 @@ class GradientExchange:
                 self._bucket_of[id(p)] = (bi, si)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._fired = set()
+        self._next = 0                         # index of the next bucket to go on the wire (in-order launch)
         self.launched_in_backward = 0          # collectives queued from hooks during the last backward (tests / bench line)
         self._in_backward = False
 
@@ -175,14 +176,21 @@ class GradientExchange:
             h.remove()
         self._hooks = []
 
-    def zero_grad(self):
-        """Zero every bucket and point every parameter's .grad at its slice of the bucket."""
+    def zero_grad(self, expected=None):
+        """Zero every bucket and point every parameter's .grad at its slice of the bucket.  `expected`: the parameters that receive a
+        gradient at this step (a decision every rank makes identically, e.g. MaterialTrainer.trainable(step)); the others are not
+        waited for -- a bucket is complete when its EXPECTED gradients have landed (buckets go out in order, so a parameter that is
+        never written would otherwise hold back every bucket behind it until finish())."""
+        keep = None if expected is None else {id(p) for p in expected}
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"], b["work"], b["sent"], b["events"] = len(b["params"]), [], False, None
+            b["work"], b["sent"], b["events"] = [], False, None
+            b["pending"] = len(b["params"]) if keep is None else sum(1 for p in b["params"] if id(p) in keep)
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
+        self._expected = keep
         self._fired = set()
+        self._next = 0
         self.launched_in_backward = 0
         self._in_backward = True
 
@@ -215,23 +223,29 @@ class GradientExchange:
         if slot is None or id(p) in self._fired:
             return
         self._fired.add(id(p))
+        counted = getattr(self, "_expected", None) is None or id(p) in self._expected
         b = self.buckets[slot[0]]
         v = b["views"][slot[1]]
         if p.grad is not v:
             # autograd replaced the view (first accumulation into an undefined / non-writable grad): put the numbers where they belong
             v.copy_(p.grad)
             p.grad = v
-        b["pending"] -= 1
-        if b["pending"] == 0:
-            self._send(b)
+        if counted:
+            b["pending"] -= 1
+        # buckets go on the wire STRICTLY in bucket order (as torch's DDP reducer does): every rank then issues the same sequence of
+        # collectives even if its autograd graph completes the buckets in another order (a rank without a single hit ray skips a
+        # branch of the graph) -- a bucket that is ready early waits for its predecessors
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._send(self.buckets[self._next])
+            self._next += 1
 
     def finish(self, expected=None):
         """After backward: send the buckets that are still waiting for a gradient (their missing slices are zeros), wait for
         every collective, and give parameters outside `expected` that received nothing their None grad back."""
         self._in_backward = False
-        for b in self.buckets:
-            if not b["sent"]:
-                self._send(b)
+        for b in self.buckets[self._next:]:
+            self._send(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b["work"] is None:                                  # gloo with device tensors: host staging
                 host = b["flat"].cpu()

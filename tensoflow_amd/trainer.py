@@ -148,7 +148,7 @@ class MaterialTrainer:
         self.net.train()
         ex = self._exchange()
         if ex is not None:
-            ex.zero_grad()                                                # gradients accumulate into the persistent exchange buckets
+            ex.zero_grad(expected=self.trainable(step))                   # gradients accumulate into the persistent exchange buckets
         else:
             self.optimizer.zero_grad(set_to_none=True)
         self.refresh_flow_copies(step)                                    # MaterialRenderer.train_step calls update_step first (:549)
@@ -338,7 +338,7 @@ class ShapeTrainer:
         net.train()
         ex = MaterialTrainer._exchange(self)                                           # (same rule: world > 1, rebuilt after a grid upsample)
         if ex is not None:
-            ex.zero_grad()
+            ex.zero_grad(expected=self.trainable())
         else:
             self.optimizer.zero_grad(set_to_none=True)
         net.color_network.envlight.build_mips()
