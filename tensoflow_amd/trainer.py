@@ -148,6 +148,7 @@ class MaterialTrainer:
         self.net.train()
         ex = self._exchange()
         if ex is not None:
+            ex.stats = getattr(self, "comm_stats", None)                  # (before backward: the buckets are sent from inside it)
             ex.zero_grad(expected=self.trainable(step))                   # gradients accumulate into the persistent exchange buckets
         else:
             self.optimizer.zero_grad(set_to_none=True)
@@ -160,7 +161,6 @@ class MaterialTrainer:
         loss = sum(v.mean() for v in terms.values())
         loss.backward()                                                   # every bucket's collective is queued as its last gradient lands
         if ex is not None:
-            ex.stats = getattr(self, "comm_stats", None)
             ex.finish(expected=self.trainable(step))
         self.optimizer.step()
         # learning-rate bookkeeping, in the reference's order (:247-252)
