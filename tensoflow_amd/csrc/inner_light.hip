@@ -769,36 +769,64 @@ static __global__ void __launch_bounds__(256) inner_light_cols3_kernel(const flo
 __device__ unsigned long long g_il3_stamps[8 * 16];
 extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_il3_stamps), sizeof(unsigned long long) * 128); }
 #endif
-struct IL3 {
-  static constexpr int RT = 2;                       // ray tiles per team pass
-  static constexpr int TEAM16 = 16 * RT * 2 * 64;    // 16-byte units of one team's activation image (64 KB)
 #ifndef IL3_PF
 #define IL3_PF 2
 #endif
+// Two operand forms of the staggered kernel:
+//   TERMS = 3 (TF_PREC_F16X3): activations AND weights split hi + lo, a_hi w_hi + a_lo w_hi + a_hi w_lo; a team pass is 64 rays
+//     (2 ray tiles x 2 planes = 64 KB of B-fragments per team);
+//   TERMS = 2 (TF_PREC_F16X2): activations rounded to f16 ONCE per layer, weights split hi + lo (x w_hi + x w_lo); one plane per
+//     ray tile, so the same 64 KB hold a 128-ray team pass (4 ray tiles): every weight fragment fetched from L2 feeds twice the
+//     rays (the f16x3 form's roof is the L2 -> CU fill rate of its weight stream) and a product term costs two MFMAs, not three.
+//     Every lane stands for two rays of the pass (ray 64 e + lane, e = 0, 1) in the vector steps.
+template <int TERMS>
+struct IL3 {
+#ifndef IL3_RT2
+#define IL3_RT2 4
+#endif
+  static constexpr int RT = TERMS == 3 ? 2 : IL3_RT2;      // ray tiles per team pass
+  static constexpr int XP = TERMS == 3 ? 2 : 1;      // activation planes (hi | lo)
+  static constexpr int NR = (RT + 1) / 2;            // rays per lane in the vector steps
+  static constexpr int RAYS = 32 * RT;               // rays per team pass
+  static constexpr int TEAM16 = 16 * RT * XP * 64;   // 16-byte units of one team's activation image (64 KB in both forms)
+  static constexpr int STAGE = 3 * RAYS * 4 + RAYS;  // floats of one team's input stage: hit point | normal | direction rows (16 B each) | depths
+  static constexpr int PART = 4 * 3 * RT * 32;       // floats of one team's partial sums of the 256 -> 3 layer: [wave][ray tile * 3 + output][ray]
   static constexpr int PF = IL3_PF;                  // k-steps of weight fragments in flight
 };
-struct Il3Ring { tf_h8 a[IL3::PF + 1][2][2]; };
+struct Il3Ring { tf_h8 a[IL3_PF + 1][2][2]; };
 
 // 8-byte slot of input column k (k % 4 == 0) in a team's layer-1 B-fragment image, RELATIVE to the slot of the lane's ray
 // (il3_ray_slot8): [k-step][ray tile][hi|lo][lane][8 halves]; a compile-time constant for a compile-time k
+template <int TERMS>
 __device__ __forceinline__ constexpr int il3_col_slot8(int k, int plane) {
-  return (((2 * (k >> 5) + ((k >> 4) & 1)) * IL3::RT * 2 + plane) * 64 + 32 * ((k >> 2) & 1)) * 2 + ((k >> 3) & 1);
+  return (((k >> 4) * IL3<TERMS>::RT * IL3<TERMS>::XP + plane) * 64 + 32 * ((k >> 2) & 1)) * 2 + ((k >> 3) & 1);
 }
-__device__ __forceinline__ int il3_ray_slot8(int r, int j) { return (r * 2 * 64 + j) * 2; }
+template <int TERMS>
+__device__ __forceinline__ int il3_ray_slot8(int r, int j) { return (r * IL3<TERMS>::XP * 64 + j) * 2; }
+template <int TERMS>
 __device__ __forceinline__ void il3_store4(uint2* a8 /* team image + the ray's slot */, int k, float a, float b, float c, float d) {
-  // hi = f16(x), lo = f16(x - hi): 6 instructions per four values (v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16, as tf_split8); written as
-  // (_Float16)(x - (float)hi) the compiler spends ~5 instructions per VALUE -- 700 of an encoding pass's vector instructions per ray
-  uint2 hv, lv;
-  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
-      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
-      "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(hv.x), "=&v"(hv.y), "=&v"(lv.x), "=&v"(lv.y)
-      : "v"(a), "v"(b), "v"(c), "v"(d));
-  a8[il3_col_slot8(k, 0)] = hv;
-  a8[il3_col_slot8(k, 1)] = lv;
+  if (TERMS == 3) {
+    // hi = f16(x), lo = f16(x - hi): 6 instructions per four values (v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16, as tf_split8); written as
+    // (_Float16)(x - (float)hi) the compiler spends ~5 instructions per VALUE -- 700 of an encoding pass's vector instructions per ray
+    uint2 hv, lv;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hv.x), "=&v"(hv.y), "=&v"(lv.x), "=&v"(lv.y)
+        : "v"(a), "v"(b), "v"(c), "v"(d));
+    a8[il3_col_slot8<TERMS>(k, 0)] = hv;
+    a8[il3_col_slot8<TERMS>(k, 1)] = lv;
+  } else {
+    uint2 hv;
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_cvt_pk_f16_f32 %1, %4, %5"
+        : "=&v"(hv.x), "=&v"(hv.y)
+        : "v"(a), "v"(b), "v"(c), "v"(d));
+    a8[il3_col_slot8<TERMS>(k, 0)] = hv;
+  }
 }
 
 typedef const __attribute__((address_space(1))) tf_h8* il3_gw_t;
@@ -813,7 +841,7 @@ __device__ __forceinline__ il3_gw_t il3_kstep_base(il3_gw_t Wl, int T0, int s) {
 }
 __device__ __forceinline__ void il3_prefetch(il3_gw_t Wl /* wave-uniform */, int T0, int lane, Il3Ring& ring) {
 #pragma unroll
-  for (int s = 0; s < IL3::PF; ++s) {
+  for (int s = 0; s < IL3_PF; ++s) {
     il3_gw_t b = il3_kstep_base(Wl, T0, s);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -822,20 +850,22 @@ __device__ __forceinline__ void il3_prefetch(il3_gw_t Wl /* wave-uniform */, int
   }
 }
 
-// acc[t][r] (+)= W x over K16 k-steps for this wave's unit tiles T0, T0 + 1 and the team's two ray tiles; the first PF k-steps
+// acc[t][r] (+)= W x over K16 k-steps for this wave's unit tiles T0, T0 + 1 and the team's ray tiles; the first PF k-steps
 // of weight fragments are already in `ring` (il3_prefetch, issued a step earlier).
-template <int K16>
+template <int K16, int TERMS>
 __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0, int lane,
-                                          const tf_h8* __restrict__ actl /* team image + lane */, Il3Ring& ring, f32x16 (&acc)[2][2]) {
-  constexpr int PF = IL3::PF;
-  tf_h8 bq[2][2][2];
+                                          const tf_h8* __restrict__ actl /* team image + lane */, Il3Ring& ring,
+                                          f32x16 (&acc)[2][IL3<TERMS>::RT]) {
+  constexpr int PF = IL3_PF, RT = IL3<TERMS>::RT, XP = IL3<TERMS>::XP;
 #ifdef IL3_SETPRIO
   __builtin_amdgcn_s_setprio(IL3_SETPRIO);     // the wave in a matrix phase wins the SIMD's issue arbitration against its partner's vector phase
 #endif
+  {
+  tf_h8 bq[2][RT][XP];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int p = 0; p < 2; ++p) bq[0][r][p] = actl[((0 * 2 + r) * 2 + p) * 64];
+    for (int p = 0; p < XP; ++p) bq[0][r][p] = actl[((0 * RT + r) * XP + p) * 64];
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
     if (s + PF < K16) {
@@ -847,13 +877,13 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
     }
     if (s + 1 < K16) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * 2 + r) * 2 + p) * 64];
+        for (int p = 0; p < XP; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * RT + r) * XP + p) * 64];
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const tf_h8 b_hi = bq[s & 1][r][0], b_lo = bq[s & 1][r][1];
+    for (int r = 0; r < RT; ++r) {
+      const tf_h8 b_hi = bq[s & 1][r][0], b_lo = bq[s & 1][r][XP - 1];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const tf_h8 a_hi = ring.a[s % (PF + 1)][t][0];
@@ -865,43 +895,202 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
     // order inside a k-step: the activation fragments of k-step s + 1 and the weight fragments of k-step s + PF are REQUESTED before
     // the 12 MFMAs of k-step s (left to itself the scheduler sinks the LDS reads behind the last MFMA -- they reuse the registers of
     // the fragments in use -- and every k-step then waits out an LDS round trip with the matrix pipe idle)
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads
-    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // VMEM reads
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, RT * XP, 0);         // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);               // VMEM reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT * TERMS, 0);  // MFMA
     __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
+  }
   }
 #ifdef IL3_SETPRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
-__device__ __forceinline__ void il3_bias(const float* __restrict__ lb /* layer's rows of this lane half */, int T0, f32x16 (&acc)[2][2]) {
+template <int RT>
+__device__ __forceinline__ void il3_bias(const float* __restrict__ lb /* layer's rows of this lane half */, int T0, f32x16 (&acc)[2][RT]) {
+  {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const float4 v4 = *reinterpret_cast<const float4*>(lb + (T0 + t) * 16 + 4 * qd);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) { acc[t][r][4 * qd] = v4.x; acc[t][r][4 * qd + 1] = v4.y; acc[t][r][4 * qd + 2] = v4.z; acc[t][r][4 * qd + 3] = v4.w; }
+      for (int r = 0; r < RT; ++r) { acc[t][r][4 * qd] = v4.x; acc[t][r][4 * qd + 1] = v4.y; acc[t][r][4 * qd + 2] = v4.z; acc[t][r][4 * qd + 3] = v4.w; }
     }
+  }
 }
 
-// ReLU + hi/lo split of this wave's 64 units x 64 rays into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3)
-__device__ __forceinline__ void il3_publish(tf_h8* __restrict__ actl /* team image + lane */, int T0, const f32x16 (&acc)[2][2]) {
+// ReLU + operand conversion of this wave's 64 units x (32 RT) rays into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3)
+template <int TERMS>
+__device__ __forceinline__ void il3_publish(tf_h8* __restrict__ actl /* team image + lane */, int T0, const f32x16 (&acc)[2][IL3<TERMS>::RT]) {
+  constexpr int RT = IL3<TERMS>::RT, XP = IL3<TERMS>::XP;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         float x8[8];
+        tf_h8* dst = actl + (((2 * (T0 + t) + u) * RT + r) * XP) * 64;
+        if (TERMS == 3) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
-        tf_h8 hi, lo;
-        tf_split8(x8, hi, lo);
-        tf_h8* dst = actl + (((2 * (T0 + t) + u) * 2 + r) * 2) * 64;
-        dst[0] = hi; dst[64] = lo;
+          for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
+          tf_h8 hi, lo;
+          tf_split8(x8, hi, lo);
+          dst[0] = hi; dst[64] = lo;
+        } else {
+          // one rounded operand per value: ReLU AFTER the conversion, on the packed halves (rounding to f16 is monotonic and keeps the
+          // sign, so max(f16(x), 0) = f16(max(x, 0)): one v_pk_max_f16 per two values instead of one v_max_f32 per value)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x8[e] = acc[t][r][8 * u + e];
+          tf_h8 hi;
+          tf_cvt8(x8, hi);
+          const tf_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+          dst[0] = __builtin_elementwise_max(hi, zero);
+          // (with 128 accumulator registers live the scheduler must not gather the conversions in front of the stores)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+}
+
+
+// ---- 128-ray form (TERMS = 2): a wave's 64 units x 128 rays are 128 accumulator registers -- with the weight ring, the activation
+// fragments and what lives across a matrix step more than the register allocator places without spilling (16-register tuples in a
+// file fragmented by 4-register ones: 110-170 spilled registers in every arrangement tried).  The wave therefore runs a layer as
+// TWO HALVES, one unit tile (32 units x 128 rays = 64 registers) at a time: every weight fragment is still fetched once per 128 rays
+// (two fragments -- hi | lo of one tile -- feed 8 MFMAs), the activation fragments are read twice (62 B / clock and CU: half of the
+// LDS rate); the first half's output waits as 32 registers of packed f16 until the second half has read the image.
+#ifndef IL4_PF
+#define IL4_PF 2
+#endif
+struct Il4Ring { tf_h8 a[IL4_PF + 1][2]; };
+__device__ __forceinline__ void il4_prefetch(il3_gw_t Wl /* wave-uniform */, int T, int lane, Il4Ring& ring) {
+#pragma unroll
+  for (int s = 0; s < IL4_PF; ++s) {
+    il3_gw_t b = il3_kstep_base(Wl, T, s);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) ring.a[s][p] = b[lane + p * 64];
+  }
+}
+// acc[r] = bias + W x for unit tile T and the team's four ray tiles (the first PF k-steps of weight fragments are in `ring`).
+// NEXT: the last PF k-steps request the first PF k-steps of unit tile T + 1 (the wave's second half of the layer): one continuous
+// weight stream over both halves, the ring's slots keep rotating (2 K16 k-steps).
+template <int K16, bool NEXT, int S0 /* ring slot of k-step 0 */>
+__device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, int lane, const float* __restrict__ lb /* layer's rows of this lane half */,
+                                         const tf_h8* __restrict__ actl /* team image + lane */, Il4Ring& ring, f32x16 (&acc)[4]) {
+  constexpr int PF = IL4_PF;
+  // the bias tile is the C operand of each ray tile's FIRST product (no copies into the four accumulators: a wave does not overlap
+  // its own vector instructions with its own MFMAs, so every vector instruction of a matrix step is 4 idle cycles of the matrix pipe)
+  f32x16 bv;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const float4 v4 = *reinterpret_cast<const float4*>(lb + T * 16 + 4 * qd);
+    bv[4 * qd] = v4.x; bv[4 * qd + 1] = v4.y; bv[4 * qd + 2] = v4.z; bv[4 * qd + 3] = v4.w;
+  }
+#ifdef IL4_BQ1
+  // activation fragments NOT double buffered: ray tile r's fragment of k-step s + 1 is requested right behind the two MFMAs that read
+  // its fragment of k-step s (an MFMA has taken its operands when the next instruction issues) -- six MFMAs ahead of its first use
+  tf_h8 bq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bq[r] = actl[r * 64];
+#pragma unroll
+  for (int s = 0; s < K16; ++s) {
+    if (s + PF < K16 || NEXT) {
+      il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][0], bq[r], s == 0 ? bv : acc[r]);
+      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][1], bq[r], acc[r]);
+      if (s + 1 < K16) bq[r] = actl[((s + 1) * 4 + r) * 64];
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM reads (k-step s + PF)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
+  tf_h8 bq[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bq[0][r] = actl[r * 64];
+#pragma unroll
+  for (int s = 0; s < K16; ++s) {
+    if (s + PF < K16 || NEXT) {
+#ifdef IL4_SAME_TILE   // dev-only timing ablation: every wave streams unit tile 0's fragments (one L2 -> CU fetch serves the team)
+      il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, 0, s + PF) : il3_kstep_base(Wl, 0, s + PF - K16);
+#else
+      il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
+#endif
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
+    }
+    if (s + 1 < K16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bq[(s + 1) & 1][r] = actl[((s + 1) * 4 + r) * 64];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][0], bq[s & 1][r], s == 0 ? bv : acc[r]);
+      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][1], bq[s & 1][r], acc[r]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // DS reads (k-step s + 1)
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM reads (k-step s + PF)
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // MFMA
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+}
+// One rounding to f16 of a half's 32 units x 128 rays: [ray tile][k-step half u] fragments of 8 halves.  The vector fptrunc
+// (v_cvt_pk_f16_f32, round to nearest even): compiler-visible, so that hipcc pads the MFMA -> reader hazard (it does not for an asm
+// statement reading MFMA results).  The ReLU follows at publish time (a vector step, not a matrix step).
+__device__ __forceinline__ void il4_pack(const f32x16 (&acc)[4], tf_h8 (&h)[4][2]) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x8 xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = acc[r][8 * u + e];
+      h[r][u] = __builtin_convertvector(xv, tf_h8);
+    }
+}
+// ReLU + store into the next layer's B-fragments: unit tile T is k-steps 2 T, 2 T + 1.  ReLU on the packed halves AS SIGNED 16-BIT
+// INTEGERS -- rounding to f16 is monotonic and keeps the sign, a negative half is a negative integer, a non-negative one its own bit
+// pattern: one v_pk_max_i16 per two values (max(x, 0) on halves costs a canonicalising v_pk_max_f16 x, x in front of each)
+__device__ __forceinline__ void il4_publish(tf_h8* __restrict__ actl /* team image + lane */, int T, const tf_h8 (&h)[4][2]) {
+  typedef short i16x8 __attribute__((ext_vector_type(8)));
+  const i16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      actl[((2 * T + u) * 4 + r) * 64] = __builtin_bit_cast(tf_h8, __builtin_elementwise_max(__builtin_bit_cast(i16x8, h[r][u]), zero));
+}
+// a half's share of the 256 -> 3 layer (exact fp32 on the vector unit): sum[r][c] += relu(acc[r]) . w4 rows of unit tile T
+__device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 256 */, int T, const f32x16 (&acc)[4], float (&sum)[4][3]) {
+#ifdef IL4_NO_OUT3   // dev-only timing ablation
+  sum[0][0] += acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+  return;
+#endif
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    float4 wr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4h + c * 512 + T * 16 + 4 * qd);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x0 = tf_relu(acc[r][4 * qd]), x1 = tf_relu(acc[r][4 * qd + 1]);
+      const float x2 = tf_relu(acc[r][4 * qd + 2]), x3 = tf_relu(acc[r][4 * qd + 3]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sum[r][c] = fmaf(x3, wr[c].w, fmaf(x2, wr[c].z, fmaf(x1, wr[c].y, fmaf(x0, wr[c].x, sum[r][c]))));
+    }
+  }
 }
 
 __device__ __forceinline__ void il3_barrier() {
@@ -913,22 +1102,27 @@ __device__ __forceinline__ void il3_barrier() {
 // OUTER: the same network shape fed with the IDE of the ray DIRECTION itself (MCShadingNetwork.predict_outer_lights, 'direction':
 // network/fields.py:913-916 -- sph_enc(directions, 0), no reflection, no normalisation, no positional columns: their weights are zero
 // in the image and `pts` / `nrm` alias `view`)
-template <bool OUTER>
+template <bool OUTER, int TERMS>
 __global__ void __launch_bounds__(512, 1)
 inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
                     const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
                     const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
                     float* __restrict__ out) {
+  typedef IL3<TERMS> C;
+  constexpr int RT = C::RT, NR = C::NR, RAYS = C::RAYS;
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   if (m <= 0) return;
-  __shared__ __attribute__((aligned(16))) tf_h8 act[2 * IL3::TEAM16];       // 128 KB: [team][k-step][ray tile][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) tf_h8 act[2 * C::TEAM16];         // 128 KB: [team][k-step][ray tile][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) float lbias[3 * 512];             // [layer][lane half][tile * 16 + reg]
   __shared__ __attribute__((aligned(16))) float w4a[3 * 512];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
-  __shared__ float part[2 * 4 * 6 * 32];                                    // [team][wave][ray tile * 3 + output][ray]
-  __shared__ __attribute__((aligned(16))) float stage[2 * (3 * 64 * 4 + 64)];   // [team]: hit point | normal | direction rows of the NEXT pass's 64 rays (16 bytes per
-                                                                                // ray and array: where a 12-byte LDS-DMA lands) and their depths
-  __shared__ long long stage_src[2 * 64];                                       // ... and their source indices
+  // partial sums of the 256 -> 3 layer, [team][wave][ray tile * 3 + output][ray].  They live from step FE to the tail of step M1,
+  // while k-steps 8..15 of the team's image are unused (the input row is 128 columns: k-steps 0..7; layer 3 has been read, layer 1 is
+  // published one barrier later): the 128-ray form keeps them THERE (its stage is twice the size and the 160 KB are spent).
+  __shared__ float part_own[TERMS == 3 ? 2 * C::PART : 4];
+  __shared__ __attribute__((aligned(16))) float stage[2 * C::STAGE];        // [team]: hit point | normal | direction rows of the NEXT pass's rays (16 bytes per
+                                                                            // ray and array: where a 12-byte LDS-DMA lands) and their depths
+  __shared__ long long stage_src[2 * RAYS];                                 // ... and their source indices
   __shared__ __attribute__((aligned(16))) float idem[36 * 20];              // IDE polynomial coefficients [column][power (17, padded to 20)]: read as
                                                                             // broadcast ds_read_b128 (through the scalar cache the 222 coefficients
                                                                             // of a ray went through v_mov copies into packed-FMA operands: 43 spills)
@@ -940,65 +1134,78 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
     w4a[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kW4a + i];
   }
-  const long long n_pass = (m + 63) / 64;
+  const long long n_pass = (m + RAYS - 1) / RAYS;
   const int n_iter = (int)((n_pass + 2LL * gridDim.x - 1) / (2LL * gridDim.x));
   const int T0 = 2 * w;
-  tf_h8* actt = act + team * IL3::TEAM16;
+  tf_h8* actt = act + team * C::TEAM16;
   uint2* act8 = reinterpret_cast<uint2*>(actt);
-  float* partt = part + team * (4 * 6 * 32);
+  float* partt = TERMS == 3 ? part_own + team * C::PART : reinterpret_cast<float*>(actt + 8 * RT * C::XP * 64);
   auto pass_of = [&](int it) { return ((long long)it * gridDim.x + blockIdx.x) * 2 + team; };
-  // lane l of every wave of a team stands for ray l of the team's pass (the four waves split a ray's FEATURES).
+  // lane l of every wave of a team stands for ray l (and, in the 128-ray form, ray 64 + l) of the team's pass (the four waves split a
+  // ray's FEATURES).
   // Input rows: every wave needs all of its ray's inputs, but they are GATHERED once per team and never pass through registers: in the
   // gather step wave 0 / 1 / 2 sends the hit-point / normal / direction row of ray `lane` of the NEXT pass straight into the team's
-  // LDS stage by LDS-DMA (one instruction per wave), wave 3 the depth and the source index; the encodings read their ray's rows from
-  // there one pass later.  (Gathered by every wave into registers the rows cost four times the random requests and 19 registers held
-  // across the matrix steps.)
-  float* staget = stage + team * (3 * 64 * 4 + 64);
-  long long* stage_srct = stage_src + team * 64;
-  long long src_nxt = 0;                   // source index of ray `lane` of the next pass to gather
-  long long src_cur = 0, src_out = 0;      // ... of the pass in flight / of the pass being stored
-  float dep_out = 1.f, dep_cur = 1.f;
-  auto row_src = [&](int it, int ln, const long long* ix) {
-    long long row = pass_of(it) * 64 + ln;
+  // LDS stage by LDS-DMA (one instruction per wave and 64 rays), wave 3 the depth and the source index; the encodings read their ray's
+  // rows from there one pass later.  (Gathered by every wave into registers the rows cost four times the random requests and 19
+  // registers held across the matrix steps.)
+  float* staget = stage + team * C::STAGE;
+  long long* stage_srct = stage_src + team * RAYS;
+  // (128-ray form: 32-bit source indices -- the launcher checks the capacity -- : six registers instead of twelve across the matrix steps)
+  typedef std::conditional_t<TERMS == 3, long long, unsigned> src_t;
+  src_t src_nxt[NR];                           // source index of ray 64 e + lane of the next pass to gather
+  src_t src_cur[NR], src_out[NR];              // ... of the pass in flight / of the pass being stored
+  float dep_out[NR], dep_cur[NR];
+#pragma unroll
+  for (int e = 0; e < NR; ++e) { src_nxt[e] = 0; src_cur[e] = 0; src_out[e] = 0; dep_out[e] = 1.f; dep_cur[e] = 1.f; }
+  auto row_src = [&](int it, int q, const long long* ix) {
+    long long row = pass_of(it) * RAYS + q;
     if (row >= m) row = m - 1;
 #ifdef IL3_ABLATE_GATHER   // dev-only timing ablation: input rows read in order (coalesced), not through the hit list
-    return row;
+    return (src_t)row;
 #endif
-    return ix ? ix[row] : row;
+    return (src_t)(ix ? ix[row] : row);
   };
   // wave-uniform role: which array this wave sends (w < 3) -- or depth + index (w == 3)
-  auto gather_dma = [&](long long src) {
-    if (w < 3) {
-      // (three uniform branches: a select over the three pointers is lowered to a table in scratch memory)
-      const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + w * 256));
-      if (w == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(pts + 3 * src) : "memory");     // lands at 16 bytes per lane
-      else if (w == 1) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(nrm + 3 * src) : "memory");
-      else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(view + 3 * src) : "memory");
-    } else {
-      if (depth) {
-        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + 768));
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(la), "v"(depth + src) : "memory");       // 4 bytes per lane
+  auto gather_dma = [&](const src_t (&src)[NR], int ln /* the lane index (the per-pass opaque copy inside the pass loop) */) {
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      if (w < 3) {
+        // (three uniform branches: a select over the three pointers is lowered to a table in scratch memory)
+        const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + (w * RAYS + 64 * e) * 4));
+        if (w == 0) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(pts + 3 * (long long)src[e]) : "memory");     // lands at 16 bytes per lane
+        else if (w == 1) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(nrm + 3 * (long long)src[e]) : "memory");
+        else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx3 %1, off" ::"s"(la), "v"(view + 3 * (long long)src[e]) : "memory");
       } else {
-        staget[768 + lane] = 1.f;
+        if (depth) {
+          const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) float*)(staget + 3 * RAYS * 4 + 64 * e));
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" ::"s"(la), "v"(depth + src[e]) : "memory");       // 4 bytes per lane
+        } else {
+          staget[3 * RAYS * 4 + 64 * e + ln] = 1.f;
+        }
+        stage_srct[64 * e + ln] = src[e];
       }
-      stage_srct[lane] = src;
     }
   };
-  src_nxt = row_src(0, lane, idx);
-  gather_dma(src_nxt);
+#pragma unroll
+  for (int e = 0; e < NR; ++e) src_nxt[e] = row_src(0, 64 * e + lane, idx);
+  gather_dma(src_nxt, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  src_nxt = n_iter > 1 ? row_src(1, lane, idx) : 0;
-  Il3Ring ring;
-  f32x16 acc[2][2];
+#pragma unroll
+  for (int e = 0; e < NR; ++e) src_nxt[e] = n_iter > 1 ? row_src(1, 64 * e + lane, idx) : 0;
+  std::conditional_t<TERMS == 3, Il3Ring, Il4Ring> ring;
+  f32x16 acc[TERMS == 3 ? 2 : 1][RT];      // (128-ray form: one unit tile at a time)
+  float fsum[TERMS == 3 ? 1 : RT][3];      // 128-ray form: the wave's share of the 256 -> 3 layer, from step M3 to step FE
   const float b4[3] = {ws_arg[kIB4 + 0], ws_arg[kIB4 + 2], ws_arg[kIB4 + 4]};     // packed order: [n * 2 + half], unit n = reg for n < 4
   __syncthreads();
   // Both teams run the SAME straight-line program; team B passes three barriers before it starts and team A three after it has
   // finished, so that A is three steps ahead at every moment (s_barrier only counts arrivals).  Straight-line code instead of a
   // step machine keeps the register allocator's liveness exact: the accumulators are dead during the encodings, the weight ring
   // between a matrix phase and the next prefetch (as a step machine the kernel spilled 192 registers).
-#ifdef IL3_STAMPS   // dev-only: shader-clock stamps of one iteration of workgroup 0, per wave (phase ends and barrier releases)
-  unsigned long long st[20];
-#define IL3_STAMP(i) do { if (it == 40) st[i] = __builtin_readcyclecounter(); } while (0)
+#ifdef IL3_STAMPS   // dev-only: shader-clock stamps of one iteration of workgroup 0, per wave (phase ends and barrier releases), stored as taken
+#ifndef IL3_STAMP_MASK
+#define IL3_STAMP_MASK 0xffff
+#endif
+#define IL3_STAMP(i) do { if (((IL3_STAMP_MASK) >> (i)) & 1) { if (it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + (i)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define IL3_STAMP(i) do {} while (0)
 #endif
@@ -1021,12 +1228,22 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     const int hh_o = lane_o >> 5;
     const float vsign_o = (idx_o && !OUTER) ? -1.f : 1.f;
     IL3_STAMP(0);
+#ifdef IL3_STAMPS
+    if (it == 41 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 15] = __builtin_readcyclecounter();
+#endif
     // ================= step FE
-    // ---- F: the 256 -> 3 layer of the pass whose layer 3 this wave has just finished (its accumulators)
+    // ---- F: the 256 -> 3 layer of the pass whose layer 3 this wave has just finished (64-ray form: from its accumulators; 128-ray form:
+    // the sums were formed behind either half of step M3)
     if (it >= 1) {
-      float sum[2][3];
+      float sum[RT][3];
+      if constexpr (TERMS == 2) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sum[r][c] = fsum[r][c];
+      } else {
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) sum[r][c] = 0.f;
 #pragma unroll
@@ -1037,21 +1254,23 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
           for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4a + c * 512 + hh_o * 256 + (T0 + t) * 16 + 4 * qd);
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
+          for (int r = 0; r < RT; ++r) {
             const float x0 = tf_relu(acc[t][r][4 * qd]), x1 = tf_relu(acc[t][r][4 * qd + 1]);
             const float x2 = tf_relu(acc[t][r][4 * qd + 2]), x3 = tf_relu(acc[t][r][4 * qd + 3]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) sum[r][c] = fmaf(x3, wr[c].w, fmaf(x2, wr[c].z, fmaf(x1, wr[c].y, fmaf(x0, wr[c].x, sum[r][c]))));
           }
         }
+      }
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float tot = sum[r][c] + __shfl_xor(sum[r][c], 32);         // the two lane halves hold different units of the same ray
-          if (hh_o == 0) partt[(w * 6 + r * 3 + c) * 32 + (lane_o & 31)] = tot;
+          if (hh_o == 0) partt[(w * 3 * RT + r * 3 + c) * 32 + (lane_o & 31)] = tot;
         }
-      src_out = src_cur;
+#pragma unroll
+      for (int e = 0; e < NR; ++e) src_out[e] = src_cur[e];
     }
     IL3_STAMP(13);
     // ---- E: encodings of pass `it`.  A ray's 128 input columns are split over the team's four waves (il3_orig_col): wave w evaluates
@@ -1059,20 +1278,32 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     //   wave 0: IDE columns 0..15      wave 1: 20..23, 32..35      wave 2: 16..19, 28..31 + the zero granule      wave 3: 24..27 + p
     // Every 4-column store granule has one owner.
     {
-      // this pass's input rows of the lane's ray: from the team's stage (sent there by LDS-DMA during the previous pass)
-      const float4 rp = *reinterpret_cast<const float4*>(staget + 4 * lane_o), rn = *reinterpret_cast<const float4*>(staget + 256 + 4 * lane_o),
-                   rv = *reinterpret_cast<const float4*>(staget + 512 + 4 * lane_o);
-      const float p[3] = {rp.x, rp.y, rp.z};
-      float n[3] = {rn.x, rn.y, rn.z};
-      float v[3] = {vsign_o * rv.x, vsign_o * rv.y, vsign_o * rv.z};
-      dep_out = dep_cur;
-      dep_cur = staget[768 + lane_o];
-      src_cur = stage_srct[lane_o];
+#pragma unroll
+      for (int e = 0; e < NR; ++e) {
+        dep_out[e] = dep_cur[e];
+        dep_cur[e] = staget[3 * RAYS * 4 + 64 * e + lane_o];
+        src_cur[e] = (src_t)stage_srct[64 * e + lane_o];
+      }
       if (live) {
+        // (128-ray form: the two rays of a lane one after the other in a loop that is NOT unrolled -- the store addresses of a ray are
+        // its slot + compile-time constants either way, and the step's registers and code stay those of one ray)
+#ifdef IL3_E_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+        for (int e = 0; e < NR; ++e) {
+        const int q_o = 64 * e + lane_o;
+        // this pass's input rows of the lane's ray: from the team's stage (sent there by LDS-DMA during the previous pass)
+        const float4 rp = *reinterpret_cast<const float4*>(staget + 4 * q_o), rn = *reinterpret_cast<const float4*>(staget + RAYS * 4 + 4 * q_o),
+                     rv = *reinterpret_cast<const float4*>(staget + 2 * RAYS * 4 + 4 * q_o);
+        const float p[3] = {rp.x, rp.y, rp.z};
+        float n[3] = {rn.x, rn.y, rn.z};
+        float v[3] = {vsign_o * rv.x, vsign_o * rv.y, vsign_o * rv.z};
         // this ray's slot in the team image, made opaque per pass: the 64 store addresses of a pass are this + compile-time constants
         // (immediate offsets); as loop invariants of the pass loop they were each materialised in a register and kept across the
         // matrix phases (93 registers sat unused through a matrix phase; 28-44 spills, whose reloads wait out the gathers)
-        int ray_slot = il3_ray_slot8(lane_o >> 5, lane_o & 31);
+        int ray_slot = il3_ray_slot8<TERMS>(q_o >> 5, q_o & 31);
         uint2* a8 = act8 + ray_slot;
         float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
         n[0] *= inv; n[1] *= inv; n[2] *= inv;
@@ -1116,8 +1347,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
               re[cc] = cre[mm] * poly;
               im[cc] = cim[mm] * poly;
             }
-            il3_store4(a8, 4 * gq, re[0], re[1], re[2], re[3]);
-            il3_store4(a8, 36 + 4 * gq, im[0], im[1], im[2], im[3]);
+            il3_store4<TERMS>(a8, 4 * gq, re[0], re[1], re[2], re[3]);
+            il3_store4<TERMS>(a8, 36 + 4 * gq, im[0], im[1], im[2], im[3]);
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -1128,10 +1359,10 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           ide_cols(std::integral_constant<int, 20>{}, std::integral_constant<int, 24>{}, std::integral_constant<int, 32>{}, std::integral_constant<int, 36>{});
         } else if (w == 2) {
           ide_cols(std::integral_constant<int, 16>{}, std::integral_constant<int, 20>{}, std::integral_constant<int, 28>{}, std::integral_constant<int, 32>{});
-          il3_store4(a8, 124, 0.f, 0.f, 0.f, 0.f);
+          il3_store4<TERMS>(a8, 124, 0.f, 0.f, 0.f, 0.f);
         } else {
           ide_cols(std::integral_constant<int, 24>{}, std::integral_constant<int, 28>{}, I0{}, I0{});
-          il3_store4(a8, 120, p[0], p[1], p[2], 0.f);
+          il3_store4<TERMS>(a8, 120, p[0], p[1], p[2], 0.f);
         }
 #endif
 #ifndef IL3_ABLATE_E
@@ -1147,11 +1378,14 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           }
 #pragma unroll
           for (int gq = 0; gq < 3; ++gq)
-            il3_store4(a8, 72 + 12 * w + 4 * gq, e12[4 * gq], e12[4 * gq + 1], e12[4 * gq + 2], e12[4 * gq + 3]);
+            il3_store4<TERMS>(a8, 72 + 12 * w + 4 * gq, e12[4 * gq], e12[4 * gq + 1], e12[4 * gq + 2], e12[4 * gq + 3]);
         }
 #endif
+        }
         IL3_STAMP(14);
-        il3_prefetch((gw_t)(W + kQ1 / 4), T0, lane, ring);      // layer 1's first weight fragments (the ring's registers are free for the encodings above)
+        // layer 1's first weight fragments (the ring's registers are free for the encodings above)
+        if constexpr (TERMS == 2) il4_prefetch((gw_t)(W + kQ1 / 4), T0, lane, ring);
+        else il3_prefetch((gw_t)(W + kQ1 / 4), T0, lane, ring);
       }
     }
     IL3_STAMP(1);
@@ -1159,22 +1393,39 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     IL3_STAMP(2);
     // ================= step M1; behind its matrix products, the radiance of the pass finished one step ago (fixed-order sum of the four
     // waves' partial sums).  Behind, not in front: the scattered stores would sit ahead of this step's weight loads in the in-order vmcnt.
+    tf_h8 held[TERMS == 3 ? 1 : RT][2];      // 128-ray form: the first half's output (unit tile T0) as packed f16, until the image may be overwritten
     if (live) {
-      il3_bias(lbias + hh * 256, T0, acc);
+      if constexpr (TERMS == 2) {
+        constexpr int K1 = OUTER ? 5 : 8;
+        il4_half<K1, true, 0>((gw_t)(W + kQ1 / 4), T0, lane, lbias + hh * 256, actt + lane, ring, acc[0]);
+        il4_pack(acc[0], held);
+        il4_half<K1, false, K1 % (IL4_PF + 1)>((gw_t)(W + kQ1 / 4), T0 + 1, lane, lbias + hh * 256, actt + lane, ring, acc[0]);
+      } else {
+      il3_bias<RT>(lbias + hh * 256, T0, acc);
 #ifndef IL3_ABLATE_M    // dev-only timing ablation: no matrix products
       // (the direction-encoded outer net has 72 input columns: five k-steps, the rest of its image is zero)
-      il3_layer<OUTER ? 5 : 8>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
+      il3_layer<OUTER ? 5 : 8, TERMS>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
 #endif
+      }
     }
-    if (it >= 1 && w < 2 && hh_o == w) {
-      const long long orow = pass_of(it - 1) * 64 + lane_o;
+    // wave w stores ray tile w of the pass (128-ray form: all four waves; 64-ray form: waves 0, 1): the lanes of half w & 1 hold
+    // that tile's source indices (ray 64 (w >> 1) + lane)
+#ifdef IL3_ABLATE_O
+    if (it >= 1 && w < RT && hh_o == (w & 1) && near_eps == 12345.f) {
+#else
+    if (it >= 1 && w < RT && hh_o == (w & 1)) {
+#endif
+      const int e = NR == 1 ? 0 : (w >> 1);
+      const long long orow = pass_of(it - 1) * RAYS + 64 * e + lane_o;
       if (orow < m) {
-        const float near = (depth && !(dep_out > near_eps)) ? 0.f : 1.f;
+        const float dpo = NR == 1 ? dep_out[0] : (e ? dep_out[NR - 1] : dep_out[0]);
+        const long long so = NR == 1 ? (long long)src_out[0] : (long long)(e ? src_out[NR - 1] : src_out[0]);
+        const float near = (depth && !(dpo > near_eps)) ? 0.f : 1.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int o = (w * 3 + c) * 32 + (lane_o & 31);
-          const float x = ((partt[o] + partt[6 * 32 + o]) + (partt[2 * 6 * 32 + o] + partt[3 * 6 * 32 + o])) + b4[c];
-          out[3 * src_out + c] = expf(fminf(x, exp_max)) * near;
+          const float x = ((partt[o] + partt[3 * RT * 32 + o]) + (partt[2 * 3 * RT * 32 + o] + partt[3 * 3 * RT * 32 + o])) + b4[c];
+          out[3 * so + c] = expf(fminf(x, exp_max)) * near;
         }
       }
     }
@@ -1185,33 +1436,68 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     // ================= steps P1 M2 P2 M3
 #pragma unroll
     for (int layer = 1; layer < 3; ++layer) {
-      il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);   // lands while this wave publishes and waits for its partner
+      // the next layer's first weight fragments: they land while this wave publishes and waits for its partner
+      if constexpr (TERMS == 2) il4_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
+      else il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
+#ifdef IL3_ABLATE_G
+      if (layer == 1 && it + 1 < n_iter && near_eps == 12345.f) {
+#else
       if (layer == 1 && it + 1 < n_iter) {
+#endif
         // the gather step: BEHIND layer 2's weight prefetch and a publish + barrier wait ahead of the first wait that has to see it
         // retired (vmcnt retires in order: a random-row gather -- an HBM round trip -- in front of a matrix phase's weight loads stalls
         // that phase's first counted wait for the whole round trip)
-        gather_dma(src_nxt);
-        if (it + 2 < n_iter) src_nxt = row_src(it + 2, lane_o, idx_o);
+        gather_dma(src_nxt, lane_o);
+        if (it + 2 < n_iter) {
+#pragma unroll
+          for (int e = 0; e < NR; ++e) src_nxt[e] = row_src(it + 2, 64 * e + lane_o, idx_o);
+        }
       }
 #ifndef IL3_ABLATE_P    // dev-only timing ablation: nothing is published
-      il3_publish(actt + lane, T0, acc);
+      if constexpr (TERMS == 2) {
+        il4_publish(actt + lane, T0, held);
+        il4_pack(acc[0], held);
+        il4_publish(actt + lane, T0 + 1, held);
+      } else {
+        il3_publish<TERMS>(actt + lane, T0, acc);
+      }
 #endif
       IL3_STAMP(4 * layer + 1);
       il3_barrier();
       IL3_STAMP(4 * layer + 2);
-      il3_bias(lbias + layer * 512 + hh * 256, T0, acc);
-#ifndef IL3_ABLATE_M
-      il3_layer<16>((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, actt + lane, ring, acc);
+      if constexpr (TERMS == 2) {
+        il3_gw_t Wl = (gw_t)(W + (layer == 1 ? kH2 : kH3) / 4);
+        const float* lb = lbias + layer * 512 + hh * 256;
+        const float* w4h = w4a + hh * 256;
+        il4_half<16, true, 0>(Wl, T0, lane, lb, actt + lane, ring, acc[0]);
+#ifdef IL4_STAMP_HALF
+        if (layer == IL4_STAMP_HALF && it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 7] = __builtin_readcyclecounter();
 #endif
+        if (layer == 1) {
+          il4_pack(acc[0], held);
+        } else {
+#pragma unroll
+          for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) fsum[r][c] = 0.f;
+          il4_out3(w4h, T0, acc[0], fsum);
+        }
+#ifdef IL4_STAMP_HALF
+        if (layer == IL4_STAMP_HALF && it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 8] = __builtin_readcyclecounter();
+#endif
+        il4_half<16, false, 16 % (IL4_PF + 1)>(Wl, T0 + 1, lane, lb, actt + lane, ring, acc[0]);
+        if (layer == 2) il4_out3(w4h, T0 + 1, acc[0], fsum);
+      } else {
+      il3_bias<RT>(lbias + layer * 512 + hh * 256, T0, acc);
+#ifndef IL3_ABLATE_M
+      il3_layer<16, TERMS>((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, actt + lane, ring, acc);
+#endif
+      }
       IL3_STAMP(4 * layer + 3);
       il3_barrier();
       IL3_STAMP(4 * layer + 4);
     }
   }
-#ifdef IL3_STAMPS
-  if (blockIdx.x == 0 && lane == 0 && n_iter > 40)
-    for (int q = 0; q < 16; ++q) g_il3_stamps[wave8 * 16 + q] = st[q];
-#endif
   // `break` above leaves after the FE barrier of the step that has no pass: 6 n_iter + 1 barriers so far for either team
   if (team == 0) { il3_barrier(); il3_barrier(); il3_barrier(); }
 }
@@ -1233,6 +1519,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   precision &= ~TF_WEIGHTS_PACKED;
   const bool ring = (precision & 0x200) != 0;   // dev-only: the slab-ring kernel (kept for A/B timing of the column-owned one)
   precision &= ~0x200;
+  const bool cols_x2 = (precision & 0x400) != 0;   // dev-only: TF_PREC_F16X2 on the column-owned kernel (A/B timing of the staggered 128-ray form)
+  precision &= ~0x400;
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16 || precision == TF_PREC_F16X2, TF_EINVAL,
              "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
@@ -1287,8 +1575,17 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     // staggered two-team kernel: one 512-thread workgroup per CU, two 64-ray passes in flight
     long long blocks = ((m + 63) / 64 + 1) / 2;
     if (blocks > 256) blocks = 256;
-    if (outer) inner_light3_kernel<true><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
-    else inner_light3_kernel<false><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    if (outer) inner_light3_kernel<true, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    else inner_light3_kernel<false, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    TF_LAUNCH_CHECK(who);
+    return TF_OK;
+  }
+  if (precision == TF_PREC_F16X2 && !ring && !cols_x2) {
+    // ... its 128-ray form: two 128-ray passes in flight (source indices are carried as 32-bit values)
+    TF_REQUIRE(m <= 0x7fffffffLL, TF_ESHAPE, "%s: more than 2^31 - 1 rays in one call", who);
+    long long blocks = ((m + 127) / 128 + 1) / 2;
+    if (blocks > 256) blocks = 256;
+    inner_light3_kernel<false, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
     return TF_OK;
   }

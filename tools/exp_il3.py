@@ -50,6 +50,10 @@ if os.environ.get("TF_LIB") or os.environ.get("TF_TIMING_ONLY"):
         st = (C.c_ulonglong * 128)()
         lib.tf_il3_stamps.argtypes = [C.c_void_p]
         lib.tf_il3_stamps(st)
+        print("raw stamps (relative to the earliest stamp 0; index 15 = stamp 0 of the next iteration):")
+        t00 = min(st[wv * 16] for wv in range(8))
+        for wv in range(8):
+            print(f"  wave {wv}: " + " ".join(f"{q}:{(st[wv * 16 + q] - t00) if st[wv * 16 + q] else -1}" for q in range(16)))
         names = ["FE", "w", "M1", "w", "P1", "w", "M2", "w", "P2", "w", "M3", "w"]
         t0 = min(st[wv * 16] for wv in range(8))
         for wv in range(8):
