@@ -77,7 +77,7 @@ def compact_line(line):
                        "vs_baseline", "dtype", "data"))
     cfg = line.get("config", {})
     out["config"] = _pick(cfg, ("workload", "points_per_gpu_per_step", "points_per_shade_call", "mesh_triangles", "hit_fraction",
-                                "live_ray_fraction", "aux_outputs", "parallelism"))
+                                "live_ray_fraction", "inner_light_operands", "aux_outputs", "parallelism"))
     if isinstance(out["config"].get("workload"), str):
         out["config"]["workload"] = out["config"]["workload"][:200]
     if isinstance(line.get("roofline"), dict):
@@ -95,7 +95,7 @@ def compact_line(line):
     for key, fields in (("flow_only", ("points_per_s",)), ("train", ("ms_per_step",)), ("train_dp", ("ms_per_step", "ranks")),
                         ("shape_train", ("ms_per_step",)), ("march", ("rays_per_s", "sdf_alpha_samples_per_s", "algorithmic_frac_of_hbm_peak")),
                         ("config3_flow256", ("points_per_s",)), ("config4_frame512", ("ms_per_frame",)),
-                        ("eval_with_aux_maps", ("points_per_s",))):
+                        ("eval_with_aux_maps", ("points_per_s",)), ("inner_light_f16x3", ("points_per_s",))):
         v = line.get(key)
         if isinstance(v, dict):
             got = _pick(v, fields + ("error",))
@@ -891,7 +891,7 @@ def main():
             # executed matrix-core flop: 336 v_mfma_f32_32x32x16_f16 per 32-ray tile and product term (K padded to 128 / 256)
             terms = {_ops.PREC_F16X3: 3, _ops.PREC_F16X2: 2, _ops.PREC_F16: 1}.get(sh.inner_precision, 3)
             executed = hits / 32.0 * 336 * terms * 2 * 32 * 32 * 16 / (summ[dom][0] * 1e-3) / 1e12 if args.precision == "f16x3" else ach
-            roof = dict(kernel="inner_light3_kernel" if (args.precision == "f16x3" and sh.inner_precision == _ops.PREC_F16X3) else "inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
+            roof = dict(kernel="inner_light3_kernel" if (args.precision == "f16x3" and sh.inner_precision in (_ops.PREC_F16X3, _ops.PREC_F16X2)) else "inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
                         frac=ach / peak, traffic=pmc_traffic("inner_light3_kernel") or pmc_traffic("inner_light2_kernel") or pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         executed_tflops=executed, frac_executed=executed / peak,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
@@ -912,8 +912,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: compressor material stage, MCShadingNetwork eval with flow samplers, "
                                    f"{S} flow samples per lobe + 512 fixed diffuse dirs = {2 * S + 512} secondary rays/point",
-                       "arithmetic": "fp32 end to end at the ABI; every decoder product (flow coupling nets, inner-light MLP, per-point nets) is fp32-grade: "
-                                     + ("exact fp32 MFMA" if args.precision == "f32" else "f16x3 operand split (x = hi + lo, three f16 MFMAs per product term, fp32 accumulate: 22 significant bits per operand) in EVERY decoder, none on plain f16 operands"),
+                       "arithmetic": "fp32 end to end at the ABI; decoder products: "
+                                     + ("exact fp32 MFMA" if args.precision == "f32" else
+                                        "f16x3 operand split (x = hi + lo, three f16 MFMAs per product term, fp32 accumulate) in the flow coupling nets and the per-point nets; inner-light MLP: "
+                                        + {_ops.PREC_F16X3: "f16x3 as well", _ops.PREC_F16X2: "weights split hi + lo, activations rounded to f16 once per layer (f16x2: two MFMAs per product term; per ray inside the fp32 reference's own error against fp64 -- tools/exp_il_precision.py; `inner_light_f16x3` = the same pass with every operand split)",
+                                           _ops.PREC_F16: "plain f16 operands"}.get(sh.inner_precision, "?")),
+                       "inner_light_operands": {_ops.PREC_F16X3: "f16x3", _ops.PREC_F16X2: "f16x2 (weights hi+lo, activations f16 per layer)", _ops.PREC_F16: "f16", _ops.PREC_F32: "f32"}.get(sh.inner_precision if args.precision != "f32" else _ops.PREC_F32, "?"),
                        "points_per_gpu_per_step": pn, "field": "mat R=512 C=36; 2 flows R=512 C=12; env 6x128x128",
                        "points_per_shade_call": chunk,
                        "mesh_triangles": int(len(faces)), "hit_fraction": hit_frac, "live_ray_fraction": live_frac,
@@ -971,6 +975,18 @@ def main():
                 line["config4_fp16"] = fp16_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps), ref_p)
             except Exception as e:
                 line["config4_fp16"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_train and args.precision == "f16x3":
+            # the headline pass with EVERY operand of the inner-light decoder split hi + lo (three MFMAs per product term: rounds 1-3's
+            # arithmetic of that net; round 4's default rounds its activations to f16 once per layer -- MCShader.inner_precision)
+            try:
+                keep_ip = sh.inner_precision
+                sh.inner_precision = _ops.PREC_F16X3
+                line["inner_light_f16x3"] = flow_count_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps))
+                line["inner_light_f16x3"]["workload"] += ", inner-light decoder with activations AND weights split hi + lo (3 MFMAs per product term)"
+            except Exception as e:
+                line["inner_light_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                sh.inner_precision = keep_ip
         if world == 1 and not args.no_train and args.precision == "f16x3":
             # NOT parity-grade arithmetic, reported only: the headline pass with the inner-light decoder alone on plain f16 operands
             # (one MFMA per product term; the flow nets stay f16x3).  Per-pixel error stays inside 1e-4 on the reference goldens

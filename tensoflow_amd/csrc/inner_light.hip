@@ -1072,10 +1072,14 @@ __device__ __forceinline__ void il4_publish(tf_h8* __restrict__ actl /* team ima
     for (int u = 0; u < 2; ++u)
       actl[((2 * T + u) * 4 + r) * 64] = __builtin_bit_cast(tf_h8, __builtin_elementwise_max(__builtin_bit_cast(i16x8, h[r][u]), zero));
 }
-// a half's share of the 256 -> 3 layer (exact fp32 on the vector unit): sum[r][c] += relu(acc[r]) . w4 rows of unit tile T
-__device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 256 */, int T, const f32x16 (&acc)[4], float (&sum)[4][3]) {
+// a half's share of the 256 -> 3 layer (exact fp32 on the vector unit): sum[r][c] += relu(acc[r]) . w4 rows of unit tile T.
+// Packed: the sums are kept as PAIRS (even | odd unit of a register pair), one v_pk_fma_f32 per two products -- 10 instead of 16 vector
+// instructions per ray tile and four units, in a matrix step where every vector instruction is 4 idle cycles of the matrix pipe; the
+// packed operands are ReLU results (v_max), not MFMA results (the hazard of DESIGN 'things the compiler got wrong' 6).
+typedef float il4_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 256 */, int T, const f32x16 (&acc)[4], il4_f2 (&sum)[4][3]) {
 #ifdef IL4_NO_OUT3   // dev-only timing ablation
-  sum[0][0] += acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+  sum[0][0][0] += acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
   return;
 #endif
 #pragma unroll
@@ -1085,10 +1089,12 @@ __device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + 
     for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4h + c * 512 + T * 16 + 4 * qd);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float x0 = tf_relu(acc[r][4 * qd]), x1 = tf_relu(acc[r][4 * qd + 1]);
-      const float x2 = tf_relu(acc[r][4 * qd + 2]), x3 = tf_relu(acc[r][4 * qd + 3]);
+      const il4_f2 xa = {tf_relu(acc[r][4 * qd]), tf_relu(acc[r][4 * qd + 1])}, xb = {tf_relu(acc[r][4 * qd + 2]), tf_relu(acc[r][4 * qd + 3])};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) sum[r][c] = fmaf(x3, wr[c].w, fmaf(x2, wr[c].z, fmaf(x1, wr[c].y, fmaf(x0, wr[c].x, sum[r][c]))));
+      for (int c = 0; c < 3; ++c) {
+        const il4_f2 wa = {wr[c].x, wr[c].y}, wb = {wr[c].z, wr[c].w};
+        sum[r][c] = __builtin_elementwise_fma(xb, wb, __builtin_elementwise_fma(xa, wa, sum[r][c]));
+      }
     }
   }
 }
@@ -1194,7 +1200,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   for (int e = 0; e < NR; ++e) src_nxt[e] = n_iter > 1 ? row_src(1, 64 * e + lane, idx) : 0;
   std::conditional_t<TERMS == 3, Il3Ring, Il4Ring> ring;
   f32x16 acc[TERMS == 3 ? 2 : 1][RT];      // (128-ray form: one unit tile at a time)
-  float fsum[TERMS == 3 ? 1 : RT][3];      // 128-ray form: the wave's share of the 256 -> 3 layer, from step M3 to step FE
+  il4_f2 fsum[TERMS == 3 ? 1 : RT][3];     // 128-ray form: the wave's share of the 256 -> 3 layer (pairs: even | odd units), from step M3 to step FE
   const float b4[3] = {ws_arg[kIB4 + 0], ws_arg[kIB4 + 2], ws_arg[kIB4 + 4]};     // packed order: [n * 2 + half], unit n = reg for n < 4
   __syncthreads();
   // Both teams run the SAME straight-line program; team B passes three barriers before it starts and team A three after it has
@@ -1240,7 +1246,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int c = 0; c < 3; ++c) sum[r][c] = fsum[r][c];
+          for (int c = 0; c < 3; ++c) sum[r][c] = fsum[r][c][0] + fsum[r][c][1];
       } else {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
@@ -1479,7 +1485,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
           for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) fsum[r][c] = 0.f;
+            for (int c = 0; c < 3; ++c) fsum[r][c] = il4_f2{0.f, 0.f};
           il4_out3(w4h, T0, acc[0], fsum);
         }
 #ifdef IL4_STAMP_HALF

@@ -36,7 +36,7 @@ def test_flow_and_inner_light_bitwise_repeatable(dev):
     W = [(wn_weight(sd, f"inner_light.{i}").to(dev), sd[f"inner_light.{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
     g = torch.Generator().manual_seed(2)
     p, v, n = [torch.randn(100_003, 3, generator=g).to(dev) for _ in range(3)]
-    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16):
+    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16X2, ops.PREC_F16):
         _same(lambda: [ops.inner_light(W, p, v, n, precision=prec)])
 
 

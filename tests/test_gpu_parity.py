@@ -323,11 +323,45 @@ def test_inner_light_matches_oracle(golden, dev):
     nrm = torch.randn(m, 3, generator=gen)
     ref = osh.inner_light(g.sd, pts, view, nrm)
     W = [(wn_weight(g.sd, f"inner_light.{i}").to(dev), g.sd[f"inner_light.{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
-    for prec in (ops.PREC_F32, ops.PREC_F16X3):
+    for prec in (ops.PREC_F32, ops.PREC_F16X3, ops.PREC_F16X2):
         got = ops.inner_light(W, pts.to(dev), view.to(dev), nrm.to(dev), precision=prec)
         err = rel_err(got.cpu(), ref)
         print(f"inner_light precision={prec}: max rel err {err:.2e}")
         assert err < TOL
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16x2"])
+def test_inner_light_indexed_ragged_counts(golden, dev, prec):
+    """The staggered kernel's two forms (64-ray passes, f16x3; 128-ray passes, f16x2: MCShader's default) through the hit list:
+    device-side counts around the pass sizes (1 ray ... two workgroups' worth), only the listed rows written, the near mask applied,
+    against the oracle's inner_light on the same rays."""
+    from oracle import shading as osh
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import wn_weight
+    g = golden("shading_small")
+    p = {"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[prec]
+    gen = torch.Generator().manual_seed(7)
+    n = 3000
+    pos = torch.rand(n, 3, generator=gen) * 1.6 - 0.8
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    depth = torch.rand(n, generator=gen) + 0.1
+    depth[::17] = 0.0                                   # below near_eps: the light is masked to 0
+    idx = torch.randperm(n, generator=gen)
+    ref = osh.inner_light(g.sd, pos, -dirs, nrm) * (depth > 1e-5).float()[:, None]
+    W = [(wn_weight(g.sd, f"inner_light.{i}").to(dev), g.sd[f"inner_light.{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
+    args = [t.to(dev) for t in (pos, dirs, nrm)]
+    for m in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1000, 3000):
+        lights = torch.full((n, 3), -7.0, device=dev)
+        count = torch.tensor([m], dtype=torch.int64, device=dev)
+        ops.inner_light_indexed(W, *args, idx.to(dev), count, depth.to(dev), lights, precision=p)
+        got = lights.cpu()
+        sel = idx[:m]
+        rest = torch.ones(n, dtype=torch.bool)
+        rest[sel] = False
+        assert bool((got[rest] == -7.0).all()), m        # rows outside the list are not touched
+        assert rel_err(got[sel], ref[sel]) < TOL, (m, rel_err(got[sel], ref[sel]))
+        assert bool((got[sel][depth[sel] <= 1e-5] == 0).all())
 
 
 def test_point_prep_matches_oracle(golden, dev):
