@@ -40,7 +40,8 @@ typedef enum TfStatus {
  * TF_PREC_F16: plain f16 operands (the hi halves only), fp32 accumulate -- one MFMA per product term; in the flow nets NOT
  * within the 1e-4 parity bar (BASELINE configs[4] "fp16 field + flow": reported with its PSNR against the fp32-accurate path).
  * Accepted by tf_flow_sample_fwd / tf_flow_logq_fwd and tf_inner_light_fwd / tf_inner_light_indexed_fwd; others reject it.
- * TF_PREC_F16X2 (inner-light net only): weights split hi + lo, activations rounded to f16 once per layer (w_hi x + w_lo x). */
+ * TF_PREC_F16X2 (inner-light net only): weights split hi + lo, activations rounded to f16 once per layer (w_hi x + w_lo x): per ray
+ * inside the error of fp32 PyTorch against fp64; runs on the 128-ray form of the staggered kernel. */
 typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1, TF_PREC_F16 = 2, TF_PREC_F16X2 = 3 } TfPrecision;
 /* OR-ed into a `precision` argument: `workspace` still holds this network's packed weights from an earlier call with
  * the same weights and precision (the caller tracks weight updates), so the fragment re-pack launches are skipped. */
