@@ -691,13 +691,16 @@ class ShapeShadingNetwork(nn.Module):
         import os
         from ..synth import synthetic_fg_lut
         self.cfg = {**self.default_cfg, **cfg}
-        if self.cfg["human_light"] or self.cfg["sphere_direction"] or self.cfg["mat_pos_multires"] >= 0:
-            raise NotImplementedError("ShapeShadingNetwork: human_light=False, sphere_direction=False, mat_pos_multires=-1 (what every shipped configs/shape file sets); "
-                                      "the material stage builds the human-light / sphere_direction variants (MCShadingNetwork)")
+        # Variants no shipped configs/shape file sets (human_light / sphere_direction / mat_pos_multires >= 0, fields.py:344,354-357,
+        # 367-370,394-404): built as the reference builds them and evaluated by the differentiable composition below in every mode --
+        # the one-launch inference kernel instantiates the default (mat_mlp on the 128 features alone, no capturer reflection).
+        mp = int(self.cfg["mat_pos_multires"])
+        self._mat_pos_dim = 0 if mp < 0 else 3 if mp == 0 else 3 + 6 * mp
+        self._composed_only = bool(self.cfg["human_light"]) or self._mat_pos_dim > 0
         fd, em = self.cfg["app_feats_dim"], self.cfg["light_exp_max"]
         if self.cfg["has_radiance_field"]:
             self.rad_mlp = _predictor3(fd + 3 + 27 + 3, 3, nn.Sigmoid())      # pos_multires=0 (raw xyz), dir_multires=4
-        self.mat_mlp = _predictor3(fd, 5, nn.Sigmoid())
+        self.mat_mlp = _predictor3(fd + self._mat_pos_dim, 5, nn.Sigmoid())
         path = self.cfg["fg_lut_path"]
         if path and os.path.exists(path):
             lut = torch.from_numpy(np.fromfile(path, dtype=np.float32).reshape(1, 256, 256, 2))
@@ -705,13 +708,17 @@ class ShapeShadingNetwork(nn.Module):
             lut = synthetic_fg_lut()
         self.register_buffer("FG_LUT", lut)
         pos_dim = 3 + 6 * self.cfg["light_pos_freq"]
-        self.outer_light = _predictor3(72, 3, _Exp(em))      # present in reference checkpoints, unused by forward (fields.py:428)
+        # present in reference checkpoints, unused by forward (fields.py:428); 'sphere_direction' doubles its input (:354-357)
+        self.outer_light = _predictor3(144 if self.cfg["sphere_direction"] else 72, 3, _Exp(em))
         nn.init.constant_(self.outer_light[-2].bias, np.log(0.5))
         self.envlight = EnvLight(trainable=True, max_res=128, device=device)
         self.inner_light = _predictor3(pos_dim + 72, 3, _Exp(em))
         nn.init.constant_(self.inner_light[-2].bias, np.log(0.5))
         self.inner_weight = _predictor3(pos_dim + 39, 1, nn.Identity())
         nn.init.constant_(self.inner_weight[-2].bias, self.cfg["inner_init"])
+        if self.cfg["human_light"]:      # the light reflected from the photo capturer (fields.py:367-370): IPE(2 x 2 x 6) -> 4, exp(min(., 0))
+            self.human_light_predictor = _predictor3(24, 4, _Exp(0.0))
+            nn.init.constant_(self.human_light_predictor[-2].bias, np.log(0.01))
         self.to(device)
         self._op, self._op_version = None, None
 
@@ -751,7 +758,36 @@ class ShapeShadingNetwork(nn.Module):
         return normals, F.normalize(view_dirs, dim=-1)
 
     # ------------------------------------------------------------------ differentiable composition
-    def _composed(self, points, normals, view_dirs, feat, inter_results, want_rad=False):
+    def _mat_input(self, points, feat):
+        """fields.py:488-494: the material net's input -- the features, with mat_pos_multires >= 0 the (embedded) position behind them."""
+        if self._mat_pos_dim == 0:
+            return feat
+        from ..encodings import posenc
+        mp = int(self.cfg["mat_pos_multires"])
+        return torch.cat([feat, points if mp == 0 else posenc(points, mp)], -1)
+
+    def predict_human_light(self, points, reflective, human_poses, roughness):
+        """fields.py:377-392 with get_camera_plane_intersection (utils/network_utils.py:69-88) and IPE (:56-61: E[sin] of a Gaussian
+        with mean 2^k m and variance 4^k v) -> (human_lights [N,3], human_weights [N,1])."""
+        R, t = human_poses[:, :, :3], human_poses[:, :, 3]
+        p_ = torch.einsum("nij,nj->ni", R, points) + t
+        d_ = torch.einsum("nij,nj->ni", R, reflective)
+        hits = d_[:, 2].abs() > 1e-4
+        dz = torch.where(hits, d_[:, 2], torch.full_like(d_[:, 2], 1e-4))     # (the reference writes 1e-4 through a view of dirs_)
+        d_ = torch.cat([d_[:, :2], dz[:, None]], -1)
+        dist = -p_[:, 2] / dz
+        mean = (p_ + dist[:, None] * d_)[:, :2] * 0.3
+        var = roughness * (dist[:, None] * 0.3) ** 2
+        hits = (hits & (mean.norm(dim=-1) < 1.5) & (dist > 0)).float()[:, None]
+        mean, var = mean * hits, (var * hits).expand(-1, 2)
+        sc = 2.0 ** torch.arange(6, device=mean.device)
+        sm = (mean[:, None, :] * sc[:, None]).reshape(-1, 12)
+        sv = (var[:, None, :] * (sc ** 2)[:, None]).reshape(-1, 12)
+        pe = torch.exp(-0.5 * torch.cat([sv, sv], -1)) * torch.sin(torch.cat([sm, sm + 0.5 * math.pi], -1))
+        h = _mlp(self.human_light_predictor, pe) * hits
+        return h[:, :3], h[:, 3:].clamp(0.0, 1.0)
+
+    def _composed(self, points, normals, view_dirs, feat, inter_results, want_rad=False, human_poses=None):
         from ..encodings import ide5, linear_to_srgb, posenc
         env = self.envlight
         if not hasattr(env, "specular"):
@@ -759,7 +795,7 @@ class ShapeShadingNetwork(nn.Module):
         normals, view_dirs = self._unit_inputs(normals, view_dirs)
         NoV = (normals * view_dirs).sum(-1, keepdim=True)
         reflective = NoV * normals * 2 - view_dirs
-        mat = _mlp(self.mat_mlp, feat)
+        mat = _mlp(self.mat_mlp, self._mat_input(points, feat))
         albedo, roughness, metallic = mat[..., :3] * 0.77 + 0.03, mat[..., 3:4] * 0.9 + 0.09, mat[..., 4:]
         diffuse_albedo = (1 - metallic) * albedo
         diffuse_light = env(normals)
@@ -770,7 +806,15 @@ class ShapeShadingNetwork(nn.Module):
         indirect_light = _mlp(self.inner_light, torch.cat([pts, ide5(reflective, roughness)], -1))
         occ_prob = _mlp(self.inner_weight, torch.cat([pts.detach(), posenc(reflective, 6).detach()], -1)) * 0.5 + 0.5
         occ = occ_prob.clamp(0, 1)
-        specular_light = indirect_light * occ + direct_light * (1 - occ)
+        if self.cfg["human_light"]:
+            if human_poses is None:
+                raise ValueError("ShapeShadingNetwork(human_light=True): forward() needs the per-sample human_poses [N,3,4]")
+            hl, hw = self.predict_human_light(points, reflective, human_poses, roughness)
+            human = hl * hw
+            specular_light = indirect_light * occ + (human + direct_light * (1 - hw)) * (1 - occ)
+        else:
+            human = None
+            specular_light = indirect_light * occ + direct_light * (1 - occ)
         # FG LUT: dr.texture(filter_mode='linear', boundary_mode='clamp'), texel centres at (i + .5) / n
         uv = torch.cat([NoV.clamp(0, 1), roughness.clamp(0, 1)], -1)
         lut = self.FG_LUT.reshape(self.FG_LUT.shape[-3], self.FG_LUT.shape[-2], 2).permute(2, 0, 1)[None]
@@ -787,6 +831,8 @@ class ShapeShadingNetwork(nn.Module):
                  "diffuse_albedo": diffuse_albedo, "diffuse_light": c01(linear_to_srgb(diffuse_light)),
                  "diffuse_color": c01(linear_to_srgb(diffuse_color)), "metallic": metallic, "roughness": roughness, "albedo": albedo,
                  "occ_prob": c01(occ_prob), "indirect_light": indirect_light * occ}
+        if human is not None:
+            inter["human_light"] = linear_to_srgb(human)
         return color, occ_info, inter
 
     def forward(self, points, normals, view_dirs, feature_vectors, human_poses=None, inter_results=False, step=None):
@@ -798,13 +844,13 @@ class ShapeShadingNetwork(nn.Module):
             return (z(3), occ_info, {}) if inter_results else (z(3), z(3) if want_rad else None, occ_info)
         needs_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or normals.requires_grad
                                                    or feature_vectors.requires_grad)
-        if needs_graph or inter_results:
-            return self._composed(points, normals, view_dirs, feature_vectors, inter_results, want_rad)
+        if needs_graph or inter_results or self._composed_only:
+            return self._composed(points, normals, view_dirs, feature_vectors, inter_results, want_rad, human_poses)
         color, occ_prob, roughness, reflective = self._fused()(points, normals, view_dirs, feature_vectors)
         rad = self._radiance(points, *self._unit_inputs(normals, view_dirs), feature_vectors) if want_rad else None
         return color, rad, {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
 
     def predict_materials(self, points, feature_vectors):
         """fields.py:569-575: raw mat_mlp outputs (no albedo / roughness remapping, as in the reference)."""
-        mat = _mlp(self.mat_mlp, feature_vectors)
+        mat = _mlp(self.mat_mlp, self._mat_input(points, feature_vectors))
         return mat[..., 4:], mat[..., 3:4], mat[..., :3]

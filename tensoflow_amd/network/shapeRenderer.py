@@ -265,7 +265,9 @@ class ShapeRenderer(nn.Module):
         levels = torch.log2(self.compute_ball_radii(mid[:, None], radiis[ray_indices], rays_cos[ray_indices]) / self.base_radii)
         alpha, gradients, feat, inv_s, sdf, hessian = self.compute_sdf_alpha(points, levels, dists, viewdir, cos_anneal_ratio, step, is_train)
         normals = F.normalize(gradients, dim=-1)
-        color, radiance, occ_info = self.color_network(points, normals, -viewdir, feat, None, step=step)
+        # (per-sample capturer poses, shapeRenderer.py:1139: read by the human_light variant of the shading only)
+        poses_pt = human_poses[ray_indices] if (human_poses is not None and self.color_network.cfg["human_light"]) else None
+        color, radiance, occ_info = self.color_network(points, normals, -viewdir, feat, poses_pt, step=step)
         gradient_error = (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2
         zero = torch.zeros(1, device=rays_o.device)
         vals = [color, gradients] + ([radiance, occ_info["roughness"]] if radiance is not None else [])
@@ -301,7 +303,7 @@ class ShapeRenderer(nn.Module):
         if step is not None and step < 1000:
             outputs["sdf_pts"], outputs["sdf_vals"] = (points, sdf) if N > 0 else (zero, zero)
         if not is_train:
-            outputs.update(self._validation_outputs(rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step))
+            outputs.update(self._validation_outputs(rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step, human_poses))
         return outputs
 
     @torch.no_grad()
@@ -338,7 +340,7 @@ class ShapeRenderer(nn.Module):
         return F.l1_loss(occ_info["occ_prob"].index_select(0, idx), gt)      # (index_select: its backward is an atomic index_add, not the sort of x[idx])
 
     @torch.no_grad()
-    def _validation_outputs(self, rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step):
+    def _validation_outputs(self, rays_o, viewdirs, radiis, rays_cos, ray_indices, mid, weights, acc, normal, step, human_poses=None):
         """Eval branch of render_core (shapeRenderer.py:1239-1275): expected depth -> surface point -> materials / lights there,
         traced occlusion probability along the reflected direction (get_intersection, utils/network_utils.py:172-202)."""
         rn = rays_o.shape[0]
@@ -352,7 +354,8 @@ class ShapeRenderer(nn.Module):
         if not self.cfg["nerfDataType"]:
             out["normal_vis"] = ((normals + 1.0) * 0.5) * inner
         feat = self.sdf_network(points.contiguous(), level.reshape(-1).contiguous())[..., 1:]
-        _, occ_info, inter = self.color_network(points, normals, -viewdirs, feat.contiguous(), None, inter_results=True, step=step)
+        poses = human_poses if (human_poses is not None and self.color_network.cfg["human_light"]) else None
+        _, occ_info, inter = self.color_network(points, normals, -viewdirs, feat.contiguous(), poses, inter_results=True, step=step)
         # traced occlusion along the reflected ray: 128 uniform + 9 importance field evaluations per pixel
         occ_gt = self._traced_occlusion(points, occ_info["reflective"], 128, 9)
         out["occ_prob_gt"] = occ_gt
@@ -473,7 +476,7 @@ class ShapeRenderer(nn.Module):
         batch, rn, h, w = construct_ray_batch_nerf(info, device=self.device, is_train=False)
         keys = ["ray_rgb", "gradient_error", "depth", "acc", "normal_vis", "diffuse_albedo", "diffuse_light", "diffuse_color",
                 "specular_albedo", "specular_light", "specular_color", "specular_ref", "specular_direct_light", "metallic",
-                "roughness", "occ_prob", "indirect_light", "occ_prob_gt", "radiance", "roughness_weights"]
+                "roughness", "occ_prob", "indirect_light", "occ_prob_gt", "radiance", "roughness_weights", "human_light"]
         outputs = {}
         trn = self.cfg["test_ray_num"]
         for ri in range(0, rn, trn):

@@ -478,3 +478,47 @@ def test_config5_frame_crop_512_flow_samples_f16_mode(golden, dev):
           f"max {float(err.max()):.2e}, PSNR {psnr(got, ref):.1f} dB, {int((err > 1e-4).sum())} beyond 1e-4")
     assert p16 > 60.0 and not torch.equal(f16, f32g)
     assert psnr(got, ref) > 80.0 and float((err <= 1e-4).float().mean()) >= 0.95 and float(err.max()) < 3e-3
+
+
+def test_shape_shading_variants_golden(golden, dev):
+    """ShapeShadingNetwork with the switches no shipped configs/shape file sets -- human_light (the capturer's reflection: camera-plane
+    intersection, IPE with the roughness as variance, a 24 -> 4 net), sphere_direction (144-input outer net: state-dict shape only) and
+    mat_pos_multires = 4 (/root/reference/network/fields.py:344,354-357,367-370,377-392,394-404,420-439) -- against the reference's own
+    forward (both forms), predict_materials and the gradients of a weighted colour sum (golden `shape_variants`, tools/gen_golden.py)."""
+    from tensoflow_amd.network.fields import ShapeShadingNetwork
+    g = golden("shape_variants")
+    cn = ShapeShadingNetwork(dict(human_light=True, sphere_direction=True, mat_pos_multires=4), device=dev)
+    missing, unexpected = cn.load_state_dict(g.sd, strict=False)
+    assert not unexpected and all("FG_LUT" in k or "envlight.base" in k for k in missing), (missing, unexpected)
+    cn.envlight.specular = [g[f"env_spec{i}"].to(dev) for i in range(3)]
+    cn.envlight.diffuse = g["env_diffuse"].to(dev)
+    cn.FG_LUT = g["fg_lut"].to(dev)
+    c = lambda k: g[k].to(dev)
+    assert float(g["frac_human_hits"]) > 0.2                      # the capturer's reflection is exercised, not masked away
+    with torch.no_grad():
+        col, none, occ = cn(c("pts"), c("normals"), c("view_dirs"), c("feat"), c("human_poses"), step=100)
+        col2, occ2, inter = cn(c("pts"), c("normals"), c("view_dirs"), c("feat"), c("human_poses"), inter_results=True, step=100)
+        met, rough, alb = cn.predict_materials(c("pts"), c("feat"))
+    assert none is None
+    assert rel_err(col.cpu(), g["color"]) < TOL and rel_err(col2.cpu(), g["color"]) < TOL
+    for k in ("occ_prob", "roughness", "reflective"):
+        assert rel_err(occ[k].cpu(), g[k]) < TOL, k
+    assert set(inter) == {k[6:] for k in g.a if k.startswith("inter/")}
+    for k, v in inter.items():
+        assert rel_err(v.cpu(), g["inter/" + k]) < TOL, k
+    assert rel_err(met.cpu(), g["pm_metallic"]) < TOL and rel_err(rough.cpu(), g["pm_roughness"]) < TOL and rel_err(alb.cpu(), g["pm_albedo"]) < TOL
+    # gradients: parameters of every net the forward reaches (the outer net gets none, as in the reference), normals, features
+    cn.zero_grad()
+    nr, ft = c("normals").requires_grad_(True), c("feat").requires_grad_(True)
+    col, _, occ = cn(c("pts"), nr, c("view_dirs"), ft, c("human_poses"), step=100)
+    ((col * c("bwd_w")).sum() + occ["occ_prob"].sum()).backward()
+    got = {k: p.grad for k, p in cn.named_parameters() if p.grad is not None and "envlight" not in k}
+    want = g.grad
+    assert set(got) == set(want), (sorted(set(got) ^ set(want)))
+    sc_err = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))     # of the tensor's scale
+    for k in want:
+        assert sc_err(got[k].cpu(), want[k]) < 2e-4, (k, sc_err(got[k].cpu(), want[k]))
+    assert sc_err(nr.grad.cpu(), g["g_normals"]) < 2e-4 and sc_err(ft.grad.cpu(), g["g_feat"]) < 2e-4
+    # without the poses the human-light variant refuses (the reference would fail inside get_camera_plane_intersection)
+    with pytest.raises(ValueError):
+        cn(c("pts"), c("normals"), c("view_dirs"), c("feat"), None, step=100)

@@ -909,6 +909,50 @@ def gen_shading_custom():
     save("shading_custom", sd=changed, **arr)
 
 
+def gen_shape_variants():
+    """ShapeShadingNetwork.forward with the switches no shipped configs/shape file sets (fields.py:344,354-357,367-370,377-392,
+    394-404,420-439): human_light (the capturer's reflection through IPE + a 24 -> 4 net), sphere_direction (144-input outer net:
+    state-dict shape only, forward never calls it) and mat_pos_multires = 4 (embedded position behind the features of mat_mlp):
+    both forms of forward (colour / intermediate dict) and the gradients of a weighted colour sum."""
+    from network.fields import ShapeShadingNetwork
+    torch.manual_seed(4417)
+    cn = ShapeShadingNetwork(dict(human_light=True, sphere_direction=True, mat_pos_multires=4))
+    perturb_([p for n, p in cn.named_parameters() if "original1" in n], 0.05, 11)
+    g = torch.Generator().manual_seed(23)
+    spec = [0.5 * torch.randn(6, s, s, 3, generator=g) - 0.7 for s in (16, 8, 4)]
+    diff = 0.5 * torch.randn(6, 4, 4, 3, generator=g) - 0.7
+    cn.envlight.specular, cn.envlight.diffuse = spec, diff
+    u = torch.linspace(0, 1, 32)
+    lut = torch.stack(torch.meshgrid(u, u, indexing="ij"), -1)
+    cn.FG_LUT = torch.stack([0.9 * (1 - lut[..., 1]) * lut[..., 0] + 0.05, 0.1 * (1 - lut[..., 0]) ** 2], -1)[None].contiguous()
+    n = 300
+    pts = torch.rand(n, 3, generator=g) * 1.6 - 0.8
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    view = torch.nn.functional.normalize(nrm + 0.8 * torch.randn(n, 3, generator=g), dim=-1)
+    feat = 0.5 * torch.randn(n, 128, generator=g)
+    # capturer poses: random rotations, the camera plane 1.5-3 units away (a good share of the reflected rays reach it inside |m| < 1.5)
+    q, _ = torch.linalg.qr(torch.randn(n, 3, 3, generator=g))
+    poses = torch.cat([q, (torch.rand(n, 3, 1, generator=g) * 2 - 1) * torch.tensor([0.5, 0.5, 3.0])[None, :, None]], -1).contiguous()
+    arr = dict(pts=pts, normals=nrm, view_dirs=view, feat=feat, human_poses=poses)
+    with torch.no_grad():
+        col, none, occ = cn(pts, nrm.clone(), view, feat, poses, step=100)
+        assert none is None
+        col2, occ2, inter = cn(pts, nrm.clone(), view, feat, poses, inter_results=True, step=100)
+        met, rough, alb = cn.predict_materials(pts, feat)
+    arr.update(color=col, occ_prob=occ["occ_prob"], roughness=occ["roughness"], reflective=occ["reflective"],
+               pm_metallic=met, pm_roughness=rough, pm_albedo=alb, **{"inter/" + k: v for k, v in inter.items()})
+    arr["frac_human_hits"] = (inter["human_light"].abs().sum(-1) > 0).float().mean()
+    w = torch.rand(n, 3, generator=g)
+    cn.zero_grad()
+    nr, ft = nrm.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    col, _, occ = cn(pts, nr, view, ft, poses, step=100)
+    ((col * w).sum() + occ["occ_prob"].sum()).backward()
+    grads = {"grad/" + k: p.grad for k, p in cn.named_parameters() if p.grad is not None and "envlight" not in k}
+    sd = {k: v for k, v in cn.state_dict().items() if "FG_LUT" not in k and "envlight.base" not in k}
+    save("shape_variants", sd=sd, bwd_w=w, g_normals=nr.grad, g_feat=ft.grad, fg_lut=cn.FG_LUT, env_diffuse=diff, env_spec0=spec[0],
+         env_spec1=spec[1], env_spec2=spec[2], **arr, **grads)
+
+
 def gen_march_grad():
     """Geometry-only training direction of the ray-march: loss over compute_sdf_alpha + nerfacc compositing outputs
     (shapeRenderer.py:995-1025, :1166-1206); gradients of the SDF field, decoder and variance from the reference autograd."""
@@ -1072,7 +1116,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
