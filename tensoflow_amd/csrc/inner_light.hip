@@ -1377,10 +1377,21 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           float e12[12];
           const bool small = __all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f);
 #pragma unroll
-          for (int i = 0; i < 6; ++i) {
+          for (int i = 0; i < (TERMS == 2 ? 3 : 6); ++i) {
             const float arg = p[i % 3] * (float)(1 << (i / 3)) * (w == 0 ? 1.f : w == 1 ? 4.f : w == 2 ? 16.f : 64.f);   // exact: powers of two
             if (small) tf_sincos_small(arg, e12[2 * i], e12[2 * i + 1]);
             else tf_sincos(arg, e12[2 * i], e12[2 * i + 1]);
+          }
+          if constexpr (TERMS == 2) {
+            // the wave's second octave by angle doubling from the first (these operands are rounded to f16, 2^-12, on their way into
+            // the matrix cores; the doubled pair is within 3e-7 of a range-reduced evaluation): 3 instead of 6 range reductions and
+            // polynomial pairs per ray, in the longest vector step of the cycle
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const float sn = e12[2 * i], cs = e12[2 * i + 1];
+              e12[2 * (i + 3)] = 2.f * sn * cs;
+              e12[2 * (i + 3) + 1] = fmaf(-2.f * sn, sn, 1.f);
+            }
           }
 #pragma unroll
           for (int gq = 0; gq < 3; ++gq)
