@@ -1268,6 +1268,17 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           }
         }
       }
+      if constexpr (TERMS == 2) {
+        // the two lane halves hold different units of the same ray.  Two sums per v_permlane32_swap: afterwards one register holds
+        // {a's lanes 0..31 | b's lanes 0..31}, the other {a's 32..63 | b's 32..63}; their sum is a's total in lanes 0..31 and b's in
+        // lanes 32..63, and all 64 lanes store (rows k, k + 1 of `part` are contiguous) -- no cross-lane read through the LDS pipe,
+        // half the stores, in the longest vector step of the cycle
+#pragma unroll
+        for (int k = 0; k < 3 * RT; k += 2) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[k / 3][k % 3]), __float_as_uint(sum[(k + 1) / 3][(k + 1) % 3]), false, false);
+          partt[(w * 3 * RT + k) * 32 + lane_o] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -1275,6 +1286,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           const float tot = sum[r][c] + __shfl_xor(sum[r][c], 32);         // the two lane halves hold different units of the same ray
           if (hh_o == 0) partt[(w * 3 * RT + r * 3 + c) * 32 + (lane_o & 31)] = tot;
         }
+      }
 #pragma unroll
       for (int e = 0; e < NR; ++e) src_out[e] = src_cur[e];
     }
