@@ -781,12 +781,9 @@ extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out
 //     Every lane stands for two rays of the pass (ray 64 e + lane, e = 0, 1) in the vector steps.
 template <int TERMS>
 struct IL3 {
-#ifndef IL3_RT2
-#define IL3_RT2 4
-#endif
-  static constexpr int RT = TERMS == 3 ? 2 : IL3_RT2;      // ray tiles per team pass
+  static constexpr int RT = TERMS == 3 ? 2 : 4;      // ray tiles per team pass
   static constexpr int XP = TERMS == 3 ? 2 : 1;      // activation planes (hi | lo)
-  static constexpr int NR = (RT + 1) / 2;            // rays per lane in the vector steps
+  static constexpr int NR = RT / 2;                  // rays per lane in the vector steps
   static constexpr int RAYS = 32 * RT;               // rays per team pass
   static constexpr int TEAM16 = 16 * RT * XP * 64;   // 16-byte units of one team's activation image (64 KB in both forms)
   static constexpr int STAGE = 3 * RAYS * 4 + RAYS;  // floats of one team's input stage: hit point | normal | direction rows (16 B each) | depths
@@ -987,34 +984,6 @@ __device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, 
     const float4 v4 = *reinterpret_cast<const float4*>(lb + T * 16 + 4 * qd);
     bv[4 * qd] = v4.x; bv[4 * qd + 1] = v4.y; bv[4 * qd + 2] = v4.z; bv[4 * qd + 3] = v4.w;
   }
-#ifdef IL4_BQ1
-  // activation fragments NOT double buffered: ray tile r's fragment of k-step s + 1 is requested right behind the two MFMAs that read
-  // its fragment of k-step s (an MFMA has taken its operands when the next instruction issues) -- six MFMAs ahead of its first use
-  tf_h8 bq[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bq[r] = actl[r * 64];
-#pragma unroll
-  for (int s = 0; s < K16; ++s) {
-    if (s + PF < K16 || NEXT) {
-      il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
-#pragma unroll
-      for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][0], bq[r], s == 0 ? bv : acc[r]);
-      acc[r] = tf_mfma_h(ring.a[(S0 + s) % (PF + 1)][1], bq[r], acc[r]);
-      if (s + 1 < K16) bq[r] = actl[((s + 1) * 4 + r) * 64];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM reads (k-step s + PF)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#else
   tf_h8 bq[2][4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bq[0][r] = actl[r * 64];
@@ -1025,7 +994,6 @@ __device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, 
       il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, 0, s + PF) : il3_kstep_base(Wl, 0, s + PF - K16);
 #else
       il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
-#endif
 #pragma unroll
       for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
     }
@@ -1078,10 +1046,6 @@ __device__ __forceinline__ void il4_publish(tf_h8* __restrict__ actl /* team ima
 // packed operands are ReLU results (v_max), not MFMA results (the hazard of DESIGN 'things the compiler got wrong' 6).
 typedef float il4_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 256 */, int T, const f32x16 (&acc)[4], il4_f2 (&sum)[4][3]) {
-#ifdef IL4_NO_OUT3   // dev-only timing ablation
-  sum[0][0][0] += acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
-  return;
-#endif
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     float4 wr[3];
@@ -1305,11 +1269,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
       if (live) {
         // (128-ray form: the two rays of a lane one after the other in a loop that is NOT unrolled -- the store addresses of a ray are
         // its slot + compile-time constants either way, and the step's registers and code stay those of one ray)
-#ifdef IL3_E_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
         for (int e = 0; e < NR; ++e) {
         const int q_o = 64 * e + lane_o;
         // this pass's input rows of the lane's ray: from the team's stage (sent there by LDS-DMA during the previous pass)
@@ -1439,11 +1399,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     }
     // wave w stores ray tile w of the pass (128-ray form: all four waves; 64-ray form: waves 0, 1): the lanes of half w & 1 hold
     // that tile's source indices (ray 64 (w >> 1) + lane)
-#ifdef IL3_ABLATE_O
-    if (it >= 1 && w < RT && hh_o == (w & 1) && near_eps == 12345.f) {
-#else
     if (it >= 1 && w < RT && hh_o == (w & 1)) {
-#endif
       const int e = NR == 1 ? 0 : (w >> 1);
       const long long orow = pass_of(it - 1) * RAYS + 64 * e + lane_o;
       if (orow < m) {
@@ -1468,11 +1424,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
       // the next layer's first weight fragments: they land while this wave publishes and waits for its partner
       if constexpr (TERMS == 2) il4_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
       else il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
-#ifdef IL3_ABLATE_G
-      if (layer == 1 && it + 1 < n_iter && near_eps == 12345.f) {
-#else
       if (layer == 1 && it + 1 < n_iter) {
-#endif
         // the gather step: BEHIND layer 2's weight prefetch and a publish + barrier wait ahead of the first wait that has to see it
         // retired (vmcnt retires in order: a random-row gather -- an HBM round trip -- in front of a matrix phase's weight loads stalls
         // that phase's first counted wait for the whole round trip)
