@@ -21,11 +21,25 @@ dirs = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g),
 nrm = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1)
 depth = torch.rand(n, device=dev, generator=g) + 0.1
 idx = torch.randperm(n, device=dev, generator=g)
+if os.environ.get("IL_SPARSE"):
+    # the bench's access pattern: the hit list is SORTED and covers ~15 % of the rows of much larger ray arrays (IL_SPARSE = density)
+    dens = float(os.environ["IL_SPARSE"])
+    n_all = int(n / dens)
+    pos = (torch.rand(n_all, 3, device=dev, generator=g) * 2 - 1) * 0.8
+    dirs = torch.nn.functional.normalize(torch.randn(n_all, 3, device=dev, generator=g), dim=-1)
+    nrm = torch.nn.functional.normalize(torch.randn(n_all, 3, device=dev, generator=g), dim=-1)
+    depth = torch.rand(n_all, device=dev, generator=g) + 0.1
+    idx = torch.nonzero(torch.rand(n_all, device=dev, generator=g) < dens)[:, 0].contiguous()
+    n = int(idx.numel())
+    print(f"sparse sorted hit list: {n} of {n_all} rows")
+    n_rows = n_all
+else:
+    n_rows = n
 count = torch.tensor([n], dtype=torch.int64, device=dev)
 res = {}
 for p in precs:
     cache = ops.PackCache()
-    lights = torch.zeros(n, 3, device=dev)
+    lights = torch.zeros(n_rows, 3, device=dev)
     for _ in range(2):
         ops.inner_light_indexed(W, pos, dirs, nrm, idx, count, depth, lights, precision=p, cache=cache)
     torch.cuda.synchronize()
