@@ -381,6 +381,14 @@ int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, const float*
                                const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
                                float near_eps, float exp_max, int32_t precision, float* lights, float* workspace,
                                size_t workspace_floats, tf_stream_t stream);
+/* The same in a TRAINING step (what autograd keeps of get_inner_lights, fields.py:905-911, for the backward pass of its four Linear
+ * layers): besides `lights`, the post-ReLU activations of the three hidden layers, acts[3][capacity][256] fp32, row r = the ray
+ * idx[r] (rows >= *count_dev are not written).  tf_linear_bwd reads them as the saved inputs / outputs of the layers instead of
+ * recomputing the net with the dense-layer kernels.  precision: TF_PREC_F16X3 (| TF_WEIGHTS_PACKED) only. */
+int tf_inner_light_indexed_train_fwd(const TfMlp4* net, const float* pos, const float* dirs, const float* nrm,
+                                     const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
+                                     float near_eps, float exp_max, int32_t precision, float* lights, float* acts,
+                                     float* workspace, size_t workspace_floats, tf_stream_t stream);
 /* MCShadingNetwork.predict_outer_lights with outer_light_version = 'direction' (network/fields.py:913-916, the net built at
  * :716-718: make_predictor_4layer(72, 3, 'exp', light_exp_max); configs/mat/syn/{lego,armadillo,horse}.yaml) for the rays that MISSED
  * the mesh (get_lights :962-968): lights[i] = exp(min(net(IDE5(dirs[i], roughness 0)), exp_max)) for i = idx[r], r < *count_dev.

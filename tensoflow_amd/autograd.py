@@ -153,20 +153,30 @@ class LightsFn(torch.autograd.Function):
             ops.outer_light_indexed(ow, dirs, idx_m, count_m, lights, exp_max=outer_exp_max)      # near mask of a miss: 1
         idx, count = ops.compact_mask(hit.view(torch.uint8))
         weights = [(inner_wb[2 * l].detach(), inner_wb[2 * l + 1].detach()) for l in range(4)]
-        ops.inner_light_indexed(weights, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=exp_max, precision=precision)
+        # the hidden layers' activations come out of the fused forward (fp32-grade operand split) when a backward pass will want them:
+        # LightsFn.backward then differentiates the dense layers on them instead of recomputing three 256-wide layers first
+        acts = None
+        if precision == ops.PREC_F16X3 and any(ctx.needs_input_grad[9:17]):
+            acts = torch.empty(3, idx.numel(), 256, device=dirs.device)
+        ops.inner_light_indexed(weights, inters, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=exp_max, precision=precision, acts=acts)
         ctx.has_env = env_base is not None
+        ctx.acts = acts
         ctx.save_for_backward(env_base if ctx.has_env else idx_m, dirs, inters, nrm, depth, hit, idx, count, count_m if not ctx.has_env else count, *wb)
         ctx.exp_max, ctx.outer_exp_max = exp_max, outer_exp_max
         ctx.mark_non_differentiable(hit)
         return lights, hit
 
     @staticmethod
-    def _net_bwd(X, gsel, ws, count, exp_max):
-        """Recompute the four layers on X and differentiate them (HIP dense-layer kernels): -> 8 gradients (weight, bias per layer).
-        The row count stays on the device (`count`): launches are sized for the capacity and clamp to it in-kernel -- no host sync."""
+    def _net_bwd(X, gsel, ws, count, exp_max, hidden=None):
+        """Differentiate the four layers on X (HIP dense-layer kernels): -> 8 gradients (weight, bias per layer).  `hidden` [3, cap, 256]:
+        the hidden activations the fused forward saved; None: the four layers are recomputed first.  The row count stays on the device
+        (`count`): launches are sized for the capacity and clamp to it in-kernel -- no host sync."""
         acts = [ops.ACT_RELU, ops.ACT_RELU, ops.ACT_RELU, ops.ACT_EXP_CLAMP]
         hs = [X]
         for l in range(4):
+            if hidden is not None and l < 3:
+                hs.append(hidden[l])
+                continue
             hs.append(ops.linear_fwd(hs[-1], ws[2 * l], ws[2 * l + 1], acts[l], exp_max, n_dev=count))
         grads = [None] * 8
         gy = gsel
@@ -197,7 +207,8 @@ class LightsFn(torch.autograd.Function):
         gsel = g.index_select(0, idx.clamp(0, g.shape[0] - 1))                    # [cap, 3]
         wi = list(ws[:8])
         wi[0] = torch.nn.functional.pad(wi[0], (0, 5))
-        grads = LightsFn._net_bwd(X, gsel, wi, count, ctx.exp_max)
+        grads = LightsFn._net_bwd(X, gsel, wi, count, ctx.exp_max, hidden=ctx.acts)
+        ctx.acts = None
         grads[0] = grads[0][:, :123].contiguous()
         return (g_base, None, None, None, None, None, None, None, None, *grads, *g_outer)
 

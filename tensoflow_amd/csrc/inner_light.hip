@@ -1072,12 +1072,35 @@ __device__ __forceinline__ void il3_barrier() {
 // OUTER: the same network shape fed with the IDE of the ray DIRECTION itself (MCShadingNetwork.predict_outer_lights, 'direction':
 // network/fields.py:913-916 -- sph_enc(directions, 0), no reflection, no normalisation, no positional columns: their weights are zero
 // in the image and `pts` / `nrm` alias `view`)
-template <bool OUTER, int TERMS>
+
+// SAVE: ReLU(acc) of this wave's 64 units x 64 rays as fp32 rows acts_l[row][256] (row = pass * 64 + ray < m): accumulator register
+// j of lane (ray, half h) is unit 32 tile + (j & 3) + 8 (j >> 2) + 4 h -- four consecutive units per group of four registers
+__device__ __forceinline__ void il3_save_acts(float* __restrict__ acts_l, long long row0, long long m, int T0, int lane, const f32x16 (&acc)[2][2]) {
+  const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const long long row = row0 + 32 * r + j;
+    if (row >= m) continue;
+    float* dst = acts_l + row * 256 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + 32 * (T0 + t) + 8 * g) =
+            make_float4(tf_relu(acc[t][r][4 * g]), tf_relu(acc[t][r][4 * g + 1]), tf_relu(acc[t][r][4 * g + 2]), tf_relu(acc[t][r][4 * g + 3]));
+  }
+}
+
+// SAVE (64-ray form, training): the three hidden layers' post-ReLU activations are also written, acts[layer][row][256] with row = the
+// ray's position in the hit list (capacity rows per layer) -- what the backward pass of the net's dense layers (tf_linear_bwd) reads,
+// instead of recomputing the three 256-wide layers with the dense-layer kernels (LightsFn.backward: 1.2 ms of a 12 ms training step).
+template <bool OUTER, int TERMS, bool SAVE = false>
 __global__ void __launch_bounds__(512, 1)
 inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
                     const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
                     const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
-                    float* __restrict__ out) {
+                    float* __restrict__ out, float* __restrict__ acts = nullptr) {
+  static_assert(!SAVE || TERMS == 3, "activations are saved by the 64-ray form");
   typedef IL3<TERMS> C;
   constexpr int RT = C::RT, NR = C::NR, RAYS = C::RAYS;
   long long m = m_arg;
@@ -1212,6 +1235,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
           for (int c = 0; c < 3; ++c) sum[r][c] = fsum[r][c][0] + fsum[r][c][1];
       } else {
+      if constexpr (SAVE) il3_save_acts(acts + 2 * m_arg * 256, pass_of(it - 1) * RAYS, m, T0, lane_o, acc);
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -1441,6 +1465,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         il4_publish(actt + lane, T0 + 1, held);
       } else {
         il3_publish<TERMS>(actt + lane, T0, acc);
+        if constexpr (SAVE) il3_save_acts(acts + (layer - 1) * m_arg * 256, pass_of(it) * RAYS, m, T0, lane, acc);
       }
 #endif
       IL3_STAMP(4 * layer + 1);
@@ -1494,7 +1519,7 @@ static __global__ void __launch_bounds__(256) inner_light_cols_kernel(const floa
 static int inner_light_launch(const TfMlp4* net, const float* pts, const float* view, const float* nrm, int64_t m,
                               const int64_t* idx, const int64_t* count_dev, const float* depth, float near_eps, float exp_max,
                               int32_t precision, float* out, float* workspace, size_t workspace_floats, hipStream_t stream,
-                              const char* who, bool outer = false) {
+                              const char* who, bool outer = false, float* acts = nullptr) {
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
@@ -1505,6 +1530,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16 || precision == TF_PREC_F16X2, TF_EINVAL,
              "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
+  TF_REQUIRE(!acts || (precision == TF_PREC_F16X3 && !ring && !outer), TF_EINVAL, "%s: activations are saved by the fp32-grade staggered "
+             "kernel only (precision TF_PREC_F16X3)", who);
   TF_REQUIRE(!outer || (precision == TF_PREC_F16X3 && !ring), TF_EINVAL, "%s: the direction-encoded outer light runs on the fp32-grade "
              "staggered kernel only (precision TF_PREC_F16X3)", who);
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
@@ -1557,6 +1584,7 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     long long blocks = ((m + 63) / 64 + 1) / 2;
     if (blocks > 256) blocks = 256;
     if (outer) inner_light3_kernel<true, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    else if (acts) inner_light3_kernel<false, 3, true><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS, acts);
     else inner_light3_kernel<false, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
     return TF_OK;
@@ -1610,6 +1638,16 @@ extern "C" int tf_inner_light_indexed_fwd(const TfMlp4* net, const float* pos, c
   TF_REQUIRE(capacity == 0 || (idx && count_dev), TF_EINVAL, "tf_inner_light_indexed_fwd: idx / count_dev is null");
   return inner_light_launch(net, pos, dirs, nrm, capacity, idx, count_dev, depth, near_eps, exp_max, precision, lights, workspace,
                             workspace_floats, (hipStream_t)stream, "tf_inner_light_indexed_fwd");
+}
+
+extern "C" int tf_inner_light_indexed_train_fwd(const TfMlp4* net, const float* pos, const float* dirs, const float* nrm,
+                                                const int64_t* idx, const int64_t* count_dev, int64_t capacity, const float* depth,
+                                                float near_eps, float exp_max, int32_t precision, float* lights, float* acts,
+                                                float* workspace, size_t workspace_floats, tf_stream_t stream) {
+  TF_REQUIRE(capacity == 0 || (idx && count_dev), TF_EINVAL, "tf_inner_light_indexed_train_fwd: idx / count_dev is null");
+  TF_REQUIRE(acts, TF_EINVAL, "tf_inner_light_indexed_train_fwd: acts is null");
+  return inner_light_launch(net, pos, dirs, nrm, capacity, idx, count_dev, depth, near_eps, exp_max, precision, lights, workspace,
+                            workspace_floats, (hipStream_t)stream, "tf_inner_light_indexed_train_fwd", false, acts);
 }
 
 extern "C" int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, const int64_t* idx, const int64_t* count_dev,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "tf_inner_light_workspace_floats": (sz, []),
     "tf_inner_light_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, i64, f32, i32, c_f, c_f, sz, c_f]),
     "tf_inner_light_indexed_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, c_f, c_f, i64, c_f, f32, f32, i32, c_f, c_f, sz, c_f]),
+    "tf_inner_light_indexed_train_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, c_f, c_f, i64, c_f, f32, f32, i32, c_f, c_f, c_f, sz, c_f]),
     "tf_outer_light_indexed_fwd": (C.c_int, [P(TfMlp4), c_f, c_f, c_f, i64, f32, i32, c_f, c_f, sz, c_f]),
     "tf_compact_mask": (C.c_int, [c_f, i64, c_f, c_f, c_f]),
     "tf_compact_below": (C.c_int, [c_f, f32, i64, c_f, c_f, c_f]),

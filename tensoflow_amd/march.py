@@ -114,10 +114,13 @@ def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n
     dists = t[:, 1:] - t[:, :-1]
     dists = torch.cat([dists, dists[:, -1:]], -1)
     mid = t + dists * 0.5
-    ridx = torch.arange(rn, device=o.device)[:, None].expand(rn, t.shape[1])
     p = o[:, None] + d[:, None] * mid[..., None]
     inner = ~((aabb[0] > p) | (p > aabb[1])).any(-1)
-    return t[inner], (t + dists)[inner], ridx[inner]
+    # ONE compaction (one host sync for the data-dependent size) instead of three boolean-mask indexings; row-major order = the
+    # reference's t[inner] order, ray index = flat index // samples per ray
+    keep = torch.nonzero(inner.reshape(-1))[:, 0]
+    t0 = t.reshape(-1).index_select(0, keep)
+    return t0, t0 + dists.reshape(-1).index_select(0, keep), torch.div(keep, t.shape[1], rounding_mode="floor")
 
 
 @torch.no_grad()

@@ -804,7 +804,9 @@ class ShapeShadingNetwork(nn.Module):
         direct_light = env(reflective, roughness)
         pts = posenc(points, self.cfg["light_pos_freq"])
         indirect_light = _mlp(self.inner_light, torch.cat([pts, ide5(reflective, roughness)], -1))
-        occ_prob = _mlp(self.inner_weight, torch.cat([pts.detach(), posenc(reflective, 6).detach()], -1)) * 0.5 + 0.5
+        # (the occlusion net's inputs are detached in the reference, fields.py:434: the embedding runs on the detached direction, as
+        # one launch of the encoding kernel instead of twelve differentiable sin / cos and a concatenation)
+        occ_prob = _mlp(self.inner_weight, torch.cat([pts.detach(), posenc(reflective.detach(), 6)], -1)) * 0.5 + 0.5
         occ = occ_prob.clamp(0, 1)
         if self.cfg["human_light"]:
             if human_poses is None:

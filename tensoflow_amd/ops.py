@@ -552,8 +552,10 @@ def _mlp4(weights, in_dim=123):
     return net, keep
 
 
-def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=5.0, precision=1, cache=None):
-    """In place: lights[i] = inner_light(pos[i], -dirs[i], nrm[i]) * (depth[i] > near_eps) for i in idx[:count]."""
+def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near_eps=1e-5, exp_max=5.0, precision=1, cache=None, acts=None):
+    """In place: lights[i] = inner_light(pos[i], -dirs[i], nrm[i]) * (depth[i] > near_eps) for i in idx[:count].
+    acts: [3, idx.numel(), 256] fp32 (training, precision PREC_F16X3): also receives the three hidden layers' post-ReLU activations,
+    row r = ray idx[r] (tf_inner_light_indexed_train_fwd)."""
     lib = L.load()
     net, keep = _mlp4(weights)
     if cache is None:
@@ -561,6 +563,12 @@ def inner_light_indexed(weights, pos, dirs, nrm, idx, count, depth, lights, near
     else:
         ws = cache.workspace(lib.tf_inner_light_workspace_floats(), pos.device)
         flag = cache.flag(keep, precision)
+    if acts is not None:
+        assert acts.is_contiguous() and acts.dtype == torch.float32 and tuple(acts.shape) == (3, idx.numel(), 256)
+        L.check(lib.tf_inner_light_indexed_train_fwd(C.byref(net), _p(pos), _p(dirs), _p(nrm), _p(idx, torch.int64), _p(count, torch.int64),
+                                                     idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision) | flag, _p(lights),
+                                                     _p(acts), _p(ws), ws.numel(), _stream()), "tf_inner_light_indexed_train_fwd")
+        return lights
     L.check(lib.tf_inner_light_indexed_fwd(C.byref(net), _p(pos), _p(dirs), _p(nrm), _p(idx, torch.int64), _p(count, torch.int64),
                                            idx.numel(), _p(depth), float(near_eps), float(exp_max), int(precision) | flag, _p(lights),
                                            _p(ws), ws.numel(), _stream()), "tf_inner_light_indexed_fwd")

@@ -647,3 +647,43 @@ def test_half_texel_pyramid_is_the_fp32_path_on_the_rounded_field(golden, dev):
         ops.sdf_forward(p16, *W, xyz, lv, AABB, want_feat=False, precision=ops.PREC_F32)
     with pytest.raises(RuntimeError):                                  # inference-only format
         ops.vm_gather_bwd(p16, xyz, lv, AABB, torch.ones(5000, 108, device=dev))
+
+
+def test_inner_light_train_forward_saves_hidden_activations(golden, dev):
+    """tf_inner_light_indexed_train_fwd: the lights of tf_inner_light_indexed_fwd (same bits) plus the three hidden layers' post-ReLU
+    activations by hit-list row, against the dense-layer kernels on the encoded rows (tf_inner_light_encode + tf_linear_fwd: what
+    LightsFn.backward recomputed before round 4); rows beyond the device-side count are not written; the weight gradients through
+    LightsFn agree with the recompute path."""
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import wn_weight
+    g = golden("shading_small")
+    gen = torch.Generator().manual_seed(12)
+    n, m = 5000, 3217                                   # capacity (all rays) and hits: neither a multiple of the 64-ray pass
+    pos = (torch.rand(n, 3, generator=gen) * 1.6 - 0.8).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+    depth = (torch.rand(n, generator=gen) + 0.1).to(dev)
+    idx = torch.randperm(n, generator=gen).to(dev)
+    count = torch.tensor([m], dtype=torch.int64, device=dev)
+    W = [(wn_weight(g.sd, f"inner_light.{i}").to(dev).contiguous(), g.sd[f"inner_light.{i}.bias"].to(dev).contiguous()) for i in (0, 2, 4, 6)]
+    a = torch.full((n, 3), -7.0, device=dev)
+    b = torch.full((n, 3), -7.0, device=dev)
+    acts = torch.full((3, n, 256), -7.0, device=dev)
+    ops.inner_light_indexed(W, pos, dirs, nrm, idx, count, depth, a, precision=ops.PREC_F16X3)
+    ops.inner_light_indexed(W, pos, dirs, nrm, idx, count, depth, b, precision=ops.PREC_F16X3, acts=acts)
+    assert torch.equal(a, b)
+    assert bool((acts[:, m:] == -7.0).all())            # rows beyond the count are not touched
+    # layer by layer with the dense-layer kernels (exact fp32): each saved layer from the saved layer below it, the lights from the
+    # last one -- the row / unit mapping and the values to fp32 rounding.  The first layer against the encoding kernel's rows: the two
+    # kernels sum the degree-16 IDE polynomials in different orders (they cancel in fp32: ~1e-4 in those features), so that step is
+    # held to the level the operand-mode tests hold the rays to.
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    X = ops.inner_light_encode(pos, dirs, nrm, idx, count, ld=128)
+    w0 = torch.nn.functional.pad(W[0][0], (0, 5))
+    e1 = rel(acts[0, :m], ops.linear_fwd(X, w0, W[0][1], ops.ACT_RELU, 0.0, n_dev=count)[:m])
+    e2 = rel(acts[1, :m], ops.linear_fwd(acts[0].contiguous(), W[1][0], W[1][1], ops.ACT_RELU, 0.0, n_dev=count)[:m])
+    e3 = rel(acts[2, :m], ops.linear_fwd(acts[1].contiguous(), W[2][0], W[2][1], ops.ACT_RELU, 0.0, n_dev=count)[:m])
+    out = ops.linear_fwd(acts[2].contiguous(), W[3][0], W[3][1], ops.ACT_EXP_CLAMP, 5.0, n_dev=count)[:m]
+    e4 = rel(out, a[idx[:m]])
+    print(f"saved activations: layer 1 vs encode + dense {e1:.2e}; layer 2 from saved 1 {e2:.2e}; layer 3 from saved 2 {e3:.2e}; lights from saved 3 {e4:.2e}")
+    assert e1 < 3e-3 and e2 < 1e-5 and e3 < 1e-5 and e4 < 1e-5, (e1, e2, e3, e4)
