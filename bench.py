@@ -86,9 +86,13 @@ def compact_line(line):
     # the inner-light and traversal kernels take the same time within a few per cent from round 4 on: whichever is NOT the dominant
     # one of this run is carried beside it, so that the line always holds the matrix-core kernel's figures
     ro = line.get("roofline_other")
-    if isinstance(ro, dict) and isinstance(ro.get("inner_light3_kernel"), dict):
-        out["roofline_other"] = {"inner_light3_kernel": _pick(ro["inner_light3_kernel"], ("bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                                                          "avg_launch_ms", "executed_tflops"))}
+    if isinstance(ro, dict):
+        keep = {k: _pick(ro[k], ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "executed_tflops"))
+                for k in ("inner_light3_kernel", "bvh_trace_kernel") if isinstance(ro.get(k), dict)}
+        if keep:
+            out["roofline_other"] = keep
+    if "longest_stage" in line:
+        out["longest_stage"] = line["longest_stage"]
     cb = line.get("cpu_baseline")
     if isinstance(cb, dict):
         out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
@@ -886,6 +890,13 @@ def main():
         summ = timer.summary()
         stages = {k: dict(ms_per_step=v[0] / args.steps, launches=v[1]) for k, v in summ.items()}
         dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+        # From round 4 on the inner-light kernel and the traversal take the same time within run-to-run noise (58.8 vs 58.9 ms per step).
+        # `roofline` stays on the kernel every earlier round reported (and the one with an algorithmic work figure) while
+        # it is within 5 % of the longest stage; the longest stage's own figures are then carried as `roofline_other[<its kernel>]`, so
+        # the line holds both whichever way the tie falls.
+        longest = dom
+        if dom != "inner_light" and "inner_light" in stages and stages["inner_light"]["ms_per_step"] >= 0.95 * stages[dom]["ms_per_step"]:
+            dom = "inner_light"
         hits = int(sh.hit_total.item()) if sh.hit_total is not None else 0
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
         traced_per_step = int(live_rays.item())
@@ -935,7 +946,10 @@ def main():
                        "deviations_from_SURVEY_8d_config3": "surface points on the sphere only: hit fraction 0.148 where the survey sketched ~0.20; the "
                                                              "`scene_points` probe shades points over sphere AND torus (measured hit fraction there)"},
             "roofline": roof,
-            "roofline_other": other_rooflines(summ, timer, hits, args, sh, dom),
+            "roofline_other": dict(other_rooflines(summ, timer, hits, args, sh, dom),
+                                   **({"bvh_trace_kernel": bvh_roofline(summ, "bvh_trace", traced_per_step * args.steps, pn * (2 * S + 512) * args.steps)}
+                                      if (dom != "bvh_trace" and "bvh_trace" in summ) else {})),
+            "longest_stage": longest,
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "stages_overlapped_ms_per_step": dict(
                 {k: round(v[0] / args.steps, 3) for k, v in timer.summary_overlapped().items()},
