@@ -63,3 +63,17 @@ def test_emit_prints_exactly_one_stdout_line(capsys, tmp_path, monkeypatch):
     assert cap.err.startswith("BENCH_DETAIL ")
     _strict(cap.err[len("BENCH_DETAIL "):])
     _strict(open(tmp_path / "gpurun_out" / "bench_detail.json").read())
+
+
+def test_compact_line_carries_both_tied_kernels():
+    """Round 4: the inner-light kernel and the traversal take the same time within noise; the line holds the figures of both -- the
+    one `roofline` describes and the other under `roofline_other` -- and names the longest stage, still under the limit."""
+    with open(os.path.join(REPO, "profiles", "r4n_bench_detail.json")) as f:
+        line = json.load(f)
+    assert line["roofline"]["kernel"] == "inner_light3_kernel" and "bvh_trace_kernel" in line["roofline_other"]
+    got = _strict(bench.compact_line(line))
+    assert got["roofline"]["kernel"] == "inner_light3_kernel" and got["longest_stage"] in ("inner_light", "bvh_trace")
+    other = got["roofline_other"]["bvh_trace_kernel"]
+    assert other["bound"] == "hbm" and 0 < other["frac"] < 1 and other["avg_launch_ms"] > 0
+    assert got["config"]["inner_light_operands"].startswith("f16x2")
+    assert len(bench.compact_line(line)) < 3072
