@@ -917,9 +917,11 @@ __device__ __forceinline__ void il3_bias(const float* __restrict__ lb /* layer's
   }
 }
 
-// ReLU + operand conversion of this wave's 64 units x (32 RT) rays into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3)
+// ReLU + hi / lo split of this wave's 64 units x 64 rays into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3): the 64-ray form
+// (the 128-ray form converts and publishes per unit-tile half: il4_pack / il4_publish)
 template <int TERMS>
 __device__ __forceinline__ void il3_publish(tf_h8* __restrict__ actl /* team image + lane */, int T0, const f32x16 (&acc)[2][IL3<TERMS>::RT]) {
+  static_assert(TERMS == 3, "64-ray form");
   constexpr int RT = IL3<TERMS>::RT, XP = IL3<TERMS>::XP;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -929,24 +931,11 @@ __device__ __forceinline__ void il3_publish(tf_h8* __restrict__ actl /* team ima
       for (int u = 0; u < 2; ++u) {
         float x8[8];
         tf_h8* dst = actl + (((2 * (T0 + t) + u) * RT + r) * XP) * 64;
-        if (TERMS == 3) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
-          tf_h8 hi, lo;
-          tf_split8(x8, hi, lo);
-          dst[0] = hi; dst[64] = lo;
-        } else {
-          // one rounded operand per value: ReLU AFTER the conversion, on the packed halves (rounding to f16 is monotonic and keeps the
-          // sign, so max(f16(x), 0) = f16(max(x, 0)): one v_pk_max_f16 per two values instead of one v_max_f32 per value)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = acc[t][r][8 * u + e];
-          tf_h8 hi;
-          tf_cvt8(x8, hi);
-          const tf_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-          dst[0] = __builtin_elementwise_max(hi, zero);
-          // (with 128 accumulator registers live the scheduler must not gather the conversions in front of the stores)
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
+        tf_h8 hi, lo;
+        tf_split8(x8, hi, lo);
+        dst[0] = hi; dst[64] = lo;
       }
 }
 
@@ -994,6 +983,7 @@ __device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, 
       il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, 0, s + PF) : il3_kstep_base(Wl, 0, s + PF - K16);
 #else
       il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
+#endif
 #pragma unroll
       for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
     }
@@ -1011,7 +1001,6 @@ __device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, 
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // MFMA
     __builtin_amdgcn_sched_barrier(0);
   }
-#endif
 }
 // One rounding to f16 of a half's 32 units x 128 rays: [ray tile][k-step half u] fragments of 8 halves.  The vector fptrunc
 // (v_cvt_pk_f16_f32, round to nearest even): compiler-visible, so that hipcc pads the MFMA -> reader hazard (it does not for an asm
