@@ -877,13 +877,37 @@ def main():
     pts_p, view_p, nrm_p = pts[:chunk].contiguous(), view[:chunk].contiguous(), nrm[:chunk].contiguous()
 
     train_dp = None
+    train_dp_hung = False
     if not args.no_train:                             # world == 1 included: the same leg without an exchange, so that N = 1 can be compared with N > 1
         from tensoflow_amd.shading import _NoTimer as _NT
         sh.timer = _NT()
-        try:
-            train_dp = train_dp_leg(device, verts, faces, aabb, unit, world, rank, max(2, args.steps), args.train_points)
-        except Exception as e:      # every rank takes the same branch (same code, same inputs); the eval line is never lost over it
-            train_dp = {"error": f"{type(e).__name__}: {e}"}
+        box = {}
+
+        def _leg():
+            try:
+                torch.cuda.set_device(device)
+                if os.environ.get("TENSOFLOW_BENCH_FAKE_HANG") and world > 1:      # test hook: a collective that never returns
+                    time.sleep(1e6)
+                box["r"] = train_dp_leg(device, verts, faces, aabb, unit, world, rank, max(2, args.steps), args.train_points)
+            except Exception as e:      # every rank takes the same branch (same code, same inputs); the eval line is never lost over it
+                box["r"] = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            # The eval figure above is complete; this leg is the only place of the run where ranks EXCHANGE data (RCCL), and a collective
+            # that one rank never enters would block the others until the process-group timeout -- and the line with them.  It runs under
+            # a watchdog: past the limit the leg is reported as not returned, the line is printed and the process leaves without waiting.
+            import threading
+            limit = float(os.environ.get("TENSOFLOW_BENCH_TRAIN_DP_TIMEOUT", "240"))
+            th = threading.Thread(target=_leg, daemon=True)
+            th.start()
+            th.join(limit)
+            if th.is_alive():
+                train_dp_hung = True
+                train_dp = {"error": f"no result within {limit:.0f} s (a rank did not return from the training leg); the eval figures are unaffected", "ranks": world}
+            else:
+                train_dp = box.get("r")
+        else:
+            _leg()
+            train_dp = box.get("r")
         sh.timer = timer
 
     if rank == 0:
@@ -1102,6 +1126,12 @@ def main():
                 line["march"]["cpu_baseline"] = march_cpu_baseline()
         emit(line)
     if dist_on:
+        # The line is out.  No closing barrier and no process-group teardown: if any rank is still inside the training leg's exchange
+        # (its own watchdog ends it), a rank waiting for it here would turn a finished measurement into a failed run.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if train_dp_hung or dist.get_backend() == "nccl":
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 
