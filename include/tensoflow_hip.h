@@ -393,8 +393,8 @@ int tf_inner_light_indexed_train_fwd(const TfMlp4* net, const float* pos, const 
  * :716-718: make_predictor_4layer(72, 3, 'exp', light_exp_max); configs/mat/syn/{lego,armadillo,horse}.yaml) for the rays that MISSED
  * the mesh (get_lights :962-968): lights[i] = exp(min(net(IDE5(dirs[i], roughness 0)), exp_max)) for i = idx[r], r < *count_dev.
  * net->w[0] is the [256,72] first layer; the other layers as TfMlp4.  The direction rows are encoded as they are (the reference
- * does not normalise them).  precision: TF_PREC_F16X3 (| TF_WEIGHTS_PACKED) only -- the net runs on the staggered fp32-grade kernel of
- * the inner light; `workspace` as tf_inner_light_workspace_floats(), one workspace PER NET.  A missing ray's depth is TF_MISS_DEPTH, so
+ * does not normalise them).  precision: TF_PREC_F16X3 or TF_PREC_F16X2 (| TF_WEIGHTS_PACKED) -- the net runs on the staggered kernel of
+ * the inner light (its 64-ray / 128-ray form); `workspace` as tf_inner_light_workspace_floats(), one workspace PER NET.  A missing ray's depth is TF_MISS_DEPTH, so
  * get_lights' near mask (:973) is 1 on every row written here. */
 int tf_outer_light_indexed_fwd(const TfMlp4* net, const float* dirs, const int64_t* idx, const int64_t* count_dev,
                                int64_t capacity, float exp_max, int32_t precision, float* lights, float* workspace,

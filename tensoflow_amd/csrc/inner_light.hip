@@ -1521,8 +1521,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   if (m == 0) return TF_OK;
   TF_REQUIRE(!acts || (precision == TF_PREC_F16X3 && !ring && !outer), TF_EINVAL, "%s: activations are saved by the fp32-grade staggered "
              "kernel only (precision TF_PREC_F16X3)", who);
-  TF_REQUIRE(!outer || (precision == TF_PREC_F16X3 && !ring), TF_EINVAL, "%s: the direction-encoded outer light runs on the fp32-grade "
-             "staggered kernel only (precision TF_PREC_F16X3)", who);
+  TF_REQUIRE(!outer || ((precision == TF_PREC_F16X3 || precision == TF_PREC_F16X2) && !ring && !cols_x2), TF_EINVAL, "%s: the direction-encoded "
+             "outer light runs on the staggered kernel only (precision TF_PREC_F16X3 or TF_PREC_F16X2)", who);
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
              workspace_floats, kInnerWsFloats);
@@ -1583,7 +1583,8 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     TF_REQUIRE(m <= 0x7fffffffLL, TF_ESHAPE, "%s: more than 2^31 - 1 rays in one call", who);
     long long blocks = ((m + 127) / 128 + 1) / 2;
     if (blocks > 256) blocks = 256;
-    inner_light3_kernel<false, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    if (outer) inner_light3_kernel<true, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    else inner_light3_kernel<false, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
     return TF_OK;
   }

@@ -430,7 +430,8 @@ class MCShader:
                     miss &= live.reshape(-1).to(torch.uint8)
                 idx_m, count_m = ops.compact_mask(miss)
                 if not self.outer_sphere and self.human is None:
-                    ops.outer_light_indexed(self.outer, dirs, idx_m, count_m, hit_lights, exp_max=self.light_exp_max, cache=self.outer_cache)
+                    ops.outer_light_indexed(self.outer, dirs, idx_m, count_m, hit_lights, exp_max=self.light_exp_max, cache=self.outer_cache,
+                                            precision=self.inner_precision if self.inner_precision in (ops.PREC_F16X3, ops.PREC_F16X2) else ops.PREC_F16X3)
                 else:
                     # composed variants (configs/mat/custom): one host sync for the count, slices of 2^21 rays to bound the encodings
                     n, T = int(count_m), dirs.shape[0] // pts_rep.shape[0]

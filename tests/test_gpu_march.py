@@ -495,6 +495,17 @@ def test_direction_outer_light_eval_golden(golden, dev):
     print(f"direction outer light, per-ray error against the fp64 oracle: reference {e_ref:.2e}, staggered kernel {e_kernel:.2e}, "
           f"composed {e_comp:.2e} ({int(miss.sum())} missing + {int(hit.sum())} hit rays)")
     assert e_kernel < max(TOL, 2 * e_ref) and e_comp < max(TOL, 2 * e_ref)
+    # both forms of the staggered kernel (MCShader's default rounds the activations to f16 once per layer: 128-ray form; every operand
+    # split: 64-ray form) are held to that bar
+    from tensoflow_amd import ops
+    keep_ip = sh.inner_precision
+    for ip in (ops.PREC_F16X3, ops.PREC_F16X2):
+        sh.inner_precision = ip
+        l2, h2, _ = sh.lights(pts16, g["gl_dirs"].to(dev).contiguous())
+        e2 = rel(torch.where(miss[:, None], l2.cpu(), ref64.float()))
+        print(f"  inner_precision {ip}: per-ray error of the outer net against fp64 {e2:.2e}")
+        assert torch.equal(h2.cpu(), g["gl_hit"].bool()) and e2 < max(TOL, 2 * e_ref), (ip, e2, e_ref)
+    sh.inner_precision = keep_ip
     hl = lights.cpu()[~miss]
     assert float(((hl - g["gl_lights"][~miss]).abs() / g["gl_lights"][~miss].abs().clamp_min(1e-2)).max()) < 1e-3     # inner light on the hits
     with torch.no_grad():
