@@ -567,6 +567,15 @@ int tf_linear_fwd(const float* X, const float* W, const float* b, int64_t n, int
 int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
                   float act_param, int32_t precision, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev,
                   tf_stream_t stream);
+/* One layer of a backward CHAIN through stacked layers (what autograd does to make_predictor_4layer, network/other_field.py:86-119, one
+ * Linear + activation node after the other): tf_linear_bwd plus, in the same launches, the activation backward of the layer BELOW.
+ * x_act / x_act_param: the activation that produced X (TF_ACT_NONE: X is no layer's output -- plain gX).  Then gX [n,K] receives
+ * (gZ . W) * x_act'(X), the gradient wrt the PRE-activation of the layer below, and gbx [K] (or NULL) its column sums = that layer's
+ * bias gradient.  gy_is_gz != 0: gY already is this layer's pre-activation gradient (the previous call's gX): no activation pass, Y and
+ * gZ are not read, gb must be NULL (it was the previous call's gbx). */
+int tf_linear_bwd_fused(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
+                        float act_param, int32_t gy_is_gz, int32_t x_act, float x_act_param, int32_t precision, float* gZ, float* gX,
+                        float* gW, float* gb, float* gbx, const int64_t* n_dev, tf_stream_t stream);
 
 /* -----------------------------------------------------------------------------------
  * Encodings of the TRAINING direction (the inference kernels evaluate the same functions in registers).

@@ -178,12 +178,19 @@ class LightsFn(torch.autograd.Function):
                 hs.append(hidden[l])
                 continue
             hs.append(ops.linear_fwd(hs[-1], ws[2 * l], ws[2 * l + 1], acts[l], exp_max, n_dev=count))
+        # a CHAIN: every call also runs the activation backward of the layer below in its data-gradient product (mask in the epilogue,
+        # bias gradient as column sums) -- no separate pass over the [rows, 256] gradients between the layers
         grads = [None] * 8
-        gy = gsel
+        gy, is_gz = gsel, False
         for l in (3, 2, 1, 0):
-            gx, gw, gb = ops.linear_bwd(hs[l], ws[2 * l], hs[l + 1], gy, acts[l], exp_max, need_gx=l > 0, n_dev=count)
-            grads[2 * l], grads[2 * l + 1] = gw, gb
-            gy = gx
+            gx, gw, gb, gbx = ops.linear_bwd_fused(hs[l], ws[2 * l], hs[l + 1], gy, acts[l], exp_max, gy_is_gz=is_gz,
+                                                   x_act=acts[l - 1] if l > 0 else ops.ACT_NONE, need_gx=l > 0, need_gbx=l > 0, n_dev=count)
+            grads[2 * l] = gw
+            if not is_gz:
+                grads[2 * l + 1] = gb
+            if l > 0:
+                grads[2 * (l - 1) + 1] = gbx
+            gy, is_gz = gx, l > 0
         return grads
 
     @staticmethod

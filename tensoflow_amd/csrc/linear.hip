@@ -236,6 +236,9 @@ struct Gemm2Args {
   long long M, N, K, k_split;
   int act; float act_param; int atomic;
   const long long* n_dev; int rows_are_m;
+  // data-gradient product of a layer CHAIN (tf_linear_bwd_fused): C(m, n) *= act'(mulY(m, n)) with mulY [M][sC] the post-activation
+  // output of the layer below (= this layer's input), and colsum[n] += sum_m C(m, n) -- that layer's bias gradient
+  const float* mulY = nullptr; int mul_act = 0; float mul_param = 0.f; float* colsum = nullptr;
 };
 
 template <bool A_RF, bool B_RF>
@@ -334,13 +337,23 @@ __global__ void __launch_bounds__(256, 4) gemm2_kernel(Gemm2Args G) {
       const long long n = n0 + 64 * wn + 32 * b + i;
       if (n >= G.N) continue;
       const float bv = G.bias ? G.bias[n] : 0.f;
+      float cs = 0.f;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const long long m = m0 + 64 * wm + 32 * a + tf_rho(reg, h);
         if (m >= G.M) continue;
         float* dst = G.C + m * G.sC + n;
         if (G.atomic) atomicAdd(dst, acc[a][b][reg]);
+        else if (G.mulY) {
+          const float v = acc[a][b][reg] * act_bwd_from_y(G.mulY[m * G.sC + n], G.mul_act, G.mul_param);
+          *dst = v;
+          cs += v;
+        }
         else *dst = act_fwd(acc[a][b][reg] + bv, G.act, G.act_param);
+      }
+      if (G.colsum) {                       // the two lane halves hold the other 16 rows of this column: one atomic per wave and column
+        cs += __shfl_xor(cs, 32);
+        if (h == 0) atomicAdd(G.colsum + n, cs);
       }
     }
 }
@@ -407,6 +420,46 @@ __global__ void __launch_bounds__(256) thin_data_kernel(const float* __restrict_
     o.x = fmaf(g, w.x, o.x); o.y = fmaf(g, w.y, o.y); o.z = fmaf(g, w.z, o.z); o.w = fmaf(g, w.w, o.w);
   }
   *reinterpret_cast<float4*>(gX + r * K + k) = o;
+}
+
+// ... the same followed by the activation backward of the layer BELOW (tf_linear_bwd_fused): gZx[r][k] = gx[r][k] * act'(X[r][k]) and
+// gbx[k] += sum_r gZx[r][k].  A thread keeps its four k and walks the rows of the workgroup's 1 024-row slab, so that the column sums
+// leave the workgroup as one atomic per column.
+template <int NOUT>
+__global__ void __launch_bounds__(256) thin_data_mask_kernel(const float* __restrict__ gZ, const float* __restrict__ W, const float* __restrict__ X,
+                                                             long long n, int K, int xact, float xp, float* __restrict__ gZx,
+                                                             float* __restrict__ gbx, const long long* __restrict__ n_dev) {
+  if (n_dev) n = min(n, max(0LL, *n_dev));
+  const int kq = K / 4, rp = 256 / kq;
+  const int t = threadIdx.x, sub = t / kq, k = 4 * (t - sub * kq);
+  const long long r0 = (long long)blockIdx.x * 1024, r1 = min(r0 + 1024, n);
+  if (r0 >= n) return;                                 // workgroup-uniform
+  __shared__ float part[1024];
+  for (int e = t; e < K; e += 256) part[e] = 0.f;
+  __syncthreads();
+  if (sub < rp) {
+    float4 w[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) w[j] = *reinterpret_cast<const float4*>(W + j * K + k);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + sub; r < r1; r += rp) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) {
+        const float g = gZ[r * NOUT + j];
+        o.x = fmaf(g, w[j].x, o.x); o.y = fmaf(g, w[j].y, o.y); o.z = fmaf(g, w[j].z, o.z); o.w = fmaf(g, w[j].w, o.w);
+      }
+      const float4 x = *reinterpret_cast<const float4*>(X + r * K + k);
+      o.x *= act_bwd_from_y(x.x, xact, xp); o.y *= act_bwd_from_y(x.y, xact, xp);
+      o.z *= act_bwd_from_y(x.z, xact, xp); o.w *= act_bwd_from_y(x.w, xact, xp);
+      *reinterpret_cast<float4*>(gZx + r * K + k) = o;
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    if (gbx) { atomicAdd(&part[k], s.x); atomicAdd(&part[k + 1], s.y); atomicAdd(&part[k + 2], s.z); atomicAdd(&part[k + 3], s.w); }
+  }
+  __syncthreads();
+  if (gbx)
+    for (int e = t; e < K; e += 256) atomicAdd(gbx + e, part[e]);
 }
 
 template <int NOUT>
@@ -513,15 +566,26 @@ __global__ void __launch_bounds__(256) act_bwd_small_kernel(const float* __restr
 // The two backward products of a dense layer given gZ = d loss / d (pre-activation) [n,N]: gX [n,K] = gZ . W (overwritten) and
 // gW [N,K] += gZ^T . X (ATOMIC accumulation into whatever gW holds: tf_linear_bwd zeroes it first; tf_sdf_alpha_bwd accumulates over
 // sample chunks).  Internal to the library (tf_internal.h): no activation pass, no bias gradient.
+// xact != TF_ACT_NONE (tf_linear_bwd_fused): gX receives (gZ . W) * xact'(X) -- the gradient wrt the PRE-activation of the layer below,
+// whose post-activation output X is -- and gbx [K] (or null) accumulates its column sums; shapes that neither the aligned matrix-core
+// kernel nor the thin kernels take run the plain product followed by the activation pass.
+static int linear_products_x(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
+                             const long long* n_dev, hipStream_t stream, int xact, float xact_param, float* gbx);
 int tf_linear_products(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
                        const long long* n_dev, hipStream_t stream) {
+  return linear_products_x(X, W, gZ, n, K, N, precision, gX, gW, n_dev, stream, TF_ACT_NONE, 0.f, nullptr);
+}
+static int linear_products_x(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
+                             const long long* n_dev, hipStream_t stream, int xact, float xact_param, float* gbx) {
   const bool h3 = precision == TF_PREC_F16X3;
+  const bool fuse = xact != TF_ACT_NONE && gX;
   if (n == 0) return TF_OK;
   if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
     const long long* nd = n_dev;
 #define TF_THIN(NO)                                                                                                                  \
     do {                                                                                                                              \
-      if (gX) thin_data_kernel<NO><<<tf_blocks(n * (K / 4), 256), 256, 0, stream>>>(gZ, W, n, K, gX, nd);                             \
+      if (gX && fuse) thin_data_mask_kernel<NO><<<tf_blocks(n, 1024), 256, 0, stream>>>(gZ, W, X, n, K, xact, xact_param, gX, gbx, nd); \
+      else if (gX) thin_data_kernel<NO><<<tf_blocks(n * (K / 4), 256), 256, 0, stream>>>(gZ, W, n, K, gX, nd);                        \
       if (gW) thin_weight_kernel<NO><<<tf_blocks(n, 1024), 256, 0, stream>>>(gZ, X, n, K, gW, nd);                                     \
     } while (0)
     if (N == 1) TF_THIN(1); else if (N == 2) TF_THIN(2); else if (N == 3) TF_THIN(3); else TF_THIN(4);
@@ -533,14 +597,23 @@ int tf_linear_products(const float* X, const float* W, const float* gZ, long lon
                   aligned16(X) && aligned16(W) && aligned16(gZ);
   if (gX) {   // gX [n,K] = gZ [n,N] . W [N,K]
     int rc;
+    bool fused_here = false;
     if (g2) {
       Gemm2Args G2{gZ, N, W, K, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
+      if (fuse) { G2.mulY = X; G2.mul_act = xact; G2.mul_param = xact_param; G2.colsum = gbx; fused_here = true; }
       rc = launch2<true, false>(G2, 1, stream, "tf_linear_bwd(data)");
     } else {
       GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
       rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
     }
     if (rc != TF_OK) return rc;
+    if (fuse && !fused_here) {      // the activation pass of the layer below, in place
+      int slab = 256;
+      while (slab > 8 && n / slab < 1024) slab >>= 1;
+      if (K >= 64) act_bwd_kernel<<<tf_blocks(n, slab), 256, 0, stream>>>(gX, X, n, K, xact, xact_param, gX, gbx, n_dev, slab);
+      else act_bwd_small_kernel<<<tf_blocks(n * K, 4096), 256, 0, stream>>>(gX, X, n * K, K, xact, xact_param, gX, gbx, n_dev);
+      TF_LAUNCH_CHECK("tf_linear_bwd_fused(act below)");
+    }
   }
   if (gW) {   // gW [N,K] = gZ^T . X : A(m = unit, k = row) = gZ[row N + unit], B(k = row, n = k) = X[row K + n]
 #ifndef TF_WGRAD_SPLIT
@@ -613,3 +686,36 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
   return tf_linear_products(X, W, gZ, n, K, N, h3 ? TF_PREC_F16X3 : TF_PREC_F32, gX, gW, (const long long*)n_dev, stream);
 }
+
+// One layer of a backward CHAIN through stacked dense layers (LightsFn.backward: the inner-light net's four layers): as tf_linear_bwd,
+// and in the same launches the activation backward of the layer BELOW -- gX then holds the gradient wrt that layer's pre-activation and
+// gbx its bias gradient, so the next call of the chain passes them on with gy_is_gz = 1 and runs no activation pass of its own.
+extern "C" int tf_linear_bwd_fused(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
+                                   float act_param, int32_t gy_is_gz, int32_t x_act, float x_act_param, int32_t precision, float* gZ,
+                                   float* gX, float* gW, float* gb, float* gbx, const int64_t* n_dev, tf_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_bwd_fused: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_bwd_fused: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
+  TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP && x_act >= TF_ACT_NONE && x_act <= TF_ACT_EXP_CLAMP, TF_EINVAL,
+             "tf_linear_bwd_fused: unknown activation %d / %d", act, x_act);
+  TF_REQUIRE(W && (n == 0 || (X && gY && (gy_is_gz || (Y && gZ)))), TF_EINVAL, "tf_linear_bwd_fused: null pointer");
+  TF_REQUIRE(!gy_is_gz || !gb, TF_EINVAL, "tf_linear_bwd_fused: with gy_is_gz the bias gradient came out of the previous call (gbx)");
+  TF_REQUIRE(!gbx || gX, TF_EINVAL, "tf_linear_bwd_fused: gbx needs gX");
+  if (gW) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (gb) { hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (gbx) { hipError_t e = hipMemsetAsync(gbx, 0, sizeof(float) * (size_t)K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (n == 0) return TF_OK;
+  const float* gz = gY;
+  if (!gy_is_gz) {
+    if (N >= 64) {
+      int slab = 256;
+      while (slab > 8 && n / slab < 1024) slab >>= 1;
+      act_bwd_kernel<<<tf_blocks(n, slab), 256, 0, stream>>>(gY, Y, n, N, act, act_param, gZ, gb, (const long long*)n_dev, slab);
+    }
+    else act_bwd_small_kernel<<<tf_blocks(n * N, 4096), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
+    TF_LAUNCH_CHECK("tf_linear_bwd_fused(act)");
+    gz = gZ;
+  }
+  return linear_products_x(X, W, gz, n, K, N, precision, gX, gW, (const long long*)n_dev, stream, gX ? x_act : TF_ACT_NONE, x_act_param, gbx);
+}
+

@@ -421,6 +421,29 @@ def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=T
     return gx, gw, gb
 
 
+def linear_bwd_fused(x, w, y, gy, act=ACT_NONE, act_param=0.0, gy_is_gz=False, x_act=ACT_NONE, x_act_param=0.0, need_gx=True,
+                     need_gw=True, need_gb=True, need_gbx=False, n_dev=None, precision=None):
+    """One layer of a backward chain (tf_linear_bwd_fused) -> (gx, gw, gb, gbx).  With x_act the returned gx is the gradient wrt the
+    PRE-activation of the layer below (whose output x is) and gbx that layer's bias gradient; pass it on with gy_is_gz=True."""
+    lib = L.load()
+    x, w, gy = _f(x), _f(w), _f(gy)
+    n, K = x.shape
+    N = w.shape[0]
+    y = None if gy_is_gz else _f(y)
+    gz = None if gy_is_gz else torch.empty(n, N, device=x.device)
+    gx = torch.empty(n, K, device=x.device) if need_gx else None
+    gw = torch.empty(N, K, device=x.device) if need_gw else None
+    gb = torch.empty(N, device=x.device) if (need_gb and not gy_is_gz) else None
+    gbx = torch.empty(K, device=x.device) if (need_gbx and need_gx) else None
+    L.check(lib.tf_linear_bwd_fused(_p(x), _p(w), _p(y) if y is not None else None, _p(gy), n, K, N, int(act), float(act_param),
+                                    1 if gy_is_gz else 0, int(x_act), float(x_act_param),
+                                    int(LINEAR_PRECISION if precision is None else precision), _p(gz) if gz is not None else None,
+                                    _p(gx) if gx is not None else None, _p(gw) if gw is not None else None,
+                                    _p(gb) if gb is not None else None, _p(gbx) if gbx is not None else None,
+                                    _p(n_dev, torch.int64) if n_dev is not None else None, _stream()), "tf_linear_bwd_fused")
+    return gx, gw, gb, gbx
+
+
 def pwquad(wv, y, inverse):
     """ElementWisePWQuadraticTransform.flow_inv (inverse=False: density direction) / .flow (inverse=True: sampling direction) on
     parameter rows wv [m,21] and y [m] -> out [m], logj [m], bins [m] int32 (flow.py:332-525; the device functions of the fused

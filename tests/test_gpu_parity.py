@@ -687,3 +687,40 @@ def test_inner_light_train_forward_saves_hidden_activations(golden, dev):
     e4 = rel(out, a[idx[:m]])
     print(f"saved activations: layer 1 vs encode + dense {e1:.2e}; layer 2 from saved 1 {e2:.2e}; layer 3 from saved 2 {e3:.2e}; lights from saved 3 {e4:.2e}")
     assert e1 < 3e-3 and e2 < 1e-5 and e3 < 1e-5 and e4 < 1e-5, (e1, e2, e3, e4)
+
+
+@pytest.mark.parametrize("n,cnt", [(5000, 3217), (300, 300)])
+def test_linear_bwd_chain_equals_layer_by_layer(dev, n, cnt):
+    """tf_linear_bwd_fused down a 123(128)-256-256-256-3 stack (ReLU, ReLU, ReLU, exp-clamp: make_predictor_4layer) against tf_linear_bwd
+    layer by layer: the activation backward of the layer below folded into the data-gradient product (matrix-core epilogue for the
+    256-wide layers, the streaming kernel under the 3-wide one) and its bias gradient as column sums; device-side row count."""
+    from tensoflow_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    dims = [128, 256, 256, 256, 3]
+    acts = [ops.ACT_RELU, ops.ACT_RELU, ops.ACT_RELU, ops.ACT_EXP_CLAMP]
+    Ws = [(torch.randn(dims[l + 1], dims[l], generator=gen) * (1.5 / dims[l] ** 0.5)).to(dev) for l in range(4)]
+    bs = [(0.1 * torch.randn(dims[l + 1], generator=gen)).to(dev) for l in range(4)]
+    count = torch.tensor([cnt], dtype=torch.int64, device=dev)
+    hs = [torch.randn(n, 128, generator=gen).to(dev)]
+    for l in range(4):
+        hs.append(ops.linear_fwd(hs[-1], Ws[l], bs[l], acts[l], 5.0, n_dev=count))
+    g = torch.randn(n, 3, generator=gen).to(dev)
+    ref, gy = {}, g
+    for l in (3, 2, 1, 0):
+        gx, gw, gb = ops.linear_bwd(hs[l], Ws[l], hs[l + 1], gy, acts[l], 5.0, need_gx=l > 0, n_dev=count)
+        ref[l] = (gw, gb)
+        gy = gx
+    got, gy, is_gz = {}, g, False
+    for l in (3, 2, 1, 0):
+        gx, gw, gb, gbx = ops.linear_bwd_fused(hs[l], Ws[l], hs[l + 1], gy, acts[l], 5.0, gy_is_gz=is_gz,
+                                               x_act=acts[l - 1] if l > 0 else ops.ACT_NONE, need_gx=l > 0, need_gbx=l > 0, n_dev=count)
+        got.setdefault(l, [None, None])[0] = gw
+        if not is_gz:
+            got[l][1] = gb
+        if l > 0:
+            got.setdefault(l - 1, [None, None])[1] = gbx
+        gy, is_gz = gx, l > 0
+    for l in range(4):
+        for a, b, name in ((got[l][0], ref[l][0], "weight"), (got[l][1], ref[l][1], "bias")):
+            err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+            assert err < 2e-5, (l, name, err)          # the same products; sums accumulate in another order (atomics)
