@@ -28,12 +28,56 @@ class LinearActFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class MlpChainFn(torch.autograd.Function):
+    """A whole stack of Linear + activation layers as ONE autograd node: forward = tf_linear_fwd per layer (outputs kept), backward =
+    tf_linear_bwd_fused down the stack -- each layer's data-gradient product also runs the activation backward of the layer below, so
+    no pass over the [rows, width] gradients remains between the layers (LinearActFn per layer: one such pass per layer).
+    args: x, n_dev, acts (tuple of (act, param) per layer), then weight, bias (or None) per layer."""
+
+    @staticmethod
+    def forward(ctx, x, n_dev, acts, *wb):
+        hs = [x.contiguous()]
+        ws = []
+        for l, (act, prm) in enumerate(acts):
+            w, b = wb[2 * l].contiguous(), wb[2 * l + 1]
+            ws.append(w)
+            hs.append(ops.linear_fwd(hs[-1].detach(), w.detach(), None if b is None else b.detach(), act, prm, n_dev=n_dev))
+        ctx.save_for_backward(*hs, *ws)
+        ctx.cfg = (acts, n_dev, [b is not None for b in wb[1::2]])
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        acts, n_dev, has_b = ctx.cfg
+        L_ = len(acts)
+        saved = ctx.saved_tensors
+        hs, ws = saved[:L_ + 1], saved[L_ + 1:]
+        grads = [None] * (2 * L_)
+        g, is_gz = gy.contiguous(), False
+        for l in range(L_ - 1, -1, -1):
+            below = l > 0
+            need_gx = below or ctx.needs_input_grad[0]
+            gx, gw, gb, gbx = ops.linear_bwd_fused(hs[l], ws[l], hs[l + 1], g, acts[l][0], acts[l][1], gy_is_gz=is_gz,
+                                                   x_act=acts[l - 1][0] if below else ops.ACT_NONE,
+                                                   x_act_param=acts[l - 1][1] if below else 0.0, need_gx=need_gx,
+                                                   need_gw=ctx.needs_input_grad[3 + 2 * l], need_gb=has_b[l] and ctx.needs_input_grad[4 + 2 * l],
+                                                   need_gbx=below and has_b[l - 1] and ctx.needs_input_grad[4 + 2 * (l - 1)], n_dev=n_dev)
+            grads[2 * l] = gw
+            if not is_gz:
+                grads[2 * l + 1] = gb
+            if below:
+                grads[2 * (l - 1) + 1] = gbx
+            g, is_gz = gx, below
+        return (g if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
 def mlp_apply(seq, x, n_dev=None):
     """Evaluate an nn.Sequential of Linear / activation modules (make_predictor_3layer / _4layer and TensoSDF.sdf_mat shapes) with
     every Linear + its following activation as ONE LinearActFn.  The modules keep their parameters (weight-norm parametrizations
     included: `layer.weight` composes g v / |v| under autograd) and their state_dict keys; only the arithmetic moves."""
     mods = list(seq)
     i = 0
+    layers = []
     while i < len(mods):
         m = mods[i]
         if not isinstance(m, torch.nn.Linear):
@@ -54,9 +98,15 @@ def mlp_apply(seq, x, n_dev=None):
                 act, prm = ops.ACT_EXP_CLAMP, float(a.max_light)
             else:
                 raise NotImplementedError(f"mlp_apply: activation {type(a).__name__}")
-        x = LinearActFn.apply(x, m.weight, m.bias, act, prm, n_dev)
+        layers.append((m, act, prm))
         i += step
-    return x
+    if len(layers) == 1:
+        m, act, prm = layers[0]
+        return LinearActFn.apply(x, m.weight, m.bias, act, prm, n_dev)
+    wb = []
+    for m, _, _ in layers:
+        wb += [m.weight, m.bias]
+    return MlpChainFn.apply(x, n_dev, tuple((a, p) for _, a, p in layers), *wb)
 
 
 class VmGatherFn(torch.autograd.Function):

@@ -578,7 +578,7 @@ int tf_linear_products(const float* X, const float* W, const float* gZ, long lon
 static int linear_products_x(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
                              const long long* n_dev, hipStream_t stream, int xact, float xact_param, float* gbx) {
   const bool h3 = precision == TF_PREC_F16X3;
-  const bool fuse = xact != TF_ACT_NONE && gX;
+  const bool fuse = (xact != TF_ACT_NONE || gbx) && gX;      // (a layer below without an activation still gets its bias gradient here)
   if (n == 0) return TF_OK;
   if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
     const long long* nd = n_dev;
@@ -716,6 +716,6 @@ extern "C" int tf_linear_bwd_fused(const float* X, const float* W, const float* 
     TF_LAUNCH_CHECK("tf_linear_bwd_fused(act)");
     gz = gZ;
   }
-  return linear_products_x(X, W, gz, n, K, N, precision, gX, gW, (const long long*)n_dev, stream, gX ? x_act : TF_ACT_NONE, x_act_param, gbx);
+  return linear_products_x(X, W, gz, n, K, N, precision, gX, gW, (const long long*)n_dev, stream, gX ? x_act : (int)TF_ACT_NONE, x_act_param, gbx);
 }
 
