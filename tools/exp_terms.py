@@ -6,7 +6,7 @@ from tensoflow_amd.shading import StageTimer, MCShader
 from tensoflow_amd.synth import sphere_surface_points
 dev = torch.device("cuda:0")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-names = {None: "f16x3", 3: "f16x2", 2: "f16", 0x201: "ring f16x3", 0x203: "ring f16x2", 0x202: "ring f16", 0: "f32"}
+names = {1: "f16x3", 3: "f16x2 (128-ray staggered form)", 0x403: "f16x2 (column-owned kernel)", 2: "f16", 0x201: "ring f16x3", 0x203: "ring f16x2", 0x202: "ring f16", 0: "f32"}
 # goldens
 for g in ("shading_small", "shading_default"):
     z = np.load(os.path.join(REPO, "tests", "golden", g + ".npz"))
@@ -15,7 +15,7 @@ for g in ("shading_small", "shading_default"):
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in z["sn"]]
     pts, view, nrm = [torch.from_numpy(z[k]).to(dev) for k in ("pts", "view_in", "normals_in")]
     sh = MCShader(sd, z["verts"], z["faces"], aabb, float(z["unit_size"]), device=dev, n_fixed_diffuse=n_fd)
-    for ip in (None, 3, 2, 0x201):
+    for ip in (1, 3, 2, 0x201):
         sh.inner_precision = ip
         out = sh.shade(pts, view, nrm, sn_d, sn_s)["colors"].cpu()
         d = (out - torch.from_numpy(z["out/rgb_pr_nis"])).abs()
@@ -24,7 +24,7 @@ pn = 65536
 sh, sd, verts, faces, aabb, unit = bench.build_scene(dev, 4, (224, 448, 256, 128))
 pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(pn, seed=6)]
 base = None
-for ip in (None, 3, 2, 0x201, 0x203, 0x202, 0):
+for ip in (1, 3, 0x403, 2, 0x201, 0x203, 0x202, 0):
     sh.inner_precision = ip
     sh.timer = bench_t = StageTimer()
     for _ in range(2): out = sh.shade(pts, view, nrm, 128, 128)
