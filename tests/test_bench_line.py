@@ -68,7 +68,7 @@ def test_emit_prints_exactly_one_stdout_line(capsys, tmp_path, monkeypatch):
 def test_compact_line_carries_both_tied_kernels():
     """Round 4: the inner-light kernel and the traversal take the same time within noise; the line holds the figures of both -- the
     one `roofline` describes and the other under `roofline_other` -- and names the longest stage, still under the limit."""
-    with open(os.path.join(REPO, "profiles", "r4p_bench_detail.json")) as f:
+    with open(os.path.join(REPO, "profiles", "r4q_bench_detail.json")) as f:
         line = json.load(f)
     assert line["roofline"]["kernel"] == "inner_light3_kernel" and "bvh_trace_kernel" in line["roofline_other"]
     got = _strict(bench.compact_line(line))
