@@ -59,6 +59,18 @@ typedef enum TfActivation {
 int tf_version(void);
 const char* tf_last_error(void);
 
+/* Launch budget of the three stage kernels of the rendering integral (per calling thread; 0 = the kernel's own default), read at
+ * enqueue time by tf_bvh_trace, tf_flow_sample_fwd / tf_flow_logq_fwd and tf_inner_light_indexed_fwd.  The reference runs
+ * sample -> get_lights -> reduce strictly one after another (network/fields.py:1085-1225); here a caller may run the stages of
+ * successive sub-batches on different streams, and whether two kernels are CO-RESIDENT on a CU is decided by registers, LDS and wave
+ * slots -- so each kernel can be told to take less than the whole CU:
+ *   bvh_blocks_per_cu    1..8: persistent traversal workgroups per CU (one wave per SIMD each, 72 registers; default: all that fit);
+ *   flow_waves_per_block 4 / 8 / 12: waves of the flow kernel's one workgroup per CU (one / two / three per SIMD, 168 registers each);
+ *   inner_teams          1: the inner-light kernel as ONE four-wave team per workgroup (one wave per SIMD, half a CU's registers, 88 KB of
+ *                        LDS); 2: the staggered two-team workgroup that owns a CU.
+ * Results do not depend on the budget (bit-identical). */
+int tf_set_launch_budget(int32_t bvh_blocks_per_cu, int32_t flow_waves_per_block, int32_t inner_teams);
+
 /* ------------------------------------------------------------------------------------------
  * VM-decomposed tensorial field (3 planes + 3 lines, C components each).
  * Replaces the 6 x dr.texture(...) + permute/contiguous + per-call mip rebuild of

@@ -11,6 +11,7 @@
 // Bound: fp32 MFMA (157 TF/s); HBM traffic is 16-20 B per sample.
 #include "mfma_mlp.h"
 #include "tf_common.h"
+#include "tf_internal.h"
 
 #define FLOW_NB 10
 static constexpr float kEps32 = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
@@ -642,7 +643,9 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   }
   TF_REQUIRE(pn < (1LL << 31), TF_ESHAPE, "%s: pn must be < 2^31", who);
   const long long tiles = (m + 63) / 64;   // 64-row groups
-  const int waves_per_block = h3 ? FLOW_WPB_H3 : 8;
+  // tf_set_launch_budget: 4 or 8 waves (one / two per SIMD) leave two thirds / one third of a CU's registers to another stream's kernel
+  const int wpb_budget = tf_launch_budget().flow_waves_per_block;
+  const int waves_per_block = h3 ? (wpb_budget > 0 && wpb_budget < FLOW_WPB_H3 ? wpb_budget : FLOW_WPB_H3) : (wpb_budget == 4 ? 4 : 8);
   long long blocks = (tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > 256) blocks = 256;  // one resident 8-wave workgroup per CU; waves loop over tiles
   if (precision == TF_PREC_F16)

@@ -7,10 +7,12 @@
 // (mfma_mlp.h); the 688 KB of fragment-ordered weights stream from L2 (256 coalesced bytes per MFMA).
 // Weight-norm is folded by the caller (effective W = g * v / |v|).
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mfma_mlp.h"
 #include "tf_common.h"
+#include "tf_internal.h"
 
 // fragment workspace layout (floats)
 static constexpr int kI1 = 0;                       // [8][64][64]   123 -> 256 (K padded to 128)
@@ -1045,12 +1047,12 @@ __device__ __forceinline__ void il4_publish(tf_h8* __restrict__ actl /* team ima
 // instructions per ray tile and four units, in a matrix step where every vector instruction is 4 idle cycles of the matrix pipe; the
 // packed operands are ReLU results (v_max), not MFMA results (the hazard of DESIGN 'things the compiler got wrong' 6).
 typedef float il4_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 256 */, int T, const f32x16 (&acc)[4], il4_f2 (&sum)[4][3]) {
+__device__ __forceinline__ void il4_out3(const float* __restrict__ w4h /* w4a + lane half * 128 */, int T, const f32x16 (&acc)[4], il4_f2 (&sum)[4][3]) {
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     float4 wr[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4h + c * 512 + T * 16 + 4 * qd);
+    for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4h + c * 256 + T * 16 + 4 * qd);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const il4_f2 xa = {tf_relu(acc[r][4 * qd]), tf_relu(acc[r][4 * qd + 1])}, xb = {tf_relu(acc[r][4 * qd + 2]), tf_relu(acc[r][4 * qd + 3])};
@@ -1094,8 +1096,14 @@ __device__ __forceinline__ void il3_save_acts(float* __restrict__ acts_l, long l
 // SAVE (64-ray form, training): the three hidden layers' post-ReLU activations are also written, acts[layer][row][256] with row = the
 // ray's position in the hit list (capacity rows per layer) -- what the backward pass of the net's dense layers (tf_linear_bwd) reads,
 // instead of recomputing the three 256-wide layers with the dense-layer kernels (LightsFn.backward: 1.2 ms of a 12 ms training step).
-template <bool OUTER, int TERMS, bool SAVE = false>
-__global__ void __launch_bounds__(512, 1)
+// TEAMS = 1 (tf_set_launch_budget inner_teams = 1): ONE team per 256-thread workgroup -- one wave per SIMD, 88 KB of LDS, half of
+// a CU's register file -- so that the traversal's (or another stream's) waves are resident beside it on every CU and issue in the
+// slots this team leaves (its vector steps FE / P1 / P2 leave the matrix pipe idle, its matrix steps the vector unit).  The team runs
+// the same six-step cycle; what the partner team hid is now hidden by a different kernel.
+// (128-ray form: 32-bit source indices -- the launcher checks the capacity -- : six registers instead of twelve across the matrix steps)
+template <int TERMS> using il3_src_t = std::conditional_t<TERMS == 3, long long, unsigned>;
+template <bool OUTER, int TERMS, bool SAVE = false, int TEAMS = 2>
+__global__ void __launch_bounds__(256 * TEAMS, TEAMS == 1 ? 2 : 1) __attribute__((amdgpu_num_vgpr(256)))
 inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
                     const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
                     const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
@@ -1106,34 +1114,34 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   long long m = m_arg;
   if (count_dev) m = min(m_arg, *count_dev);
   if (m <= 0) return;
-  __shared__ __attribute__((aligned(16))) tf_h8 act[2 * C::TEAM16];         // 128 KB: [team][k-step][ray tile][hi|lo][lane]
-  __shared__ __attribute__((aligned(16))) float lbias[3 * 512];             // [layer][lane half][tile * 16 + reg]
-  __shared__ __attribute__((aligned(16))) float w4a[3 * 512];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
+  __shared__ __attribute__((aligned(16))) tf_h8 act[TEAMS * C::TEAM16];     // 128 KB: [team][k-step][ray tile][hi|lo][lane]
+  __shared__ __attribute__((aligned(16))) float lbias[3 * 256];             // [layer][lane half][tile * 16 + reg] (128 per half)
+  __shared__ __attribute__((aligned(16))) float w4a[3 * 256];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
   // partial sums of the 256 -> 3 layer, [team][wave][ray tile * 3 + output][ray].  They live from step FE to the tail of step M1,
   // while k-steps 8..15 of the team's image are unused (the input row is 128 columns: k-steps 0..7; layer 3 has been read, layer 1 is
   // published one barrier later): the 128-ray form keeps them THERE (its stage is twice the size and the 160 KB are spent).
-  __shared__ float part_own[TERMS == 3 ? 2 * C::PART : 4];
-  __shared__ __attribute__((aligned(16))) float stage[2 * C::STAGE];        // [team]: hit point | normal | direction rows of the NEXT pass's rays (16 bytes per
+  __shared__ float part_own[TERMS == 3 ? TEAMS * C::PART : 4];
+  __shared__ __attribute__((aligned(16))) float stage[TEAMS * C::STAGE];    // [team]: hit point | normal | direction rows of the NEXT pass's rays (16 bytes per
                                                                             // ray and array: where a 12-byte LDS-DMA lands) and their depths
-  __shared__ long long stage_src[2 * RAYS];                                 // ... and their source indices
+  __shared__ il3_src_t<TERMS> stage_src[TEAMS * RAYS];                             // ... and their source indices
   __shared__ __attribute__((aligned(16))) float idem[36 * 20];              // IDE polynomial coefficients [column][power (17, padded to 20)]: read as
                                                                             // broadcast ds_read_b128 (through the scalar cache the 222 coefficients
                                                                             // of a ray went through v_mov copies into packed-FMA operands: 43 spills)
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), team = wave8 >> 2, w = wave8 & 3;
-  for (int i = tid; i < 36 * 20; i += 512) idem[i] = (i % 20) < 17 ? ws_arg[kIdeMat + (i % 20) * 36 + i / 20] : 0.f;
-  for (int i = tid; i < 3 * 256; i += 512) {
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6), team = TEAMS == 1 ? 0 : wave8 >> 2, w = wave8 & 3;
+  for (int i = tid; i < 36 * 20; i += 256 * TEAMS) idem[i] = (i % 20) < 17 ? ws_arg[kIdeMat + (i % 20) * 36 + i / 20] : 0.f;
+  for (int i = tid; i < 3 * 256; i += 256 * TEAMS) {
     const int layer = i / 256, r = i % 256;              // packed order (tf_pack_bias_kernel): r = n * 2 + half, n = tile * 16 + reg < 128
-    lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
-    w4a[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kW4a + i];
+    lbias[layer * 256 + (r & 1) * 128 + (r >> 1)] = ws_arg[kIB1 + i];
+    w4a[layer * 256 + (r & 1) * 128 + (r >> 1)] = ws_arg[kW4a + i];
   }
   const long long n_pass = (m + RAYS - 1) / RAYS;
-  const int n_iter = (int)((n_pass + 2LL * gridDim.x - 1) / (2LL * gridDim.x));
+  const int n_iter = (int)((n_pass + (long long)TEAMS * gridDim.x - 1) / ((long long)TEAMS * gridDim.x));
   const int T0 = 2 * w;
   tf_h8* actt = act + team * C::TEAM16;
   uint2* act8 = reinterpret_cast<uint2*>(actt);
   float* partt = TERMS == 3 ? part_own + team * C::PART : reinterpret_cast<float*>(actt + 8 * RT * C::XP * 64);
-  auto pass_of = [&](int it) { return ((long long)it * gridDim.x + blockIdx.x) * 2 + team; };
+  auto pass_of = [&](int it) { return ((long long)it * gridDim.x + blockIdx.x) * TEAMS + team; };
   // lane l of every wave of a team stands for ray l (and, in the 128-ray form, ray 64 + l) of the team's pass (the four waves split a
   // ray's FEATURES).
   // Input rows: every wave needs all of its ray's inputs, but they are GATHERED once per team and never pass through registers: in the
@@ -1142,9 +1150,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   // rows from there one pass later.  (Gathered by every wave into registers the rows cost four times the random requests and 19
   // registers held across the matrix steps.)
   float* staget = stage + team * C::STAGE;
-  long long* stage_srct = stage_src + team * RAYS;
-  // (128-ray form: 32-bit source indices -- the launcher checks the capacity -- : six registers instead of twelve across the matrix steps)
-  typedef std::conditional_t<TERMS == 3, long long, unsigned> src_t;
+  il3_src_t<TERMS>* stage_srct = stage_src + team * RAYS;
+  typedef il3_src_t<TERMS> src_t;
   src_t src_nxt[NR];                           // source index of ray 64 e + lane of the next pass to gather
   src_t src_cur[NR], src_out[NR];              // ... of the pass in flight / of the pass being stored
   float dep_out[NR], dep_cur[NR];
@@ -1202,7 +1209,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #else
 #define IL3_STAMP(i) do {} while (0)
 #endif
-  if (team == 1) { il3_barrier(); il3_barrier(); il3_barrier(); }
+  if (TEAMS == 2 && team == 1) { il3_barrier(); il3_barrier(); il3_barrier(); }
   typedef const __attribute__((address_space(1))) tf_h8* gw_t;      // weights are read as GLOBAL loads (a generic pointer makes them flat loads,
                                                                      // which count against lgkmcnt as well and serialise with the LDS reads)
   for (int it = 0; it <= n_iter; ++it) {
@@ -1246,7 +1253,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         for (int qd = 0; qd < 4; ++qd) {
           float4 wr[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4a + c * 512 + hh_o * 256 + (T0 + t) * 16 + 4 * qd);
+          for (int c = 0; c < 3; ++c) wr[c] = *reinterpret_cast<const float4*>(w4a + c * 256 + hh_o * 128 + (T0 + t) * 16 + 4 * qd);
 #pragma unroll
           for (int r = 0; r < RT; ++r) {
             const float x0 = tf_relu(acc[t][r][4 * qd]), x1 = tf_relu(acc[t][r][4 * qd + 1]);
@@ -1410,11 +1417,11 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     if (live) {
       if constexpr (TERMS == 2) {
         constexpr int K1 = OUTER ? 5 : 8;
-        il4_half<K1, true, 0>((gw_t)(W + kQ1 / 4), T0, lane, lbias + hh * 256, actt + lane, ring, acc[0]);
+        il4_half<K1, true, 0>((gw_t)(W + kQ1 / 4), T0, lane, lbias + hh * 128, actt + lane, ring, acc[0]);
         il4_pack(acc[0], held);
-        il4_half<K1, false, K1 % (IL4_PF + 1)>((gw_t)(W + kQ1 / 4), T0 + 1, lane, lbias + hh * 256, actt + lane, ring, acc[0]);
+        il4_half<K1, false, K1 % (IL4_PF + 1)>((gw_t)(W + kQ1 / 4), T0 + 1, lane, lbias + hh * 128, actt + lane, ring, acc[0]);
       } else {
-      il3_bias<RT>(lbias + hh * 256, T0, acc);
+      il3_bias<RT>(lbias + hh * 128, T0, acc);
 #ifndef IL3_ABLATE_M    // dev-only timing ablation: no matrix products
       // (the direction-encoded outer net has 72 input columns: five k-steps, the rest of its image is zero)
       il3_layer<OUTER ? 5 : 8, TERMS>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
@@ -1473,8 +1480,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
       IL3_STAMP(4 * layer + 2);
       if constexpr (TERMS == 2) {
         il3_gw_t Wl = (gw_t)(W + (layer == 1 ? kH2 : kH3) / 4);
-        const float* lb = lbias + layer * 512 + hh * 256;
-        const float* w4h = w4a + hh * 256;
+        const float* lb = lbias + layer * 256 + hh * 128;
+        const float* w4h = w4a + hh * 128;
         il4_half<16, true, 0>(Wl, T0, lane, lb, actt + lane, ring, acc[0]);
 #ifdef IL4_STAMP_HALF
         if (layer == IL4_STAMP_HALF && it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 7] = __builtin_readcyclecounter();
@@ -1494,7 +1501,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         il4_half<16, false, 16 % (IL4_PF + 1)>(Wl, T0 + 1, lane, lb, actt + lane, ring, acc[0]);
         if (layer == 2) il4_out3(w4h, T0 + 1, acc[0], fsum);
       } else {
-      il3_bias<RT>(lbias + layer * 512 + hh * 256, T0, acc);
+      il3_bias<RT>(lbias + layer * 256 + hh * 128, T0, acc);
 #ifndef IL3_ABLATE_M
       il3_layer<16, TERMS>((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, actt + lane, ring, acc);
 #endif
@@ -1505,7 +1512,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     }
   }
   // `break` above leaves after the FE barrier of the step that has no pass: 6 n_iter + 1 barriers so far for either team
-  if (team == 0) { il3_barrier(); il3_barrier(); il3_barrier(); }
+  if (TEAMS == 2 && team == 0) { il3_barrier(); il3_barrier(); il3_barrier(); }
 }
 
 // Layer-1 weights with the columns in the order of the column-owned kernel's input row: [IDE (72) | pos_enc8 (51)].
@@ -1579,11 +1586,18 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   const bool cols = (precision == TF_PREC_F16 || precision == TF_PREC_F16X2) && !ring;
 #endif
 #ifndef IL3_OFF
+  const bool one_team = tf_launch_budget().inner_teams == 1 && !outer && !acts;
+  // one single-team workgroup per CU: two would fit (81.7 KB of LDS, 256 registers per wave) and leave nothing for the kernel this
+  // budget makes room for, so the launch asks for 8 KB of (unused) dynamic LDS on top
+  static const bool il1_nopad = getenv("TF_IL1_NOPAD") != nullptr;      // dev: two unsynchronised single-team workgroups per CU
+  const size_t il1_pad = il1_nopad ? 0 : 8192;
   if (precision == TF_PREC_F16X3 && !ring) {
     // staggered two-team kernel: one 512-thread workgroup per CU, two 64-ray passes in flight
     long long blocks = ((m + 63) / 64 + 1) / 2;
-    if (blocks > 256) blocks = 256;
-    if (outer) inner_light3_kernel<true, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    if (one_team) blocks = (m + 63) / 64;
+    if (blocks > (one_team && il1_nopad ? 512 : 256)) blocks = one_team && il1_nopad ? 512 : 256;
+    if (one_team) inner_light3_kernel<false, 3, false, 1><<<(unsigned)blocks, 256, il1_pad, stream>>>(IL_ARGS);
+    else if (outer) inner_light3_kernel<true, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     else if (acts) inner_light3_kernel<false, 3, true><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS, acts);
     else inner_light3_kernel<false, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
@@ -1593,8 +1607,10 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     // ... its 128-ray form: two 128-ray passes in flight (source indices are carried as 32-bit values)
     TF_REQUIRE(m <= 0x7fffffffLL, TF_ESHAPE, "%s: more than 2^31 - 1 rays in one call", who);
     long long blocks = ((m + 127) / 128 + 1) / 2;
-    if (blocks > 256) blocks = 256;
-    if (outer) inner_light3_kernel<true, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
+    if (one_team) blocks = (m + 127) / 128;
+    if (blocks > (one_team && il1_nopad ? 512 : 256)) blocks = one_team && il1_nopad ? 512 : 256;
+    if (one_team) inner_light3_kernel<false, 2, false, 1><<<(unsigned)blocks, 256, il1_pad, stream>>>(IL_ARGS);
+    else if (outer) inner_light3_kernel<true, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     else inner_light3_kernel<false, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     TF_LAUNCH_CHECK(who);
     return TF_OK;

@@ -341,11 +341,15 @@ __global__ void __launch_bounds__(256) sample_ray_merge_kernel(const float* __re
     if (sdf_out) sdf_out[r * So + i + c] = sdf[r * S + i];
   }
   if (lane < n_imp) {
+    // rank by FULL counting, as a stable sort orders them: the inverse-CDF value b0 + frac * fl(b1 - b0) can exceed b1 by an ulp while
+    // the next sample equals b1, so the new samples are not assumed to arrive sorted among themselves (every output slot is written
+    // exactly once whatever the order)
     const float v = Nn[lane];
     int c = 0;
     for (int i = 0; i < S; ++i) c += Z[i] <= v ? 1 : 0;
-    z_out[r * So + lane + c] = v;
-    if (sdf_out) sdf_out[r * So + lane + c] = nsdf[r * n_imp + lane];
+    for (int j = 0; j < n_imp; ++j) c += (Nn[j] < v || (Nn[j] == v && j < lane)) ? 1 : 0;
+    z_out[r * So + c] = v;
+    if (sdf_out) sdf_out[r * So + c] = nsdf[r * n_imp + lane];
   }
 }
 

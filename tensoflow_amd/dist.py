@@ -122,7 +122,8 @@ class GradientExchange:
         ex.zero_grad()            # instead of optimizer.zero_grad(set_to_none=True): zeroes the buckets, re-attaches the views
         loss.backward()           # hooks fire; complete buckets are already on the wire
         ex.finish(expected)       # buckets whose hooks did not all fire are sent now; waits; parameters outside `expected`
-                                  # that received nothing get grad = None again (the optimizer must not step them)
+                                  # get grad = None again (the optimizer must not step them; one that DID receive a gradient
+                                  # is a broken contract: the hook raises)
     A parameter that receives no gradient on THIS rank but does on another still takes part as zeros, as in allreduce_gradients."""
 
     def __init__(self, params, world=None, bucket_bytes=64 << 20, mode="auto", stats=None):
@@ -225,6 +226,14 @@ class GradientExchange:
         self._fired.add(id(p))
         counted = getattr(self, "_expected", None) is None or id(p) in self._expected
         b = self.buckets[slot[0]]
+        if not counted:
+            # A parameter the caller declared gradient-free at this step (zero_grad(expected=...)) received one.  Its bucket is not
+            # held back for it, so the bucket may already be on the wire -- autograd would then be accumulating into a buffer an
+            # asynchronous reduce-scatter / all-gather is reading and writing -- and the ranks would step it with un-averaged
+            # numbers.  `expected` is a contract every rank evaluates identically: breaking it is an error, not a slow path.
+            name = next((n for n, q in getattr(self, "named", {}).items() if q is p), f"shape {tuple(p.shape)}")
+            raise RuntimeError(f"GradientExchange: parameter {name} is outside this step's `expected` set but received a gradient"
+                               + (" after its bucket was sent" if b["sent"] else ""))
         v = b["views"][slot[1]]
         if p.grad is not v:
             # autograd replaced the view (first accumulation into an undefined / non-writable grad): put the numbers where they belong
@@ -260,7 +269,7 @@ class GradientExchange:
         if expected is not None:
             keep = {id(p) for p in expected}
             for p in self.params:
-                if id(p) not in keep and id(p) not in self._fired:
+                if id(p) not in keep:          # (none of them can have fired: _on_grad raises)
                     p.grad = None
         return sum(1 for b in self.buckets if b["sent"])
 
@@ -276,3 +285,43 @@ def gather_rows(local_rows, n_total, rank, world):
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], 0)
+
+
+def rank_world(rank=None, world=None):
+    """(rank, world) of this process: the arguments if given, else torch.distributed's, else (0, 1)."""
+    on = dist.is_available() and dist.is_initialized()
+    if world is None:
+        world = dist.get_world_size() if on else 1
+    if rank is None:
+        rank = dist.get_rank() if on else 0
+    return int(rank), int(world)
+
+
+def gather_maps(maps, n_total, rank, world):
+    """Frame assembly of a tiled `nvs` (materialRenderer.py:705-752 chunks a frame in 512-ray pieces on one GPU; here the pieces
+    are the multi-GPU unit): every rank holds rows shard_range(n_total, rank, world) of each per-pixel map
+    {key: [n_local, C]} (float, or bool masks); ONE all-gather of the channel-concatenated rows returns {key: [n_total, C]} on every
+    rank (an 800 x 800 frame with the material stage's 15 maps + hit mask is 32 floats per pixel = 82 MB)."""
+    if world == 1:
+        return maps
+    keys = list(maps)
+    widths = [maps[k].shape[1] if maps[k].dim() > 1 else 1 for k in keys]
+    lo, hi = shard_range(n_total, rank, world)
+    for k in keys:
+        if maps[k].shape[0] != hi - lo:
+            raise RuntimeError(f"gather_maps: rank {rank} holds {maps[k].shape[0]} rows of `{k}`, its shard of {n_total} is {hi - lo}")
+    flat = torch.cat([maps[k].reshape(hi - lo, -1).float() for k in keys], 1)
+    if flat.is_cuda and dist.get_backend() == "gloo":        # 1-GPU dry runs of the N-rank path: staged through the host
+        full = gather_rows(flat.cpu(), n_total, rank, world).to(flat.device)
+    else:
+        full = gather_rows(flat, n_total, rank, world)
+    out, c0 = {}, 0
+    for k, wd in zip(keys, widths):
+        v = full[:, c0:c0 + wd]
+        c0 += wd
+        if maps[k].dtype == torch.bool:
+            v = v > 0.5
+        else:
+            v = v.to(maps[k].dtype)
+        out[k] = v if maps[k].dim() > 1 else v[:, 0]
+    return out

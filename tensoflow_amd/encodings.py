@@ -46,9 +46,12 @@ def ide5(xyz, kappa_inv, wide=False):
     the direction to ~2e-3 (tools/gen_golden.py:gen_shading_direction measures both against an fp64 run) -- so where the training
     direction differentiates THROUGH the encoding (the 'direction' outer light under the roughness-warped fixed samplers) the wide
     form keeps this implementation's noise below the reference's instead of adding a second, independent copy of it."""
-    if xyz.is_cuda and xyz.dim() == 2 and xyz.dtype == torch.float32 and (torch.is_tensor(kappa_inv) or kappa_inv == 0):
+    if xyz.is_cuda and xyz.dim() == 2 and xyz.shape[1] == 3 and xyz.dtype == torch.float32 and _kappa_fits(xyz, kappa_inv):
         # round 4: one kernel forward, one backward (tf_ide5_fwd / tf_ide5_bwd: fp64 Horner on the fp32-rounded table, i.e. the `wide`
-        # evaluation for every caller) instead of ~120 element-wise launches and autograd's ~250
+        # evaluation for every caller) instead of ~120 element-wise launches and autograd's ~250.  The kernel reads kappa[r] for every
+        # row r: a broadcastable kappa_inv (0-dim, [1,1]) is expanded to one value per row first.
+        if torch.is_tensor(kappa_inv) and kappa_inv.numel() != xyz.shape[0]:
+            kappa_inv = kappa_inv.reshape(-1, 1).expand(xyz.shape[0], 1)
         return Ide5Fn.apply(xyz, kappa_inv if torch.is_tensor(kappa_inv) else None)
     if wide:
         return _ide5_wide(xyz, kappa_inv)
@@ -73,6 +76,14 @@ def ide5(xyz, kappa_inv, wide=False):
     return torch.cat([re * poly * att, im * poly * att], -1)
 
 
+def _kappa_fits(xyz, kappa_inv):
+    """The fused kernels take kappa_inv as None (== 0) or as ONE fp32 value per row on xyz's device (after broadcasting)."""
+    if not torch.is_tensor(kappa_inv):
+        return kappa_inv == 0
+    return (kappa_inv.dtype == torch.float32 and kappa_inv.device == xyz.device and kappa_inv.numel() in (1, xyz.shape[0])
+            and (kappa_inv.dim() <= 1 or kappa_inv.shape[-1] == 1))
+
+
 class Ide5Fn(torch.autograd.Function):
     """ide5 on the device: forward tf_ide5_fwd, backward tf_ide5_bwd (closed form wrt the direction and kappa_inv)."""
 
@@ -87,6 +98,11 @@ class Ide5Fn(torch.autograd.Function):
     def forward(ctx, xyz, kappa_inv):
         from . import ops
         xyz = xyz.contiguous()
+        if xyz.dim() != 2 or xyz.shape[1] != 3 or xyz.dtype != torch.float32:
+            raise RuntimeError(f"Ide5Fn: xyz must be fp32 [n,3], got {xyz.dtype} {tuple(xyz.shape)}")
+        if kappa_inv is not None and (kappa_inv.numel() != xyz.shape[0] or kappa_inv.dtype != torch.float32 or kappa_inv.device != xyz.device):
+            raise RuntimeError(f"Ide5Fn: kappa_inv must hold one fp32 value per row on {xyz.device}, got {kappa_inv.dtype} "
+                               f"{tuple(kappa_inv.shape)} on {kappa_inv.device} for {xyz.shape[0]} rows")
         kap = None if kappa_inv is None else kappa_inv.reshape(-1).contiguous()
         ctx.save_for_backward(xyz, kap if kap is not None else torch.empty(0, device=xyz.device))
         ctx.has_kap = kap is not None

@@ -236,7 +236,9 @@ class MCShadingNetwork(nn.Module):
         old = self._shader
         self._shader = MCShader(sd, v, f, self.aabb, self.unit_size, device="cuda", n_fixed_diffuse=self.cfg["diffuse_sample_num"],
                                 exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"],
-                                bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"])
+                                bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"],
+                                # not a reference key: "f16x2" opts in to the narrower inner-light operands (MCShader.__init__); default f16x3
+                                inner_precision={"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[self.cfg.get("inner_light_operands", "f16x3")])
         if self._composed_lights:
             self._shader.overlap_dirs = False      # (the composed miss branch allocates between the streams' kernels: keep one stream)
         self._shader_version = ver

@@ -230,33 +230,55 @@ class MaterialRenderer(nn.Module):
     def compute_diffuse_light_regularization(self, diffuse_lights):
         return torch.sum(torch.abs(diffuse_lights - torch.mean(diffuse_lights, dim=-1, keepdim=True)), dim=-1) * self.cfg["reg_diffuse_light_lambda"]
 
+    NVS_KEYS = {"color": 3, "normal": 3, "spec_light": 3, "diff_light": 3, "indirect_light": 3, "spec_color": 3, "diff_color": 3, "albedo": 3,
+                "roughness": 1, "metallic": 1, "occ_trace": 1, "variance_diffuse_vis": 1, "variance_specular_vis": 1,
+                "variance_diffuse_vis_nis": 1, "variance_specular_vis_nis": 1}
+
+    @staticmethod
+    def assemble_frame(local, hit_local, h, w, rank, world):
+        """The frame from every rank's rows: `local` {key: [n_local, C]} and `hit_local` [n_local] bool are rows
+        dist.shard_range(h * w, rank, world) of the per-pixel maps; one all-gather (dist.gather_maps), then the ONE thing the reference's
+        512-ray chunk loop decides on the whole frame: a pixel that misses gets the normal (0,0,1) inside `if sum(hit) > 0`
+        (materialRenderer.py:713,725), i.e. only in 512-ray chunks -- counted from pixel 0 of the FRAME, whatever the tiling -- that
+        contain a hit.  -> {key: [h,w,C] numpy}."""
+        from .. import dist as tdist
+        rn = h * w
+        full = tdist.gather_maps(dict(local, _hit=hit_local), rn, rank, world)
+        hit_all = full.pop("_hit")
+        pad = (-rn) % 512
+        blk = torch.cat([hit_all, hit_all.new_zeros(pad)]).view(-1, 512).any(1).repeat_interleave(512)[:rn]
+        nz = full["normal"][:, 2]
+        full["normal"] = torch.cat([full["normal"][:, :2], torch.where(~hit_all & blk, torch.ones_like(nz), nz)[:, None]], 1)
+        return {k: v.reshape(h, w, -1).cpu().numpy() for k, v in full.items()}
+
     @torch.no_grad()
-    def nvs(self, pose, K, h, w, chunk=65536):
+    def nvs(self, pose, K, h, w, chunk=65536, rank=None, world=None):
         """materialRenderer.py:641-752 (nerfDataType rays, :647-672): primary rays -> BVH -> SDF refinement (32 + 9 evaluations) ->
         MCShadingNetwork.forward(step=None) on the pixels that see the object -> dict of 15 [h,w,C] numpy maps under the reference's
         keys (:707): colour (white background, :743), normal, specular / diffuse / indirect light, specular / diffuse colour, albedo,
         roughness (sqrt of the squared prediction, :739), metallic, occ_trace (= visibility) and the four variance maps, which the
-        reference leaves at zero (their assignments are commented out, :732-735).  The reference shades 512 rays per pass; `chunk`
-        only sizes the launches here -- except for ONE thing its chunk loop decides: a pixel that misses gets the normal (0,0,1)
-        inside `if sum(hit) > 0` (:713,725), i.e. only in 512-ray chunks that contain a hit; reproduced below."""
+        reference leaves at zero (their assignments are commented out, :732-735).  The reference shades 512 rays per pass on one GPU
+        (:705-709); `chunk` only sizes the launches here, and with world > 1 (default: torch.distributed's rank / world when a process
+        group is up) those pieces are the multi-GPU unit: this rank renders rows dist.shard_range(h * w, rank, world) of the frame and
+        `assemble_frame` all-gathers the maps, so every rank returns the whole frame ('tile the image, all-gather')."""
+        from .. import dist as tdist
         dev = self.device
         K = torch.from_numpy(np.asarray(K, np.float32)).to(dev)
         pose = torch.from_numpy(np.asarray(pose, np.float32)).to(dev)
         h, w = int(h), int(w)
+        rank, world = tdist.rank_world(rank, world)
+        lo, hi = tdist.shard_range(h * w, rank, world)
         i, j = torch.meshgrid(torch.linspace(0, w - 1, w, device=dev), torch.linspace(0, h - 1, h, device=dev), indexing="ij")
         i, j = i.t(), j.t()
-        dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)
+        dirs = torch.stack([(i - K[0][2]) / K[0][0], -(j - K[1][2]) / K[1][1], -torch.ones_like(i)], -1).reshape(-1, 3)[lo:hi]
         rays_d = F.normalize(dirs @ pose[:3, :3].t(), dim=-1).contiguous()
-        rays_o = pose[:3, 3].expand(h * w, 3).contiguous()
-        rn = h * w
+        rn = hi - lo
+        rays_o = pose[:3, 3].expand(rn, 3).contiguous()
         human = self.shader_network.cfg["human_lights"]
         if human:
             from ..dataset import human_coordinate_poses
             hp_all = human_coordinate_poses(pose[None, :3], self.cfg.get("fixed_camera", False))[0]
-        keys = {"color": 3, "normal": 3, "spec_light": 3, "diff_light": 3, "indirect_light": 3, "spec_color": 3, "diff_color": 3, "albedo": 3,
-                "roughness": 1, "metallic": 1, "occ_trace": 1, "variance_diffuse_vis": 1, "variance_specular_vis": 1,
-                "variance_diffuse_vis_nis": 1, "variance_specular_vis_nis": 1}
-        out = {k: torch.zeros(rn, c, device=dev) for k, c in keys.items()}
+        out = {k: torch.zeros(rn, c, device=dev) for k, c in self.NVS_KEYS.items()}
         out["color"][:] = 1.0
         hit_all = torch.zeros(rn, dtype=torch.bool, device=dev)
         src = {"color": "rgb_pr", "spec_light": "specular_light", "diff_light": "diffuse_light", "indirect_light": "indirect_light",
@@ -274,11 +296,7 @@ class MaterialRenderer(nn.Module):
                 out[k][s + idx] = sh[sk]
             out["normal"][s + idx] = nrm[idx]
             out["roughness"][s + idx] = torch.sqrt(sh["roughness"])      # predictions are squared roughness (:739)
-        # normal of the pixels that miss: (0,0,1) where the reference's 512-ray chunk holds a hit, zero elsewhere (:713,725)
-        pad = (-rn) % 512
-        blk = torch.cat([hit_all, hit_all.new_zeros(pad)]).view(-1, 512).any(1).repeat_interleave(512)[:rn]
-        out["normal"][:, 2] = torch.where(~hit_all & blk, torch.ones_like(out["normal"][:, 2]), out["normal"][:, 2])
-        return {k: v.reshape(h, w, -1).cpu().numpy() for k, v in out.items()}
+        return self.assemble_frame(out, hit_all, h, w, rank, world)
 
     @torch.no_grad()
     def predict_materials(self, batch_size=8192):

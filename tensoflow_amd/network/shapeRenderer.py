@@ -364,9 +364,11 @@ class ShapeRenderer(nn.Module):
 
     # ------------------------------------------------------------------------------ novel view
     @torch.no_grad()
-    def nvs(self, pose, K, h, w):
+    def nvs(self, pose, K, h, w, rank=None, world=None):
         """shapeRenderer.py:569-668 (nerfDataType ray construction) -> dict of [h,w,C] numpy arrays.  The reference renders 2048
-        rays per pass (launch-bound); here `test_ray_num` rays per pass, default raised by the caller as HBM allows."""
+        rays per pass (launch-bound); here `test_ray_num` rays per pass, default raised by the caller as HBM allows.  With world > 1
+        (default: torch.distributed's rank / world when a process group is up) this rank marches rows dist.shard_range(h * w, rank,
+        world) of the frame and one all-gather assembles the maps on every rank."""
         if not self.cfg["nerfDataType"]:
             raise NotImplementedError("the reference's non-NeRF ray construction raises as well (:577)")
         dev = self.device
@@ -388,20 +390,24 @@ class ShapeRenderer(nn.Module):
         keys = {"color": "ray_rgb", "albedo": "albedo", "roughness": "roughness", "normal": "normal", "normal_vis": "normal_vis",
                 "occ_predict": "occ_prob", "occ_trace": "occ_prob_gt", "diff_color": "diffuse_color", "spec_color": "specular_color",
                 "diff_light": "diffuse_light", "spec_light": "specular_light", "indirect_light": "indirect_light"}
+        from .. import dist as tdist
+        rank, world = tdist.rank_world(rank, world)
+        lo, hi = tdist.shard_range(h * w, rank, world)
         output = {k: [] for k in keys}
         trn = self.cfg["test_ray_num"]
-        for ri in range(0, h * w, trn):
-            sl = slice(ri, ri + trn)
+        for ri in range(lo, hi, trn):
+            sl = slice(ri, min(ri + trn, hi))
             batch = {"rays_o": rays_o[sl].contiguous(), "rays_d": rays_d[sl].contiguous(), "dirs": dirs[sl].contiguous(),
                      "radiis": radiis[sl].contiguous(), "rays_cos": rays_cos[sl].contiguous()}
             near, far = self.near_far_from_sphere(batch["rays_o"], batch["rays_d"])
             cur = self.render(batch, near, far, None, is_train=False, step=300000)
             for k, src in keys.items():
-                output[k].append(cur[src].detach().cpu().numpy())
-        for k in output:
-            val = np.concatenate(output[k], 0)
-            output[k] = np.reshape(val, [h, w, val.shape[-1]])
-        return output
+                output[k].append(cur[src].detach().reshape(sl.stop - sl.start, -1))
+        local = {k: (torch.cat(v, 0) if v else torch.zeros(0, 1, device=dev)) for k, v in output.items()}
+        if world > 1 and lo == hi:        # (more ranks than rows: this rank contributes nothing, its maps still need the right widths)
+            raise RuntimeError("ShapeRenderer.nvs: fewer pixels than ranks")
+        full = tdist.gather_maps(local, h * w, rank, world)
+        return {k: v.reshape(h, w, -1).cpu().numpy() for k, v in full.items()}
 
     # ------------------------------------------------------------------------------ dataset side (TensoSDF synthetic scenes)
     def _init_dataset(self):

@@ -142,6 +142,11 @@ def _sdf_mlp(w1, b1, w2, b2):
     return m, keep
 
 
+def set_launch_budget(bvh_blocks_per_cu=0, flow_waves_per_block=0, inner_teams=0):
+    """tf_set_launch_budget: how much of a CU the traversal / flow / inner-light kernels launched next (by this thread) take; 0 = default."""
+    L.check(L.load().tf_set_launch_budget(int(bvh_blocks_per_cu), int(flow_waves_per_block), int(inner_teams)), "tf_set_launch_budget")
+
+
 _ws_cache = {}
 
 

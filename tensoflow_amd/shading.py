@@ -263,19 +263,18 @@ class MCShader:
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False,
-                 light_exp_max=5.0):
+                 light_exp_max=5.0, inner_precision=None):
         self.device = device
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
-        # Inner-light decoder (123-256-256-256-3), round 4: ops.PREC_F16X2 -- weights split hi + lo (fp32-grade), the ACTIVATIONS
-        # rounded to f16 once per layer (two MFMAs per product term, 128-ray passes of the staggered kernel).  Measured against an
-        # fp64 evaluation of the net (tools/exp_il_precision.py, 262 k rays): per ray this mode's worst case and 99.9th percentile sit
-        # BELOW those of the reference's own fp32 arithmetic (stress net: 1.85e-3 / 8.5e-4 against 2.15e-3 / 9.3e-4 -- the degree-16
-        # IDE polynomials cancel in fp32, whatever multiplies them afterwards), its rms is 2.5 x the reference's (2.4e-4 against
-        # 9.6e-5), and a pixel averages ~100 such rays: every golden holds at 1e-4 per pixel, per ray all modes stay inside the 3e-3
-        # band (tests/test_gpu_parity.py::test_inner_light_operand_modes_on_trained_like_net).  ops.PREC_F16X3 (every operand split:
-        # the bench reports it as `inner_light_f16x3`) and ops.PREC_F32 stay selectable; ops.PREC_F16 (weights rounded as well) is an
-        # explicit opt-in, never a default.
-        self.inner_precision = ops.PREC_F16X2
+        # Inner-light decoder (123-256-256-256-3).  Library default: ops.PREC_F16X3 -- every operand split hi + lo, the arithmetic of the
+        # flow nets and the per-point nets (fp32-grade: 22 significant bits per operand).  ops.PREC_F16X2 is an explicit opt-in
+        # (`inner_precision=` here, `--inner-precision f16x2` in bench.py, which labels its line accordingly): weights split hi + lo, the
+        # ACTIVATIONS rounded to f16 once per layer (two MFMAs per product term, 128-ray passes of the staggered kernel).  Measured
+        # against an fp64 evaluation of the net (tools/exp_il_precision.py, 262 k rays): per ray its worst case and 99.9th percentile
+        # sit below those of the reference's own fp32 arithmetic, its rms is 2.5 x the reference's, every golden holds at 1e-4 per pixel
+        # (tests/test_gpu_parity.py::test_inner_light_operand_modes_on_trained_like_net) -- tolerance-meeting, but narrower than the
+        # reference's fp32, hence never what a caller gets without asking.  ops.PREC_F16 (weights rounded as well) likewise.
+        self.inner_precision = ops.PREC_F16X3 if inner_precision is None else int(inner_precision)
         self.cull_dead_rays = True      # skip BVH + inner light for rays whose weight is exactly 0 (result unchanged)
         self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
         self.unit = float(unit_size)

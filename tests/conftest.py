@@ -51,7 +51,13 @@ def rel_err(a, b):
     """max |a-b| / max(|b|, 1) -- the 'relative fp32' measure used throughout.  For quantities below 1 (colours, alpha, sdf,
     roughness, weights) this is an ABSOLUTE bound; `true_rel_err` below is the relative one."""
     a, b = a.double(), b.double()
-    return float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) if a.numel() else 0.0
+    v = float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) if a.numel() else 0.0
+    if os.environ.get("TF_PARITY_LOG"):      # dev: every call site with both measures (which sites can be held to the relative one?)
+        import inspect
+        fr = inspect.stack()[1]
+        with open(os.environ["TF_PARITY_LOG"], "a") as f:
+            f.write(f"{os.path.basename(fr.filename)}:{fr.lineno}\t{fr.function}\t{v:.3e}\t{true_rel_err(a, b):.3e}\t{float(b.abs().max()) if b.numel() else 0:.3e}\n")
+    return v
 
 
 def true_rel_err(a, b, floor=1e-3):

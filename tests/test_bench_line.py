@@ -77,3 +77,25 @@ def test_compact_line_carries_both_tied_kernels():
     assert other["bound"] == "hbm" and 0 < other["frac"] < 1 and other["avg_launch_ms"] > 0
     assert got["config"]["inner_light_operands"].startswith("f16x2")
     assert len(bench.compact_line(line)) < 3072
+
+
+def test_compact_line_carries_the_stricter_readings_of_the_headline():
+    """Round 5: `dtype` names the narrowest operand format per net; the fp32-grade and the with-aux-maps values, both forms of the
+    dominant kernel's roofline, the hit-fraction probes and the psnr leg under both operand modes ride in the ONE line."""
+    with open(os.path.join(REPO, "profiles", "r4q_bench_detail.json")) as f:
+        line = json.load(f)
+    line["dtype"] = "f32 ABI; f16x3 flow/point nets; f16x2 inner light"
+    line["value_fp32_grade"] = 4.98e6
+    line["value_with_aux"] = 4.40e6
+    line["inner_light_f16x3"]["roofline"] = dict(kernel="inner_light3_kernel<.,3> (64-ray form)", bound="mfma", achieved=445.0, peak=2500.0, unit="TFLOP/s",
+                                                 frac=0.178, avg_launch_ms=21.8, executed_tflops=1400.0, frac_executed=0.56)
+    line["hit_fraction_probes"] = {"headline": [0.1475, 5.78e6], "scene_points": [0.136, 5.98e6], "fat_torus_scene": [0.25, 4.6e6], "note": "n" * 300}
+    line["psnr"]["inner_light_modes"] = {"f16x2": [0.9892, 1.79e-3], "f16x3": [0.9898, 1.8e-3], "same_outlier_points": False, "outliers_in_one_mode_only": 6,
+                                         "note": "n" * 300}
+    text = bench.compact_line(line)
+    assert len(text) < 3072
+    got = _strict(text)
+    assert got["dtype"].endswith("f16x2 inner light") and got["value_fp32_grade"] == 4.98e6 and got["value_with_aux"] == 4.40e6
+    assert got["roofline_f16x3"]["frac"] == 0.178 and got["roofline"]["frac"] > got["roofline_f16x3"]["frac"]
+    assert got["hit_fraction_probes"]["fat_torus_scene"] == [0.25, 4.6e6] and "note" not in got["hit_fraction_probes"]
+    assert got["psnr"]["inner_light_modes"]["outliers_in_one_mode_only"] == 6 and "note" not in got["psnr"]["inner_light_modes"]

@@ -15,6 +15,31 @@ def dev():
     return torch.device("cuda:0")
 
 
+def test_ide5_broadcast_kappa_and_argument_checks(dev):
+    """A kappa_inv that broadcasts against the rows ([1,1], 0-dim, a Python 0) is valid in the torch composition the kernel replaced;
+    the fused path expands it to one value per row instead of reading past its end, and Ide5Fn rejects what it cannot take."""
+    from tensoflow_amd import encodings as E
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.nn.functional.normalize(torch.randn(257, 3, generator=g), dim=-1).to(dev)
+    full = E.ide5(xyz, torch.full((257, 1), 0.3, device=dev))
+    k11 = torch.full((1, 1), 0.3, device=dev, requires_grad=True)
+    out = E.ide5(xyz, k11)
+    assert torch.equal(out, full)
+    gk, = torch.autograd.grad(out.sum(), [k11])
+    kf = torch.full((257, 1), 0.3, device=dev, requires_grad=True)
+    gf, = torch.autograd.grad(E.ide5(xyz, kf).sum(), [kf])
+    assert gk.shape == (1, 1) and abs(float(gk) - float(gf.sum())) < 1e-4 * abs(float(gf.sum()))
+    assert torch.equal(E.ide5(xyz, torch.tensor(0.3, device=dev)), full)
+    assert torch.equal(E.ide5(xyz, 0), E.ide5(xyz, torch.zeros(257, 1, device=dev)))
+    with pytest.raises(RuntimeError, match="one fp32 value per row"):
+        E.Ide5Fn.apply(xyz, torch.zeros(5, 1, device=dev))
+    with pytest.raises(RuntimeError, match=r"fp32 \[n,3\]"):
+        E.Ide5Fn.apply(xyz[:, :2], None)
+    # kappa on another device / dtype: the torch composition serves it (no kernel reads it)
+    half = E.ide5(xyz, torch.full((257, 1), 0.3, device=dev, dtype=torch.float64))
+    assert float((half.float() - full).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("n,with_kappa", [(5000, True), (777, False), (1, True)])
 def test_ide5_kernel_forward_and_backward(dev, n, with_kappa):
     from tensoflow_amd import encodings as E

@@ -59,6 +59,25 @@ def test_sample_ray_bit_exact_indices(golden, dev):
     assert rel_err(near.cpu(), g["near"]) < 1e-6 and rel_err(far.cpu(), g["far"]) < 1e-6
 
 
+def test_sample_ray_merge_is_a_stable_sort_for_any_order_of_the_new_samples(dev):
+    """tf_sample_ray_merge == torch.sort(cat([z, new_t]), stable) (shapeRenderer.py:851-869) also when the new samples do NOT arrive
+    sorted among themselves (the inverse-CDF value b0 + frac * fl(b1 - b0) can exceed b1 by an ulp while the next sample equals b1)
+    and when values tie (old samples first, then new ones in their own order): every output slot is written exactly once."""
+    from tensoflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rn, S, n_imp = 301, 96, 16
+    z = torch.sort(torch.rand(rn, S, generator=g), dim=-1)[0]
+    new_t = torch.rand(rn, n_imp, generator=g)                       # unsorted
+    new_t[:, 3] = z[:, 10]                                           # ties with an old sample ...
+    new_t[:, 7] = new_t[:, 2]                                        # ... and among the new ones
+    new_t[:, 9] = torch.nextafter(new_t[:, 8], torch.ones(rn))       # one ulp apart, out of order
+    sdf, nsdf = torch.randn(rn, S, generator=g), torch.randn(rn, n_imp, generator=g)
+    z_out, sdf_out = ops.sample_ray_merge(z.to(dev), sdf.to(dev), new_t.to(dev), nsdf.to(dev))
+    zz, idx = torch.sort(torch.cat([z, new_t], -1), dim=-1, stable=True)
+    assert torch.equal(z_out.cpu(), zz)
+    assert torch.equal(sdf_out.cpu(), torch.gather(torch.cat([sdf, nsdf], -1), 1, idx))
+
+
 @pytest.mark.parametrize("rn,perturb,cap", [(1023, False, None), (257, True, 100.0), (3, False, 20.0)])
 def test_sample_ray_kernels_match_torch_composition(golden, dev, rn, perturb, cap):
     """tf_sample_ray_init / _upsample / _merge (round 4) against the torch composition they replace (march.sample_ray_torch, itself
