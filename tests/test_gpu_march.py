@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AABB, rel_err
+from conftest import AABB, parity, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -27,14 +27,14 @@ def check_aux(out, ref, sfx="", human_expected=False, tol=TOL):
     fp32): held relative to each array's scale (true_rel_err, floor 1e-3 of its maximum) at 10x the pixel tolerance."""
     from conftest import true_rel_err
     for k in AUX_MAPS:
-        assert rel_err(out[k + sfx].detach().cpu(), ref(k + sfx)) < tol, k + sfx
+        parity(out[k + sfx].detach().cpu(), ref(k + sfx), tol=tol, label=f"shade_mixed aux {k + sfx}")
     for k in AUX_VARS:
         got, want = out[k + sfx].detach().cpu(), ref(k + sfx)
         assert got.shape == want.shape, (k + sfx, got.shape, want.shape)
         assert true_rel_err(got, want) < 10 * tol, (k + sfx, true_rel_err(got, want))
     hl, hl_ref = out["human_lights" + sfx].cpu(), ref("human_lights" + sfx)
     assert hl.shape == hl_ref.shape, (hl.shape, hl_ref.shape)                # one row per unmasked specular ray that misses
-    assert rel_err(hl, hl_ref) < tol
+    parity(hl, hl_ref, tol=tol, label="shade_mixed human_lights")
     assert (float(hl_ref.abs().max()) > 0.1) == human_expected
     inter, inter_ref = out["inter" + sfx].cpu(), ref("inter" + sfx)
     assert inter.shape == inter_ref.shape
@@ -54,9 +54,11 @@ def test_sample_ray_bit_exact_indices(golden, dev):
     c = lambda k: g[k].to(dev)
     t0, t1, ridx = march.sample_ray(f, c("rays_o"), c("dirs"), c("near"), c("far"), c("radiis"), c("rays_cos"), float(g["base_radii"]))
     assert ridx.dtype == torch.int64 and torch.equal(ridx.cpu(), g["ray_indices"])       # bit-exact
-    assert rel_err(t0.cpu(), g["t_starts"]) < TOL and rel_err(t1.cpu(), g["t_ends"]) < TOL
+    parity(t0.cpu(), g["t_starts"], label="sample_ray_bit_exact_indices:57.0")
+    parity(t1.cpu(), g["t_ends"], label="sample_ray_bit_exact_indices:57.1")
     near, far = march.near_far_from_sphere(c("rays_o"), c("dirs"))
-    assert rel_err(near.cpu(), g["near"]) < 1e-6 and rel_err(far.cpu(), g["far"]) < 1e-6
+    parity(near.cpu(), g["near"], abs_tol=1e-6, label="sample_ray_bit_exact_indices:59.0")
+    parity(far.cpu(), g["far"], abs_tol=1e-6, label="sample_ray_bit_exact_indices:59.1")
 
 
 def test_sample_ray_merge_is_a_stable_sort_for_any_order_of_the_new_samples(dev):
@@ -110,10 +112,10 @@ def test_shape_shading(golden, dev):
     ridx = g["ray_indices"]
     nrm = torch.nn.functional.normalize(g["sa_grad"], dim=-1)
     col, occ, rough, refl = sh(g["sample_pts"].to(dev), nrm.to(dev), (-g["dirs"][ridx]).to(dev), g["sa_feat"].to(dev))
-    assert rel_err(col.cpu(), g["shade_color"]) < TOL
-    assert rel_err(occ.cpu(), g["shade_occ_prob"]) < TOL
-    assert rel_err(rough.cpu(), g["shade_roughness"]) < TOL
-    assert rel_err(refl.cpu(), g["shade_reflective"]) < TOL
+    parity(col.cpu(), g["shade_color"], label="shape_shading:113")
+    parity(occ.cpu(), g["shade_occ_prob"], label="shape_shading:114")
+    parity(rough.cpu(), g["shade_roughness"], label="shape_shading:115")
+    parity(refl.cpu(), g["shade_reflective"], label="shape_shading:116")
 
 
 def test_shape_shading_ragged_and_degenerate(golden, dev):
@@ -135,8 +137,10 @@ def test_shape_shading_ragged_and_degenerate(golden, dev):
     feat = torch.randn(n, 128, generator=gen) * 0.5
     col, occ, rough, refl = sh(pts.to(dev), nrm.to(dev), view.to(dev), feat.to(dev))
     rc, ro, rr, rf = om.shape_shade(g.sd, env, g["fg_lut"], pts, nrm, view, feat)
-    assert rel_err(col.cpu(), rc) < TOL and rel_err(occ.cpu(), ro) < TOL
-    assert rel_err(rough.cpu(), rr) < TOL and rel_err(refl.cpu(), rf) < TOL
+    parity(col.cpu(), rc, label="shape_shading_ragged_and_degenerate:138.0")
+    parity(occ.cpu(), ro, label="shape_shading_ragged_and_degenerate:138.1")
+    parity(rough.cpu(), rr, label="shape_shading_ragged_and_degenerate:139.0")
+    parity(refl.cpu(), rf, label="shape_shading_ragged_and_degenerate:139.1")
 
 
 def test_render_core(golden, dev):
@@ -150,8 +154,8 @@ def test_render_core(golden, dev):
     out = march.render_core(f, c("rays_o"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"),
                             float(g["base_radii"]), inv_s, 0.5, shade_fn=lambda p, n, v, ft: sh(p, n, v, ft)[0])
     for k in ("ray_rgb", "acc", "normal", "gradient_error", "loss_sparse"):
-        assert rel_err(out[k].cpu(), g["rc/" + k]) < TOL, k
-    assert rel_err(out["loss_hessian"].cpu(), g["rc/loss_hessian"]) < 2e-3
+        parity(out[k].cpu(), g["rc/" + k], label=f"render_core {k}")
+    parity(out["loss_hessian"].cpu(), g["rc/loss_hessian"], tol=2e-3, label="render_core loss_hessian")
     # size-independent properties: weights of a ray sum to acc <= 1, rgb in [0, 1]
     assert float(out["acc"].max()) <= 1 + 1e-5 and float(out["ray_rgb"].min()) >= -1e-6
 
@@ -172,13 +176,13 @@ def test_march_full_size_properties(dev):
     assert (t0[1:][same] >= t0[:-1][same] - 1e-6).all()                    # sorted along each ray
     out = march.render_core(f, o, d, radii, cos, t0, t1, ridx, base_radii, 20.0, 1.0)
     w_sum = torch.zeros(4096, device=dev).index_add_(0, ridx, out["weights"])
-    assert rel_err(w_sum.cpu(), out["acc"][:, 0].cpu()) < 1e-5             # checksum of the scan
+    parity(w_sum.cpu(), out["acc"][:, 0].cpu(), abs_tol=1e-5, label="march_full_size_properties:175")  # checksum of the scan
     assert float(out["acc"].max()) <= 1 + 1e-5 and float(out["acc"].mean()) > 0.01
     # linearity of compositing in the values
     v = torch.randn(ridx.shape[0], 3, device=dev)
     _, _, a = ops.composite(out["alpha"], ridx, v, 4096)
     _, _, b = ops.composite(out["alpha"], ridx, 2 * v, 4096)
-    assert rel_err((2 * a).cpu(), b.cpu()) < 1e-6
+    parity((2 * a).cpu(), b.cpu(), abs_tol=1e-6, label="march_full_size_properties:181")
 
 
 # ------------------------------------------------------------------------------- drop-in modules
@@ -189,10 +193,11 @@ def test_module_tensosdf(golden, dev):
     m.load_state_dict(g.sd)
     with torch.no_grad():
         out = m(g["pts"].to(dev), g["level"].to(dev))
-        assert rel_err(out.cpu(), g["out_lvl"]) < TOL
-        assert rel_err(m.sdf(g["pts"].to(dev)).cpu(), g["out_none"][:, :1]) < TOL
+        parity(out.cpu(), g["out_lvl"], label="module_tensosdf:192")
+        parity(m.sdf(g["pts"].to(dev)).cpu(), g["out_none"][:, :1], label="module_tensosdf:193")
         grad, nh = m.gradient(g["pts"].to(dev), g["level"].to(dev), training=True, sdf=out[:, :1])
-        assert rel_err(grad.cpu(), g["grad_lvl"]) < TOL and rel_err(nh.cpu(), g["normal_hessian"]) < 2e-3
+        parity(grad.cpu(), g["grad_lvl"], label="module_tensosdf:195.0")
+        parity(nh.cpu(), g["normal_hessian"], tol=2e-3, label="module_tensosdf:195.1")
         grad0, none = m.gradient(g["pts"].to(dev), None, training=False)
         assert none is None and rel_err(grad0.cpu(), g["grad_none"]) < TOL
         # parameters changed in place -> the packed pyramid is rebuilt
@@ -208,11 +213,12 @@ def test_module_tensoflow(golden, dev):
     m.eval()
     c = lambda k: g[k].to(dev)
     with torch.no_grad():
-        assert rel_err(m.tenso_feature(c("pts")).cpu(), g["cond_feat"]) < TOL
+        parity(m.tenso_feature(c("pts")).cpu(), g["cond_feat"], label="module_tensoflow:211")
         ang, logj = m.sample(c("pts"), c("view_angles"), c("roughness"), 32, return_jacobian=True)
         assert float(torch.quantile((ang.cpu() - g["angles_32"]).abs().flatten(), 0.999)) < TOL
         z, logq = m(c("pts"), c("view_angles"), c("roughness"), c("x_rid"), return_jacobian=True, rays_id=c("rays_id"))
-        assert rel_err(z.cpu(), g["z_rid"]) < TOL and rel_err(logq.cpu(), g["logq_rid"]) < TOL
+        parity(z.cpu(), g["z_rid"], label="module_tensoflow:215.0")
+        parity(logq.cpu(), g["logq_rid"], label="module_tensoflow:215.1")
 
 
 def test_module_mcshading(golden, dev):
@@ -226,19 +232,19 @@ def test_module_mcshading(golden, dev):
     assert not missing, missing                                  # every parameter of the mirror exists in the reference checkpoint
     m.shader()
     colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)   # autograd on: flow pass
-    assert rel_err(colors.detach().cpu(), g.out["rgb_pr_nis"]) < TOL
-    assert rel_err(outputs["albedo"].detach().cpu(), g.out["albedo"]) < TOL
+    parity(colors.detach().cpu(), g.out["rgb_pr_nis"], label="module_mcshading:229")
+    parity(outputs["albedo"].detach().cpu(), g.out["albedo"], label="module_mcshading:230")
     # eval (no autograd, step=None): the reference runs the fixed-sampler pass (-> colors and the plain outputs) and the
     # flow-sampler pass (-> the *_nis outputs), fields.py:1467-1473
     with torch.no_grad():
         colors, outputs = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
-    assert rel_err(colors.cpu(), g["colors"]) < TOL
-    assert rel_err(outputs["rgb_pr_nis"].cpu(), g.out["rgb_pr_nis"]) < TOL
+    parity(colors.cpu(), g["colors"], label="module_mcshading:235")
+    parity(outputs["rgb_pr_nis"].cpu(), g.out["rgb_pr_nis"], label="module_mcshading:236")
     for k in ("albedo", "roughness", "metallic", "diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility",
               "indirect_light"):
-        assert rel_err(outputs[k].cpu(), g.out[k]) < TOL, k
+        parity(outputs[k].cpu(), g.out[k], label=f"MCShadingNetwork outputs {k}")
         if k + "_nis" in g.out:
-            assert rel_err(outputs[k + "_nis"].cpu(), g.out[k + "_nis"]) < TOL, k + "_nis"
+            parity(outputs[k + "_nis"].cpu(), g.out[k + "_nis"], label=f"MCShadingNetwork outputs {k}_nis")
     for sfx in ("", "_nis"):
         check_aux(outputs, lambda k: g.out[k], sfx)
         assert float(outputs["loss_nis" + sfx]) == 0.0
@@ -304,11 +310,11 @@ def test_update_alpha_mask_golden(golden, dev):
     f = march.SdfField(base.sd, AABB, [32, 32, 32], 3, device=dev)
     inv_s, thres, mul = float(g["inv_s"]), float(g["thres"]), float(g["mul_length"])
     m1, aabb1, raw1 = march.update_alpha_mask(f, inv_s, grid=(24, 20, 28), thres=thres, mul_length=mul, return_alpha=True)
-    assert rel_err(raw1.cpu(), g["alpha_24x20x28"]) < TOL
+    parity(raw1.cpu(), g["alpha_24x20x28"], label="update_alpha_mask_golden:307")
     assert torch.equal(m1.volume.cpu().bool(), g["mask1"].bool())
     assert torch.allclose(aabb1.cpu(), g["aabb1"], atol=1e-6)
     m2, aabb2, raw2 = march.update_alpha_mask(f, inv_s, grid=(40, 40, 40), thres=thres, mul_length=mul, prev=m1, return_alpha=True)
-    assert rel_err(raw2.cpu(), g["alpha_40_masked"]) < TOL
+    parity(raw2.cpu(), g["alpha_40_masked"], label="update_alpha_mask_golden:311")
     assert torch.equal(m2.volume.cpu().bool(), g["mask2"].bool())
     assert torch.allclose(aabb2.cpu(), g["aabb2"], atol=1e-6)
     assert 0.1 < float(m2.volume.float().mean()) < 0.4
@@ -323,8 +329,9 @@ def test_trace_sdf_with_mesh(golden, dev):
     inters, normals, depth, hit = surface.trace_sdf_with_mesh(bvh, f, g["rays_o"].to(dev), g["rays_d"].to(dev), float(g["inv_s"]),
                                                              float(g["unit_size"]))
     assert torch.equal(hit.cpu(), g["hit"].bool())
-    assert rel_err(depth.cpu(), g["depth"]) < TOL and rel_err(inters.cpu(), g["inters"]) < TOL
-    assert rel_err(normals.cpu(), g["normals"]) < 5e-4      # FD normal of a normalised difference of ~1e-3-sized sdf values
+    parity(depth.cpu(), g["depth"], label="trace_sdf_with_mesh:326.0")
+    parity(inters.cpu(), g["inters"], label="trace_sdf_with_mesh:326.1")
+    parity(normals.cpu(), g["normals"], tol=5e-4, label="trace_sdf_with_mesh:327")  # FD normal of a normalised difference of ~1e-3-sized sdf values
 
 
 def test_render_frame_small(golden, dev):
@@ -345,7 +352,7 @@ def test_render_frame_small(golden, dev):
     inters, nrm, depth, hit = surface.trace_sdf_with_mesh(sh.bvh, f, o, d, float(gr["inv_s"]), float(gr["unit_size"]))
     idx = torch.nonzero(hit[:, 0])[:, 0]
     direct = sh.shade(inters[idx], -d[idx], nrm[idx], 16, 8)["colors"]
-    assert rel_err(out["color"][idx].cpu(), direct.cpu()) < 1e-6
+    parity(out["color"][idx].cpu(), direct.cpu(), abs_tol=1e-6, label="render_frame_small:348")
 
 
 def test_tensoflow_backward_golden(golden, dev):
@@ -356,7 +363,7 @@ def test_tensoflow_backward_golden(golden, dev):
     m.load_state_dict(g.sd)
     c = lambda k: g[k].to(dev)
     z, logq = m(c("pts"), c("view_angles"), c("roughness"), c("x_rand"), return_jacobian=True)
-    assert rel_err(logq.detach().cpu(), g["logq_rand"]) < TOL
+    parity(logq.detach().cpu(), g["logq_rand"], label="tensoflow_backward_golden:359")
     (-(c("bwd_w") * logq).mean()).backward()
     checked = 0
     for name, p in m.named_parameters():
@@ -391,11 +398,11 @@ def test_mcshading_training_step_golden(golden, dev):
     m.eval()
     m.use_flow_diffuse_copy = m.use_flow_specular_copy = True          # as after update_step(999): the flow copies sample
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, 600, False)
-    assert rel_err(colors.detach().cpu(), g["colors"]) < TOL
+    parity(colors.detach().cpu(), g["colors"], label="mcshading_training_step_golden:394")
     assert abs(float(out["loss_nis_diffuse"]) - float(g["loss_nis_diffuse"])) < 1e-4 * max(1, abs(float(g["loss_nis_diffuse"])))
     assert abs(float(out["loss_nis_specular"]) - float(g["loss_nis_specular"])) < 1e-4 * max(1, abs(float(g["loss_nis_specular"])))
     for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light"):
-        assert rel_err(out[k].detach().cpu(), g["out600/" + k]) < TOL, k
+        parity(out[k].detach().cpu(), g["out600/" + k], label=f"MCShadingNetwork training outputs {k}")
     check_aux(out, lambda k: g["out600/" + k])             # `variance` is what the reference trainer's progress line reads (trainer_inv.py:299)
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     worst, checked = 0.0, 0
@@ -436,12 +443,12 @@ def test_mcshading_training_step_before_flow_copies_golden(golden, dev, step):
     m.eval()
     assert not m.use_flow_diffuse_copy and not m.use_flow_specular_copy
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, step, False)
-    assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    parity(colors.detach().cpu(), g[f"colors_{step}"], label="mcshading_training_step_before_flow_copies_golden:439")
     for k in ("loss_nis_diffuse", "loss_nis_specular"):
         ref = float(g[f"{k}_{step}"])
         assert abs(float(out[k]) - ref) < 1e-4 * max(1, abs(ref)), (k, float(out[k]), ref)
     for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light"):
-        assert rel_err(out[k].detach().cpu(), g[f"out{step}/" + k]) < TOL, k
+        parity(out[k].detach().cpu(), g[f"out{step}/" + k], label=f"MCShadingNetwork training outputs (step {step}) {k}")
     check_aux(out, lambda k: g[f"out{step}/" + k])
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     grads = {k[len(f"grad{step}/"):]: v for k, v in g.a.items() if k.startswith(f"grad{step}/")}
@@ -529,14 +536,14 @@ def test_direction_outer_light_eval_golden(golden, dev):
     assert float(((hl - g["gl_lights"][~miss]).abs() / g["gl_lights"][~miss].abs().clamp_min(1e-2)).max()) < 1e-3     # inner light on the hits
     with torch.no_grad():
         colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
-    assert rel_err(colors.cpu(), g["colors"]) < TOL
+    parity(colors.cpu(), g["colors"], label="direction_outer_light_eval_golden:532")
     for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light", "rgb_pr_nis",
               "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis", "specular_light_nis"):
-        assert rel_err(out[k].cpu(), g.out[k]) < TOL, k
+        parity(out[k].cpu(), g.out[k], label=f"direction outer light outputs {k}")
     # the throughput path (zero-weight rays culled: their rows are never evaluated) gives the same colours
     sh.cull_dead_rays = True
     o2 = sh.shade(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), sn_d, sn_s)
-    assert rel_err(o2["colors"].cpu(), g.out["rgb_pr_nis"]) < TOL
+    parity(o2["colors"].cpu(), g.out["rgb_pr_nis"], label="direction_outer_light_eval_golden:539")
     # lat-long image of the learned light (fields.py:1475-1510) goes through the same net
     img = m.env_light(8, 16)
     assert img.shape == (8, 16, 3) and torch.isfinite(img).all()
@@ -551,7 +558,7 @@ def test_direction_outer_light_training_golden(golden, dev, step):
     if step >= 1000:
         m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, step, False)
-    assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    parity(colors.detach().cpu(), g[f"colors_{step}"], label="direction_outer_light_training_golden:554")
     check_aux(out, lambda k: g[f"out{step}/" + k])
     if step >= 1000:
         assert abs(float(out["loss_nis"]) - float(g["loss_nis_1200"])) < 1e-4 * max(1, abs(float(g["loss_nis_1200"])))
@@ -615,10 +622,10 @@ def test_sphere_direction_and_human_lights_eval_golden(golden, dev):
     poses = g["human_poses"].to(dev)
     with torch.no_grad():
         colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), poses, None, False)
-    assert rel_err(colors.cpu(), g["colors"]) < TOL
+    parity(colors.cpu(), g["colors"], label="sphere_direction_and_human_lights_eval_golden:618")
     for k in ("diffuse_light", "specular_light", "diffuse_color", "specular_color", "visibility", "indirect_light", "rgb_pr_nis",
               "diffuse_color_nis", "specular_color_nis", "visibility_nis", "indirect_light_nis", "diffuse_light_nis", "specular_light_nis"):
-        assert rel_err(out[k].cpu(), g.out[k]) < TOL, k
+        parity(out[k].cpu(), g.out[k], label=f"sphere_direction outputs {k}")
     for sfx in ("", "_nis"):
         check_aux(out, lambda k: g.out[k], sfx, human_expected=True)       # human_lights * human_weights of the missing specular rays
     img = m.env_light(8, 16)                          # predict_outer_lights_pts('sphere_direction') feeds the direction's IDE twice (:1515-1516)
@@ -636,7 +643,7 @@ def test_sphere_direction_and_human_lights_training_golden(golden, dev, step):
     if step >= 1000:
         m.use_flow_diffuse_copy = m.use_flow_specular_copy = True
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), g["human_poses"].to(dev), step, False)
-    assert rel_err(colors.detach().cpu(), g[f"colors_{step}"]) < TOL
+    parity(colors.detach().cpu(), g[f"colors_{step}"], label="sphere_direction_and_human_lights_training_golden:639")
     check_aux(out, lambda k: g[f"out{step}/" + k], human_expected=True)
     ((colors * g["bwd_w"].to(dev)).sum() + out["loss_nis"]).backward()
     grads = {k[len(f"grad{step}/"):]: v for k, v in g.a.items() if k.startswith(f"grad{step}/")}
@@ -672,7 +679,7 @@ def test_sdf_alpha_training_golden(golden, dev):
     rn = int(g["n_rays"])
     alpha, grad, feat, sdf, nh = SdfAlphaFn.apply(c("pts"), c("level")[:, 0].contiguous(), c("dists"), c("dirs"), inv_s, 0.5, AABB, units,
                                                   3, *params)
-    assert rel_err(alpha.detach().cpu(), g["alpha"]) < TOL
+    parity(alpha.detach().cpu(), g["alpha"], label="sdf_alpha_training_golden:675")
     vals = torch.cat([grad, feat[:, :8]], -1).contiguous()
     w, acc, out = CompositeFn.apply(alpha, vals, c("ray_indices"), rn)
     inv_vec = inv_s.expand(alpha.shape[0]).clip(1e-6, 1e6)

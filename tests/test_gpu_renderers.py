@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import AABB, rel_err
+from conftest import AABB, parity, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -51,7 +51,7 @@ def test_cube_lookup_direction_gradient(dev):
     tref = tex.clone().requires_grad_(True)
     (ot.cube_bilinear(tref, dref) * gout).sum().backward()
     g_base, g_dirs = ops.cube_lookup_bwd_dirs(tex.to(dev), d.to(dev), gout.to(dev), apply_exp=False)
-    assert rel_err(g_base.cpu(), tref.grad) < TOL
+    parity(g_base.cpu(), tref.grad, label="cube_lookup_direction_gradient:54")
     # a direction within float rounding of a texel boundary picks the other cell on one side: compare away from them
     err = ((g_dirs.cpu() - dref.grad).abs() / dref.grad.abs().clamp_min(1.0)).amax(-1)
     assert float(torch.quantile(err, 0.995)) < TOL and float((err > 1e-3).float().mean()) < 0.005
@@ -67,26 +67,27 @@ def test_shape_renderer_render_core_inference(golden, dev):
         t0, t1, ridx = r.sample_ray(c("rays_o"), c("dirs"), c("near"), c("far"), 0, radiis=c("radiis"), rays_cos=c("rays_cos"))
         assert torch.equal(ridx.cpu(), g["ray_indices"]) and rel_err(t0.cpu(), g["t_starts"]) < TOL
         near, far = r.near_far_from_sphere(c("rays_o"), c("dirs"))
-        assert rel_err(near.cpu(), g["near"]) < 1e-6
+        parity(near.cpu(), g["near"], abs_tol=1e-6, label="shape_renderer_render_core_inference:70")
         out = r.render_core(c("rays_o"), c("dirs"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"),
                             None, cos_anneal_ratio=0.5, step=100, is_train=True)
         for k in ("ray_rgb", "acc", "normal", "gradient_error", "std", "loss_sparse"):
-            assert rel_err(out[k].cpu(), g["rc/" + k]) < TOL, k
-        assert rel_err(out["loss_hessian"].cpu(), g["rc/loss_hessian"]) < 2e-3
+            parity(out[k].cpu(), g["rc/" + k], label=f"render_core(train) {k}")
+        parity(out["loss_hessian"].cpu(), g["rc/loss_hessian"], tol=2e-3, label="render_core(train) loss_hessian")
         # compute_sdf_alpha with the three anneal ratios of the golden
         mid = (c("t_starts") + c("t_ends")) * 0.5
         for ca in (0.0, 0.5, 1.0):
             alpha, grad, feat, inv_s, sdf, hess = r.compute_sdf_alpha(c("sample_pts"), c("sample_levels"), c("t_ends") - c("t_starts"),
                                                                     c("dirs")[c("ray_indices")], ca, 100, True)
-            assert rel_err(alpha.cpu(), g[f"alpha_{ca}"]) < TOL
-        assert rel_err(inv_s.cpu(), g["sa_inv_s"]) < 1e-6 and rel_err(feat.cpu(), g["sa_feat"]) < TOL
+            parity(alpha.cpu(), g[f"alpha_{ca}"], label=f"compute_sdf_alpha alpha (cos anneal {ca})")
+        parity(inv_s.cpu(), g["sa_inv_s"], abs_tol=1e-6, label="shape_renderer_render_core_inference:82.0")
+        parity(feat.cpu(), g["sa_feat"], label="shape_renderer_render_core_inference:82.1")
         # the validation branch produces the reference's keys and stays finite
         val = r.render_core(c("rays_o"), c("dirs"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"),
                             None, cos_anneal_ratio=1.0, step=300000, is_train=False)
         for k in ("normal_vis", "depth", "occ_prob_gt", "albedo", "roughness", "metallic", "diffuse_color", "specular_color", "diffuse_light",
                   "specular_light", "indirect_light", "occ_prob"):
             assert k in val and torch.isfinite(val[k]).all(), k
-        assert rel_err(val["ray_rgb"].cpu(), out["ray_rgb"].cpu()) < 0.2           # different anneal ratio only
+        parity(val["ray_rgb"].cpu(), out["ray_rgb"].cpu(), tol=0.2, absolute=True, label="render_core validation-vs-train ray_rgb (different anneal ratio)")  # different anneal ratio only
 
 
 def _eval_renderer(golden, dev):
@@ -126,8 +127,7 @@ def test_shape_renderer_validation_branch_golden(golden, dev):
     assert int((ge["val/occ_prob_gt"] > 1e-3).sum()) > 40                          # the fixture exercises the trace
     for k in VAL_KEYS:
         assert k in val, k
-        e = rel_err(val[k].cpu().reshape(ge["val/" + k].shape), ge["val/" + k])
-        assert e < TOL, (k, e)
+        parity(val[k].cpu().reshape(ge["val/" + k].shape), ge["val/" + k], label=f"render_core(validation) {k}")
 
 
 def test_shape_renderer_nvs_golden(golden, dev):
@@ -172,7 +172,8 @@ def test_shape_shading_network_composed_matches_fused(golden, dev):
     assert col_c.requires_grad
     for a, b, k in ((col_f, col_c, "shade_color"), (occ_f["occ_prob"], occ_c["occ_prob"], "shade_occ_prob"),
                     (occ_f["roughness"], occ_c["roughness"], "shade_roughness"), (occ_f["reflective"], occ_c["reflective"], "shade_reflective")):
-        assert rel_err(a.cpu(), g[k]) < TOL and rel_err(b.detach().cpu(), g[k]) < TOL, k
+        parity(a.cpu(), g[k], label=f"shape shading fused {k}")
+        parity(b.detach().cpu(), g[k], label=f"shape shading composed {k}")
 
 
 def test_shape_renderer_training_gradients(golden, dev):
@@ -183,7 +184,7 @@ def test_shape_renderer_training_gradients(golden, dev):
     c = lambda k: g[k].to(dev)
     out = r.render_core(c("rays_o"), c("dirs"), c("dirs"), c("radiis"), c("rays_cos"), c("t_starts"), c("t_ends"), c("ray_indices"), None,
                         cos_anneal_ratio=0.5, step=100, is_train=True)
-    assert rel_err(out["ray_rgb"].detach().cpu(), g["rc/ray_rgb"]) < TOL
+    parity(out["ray_rgb"].detach().cpu(), g["rc/ray_rgb"], label="shape_renderer_training_gradients:186")
     ((out["ray_rgb"] * c("bwd_w")).sum() + out["acc"].sum() + 0.1 * out["gradient_error"].mean()).backward()
     checked, worst = 0, 0.0
     for name, p in r.named_parameters():
@@ -216,8 +217,8 @@ def test_shape_renderer_late_training_golden(golden, dev):
                         cos_anneal_ratio=0.6, step=30000, is_train=True)
     for res, tag in ((fused, "fused"), (out, "autograd")):
         for k in ("ray_rgb", "acc", "normal", "radiance", "roughness_weights", "std", "loss_occ", "loss_gaussian", "loss_tv_sdf", "loss_sparse"):
-            assert rel_err(res[k].detach().cpu().reshape(g["rc/" + k].shape), g["rc/" + k]) < TOL, (tag, k)
-        assert rel_err(res["loss_hessian"].detach().cpu(), g["rc/loss_hessian"]) < 2e-3
+            parity(res[k].detach().cpu().reshape(g["rc/" + k].shape), g["rc/" + k], label=f"render_core(late training) {k}")
+        parity(res["loss_hessian"].detach().cpu(), g["rc/loss_hessian"], tol=2e-3, label="render_core(late training) loss_hessian")
     w = c("bwd_w")
     loss = ((out["ray_rgb"] * w).sum() + (out["radiance"] * w.flip(0)).sum() + out["acc"].sum() + 0.1 * out["gradient_error"].mean()
             + out["loss_occ"].sum() + 1e-3 * out["loss_gaussian"] + out["loss_tv_sdf"] + 0.1 * out["loss_sparse"])
@@ -251,7 +252,7 @@ def test_shape_renderer_alpha_mask_and_nvs(golden, dev):
         assert 0.0 < keep < 1.0
         culled = r.render_core(*args, cos_anneal_ratio=0.5, step=2000, is_train=True)
         assert culled["sample_num"] <= ref["sample_num"]
-        assert rel_err(culled["ray_rgb"].cpu(), ref["ray_rgb"].cpu()) < 5e-3        # only near-zero-opacity samples are dropped
+        parity(culled["ray_rgb"].cpu(), ref["ray_rgb"].cpu(), tol=5e-3, absolute=True, label="alpha-mask culled ray_rgb")  # only near-zero-opacity samples are dropped
         # checkpoint round trip carries the mask
         ck = r.ckpt_to_save()
         r2 = _shape_renderer(g, dev)
@@ -293,8 +294,10 @@ def test_material_renderer(golden, dev, tmp_path):
     assert not missing
     with torch.no_grad():
         out = m2.shade(gs["pts"].to(dev), gs["view_in"].to(dev), gs["normals_in"].to(dev), None, False)
-    assert rel_err(out["rgb_pr"].cpu(), gs["colors"]) < TOL and rel_err(out["rgb_pr_nis"].cpu(), gs.out["rgb_pr_nis"]) < TOL
-    assert rel_err(out["albedo"].cpu(), gs.out["albedo"]) < TOL and rel_err(out["visibility"].cpu(), gs.out["visibility"]) < TOL
+    parity(out["rgb_pr"].cpu(), gs["colors"], label="material_renderer:296.0")
+    parity(out["rgb_pr_nis"].cpu(), gs.out["rgb_pr_nis"], label="material_renderer:296.1")
+    parity(out["albedo"].cpu(), gs.out["albedo"], label="material_renderer:297.0")
+    parity(out["visibility"].cpu(), gs.out["visibility"], label="material_renderer:297.1")
     # the same geometry handed over as a .ply file (what the reference reads with open3d): identical colours
     write_ply(str(tmp_path / "golden.ply"), gs["verts"].numpy(), gs["faces"].numpy())
     m3 = MaterialRenderer({"mesh": str(tmp_path / "golden.ply"), "shader_cfg": shader_cfg, "gridSize": [32, 32, 32]}, training=False, nvs=True)
@@ -345,16 +348,16 @@ def test_material_renderer_nvs_frame_golden(golden, dev):
     inters, normals, depth, hit = m.trace_sdf_with_mesh(g["rays_o"].to(dev), g["rays_d"].to(dev))
     ref_hit = g["hit"].bool()
     assert torch.equal(hit[:, 0].cpu(), ref_hit) and 0.2 < float(ref_hit.float().mean()) < 0.8
-    assert rel_err(inters.cpu()[ref_hit], g["inters"][ref_hit]) < TOL and rel_err(normals.cpu()[ref_hit], g["normals"][ref_hit]) < TOL
+    parity(inters.cpu()[ref_hit], g["inters"][ref_hit], label="material nvs refined hit points")
+    parity(normals.cpu()[ref_hit], g["normals"][ref_hit], label="material nvs refined normals")
     frame = m.nvs(g["nvs_pose"].numpy(), g["nvs_K"].numpy(), h, w)
     nvs = {k[4:]: v for k, v in g.a.items() if k.startswith("nvs/")}
     assert set(frame) == set(nvs) and len(nvs) == 15
     worst = {}
     for k, ref in nvs.items():
         assert frame[k].shape == tuple(ref.shape) and frame[k].dtype == np.float32, k
-        worst[k] = rel_err(torch.from_numpy(frame[k]), ref)
-    print("MaterialRenderer.nvs vs reference, per key:", {k: f"{v:.1e}" for k, v in worst.items()})
-    assert all(v < TOL for v in worst.values()), worst
+        worst[k] = parity(torch.from_numpy(frame[k]), ref, label=f"material nvs frame {k}")
+    print("MaterialRenderer.nvs vs reference, per key (relative measure):", {k: f"{v:.1e}" for k, v in worst.items()})
     assert float(nvs["occ_trace"].reshape(-1)[ref_hit].min()) < 0.9 and float(nvs["indirect_light"].max()) > 0.05     # the ring is seen by secondary rays
     small = m.nvs(g["nvs_pose"].numpy(), g["nvs_K"].numpy(), h, w, chunk=100)
     for k in nvs:
@@ -500,13 +503,16 @@ def test_shape_shading_variants_golden(golden, dev):
         col2, occ2, inter = cn(c("pts"), c("normals"), c("view_dirs"), c("feat"), c("human_poses"), inter_results=True, step=100)
         met, rough, alb = cn.predict_materials(c("pts"), c("feat"))
     assert none is None
-    assert rel_err(col.cpu(), g["color"]) < TOL and rel_err(col2.cpu(), g["color"]) < TOL
+    parity(col.cpu(), g["color"], label="shape_shading_variants_golden:503.0")
+    parity(col2.cpu(), g["color"], label="shape_shading_variants_golden:503.1")
     for k in ("occ_prob", "roughness", "reflective"):
-        assert rel_err(occ[k].cpu(), g[k]) < TOL, k
+        parity(occ[k].cpu(), g[k], label=f"shape shading variants occ {k}")
     assert set(inter) == {k[6:] for k in g.a if k.startswith("inter/")}
     for k, v in inter.items():
-        assert rel_err(v.cpu(), g["inter/" + k]) < TOL, k
-    assert rel_err(met.cpu(), g["pm_metallic"]) < TOL and rel_err(rough.cpu(), g["pm_roughness"]) < TOL and rel_err(alb.cpu(), g["pm_albedo"]) < TOL
+        parity(v.cpu(), g["inter/" + k], label=f"shape shading variants inter {k}")
+    parity(met.cpu(), g["pm_metallic"], label="shape_shading_variants_golden:509.0")
+    parity(rough.cpu(), g["pm_roughness"], label="shape_shading_variants_golden:509.1")
+    parity(alb.cpu(), g["pm_albedo"], label="shape_shading_variants_golden:509.2")
     # gradients: parameters of every net the forward reaches (the outer net gets none, as in the reference), normals, features
     cn.zero_grad()
     nr, ft = c("normals").requires_grad_(True), c("feat").requires_grad_(True)

@@ -4,6 +4,8 @@
 //   1  VALU stream: independent v_fma_f32 on 16 registers
 //   2  dependent global loads (pointer chase through an L2-resident table, one 16-byte load per step)
 //   3  LDS reads (ds_read_b128, independent)
+//   4  plain v_fma_f32 (inline asm: the compiler packs role 1's stream into v_pk_fma_f32, two passes per instruction)
+//   5  integer VALU (v_add_u32 / v_xor_b32)
 // Prints ns per iteration for A alone, B alone and A + B together: "sum" = the units serialise, "max" = they overlap.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +37,29 @@ __device__ __forceinline__ float role_valu(int iters) {
   float s = 0.f;
   for (int i = 0; i < 16; ++i) s += v[i];
   return s;
+}
+__device__ __forceinline__ float role_fma1(int iters) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = 1.0f + 0.001f * (threadIdx.x + i);
+  const float m = 1.0001f, a = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[q % 16]) : "v"(m), "v"(a));
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  return s;
+}
+__device__ __forceinline__ float role_int(int iters) {
+  unsigned v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 2654435761u + i;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(v[q % 16]) : "v"(0x9e3779b9u), "v"((unsigned)q));
+  }
+  unsigned s = 0;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  return (float)s;
 }
 __device__ __forceinline__ float role_chase(int iters, const uint4* table, unsigned mask) {
   unsigned p = (threadIdx.x * 2654435761u + blockIdx.x * 40503u) & mask;
@@ -68,15 +93,17 @@ __global__ void __launch_bounds__(512) k(int itersA, int itersB, const uint4* ta
   else if (role == 1) s = role_valu(iters);
   else if (role == 2) s = role_chase(iters, table, mask);
   else if (role == 3) s = role_lds(iters, frag);
+  else if (role == 4) s = role_fma1(iters);
+  else if (role == 5) s = role_int(iters);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 typedef void (*kern_t)(int, int, const uint4*, unsigned, int, float*);
 template <int A> static kern_t pickB(int b) {
-  switch (b) { case -1: return k<A, -1>; case 0: return k<A, 0>; case 1: return k<A, 1>; case 2: return k<A, 2>; default: return k<A, 3>; }
+  switch (b) { case -1: return k<A, -1>; case 0: return k<A, 0>; case 1: return k<A, 1>; case 2: return k<A, 2>; case 3: return k<A, 3>; case 4: return k<A, 4>; default: return k<A, 5>; }
 }
 static kern_t pick(int a, int b) {
-  switch (a) { case 0: return pickB<0>(b); case 1: return pickB<1>(b); case 2: return pickB<2>(b); default: return pickB<3>(b); }
+  switch (a) { case 0: return pickB<0>(b); case 1: return pickB<1>(b); case 2: return pickB<2>(b); case 3: return pickB<3>(b); case 4: return pickB<4>(b); default: return pickB<5>(b); }
 }
 static float run(int cu, int roleA, int roleB, int itA, int itB, const uint4* table, unsigned mask, float* out, int prio = 0) {
   const int threads = roleB < 0 ? 256 : 512;
@@ -97,15 +124,16 @@ int main() {
   for (unsigned i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = make_uint4(x >> 8, i, 0, 0); }
   uint4* table; hipMalloc(&table, n * sizeof(uint4)); hipMemcpy(table, h.data(), n * sizeof(uint4), hipMemcpyHostToDevice);
   float* out; hipMalloc(&out, sizeof(float) * cu * 512);
-  const char* names[4] = {"mfma", "valu", "chase", "lds"};
-  const int iters[4] = {20000, 20000, 2000, 20000};
-  float alone[4];
-  for (int r = 0; r < 4; ++r) {
+  const char* names[6] = {"mfma", "valu", "chase", "lds", "fma1", "int"};
+  const int iters[6] = {20000, 20000, 2000, 20000, 20000, 20000};
+  float alone[6];
+  for (int r = 0; r < 6; ++r) {
     alone[r] = run(cu, r, -1, iters[r], 0, table, n - 1, out);
     printf("%-6s alone (1 wave/SIMD): %8.3f ms = %7.1f ns per iteration\n", names[r], alone[r], alone[r] * 1e6 / iters[r]);
   }
-  for (int a = 0; a < 4; ++a)
-    for (int b = a; b < 4; ++b) {
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) {
+      if (a >= 1 && b >= 4 && !(a == b)) continue;      // (the extra vector roles are paired with the matrix role and with themselves)
       // scale B's iteration count so that both roles last about as long alone
       const int itB = (int)(iters[b] * (alone[a] / alone[b]));
       const float ms = run(cu, a, b, iters[a], itB, table, n - 1, out);
