@@ -149,7 +149,7 @@ class FlowLogqFn(torch.autograd.Function):
         # d logq / d x is only asked for between nis_loss_iter and nis_start_iter, where the NIS loss is fitted on the fixed GGX half
         # angles and those depend on the predicted roughness (fields.py:1296-1318 with sample_specular_directions): closed form in the
         # same kernel (round 3; central differences of the forward -- round 2 -- were exact in the median and off by more than the
-        # gradient itself on the 0.03 % of samples whose stencil straddled a knot of a narrow spline bin: tools/exp_flow_dx.py)
+        # gradient itself on the 0.03 % of samples whose stencil straddled a knot of a narrow spline bin: tools/exp_flow_dx.py of the round-4 tree, git a8fd04d)
         want_gx = ctx.needs_input_grad[1]
         res = ops.flow_logq_bwd(weights, cond.detach(), x, g_logq.contiguous(), rays_id=ctx.rays_id, want_gx=want_gx)
         grads, g_cond = res[0], res[1]

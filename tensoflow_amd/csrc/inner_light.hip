@@ -2,10 +2,16 @@
 // MCShadingNetwork.get_inner_lights (network/fields.py:905-911) =
 //   cat[pos_enc8(p) (51), IDE5(reflect(view, n), kappa_inv = 0) (72)] -> 123-256-256-256-3 (ReLU),
 //   out = exp(min(x, exp_max))            (make_predictor_4layer, network/other_field.py:86-119)
-// evaluated for every secondary ray that hits geometry (327 kflop per ray: the largest flop term of the
-// integral).  One wave per 32 rays, fp32 MFMA, activations in accumulator registers between layers
-// (mfma_mlp.h); the 688 KB of fragment-ordered weights stream from L2 (256 coalesced bytes per MFMA).
-// Weight-norm is folded by the caller (effective W = g * v / |v|).
+// evaluated for every secondary ray that hits geometry (327 kflop per ray: the largest flop term of the integral); the same kernel
+// serves predict_outer_lights('direction') (fields.py:913-916) on the rays that miss.  Weight-norm is folded by the caller.
+//
+//   TfPrecision     kernel                                         file                      operands of a product
+//   TF_PREC_F16X3   inner_light3_kernel<., 3>  (64-ray passes)     this file                 weights hi + lo, activations hi + lo (3 MFMAs): fp32-grade, the library default
+//   TF_PREC_F16X2   inner_light3_kernel<., 2>  (128-ray passes)    this file                 weights hi + lo, activations f16 once per layer (2 MFMAs): opt-in
+//   TF_PREC_F16     inner_light2_kernel<1>     (column-owned)      inner_light_modes.hip     plain f16 (1 MFMA): opt-in, not parity grade
+//   TF_PREC_F32     inner_light_kernel         (slab ring)         inner_light_modes.hip     exact fp32 MFMA: the yardstick of the parity tests
+// (the training forward, tf_inner_light_indexed_train_fwd, is the SAVE instantiation of the 64-ray form; tf_set_launch_budget's
+// inner_teams = 1 the TEAMS = 1 instantiations.)  Dev-only stamps are compiled in with -DTF_DEV.
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -13,27 +19,8 @@
 #include "mfma_mlp.h"
 #include "tf_common.h"
 #include "tf_internal.h"
+#include "inner_light_ws.h"
 
-// fragment workspace layout (floats)
-static constexpr int kI1 = 0;                       // [8][64][64]   123 -> 256 (K padded to 128)
-static constexpr int kI2 = kI1 + 8 * 64 * 64;       // [8][128][64]
-static constexpr int kI3 = kI2 + 8 * 128 * 64;      // [8][128][64]
-static constexpr int kI4 = kI3 + 8 * 128 * 64;      // [1][128][64]  256 -> 3
-static constexpr int kIB1 = kI4 + 128 * 64;         // biases, accumulator order
-static constexpr int kIB2 = kIB1 + 256;
-static constexpr int kIB3 = kIB2 + 256;
-static constexpr int kIB4 = kIB3 + 256;
-static constexpr int kIdeMat = kIB4 + 32;           // [17][36] IDE polynomial coefficients
-// f16x3 fragments (hi|lo halves), offsets in FLOAT units (each k-step16 of 8 unit tiles = 4096 floats)
-static constexpr int kH1 = ((kIdeMat + 17 * 36 + 1023) / 1024) * 1024;   // 123 -> 256: 8 k-steps16
-static constexpr int kH2 = kH1 + 8 * 4096;          // 256 -> 256: 16 k-steps16
-static constexpr int kH3 = kH2 + 16 * 4096;
-static constexpr int kH4 = kH3 + 16 * 4096;         // 256 -> 3: 16 k-steps16 x 1 tile = 2 slabs
-static constexpr int kP1 = kH4 + 2 * 4096;          // 123 -> 256 with the IDE features first (inner_light_cols_kernel): 8 k-steps16
-static constexpr int kWp = kP1 + 8 * 4096;          // [256][123] scratch of the column permutation
-static constexpr int kW4a = kWp + 256 * 128 + 32;   // [3][256]: rows of the 256 -> 3 layer in accumulator order (tf_pack_bias_kernel), staggered kernel
-static constexpr int kQ1 = ((kW4a + 3 * 256 + 1023) / 1024) * 1024;   // 123 -> 256 in the staggered kernel's input order (il3_orig_col): 8 k-steps16
-static constexpr int kInnerWsFloats = kQ1 + 8 * 4096;
 
 extern "C" size_t tf_inner_light_workspace_floats(void) { return kInnerWsFloats; }
 static void ide_tables_host(float* mat);
@@ -66,665 +53,6 @@ static const float* ide_tables_cached() {
   return t.v;
 }
 
-__device__ __forceinline__ float relu(float x) { return tf_relu(x); }
-
-// hidden layer on the continuous weight stream (mfma_mlp.h): every hidden layer here has an even slab count, so the
-// fragment-set parity is 0 at each layer start
-// `bias`: this lane half's 256 biases in accumulator order, in LDS (all 32 lanes of a half read the same 16 bytes: broadcast).
-// Fetched from the global workspace the 128 single-dword loads per layer cost ~10 % of the kernel: their issue slots, and
-// the counted vmcnt of the weight ring has to wait for them.
-template <int K16, int TIN, int TERMS>
-__device__ __forceinline__ void hidden_layer_h3(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias, int h,
-                                                const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
-#ifdef TF_ABLATE_EPILOGUE   // dev-only timing ablation: no bias read, no ReLU (results are garbage)
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = 0.f;
-  tf_layer_h3s<K16, 8, TIN, 0, TERMS>(S, FA, FB, in, out);
-  return;
-#endif
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
-      out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
-    }
-  tf_layer_h3s<K16, 8, TIN, 0, TERMS>(S, FA, FB, in, out);
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
-}
-
-// pre-split form (mfma_mlp.h): `B` = this layer's input as f16 (hi | lo) operands; the output is ReLU'd in place.
-template <int K16, int TERMS>
-__device__ __forceinline__ void hidden_layer_ps(TfStream& S, TfFrag& FA, TfFrag& FB, const float* __restrict__ bias,
-                                                const TfSplitIn<K16>& B, f32x16 (&out)[8]) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v4 = *reinterpret_cast<const float4*>(bias + t * 16 + 4 * q);
-      out[t][4 * q] = v4.x; out[t][4 * q + 1] = v4.y; out[t][4 * q + 2] = v4.z; out[t][4 * q + 3] = v4.w;
-    }
-  tf_layer_h3s_ps<K16, 8, 0, TERMS>(S, FA, FB, B, out);
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
-}
-
-template <int KSTEPS, int TIN>
-__device__ __forceinline__ void hidden_layer(const float* __restrict__ wslab, const float* __restrict__ bias,
-                                             float* __restrict__ lds, int tid, int lane, int h,
-                                             const f32x16 (&in)[TIN], f32x16 (&out)[8]) {
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = bias[(t * 16 + j) * 2 + h];
-  tf_layer_stream<KSTEPS, 8, TIN, 8, 3>(wslab, lds, tid, lane, in, out);
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[t][j] = relu(out[t][j]);
-}
-
-// Dense mode (idx == nullptr): row r reads pts/view/nrm[r] and writes out[r].
-// Indexed mode: row r stands for ray i = idx[r], r < *count_dev (device-side count: no host sync between the BVH
-// trace and this kernel); view = -view[i] (the ray direction is passed), out[i] = light * (depth[i] > near_eps).
-// MODE: 0 = exact fp32 MFMA, 3 = f16x3, 1 = plain f16 operands (TF_PREC_F16: the same slab stream, hi halves only)
-template <int MODE>
-__global__ void __launch_bounds__(256) inner_light_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts,
-                                                          const float* __restrict__ view, const float* __restrict__ nrm,
-                                                          long long m_arg, const long long* __restrict__ idx,
-                                                          const long long* __restrict__ count_dev,
-                                                          const float* __restrict__ depth, float near_eps, float exp_max,
-                                                          float* __restrict__ out) {
-  constexpr bool H3 = MODE != 0;
-  constexpr int TERMS = MODE == 1 ? 1 : MODE == 2 ? 2 : 3;
-  long long m = m_arg;
-  if (count_dev) m = min(m_arg, *count_dev);
-  if (m <= 0) return;
-  __shared__ __attribute__((aligned(16))) float lds[4 * 4096];   // weight-slab ring (f16x3: 4 slabs, f32: 3)
-  const int tid = threadIdx.x, lane = threadIdx.x & 63, h = lane >> 5;
-  const long long n_groups = (m + 127) / 128;   // a workgroup advances 4 tiles (128 rays) in lockstep
-  // f16x3: the four layers' fragment images are contiguous (kH1..kH4): one stream of 8 + 16 + 16 + 2 = 42 slabs per tile
-  // biases of the four layers, re-laid-out per lane half: lbias[layer][half][n] = packed[(n) * 2 + half]
-  __shared__ __attribute__((aligned(16))) float lbias[4 * 2 * 128 * 2];
-  if (H3) {
-    for (int i = tid; i < 3 * 256 + 32; i += 256) {
-      const int layer = i < 768 ? i / 256 : 3, r = i < 768 ? i % 256 : i - 768;   // r = n * 2 + half
-      lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
-    }
-  }
-#ifdef TF_CLOCK_PROBE   // dev-only: shader-clock ticks spent by workgroup 0 (s_memtime counts shader clocks on this part)
-  const unsigned long long probe_t0 = __builtin_readcyclecounter();
-#endif
-  TfStream S;
-  TfFrag FA, FB;
-  if (H3) tf_stream_begin(S, reinterpret_cast<const _Float16*>(ws_arg + kH1), 42, lds, tid, lane, FA);   // contains a barrier
-  for (long long tg = blockIdx.x; tg < n_groups; tg += gridDim.x) {
-    // opaque per-iteration copy of the workspace base: biases / IDE table / slab addresses are loop-invariant and
-    // would otherwise be hoisted out of the tile loop, spilled, and reloaded behind s_waitcnt vmcnt(0)
-    const float* ws = ws_arg;
-    asm volatile("" : "+s"(ws));
-    const long long tile = tg * 4 + (threadIdx.x >> 6);
-    long long row = tile * 32 + (lane & 31);
-    const bool valid = row < m;
-    if (!valid) row = m - 1;
-    const long long src = idx ? idx[row] : row;
-    const float vsign = idx ? -1.f : 1.f;
-    // ---- encodings (each lane computes all 123 and keeps the half its MFMA operand slots need)
-    float enc[128];
-    const float p[3] = {pts[3 * src], pts[3 * src + 1], pts[3 * src + 2]};
-#ifdef TF_ABLATE_ENC   // dev-only timing ablation
-#pragma unroll
-    for (int k = 0; k < 128; ++k) enc[k] = p[k % 3] * (float)k + nrm[3 * src] + view[3 * src];
-    if (false) {
-#else
-    {
-#endif
-#pragma unroll
-    for (int k = 0; k < 3; ++k) enc[k] = p[k];
-    // arguments p * 2^f, f < 8: inside |p| < 3 (any scene in the unit sphere) the fp32 three-constant reduction is exact
-    // (|k| < 2^8); the double-precision reduction (24 x ~8 f64 instructions per tile) is kept for out-of-range callers only
-    if (__all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f)) {
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tf_sincos_small(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
-    } else {
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tf_sincos(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
-    }
-    float n[3] = {nrm[3 * src], nrm[3 * src + 1], nrm[3 * src + 2]};
-    float v[3] = {vsign * view[3 * src], vsign * view[3 * src + 1], vsign * view[3 * src + 2]};
-    float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
-    n[0] *= inv; n[1] *= inv; n[2] *= inv;
-    inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-    v[0] *= inv; v[1] *= inv; v[2] *= inv;
-    const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
-    const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
-    {
-      // IDE: sph[i] = (rx + i ry)^m_i * sum_k mat[k][i] rz^k ; output = [Re(36) | Im(36)]
-      float zp[17];
-      zp[0] = 1.f;
-#pragma unroll
-      for (int k = 1; k < 17; ++k) zp[k] = zp[k - 1] * rz;
-      float cre[17], cim[17];
-      cre[0] = 1.f; cim[0] = 0.f;
-#pragma unroll
-      for (int k = 1; k < 17; ++k) {
-        cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
-        cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
-      }
-      // the 17 x 36 polynomial table is wave-uniform: read it through the scalar cache (s_load) -- as a generic pointer the reads
-      // were 44 flat_load_dwordx4 per tile, each tile start waiting on vmcnt(0) behind the weight DMAs in flight
-      const __attribute__((address_space(4))) float* mat =
-          (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
-      // column of (d, mm) = (2^d - 1) + d + mm: every index below is a compile-time constant once the loops are unrolled
-      // (a running `col++` counter left enc[] dynamically indexed, i.e. in scratch memory)
-#pragma unroll
-      for (int d = 0; d < 5; ++d) {
-#pragma unroll
-        for (int mm = 0; mm <= (1 << d); ++mm) {
-          const int col = (1 << d) - 1 + d + mm;
-          float poly = 0.f;
-#pragma unroll
-          for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
-          enc[51 + col] = cre[mm] * poly;
-          enc[51 + 36 + col] = cim[mm] * poly;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 123; k < 128; ++k) enc[k] = 0.f;
-    }
-    f32x16 a[8], b[8];
-    {
-      const unsigned long long upper_half = 0xFFFFFFFF00000000ULL;   // lanes 32..63 (h = 1)
-      f32x16 in1[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int k0 = 32 * t + (j & 3) + 8 * (j >> 2);
-          // explicit v_cndmask: written as `h ? enc[k0 + 4] : enc[k0]` the compiler folds the select into the ADDRESS
-          // and keeps enc[] as a lane-indexed array in scratch memory (128 stores + 16 loads per ray)
-          asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(in1[t][j]) : "v"(enc[k0]), "v"(enc[k0 + 4]), "s"(upper_half));
-        }
-#ifndef TF_INNER_PRESPLIT   // default: operands split k-step by k-step inside the slab steps
-      if (H3) hidden_layer_h3<8, 4, TERMS>(S, FA, FB, lbias + h * 256, h, in1, a);
-      else hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
-    }
-    if (H3) {
-      hidden_layer_h3<16, 8, TERMS>(S, FA, FB, lbias + 512 + h * 256, h, a, b);
-      hidden_layer_h3<16, 8, TERMS>(S, FA, FB, lbias + 1024 + h * 256, h, b, a);
-    } else {
-      hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
-      hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
-    }
-    f32x16 o[1];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
-    if (H3) tf_layer_h3s<16, 1, 8, 0, TERMS>(S, FA, FB, a, o);
-    else tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
-#else
-      if (H3) {
-        TfSplitIn<8> B1;
-        tf_presplit<8, 4, TERMS>(in1, B1);
-        hidden_layer_ps<8, TERMS>(S, FA, FB, lbias + h * 256, B1, a);
-      } else {
-        hidden_layer<64, 4>(ws + kI1, ws + kIB1, lds, tid, lane, h, in1, a);
-      }
-    }
-    f32x16 o[1];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[0][j] = H3 ? lbias[1536 + h * 256 + j] : ws[kIB4 + j * 2 + h];
-    if (H3) {
-      // dev-only variant (-DTF_INNER_PRESPLIT): each layer's input converted to MFMA operands once, at the layer boundary.
-      // Measured: f16x3 2.65 ms vs 2.52 in-step per 3 M rays (plain f16: 1.25 vs 1.35) -- the conversion is not hidden either way
-      TfSplitIn<16> B2;
-      tf_presplit<16, 8, TERMS>(a, B2);
-      hidden_layer_ps<16, TERMS>(S, FA, FB, lbias + 512 + h * 256, B2, b);
-      tf_presplit<16, 8, TERMS>(b, B2);
-      hidden_layer_ps<16, TERMS>(S, FA, FB, lbias + 1024 + h * 256, B2, a);
-      tf_presplit<16, 8, TERMS>(a, B2);
-      tf_layer_h3s_ps<16, 1, 0, TERMS>(S, FA, FB, B2, o);
-    } else {
-      hidden_layer<128, 8>(ws + kI2, ws + kIB2, lds, tid, lane, h, a, b);
-      hidden_layer<128, 8>(ws + kI3, ws + kIB3, lds, tid, lane, h, b, a);
-      tf_layer_stream<128, 1, 8, 64, 3>(ws + kI4, lds, tid, lane, a, o);
-    }
-#endif
-    if (valid && h == 0) {
-      const float near = (depth && !(depth[src] > near_eps)) ? 0.f : 1.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) out[3 * src + c] = expf(fminf(o[0][c], exp_max)) * near;
-    }
-  }
-  if (H3) tf_stream_end();
-#ifdef TF_CLOCK_PROBE
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    printf("inner_light<%d> wg0: %llu ticks for %lld tiles\n", MODE, __builtin_readcyclecounter() - probe_t0,
-           (n_groups - blockIdx.x + gridDim.x - 1) / gridDim.x);
-#endif
-}
-
-
-// =====================================================================================================================
-// Column-owned form (f16x3 / f16x2 / f16 arithmetic).  The kernel above walks the whole weight image once per 128 rays through
-// an LDS ring: 42 slab steps per pass, each with a workgroup barrier, four LDS-DMA pieces and 16 fragment reads per wave in
-// front of 24 MFMAs -- the matrix pipe is busy 57 % of the time and every weight byte crosses the LDS once per 32 rays.
-// Here the roles of weights and activations are swapped:
-//   * a wave OWNS 64 of a layer's 256 output units (two 32-unit tiles) for all R = 128 rays of the pass (four 32-ray
-//     tiles): its weight fragments come straight from L2 into registers (1 KB coalesced wave loads, nobody else in the
-//     workgroup needs them) and each one feeds 4 ray tiles x TERMS MFMAs;
-//   * the ACTIVATIONS of a layer live in LDS as f16 MFMA B-fragments ([k-step][ray tile][hi|lo][lane][8 halves], written
-//     by the wave that produced them straight from its accumulator registers -- the unit permutation folded into the weight
-//     packing makes an accumulator lane's 8 registers one 16-byte B-fragment), every wave reads all of them;
-//   * two barriers per layer (inputs read / outputs written) instead of one per 16 KB of weights; per k-step a wave issues 2-4
-//     global loads + 4-8 ds_read_b128 for 8-24 MFMAs.
-// TERMS = 3: weights and activations split hi + lo (fp32-grade products, 128 KB of LDS, one workgroup per CU).
-// TERMS = 2: weights split, activations rounded to f16 once per layer.  TERMS = 1: plain f16 operands.  (64 KB of LDS: two
-// workgroups per CU -- one computes its encodings / epilogues under the other's MFMAs.)
-// The input row is cat[IDE (72), pos_enc8 (51), 0 (5)] -- IDE first so that no 4-value store granule straddles the two encoders
-// (waves 0-1 compute the positional encoding of the pass's 128 rays, waves 2-3 the IDE); layer 1's weight columns are packed in
-// that order (kP1).
-template <int TERMS>
-struct IL2 {
-  static constexpr int R = 128, RT = 4;
-  static constexpr int XP = TERMS == 3 ? 2 : 1;     // activation planes in LDS (hi | lo)
-  static constexpr int AP = TERMS >= 2 ? 2 : 1;     // weight planes fetched
-  static constexpr int ACT16 = 16 * RT * XP * 64;   // 16-byte units
-};
-
-// 8-byte slot of feature k (k % 4 == 0) of ray (r, j) in the layer-1 B-fragment image; `plane` 0 = hi, 1 = lo
-template <int XP>
-__device__ __forceinline__ int il2_slot8(int k, int r, int j, int plane) {
-  const int s = 2 * (k >> 5) + ((k >> 4) & 1), c = (k >> 3) & 1, h = (k >> 2) & 1;
-  return ((((s * 4 + r) * XP + plane) * 64 + j + 32 * h) << 1) + c;   // in 8-byte units
-}
-
-template <int XP>
-__device__ __forceinline__ void il2_store4(uint2* act8, int k, int r, int j, float a, float b, float c, float d) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 h01 = {(_Float16)a, (_Float16)b}, h23 = {(_Float16)c, (_Float16)d};
-  uint2 v;
-  v.x = __builtin_bit_cast(unsigned, h01); v.y = __builtin_bit_cast(unsigned, h23);
-  act8[il2_slot8<XP>(k, r, j, 0)] = v;
-  if (XP == 2) {
-    const h2 l01 = {(_Float16)(a - (float)h01[0]), (_Float16)(b - (float)h01[1])};
-    const h2 l23 = {(_Float16)(c - (float)h23[0]), (_Float16)(d - (float)h23[1])};
-    v.x = __builtin_bit_cast(unsigned, l01); v.y = __builtin_bit_cast(unsigned, l23);
-    act8[il2_slot8<XP>(k, r, j, 1)] = v;
-  }
-}
-
-// Weight fragments in flight: a ring of PF + 1 k-steps (two unit tiles x AP planes each).  A layer starts with its first PF
-// k-steps already requested (il2_prefetch, issued before the barriers / epilogue of the layer in front of it: an L2 round trip
-// per layer start was otherwise exposed four times per pass).
-#ifndef IL2_PF
-#define IL2_PF 3
-#endif
-constexpr int kIl2Pf = IL2_PF;
-template <int TERMS>
-struct Il2Ring { tf_h8 a[kIl2Pf + 1][2][IL2<TERMS>::AP]; };
-
-template <int TERMS>
-__device__ __forceinline__ void il2_prefetch(const tf_h8* __restrict__ Wl /* wave-uniform */, int T0, int lane, Il2Ring<TERMS>& ring) {
-  typedef IL2<TERMS> C;
-  // scalar base + 32-bit lane offset (global_load ... v_off, s[base:base+1]): written as a per-lane 64-bit pointer every
-  // k-step's address became a loop-invariant VGPR pair, hoisted out of the pass loop and spilled
-  const tf_h8* wp = Wl + T0 * 128;
-#pragma unroll
-  for (int s = 0; s < kIl2Pf; ++s)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int p = 0; p < C::AP; ++p) ring.a[s][t][p] = wp[(unsigned)((s * 8 + t) * 128 + p * 64 + lane)];
-}
-
-// One hidden layer for this wave's two unit tiles T0, T0 + 1: acc[t][r] = bias + W x over K16 k-steps.
-// Wl: the layer's fragment image [k-step][8 unit tiles][hi|lo][lane] in 16-byte units, already offset by `lane`.
-template <int K16, int TERMS>
-__device__ __forceinline__ void il2_layer(const tf_h8* __restrict__ Wl /* wave-uniform */, int T0, int lane,
-                                          const tf_h8* __restrict__ actl /* + lane */,
-                                          Il2Ring<TERMS>& ring, const f32x16 (&bias)[2], f32x16 (&acc)[2][4]) {
-  typedef IL2<TERMS> C;
-  constexpr int PF = kIl2Pf;
-  const tf_h8* wp = Wl + T0 * 128;                    // (unit tile T0, plane 0) of k-step 0
-#ifdef IL2_NO_XPF
-  il2_prefetch<TERMS>(Wl, T0, lane, ring);
-#endif
-  // B fragments (activations) of k-step s + 1 are requested BEFORE the MFMAs of k-step s (register double buffer): read, wait and
-  // multiply in sequence left the matrix pipe idle for an LDS round trip (~200 cycles) in front of every 256 cycles of MFMAs.
-  tf_h8 bq[2][4][C::XP];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int p = 0; p < C::XP; ++p) bq[0][r][p] = actl[((0 * 4 + r) * C::XP + p) * 64];
-#pragma unroll
-  for (int s = 0; s < K16; ++s) {
-    if (s + PF < K16) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < C::AP; ++p) ring.a[(s + PF) % (PF + 1)][t][p] = wp[(unsigned)(((s + PF) * 8 + t) * 128 + p * 64 + lane)];
-    }
-    if (s + 1 < K16) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int p = 0; p < C::XP; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * 4 + r) * C::XP + p) * 64];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const tf_h8 b_hi = bq[s & 1][r][0];
-      const tf_h8 b_lo = bq[s & 1][r][C::XP - 1];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const tf_h8 a_hi = ring.a[s % (PF + 1)][t][0];
-        acc[t][r] = tf_mfma_h(a_hi, b_hi, s == 0 ? bias[t] : acc[t][r]);
-        if (TERMS == 3) acc[t][r] = tf_mfma_h(a_hi, b_lo, acc[t][r]);
-        if (TERMS >= 2) acc[t][r] = tf_mfma_h(ring.a[s % (PF + 1)][t][C::AP - 1], b_hi, acc[t][r]);
-      }
-    }
-#ifndef IL2_NO_SB
-    __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
-#endif
-  }
-}
-
-// ReLU + conversion of this wave's 64 output units into the next layer's B-fragments (k-steps 2 T0 .. 2 T0 + 3).
-template <int TERMS>
-__device__ __forceinline__ void il2_publish(tf_h8* __restrict__ actl /* + lane */, int T0, const f32x16 (&acc)[2][4]) {
-  typedef IL2<TERMS> C;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        float x8[8];
-        tf_h8* dst = actl + (((2 * (T0 + t) + u) * 4 + r) * C::XP) * 64;
-        if (TERMS == 3) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = tf_relu(acc[t][r][8 * u + e]);
-          tf_h8 hi, lo;
-          tf_split8(x8, hi, lo);
-          dst[0] = hi; dst[64] = lo;
-        } else {
-          // one rounded operand per value: ReLU AFTER the conversion, on the packed halves (v_pk_max_f16: one instruction per two
-          // values instead of one v_max_f32 per value).  Rounding to f16 is monotonic and keeps the sign, so max(f16(x), 0) = f16(max(x, 0)):
-          // colours bit-identical; time unchanged (9.6 ms: the epilogue's vector instructions are not what a pass waits for).
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x8[e] = acc[t][r][8 * u + e];
-          tf_h8 hi;
-          tf_cvt8(x8, hi);
-          const tf_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-          dst[0] = __builtin_elementwise_max(hi, zero);
-        }
-      }
-}
-
-template <int TERMS>
-__global__ void __launch_bounds__(256, TERMS == 3 ? 1 : 2)
-inner_light2_kernel(const float* __restrict__ ws_arg, const float* __restrict__ pts, const float* __restrict__ view,
-                    const float* __restrict__ nrm, long long m_arg, const long long* __restrict__ idx,
-                    const long long* __restrict__ count_dev, const float* __restrict__ depth, float near_eps, float exp_max,
-                    float* __restrict__ out) {
-  typedef IL2<TERMS> C;
-  long long m = m_arg;
-  if (count_dev) m = min(m_arg, *count_dev);
-  if (m <= 0) return;
-  __shared__ __attribute__((aligned(16))) tf_h8 act[C::ACT16];
-  __shared__ __attribute__((aligned(16))) float lbias[4 * 2 * 256];   // [layer][lane half][tile * 16 + reg]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5;
-  for (int i = tid; i < 3 * 256 + 32; i += 256) {
-    const int layer = i < 768 ? i / 256 : 3, r = i < 768 ? i % 256 : i - 768;   // packed order: r = n * 2 + half
-    lbias[layer * 512 + (r & 1) * 256 + (r >> 1)] = ws_arg[kIB1 + i];
-  }
-  const long long n_pass = (m + C::R - 1) / C::R;
-  const float vsign = idx ? -1.f : 1.f;
-  const int T0 = 2 * wave;
-#ifdef IL2_CLOCK    // dev-only: shader clock held inside this kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
-  const unsigned long long ck0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  uint2* act8 = reinterpret_cast<uint2*>(act);
-  const int q_enc = 64 * (wave & 1) + lane;                // ray of the pass this lane encodes
-  const int q_out = 32 * wave + (lane & 31);               // ray of the pass whose radiance this lane stores (lanes 0..31)
-  // inputs of the first pass; inside the loop the NEXT pass's index row and input rows are requested a layer or two ahead
-  // of their use (two dependent L2 / HBM round trips otherwise open every pass)
-  float in9[9];                                            // pts | nrm | view of the ray this lane encodes
-  long long nsrc;
-  auto load_inputs = [&](long long src) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { in9[k] = pts[3 * src + k]; in9[3 + k] = nrm[3 * src + k]; in9[6 + k] = view[3 * src + k]; }
-  };
-  {
-    long long row = (long long)blockIdx.x * C::R + q_enc;
-    if (row >= m) row = m - 1;
-    nsrc = idx ? idx[row] : row;
-    load_inputs(nsrc);
-  }
-  Il2Ring<TERMS> ring;
-#ifndef IL2_NO_XPF
-  il2_prefetch<TERMS>(reinterpret_cast<const tf_h8*>(ws_arg) + kP1 / 4, T0, lane, ring);
-#endif
-#ifdef IL2_STAMPS   // dev-only: shader-clock stamps of one pass of workgroup 0, per wave
-  unsigned long long st[12];
-  int n_st = 0;
-#define IL2_STAMP() do { if (blockIdx.x == 0 && pass == blockIdx.x + 4LL * gridDim.x && n_st < 12) st[n_st++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define IL2_STAMP() do {} while (0)
-#endif
-  for (long long pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
-    const float* ws = ws_arg;
-    asm volatile("" : "+s"(ws));
-    IL2_STAMP();
-    const tf_h8* W = reinterpret_cast<const tf_h8*>(ws);     // wave-uniform, 16-byte units (kP1 etc. are float offsets)
-    // ---- encodings of the pass's 128 rays, 64 per wave, the work of a ray split over TWO waves so that all four are equally
-    // busy (the whole IDE on one wave pair cost 6.9 k cycles against 5.3 k for the positional encoding on the other):
-    //   waves 0-1: positional encoding (features 72..122) + IDE columns 0..11  (l = 1, 2, 4 and the first two orders of l = 8)
-    //   waves 2-3: IDE columns 12..35 (rest of l = 8, all of l = 16)
-    // Every 4-feature store granule has one owner (12 and 36 + 12 are multiples of 4).
-    {
-      const int r = q_enc >> 5, j = q_enc & 31;
-      // reflected direction (both wave pairs need it)
-      float n[3] = {in9[3], in9[4], in9[5]};
-      float v[3] = {vsign * in9[6], vsign * in9[7], vsign * in9[8]};
-      float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
-      n[0] *= inv; n[1] *= inv; n[2] *= inv;
-      inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-      v[0] *= inv; v[1] *= inv; v[2] *= inv;
-      const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
-      const float rx = vn * n[0] * 2.f - v[0], ry = vn * n[1] * 2.f - v[1], rz = vn * n[2] * 2.f - v[2];
-      const __attribute__((address_space(4))) float* mat =
-          (const __attribute__((address_space(4))) float*)(unsigned long long)(ws + kIdeMat);
-      // IDE columns [C0, C1): sph[col] = (rx + i ry)^mm * sum_k mat[k][col] rz^k; Re -> feature col, Im -> feature 36 + col
-      auto ide_cols = [&](auto c0_, auto c1_) {
-        constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value;
-        constexpr int KMAX = C1 <= 12 ? 8 : 16, MMAX = C1 <= 12 ? 4 : 16;
-        float zp[KMAX + 1], cre[MMAX + 1], cim[MMAX + 1];
-        zp[0] = 1.f; cre[0] = 1.f; cim[0] = 0.f;
-#pragma unroll
-        for (int k = 1; k <= KMAX; ++k) zp[k] = zp[k - 1] * rz;
-#pragma unroll
-        for (int k = 1; k <= MMAX; ++k) {
-          cre[k] = cre[k - 1] * rx - cim[k - 1] * ry;
-          cim[k] = cre[k - 1] * ry + cim[k - 1] * rx;
-        }
-        float re[C1 - C0], im[C1 - C0];
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-#pragma unroll
-          for (int mm = 0; mm <= (1 << d); ++mm) {
-            const int col = (1 << d) - 1 + d + mm;
-            if (col >= C0 && col < C1) {
-              float poly = 0.f;
-#ifndef IL2_ABLATE_IDE   // dev-only timing ablation
-#pragma unroll
-              for (int k = 0; k <= (1 << d) - mm; ++k) poly += zp[k] * mat[k * 36 + col];
-#else
-              poly = zp[1];
-#endif
-              re[col - C0] = cre[mm] * poly;
-              im[col - C0] = cim[mm] * poly;
-            }
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < (C1 - C0) / 4; ++g) {
-          il2_store4<C::XP>(act8, C0 + 4 * g, r, j, re[4 * g], re[4 * g + 1], re[4 * g + 2], re[4 * g + 3]);
-          il2_store4<C::XP>(act8, 36 + C0 + 4 * g, r, j, im[4 * g], im[4 * g + 1], im[4 * g + 2], im[4 * g + 3]);
-        }
-      };
-      if (wave < 2) {
-        const float p[3] = {in9[0], in9[1], in9[2]};
-        float enc[56];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) enc[k] = p[k];
-        if (TERMS <= 2) {
-          // operands are rounded to f16 (2^-12) on their way into the matrix cores: octaves 1..7 by angle doubling from ONE
-          // accurate sincos per coordinate (error doubles per octave: <= 1.3e-5 at 2^7 p) instead of 24 range-reduced evaluations
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            float sn, cs;
-            if (fabsf(p[k]) < 3.f) tf_sincos_small(p[k], sn, cs); else tf_sincos(p[k], sn, cs);
-            enc[3 + k] = sn; enc[6 + k] = cs;
-#pragma unroll
-            for (int f = 1; f < 8; ++f) {
-              const float s2 = 2.f * sn * cs, c2 = fmaf(-2.f * sn, sn, 1.f);
-              sn = s2; cs = c2;
-              enc[3 + 6 * f + k] = sn; enc[3 + 6 * f + 3 + k] = cs;
-            }
-          }
-        } else if (__all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f)) {
-#pragma unroll
-          for (int f = 0; f < 8; ++f)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tf_sincos_small(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
-        } else {
-#pragma unroll
-          for (int f = 0; f < 8; ++f)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tf_sincos(p[k] * (float)(1 << f), enc[3 + 6 * f + k], enc[3 + 6 * f + 3 + k]);
-        }
-#pragma unroll
-        for (int k = 51; k < 56; ++k) enc[k] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 14; ++g) il2_store4<C::XP>(act8, 72 + 4 * g, r, j, enc[4 * g], enc[4 * g + 1], enc[4 * g + 2], enc[4 * g + 3]);
-        ide_cols(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
-      } else {
-        ide_cols(std::integral_constant<int, 12>{}, std::integral_constant<int, 36>{});
-      }
-    }
-    // index rows: this pass's output ray, the next pass's input ray
-    long long orow = pass * C::R + q_out;
-    const bool ovalid = orow < m;
-    if (!ovalid) orow = m - 1;
-    const long long osrc = idx ? idx[orow] : orow;
-    const long long npass = pass + gridDim.x;
-    if (npass < n_pass) {
-      long long row = npass * C::R + q_enc;
-      if (row >= m) row = m - 1;
-      nsrc = idx ? idx[row] : row;
-    }
-    IL2_STAMP();
-    __syncthreads();
-    IL2_STAMP();
-    f32x16 acc[2][4], bias[2];
-    // ---- layer 1 (K = 128)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float4 v4 = *reinterpret_cast<const float4*>(lbias + hh * 256 + (T0 + t) * 16 + 4 * qd);
-        bias[t][4 * qd] = v4.x; bias[t][4 * qd + 1] = v4.y; bias[t][4 * qd + 2] = v4.z; bias[t][4 * qd + 3] = v4.w;
-      }
-    il2_layer<8, TERMS>(W + kP1 / 4, T0, lane, act + lane, ring, bias, acc);
-#ifndef IL2_NO_XPF
-    il2_prefetch<TERMS>(W + kH2 / 4, T0, lane, ring);
-#endif
-    IL2_STAMP();
-    __syncthreads();
-    IL2_STAMP();
-    il2_publish<TERMS>(act + lane, T0, acc);
-    IL2_STAMP();
-    __syncthreads();
-    IL2_STAMP();
-    // ---- layers 2, 3 (K = 256)
-    const float dep = depth ? depth[osrc] : 1.f;
-    if (npass < n_pass) load_inputs(nsrc);                  // next pass's input rows (consumed at the top of the next iteration)
-    tf_h8 a4[16];                                            // layer 4's weight fragments (hi), requested under layer 3's epilogue
-#pragma unroll
-    for (int layer = 1; layer < 3; ++layer) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const float4 v4 = *reinterpret_cast<const float4*>(lbias + layer * 512 + hh * 256 + (T0 + t) * 16 + 4 * qd);
-          bias[t][4 * qd] = v4.x; bias[t][4 * qd + 1] = v4.y; bias[t][4 * qd + 2] = v4.z; bias[t][4 * qd + 3] = v4.w;
-        }
-      il2_layer<16, TERMS>(W + (layer == 1 ? kH2 : kH3) / 4, T0, lane, act + lane, ring, bias, acc);
-#ifndef IL2_NO_XPF
-      if (layer == 1) il2_prefetch<TERMS>(W + kH3 / 4, T0, lane, ring);
-#endif
-      if (layer == 2) {
-        const tf_h8* W4 = W + kH4 / 4;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) a4[s] = W4[(unsigned)(s * 128 + lane)];
-      }
-      if (layer == 1) IL2_STAMP();
-      __syncthreads();
-      il2_publish<TERMS>(act + lane, T0, acc);
-      __syncthreads();
-      if (layer == 1) IL2_STAMP();
-    }
-    IL2_STAMP();
-    // ---- layer 4 (256 -> 3): wave w takes ray tile w
-    {
-      f32x16 o;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] = lbias[1536 + hh * 256 + j];
-      const tf_h8* W4 = W + kH4 / 4;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const tf_h8 b_hi = act[((s * 4 + wave) * C::XP) * 64 + lane];
-        o = tf_mfma_h(a4[s], b_hi, o);
-        if (TERMS == 3) o = tf_mfma_h(a4[s], act[((s * 4 + wave) * C::XP + 1) * 64 + lane], o);
-        if (TERMS >= 2) o = tf_mfma_h(W4[(unsigned)(s * 128 + 64 + lane)], b_hi, o);
-      }
-#ifndef IL2_NO_XPF
-      il2_prefetch<TERMS>(W + kP1 / 4, T0, lane, ring);           // the next pass's first layer
-#endif
-      if (ovalid && hh == 0) {
-        const float near = (depth && !(dep > near_eps)) ? 0.f : 1.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) out[3 * osrc + c] = expf(fminf(o[c], exp_max)) * near;
-      }
-    }
-    IL2_STAMP();
-    __syncthreads();      // the next pass's encodings overwrite the activation image
-  }
-#ifdef IL2_CLOCK
-  if (blockIdx.x == 0 && tid == 0) {
-    const unsigned long long ck1 = __builtin_readcyclecounter(), rt1 = __builtin_amdgcn_s_memrealtime();
-    printf("il2<%d> block 0: %llu shader ticks in %.1f us -> %.3f GHz\n", TERMS, ck1 - ck0, (rt1 - rt0) * 0.01, (double)(ck1 - ck0) / ((rt1 - rt0) * 10.0));
-  }
-#endif
-#ifdef IL2_STAMPS
-  if (blockIdx.x == 0 && lane == 0 && n_st > 1) {
-    printf("il2<%d> wave %d: enc %llu | bar %llu | L1 %llu | bar %llu | pub %llu | bar %llu | L2 %llu | bar+pub+bar %llu | L3.. %llu | L4 %llu | total %llu\n", TERMS, wave,
-           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8], st[10] - st[9], st[10] - st[0]);
-  }
-#endif
-}
 
 // =====================================================================================================================
 // Staggered two-team form of the column-owned kernel: fp32-grade (f16x3) products at two waves per SIMD.
@@ -767,7 +95,7 @@ static __global__ void __launch_bounds__(256) inner_light_cols3_kernel(const flo
   Wp[e] = c >= 0 ? W[row * in_cols + c] : 0.f;
 }
 
-#ifdef IL3_STAMPS
+#ifdef TF_DEV
 __device__ unsigned long long g_il3_stamps[8 * 16];
 extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_il3_stamps), sizeof(unsigned long long) * 128); }
 #endif
@@ -856,9 +184,6 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
                                           const tf_h8* __restrict__ actl /* team image + lane */, Il3Ring& ring,
                                           f32x16 (&acc)[2][IL3<TERMS>::RT]) {
   constexpr int PF = IL3_PF, RT = IL3<TERMS>::RT, XP = IL3<TERMS>::XP;
-#ifdef IL3_SETPRIO
-  __builtin_amdgcn_s_setprio(IL3_SETPRIO);     // the wave in a matrix phase wins the SIMD's issue arbitration against its partner's vector phase
-#endif
   {
   tf_h8 bq[2][RT][XP];
 #pragma unroll
@@ -900,9 +225,6 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
     __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
   }
   }
-#ifdef IL3_SETPRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
 }
 
 template <int RT>
@@ -989,11 +311,7 @@ __device__ __forceinline__ void il4_half(il3_gw_t Wl /* wave-uniform */, int T, 
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
     if (s + PF < K16 || NEXT) {
-#ifdef IL4_SAME_TILE   // dev-only timing ablation: every wave streams unit tile 0's fragments (one L2 -> CU fetch serves the team)
-      il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, 0, s + PF) : il3_kstep_base(Wl, 0, s + PF - K16);
-#else
       il3_gw_t b = s + PF < K16 ? il3_kstep_base(Wl, T, s + PF) : il3_kstep_base(Wl, T + 1, s + PF - K16);
-#endif
 #pragma unroll
       for (int p = 0; p < 2; ++p) ring.a[(S0 + s + PF) % (PF + 1)][p] = b[lane + p * 64];
     }
@@ -1160,9 +478,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   auto row_src = [&](int it, int q, const long long* ix) {
     long long row = pass_of(it) * RAYS + q;
     if (row >= m) row = m - 1;
-#ifdef IL3_ABLATE_GATHER   // dev-only timing ablation: input rows read in order (coalesced), not through the hit list
-    return (src_t)row;
-#endif
     return (src_t)(ix ? ix[row] : row);
   };
   // wave-uniform role: which array this wave sends (w < 3) -- or depth + index (w == 3)
@@ -1201,7 +516,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   // finished, so that A is three steps ahead at every moment (s_barrier only counts arrivals).  Straight-line code instead of a
   // step machine keeps the register allocator's liveness exact: the accumulators are dead during the encodings, the weight ring
   // between a matrix phase and the next prefetch (as a step machine the kernel spilled 192 registers).
-#ifdef IL3_STAMPS   // dev-only: shader-clock stamps of one iteration of workgroup 0, per wave (phase ends and barrier releases), stored as taken
+#ifdef TF_DEV   // dev-only: shader-clock stamps of one iteration of workgroup 0, per wave (phase ends and barrier releases), stored as taken
 #ifndef IL3_STAMP_MASK
 #define IL3_STAMP_MASK 0xffff
 #endif
@@ -1228,7 +543,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     const int hh_o = lane_o >> 5;
     const float vsign_o = (idx_o && !OUTER) ? -1.f : 1.f;
     IL3_STAMP(0);
-#ifdef IL3_STAMPS
+#ifdef TF_DEV
     if (it == 41 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 15] = __builtin_readcyclecounter();
 #endif
     // ================= step FE
@@ -1320,7 +635,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         v[0] *= inv; v[1] *= inv; v[2] *= inv;
         const float vn = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
         const float rx = OUTER ? rv.x : vn * n[0] * 2.f - v[0], ry = OUTER ? rv.y : vn * n[1] * 2.f - v[1], rz = OUTER ? rv.z : vn * n[2] * 2.f - v[2];
-#ifndef IL3_ABLATE_E
         // IDE columns [C0, C1) (+ [D0, D1)): sph[col] = (rx + i ry)^mm * sum_q mat[q][col] rz^q; Re -> column col, Im -> 36 + col
         auto ide_cols = [&](auto c0_, auto c1_, auto d0_, auto d1_) {
           constexpr int C0 = decltype(c0_)::value, C1 = decltype(c1_)::value, D0 = decltype(d0_)::value, D1 = decltype(d1_)::value;
@@ -1373,8 +687,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           ide_cols(std::integral_constant<int, 24>{}, std::integral_constant<int, 28>{}, I0{}, I0{});
           il3_store4<TERMS>(a8, 120, p[0], p[1], p[2], 0.f);
         }
-#endif
-#ifndef IL3_ABLATE_E
         // positional block of wave w: sincos of octaves 2w, 2w + 1, interleaved [sin, cos] per (octave, coordinate) pair
         {
           float e12[12];
@@ -1400,7 +712,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           for (int gq = 0; gq < 3; ++gq)
             il3_store4<TERMS>(a8, 72 + 12 * w + 4 * gq, e12[4 * gq], e12[4 * gq + 1], e12[4 * gq + 2], e12[4 * gq + 3]);
         }
-#endif
         }
         IL3_STAMP(14);
         // layer 1's first weight fragments (the ring's registers are free for the encodings above)
@@ -1422,10 +733,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         il4_half<K1, false, K1 % (IL4_PF + 1)>((gw_t)(W + kQ1 / 4), T0 + 1, lane, lbias + hh * 128, actt + lane, ring, acc[0]);
       } else {
       il3_bias<RT>(lbias + hh * 128, T0, acc);
-#ifndef IL3_ABLATE_M    // dev-only timing ablation: no matrix products
       // (the direction-encoded outer net has 72 input columns: five k-steps, the rest of its image is zero)
       il3_layer<OUTER ? 5 : 8, TERMS>((gw_t)(W + kQ1 / 4), T0, lane, actt + lane, ring, acc);
-#endif
       }
     }
     // wave w stores ray tile w of the pass (128-ray form: all four waves; 64-ray form: waves 0, 1): the lanes of half w & 1 hold
@@ -1465,7 +774,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           for (int e = 0; e < NR; ++e) src_nxt[e] = row_src(it + 2, 64 * e + lane_o, idx_o);
         }
       }
-#ifndef IL3_ABLATE_P    // dev-only timing ablation: nothing is published
       if constexpr (TERMS == 2) {
         il4_publish(actt + lane, T0, held);
         il4_pack(acc[0], held);
@@ -1474,7 +782,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         il3_publish<TERMS>(actt + lane, T0, acc);
         if constexpr (SAVE) il3_save_acts(acts + (layer - 1) * m_arg * 256, pass_of(it) * RAYS, m, T0, lane, acc);
       }
-#endif
       IL3_STAMP(4 * layer + 1);
       il3_barrier();
       IL3_STAMP(4 * layer + 2);
@@ -1483,9 +790,6 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         const float* lb = lbias + layer * 256 + hh * 128;
         const float* w4h = w4a + hh * 128;
         il4_half<16, true, 0>(Wl, T0, lane, lb, actt + lane, ring, acc[0]);
-#ifdef IL4_STAMP_HALF
-        if (layer == IL4_STAMP_HALF && it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 7] = __builtin_readcyclecounter();
-#endif
         if (layer == 1) {
           il4_pack(acc[0], held);
         } else {
@@ -1495,16 +799,11 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
             for (int c = 0; c < 3; ++c) fsum[r][c] = il4_f2{0.f, 0.f};
           il4_out3(w4h, T0, acc[0], fsum);
         }
-#ifdef IL4_STAMP_HALF
-        if (layer == IL4_STAMP_HALF && it == 40 && blockIdx.x == 0 && lane == 0) g_il3_stamps[wave8 * 16 + 8] = __builtin_readcyclecounter();
-#endif
         il4_half<16, false, 16 % (IL4_PF + 1)>(Wl, T0 + 1, lane, lb, actt + lane, ring, acc[0]);
         if (layer == 2) il4_out3(w4h, T0 + 1, acc[0], fsum);
       } else {
       il3_bias<RT>(lbias + layer * 256 + hh * 128, T0, acc);
-#ifndef IL3_ABLATE_M
       il3_layer<16, TERMS>((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, actt + lane, ring, acc);
-#endif
       }
       IL3_STAMP(4 * layer + 3);
       il3_barrier();
@@ -1530,16 +829,12 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
   TF_REQUIRE(m >= 0, TF_ESHAPE, "%s: m < 0", who);
   const bool packed = (precision & TF_WEIGHTS_PACKED) != 0;
   precision &= ~TF_WEIGHTS_PACKED;
-  const bool ring = (precision & 0x200) != 0;   // dev-only: the slab-ring kernel (kept for A/B timing of the column-owned one)
-  precision &= ~0x200;
-  const bool cols_x2 = (precision & 0x400) != 0;   // dev-only: TF_PREC_F16X2 on the column-owned kernel (A/B timing of the staggered 128-ray form)
-  precision &= ~0x400;
   TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_F16 || precision == TF_PREC_F16X2, TF_EINVAL,
              "%s: unknown precision %d", who, precision);
   if (m == 0) return TF_OK;
-  TF_REQUIRE(!acts || (precision == TF_PREC_F16X3 && !ring && !outer), TF_EINVAL, "%s: activations are saved by the fp32-grade staggered "
+  TF_REQUIRE(!acts || (precision == TF_PREC_F16X3 && !outer), TF_EINVAL, "%s: activations are saved by the fp32-grade staggered "
              "kernel only (precision TF_PREC_F16X3)", who);
-  TF_REQUIRE(!outer || ((precision == TF_PREC_F16X3 || precision == TF_PREC_F16X2) && !ring && !cols_x2), TF_EINVAL, "%s: the direction-encoded "
+  TF_REQUIRE(!outer || precision == TF_PREC_F16X3 || precision == TF_PREC_F16X2, TF_EINVAL, "%s: the direction-encoded "
              "outer light runs on the staggered kernel only (precision TF_PREC_F16X3 or TF_PREC_F16X2)", who);
   TF_REQUIRE(net && pts && view && nrm && out && workspace, TF_EINVAL, "%s: null pointer", who);
   TF_REQUIRE(workspace_floats >= (size_t)kInnerWsFloats, TF_ESHAPE, "%s: workspace too small (%zu < %d floats)", who,
@@ -1553,17 +848,16 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
       tf_pack_wfrag_kernel<<<tf_blocks(128 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 128, workspace + kI4, 1);
     } else {
       _Float16* hw = reinterpret_cast<_Float16*>(workspace);
-      if (!outer)      // (the first-layer images of the other kernels read a [256,123] matrix: the outer net's is [256,72])
-        tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(net->w[0], 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kH1);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[1], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH2);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 16 * 64, 256), 256, 0, stream>>>(net->w[2], 256, 256, 0, 256, 8, 16, hw + 2 * (size_t)kH3);
       tf_pack_wfrag_h3_kernel<<<tf_blocks(1 * 16 * 64, 256), 256, 0, stream>>>(net->w[3], 3, 256, 0, 256, 1, 16, hw + 2 * (size_t)kH4);
-      if (!outer) {
+      if (precision == TF_PREC_F16) {       // the column-owned kernel's first layer: IDE columns first (kP1)
         inner_light_cols_kernel<<<tf_blocks(256 * 123, 256), 256, 0, stream>>>(net->w[0], workspace + kWp);
         tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 123, 0, 123, 8, 8, hw + 2 * (size_t)kP1);
+      } else {                              // the staggered kernel's: its four waves' column order (kQ1; the outer net's matrix is [256,72])
+        inner_light_cols3_kernel<<<tf_blocks(256 * 128, 256), 256, 0, stream>>>(net->w[0], outer ? 72 : 123, workspace + kWp);
+        tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 128, 0, 128, 8, 8, hw + 2 * (size_t)kQ1);
       }
-      inner_light_cols3_kernel<<<tf_blocks(256 * 128, 256), 256, 0, stream>>>(net->w[0], outer ? 72 : 123, workspace + kWp);     // same stream: after the pack above has read kWp
-      tf_pack_wfrag_h3_kernel<<<tf_blocks(8 * 8 * 64, 256), 256, 0, stream>>>(workspace + kWp, 256, 128, 0, 128, 8, 8, hw + 2 * (size_t)kQ1);
     }
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[0], 256, 8, workspace + kIB1);
     tf_pack_bias_kernel<<<1, 256, 0, stream>>>(net->b[1], 256, 8, workspace + kIB2);
@@ -1574,68 +868,36 @@ static int inner_light_launch(const TfMlp4* net, const float* pts, const float* 
     hipError_t e = hipMemcpyAsync(workspace + kIdeMat, ide_tables_cached(), 17 * 36 * sizeof(float), hipMemcpyHostToDevice, stream);
     TF_REQUIRE(e == hipSuccess, TF_EHIP, "%s: hipMemcpyAsync failed: %s", who, hipGetErrorString(e));
   }
-#ifndef TF_INNER_BLOCKS
-#define TF_INNER_BLOCKS 1024   // persistent workgroups (one resident per CU at a time)
-#endif
 #define IL_ARGS workspace, pts, view, nrm, m, (const long long*)idx, (const long long*)count_dev, depth, near_eps, exp_max, out
-  // f16x3 stays on the slab-ring kernel (measured: 6.1 ms against 6.8 ms column-owned per 7.4 M rays -- with hi + lo activations
-  // the column-owned image needs 128 KB of LDS, one workgroup per CU, and loses its overlap partner); IL2_X3 (dev) switches it over
-#ifdef IL2_X3
-  const bool cols = precision != TF_PREC_F32 && !ring;
-#else
-  const bool cols = (precision == TF_PREC_F16 || precision == TF_PREC_F16X2) && !ring;
-#endif
-#ifndef IL3_OFF
+  // Which kernel serves which TfPrecision (this file's header comment): F16X3 / F16X2 the staggered kernel below, F32 / F16 the two
+  // kernels of inner_light_modes.hip
   const bool one_team = tf_launch_budget().inner_teams == 1 && !outer && !acts;
   // one single-team workgroup per CU: two would fit (81.7 KB of LDS, 256 registers per wave) and leave nothing for the kernel this
   // budget makes room for, so the launch asks for 8 KB of (unused) dynamic LDS on top
   static const bool il1_nopad = getenv("TF_IL1_NOPAD") != nullptr;      // dev: two unsynchronised single-team workgroups per CU
   const size_t il1_pad = il1_nopad ? 0 : 8192;
-  if (precision == TF_PREC_F16X3 && !ring) {
+  const long long team_cap = one_team && il1_nopad ? 512 : 256;
+  if (precision == TF_PREC_F16X3) {
     // staggered two-team kernel: one 512-thread workgroup per CU, two 64-ray passes in flight
-    long long blocks = ((m + 63) / 64 + 1) / 2;
-    if (one_team) blocks = (m + 63) / 64;
-    if (blocks > (one_team && il1_nopad ? 512 : 256)) blocks = one_team && il1_nopad ? 512 : 256;
+    long long blocks = one_team ? (m + 63) / 64 : ((m + 63) / 64 + 1) / 2;
+    if (blocks > team_cap) blocks = team_cap;
     if (one_team) inner_light3_kernel<false, 3, false, 1><<<(unsigned)blocks, 256, il1_pad, stream>>>(IL_ARGS);
     else if (outer) inner_light3_kernel<true, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     else if (acts) inner_light3_kernel<false, 3, true><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS, acts);
     else inner_light3_kernel<false, 3><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
-    TF_LAUNCH_CHECK(who);
-    return TF_OK;
-  }
-  if (precision == TF_PREC_F16X2 && !ring && !cols_x2) {
+  } else if (precision == TF_PREC_F16X2) {
     // ... its 128-ray form: two 128-ray passes in flight (source indices are carried as 32-bit values)
     TF_REQUIRE(m <= 0x7fffffffLL, TF_ESHAPE, "%s: more than 2^31 - 1 rays in one call", who);
-    long long blocks = ((m + 127) / 128 + 1) / 2;
-    if (one_team) blocks = (m + 127) / 128;
-    if (blocks > (one_team && il1_nopad ? 512 : 256)) blocks = one_team && il1_nopad ? 512 : 256;
+    long long blocks = one_team ? (m + 127) / 128 : ((m + 127) / 128 + 1) / 2;
+    if (blocks > team_cap) blocks = team_cap;
     if (one_team) inner_light3_kernel<false, 2, false, 1><<<(unsigned)blocks, 256, il1_pad, stream>>>(IL_ARGS);
     else if (outer) inner_light3_kernel<true, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
     else inner_light3_kernel<false, 2><<<(unsigned)blocks, 512, 0, stream>>>(IL_ARGS);
-    TF_LAUNCH_CHECK(who);
-    return TF_OK;
+  } else if (precision == TF_PREC_F16) {
+    tf_inner_light_launch_f16(IL_ARGS, stream);
+  } else {
+    tf_inner_light_launch_f32(IL_ARGS, stream);
   }
-#endif
-  if (cols) {
-    // column-owned kernel: 128 rays per pass, persistent workgroups (two resident per CU)
-    long long blocks = (m + 127) / 128;
-    const long long cap = precision == TF_PREC_F16X3 ? 256 : 512;
-    if (blocks > cap) blocks = cap;
-#ifdef IL2_X3
-    if (precision == TF_PREC_F16X3) inner_light2_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-    else
-#endif
-    if (precision == TF_PREC_F16X2) inner_light2_kernel<2><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-    else inner_light2_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-    TF_LAUNCH_CHECK(who);
-    return TF_OK;
-  }
-  long long blocks = (m + 127) / 128;
-  if (blocks > TF_INNER_BLOCKS) blocks = TF_INNER_BLOCKS;
-  if (precision == TF_PREC_F32) inner_light_kernel<0><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-  else if (precision == TF_PREC_F16) inner_light_kernel<1><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-  else if (precision == TF_PREC_F16X2) inner_light_kernel<2><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
-  else inner_light_kernel<3><<<(unsigned)blocks, 256, 0, stream>>>(IL_ARGS);
 #undef IL_ARGS
   TF_LAUNCH_CHECK(who);
   return TF_OK;

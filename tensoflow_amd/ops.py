@@ -903,22 +903,32 @@ WEIGHTS_PACKED = 0x100
 class PackCache:
     """Caller-side memo for ONE network's packed-weight workspace: repeated calls with unchanged weights pass
     TF_WEIGHTS_PACKED and skip the fragment re-pack launches (the library itself is stateless).  Weight updates are
-    detected through (data_ptr, torch _version) of every weight tensor."""
+    detected through (data_ptr, torch _version) of every weight tensor.  One workspace PER STREAM the network is called on: a
+    workspace also holds per-call rows (the flow kernels' hoisted per-point layer-1 part), so two calls in flight on two streams
+    must not share one (round 4 measured exactly that as run-to-run different checksums)."""
 
     def __init__(self):
-        self.ws = None
-        self.key = None
+        self._per_stream = {}
+
+    def _slot(self):
+        return self._per_stream.setdefault(int(torch.cuda.current_stream().cuda_stream), {"ws": None, "key": None})
+
+    @property
+    def ws(self):
+        return self._slot()["ws"]
 
     def workspace(self, n_floats, device):
-        if self.ws is None or self.ws.numel() < n_floats or self.ws.device != torch.device(device):
-            self.ws = torch.empty(int(n_floats), dtype=torch.float32, device=device)
-            self.key = None
-        return self.ws
+        sl = self._slot()
+        if sl["ws"] is None or sl["ws"].numel() < n_floats or sl["ws"].device != torch.device(device):
+            sl["ws"] = torch.empty(int(n_floats), dtype=torch.float32, device=device)
+            sl["key"] = None
+        return sl["ws"]
 
     def flag(self, tensors, precision):
+        sl = self._slot()
         key = (int(precision), tuple((t.data_ptr(), t._version) for t in tensors))
-        hit = key == self.key
-        self.key = key
+        hit = key == sl["key"]
+        sl["key"] = key
         return WEIGHTS_PACKED if hit else 0
 
 

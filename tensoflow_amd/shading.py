@@ -326,10 +326,68 @@ class MCShader:
         self.overlap_reduce = False     # True: issue the per-pixel reduction on the second stream, under the NEXT batch's per-point stage and
                                         # flow sampling.  Measured slower (41.7 vs 40.7 ms per step): its texel gathers slow the flow kernel by
                                         # more (+2.1 ms) than the reduction's own 2.7 ms
-        self._side_stream = None
+        self._side_streams = {}         # per calling stream (two shade() calls may be in flight on two streams: shade_many)
+        self._call_streams = []
         self.timer = _NoTimer()
-        self.hit_total = None
+        self._hit_totals = {}           # per calling stream: device-side tallies of the hit rays (no sync)
         self.human_hw = None
+
+    def _side_stream_of(self, cur, dev):
+        key = int(cur.cuda_stream)
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=dev)
+        return self._side_streams[key]
+
+    @property
+    def hit_total(self):
+        """Sum of the per-stream hit tallies (a device tensor; synchronise before reading it from the host), None before any call."""
+        if not self._hit_totals:
+            return None
+        vals = list(self._hit_totals.values())
+        cur = torch.cuda.current_stream()
+        for s in self._call_streams:
+            cur.wait_stream(s)
+        tot = vals[0].clone()
+        for v in vals[1:]:
+            tot = tot + v
+        return tot
+
+    @hit_total.setter
+    def hit_total(self, v):
+        if v is not None:
+            raise ValueError("hit_total can only be reset (None)")
+        self._hit_totals = {}
+
+    @torch.no_grad()
+    def shade_many(self, pts, view_dirs, normals, sn_diffuse, sn_specular, chunk, n_streams=1, keep=("colors",)):
+        """The chunk loop of a frame / a batch (materialRenderer.py:705-709 shades 512 rays per pass, strictly one after another).
+        n_streams > 1 is a MEASUREMENT switch, not a product path (round 5, tools/exp_streams.py): with two calls in flight on two HIP
+        streams -- every stream with its own workspaces (ops.PackCache, side streams, hit tallies) -- a step is <= 1 % faster (the
+        stage kernels cannot share a CU: DESIGN.md round 5) and NOT bit-identical: of two calls that start at the same moment, ~0.04 %
+        of the second's points come out different, traced (tools/exp_streams3.py) to the first kernel of the call, the element-wise
+        `view_angles_kernel`, taking the other tangent-frame candidate on a few lanes although its inputs are bit-identical -- not
+        explained; the serial loop (n_streams = 1, the default) is the only one callers get.
+        -> list of dicts holding the `keep` entries per chunk."""
+        cur = torch.cuda.current_stream()
+        while len(self._call_streams) < n_streams:
+            self._call_streams.append(torch.cuda.Stream(device=pts.device))
+        outs = []
+        for i, c0 in enumerate(range(0, pts.shape[0], chunk)):
+            s = self._call_streams[i % n_streams] if n_streams > 1 else cur
+            if n_streams > 1:
+                s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                o = self.shade(pts[c0:c0 + chunk], view_dirs[c0:c0 + chunk], normals[c0:c0 + chunk], sn_diffuse, sn_specular)
+                outs.append({k: o[k] for k in keep if k != "_live_count"})
+                if "_live_count" in keep:          # the number of rays the traversal was handed (weight != 0): a device scalar
+                    outs[-1]["_live_count"] = o["_pos_live" if "_pos_live" in o else "live"].sum(dtype=torch.int64)
+        if n_streams > 1:
+            for s in self._call_streams[:n_streams]:
+                cur.wait_stream(s)
+            for o in outs:
+                for v in o.values():
+                    v.record_stream(cur)
+        return outs
 
     def latent(self, sn):
         if sn not in self._latent:
@@ -444,7 +502,8 @@ class MCShader:
                         hit_lights[ids] = self.miss_lights_composed(pts_rep[org], dirs[ids], poses[org] if poses is not None else None)
                         if self.human_hw is not None and self._last_hlhw is not None:
                             self.human_hw[ids] = self._last_hlhw           # human_lights * human_weights (get_lights' 2nd value, :975)
-        self.hit_total = count if self.hit_total is None else self.hit_total + count   # device-side tally (no sync)
+        key = int(torch.cuda.current_stream().cuda_stream)          # device-side tally (no sync), one per calling stream
+        self._hit_totals[key] = count if key not in self._hit_totals else self._hit_totals[key] + count
         return hit_lights, hit, depth, inters
 
     def lights(self, pts_rep, dirs, live=None, slot_order=None):
@@ -514,11 +573,10 @@ class MCShader:
             dev = pts.device
             bufs = (torch.empty(pn, T, 3, dtype=torch.float32, device=dev), torch.empty(pn, T, 3, dtype=torch.float32, device=dev),
                     torch.empty(pn, sn_specular, dtype=torch.bool, device=dev), torch.empty(pn, T, dtype=torch.uint8, device=dev))
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=dev)
             cur = torch.cuda.current_stream()
-            self._side_stream.wait_stream(cur)
-            with torch.cuda.stream(self._side_stream):
+            side = self._side_stream_of(cur, dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
                 with tm.stage("shade_dirs (diffuse + fixed rows)", overlapped=True):
                     ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
                                    slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs)
@@ -526,7 +584,7 @@ class MCShader:
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
             with tm.stage("shade_dirs"):
-                cur.wait_stream(self._side_stream)
+                cur.wait_stream(side)
                 dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
                                                         slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs)
         else:
@@ -558,9 +616,7 @@ class MCShader:
             # the reduction (texel gathers of the environment light: latency bound, matrix cores idle) goes to the side stream: it runs
             # under the per-point stage and the flow sampling of the NEXT batch unless the caller reads the colours first
             # (ShadeOutputs.__getitem__ waits).  Its inputs are kept from the allocator until that work is done (record_stream).
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=pts.device)
-            pending = self._side_stream
+            pending = self._side_stream_of(torch.cuda.current_stream(), pts.device)
             pending.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(pending):
                 with tm.stage("shade_reduce", overlapped=True):

@@ -134,13 +134,13 @@ def test_shape_renderer_nvs_golden(golden, dev):
     """A 24 x 24 ShapeRenderer.nvs frame (shapeRenderer.py:569-668) against the imported reference, every output map.  The maps
     rendered along the camera ray (colour, albedo, roughness, diffuse colour) hold 1e-4 at every pixel; so does the composited normal
     on every pixel but one on the silhouette (row 22, column 0: opacity < 1, the normalisation of acc * sum(w grad) + (1 - acc) e_z
-    amplifies fp32 noise of the gradient): 1.44e-4 with the f16x3 decoder, 1.34e-4 with the exact-fp32 one (tools/exp_val_branch.py,
+    amplifies fp32 noise of the gradient): 1.44e-4 with the f16x3 decoder, 1.34e-4 with the exact-fp32 one (tools/exp_val_branch.py of the round-4 tree, git a8fd04d,
     round 4 -- with round 3's Softplus arithmetic, 1.6x less accurate in absolute terms, the same pixel happened to land at 9e-5),
     so `normal` takes the rule of the next group.  The maps evaluated
     at the expected-depth point -- lights looked up along a finite-difference normal, the traced occlusion with its inverse-CDF
     resampling of 128 field evaluations -- hold it on >= 99 % of the pixels and stay within 5e-4 on the rest: measured 5 of 576
     pixels beyond 1e-4 (two silhouette pixels whose depth point floats off the surface, three traces), with the exact-fp32 decoder
-    deviating by the same amounts as the f16x3 one (tools/exp_val_branch.py): fp32 noise of the reference's own chain, not the
+    deviating by the same amounts as the f16x3 one (tools/exp_val_branch.py of the round-4 tree, git a8fd04d): fp32 noise of the reference's own chain, not the
     operand format."""
     r, ge = _eval_renderer(golden, dev)
     h, w = [int(v) for v in ge["nvs_hw"]]
