@@ -52,11 +52,18 @@ def softplus100(x):
 
 
 def sdf_forward(sd, xyz, level, aabb, n_levels, prefix=""):
-    """TensoSDF.forward (sdf_multires=0): -> [N, 1+app_dim]."""
+    """TensoSDF.forward (network/fields.py:262-299) -> [N, 1+app_dim].  sdf_multires = m is read off the first layer's width
+    (3C + 3 + 6m inputs): m > 0 appends get_embedder(m)(x) in place of the raw point -- of the CONTRACTED point when m == 3, of the raw
+    one otherwise (:294)."""
     planes = [sd[f"{prefix}sdf_plane.{i}"] for i in range(3)]
     lines = [sd[f"{prefix}sdf_line.{i}"] for i in range(3)]
     feat = vm_feature(planes, lines, xyz, aabb, level, n_levels)
-    h = torch.cat([feat, xyz], -1)
+    m = (sd[f"{prefix}sdf_mat.0.weight"].shape[1] - feat.shape[1] - 3) // 6
+    pos = xyz
+    if m > 0:
+        from .encodings import posenc
+        pos = posenc(contraction(xyz, aabb).reshape(-1, 3) if m == 3 else xyz, m)
+    h = torch.cat([feat, pos], -1)
     h = F.linear(h, sd[f"{prefix}sdf_mat.0.weight"], sd[f"{prefix}sdf_mat.0.bias"])
     h = softplus100(h)
     return F.linear(h, sd[f"{prefix}sdf_mat.2.weight"], sd[f"{prefix}sdf_mat.2.bias"])

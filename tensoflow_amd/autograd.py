@@ -316,8 +316,19 @@ def sdf_alpha_composed(planes, lines, W1, b1, W2, b2, pts, level, dists, dirs, i
     P = (pts[None] + offs[:, None]).reshape(-1, 3).contiguous()
     lv = None if level is None else level.reshape(-1).repeat(7).contiguous()
     feat = VmGatherFn.apply(P, lv, aabb, n_levels, *planes, *lines)
-    # 108 + 3 inputs, one zero column (and a zero weight column) added: rows of 112 floats are aligned for the dense layers' DMA kernels
-    h = LinearActFn.apply(torch.cat([feat, P, torch.zeros_like(P[:, :1])], -1), F.pad(W1, (0, 1)), b1, ops.ACT_SOFTPLUS, 100.0)
+    m_freq = (W1.shape[1] - feat.shape[1] - 3) // 6
+    if m_freq > 0:
+        # sdf_multires > 0 (fields.py:66-81, :293-299): the positional encoding of the contracted (m == 3) or raw coordinates joins the
+        # VM features; differentiable torch ops (the gather's coordinates are detached in the reference as well)
+        from .encodings import posenc
+        a = torch.as_tensor(aabb, dtype=torch.float32, device=P.device)
+        E = posenc(((P - a[0]) / (a[1] - a[0])) if m_freq == 3 else P, m_freq)
+        pad = (-(feat.shape[1] + E.shape[1])) % 4
+        x_in = torch.cat([feat, E] + ([torch.zeros_like(P[:, :1]).expand(-1, pad)] if pad else []), -1).contiguous()
+        h = LinearActFn.apply(x_in, F.pad(W1, (0, pad)), b1, ops.ACT_SOFTPLUS, 100.0)
+    else:
+        # 108 + 3 inputs, one zero column (and a zero weight column) added: rows of 112 floats are aligned for the dense layers' DMA kernels
+        h = LinearActFn.apply(torch.cat([feat, P, torch.zeros_like(P[:, :1])], -1), F.pad(W1, (0, 1)), b1, ops.ACT_SOFTPLUS, 100.0)
     s = LinearActFn.apply(h, W2[:1].contiguous(), b2[:1].contiguous(), ops.ACT_NONE, 0.0)[:, 0].view(7, N)
     app = LinearActFn.apply(h[:N].contiguous(), W2[1:].contiguous(), b2[1:].contiguous(), ops.ACT_NONE, 0.0)
     sdf = s[0]
@@ -344,6 +355,7 @@ class SdfAlphaFn(torch.autograd.Function):
         planes, lines = list(params[:3]), list(params[3:6])
         W1, b1, W2, b2 = params[6:10]
         packed = ops.VmPacked(planes, lines, n_levels)
+        ctx.composed = ops.sdf_embed_freqs(packed, W1) > 0          # sdf_multires > 0: forward and backward on the composition
         inv_host = float(inv_s)
         alpha, grad, feat, sdf, nh, taps = ops.sdf_alpha(packed, W1.detach(), b1.detach(), W2.detach(), b2.detach(), pts, level, dists, dirs,
                                                          aabb, units, inv_host, cos_anneal, want_taps=True)
@@ -358,7 +370,7 @@ class SdfAlphaFn(torch.autograd.Function):
         import os
         pts, level, dists, dirs, inv_s, sdf, taps, *params = ctx.saved_tensors
         cos_anneal, aabb, units, n_levels, has_level = ctx.cfg
-        if os.environ.get("TENSOFLOW_SDF_BWD") == "composed":         # dev switch: the torch composition
+        if ctx.composed or os.environ.get("TENSOFLOW_SDF_BWD") == "composed":         # sdf_multires > 0 (or the dev switch): the torch composition
             with torch.enable_grad():
                 leaf = [p.detach().requires_grad_(True) for p in params]
                 inv = inv_s.detach().requires_grad_(True)

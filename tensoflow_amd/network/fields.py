@@ -74,8 +74,11 @@ class TensoSDF(nn.Module):
         self.kernel_size, self.sigma = 5, 0.5                       # fields.py:34-36
         self.gaussian1d = GaussianBlur1D(self.kernel_size, self.sigma, stride=1, device=device)
         self.gaussian2d = GaussianBlur2D(self.kernel_size, self.sigma, stride=1, device=device)
-        if sdf_multires != 0:
-            raise NotImplementedError("the fused decoder instantiates sdf_multires=0 (configs/shape/*: default)")
+        # sdf_multires = m > 0 (fields.py:66-91; the reference class default is 3, the renderers' and every shipped config's 0): the
+        # positional encoding of the point (3 + 6 m values; of the CONTRACTED point when m == 3, :294) joins the VM features in front of
+        # the decoder.  The fused kernels instantiate m = 0; m > 0 runs as a composition of the gather / encoding / dense-layer kernels
+        # (ops.sdf_forward / ops.sdf_alpha / autograd.SdfAlphaFn dispatch on the width of the first layer) -- correct, not fast.
+        self.sdf_multires = int(sdf_multires)
         self.sdf_n_comp, self.sdf_dim, self.app_dim, self.device = sdf_n_comp, sdf_dim, app_dim, device
         self.matMode, self.vecMode, self.nplane, self.init_radius = [[0, 1], [0, 2], [1, 2]], [2, 1, 0], 3, 0.2
         self.update_gridSize_aabb(torch.as_tensor(gridSize), aabb, init_n_levels)
@@ -87,9 +90,14 @@ class TensoSDF(nn.Module):
             planes.append(nn.Parameter(init.clone()))
             lines.append(nn.Parameter(torch.ones(1, sdf_n_comp, int(ls), 1) * (1.0 / (sdf_n_comp * 3))))
         self.sdf_plane, self.sdf_line = nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
-        self.sdf_mat = nn.Sequential(nn.Linear(3 * sdf_n_comp + 3, sdf_dim), nn.Softplus(beta=100), nn.Linear(sdf_dim, 1 + app_dim)).to(device)
+        in_ch = 3 + 6 * self.sdf_multires
+        self.sdf_mat = nn.Sequential(nn.Linear(3 * sdf_n_comp + in_ch, sdf_dim), nn.Softplus(beta=100), nn.Linear(sdf_dim, 1 + app_dim)).to(device)
         nn.init.constant_(self.sdf_mat[0].bias, 0.0)
-        nn.init.normal_(self.sdf_mat[0].weight, 0.0, np.sqrt(2) / np.sqrt(sdf_dim))
+        if self.sdf_multires > 0:             # (:84-86) only the columns of the raw coordinates start non-zero
+            nn.init.constant_(self.sdf_mat[0].weight, 0.0)
+            nn.init.normal_(self.sdf_mat[0].weight[:, -in_ch:-(in_ch - 3)], 0.0, np.sqrt(2) / np.sqrt(sdf_dim))
+        else:
+            nn.init.normal_(self.sdf_mat[0].weight, 0.0, np.sqrt(2) / np.sqrt(sdf_dim))
         nn.init.constant_(self.sdf_mat[-1].bias, -self.init_radius)
         nn.init.normal_(self.sdf_mat[-1].weight, mean=np.sqrt(np.pi) / np.sqrt(sdf_dim), std=0.0001)
         self._packed, self._packed_version = None, None

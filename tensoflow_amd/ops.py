@@ -158,10 +158,37 @@ def _workspace(key, n_floats, device):
     return t
 
 
+def sdf_embed_freqs(packed: VmPacked, w1):
+    """sdf_multires of a TensoSDF decoder from the width of its first layer: 3C + 3 + 6 m inputs (fields.py:66-81: get_embedder(m, 3)
+    appended to the VM features).  0 = the shipped configs, served by the fused kernels; m > 0 by the composition below."""
+    extra = w1.shape[1] - 3 * packed.desc.C - 3
+    if extra < 0 or extra % 6:
+        raise RuntimeError(f"TensoSDF decoder: {w1.shape[1]} inputs for {packed.desc.C} components per plane")
+    return extra // 6
+
+
+def _sdf_decode_composed(packed, w1, b1, w2, b2, xyz, level, aabb, rows_out=None):
+    """TensoSDF.forward with sdf_multires = m > 0 (fields.py:293-299): [VM features | embed(xyz)] -> Linear -> Softplus(100) -> Linear, as a
+    composition of the gather kernel, the positional-encoding kernel and the dense-layer kernels (exact fp32).  The reference embeds
+    the CONTRACTED coordinates when m == 3 and the raw ones otherwise (:294).  rows_out: use only these rows of the second layer."""
+    from .encodings import posenc
+    m = sdf_embed_freqs(packed, w1)
+    feat = vm_gather(packed, xyz, level, aabb)
+    a = torch.as_tensor(aabb, dtype=torch.float32, device=xyz.device)
+    e = posenc(((xyz - a[0]) / (a[1] - a[0])) if m == 3 else xyz, m)
+    h = linear_fwd(torch.cat([feat, e], -1).contiguous(), w1, b1, ACT_SOFTPLUS, 100.0)
+    if rows_out is not None:
+        w2, b2 = w2[rows_out].contiguous(), b2[rows_out].contiguous()
+    return linear_fwd(h, w2, b2)
+
+
 def sdf_forward(packed: VmPacked, w1, b1, w2, b2, xyz, level, aabb, want_feat=True, precision=1):
     """TensoSDF.forward -> (sdf [n], feat [n,A] or None).  precision: PREC_F16X3 (default) or PREC_F32."""
     lib = packed.lib
     xyz = _f(xyz)
+    if sdf_embed_freqs(packed, w1) > 0:
+        out = _sdf_decode_composed(packed, w1, b1, w2, b2, xyz, level, aabb, rows_out=None if want_feat else slice(0, 1))
+        return out[:, 0].contiguous(), (out[:, 1:].contiguous() if want_feat else None)
     n = xyz.shape[0]
     mlp, keep = _sdf_mlp(w1, b1, w2, b2)
     sdf = torch.empty(n, dtype=torch.float32, device=xyz.device)
@@ -184,6 +211,28 @@ def sdf_alpha(packed: VmPacked, w1, b1, w2, b2, pts, level, dists, dirs, aabb, u
     pts, dists, dirs = _f(pts), _f(dists.reshape(-1)), _f(dirs)
     n = pts.shape[0]
     dev = pts.device
+    if sdf_embed_freqs(packed, w1) > 0:
+        # sdf_multires > 0: the seven evaluations through the composed decoder, the rest of compute_sdf_alpha element-wise
+        # (shapeRenderer.py:995-1025; fields.py:227-260)
+        u = torch.as_tensor([float(v) for v in units], dtype=torch.float32, device=dev)
+        offs = torch.zeros(7, 3, device=dev)
+        for ax in range(3):
+            offs[1 + 2 * ax, ax], offs[2 + 2 * ax, ax] = u[ax], -u[ax]
+        lv = None if level is None else _f(level.reshape(-1))
+        c = _sdf_decode_composed(packed, w1, b1, w2, b2, pts, lv, aabb, rows_out=None if want_feat else slice(0, 1))
+        sdf, feat = c[:, 0].contiguous(), (c[:, 1:].contiguous() if want_feat else None)
+        P = (pts[None] + offs[1:, None]).reshape(-1, 3).contiguous()
+        taps = _sdf_decode_composed(packed, w1, b1, w2, b2, P, None if lv is None else lv.repeat(6), aabb, rows_out=slice(0, 1)).view(6, n).t().contiguous()
+        grad = torch.stack([(taps[:, 2 * ax] - taps[:, 2 * ax + 1]) / (2 * u[ax]) for ax in range(3)], -1)
+        nh = None
+        if want_hess:
+            hess = torch.stack([(taps[:, 2 * ax] + taps[:, 2 * ax + 1] - 2 * sdf) / (u[ax] ** 2) for ax in range(3)], -1)
+            nh = (grad * hess).sum(-1) / ((grad ** 2).sum(-1) + 1e-5)
+        true_cos = (dirs * grad).sum(-1)
+        iter_cos = -(torch.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal) + torch.relu(-true_cos) * cos_anneal)
+        pc, nc = torch.sigmoid((sdf - iter_cos * dists * 0.5) * inv_s), torch.sigmoid((sdf + iter_cos * dists * 0.5) * inv_s)
+        alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clip(0.0, 1.0)
+        return (alpha, grad, feat, sdf, nh, taps) if want_taps else (alpha, grad, feat, sdf, nh)
     mlp, keep = _sdf_mlp(w1, b1, w2, b2)
     alpha = torch.empty(n, dtype=torch.float32, device=dev)
     grad = torch.empty(n, 3, dtype=torch.float32, device=dev)

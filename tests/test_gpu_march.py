@@ -205,6 +205,47 @@ def test_module_tensosdf(golden, dev):
         assert not torch.allclose(m(g["pts"].to(dev), g["level"].to(dev)), out)
 
 
+@pytest.mark.parametrize("tag", ["mr3", "mr2"])
+def test_module_tensosdf_multires(golden, dev, tag):
+    """TensoSDF(sdf_multires = 3 | 2) (fields.py:66-91, :293-299; the reference class's default is 3, no shipped config sets it): the
+    decoder then has 3C + 3 + 6 m inputs and runs as a composition of the gather / encoding / dense-layer kernels (ops.sdf_forward,
+    ops.sdf_alpha and autograd.SdfAlphaFn dispatch on the first layer's width).  Forward, FD gradient, hessian term and the parameter
+    gradients through compute_sdf_alpha's autograd node against the imported reference."""
+    from conftest import in_fp64
+    from oracle import vm_field as ovm
+    from tensoflow_amd.autograd import SdfAlphaFn
+    from tensoflow_amd.network.fields import TensoSDF
+    g = golden("tensosdf_" + tag)
+    mr = int(g["multires"])
+    m = TensoSDF(torch.tensor([32, 32, 32]), AABB, device=dev, init_n_levels=3, sdf_multires=mr)
+    assert m.sdf_mat[0].weight.shape == (256, 108 + 3 + 6 * mr)
+    m.load_state_dict(g.sd)
+    pts, level = g["pts"].to(dev), g["level"].to(dev)
+    t64 = in_fp64(ovm.sdf_forward, g.sd, g["pts"], g["level"], AABB, 3)
+    with torch.no_grad():
+        out = m(pts, level)
+        parity(out.cpu(), g["out_lvl"], truth=t64, label=f"TensoSDF multires {mr} forward")
+        parity(m(pts, None).cpu(), g["out_none"], truth=in_fp64(ovm.sdf_forward, g.sd, g["pts"], None, AABB, 3), label=f"TensoSDF multires {mr} forward, no levels")
+        parity(m.sdf(pts, level).cpu(), g["out_lvl"][:, :1], truth=t64[:, :1], label=f"TensoSDF multires {mr} sdf")
+        grad, nh = m.gradient(pts, level, training=True, sdf=out[:, :1])
+        g64, nh64 = in_fp64(ovm.sdf_gradient, g.sd, g["pts"], g["level"], AABB, 3, g["grid_size"], sdf=t64[:, :1], training=True)
+        parity(grad.cpu(), g["grad_lvl"], truth=g64, label=f"TensoSDF multires {mr} gradient")
+        parity(nh.cpu(), g["normal_hessian"], truth=nh64, abs_tol=2e-3, label=f"TensoSDF multires {mr} normal_hessian")
+    # the training direction: d sum(out * w) / d parameters through SdfAlphaFn (outputs sdf | features of the centre tap)
+    n = pts.shape[0]
+    params = list(m.sdf_plane) + list(m.sdf_line) + m._w()
+    inv_s = torch.tensor([20.0], device=dev)
+    alpha, gr, feat, sdf, nh2 = SdfAlphaFn.apply(pts, level[:, 0].contiguous(), torch.full((n,), 0.01, device=dev), torch.zeros(n, 3, device=dev), inv_s, 0.5,
+                                                 AABB, [float(u) for u in m.units], 3, *params)
+    w = g["bwd_w"].to(dev)
+    ((sdf * w[:, 0]).sum() + (feat * w[:, 1:]).sum()).backward()
+    names = [f"sdf_plane.{i}" for i in range(3)] + [f"sdf_line.{i}" for i in range(3)] + ["sdf_mat.0.weight", "sdf_mat.0.bias", "sdf_mat.2.weight", "sdf_mat.2.bias"]
+    for k, p in zip(names, params):
+        ref = g.grad[k]
+        err = float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+        assert err < 2e-4, (k, err)                      # scatter atomics and the dense layers' split reductions reorder fp32 sums
+
+
 def test_module_tensoflow(golden, dev):
     from tensoflow_amd.network.flow import TensoFlow
     g = golden("tensoflow_r32")

@@ -25,6 +25,23 @@ def test_tensosdf_forward_gradient(golden, tag):
     assert rel_err(grad0, g["grad_none"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["mr3", "mr2"])
+def test_tensosdf_multires_forward_gradient_backward(golden, tag):
+    """sdf_multires > 0 (fields.py:66-91: the reference class's default is 3; no shipped config sets it): the positional encoding of
+    the contracted (m = 3) or raw (m = 2) point in front of the decoder, against the imported reference."""
+    g = golden("tensosdf_" + tag)
+    assert g.sd["sdf_mat.0.weight"].shape[1] == 108 + 3 + 6 * int(g["multires"])
+    out_none = ovm.sdf_forward(g.sd, g["pts"], None, AABB, 3)
+    out_lvl = ovm.sdf_forward(g.sd, g["pts"], g["level"], AABB, 3)
+    assert rel_err(out_none, g["out_none"]) < 2e-6 and rel_err(out_lvl, g["out_lvl"]) < 2e-6
+    grad, nh = ovm.sdf_gradient(g.sd, g["pts"], g["level"], AABB, 3, g["grid_size"], sdf=out_lvl[:, :1], training=True)
+    assert rel_err(grad, g["grad_lvl"]) < 1e-5 and rel_err(nh, g["normal_hessian"]) < 2e-4
+    sd = {k: v.clone().requires_grad_(True) for k, v in g.sd.items()}
+    (ovm.sdf_forward(sd, g["pts"], g["level"], AABB, 3) * g["bwd_w"]).sum().backward()
+    for k, ref in g.grad.items():
+        assert rel_err(sd[k].grad, ref) < 1e-5, k
+
+
 def test_tensosdf_backward(golden):
     g = golden("tensosdf_r32_l3")
     sd = {k: v.clone().requires_grad_(True) for k, v in g.sd.items()}

@@ -81,6 +81,32 @@ def gen_tensosdf():
              units=net.units, bwd_w=w, **grads)
 
 
+def gen_tensosdf_multires():
+    """TensoSDF with sdf_multires > 0 (fields.py:66-91, :293-299; the class default is 3: embed the CONTRACTED point; any other m
+    embeds the raw point): forward with / without levels, FD gradient + hessian term, parameter gradients."""
+    from network.fields import TensoSDF
+    for tag, m in (("mr3", 3), ("mr2", 2)):
+        torch.manual_seed(6033)
+        gs = torch.tensor([32, 32, 32])
+        net = TensoSDF(gs, AABB, device="cpu", sdf_n_comp=36, sdf_dim=256, app_dim=128, init_n_levels=3, sdf_multires=m)
+        perturb_(list(net.sdf_plane) + list(net.sdf_line), 0.05, 1)
+        perturb_([net.sdf_mat[0].weight], 0.02, 2)          # the embedding's columns start at zero (:84-86): give them something to do
+        net.eval()
+        g = torch.Generator().manual_seed(12)
+        pts = torch.rand(256, 3, generator=g) * 2.4 - 1.2
+        level = torch.rand(256, 1, generator=g) * 4 - 1
+        with torch.no_grad():
+            out_none = net(pts, None)
+            out_lvl = net(pts, level)
+            grad, nh = net.gradient(pts, level, training=True, sdf=out_lvl[..., :1])
+        w = torch.randn(out_lvl.shape, generator=g)
+        net.zero_grad()
+        (net(pts, level) * w).sum().backward()
+        grads = {"grad/" + k: p.grad for k, p in net.named_parameters()}
+        save(f"tensosdf_{tag}", sd=net.state_dict(), pts=pts, level=level, out_none=out_none, out_lvl=out_lvl, grad_lvl=grad,
+             normal_hessian=nh, grid_size=gs, n_levels=np.int32(3), units=net.units, bwd_w=w, multires=np.int32(m), **grads)
+
+
 def gen_pwquad():
     from network.flow import ElementWisePWQuadraticTransform
     t = ElementWisePWQuadraticTransform()
@@ -1116,7 +1142,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
