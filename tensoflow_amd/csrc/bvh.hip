@@ -1019,16 +1019,15 @@ extern "C" int tf_bvh_trace(const uint32_t* pairs, const float* tris12, const fl
       int nb = 0;
       hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bvh_trace_kernel<true, true, true>, 256, 0);
       resident = (e2 == hipSuccess && nb > 0) ? (nb > 8 ? 8 : nb) : 4;
-      // Round 5, measured (tools/exp_cosched.py, ms per 50 M / 201 M rays of the bench): 1 workgroup per CU 15.9 / 63.1, 2: 8.8 / 34.8,
-      // 3: 6.4 / 25.0, 4: 5.2 / 20.1, 5: 4.5 / 17.4, 6: 4.1-4.2 / 15.6, all 7 that fit: 5.0-5.1 / 16.1 -- the seventh wave per SIMD costs
-      // more in the CU's vector L1 than it hides (the kernel is co-limited by that cache's access rate): six is the default
-      // (`resident` stays what the hardware admits: a launch budget may still ask for all of them)
+      // Round 5, measured (tools/exp_bvh_k.py: budgets interleaved in one process, ms per 50 M / 201 M rays of the bench): 5 workgroups
+      // per CU 4.51 / 17.3, 6: 4.09 / 15.6, all 7 that fit: 3.86 / 14.4; 1-4: 15.9 / 8.8 / 6.4 / 5.2 per 50 M (tools/exp_cosched.py).  Every
+      // wave slot still pays: the default is all that fit.
     }
     long long blocks = (m + 255) / 256;
     // tf_set_launch_budget: fewer resident workgroups per CU than fit, so that another stream's kernel (the inner-light net on the
     // matrix cores, the flow sampler on the vector unit) finds registers / wave slots on every CU beside this latency-bound one
     const int budget = tf_launch_budget().bvh_blocks_per_cu;
-    const int per_cu = budget > 0 ? (budget < resident ? budget : resident) : (resident < 6 ? resident : 6);
+    const int per_cu = budget > 0 && budget < resident ? budget : resident;
     if (blocks > 256LL * per_cu) blocks = 256LL * per_cu;   // persistent blocks pull rays until the pool is empty
 #ifndef BVH_NO_SPINE
     const bool use_spine = rays_per_origin >= 64 && m % rays_per_origin == 0;
