@@ -122,6 +122,9 @@ def compact_line(line):
                 got["error"] = str(got["error"])[:80]
             if got:
                 sec[key] = got
+    tiled = (line.get("train_dp") or {}).get("config4_frame512_tiled") if isinstance(line.get("train_dp"), dict) else None
+    if isinstance(tiled, dict):
+        sec["config4_frame512_tiled"] = _pick(tiled, ("ms_per_frame", "ranks", "ranks_reported_by_backend", "error"))
     if sec:
         out["secondary"] = sec
     st = line.get("stages_ms_per_step")
@@ -373,7 +376,7 @@ def flow_count_probe(sh, pts, view, nrm, S, steps, timer=None):
                 rays_per_s=pn * (2 * S + 512) / dt)
 
 
-def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800, field_note="fp32 VM fields"):
+def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800, field_note="fp32 VM fields", rank=0, world=1):
     """Secondary figure (BASELINE configs[4] at one GPU's share): ONE full 800 x 800 frame -- primary visibility of the 640 000 pinhole
     rays through the mesh BVH, then the flow-sampled integral with 512 samples per lobe (512 + 512 + 512 = 1 536 secondary rays per
     surface point) on every pixel that sees the object, plain-f16 operands in the flow nets and the inner-light MLP ('fp16 ... flow');
@@ -382,17 +385,25 @@ def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800, field_not
     from tensoflow_amd import ops
     from tensoflow_amd.synth import pinhole_rays
     o, d, _, _ = [torch.from_numpy(a).to(device) for a in pinhole_rays(hw * hw, seed=2, h=hw, w=hw)]
+    if world > 1:
+        # BASELINE configs[4] as written: the frame's rays tiled over the ranks (materialRenderer.py:705-709 chunks them on one GPU), every
+        # rank shades rows dist.shard_range(h * w, rank, world), ONE all-gather assembles [h * w, 3] on every rank
+        from tensoflow_amd import dist as tdist
+        lo, hi = tdist.shard_range(hw * hw, rank, world)
+        o, d = o[lo:hi].contiguous(), d[lo:hi].contiguous()
     keep, keep_ip = sh.precision, sh.inner_precision
     sh.precision = sh.inner_precision = ops.PREC_F16
 
     def frame():
         pos, nrm, depth, hit = sh.bvh.trace(o, d)
         pts, n, v = pos[hit], nrm[hit], -d[hit]
-        img = torch.ones(hw * hw, 3, device=device)
+        img = torch.ones(o.shape[0], 3, device=device)
         cols = [sh.shade(pts[c:c + chunk].contiguous(), v[c:c + chunk].contiguous(), n[c:c + chunk].contiguous(), S, S)["colors"]
                 for c in range(0, pts.shape[0], chunk)]
         if cols:
             img[hit] = torch.cat(cols)
+        if world > 1:
+            img = tdist.gather_maps({"color": img}, hw * hw, rank, world)["color"]
         return img, pts.shape[0]
 
     try:
@@ -405,9 +416,14 @@ def relight_frame_probe(sh, device, steps, S=512, chunk=65536, hw=800, field_not
         dt = (time.perf_counter() - t0) / steps
     finally:
         sh.precision, sh.inner_precision = keep, keep_ip
-    return dict(workload=f"{hw}x{hw} frame: {hw * hw} primary rays, {n_pts} surface points x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets "
-                         f"and the inner-light MLP, {field_note}", ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
-                secondary_rays_per_s=n_pts * (2 * S + 512) / dt, finite=bool(torch.isfinite(img).all()))
+    res = dict(workload=f"{hw}x{hw} frame: {hw * hw} primary rays, {n_pts} surface points" + (f" on this rank ({world} ranks, rows tiled + one all-gather)" if world > 1 else "")
+                        + f" x ({S} + 512 + {S}) secondary rays, f16 operands in the flow nets and the inner-light MLP, {field_note}",
+               ms_per_frame=dt * 1e3, frames_per_s=1.0 / dt, points_per_s=n_pts / dt,
+               secondary_rays_per_s=n_pts * (2 * S + 512) / dt, finite=bool(torch.isfinite(img).all()), frame_rows=int(img.shape[0]))
+    if world > 1:
+        import torch.distributed as dist
+        res.update(ranks=world, ranks_reported_by_backend=dist.get_world_size(), backend=dist.get_backend())
+    return res
 
 
 def fp16_probe(sh, pts, view, nrm, S, steps, ref_colors):
@@ -912,6 +928,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     value = world * pn * args.steps / dt
+    hits_timed = sh.hit_total          # device-side tally of the timed steps' hit rays (the legs below shade more points with this shader)
+    hits_timed = None if hits_timed is None else hits_timed.clone()
     # the secondary probes below run on the first chunk of the point stream
     pts_p, view_p, nrm_p = pts[:chunk].contiguous(), view[:chunk].contiguous(), nrm[:chunk].contiguous()
 
@@ -928,6 +946,12 @@ def main():
                 if os.environ.get("TENSOFLOW_BENCH_FAKE_HANG") and world > 1:      # test hook: a collective that never returns
                     time.sleep(1e6)
                 box["r"] = train_dp_leg(device, verts, faces, aabb, unit, world, rank, max(2, args.steps), args.train_points)
+                if world > 1 and args.precision == "f16x3":
+                    # configs[4]'s frame, tiled over the ranks (the other place of the run where ranks exchange data: one all-gather)
+                    try:
+                        box["r"]["config4_frame512_tiled"] = relight_frame_probe(sh, device, 2, rank=rank, world=world)
+                    except Exception as e:
+                        box["r"]["config4_frame512_tiled"] = {"error": f"{type(e).__name__}: {e}"}
             except Exception as e:      # every rank takes the same branch (same code, same inputs); the eval line is never lost over it
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}
         if world > 1:
@@ -960,7 +984,7 @@ def main():
         longest = dom
         if dom != "inner_light" and "inner_light" in stages and stages["inner_light"]["ms_per_step"] >= 0.95 * stages[dom]["ms_per_step"]:
             dom = "inner_light"
-        hits = int(sh.hit_total.item()) if sh.hit_total is not None else 0
+        hits = int(hits_timed.item()) if hits_timed is not None else 0
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
         traced_per_step = int(live_rays.item())
         live_frac = traced_per_step / max(1, pn * (2 * S + 512))
