@@ -11,48 +11,10 @@ static constexpr float kTwoPi = 6.28318530717958647692f;
 static constexpr float kHalfPi_ = 1.57079632679489661923f;
 static constexpr float kEPS = 1e-6f;
 
-struct Frame {
-  float n[3], x[3], y[3];
-};
-
-__device__ __forceinline__ void normalize3(float* v) {  // F.normalize(dim=-1), eps 1e-12
-  float inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
-  v[0] *= inv; v[1] *= inv; v[2] *= inv;
-}
-
-// get_orthogonal_directions + cross (fields.py:812-822, :829)
-__device__ __forceinline__ void make_frame(const float* nin, Frame& F) {
-  F.n[0] = nin[0]; F.n[1] = nin[1]; F.n[2] = nin[2];
-  normalize3(F.n);
-  const float o0[3] = {F.n[1], -F.n[0], 0.f};
-  const float o1[3] = {-F.n[2], 0.f, F.n[0]};
-  const float l0 = sqrtf(o0[0] * o0[0] + o0[1] * o0[1]), l1 = sqrtf(o1[0] * o1[0] + o1[2] * o1[2]);
-  const bool use0 = l0 > l1;
-  F.x[0] = use0 ? o0[0] : o1[0]; F.x[1] = use0 ? o0[1] : o1[1]; F.x[2] = use0 ? o0[2] : o1[2];
-  normalize3(F.x);
-  F.y[0] = F.n[1] * F.x[2] - F.n[2] * F.x[1];
-  F.y[1] = F.n[2] * F.x[0] - F.n[0] * F.x[2];
-  F.y[2] = F.n[0] * F.x[1] - F.n[1] * F.x[0];
-}
+#include "shade_frame.h"
 
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ float sat(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
-
-// direction_to_angle(normals, view)/(2pi, pi/2)  (fields.py:1035-1048, :1077-1079)
-__global__ void __launch_bounds__(256) view_angles_kernel(const float* __restrict__ normals, const float* __restrict__ view,
-                                                          long long pn, float* __restrict__ va) {
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= pn) return;
-  Frame F;
-  make_frame(normals + 3 * i, F);
-  float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
-  normalize3(v);
-  const float cx = dot3(F.x, v), cy = dot3(F.y, v);
-  const float cz = fminf(fmaxf(dot3(F.n, v), -1.f + kEPS), 1.f - kEPS);
-  const float phi = fmodf(atan2f(cy, cx) + kTwoPi, kTwoPi);
-  va[2 * i] = phi / kTwoPi;
-  va[2 * i + 1] = acosf(cz) / kHalfPi_;
-}
 
 __device__ __forceinline__ float ggx_d(float NoH, float a) {
   const float a2 = a * a;
@@ -479,15 +441,6 @@ extern "C" int tf_shade_reduce_aux(const float* wgt, const float* lights, const 
                                                                             near_eps, spec_mask, pn, n_diffuse, ss, colors, diffuse_lin,
                                                                             specular_lin, aux, slot_of_pos);
   TF_LAUNCH_CHECK("tf_shade_reduce_aux");
-  return TF_OK;
-}
-
-extern "C" int tf_view_angles(const float* normals, const float* view, int64_t pn, float* view_angles, tf_stream_t stream) {
-  TF_REQUIRE(pn >= 0, TF_ESHAPE, "tf_view_angles: pn < 0");
-  if (pn == 0) return TF_OK;
-  TF_REQUIRE(normals && view && view_angles, TF_EINVAL, "tf_view_angles: null pointer");
-  view_angles_kernel<<<tf_blocks(pn, 256), 256, 0, (hipStream_t)stream>>>(normals, view, pn, view_angles);
-  TF_LAUNCH_CHECK("tf_view_angles");
   return TF_OK;
 }
 

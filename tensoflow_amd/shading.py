@@ -360,13 +360,12 @@ class MCShader:
 
     @torch.no_grad()
     def shade_many(self, pts, view_dirs, normals, sn_diffuse, sn_specular, chunk, n_streams=1, keep=("colors",)):
-        """The chunk loop of a frame / a batch (materialRenderer.py:705-709 shades 512 rays per pass, strictly one after another).
-        n_streams > 1 is a MEASUREMENT switch, not a product path (round 5, tools/exp_streams.py): with two calls in flight on two HIP
-        streams -- every stream with its own workspaces (ops.PackCache, side streams, hit tallies) -- a step is <= 1 % faster (the
-        stage kernels cannot share a CU: DESIGN.md round 5) and NOT bit-identical: of two calls that start at the same moment, ~0.04 %
-        of the second's points come out different, traced (tools/exp_streams3.py) to the first kernel of the call, the element-wise
-        `view_angles_kernel`, taking the other tangent-frame candidate on a few lanes although its inputs are bit-identical -- not
-        explained; the serial loop (n_streams = 1, the default) is the only one callers get.
+        """The chunk loop of a frame / a batch (materialRenderer.py:705-709 shades 512 rays per pass, strictly one after another), with
+        `n_streams` shade() calls in flight on as many HIP streams (every stream has its own workspaces: ops.PackCache, side streams,
+        hit tallies).  Results are bit-identical to the serial loop (tests/test_gpu_determinism.py) -- after round 5 found and removed
+        the one thing that was not: hipcc's packed-fp32 form of `view_angles_kernel` (csrc/view_angles.hip) misbehaved on a few lanes
+        whenever another kernel's waves were resident beside it.  Measured gain: none (183.1 against 182.2 ms per 2^20 points: the stage
+        kernels cannot hide under one another), so n_streams = 1 stays the default.
         -> list of dicts holding the `keep` entries per chunk."""
         cur = torch.cuda.current_stream()
         while len(self._call_streams) < n_streams:

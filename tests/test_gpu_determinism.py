@@ -113,3 +113,20 @@ def test_launch_budget_does_not_change_a_bit(dev):
             ops.set_launch_budget(inner_teams=3)
     finally:
         ops.set_launch_budget()
+
+
+def test_two_calls_in_flight_equal_the_serial_loop(dev):
+    """MCShader.shade_many with two shade() calls in flight on two HIP streams (own workspaces per stream) returns the colours of the
+    serial chunk loop bit for bit.  Round 5 found the one kernel for which that did not hold -- hipcc's packed-fp32 form of
+    view_angles_kernel took the other tangent-frame candidate on a few lanes whenever another kernel's waves were resident beside
+    it (csrc/view_angles.hip is built without SLP vectorisation since) -- so this test runs calls that START TOGETHER, several times."""
+    import bench
+    from tensoflow_amd.synth import sphere_surface_points
+    sh, sd, verts, faces, aabb, unit = bench.build_scene(dev, 4, (64, 128, 96, 48))
+    pn, chunk = 98304, 24576
+    pts, nrm, view = [torch.from_numpy(a).to(dev) for a in sphere_surface_points(pn, seed=12)]
+    ref = torch.cat([o["colors"] for o in sh.shade_many(pts, view, nrm, 128, 128, chunk, n_streams=1)])
+    for _ in range(4):
+        got = torch.cat([o["colors"] for o in sh.shade_many(pts, view, nrm, 128, 128, chunk, n_streams=2)])
+        assert torch.equal(got, ref)
+    assert torch.isfinite(ref).all() and float(ref.std()) > 0.01
