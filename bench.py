@@ -483,7 +483,7 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     n_par = sum(p.numel() for p in m.parameters() if p.requires_grad)
-    return dict(workload=f"MCShadingNetwork train step: {pn} points x ({S} + 512 + {S}) rays, NIS losses on, fwd + bwd (no optimizer)",
+    return dict(workload=f"MCShadingNetwork train step: {pn} points x ({S} + 512 + {S}) rays, NIS losses on, fwd + bwd (no optimizer; the auxiliary maps of the output dict are built on access, none is read)",
                 ms_per_step=dt * 1e3, points_per_s=pn / dt, trainable_parameters=n_par)
 
 

@@ -227,13 +227,16 @@ int tf_pwquad_eval(const float* wv, const float* y, int64_t m, int32_t inverse, 
  * d W1[:, 0:7] (the sample-embedding columns) is written by the kernel into gnets[k].w[0] ([64,44], cols 0..6).
  * g_x [m,2] or NULL: gradient wrt the sample coordinates x themselves (asked for between nis_loss_iter and nis_start_iter, where the
  * NIS loss is fitted on the fixed GGX half angles and those depend on the predicted roughness: fields.py:1296-1318 with
- * sample_specular_directions :858-903) -- closed form through both splines and the kept coordinate's embedding. */
+ * sample_specular_directions :858-903) -- closed form through both splines and the kept coordinate's embedding.
+ * z [m,2] or NULL: the z output of tf_flow_logq_fwd on the same inputs (round 5).  The reverse pass needs block 1's output z[:,0]
+ * before it can re-evaluate block 0; handed the forward's own value it skips one of its three net evaluations per row, NULL
+ * recomputes it (exact fp32, as TF_PREC_F32 of the forward does). */
 typedef struct TfCouplingNetGrad {
   float* w[4];
   float* b[4];
 } TfCouplingNetGrad;
 size_t tf_flow_bwd_workspace_floats(int64_t pn);
-int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const int64_t* rays_id,
+int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const float* z, const int64_t* rays_id,
                      int64_t m, int32_t sn, int64_t pn, const float* g_logq, const TfCouplingNetGrad gnets[2],
                      float* g_point, float* g_x, float* workspace, size_t workspace_floats, tf_stream_t stream);
 
@@ -602,6 +605,11 @@ int tf_ide5_fwd(const float* xyz, const float* kappa_inv, const float* coef, int
 int tf_ide5_bwd(const float* xyz, const float* kappa_inv, const float* coef, const float* g_out, int64_t n, float* g_xyz,
                 float* g_kappa, tf_stream_t stream);
 int tf_posenc_fwd(const float* x, int64_t n, int32_t d, int32_t n_freq, float* out, tf_stream_t stream);
+/* linear_to_srgb (utils/raw_utils.py:4-17) on n floats, clamp01 != 0: followed by clamp(., 0, 1) as fields.py:1230-1256 wraps it;
+ * _bwd: g_lin = g_out * d srgb / d lin of the branch taken (zero where the clamp is active).  Round 5: the training steps spent
+ * nine element-wise launches per call on it, ~80 per material step. */
+int tf_linear_to_srgb_fwd(const float* lin, int64_t n, int32_t clamp01, float* out, tf_stream_t stream);
+int tf_linear_to_srgb_bwd(const float* lin, const float* g_out, int64_t n, int32_t clamp01, float* g_lin, tf_stream_t stream);
 
 /* TVLoss.forward (network/other_field.py:170-191) on one [C,H,W] grid (B = 1: TensoSDF.TV_loss_sdf, fields.py:133-138).
  * tf_tv_fwd: partial [tf_tv_partials()] = per-block (sum of squared differences along H, along W), interleaved; the loss is

@@ -130,28 +130,53 @@ class VmGatherFn(torch.autograd.Function):
         return (None, None, None, None, *gplanes, *glines)
 
 
+class SrgbFn(torch.autograd.Function):
+    """linear_to_srgb (utils/raw_utils.py:4-17), optionally followed by clamp(., 0, 1): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, lin, clamp01):
+        ctx.save_for_backward(lin)
+        ctx.clamp01 = bool(clamp01)
+        return ops.linear_to_srgb(lin, clamp01)
+
+    @staticmethod
+    def backward(ctx, g):
+        (lin,) = ctx.saved_tensors
+        return ops.linear_to_srgb(lin, ctx.clamp01, g_out=g.contiguous()), None
+
+
+def linear_to_srgb(lin, clamp01=False):
+    """The device form on a HIP tensor (one launch, analytic backward); the torch composition elsewhere (CPU tests of the host logic)."""
+    if lin.is_cuda:
+        return SrgbFn.apply(lin, clamp01)
+    from .encodings import linear_to_srgb as composed
+    y = composed(lin)
+    return y.clamp(0, 1) if clamp01 else y
+
+
 class FlowLogqFn(torch.autograd.Function):
     """(z, logq) = TensoFlow.forward given cond; backward = tf_flow_logq_bwd (fused HIP reverse pass)."""
 
     @staticmethod
     def forward(ctx, cond, x, rays_id, *wb):
         weights = [[(wb[8 * k + 2 * l], wb[8 * k + 2 * l + 1]) for l in range(4)] for k in range(2)]
-        z, logq = ops.flow_logq(weights, cond.detach(), x, rays_id=rays_id, precision=ops.PREC_F32)
-        ctx.save_for_backward(cond, x, *wb)
+        # split f16 operands like the eval path (fp32-grade; the exact-fp32 kernel took 2.5x as long for the same parity: round 5)
+        z, logq = ops.flow_logq(weights, cond.detach(), x, rays_id=rays_id, precision=ops.PREC_F16X3)
+        ctx.save_for_backward(cond, x, z, *wb)
         ctx.rays_id = rays_id
         ctx.mark_non_differentiable(z)
         return z, logq
 
     @staticmethod
     def backward(ctx, g_z, g_logq):
-        cond, x, *wb = ctx.saved_tensors
+        cond, x, z, *wb = ctx.saved_tensors
         weights = [[(wb[8 * k + 2 * l], wb[8 * k + 2 * l + 1]) for l in range(4)] for k in range(2)]
         # d logq / d x is only asked for between nis_loss_iter and nis_start_iter, where the NIS loss is fitted on the fixed GGX half
         # angles and those depend on the predicted roughness (fields.py:1296-1318 with sample_specular_directions): closed form in the
         # same kernel (round 3; central differences of the forward -- round 2 -- were exact in the median and off by more than the
         # gradient itself on the 0.03 % of samples whose stencil straddled a knot of a narrow spline bin: tools/exp_flow_dx.py of the round-4 tree, git a8fd04d)
         want_gx = ctx.needs_input_grad[1]
-        res = ops.flow_logq_bwd(weights, cond.detach(), x, g_logq.contiguous(), rays_id=ctx.rays_id, want_gx=want_gx)
+        res = ops.flow_logq_bwd(weights, cond.detach(), x, g_logq.contiguous(), rays_id=ctx.rays_id, want_gx=want_gx, z=z)
         grads, g_cond = res[0], res[1]
         g_x = res[2] if want_gx else None
         flat = []

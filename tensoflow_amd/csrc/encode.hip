@@ -106,6 +106,42 @@ extern "C" int tf_ide5_bwd(const float* xyz, const float* kappa_inv, const float
   return TF_OK;
 }
 
+// linear_to_srgb (utils/raw_utils.py:4-17), optionally clamped to [0, 1] (the `clamp(.., 0, 1)` fields.py wraps around most of its uses),
+// and its derivative: one launch each instead of nine element-wise launches forward and about as many backward per call.
+__device__ __forceinline__ float srgb_of(float x) {
+  const float eps = 1.1920928955078125e-07f;
+  return x <= 0.0031308f ? 12.92f * x : (211.f * powf(fmaxf(x, eps), 5.f / 12.f) - 11.f) / 200.f;
+}
+__global__ void __launch_bounds__(256) srgb_kernel(const float* __restrict__ lin, const float* __restrict__ g_out, long long n, int clamp01,
+                                                   float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = lin[i];
+  const float y = srgb_of(x);
+  if (!g_out) { out[i] = clamp01 ? fminf(fmaxf(y, 0.f), 1.f) : y; return; }
+  const float eps = 1.1920928955078125e-07f;
+  // the branch taken, as autograd differentiates torch.where / clamp(min=eps) / pow
+  float d = x <= 0.0031308f ? 12.92f : (x >= eps ? (211.f / 200.f) * (5.f / 12.f) * powf(x, -7.f / 12.f) : 0.f);
+  if (clamp01 && !(y >= 0.f && y <= 1.f)) d = 0.f;
+  out[i] = g_out[i] * d;
+}
+extern "C" int tf_linear_to_srgb_fwd(const float* lin, int64_t n, int32_t clamp01, float* out, tf_stream_t stream) {
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_linear_to_srgb_fwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(lin && out, TF_EINVAL, "tf_linear_to_srgb_fwd: null pointer");
+  srgb_kernel<<<tf_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(lin, nullptr, n, clamp01, out);
+  TF_LAUNCH_CHECK("tf_linear_to_srgb_fwd");
+  return TF_OK;
+}
+extern "C" int tf_linear_to_srgb_bwd(const float* lin, const float* g_out, int64_t n, int32_t clamp01, float* g_lin, tf_stream_t stream) {
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_linear_to_srgb_bwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(lin && g_out && g_lin, TF_EINVAL, "tf_linear_to_srgb_bwd: null pointer");
+  srgb_kernel<<<tf_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(lin, g_out, n, clamp01, g_lin);
+  TF_LAUNCH_CHECK("tf_linear_to_srgb_bwd");
+  return TF_OK;
+}
+
 extern "C" int tf_posenc_fwd(const float* x, int64_t n, int32_t d, int32_t n_freq, float* out, tf_stream_t stream) {
   TF_REQUIRE(n >= 0 && d >= 1 && n_freq >= 0 && n_freq <= 16, TF_ESHAPE, "tf_posenc_fwd: bad sizes");
   if (n == 0) return TF_OK;

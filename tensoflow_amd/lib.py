@@ -82,7 +82,7 @@ SIGNATURES = {
     "tf_linear_bwd_fused": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_pwquad_eval": (C.c_int, [c_f, c_f, i64, i32, c_f, c_f, c_f, c_f]),
     "tf_flow_bwd_workspace_floats": (sz, [i64]),
-    "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, c_f, sz, c_f]),
+    "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, c_f, sz, c_f]),
     "tf_bvh_record_dwords": (C.c_int32, []),
     "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
@@ -126,6 +126,8 @@ SIGNATURES = {
     "tf_ide5_fwd": (C.c_int, [c_f, c_f, c_f, i64, c_f, c_f]),
     "tf_ide5_bwd": (C.c_int, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f]),
     "tf_posenc_fwd": (C.c_int, [c_f, i64, i32, i32, c_f, c_f]),
+    "tf_linear_to_srgb_fwd": (C.c_int, [c_f, i64, i32, c_f, c_f]),
+    "tf_linear_to_srgb_bwd": (C.c_int, [c_f, c_f, i64, i32, c_f, c_f]),
     "tf_shade_reduce": (C.c_int, [c_f, c_f, i64, i32, i32, c_f, c_f, c_f, c_f]),
     "tf_shade_reduce_aux": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, c_f, i64, i32, i32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_reduce_env": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, i32, f32, i64, i32, i32, c_f, c_f, c_f, c_f, c_f]),

@@ -349,9 +349,9 @@ class MCShadingNetwork(nn.Module):
         return (_mlp(self.metallic_predictor, feat), _mlp(self.roughness_predictor, feat) * (1.0 - 0.04 ** 2) + 0.04 ** 2,
                 _mlp(self.albedo_predictor, feat))
 
-    def _linear_to_srgb(self, lin):
-        eps = torch.finfo(torch.float32).eps
-        return torch.where(lin <= 0.0031308, 323 / 25 * lin, (211 * lin.clamp(min=eps) ** (5 / 12) - 11) / 200)
+    def _linear_to_srgb(self, lin, clamp01=False):
+        from ..autograd import linear_to_srgb       # one launch each way on the device (was nine element-wise launches per call)
+        return linear_to_srgb(lin, clamp01)
 
     def _lights_of(self, origins, dirs, poses=None):
         """get_lights (fields.py:951-975) as a differentiable composition: visibility by tf_bvh_trace (no gradient, like the reference's
@@ -435,13 +435,20 @@ class MCShadingNetwork(nn.Module):
         from ..shading import LazyOutputs, aux_from_stats
         outputs = LazyOutputs({"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (F.normalize(normals, dim=-1) + 1) / 2,
                                "specular_mask": smask})
-        with torch.no_grad():
+        def aux_maps():
             # the rest of the reference's dict (fields.py:1232-1256, :1288-1291; `variance` is what trainer_inv.py:299 prints): one
-            # launch on the detached arrays.  (The reference's maps carry gradients nobody uses; only diffuse_light feeds a loss.)
-            hit_u8 = hit.reshape(-1).view(torch.uint8) if hit.dtype == torch.bool else hit.reshape(-1).to(torch.uint8)
-            _, _, _, stats = ops.shade_reduce_aux(wgt.detach(), smask, nd, ss, lights=lights.detach(), hit_u8=hit_u8, want_colors=False)
-            outputs.update(aux_from_stats(stats, nd, ss, metallic.detach(), specular_lin.detach(), diffuse_lin.detach(), self.cfg["diffuse_sample_num"]))
-        outputs["diffuse_light"] = torch.clamp(self._linear_to_srgb(lights[:, :nd].mean(1)), 0, 1)        # differentiable (diffuse-light regulariser)
+            # statistics launch on the detached arrays.  (The reference's maps carry gradients nobody uses; only diffuse_light feeds a
+            # loss.)  Built on first access of any of the keys (round 5): no loss term of the material stage reads them
+            # (network/loss.py; trainer.MaterialTrainer), and building them was ~70 of a training step's 223 forward launches.
+            with torch.no_grad():
+                hit_u8 = hit.reshape(-1).view(torch.uint8) if hit.dtype == torch.bool else hit.reshape(-1).to(torch.uint8)
+                _, _, _, stats = ops.shade_reduce_aux(wgt.detach(), smask, nd, ss, lights=lights.detach(), hit_u8=hit_u8, want_colors=False)
+                d = aux_from_stats(stats, nd, ss, metallic.detach(), specular_lin.detach(), diffuse_lin.detach(), self.cfg["diffuse_sample_num"])
+            d.pop("diffuse_light")                       # the differentiable one below is the dict's
+            return d
+        outputs.set_lazy_group(("specular_light", "diffuse_color", "specular_color", "approximate_light", "visibility", "indirect_light",
+                                "variance", "variance_diffuse_vis", "variance_specular_vis"), aux_maps)
+        outputs["diffuse_light"] = self._linear_to_srgb(lights[:, :nd].mean(1), clamp01=True)        # differentiable (diffuse-light regulariser)
         spec_sel = lambda: smask.bool()
         outputs.set_lazy("human_lights", lambda: (lambda sel: (hl_all.view(pn, T, 3)[:, nd:][sel] if hl_all is not None else
                                                                torch.zeros(int(sel.sum()), 3, device=dev)))(spec_sel() & ~hit.view(pn, T)[:, nd:].bool()))
@@ -558,9 +565,9 @@ class MCShadingNetwork(nn.Module):
         colors = self._linear_to_srgb(diffuse + specular)
         from ..shading import LazyOutputs
         outputs = LazyOutputs({"albedo": albedo, "roughness": roughness, "metallic": metallic, "normal": (normals + 1) / 2, "specular_mask": smask,
-                               "diffuse_light": torch.clamp(self._linear_to_srgb(d_lights.mean(1)), 0, 1)})
+                               "diffuse_light": self._linear_to_srgb(d_lights.mean(1), clamp01=True)})
         with torch.no_grad():                                   # the rest of the dict (fields.py:1232-1256, :1288-1291), as written there
-            c01 = lambda t: torch.clamp(self._linear_to_srgb(t), 0, 1)
+            c01 = lambda t: self._linear_to_srgb(t, clamp01=True)
             seg = lambda v: torch.zeros(pn, v.shape[-1], device=dev).index_add(0, rid, v)
             sh_f = s_hit.float()[:, None]
             outputs["specular_light"] = c01(seg(s_lights) / ns)

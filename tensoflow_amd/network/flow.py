@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..autograd import FlowLogqFn, VmGatherFn
-from ..shading import posenc, sphere_latent
+from ..shading import posenc, sphere_latent, sphere_latent_on
 
 
 class Reshift(nn.Module):
@@ -114,14 +114,14 @@ class TensoFlow(nn.Module):
     def _sample_nograd(self, pts, view_angles, n_samples, jitter=None):
         """sample() for a frozen copy (fields.py:1054-1065): angles [pn,sn,2], logq [pn,sn,1]."""
         cond = self._condition(pts, view_angles)
-        return ops.flow_sample(self._nets(), cond, sphere_latent(n_samples).to(pts.device), jitter, precision=ops.PREC_F32)
+        return ops.flow_sample(self._nets(), cond, sphere_latent_on(n_samples, pts.device), jitter, precision=ops.PREC_F16X3)
 
     # ---- reference API
     def sample(self, pts, reflections, roughness, n_samples, return_jacobian=False):
         """flow.py:833-855 -> angles [pn,sn,2] (, logj [pn,sn,1])."""
         _check_no_grad(self, "TensoFlow.sample")
         jitter = torch.rand(pts.shape[0], n_samples, device=pts.device) if self.training else None   # flow.py:86-87
-        ang, logj = ops.flow_sample(self._nets(), self._condition(pts, reflections), sphere_latent(n_samples).to(pts.device), jitter)
+        ang, logj = ops.flow_sample(self._nets(), self._condition(pts, reflections), sphere_latent_on(n_samples, pts.device), jitter)
         return (ang, logj) if return_jacobian else ang
 
     def forward(self, pts, reflections, roughness, x, return_jacobian=False, rays_id=None):

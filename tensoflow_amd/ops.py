@@ -362,6 +362,18 @@ def posenc_fwd(x, n_freq):
     return out
 
 
+def linear_to_srgb(lin, clamp01=False, g_out=None):
+    """tf_linear_to_srgb_fwd (g_out None) / _bwd: element-wise on any shape."""
+    lin = _f(lin)
+    out = torch.empty_like(lin)
+    if g_out is None:
+        L.check(L.load().tf_linear_to_srgb_fwd(_p(lin), lin.numel(), int(bool(clamp01)), _p(out), _stream()), "tf_linear_to_srgb_fwd")
+    else:
+        L.check(L.load().tf_linear_to_srgb_bwd(_p(lin), _p(_f(g_out)), lin.numel(), int(bool(clamp01)), _p(out), _stream()),
+                "tf_linear_to_srgb_bwd")
+    return out
+
+
 # ------------------------------------------------------------------------------ compositing
 def composite(alpha, ray_indices, values, n_rays):
     lib = L.load()
@@ -532,8 +544,9 @@ def flow_logq(weights, cond, x, rays_id=None, want_bins=False, precision=1):
     return (z, lq, bins) if want_bins else (z, lq)
 
 
-def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False):
+def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False, z=None):
     """Backward of flow_logq wrt the 16 net tensors and cond (want_gx: and wrt the sample coordinates x, closed form in the kernel).
+    z: the forward's z on the same inputs (the kernel then skips its first re-evaluation of block 1's net).
     -> (grads: 2 lists of 4 (gW, gb) pairs in torch layout, g_cond [pn,37]) (, g_x like x)."""
     lib = L.load()
     cond, x, g_logq = _f(cond), _f(x), _f(g_logq.reshape(-1))
@@ -563,7 +576,10 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False):
     ws = _workspace("flow_bwd", lib.tf_flow_bwd_workspace_floats(pn), dev)
     rid = None if rays_id is None else rays_id.contiguous()
     g_x = torch.zeros_like(x) if want_gx else None
-    L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
+    if z is not None:
+        z = _f(z)
+        assert z.shape == x.shape
+    L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(z), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
                                  _p(g_point), _p(g_x), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
     # fold the hoisted per-point part: the three products of one dense layer c [pn,37] -> [pn,64] (tf_linear_bwd)
     c = cond * 2.0 - 1.0

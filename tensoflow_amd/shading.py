@@ -52,6 +52,19 @@ def sphere_latent(sn):
     return torch.stack([phi, th], -1)
 
 
+_LATENT_ON_DEVICE = {}
+
+
+def sphere_latent_on(sn, device):
+    """sphere_latent(sn) resident on `device`, built once: a host tensor copied per call is a pageable host-to-device copy, i.e. a
+    full stream synchronisation at the top of every training step (round 5: it kept a step's forward from being queued under the
+    previous step's backward)."""
+    key = (int(sn), str(device))
+    if key not in _LATENT_ON_DEVICE:
+        _LATENT_ON_DEVICE[key] = sphere_latent(sn).to(device)
+    return _LATENT_ON_DEVICE[key]
+
+
 class StageTimer:
     """HIP-event stage timing on the stream the kernels are launched on (torch's current stream)."""
 
@@ -176,6 +189,22 @@ class LazyOutputs(dict):
     def set_lazy(self, key, fn):
         self._lazy[key] = fn
 
+    def set_lazy_group(self, keys, fn):
+        """`fn()` -> a dict holding every key of `keys`, evaluated once on the first access of any of them."""
+        keys = tuple(keys)
+
+        def take(key):
+            def build():
+                d = fn()
+                for k in keys:
+                    self._lazy.pop(k, None)
+                    if k != key:
+                        dict.__setitem__(self, k, d[k])
+                return d[key]
+            return build
+        for k in keys:
+            self._lazy[k] = take(k)
+
     def __missing__(self, key):
         if key in self._lazy:
             v = self._lazy.pop(key)()
@@ -215,20 +244,20 @@ class LazyOutputs(dict):
 def aux_from_stats(aux, nd, ns, metallic, specular_lin, diffuse_lin, diffuse_sample_num):
     """The auxiliary outputs of shade_mixed (fields.py:1228-1256, :1288-1291) from tf_shade_reduce_aux's per-point statistics
     `aux` [pn,16]: light / colour maps, approximate_light, visibility, indirect light and the three variance figures."""
-    from .encodings import linear_to_srgb
-    c01 = lambda t: t.clamp(0, 1)
+    from .autograd import linear_to_srgb
+    c01s = lambda t: linear_to_srgb(t, clamp01=True)
     dmean = aux[:, 0:3] / nd
-    spec_color = c01(linear_to_srgb(specular_lin))
+    spec_color = c01s(specular_lin)
     n, mean, m2 = aux[:, 10:11], aux[:, 11:12], aux[:, 12:13]
     sg, sg2 = n * mean, m2 + n * mean * mean                       # sum g, sum g^2 over the unmasked specular rays
     n64, mean64, m264 = n.double(), mean.double(), m2.double()
     N = n64.sum()
     mu = (n64 * mean64).sum() / N.clamp_min(1.0)
     var_all = ((m264.sum() + (n64 * (mean64 - mu) ** 2).sum()) / (N - 1.0)).float()     # torch.var(unbiased) over all M unmasked rays (:1289)
-    return {"diffuse_light": c01(linear_to_srgb(dmean)), "specular_light": c01(linear_to_srgb(aux[:, 3:6] / ns)),
-            "diffuse_color": c01(linear_to_srgb(diffuse_lin)), "specular_color": spec_color,
+    return {"diffuse_light": c01s(dmean), "specular_light": c01s(aux[:, 3:6] / ns),
+            "diffuse_color": c01s(diffuse_lin), "specular_color": spec_color,
             # (:1248 adds the ALREADY sRGB-encoded, clamped specular colour to the linear diffuse term: reproduced as written)
-            "approximate_light": c01(linear_to_srgb((1 - metallic) * dmean + spec_color)),
+            "approximate_light": c01s((1 - metallic) * dmean + spec_color),
             "visibility": 1 - aux[:, 9:10] / ns, "indirect_light": aux[:, 6:9] / ns,
             "variance": var_all,
             "variance_diffuse_vis": aux[:, 14:15] / max(nd - 1, 1) / diffuse_sample_num,

@@ -37,7 +37,7 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step(True)
         torch.cuda.synchronize()
     ev = prof.events()
@@ -68,6 +68,47 @@ def main():
                 if best is None or (s.time_range.end - s.time_range.start) < (best.time_range.end - best.time_range.start):
                     best = s
         node_n[best.name if best is not None else "(no autograd node)"] += n
+    sync = collections.Counter()
+    for e in cpu:
+        if any(k in e.name for k in ("Synchronize", "aten::item", "aten::nonzero", "_local_scalar_dense", "aten::masked_select", "aten::index", "hipMemcpy", "Memcpy")):
+            sync[e.name] += 1
+    print("\nhost syncs / dynamic-shape ops in the step:", dict(sync))
+    for e in cpu:
+        if e.name in ("hipMemcpyWithStream", "hipStreamSynchronize", "hipDeviceSynchronize", "hipMemcpyAsync"):
+            chain = [o.name for o in cpu if o is not e and o.time_range.start <= e.time_range.start and e.time_range.end <= o.time_range.end]
+            print(f"  {e.name} ({(e.time_range.end - e.time_range.start):.0f} us) inside: {' > '.join(chain[-4:])}")
+    for s_ in secs:
+        print(f"  {s_.name}: {(s_.time_range.end - s_.time_range.start) / 1e3:.3f} ms of host time")
+    # the forward's device launches in issue order, by the outermost op under the section (consecutive repeats folded)
+    fwd = [x for x in secs if x.name == "SEC forward"][0]
+    tops, cur_end = [], -1
+    for e in cpu:
+        if e is fwd or not (fwd.time_range.start <= e.time_range.start and e.time_range.end <= fwd.time_range.end):
+            continue
+        if e.time_range.start >= cur_end:                 # not nested in the previous top-level op
+            tops.append([e.name, 0])
+            cur_end = e.time_range.end
+        if e.kernels:
+            tops[-1][1] += len(e.kernels)
+    seq = []
+    for name, n in tops:
+        if n == 0:
+            continue
+        if seq and seq[-1][0] == name:
+            seq[-1][1] += n; seq[-1][2] += 1
+        else:
+            seq.append([name, n, 1])
+    print("\nforward launches in issue order (op x repeats: launches):")
+    print("  " + " | ".join(f"{nm.replace('aten::', '')}x{r}:{n}" for nm, n, r in seq))
+    by_line = collections.Counter()
+    for e in cpu:
+        if not e.kernels or not e.stack:
+            continue
+        fr = [f for f in e.stack if "/tensoflow_amd/" in f and "autograd.py" not in f and "/ops.py" not in f and "/lib.py" not in f]
+        by_line[(fr[0] if fr else e.stack[0]).split("/tensoflow_amd/")[-1][:90]] += len(e.kernels)
+    print("\nlaunches by innermost tensoflow_amd source line (forward ops; top 60):")
+    for k, v in by_line.most_common(60):
+        print(f"  {v:4d}  {k}")
     print("\nlaunches per section:", dict(sec_n))
     print("\nlaunches per innermost autograd node / Function (top 30):")
     for k, v in node_n.most_common(30):
