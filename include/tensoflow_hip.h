@@ -255,6 +255,16 @@ int tf_cube_lookup_bwd(const float* base, int32_t res, const float* dirs, int64_
  * g_base [6,R,R,3] (+=, zero first) or NULL; g_dirs [m,3] (overwritten) or NULL; at least one of them. */
 int tf_cube_lookup_bwd_dirs(const float* base, int32_t res, const float* dirs, int64_t m, int32_t apply_exp,
                             const float* g_out, float* g_base, float* g_dirs, tf_stream_t stream);
+/* EnvLight.__call__ with a roughness (network/light.py:95-122: dr.texture(..., mip=..., mip_level_bias=..., 'linear-mipmap-linear',
+ * boundary_mode='cube')): out [m,3] = (exp of) the bilinear cube fetch of levels floor(mip) and floor(mip) + 1 of the stack
+ * texs[0..n_levels-1] ([6,res[l],res[l],3] each, n_levels <= 8), blended by the fraction of mip [m] (0 <= mip <= n_levels - 1).
+ * _bwd: g_texs[l] += d out / d level l (float atomics; NULL: none), g_dirs [m,3] and g_mip [m] (either may be NULL).  Round 5: one
+ * launch each way for what the shape stage composed from ~130 element-wise launches per training step. */
+int tf_cube_lookup_mips_fwd(const float* const* texs, const int32_t* res, int32_t n_levels, const float* dirs, const float* mip,
+                            int64_t m, int32_t apply_exp, float* out, tf_stream_t stream);
+int tf_cube_lookup_mips_bwd(const float* const* texs, const int32_t* res, int32_t n_levels, const float* dirs, const float* mip,
+                            int64_t m, int32_t apply_exp, const float* g_out, float* const* g_texs, float* g_dirs, float* g_mip,
+                            tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sample generation for the march.

@@ -381,7 +381,9 @@ class SdfAlphaFn(torch.autograd.Function):
         W1, b1, W2, b2 = params[6:10]
         packed = ops.VmPacked(planes, lines, n_levels)
         ctx.composed = ops.sdf_embed_freqs(packed, W1) > 0          # sdf_multires > 0: forward and backward on the composition
-        inv_host = float(inv_s)
+        inv_host = getattr(inv_s, "_tf_host", None)                 # the caller's cached read-back (ShapeRenderer._inv_s_host)
+        if inv_host is None:
+            inv_host = float(inv_s)
         alpha, grad, feat, sdf, nh, taps = ops.sdf_alpha(packed, W1.detach(), b1.detach(), W2.detach(), b2.detach(), pts, level, dists, dirs,
                                                          aabb, units, inv_host, cos_anneal, want_taps=True)
         ctx.save_for_backward(pts, level if level is not None else torch.empty(0, device=pts.device), dists, dirs, inv_s, sdf, taps, *params)

@@ -87,6 +87,8 @@ SIGNATURES = {
     "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),
     "tf_cube_lookup_bwd_dirs": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f, c_f]),
+    "tf_cube_lookup_mips_fwd": (C.c_int, [C.POINTER(c_f), C.POINTER(i32), i32, c_f, c_f, i64, i32, c_f, c_f]),
+    "tf_cube_lookup_mips_bwd": (C.c_int, [C.POINTER(c_f), C.POINTER(i32), i32, c_f, c_f, i64, i32, c_f, C.POINTER(c_f), c_f, c_f, c_f]),
     "tf_sample_ray_init": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, P(f32 * 6), c_f, c_f, i64, i32, f32, c_f, c_f, c_f, c_f]),
     "tf_sample_ray_upsample": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, i32, f32, c_f, f32, c_f, c_f, c_f, c_f]),
     "tf_sample_ray_merge": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),

@@ -34,6 +34,17 @@ class TVLoss(nn.Module):
         return self.TVLoss_weight * 2 * total / b
 
 
+_CONST3 = {}
+
+
+def _const3(a, b, c, device):
+    """A three-vector constant resident on `device` (built per call it is a host-to-device copy, i.e. a host synchronisation)."""
+    key = (a, b, c, str(device))
+    if key not in _CONST3:
+        _CONST3[key] = torch.tensor([a, b, c], device=device)
+    return _CONST3[key]
+
+
 def _gauss_kernel(kernel_size, sigma, dims):
     x = torch.arange(-kernel_size // 2 + 1.0, kernel_size // 2 + 1.0)
     if dims == 1:
@@ -771,7 +782,7 @@ class ShapeShadingNetwork(nn.Module):
     def _unit_inputs(normals, view_dirs):
         normals = F.normalize(normals, dim=-1)
         bad = (normals[:, :2].sum(-1) == 0.0)[:, None]
-        normals = torch.where(bad, torch.tensor([0.0, 1e-6, 1.0], device=normals.device), normals)
+        normals = torch.where(bad, _const3(0.0, 1e-6, 1.0, normals.device), normals)
         return normals, F.normalize(view_dirs, dim=-1)
 
     # ------------------------------------------------------------------ differentiable composition

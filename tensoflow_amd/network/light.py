@@ -135,6 +135,24 @@ def latlong_to_cubemap(latlong, res, device="cuda"):
     return out.reshape(6, res, res, C).contiguous()
 
 
+class _CubeLookupMips(torch.autograd.Function):
+    """exp of the trilinear fetch over the specular stack (EnvLight.__call__ with a roughness): one launch each way; gradient wrt every
+    level of the stack, the direction and the (clamped) mip coordinate."""
+
+    @staticmethod
+    def forward(ctx, dirs, mip, *texs):
+        ctx.save_for_backward(dirs, mip, *texs)
+        return ops.cube_lookup_mips(texs, dirs, mip, apply_exp=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        dirs, mip, *texs = ctx.saved_tensors
+        g_texs, g_dirs, g_mip = ops.cube_lookup_mips_bwd(texs, dirs, mip, g.contiguous(), apply_exp=True,
+                                                         want_texs=any(ctx.needs_input_grad[2:]), want_dirs=ctx.needs_input_grad[0],
+                                                         want_mip=ctx.needs_input_grad[1])
+        return (g_dirs, g_mip, *(g_texs if g_texs is not None else [None] * len(texs)))
+
+
 class EnvLight(torch.nn.Module):
     def __init__(self, path=None, device=None, scale=1.0, min_res=16, start_res=16, max_res=512, min_roughness=0.08,
                  max_roughness=0.5, trainable=False):
@@ -142,6 +160,7 @@ class EnvLight(torch.nn.Module):
         self.device = device if device is not None else "cuda"
         self.scale, self.min_res, self.max_res = scale, min_res, max_res
         self.min_roughness, self.max_roughness, self.trainable, self.start_res = min_roughness, max_roughness, trainable, start_res
+        self.composed_lookup = False          # True: the specular lookup as the per-level torch composition (tests)
         self.base = torch.nn.Parameter(torch.full((6, max_res, max_res, 3), np.log(0.5), dtype=torch.float32, device=self.device),
                                        requires_grad=trainable)
         if path is not None:
@@ -186,6 +205,9 @@ class EnvLight(torch.nn.Module):
             return torch.exp(_CubeLookupLinear.apply(self.diffuse, d)).view(*prefix, -1)
         n = len(self.specular)
         mip = self.get_mip(roughness.reshape(-1)).clamp(0, n - 1)
+        if d.is_cuda and not self.composed_lookup:
+            return _CubeLookupMips.apply(d, mip, *self.specular).view(*prefix, -1)
+        # the per-level composition of rounds 1-4 (every level fetched for every sample): the checker of the fused lookup, and the CPU form
         l0 = mip.floor().clamp(max=n - 1)
         f = (mip - l0)[:, None]
         l0 = l0.long()

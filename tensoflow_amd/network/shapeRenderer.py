@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import march, ops
 from ..autograd import CompositeFn, SdfAlphaFn
 from ..surface import _neus_weights
-from .fields import ShapeShadingNetwork, SingleVarianceNetwork, TensoSDF, TVLoss
+from .fields import ShapeShadingNetwork, SingleVarianceNetwork, TensoSDF, TVLoss, _const3
 
 
 class AlphaGridMask(nn.Module):
@@ -102,6 +102,7 @@ class ShapeRenderer(nn.Module):
         self.aabbSize = self.aabb[1] - self.aabb[0]
         self.invaabbSize = 2.0 / self.aabbSize
         self.gridSize = torch.tensor(torch.as_tensor(gridSize).cpu().tolist(), dtype=torch.int32).to(self.device)
+        self._grid_size_cpu = self.gridSize.float().cpu()        # read back once per resolution change, not once per step (a blocking copy)
         self.max_levels = max_levels
         self.units = self.aabbSize / (self.gridSize - 1)
         self.stepSize = torch.mean(self.units) * self.step_ratio
@@ -165,7 +166,7 @@ class ShapeRenderer(nn.Module):
         f.W = [w.detach() for w in net._w()]
         f.aabb = self._aabb_cpu
         f.aabb_dev = self.aabb
-        f.grid_size = self.gridSize.float().cpu()
+        f.grid_size = self._grid_size_cpu
         f.units = list(self._units_f)
         f.n_levels = self.max_levels
         f.device = self.device
@@ -174,6 +175,15 @@ class ShapeRenderer(nn.Module):
 
     def _inv_s(self):
         return self.deviation_network.inv_s().clip(1e-6, 1e6)
+
+    def _inv_s_host(self):
+        """float(inv_s) for the kernels' scalar argument, read back when the parameter has changed (its version counter) instead of on
+        every call: a read-back is a host synchronisation in the middle of the step's forward."""
+        v = self.deviation_network.variance
+        key = (v.data_ptr(), v._version)
+        if getattr(self, "_inv_s_key", None) != key:
+            self._inv_s_key, self._inv_s_val = key, float(self._inv_s().detach())
+        return self._inv_s_val
 
     def near_far_from_sphere(self, rays_o, dirs):
         return march.near_far_from_sphere(rays_o, dirs, self._radius_f)
@@ -210,7 +220,7 @@ class ShapeRenderer(nn.Module):
         perturb = 0).  perturb > 0: one uniform offset per ray of +-1/n_samples (:888-890, torch.rand on the device);
         clip_sample_variance: the up-sampling sharpness 64 * 2^i is capped by the learned inv_s (:905-907)."""
         t_rand = (torch.rand(rays_o.shape[0], 1, device=rays_o.device) - 0.5) if perturb > 0 else None
-        cap = float(self._inv_s()) if self.cfg["clip_sample_variance"] else None
+        cap = self._inv_s_host() if self.cfg["clip_sample_variance"] else None
         return march.sample_ray(self._field(), rays_o, dirs, near, far, radiis, rays_cos, self._base_radii_f,
                                 n_samples=self.cfg["n_samples"], n_importance=self.cfg["n_importance"],
                                 up_steps=self.cfg["up_sample_steps"], t_rand=t_rand, inv_s_cap=cap)
@@ -227,13 +237,14 @@ class ShapeRenderer(nn.Module):
             inv_s = inv_s.detach()
         lv = None if level is None else level.reshape(-1).contiguous()
         units = list(self._units_f)
+        inv_s._tf_host = self._inv_s_host()               # SdfAlphaFn takes the scalar from here
         if torch.is_grad_enabled() and any(p.requires_grad for p in list(net.parameters()) + [self.deviation_network.variance]):
             alpha, grad, feat, sdf, nh = SdfAlphaFn.apply(points.contiguous(), lv, dists.contiguous(), dirs.contiguous(), inv_s,
                                                           float(cos_anneal_ratio), self._aabb_cpu, units, self.max_levels,
                                                           *net.sdf_plane, *net.sdf_line, *net._w())
         else:
             alpha, grad, feat, sdf, nh = ops.sdf_alpha(net._field(), *[w.detach() for w in net._w()], points, lv, dists, dirs,
-                                                       self._aabb_cpu, units, float(inv_s), float(cos_anneal_ratio), want_hess=is_train)
+                                                       self._aabb_cpu, units, inv_s._tf_host, float(cos_anneal_ratio), want_hess=is_train)
         return alpha, grad, feat, inv_s.expand(N), sdf, (nh if is_train else None)
 
     def render(self, ray_batch, near, far, human_poses=None, perturb_overwrite=-1, cos_anneal_ratio=0.0, is_train=True, step=None):
@@ -284,7 +295,7 @@ class ShapeRenderer(nn.Module):
         rgb = out[:, :3]
         if self.cfg["isBGWhite"]:
             rgb = rgb + (1 - acc)
-        normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * torch.tensor([0.0, 0.0, 1.0], device=rays_o.device), dim=-1)
+        normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * _const3(0.0, 0.0, 1.0, rays_o.device), dim=-1)
         outputs = {"ray_rgb": rgb, "gradient_error": gradient_error, "acc": acc, "sample_num": N / max(rn, 1), "normal": normal,
                    "std": torch.mean(1 / inv_s) if N > 0 else zero}
         if radiance is not None:                                   # has_radiance_field and step > radiance_field_step (:1195-1206)

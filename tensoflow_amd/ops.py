@@ -693,6 +693,38 @@ def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
     return g_base
 
 
+def _cube_stack(texs):
+    texs = [_f(t) for t in texs]
+    n = len(texs)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in texs])
+    res = (C.c_int32 * n)(*[int(t.shape[1]) for t in texs])
+    return texs, n, ptrs, res
+
+
+def cube_lookup_mips(texs, dirs, mip, apply_exp=True):
+    """tf_cube_lookup_mips_fwd: texs = the specular stack ([6,R_l,R_l,3] each), dirs [m,3], mip [m] -> [m,3]."""
+    texs, n, ptrs, res = _cube_stack(texs)
+    dirs, mip = _f(dirs), _f(mip.reshape(-1))
+    m = dirs.shape[0]
+    out = torch.empty(m, 3, dtype=torch.float32, device=dirs.device)
+    L.check(L.load().tf_cube_lookup_mips_fwd(ptrs, res, n, _p(dirs), _p(mip), m, int(apply_exp), _p(out), _stream()), "tf_cube_lookup_mips_fwd")
+    return out
+
+
+def cube_lookup_mips_bwd(texs, dirs, mip, g_out, apply_exp=True, want_texs=True, want_dirs=True, want_mip=True):
+    """-> (list of g_tex or None, g_dirs or None, g_mip or None)."""
+    texs, n, ptrs, res = _cube_stack(texs)
+    dirs, mip, g_out = _f(dirs), _f(mip.reshape(-1)), _f(g_out)
+    m = dirs.shape[0]
+    g_texs = [torch.zeros_like(t) for t in texs] if want_texs else None
+    gptrs = (C.c_void_p * n)(*[t.data_ptr() for t in g_texs]) if want_texs else None
+    g_dirs = torch.zeros(m, 3, dtype=torch.float32, device=dirs.device) if want_dirs else None
+    g_mip = torch.zeros(m, dtype=torch.float32, device=dirs.device) if want_mip else None
+    L.check(L.load().tf_cube_lookup_mips_bwd(ptrs, res, n, _p(dirs), _p(mip), m, int(apply_exp), _p(g_out), gptrs, _p(g_dirs), _p(g_mip),
+                                             _stream()), "tf_cube_lookup_mips_bwd")
+    return g_texs, g_dirs, g_mip
+
+
 def cube_lookup_bwd_dirs(base, dirs, g_out, apply_exp=False, want_base=True):
     """-> (g_base [6,R,R,3] or None, g_dirs [m,3]): gradient of the bilinear cube fetch wrt the map and wrt the direction."""
     lib = L.load()

@@ -59,6 +59,50 @@ def test_cube_lookup_direction_gradient(dev):
     assert _ is None and torch.equal(g_only, g_dirs)
 
 
+def test_envlight_specular_lookup_fused_equals_composition(dev):
+    """EnvLight.__call__ with a roughness (light.py:95-122): the one-launch trilinear fetch over the specular stack
+    (tf_cube_lookup_mips_fwd / _bwd, round 5) against the per-level composition it replaces -- values, and the gradients wrt the
+    environment map (through build_mips), the directions and the roughness -- with roughness below / above the stack's range, on
+    its knots and on the last level; and the fused sRGB op against its composition."""
+    from tensoflow_amd.network.light import EnvLight
+    gen = torch.Generator().manual_seed(5)
+    env = EnvLight(device=dev, max_res=64, trainable=True)
+    with torch.no_grad():
+        env.base.copy_((torch.randn(6, 64, 64, 3, generator=gen) * 0.5).to(dev))
+    n = 6000
+    d0 = torch.randn(n, 3, generator=gen)
+    d0[:300, 0] = 1.0; d0[:300, 1:] = d0[:300, 1:].clamp(-1, 1) * 0.999          # seam-crossing taps
+    r0 = torch.rand(n, 1, generator=gen)
+    r0[:50] = 0.01; r0[50:100] = env.min_roughness; r0[100:150] = env.max_roughness; r0[150:200] = 1.0; r0[200:250] = 1.5
+    gout = torch.randn(n, 3, generator=gen).to(dev)
+    res = {}
+    for composed in (True, False):
+        env.composed_lookup = composed
+        env.zero_grad(set_to_none=True)
+        d = d0.to(dev).requires_grad_(True)
+        r = r0.to(dev).requires_grad_(True)
+        env.build_mips()
+        out = env(d, r)
+        (out * gout).sum().backward()
+        res[composed] = (out.detach().cpu(), env.base.grad.cpu().clone(), d.grad.cpu().clone(), r.grad.cpu().clone())
+    env.composed_lookup = False
+    for name, a, b in zip(("value", "d / d map", "d / d direction", "d / d roughness"), res[False], res[True]):
+        assert float(b.abs().max()) > 0, name
+        parity(a, b, tol=2e-5, label=f"fused specular lookup vs composition: {name}")
+    # sRGB: value and derivative on both branches, at the knee, beyond 1 and below 0
+    from tensoflow_amd.autograd import linear_to_srgb
+    from tensoflow_amd.encodings import linear_to_srgb as composed_srgb
+    x0 = torch.cat([torch.rand(4000, generator=gen) * 1.6 - 0.2, torch.tensor([0.0, 0.0031308, 0.0031309, 1.0, 1e-9, -1.0])])
+    for clamp01 in (False, True):
+        xa, xb = x0.to(dev).requires_grad_(True), x0.to(dev).requires_grad_(True)
+        ya = linear_to_srgb(xa, clamp01)
+        yb = composed_srgb(xb).clamp(0, 1) if clamp01 else composed_srgb(xb)
+        gy = torch.randn(x0.shape, generator=gen).to(dev)
+        (ya * gy).sum().backward(); (yb * gy).sum().backward()
+        parity(ya.detach().cpu(), yb.detach().cpu(), abs_tol=2e-7, absolute=True, label=f"fused sRGB (clamp01={clamp01})")
+        parity(xa.grad.cpu(), xb.grad.cpu(), tol=2e-5, label=f"fused sRGB derivative (clamp01={clamp01})")
+
+
 def test_shape_renderer_render_core_inference(golden, dev):
     g = golden("march_r32")
     r = _shape_renderer(g, dev)

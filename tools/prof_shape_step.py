@@ -78,6 +78,35 @@ def main():
     secs = [e for e in cpu if e.name.startswith("SEC ")]
     nodes = [e for e in cpu if "Backward" in e.name or e.name.endswith("Fn") or e.name.startswith("autograd::engine::evaluate_function")]
     sec_n, node_n = collections.Counter(), collections.Counter()
+    for s_ in secs:
+        if s_.name.startswith("SEC "):
+            print(f"  {s_.name}: {(s_.time_range.end - s_.time_range.start) / 1e3:.3f} ms of host time")
+    for e in cpu:
+        if e.name in ("hipMemcpyWithStream", "hipStreamSynchronize", "hipDeviceSynchronize"):
+            chain = [o.name for o in cpu if o is not e and o.time_range.start <= e.time_range.start and e.time_range.end <= o.time_range.end]
+            print(f"  {e.name} ({(e.time_range.end - e.time_range.start):.0f} us) inside: {' > '.join(chain[-4:])}")
+    # device launches in issue order by the outermost op under a top-level section (consecutive repeats folded)
+    for sec in [x for x in secs if x.name.startswith("SEC ") and not x.name.startswith("SEC2")]:
+        tops, cur_end = [], -1
+        for e in cpu:
+            if e is sec or e.name.startswith("SEC2") or not (sec.time_range.start <= e.time_range.start and e.time_range.end <= sec.time_range.end):
+                continue
+            if e.time_range.start >= cur_end:
+                tops.append([e.name, 0])
+                cur_end = e.time_range.end
+            if e.kernels:
+                tops[-1][1] += len(e.kernels)
+        seq = []
+        for name, n in tops:
+            if n == 0:
+                continue
+            name = name.replace("autograd::engine::evaluate_function: ", "")
+            if seq and seq[-1][0] == name:
+                seq[-1][1] += n; seq[-1][2] += 1
+            else:
+                seq.append([name, n, 1])
+        print(f"\n{sec.name}: launches in issue order (op x repeats: launches):")
+        print("  " + " | ".join(f"{nm.replace('aten::', '')}x{r}:{n}" for nm, n, r in seq))
     for e in cpu:
         if not e.kernels:
             continue
