@@ -475,7 +475,8 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
         colors, out = m(pts, view, nrm, None, 600, True)
         ((colors * w).sum() + out["loss_nis"]).backward()
 
-    step()
+    for _ in range(3):            # allocator, pack caches and the clock settle
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -518,7 +519,8 @@ def shape_train_probe(device, steps, n_rays=1024):
             + 5e-4 * out["loss_hessian"] + out["loss_tv_sdf"]
         loss.backward()
 
-    step()
+    for _ in range(3):
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -1058,7 +1060,7 @@ def main():
             except Exception as e:
                 line["flow_only"] = {"error": f"{type(e).__name__}: {e}"}
             try:
-                line["train"] = train_probe(device, verts, faces, aabb, unit, S, max(2, args.steps))
+                line["train"] = train_probe(device, verts, faces, aabb, unit, S, max(20, args.steps))
             except Exception as e:      # the probe is informative only: never lose the headline line over it
                 line["train"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train:
@@ -1183,7 +1185,7 @@ def main():
                 line["config4_frame512"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train:
             try:
-                line["shape_train"] = shape_train_probe(device, max(2, args.steps))
+                line["shape_train"] = shape_train_probe(device, max(20, args.steps))
             except Exception as e:
                 line["shape_train"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_march:

@@ -230,7 +230,9 @@ int tf_pwquad_eval(const float* wv, const float* y, int64_t m, int32_t inverse, 
  * sample_specular_directions :858-903) -- closed form through both splines and the kept coordinate's embedding.
  * z [m,2] or NULL: the z output of tf_flow_logq_fwd on the same inputs (round 5).  The reverse pass needs block 1's output z[:,0]
  * before it can re-evaluate block 0; handed the forward's own value it skips one of its three net evaluations per row, NULL
- * recomputes it (exact fp32, as TF_PREC_F32 of the forward does). */
+ * recomputes it (split f16 operands, as the forward's TF_PREC_F16X3).
+ * g_cond [pn,37] or NULL: given, the call folds g_point itself (round 5) -- g_cond = 2 sum_k g_point[k] W1_k[:, 7:44] (overwritten),
+ * gnets[k].w[0][:, 7:44] += g_point[k]^T (2 cond - 1), gnets[k].b[0] += sum_pt g_point[k] -- and the caller has nothing left to do. */
 typedef struct TfCouplingNetGrad {
   float* w[4];
   float* b[4];
@@ -238,7 +240,7 @@ typedef struct TfCouplingNetGrad {
 size_t tf_flow_bwd_workspace_floats(int64_t pn);
 int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const float* z, const int64_t* rays_id,
                      int64_t m, int32_t sn, int64_t pn, const float* g_logq, const TfCouplingNetGrad gnets[2],
-                     float* g_point, float* g_x, float* workspace, size_t workspace_floats, tf_stream_t stream);
+                     float* g_point, float* g_cond, float* g_x, float* workspace, size_t workspace_floats, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Environment light: EnvLight.direct_light (network/light.py:125-162) = exp(bilinear cube lookup

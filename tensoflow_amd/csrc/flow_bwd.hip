@@ -549,6 +549,44 @@ __global__ void __launch_bounds__(256) flow_grad_fold_kernel(FlowGrads G, int n_
   *dst += s;
 }
 
+// The hoisted layer-1 point part, folded back (tf_flow_logq_bwd with g_cond): c = 2 cond - 1 [pn,37], P_k = c W1_k[:, 7:44]^T + b1_k
+//   g_cond[pt][j]       = 2 sum_k sum_u gP[k][pt][u] W1_k[u][7 + j]
+//   gW1_k[u][7 + j]    += sum_pt gP[k][pt][u] c[pt][j],      gb1_k[u] += sum_pt gP[k][pt][u]
+// (round 5: the caller's three small dense-layer products per net were ~20 launches per call)
+__global__ void __launch_bounds__(256) flow_point_fold_cond_kernel(const float* __restrict__ gP, const float* __restrict__ w1a,
+                                                                   const float* __restrict__ w1b, long long pn, float* __restrict__ g_cond) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= pn * 37) return;
+  const long long pt = e / 37;
+  const int j = (int)(e - pt * 37);
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float* w = (k ? w1b : w1a) + 7 + j;
+    const float* g = gP + ((long long)k * pn + pt) * 64;
+#pragma unroll 8
+    for (int u = 0; u < 64; ++u) acc += g[u] * w[u * 44];
+  }
+  g_cond[e] = 2.f * acc;
+}
+__global__ void __launch_bounds__(256) flow_point_fold_w_kernel(const float* __restrict__ gP, const float* __restrict__ cond, long long pn,
+                                                                float* __restrict__ gw1a, float* __restrict__ gb1a,
+                                                                float* __restrict__ gw1b, float* __restrict__ gb1b) {
+  const int e = blockIdx.x * 256 + threadIdx.x;            // (k, u, j'), j' fastest; j' == 37: the bias column
+  if (e >= 2 * 64 * 38) return;
+  const int j = e % 38, u = (e / 38) % 64, k = e / (38 * 64);
+  const long long p0 = (long long)blockIdx.y * 256, p1 = p0 + 256 < pn ? p0 + 256 : pn;
+  const float* g = gP + (long long)k * pn * 64 + u;
+  float acc = 0.f;
+  if (j < 37) {
+    for (long long pt = p0; pt < p1; ++pt) acc += g[pt * 64] * (2.f * cond[pt * 37 + j] - 1.f);
+    atomicAdd((k ? gw1b : gw1a) + u * 44 + 7 + j, acc);
+  } else {
+    for (long long pt = p0; pt < p1; ++pt) acc += g[pt * 64];
+    atomicAdd((k ? gb1b : gb1a) + u, acc);
+  }
+}
+
 // shared with flow.hip
 __global__ void __launch_bounds__(256) flow_point_part_kernel2(const float* __restrict__ w1a, const float* __restrict__ b1a,
                                                                const float* __restrict__ w1b, const float* __restrict__ b1b,
@@ -568,8 +606,8 @@ __global__ void __launch_bounds__(256) flow_point_part_kernel2(const float* __re
 
 extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, const float* x, const float* z_saved,
                                 const int64_t* rays_id, int64_t m, int32_t sn, int64_t pn, const float* g_logq,
-                                const TfCouplingNetGrad gnets[2], float* g_point, float* g_x, float* workspace, size_t workspace_floats,
-                                tf_stream_t stream_) {
+                                const TfCouplingNetGrad gnets[2], float* g_point, float* g_cond, float* g_x, float* workspace,
+                                size_t workspace_floats, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const char* who = "tf_flow_logq_bwd";
   TF_REQUIRE(m >= 0 && pn >= 0 && sn > 0, TF_ESHAPE, "%s: negative size / sn <= 0", who);
@@ -624,6 +662,11 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   TF_REQUIRE(e2 == hipSuccess, TF_EHIP, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e2));
   flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G, g_x, z_saved);
   flow_grad_fold_kernel<<<tf_blocks(kGradFloats, 256), 256, 0, stream>>>(G, (int)blocks);
+  if (g_cond) {
+    flow_point_fold_cond_kernel<<<tf_blocks(pn * 37, 256), 256, 0, stream>>>(g_point, nets[0].w[0], nets[1].w[0], pn, g_cond);
+    flow_point_fold_w_kernel<<<dim3((2 * 64 * 38 + 255) / 256, (unsigned)((pn + 255) / 256)), 256, 0, stream>>>(
+        g_point, cond, pn, gnets[0].w[0], gnets[0].b[0], gnets[1].w[0], gnets[1].b[0]);
+  }
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }

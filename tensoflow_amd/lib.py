@@ -82,7 +82,7 @@ SIGNATURES = {
     "tf_linear_bwd_fused": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_pwquad_eval": (C.c_int, [c_f, c_f, i64, i32, c_f, c_f, c_f, c_f]),
     "tf_flow_bwd_workspace_floats": (sz, [i64]),
-    "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, c_f, sz, c_f]),
+    "tf_flow_logq_bwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, c_f, i64, i32, i64, c_f, P(TfCouplingNetGrad * 2), c_f, c_f, c_f, c_f, sz, c_f]),
     "tf_bvh_record_dwords": (C.c_int32, []),
     "tf_cube_lookup_fwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, f32, c_f, c_f]),
     "tf_cube_lookup_bwd": (C.c_int, [c_f, i32, c_f, i64, i32, c_f, c_f, c_f]),

@@ -561,7 +561,8 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False, z=None)
     # (was 17 fills per call); 16-byte aligned slices
     sizes = [(tuple(W.shape), tuple(b.shape)) for k in range(2) for (W, b) in weights[k]]
     al = lambda n: (n + 3) // 4 * 4
-    total = sum(al(int(np.prod(ws_))) + al(int(np.prod(bs_))) for ws_, bs_ in sizes) + 2 * pn * 64
+    n_x = al(x.numel()) if want_gx else 0
+    total = sum(al(int(np.prod(ws_))) + al(int(np.prod(bs_))) for ws_, bs_ in sizes) + 2 * pn * 64 + al(pn * 37) + n_x
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     grads, off = [[], []], 0
     for k in range(2):
@@ -572,25 +573,17 @@ def flow_logq_bwd(weights, cond, x, g_logq, rays_id=None, want_gx=False, z=None)
             gb_ = flat[off:off + nb].view(bs_); off += al(nb)
             grads[k].append((gw, gb_))
             gnets[k].w[l], gnets[k].b[l] = gw.data_ptr(), gb_.data_ptr()
-    g_point = flat[off:off + 2 * pn * 64].view(2, pn, 64)
+    g_point = flat[off:off + 2 * pn * 64].view(2, pn, 64); off += 2 * pn * 64
+    g_cond = flat[off:off + pn * 37].view(pn, 37); off += al(pn * 37)
+    g_x = flat[off:off + x.numel()].view(x.shape) if want_gx else None
     ws = _workspace("flow_bwd", lib.tf_flow_bwd_workspace_floats(pn), dev)
     rid = None if rays_id is None else rays_id.contiguous()
-    g_x = torch.zeros_like(x) if want_gx else None
     if z is not None:
         z = _f(z)
         assert z.shape == x.shape
+    # the hoisted per-point part is folded inside the call (g_cond given): d W1[:, 7:], d b1 and d cond are complete on return
     L.check(lib.tf_flow_logq_bwd(C.byref(nets), _p(cond), _p(x), _p(z), _p(rid, torch.int64), m, sn, pn, _p(g_logq), C.byref(gnets),
-                                 _p(g_point), _p(g_x), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
-    # fold the hoisted per-point part: the three products of one dense layer c [pn,37] -> [pn,64] (tf_linear_bwd)
-    c = cond * 2.0 - 1.0
-    g_cond = torch.zeros_like(cond)
-    for k in range(2):
-        gW1, gb1 = grads[k][0]
-        gp = g_point[k].contiguous()
-        gx, gw, gb = linear_bwd(c, _f(weights[k][0][0])[:, 7:].contiguous(), gp, gp, ACT_NONE)
-        gW1[:, 7:] += gw
-        gb1 += gb
-        g_cond += 2.0 * gx
+                                 _p(g_point), _p(g_cond), _p(g_x), _p(ws), ws.numel(), _stream()), "tf_flow_logq_bwd")
     return (grads, g_cond, g_x) if want_gx else (grads, g_cond)
 
 
