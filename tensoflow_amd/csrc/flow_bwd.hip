@@ -572,10 +572,10 @@ __global__ void __launch_bounds__(256) flow_point_fold_cond_kernel(const float* 
 __global__ void __launch_bounds__(256) flow_point_fold_w_kernel(const float* __restrict__ gP, const float* __restrict__ cond, long long pn,
                                                                 float* __restrict__ gw1a, float* __restrict__ gb1a,
                                                                 float* __restrict__ gw1b, float* __restrict__ gb1b) {
-  const int e = blockIdx.x * 256 + threadIdx.x;            // (k, u, j'), j' fastest; j' == 37: the bias column
+  const int e = blockIdx.y * 256 + threadIdx.x;            // (k, u, j'), j' fastest; j' == 37: the bias column
   if (e >= 2 * 64 * 38) return;
   const int j = e % 38, u = (e / 38) % 64, k = e / (38 * 64);
-  const long long p0 = (long long)blockIdx.y * 32, p1 = p0 + 32 < pn ? p0 + 32 : pn;   // 19 x pn / 32 workgroups: the sum over points is the long axis
+  const long long p0 = (long long)blockIdx.x * 32, p1 = p0 + 32 < pn ? p0 + 32 : pn;   // 19 x pn / 32 workgroups: the sum over points is the long axis
   const float* g = gP + (long long)k * pn * 64 + u;
   float acc = 0.f;
   if (j < 37) {
@@ -664,7 +664,7 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   flow_grad_fold_kernel<<<tf_blocks(kGradFloats, 256), 256, 0, stream>>>(G, (int)blocks);
   if (g_cond) {
     flow_point_fold_cond_kernel<<<tf_blocks(pn * 37, 256), 256, 0, stream>>>(g_point, nets[0].w[0], nets[1].w[0], pn, g_cond);
-    flow_point_fold_w_kernel<<<dim3((2 * 64 * 38 + 255) / 256, (unsigned)((pn + 31) / 32)), 256, 0, stream>>>(
+    flow_point_fold_w_kernel<<<dim3((unsigned)((pn + 31) / 32), (2 * 64 * 38 + 255) / 256), 256, 0, stream>>>(
         g_point, cond, pn, gnets[0].w[0], gnets[0].b[0], gnets[1].w[0], gnets[1].b[0]);
   }
   TF_LAUNCH_CHECK(who);

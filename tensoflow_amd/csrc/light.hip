@@ -119,7 +119,7 @@ struct CubeStack {
 };
 
 __device__ __forceinline__ void mip_split(float mip, int n, int& l0, int& l1, float& f) {
-  const float fl = fminf(floorf(mip), (float)(n - 1));
+  const float fl = fminf(fmaxf(floorf(mip), 0.f), (float)(n - 1));   // (the caller clamps mip to [0, n - 1]; a stray value must not index outside the stack)
   l0 = (int)fl;
   f = mip - fl;
   l1 = min(l0 + 1, n - 1);
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) cube_lookup_mips_fwd_kernel(CubeStack S, 
 
 // gradient of ONE level's bilinear fetch, the wave working together on the map scatter (see cube_lookup_bwd_kernel): (gr, gg, gb) is the
 // gradient wrt this level's fetched value (zero for a lane that takes no part), `lvl` this lane's level; adds d / d direction into (ox, oy, oz)
+// (S: the stack table in LDS -- indexed by a per-lane level; indexing the kernel-argument struct that way sends it through scratch memory)
 __device__ __forceinline__ void cube_level_bwd(const CubeStack& S, int lvl, bool want_dirs, float dx, float dy, float dz, float gr, float gg,
                                                float gb, float& ox, float& oy, float& oz) {
   const float* base = S.tex[lvl];
@@ -204,9 +205,17 @@ __device__ __forceinline__ void cube_level_bwd(const CubeStack& S, int lvl, bool
   }
 }
 
-__global__ void __launch_bounds__(256) cube_lookup_mips_bwd_kernel(CubeStack S, const float* __restrict__ dirs, const float* __restrict__ mip,
+__global__ void __launch_bounds__(256) cube_lookup_mips_bwd_kernel(CubeStack S_arg, const float* __restrict__ dirs, const float* __restrict__ mip,
                                                                    long long m, int apply_exp, const float* __restrict__ g_out,
                                                                    float* __restrict__ g_dirs, float* __restrict__ g_mip) {
+  __shared__ CubeStack S;
+  if (threadIdx.x < 8) {
+    S.tex[threadIdx.x] = S_arg.tex[threadIdx.x];
+    S.g_tex[threadIdx.x] = S_arg.g_tex[threadIdx.x];
+    S.res[threadIdx.x] = S_arg.res[threadIdx.x];
+  }
+  if (threadIdx.x == 0) S.n = S_arg.n;
+  __syncthreads();
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < m;                   // a lane past the end stays in the wave for the cooperative scatter, without a gradient
   if (!live) i = m - 1;
