@@ -457,7 +457,8 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
     """Secondary figure: one TRAINING step of the material stage (BASELINE configs[2], train mode): MCShadingNetwork.forward
     with autograd (shade_mixed + both NIS losses, fields.py:1075-1335) + backward over every trainable tensor, on the
     reference's batch of 2048 surface points.  Forward and the HIP backward ops (VM gather / BRDF weights / cube map / flow
-    log-density) and every dense layer of the step (tf_linear_fwd / tf_linear_bwd, exact fp32 MFMA) run in libtensoflow_hip.so: no library GEMM."""
+    log-density) and every dense layer of the step (tf_linear_fwd / tf_linear_bwd: fp32-grade -- bf16 triple split on the aligned shapes, the exact-fp32 matrix
+    instruction elsewhere) run in libtensoflow_hip.so: no library GEMM."""
     from tensoflow_amd.network.fields import MCShadingNetwork
     from tensoflow_amd.synth import sphere_surface_points
     torch.manual_seed(6033)

@@ -581,7 +581,10 @@ int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n
  * Dense layers of the training direction.  Replace torch.nn.Linear + activation -- the library GEMMs under the reference's
  * TensoSDF decoder (network/fields.py:78-81), make_predictor_3layer / _4layer (network/other_field.py:50-119: material
  * predictors fields.py:1010-1017, inner-light net :905-911, ShapeShadingNetwork's nets :448-567) -- in forward AND backward.
- * precision: TF_PREC_F32 = exact fp32 matrix cores (v_mfma_f32_32x32x2_f32; what the training ops use), TF_PREC_F16X3 = f16 operand
+ * precision: TF_PREC_F32 = fp32-grade products with fp32's operand range (what the training ops use): on the 16-byte-aligned shapes a
+ * bf16 TRIPLE split -- x = hi + mid + lo, six v_mfma_f32_32x32x16_bf16 per 16-deep product, every term down to 2^-24 |a||b|, fp32
+ * accumulate (round 5; 3-7e-7 of the largest element against fp64, as the exact instruction) -- on the other shapes and with
+ * TF_GEMM_SPLIT=0 in the environment the exact-fp32 instruction v_mfma_f32_32x32x2_f32; TF_PREC_F16X3 = f16 operand
  * split (three v_mfma_f32_32x32x16_f16 per product term, fp32 accumulate) for operands inside the f16 range only -- unscaled
  * gradients of a mean-reduced loss are not.
  * X [n,K], W [N,K] (torch layout), b [N] or NULL, Y [n,N] row-major.

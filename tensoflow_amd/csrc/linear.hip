@@ -13,6 +13,7 @@
 // n is 1e3 .. 1e6 rows, K and N <= 256: "tall-skinny" products.  One workgroup = 4 waves = a 128 x 64 tile of C, K walked in
 // chunks of 16 through LDS ([k][m] / [k][n] images: a lane's MFMA operand is one dword, consecutive lanes consecutive addresses).
 #include "mfma_mlp.h"
+#include <cstdlib>
 #include "tf_common.h"
 #include "tf_internal.h"
 
@@ -241,8 +242,36 @@ struct Gemm2Args {
   const float* mulY = nullptr; int mul_act = 0; float mul_param = 0.f; float* colsum = nullptr;
 };
 
-template <bool A_RF, bool B_RF>
-__global__ void __launch_bounds__(256, 4) gemm2_kernel(Gemm2Args G) {
+// SPLIT (round 5; the default, see launch2): every operand element as three bf16 (x = hi + mid + lo, 24 significant bits, fp32's exponent
+// range -- the operands are gradients as often as activations, whose scale f16 does not cover), the product as six
+// v_mfma_f32_32x32x16_bf16 (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid: everything down to 2^-24 of |a||b|) instead of eight
+// v_mfma_f32_32x32x2_f32: 192 instead of 512 matrix cycles per 16 reduction elements, against ~11 vector instructions per pair of
+// operand values for the split (a lane's eight values of a fragment ARE the bf16 instruction's operand: k = 8 h + e).
+typedef __bf16 tf_b8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned g2_cvt2(float a, float b) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+  f2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
+}
+__device__ __forceinline__ void g2_split8(const float (&x)[8], tf_b8& hi, tf_b8& mid, tf_b8& lo) {
+  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+  u4_t h, m, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = x[2 * p], x1 = x[2 * p + 1];
+    const unsigned hh = g2_cvt2(x0, x1);
+    const float r0 = x0 - __uint_as_float(hh << 16), r1 = x1 - __uint_as_float(hh & 0xffff0000u);
+    const unsigned mm = g2_cvt2(r0, r1);
+    const float s0 = r0 - __uint_as_float(mm << 16), s1 = r1 - __uint_as_float(mm & 0xffff0000u);
+    h[p] = hh; m[p] = mm; l[p] = g2_cvt2(s0, s1);
+  }
+  hi = __builtin_bit_cast(tf_b8, h); mid = __builtin_bit_cast(tf_b8, m); lo = __builtin_bit_cast(tf_b8, l);
+}
+__device__ __forceinline__ f32x16 g2_mfma_b(tf_b8 a, tf_b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <bool A_RF, bool B_RF, bool SPLIT = false>
+__global__ void __launch_bounds__(256, SPLIT ? 3 : 4) gemm2_kernel(Gemm2Args G) {
   __shared__ __attribute__((aligned(16))) float lds[G2_NST][2][128 * 16];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, i = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -323,12 +352,30 @@ __global__ void __launch_bounds__(256, 4) gemm2_kernel(Gemm2Args G) {
         }
       }
     }
+    if (SPLIT) {
+      tf_b8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) { g2_split8(fa[t2], ah[t2], am[t2], al[t2]); g2_split8(fb[t2], bh[t2], bm[t2], bl[t2]); }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          f32x16 c = acc[a][b];
+          c = g2_mfma_b(am[a], bm[b], c);
+          c = g2_mfma_b(al[a], bh[b], c);
+          c = g2_mfma_b(ah[a], bl[b], c);
+          c = g2_mfma_b(am[a], bh[b], c);
+          c = g2_mfma_b(ah[a], bm[b], c);
+          acc[a][b] = g2_mfma_b(ah[a], bh[b], c);
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = tf_mfma(fa[a][t], fb[b][t], acc[a][b]);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -499,7 +546,12 @@ inline bool thin_ok(int K, int N) { return TF_GEMM2 && N >= 1 && N <= 4 && K % 4
 template <bool A_RF, bool B_RF>
 int launch2(const Gemm2Args& G, int splits, hipStream_t stream, const char* who) {
   dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)splits);
-  gemm2_kernel<A_RF, B_RF><<<grid, 256, 0, stream>>>(G);
+  // the bf16 triple split is the product form (round 5: 76.9 -> 89.3 TF/s effective on 236 k x 256 x 256, errors against fp64 the same
+  // 3-7e-7 of the largest element as the exact-fp32 instruction's, on activations and on 1e-9-scale gradients alike); TF_GEMM_SPLIT=0
+  // selects the v_mfma_f32_32x32x2_f32 form (tools/exp_gemm_split.py)
+  static const bool split = !(getenv("TF_GEMM_SPLIT") && atoi(getenv("TF_GEMM_SPLIT")) == 0);
+  if (split) gemm2_kernel<A_RF, B_RF, true><<<grid, 256, 0, stream>>>(G);
+  else gemm2_kernel<A_RF, B_RF, false><<<grid, 256, 0, stream>>>(G);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }

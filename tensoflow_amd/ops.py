@@ -447,7 +447,7 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_EXP_CLAMP = 0, 1, 2, 3, 4      # TfActivation
 
 
-LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction's dense layers: exact fp32 MFMA.  PREC_F16X3 exists in the
+LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction's dense layers: fp32-grade (round 5: a bf16 triple split on the aligned shapes -- six bf16 matrix steps per 16-deep product, fp32's range -- the exact-fp32 matrix instruction elsewhere; TF_GEMM_SPLIT=0 forces the latter).  PREC_F16X3 exists in the
                                  # kernel and is NOT the default for two measured reasons: gradients of mean-reduced losses (1e-7 .. 1e-5 per
                                  # element) fall below the f16 range and flush to zero unscaled (test_mcshading_eval_follows_parameter_updates
                                  # caught it), and the tall-skinny products are held by their tile traffic, not by the matrix rate (material
@@ -456,7 +456,7 @@ LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction'
 
 def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None, precision=None):
     """Y = act(x w^T + b) on the matrix cores (tf_linear_fwd): x [n,K], w [N,K], b [N] or None -> [n,N].
-    precision: PREC_F32 (exact fp32 MFMA; module default LINEAR_PRECISION) or PREC_F16X3 (operands within the f16 range only).
+    precision: PREC_F32 (fp32-grade, see LINEAR_PRECISION; the module default) or PREC_F16X3 (operands within the f16 range only).
     n_dev: device int64 scalar -- only the first min(n, n_dev) rows are computed (the rest of Y stays uninitialised)."""
     lib = L.load()
     x, w = _f(x), _f(w)

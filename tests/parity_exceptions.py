@@ -25,7 +25,9 @@ TABLE = [
     # ---- sigmoid outputs far below 1 (occlusion probabilities, scale 0.13, elements down to 1e-4): logit rounding ~1e-6
     (r"shape shading (fused|composed) shade_occ_prob|shape_shading:114|shape_shading_ragged_and_degenerate:138\.1", 5e-3,
      "measured 1.55e-3 / 1.39e-3 / 9.2e-4 at 5e-7 absolute: sigmoid of a 128-wide net's output, the element is 3e-4"),
-    (r"shape shading variants (occ|inter) (occ_prob|indirect_light)", 5e-4, "measured 1.69e-4 at 1.2e-7 absolute: one ulp of the sigmoid's O(1) operand"),
+    (r"shape shading variants (occ|inter) (occ_prob|indirect_light)", 1e-3,
+     "measured 1.69e-4 at 1.2e-7 absolute with the exact-fp32 product instruction, 5.07e-4 at 8.9e-8 absolute with the bf16 triple split (round 5): "
+     "either way ONE ulp of the sigmoid's O(1) operand, on elements of 1e-4"),
     (r"render_core\(validation\) (occ_prob|occ_prob_gt|indirect_light)", 2e-3,
      "measured 4.8e-4 / 7.1e-4 at 1.4e-6 / 4.7e-5 absolute: occlusion at the expected-depth point; the traced value resamples 128 sdf evaluations by inverse CDF"),
     (r"shape shading (fused|composed) shade_reflective|shape_shading:116", 1e-3, "measured 2.4e-4 at 6.0e-7 absolute: reflect(view, normal), a difference of unit vectors, components down to 1e-3"),
