@@ -198,12 +198,16 @@ class LazyOutputs(dict):
                 d = fn()
                 for k in keys:
                     self._lazy.pop(k, None)
-                    if k != key:
+                    if k != key and not dict.__contains__(self, k):      # an entry assigned explicitly since stays
                         dict.__setitem__(self, k, d[k])
                 return d[key]
             return build
         for k in keys:
             self._lazy[k] = take(k)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)          # an explicit entry replaces a pending one
+        dict.__setitem__(self, key, value)
 
     def __missing__(self, key):
         if key in self._lazy:

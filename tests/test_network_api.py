@@ -35,3 +35,46 @@ def test_fused_forward_refuses_autograd():
     m = TensoFlow(2, AABB, device="cpu", gridSize=[8, 8, 8])
     with pytest.raises(RuntimeError, match="no backward yet"):
         m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)   # sampling is a frozen-copy op
+
+
+def test_lazy_output_group_is_built_once_on_first_access():
+    """LazyOutputs.set_lazy_group (round 5: the auxiliary maps of the training pass): the builder runs once, on the first access of any
+    key of the group, and every key of the group is a plain entry afterwards; keys() / `in` / len() see the group before it is built."""
+    from tensoflow_amd.shading import LazyOutputs
+    calls = []
+
+    def build():
+        calls.append(1)
+        return {"a": 1, "b": 2, "c": 3}
+    out = LazyOutputs({"x": 0})
+    out.set_lazy_group(("a", "b", "c"), build)
+    assert set(out.keys()) == {"x", "a", "b", "c"} and "b" in out and len(out) == 4 and not calls
+    assert out["b"] == 2 and calls == [1]
+    assert out["a"] == 1 and out.get("c") == 3 and calls == [1]
+    assert dict(out.items()) == {"x": 0, "a": 1, "b": 2, "c": 3} and calls == [1]
+    # a group nobody reads costs nothing; an explicit assignment wins over the group's value
+    out2 = LazyOutputs()
+    out2.set_lazy_group(("a", "b"), build)
+    out2["a"] = 7
+    assert out2["a"] == 7 and calls == [1]
+    assert out2["b"] == 2 and out2["a"] == 7 and calls == [1, 1]
+
+
+def test_linear_to_srgb_host_form_and_inv_s_cache():
+    """autograd.linear_to_srgb off the device is the composition of encodings.linear_to_srgb (+ clamp); ShapeRenderer._inv_s_host reads the
+    scalar back once per parameter version."""
+    from tensoflow_amd.autograd import linear_to_srgb
+    from tensoflow_amd.encodings import linear_to_srgb as composed
+    x = torch.linspace(-0.2, 1.4, 97)
+    assert torch.equal(linear_to_srgb(x), composed(x))
+    assert torch.equal(linear_to_srgb(x, clamp01=True), composed(x).clamp(0, 1))
+    from tensoflow_amd.network.shapeRenderer import ShapeRenderer
+    r = ShapeRenderer.__new__(ShapeRenderer)
+    torch.nn.Module.__init__(r)
+    from tensoflow_amd.network.fields import SingleVarianceNetwork
+    r.deviation_network = SingleVarianceNetwork(0.3)
+    a = r._inv_s_host()
+    assert abs(a - float(torch.exp(torch.tensor(3.0)))) < 1e-4 and r._inv_s_host() == a
+    with torch.no_grad():
+        r.deviation_network.variance.add_(0.1)           # an optimizer step bumps the version counter
+    assert abs(r._inv_s_host() - float(torch.exp(torch.tensor(4.0)))) < 1e-3
