@@ -366,6 +366,8 @@ def linear_to_srgb(lin, clamp01=False, g_out=None):
     """tf_linear_to_srgb_fwd (g_out None) / _bwd: element-wise on any shape."""
     lin = _f(lin)
     out = torch.empty_like(lin)
+    if g_out is not None and g_out.shape != lin.shape:
+        raise RuntimeError(f"linear_to_srgb: g_out {tuple(g_out.shape)} does not match lin {tuple(lin.shape)}")
     if g_out is None:
         L.check(L.load().tf_linear_to_srgb_fwd(_p(lin), lin.numel(), int(bool(clamp01)), _p(out), _stream()), "tf_linear_to_srgb_fwd")
     else:
@@ -689,6 +691,11 @@ def cube_lookup_bwd(base, dirs, g_out, apply_exp=True):
 def _cube_stack(texs):
     texs = [_f(t) for t in texs]
     n = len(texs)
+    if not 1 <= n <= 8:
+        raise RuntimeError(f"cube_lookup_mips: 1..8 levels, got {n}")
+    for t in texs:
+        if t.dim() != 4 or t.shape[0] != 6 or t.shape[1] != t.shape[2] or t.shape[3] != 3:
+            raise RuntimeError(f"cube_lookup_mips: every level is [6,R,R,3], got {tuple(t.shape)}")
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in texs])
     res = (C.c_int32 * n)(*[int(t.shape[1]) for t in texs])
     return texs, n, ptrs, res
@@ -699,6 +706,8 @@ def cube_lookup_mips(texs, dirs, mip, apply_exp=True):
     texs, n, ptrs, res = _cube_stack(texs)
     dirs, mip = _f(dirs), _f(mip.reshape(-1))
     m = dirs.shape[0]
+    if dirs.shape != (m, 3) or mip.numel() != m:
+        raise RuntimeError(f"cube_lookup_mips: dirs [m,3] and mip [m], got {tuple(dirs.shape)} and {mip.numel()} values")
     out = torch.empty(m, 3, dtype=torch.float32, device=dirs.device)
     L.check(L.load().tf_cube_lookup_mips_fwd(ptrs, res, n, _p(dirs), _p(mip), m, int(apply_exp), _p(out), _stream()), "tf_cube_lookup_mips_fwd")
     return out
@@ -709,6 +718,8 @@ def cube_lookup_mips_bwd(texs, dirs, mip, g_out, apply_exp=True, want_texs=True,
     texs, n, ptrs, res = _cube_stack(texs)
     dirs, mip, g_out = _f(dirs), _f(mip.reshape(-1)), _f(g_out)
     m = dirs.shape[0]
+    if dirs.shape != (m, 3) or mip.numel() != m or g_out.shape != (m, 3):
+        raise RuntimeError(f"cube_lookup_mips_bwd: dirs / g_out [m,3] and mip [m], got {tuple(dirs.shape)}, {tuple(g_out.shape)}, {mip.numel()}")
     g_texs = [torch.zeros_like(t) for t in texs] if want_texs else None
     gptrs = (C.c_void_p * n)(*[t.data_ptr() for t in g_texs]) if want_texs else None
     g_dirs = torch.zeros(m, 3, dtype=torch.float32, device=dirs.device) if want_dirs else None
