@@ -531,11 +531,16 @@ __global__ void __launch_bounds__(256) flow_logq_bwd_kernel(const float* __restr
 }
 
 // fold the per-workgroup slices into the caller's gradient tensors (+=): one thread per gradient element
+// (eight groups of slices per element, joined by an atomic: one thread per element walking all 256 slices was 100 workgroups of
+// dependent-latency loads, 62 us for 26 MB)
 __global__ void __launch_bounds__(256) flow_grad_fold_kernel(FlowGrads G, int n_blocks) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kGradFloats) return;
+  const int per = (n_blocks + (int)gridDim.y - 1) / (int)gridDim.y, b0 = blockIdx.y * per, b1 = min(b0 + per, n_blocks);
+  if (b0 >= b1) return;
   float s = 0.f;
-  for (int b = 0; b < n_blocks; ++b) s += G.slices[(size_t)b * kGradFloats + e];
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) s += G.slices[(size_t)b * kGradFloats + e];
   const int net = e / kGNet, r = e % kGNet;
   float* dst;
   if (r < kGW1) dst = G.w[net][0] + r;
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(256) flow_grad_fold_kernel(FlowGrads G, int n_
   else if (r < kGB3) dst = G.b[net][2] + (r - kGB2);
   else if (r < kGB3 + 21) dst = G.b[net][3] + (r - kGB3);
   else return;
-  *dst += s;
+  atomicAdd(dst, s);
 }
 
 // The hoisted layer-1 point part, folded back (tf_flow_logq_bwd with g_cond): c = 2 cond - 1 [pn,37], P_k = c W1_k[:, 7:44]^T + b1_k
@@ -661,7 +666,7 @@ extern "C" int tf_flow_logq_bwd(const TfCouplingNet nets[2], const float* cond, 
   hipError_t e2 = hipMemsetAsync(G.slices, 0, (size_t)blocks * kGradFloats * sizeof(float), stream);
   TF_REQUIRE(e2 == hipSuccess, TF_EHIP, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e2));
   flow_logq_bwd_kernel<<<(unsigned)blocks, 256, lds, stream>>>(workspace, P, x, (const long long*)rays_id, m, sn, pn, g_logq, G, g_x, z_saved);
-  flow_grad_fold_kernel<<<tf_blocks(kGradFloats, 256), 256, 0, stream>>>(G, (int)blocks);
+  flow_grad_fold_kernel<<<dim3(tf_blocks(kGradFloats, 256), 8), 256, 0, stream>>>(G, (int)blocks);
   if (g_cond) {
     flow_point_fold_cond_kernel<<<tf_blocks(pn * 37, 256), 256, 0, stream>>>(g_point, nets[0].w[0], nets[1].w[0], pn, g_cond);
     flow_point_fold_w_kernel<<<dim3((unsigned)((pn + 31) / 32), (2 * 64 * 38 + 255) / 256), 256, 0, stream>>>(
