@@ -84,6 +84,24 @@ with torch.no_grad():
     res["alone_ms"] = {k: round(v, 3) for k, v in alone.items()}
     print(json.dumps(res["alone_ms"]), flush=True)
 
+    if os.environ.get("MODE") == "reduce":
+        # the per-pixel reduction (texel gathers of the environment light: dependent loads, few vector instructions) beside the
+        # traversal (vector-issue bound): the one pairing tools/coexec.hip predicts to overlap (valu + chase 1.05-1.19 x)
+        def reduce_():
+            return ops.shade_reduce_env(wgt, dirs, depth.reshape(pn, -1), None, hl.reshape(pn, -1, 3), sh.env, 128 + sh.fixed_d.shape[0], 128, slot_of_pos=order)
+        alone["reduce"] = timed(reduce_)
+        out = {"reduce_alone_ms": round(alone["reduce"], 3)}
+        for k in (0, 6, 5, 4):
+            ms = timed(reduce_, lambda: bvh(k))
+            out[f"reduce+bvh{k or 7}"] = dict(ms=round(ms, 3), serial_default=round(alone["reduce"] + alone["bvh_k0"], 3),
+                                               serial_same_budget=round(alone["reduce"] + alone[f"bvh_k{k}"], 3))
+        for w in (0, 8):
+            ms = timed(reduce_, lambda: flow(w))
+            out[f"reduce+flow{w or 12}"] = dict(ms=round(ms, 3), serial_default=round(alone["reduce"] + alone["flow_w0"], 3))
+        ms = timed(reduce_, lambda: inner(0))
+        out["reduce+inner2"] = dict(ms=round(ms, 3), serial_default=round(alone["reduce"] + alone["inner_t0"], 3))
+        ops.set_launch_budget()
+        print(json.dumps(out)); sys.exit(0)
     if os.environ.get("MODE") == "alone":
         ops.set_launch_budget()
         print(json.dumps(res)); sys.exit(0)
