@@ -321,11 +321,14 @@ int tf_cubemap_mip_fwd(const float* cube, int32_t res, float* out /*[6,res/2,res
 int tf_cubemap_diffuse_fwd(const float* cube, int32_t res, float* out, tf_stream_t stream);
 int tf_cubemap_diffuse_bwd(const float* g_out, int32_t res, float* g_cube, tf_stream_t stream);
 /* cos_cutoff = cosine of the lobe half-angle keeping `cutoff` of the GGX NDF mass (ops.py:428-441, computed by the host).
- * out = sum w*cube / sum w; wsum [6,res,res] (may be NULL) receives sum w for the backward. */
+ * out = sum w*cube / sum w; wsum [6,res,res] (may be NULL) receives sum w for the backward.
+ * texel_table (round 5; NULL: derived per pair in the kernel, same values): [6,res,res,4] floats from tf_cubemap_texel_table --
+ * (unit direction, area) of every texel as c_src/cubemap.cu:17-46 defines them; a function of res alone, built once. */
+int tf_cubemap_texel_table(int32_t res, float* table /* 16-byte aligned */, tf_stream_t stream);
 int tf_cubemap_specular_fwd(const float* cube, int32_t res, float roughness, float cos_cutoff, float* out, float* wsum,
-                            tf_stream_t stream);
+                            const float* texel_table, tf_stream_t stream);
 int tf_cubemap_specular_bwd(const float* g_out, const float* wsum, int32_t res, float roughness, float cos_cutoff,
-                            float* g_cube, tf_stream_t stream);
+                            float* g_cube, const float* texel_table, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * First-hit ray/mesh intersection: raytracing.RayTracer.trace (raytracing/raytracer.py:19-54) +

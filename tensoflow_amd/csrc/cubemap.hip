@@ -11,6 +11,7 @@
 //     with the roles of the fixed and the running texel swapped -- deterministic, no atomics.
 // Pair arithmetic is written in the reference's operation order with FMA contraction off: the GGX term at roughness 0.08
 // is ill-conditioned at the lobe centre (see oracle/cubemap.py).
+#include <cstdint>
 #include "tf_common.h"
 
 #pragma clang fp contract(off)
@@ -61,10 +62,13 @@ __device__ __forceinline__ float pair_weight(V3 V, V3 L, float area, float a2, f
 // output texel (four normalised corner directions, two acos: ~150 instructions per tile and texel, nine tenths of the kernel at
 // R = 128 where a narrow lobe keeps 1-4 of 1 536 tiles).  The test stays conservative (margin 3e-3 rad), and a tile that passes
 // needlessly only contributes exact zeros: results are unchanged bit for bit.
-template <int MODE, int ADJ, bool TILES>
+// TAB (round 5): the running texel's direction and area come from a table (tf_cubemap_texel_table: the same two expressions, evaluated
+// once per resolution instead of once per pair -- two integer divisions, five float divisions, a square root and the face switch were
+// ~100 of a pair's ~250 instructions); values, hence results, are bit-identical to the in-kernel form.
+template <int MODE, int ADJ, bool TILES, bool TAB = false>
 __global__ void __launch_bounds__(256) cube_filter_kernel(const float* __restrict__ src, const float* __restrict__ wsum_in, int R,
                                                           float a2, float cutoff, float theta_cut, float* __restrict__ out,
-                                                          float* __restrict__ wsum_out) {
+                                                          float* __restrict__ wsum_out, const float4* __restrict__ tab = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float s_ax[];   // per-axis angular extent, pixel_area(x,y) = s_ax[x] * s_ax[y]; then the tile table
   float4* s_tile = reinterpret_cast<float4*>(s_ax + ((R + 3) & ~3));
   if (TILES) {
@@ -101,10 +105,19 @@ __global__ void __launch_bounds__(256) cube_filter_kernel(const float* __restric
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, ws = 0.f;
 
   auto pair = [&](int b) {
-    const int bs = b / (R * R), by = (b / R) % R, bx = b % R;
-    const V3 G = texel_dir(bx, by, bs, R);
+    V3 G;
+    float areaG;
+    if (TAB) {
+      const float4 q = tab[b];
+      G = {q.x, q.y, q.z};
+      areaG = q.w;
+    } else {
+      const int bs = b / (R * R), by = (b / R) % R, bx = b % R;
+      G = texel_dir(bx, by, bs, R);
+      areaG = s_ax[bx] * s_ax[by];
+    }
     float w;
-    if (ADJ == 0) w = pair_weight<MODE>(F, G, s_ax[bx] * s_ax[by], a2, cutoff);
+    if (ADJ == 0) w = pair_weight<MODE>(F, G, areaG, a2, cutoff);
     else          w = pair_weight<MODE>(G, F, areaF, a2, cutoff);
     if (w != 0.f) {
       float s0 = src[3 * b], s1 = src[3 * b + 1], s2 = src[3 * b + 2];
@@ -158,6 +171,28 @@ __global__ void __launch_bounds__(256) cube_filter_kernel(const float* __restric
   }
 }
 
+// table of (texel direction, texel area) of a [6,R,R] map, as cube_filter_kernel derives them
+__global__ void __launch_bounds__(256) cube_texel_table_kernel(int R, float4* __restrict__ tab) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= 6 * R * R) return;
+  const int bs = b / (R * R), by = (b / R) % R, bx = b % R;
+  auto ax = [&](int i) {
+    if (R <= 1) return 1.f;
+    const int H = R / 2;
+    const int a = abs(i - H);
+    return atanf((float)(a + 1) / (float)H) - atanf((float)a / (float)H);
+  };
+  const V3 G = texel_dir(bx, by, bs, R);
+  tab[b] = make_float4(G.x, G.y, G.z, ax(bx) * ax(by));
+}
+extern "C" int tf_cubemap_texel_table(int32_t res, float* table, tf_stream_t stream) {
+  TF_REQUIRE(res >= 1 && res <= 2048, TF_ESHAPE, "tf_cubemap_texel_table: res=%d out of range", res);
+  TF_REQUIRE(table && (reinterpret_cast<uintptr_t>(table) & 15) == 0, TF_EINVAL, "tf_cubemap_texel_table: null / unaligned table");
+  cube_texel_table_kernel<<<tf_blocks(6LL * res * res, 256), 256, 0, (hipStream_t)stream>>>(res, reinterpret_cast<float4*>(table));
+  TF_LAUNCH_CHECK("tf_cubemap_texel_table");
+  return TF_OK;
+}
+
 __global__ void __launch_bounds__(256) cube_mip_kernel(const float* __restrict__ src, int R, float* __restrict__ out) {
   const int Ro = R >> 1;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -177,7 +212,7 @@ extern "C" int tf_cubemap_mip_fwd(const float* cube, int32_t res, float* out, tf
 
 template <int MODE, int ADJ>
 static int launch_filter(const char* name, const float* src, const float* wsum_in, int res, float roughness, float cos_cutoff,
-                         float* out, float* wsum_out, tf_stream_t stream) {
+                         float* out, float* wsum_out, tf_stream_t stream, const float* table = nullptr) {
   TF_REQUIRE(res >= 1 && res <= 2048, TF_ESHAPE, "%s: res=%d out of range", name, res);
   TF_REQUIRE(src && out, TF_EINVAL, "%s: null pointer", name);
   const float alpha = roughness * roughness;
@@ -185,7 +220,11 @@ static int launch_filter(const char* name, const float* src, const float* wsum_i
   const float cc = cos_cutoff < -1.f ? -1.f : (cos_cutoff > 1.f ? 1.f : cos_cutoff);
   const int T = res >> 3;
   const size_t tile_bytes = (size_t)6 * T * T * sizeof(float4);
-  if (MODE == 1 && (res & 7) == 0 && tile_bytes <= 48 * 1024)
+  TF_REQUIRE(!table || (reinterpret_cast<uintptr_t>(table) & 15) == 0, TF_EINVAL, "%s: unaligned texel table", name);
+  if (MODE == 1 && (res & 7) == 0 && tile_bytes <= 48 * 1024 && table)
+    cube_filter_kernel<MODE, ADJ, true, true><<<tf_blocks(6LL * res * res, 4), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
+        src, wsum_in, res, a2, cos_cutoff, acosf(cc), out, wsum_out, reinterpret_cast<const float4*>(table));
+  else if (MODE == 1 && (res & 7) == 0 && tile_bytes <= 48 * 1024)
     cube_filter_kernel<MODE, ADJ, true><<<tf_blocks(6LL * res * res, 4), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
         src, wsum_in, res, a2, cos_cutoff, acosf(cc), out, wsum_out);
   else
@@ -202,11 +241,11 @@ extern "C" int tf_cubemap_diffuse_bwd(const float* g_out, int32_t res, float* g_
   return launch_filter<0, 1>("tf_cubemap_diffuse_bwd", g_out, nullptr, res, 0.f, 0.f, g_cube, nullptr, stream);
 }
 extern "C" int tf_cubemap_specular_fwd(const float* cube, int32_t res, float roughness, float cos_cutoff, float* out, float* wsum,
-                                       tf_stream_t stream) {
-  return launch_filter<1, 0>("tf_cubemap_specular_fwd", cube, nullptr, res, roughness, cos_cutoff, out, wsum, stream);
+                                       const float* texel_table, tf_stream_t stream) {
+  return launch_filter<1, 0>("tf_cubemap_specular_fwd", cube, nullptr, res, roughness, cos_cutoff, out, wsum, stream, texel_table);
 }
 extern "C" int tf_cubemap_specular_bwd(const float* g_out, const float* wsum, int32_t res, float roughness, float cos_cutoff,
-                                       float* g_cube, tf_stream_t stream) {
+                                       float* g_cube, const float* texel_table, tf_stream_t stream) {
   TF_REQUIRE(wsum, TF_EINVAL, "tf_cubemap_specular_bwd: null wsum");
-  return launch_filter<1, 1>("tf_cubemap_specular_bwd", g_out, wsum, res, roughness, cos_cutoff, g_cube, nullptr, stream);
+  return launch_filter<1, 1>("tf_cubemap_specular_bwd", g_out, wsum, res, roughness, cos_cutoff, g_cube, nullptr, stream, texel_table);
 }

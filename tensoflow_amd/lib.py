@@ -97,8 +97,9 @@ SIGNATURES = {
     "tf_cubemap_mip_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
     "tf_cubemap_diffuse_fwd": (C.c_int, [c_f, i32, c_f, c_f]),
     "tf_cubemap_diffuse_bwd": (C.c_int, [c_f, i32, c_f, c_f]),
-    "tf_cubemap_specular_fwd": (C.c_int, [c_f, i32, f32, f32, c_f, c_f, c_f]),
-    "tf_cubemap_specular_bwd": (C.c_int, [c_f, c_f, i32, f32, f32, c_f, c_f]),
+    "tf_cubemap_texel_table": (C.c_int, [i32, c_f, c_f]),
+    "tf_cubemap_specular_fwd": (C.c_int, [c_f, i32, f32, f32, c_f, c_f, c_f, c_f]),
+    "tf_cubemap_specular_bwd": (C.c_int, [c_f, c_f, i32, f32, f32, c_f, c_f, c_f]),
     "tf_bvh_build_host": (i64, [C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p]),
     "tf_bvh_pack_host": (i64, [C.c_void_p, i64, C.c_void_p, i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tf_bvh_trace": (C.c_int, [c_f, c_f, P(f32 * 6), i64, c_f, c_f, i64, c_f, f32, f32, c_f, i64, c_f, c_f, c_f, c_f, i32, c_f, c_f, c_f]),

@@ -808,20 +808,36 @@ def cubemap_diffuse(cube, adjoint=False):
     return out
 
 
-def cubemap_specular(cube, roughness, cos_cutoff):
+_TEXEL_TABLES = {}
+
+
+def cubemap_texel_table(res, device):
+    """[6,res,res,4] (unit direction, area) of every texel (tf_cubemap_texel_table): a function of the resolution alone, built once per
+    (resolution, device) and handed to the GGX prefilter and its adjoint (round 5)."""
+    key = (int(res), str(device))
+    if key not in _TEXEL_TABLES:
+        tab = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+        L.check(L.load().tf_cubemap_texel_table(int(res), _p(tab), _stream()), "tf_cubemap_texel_table")
+        _TEXEL_TABLES[key] = tab
+    return _TEXEL_TABLES[key]
+
+
+def cubemap_specular(cube, roughness, cos_cutoff, use_table=True):
     """-> (filtered map, weight sums [6,R,R])"""
     cube = _cube(cube)
     out = torch.empty_like(cube)
     wsum = torch.empty(cube.shape[:3], dtype=torch.float32, device=cube.device)
-    L.check(L.load().tf_cubemap_specular_fwd(_p(cube), cube.shape[1], float(roughness), float(cos_cutoff), _p(out), _p(wsum),
+    tab = cubemap_texel_table(cube.shape[1], cube.device) if use_table else None
+    L.check(L.load().tf_cubemap_specular_fwd(_p(cube), cube.shape[1], float(roughness), float(cos_cutoff), _p(out), _p(wsum), _p(tab),
                                              _stream()), "tf_cubemap_specular_fwd")
     return out, wsum
 
 
-def cubemap_specular_bwd(g_out, wsum, roughness, cos_cutoff):
+def cubemap_specular_bwd(g_out, wsum, roughness, cos_cutoff, use_table=True):
     g_out = _cube(g_out)
     g = torch.empty_like(g_out)
-    L.check(L.load().tf_cubemap_specular_bwd(_p(g_out), _p(_f(wsum)), g_out.shape[1], float(roughness), float(cos_cutoff), _p(g),
+    tab = cubemap_texel_table(g_out.shape[1], g_out.device) if use_table else None
+    L.check(L.load().tf_cubemap_specular_bwd(_p(g_out), _p(_f(wsum)), g_out.shape[1], float(roughness), float(cos_cutoff), _p(g), _p(tab),
                                              _stream()), "tf_cubemap_specular_bwd")
     return g
 

@@ -550,6 +550,24 @@ def test_cubemap_prefilter_vs_oracle(dev):
                why="measured 1.1e-4 relative at 6e-7 absolute: fp32 sums over the GGX window in another order than numpy", label=f"cubemap specular adjoint (roughness {r})")
 
 
+def test_cubemap_texel_table_changes_no_bit(dev):
+    """The GGX prefilter and its adjoint with the texel table (tf_cubemap_texel_table, round 5: direction and area of the running texel
+    looked up instead of derived per pair) against the in-kernel derivation: the same expressions, so every output bit is the same."""
+    from tensoflow_amd import ops
+    from tensoflow_amd.network.light import ndf_cutoff
+    gen = torch.Generator().manual_seed(9)
+    for res, r in ((128, 0.08), (64, 0.29), (32, 0.5), (16, 1.0)):
+        cube = (torch.randn(6, res, res, 3, generator=gen) * 0.5).to(dev)
+        a, wa = ops.cubemap_specular(cube, r, ndf_cutoff(r), use_table=True)
+        b, wb = ops.cubemap_specular(cube, r, ndf_cutoff(r), use_table=False)
+        assert torch.equal(a, b) and torch.equal(wa, wb), (res, r)
+        g = torch.randn(6, res, res, 3, generator=gen).to(dev)
+        assert torch.equal(ops.cubemap_specular_bwd(g, wa, r, ndf_cutoff(r), use_table=True),
+                           ops.cubemap_specular_bwd(g, wa, r, ndf_cutoff(r), use_table=False)), (res, r)
+    tab = ops.cubemap_texel_table(16, dev)
+    assert tab.shape == (6, 16, 16, 4) and float((tab[..., :3].norm(dim=-1) - 1).abs().max()) < 1e-6 and float(tab[..., 3].min()) > 0
+
+
 def test_cubemap_prefilter_full_res_rows(dev):
     """128^2 base at roughness 0.08 (the sharp, ill-conditioned lobe): sampled output texels incl. face corners and edges."""
     from oracle import cubemap as oc
