@@ -636,6 +636,9 @@ int tf_linear_to_srgb_bwd(const float* lin, const float* g_out, int64_t n, int32
  *   of the loss, one float on the device; coef_h = weight * 2 / count_h (0 if count_h == 0), coef_w likewise. */
 int32_t tf_tv_partials(void);
 int tf_tv_fwd(const float* x, int32_t C, int32_t H, int32_t W, float* partial, tf_stream_t stream);
+/* loss[0] += coef_h * (sum of the H partials) + coef_w * (sum of the W partials), fixed order: several grids accumulate into one
+ * device scalar (TensoSDF.TV_loss_sdf, fields.py:133-138: six grids) without element-wise launches between them (round 5). */
+int tf_tv_finish(const float* partial, float coef_h, float coef_w, float* loss, tf_stream_t stream);
 int tf_tv_bwd(const float* x, int32_t C, int32_t H, int32_t W, const float* g_dev, float coef_h, float coef_w, float* g_x,
               tf_stream_t stream);
 

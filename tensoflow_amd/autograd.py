@@ -414,6 +414,44 @@ class SdfAlphaFn(torch.autograd.Function):
         return (None, None, None, None, g_inv.reshape(inv_s.shape), None, None, None, None, *gplanes, *glines, g_w1, g_b1, g_w2, g_b2)
 
 
+class TvLossSumFn(torch.autograd.Function):
+    """sum over several [1,C,H,W] grids of TVLoss.forward (TensoSDF.TV_loss_sdf, fields.py:133-138: three planes + three lines): per grid
+    tf_tv_fwd + tf_tv_finish accumulating into one device scalar, tf_tv_bwd per grid -- 13 launches forward instead of 36 (round 5)."""
+
+    @staticmethod
+    def forward(ctx, weight, *grids):
+        from . import lib as L
+        lib = L.load()
+        dev = grids[0].device
+        total = torch.zeros(1, dtype=torch.float32, device=dev)
+        part = torch.empty(lib.tf_tv_partials(), dtype=torch.float32, device=dev)
+        coefs = []
+        for x in grids:
+            b, c, h, w = x.shape
+            assert b == 1 and x.is_contiguous() and x.dtype == torch.float32
+            count_h, count_w = c * (h - 1) * w, c * h * (w - 1)
+            coef = (float(weight) * 2.0 / count_h if count_h else 0.0, float(weight) * 2.0 / count_w if count_w else 0.0)
+            coefs.append(coef)
+            L.check(lib.tf_tv_fwd(ops._p(x), c, h, w, ops._p(part), ops._stream()), "tf_tv_fwd")
+            L.check(lib.tf_tv_finish(ops._p(part), coef[0], coef[1], ops._p(total), ops._stream()), "tf_tv_finish")
+        ctx.coefs = coefs
+        ctx.save_for_backward(*grids)
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import lib as L
+        lib = L.load()
+        g1 = g.reshape(1).contiguous().float()
+        out = []
+        for x, coef in zip(ctx.saved_tensors, ctx.coefs):
+            _, c, h, w = x.shape
+            gx = torch.empty_like(x)
+            L.check(lib.tf_tv_bwd(ops._p(x), c, h, w, ops._p(g1), coef[0], coef[1], ops._p(gx), ops._stream()), "tf_tv_bwd")
+            out.append(gx)
+        return (None, *out)
+
+
 class TvLossFn(torch.autograd.Function):
     """TVLoss.forward (other_field.py:170-191) of one [1,C,H,W] grid: tf_tv_fwd (+ a fixed-order sum of its 1 024 partials) and
     tf_tv_bwd -- two launches forward, one backward, instead of ~12 + autograd's slice backwards on a plane-sized tensor."""

@@ -43,9 +43,33 @@ __global__ void __launch_bounds__(256) tv_bwd_kernel(const float* __restrict__ x
   if (j + 1 < W) b -= x[e + 1] - v;
   gx[e] = up * (2.f * ch * a + 2.f * cw * b);
 }
+// loss[0] += coef_h * sum of the H partials + coef_w * sum of the W partials, in a fixed order (one workgroup): the six grids of
+// TensoSDF.TV_loss_sdf accumulate into one scalar without an element-wise launch between them (round 5)
+__global__ void __launch_bounds__(256) tv_finish_kernel(const float* __restrict__ partial, float ch, float cw, float* __restrict__ loss) {
+  float sh = 0.f, sw = 0.f;
+#pragma unroll
+  for (int k = 0; k < kTvBlocks / 256; ++k) {
+    sh += partial[2 * (k * 256 + threadIdx.x)];
+    sw += partial[2 * (k * 256 + threadIdx.x) + 1];
+  }
+  __shared__ float red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sh += __shfl_xor(sh, o); sw += __shfl_xor(sw, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sh; red[1][threadIdx.x >> 6] = sw; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    loss[0] += ch * ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + cw * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+}
 }  // namespace
 
 extern "C" int32_t tf_tv_partials(void) { return 2 * kTvBlocks; }
+
+extern "C" int tf_tv_finish(const float* partial, float coef_h, float coef_w, float* loss, tf_stream_t stream) {
+  TF_REQUIRE(partial && loss, TF_EINVAL, "tf_tv_finish: null pointer");
+  tv_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partial, coef_h, coef_w, loss);
+  TF_LAUNCH_CHECK("tf_tv_finish");
+  return TF_OK;
+}
 
 extern "C" int tf_tv_fwd(const float* x, int32_t C, int32_t H, int32_t W, float* partial, tf_stream_t stream) {
   TF_REQUIRE(C >= 1 && H >= 1 && W >= 1, TF_ESHAPE, "tf_tv_fwd: bad sizes");

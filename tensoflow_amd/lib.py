@@ -125,6 +125,7 @@ SIGNATURES = {
     "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, i32, c_f, sz, c_f]),
     "tf_tv_partials": (C.c_int32, []),
     "tf_tv_fwd": (C.c_int, [c_f, i32, i32, i32, c_f, c_f]),
+    "tf_tv_finish": (C.c_int, [c_f, f32, f32, c_f, c_f]),
     "tf_tv_bwd": (C.c_int, [c_f, i32, i32, i32, c_f, f32, f32, c_f, c_f]),
     "tf_ide5_fwd": (C.c_int, [c_f, c_f, c_f, i64, c_f, c_f]),
     "tf_ide5_bwd": (C.c_int, [c_f, c_f, c_f, c_f, i64, c_f, c_f, c_f]),

@@ -153,6 +153,10 @@ class TensoSDF(nn.Module):
     # parameter-only regularisers (device-resident torch; they never touch a ray)
     def TV_loss_sdf(self, reg):
         """fields.py:133-138."""
+        grids = [g for i in range(self.nplane) for g in (self.sdf_plane[i], self.sdf_line[i])]
+        if isinstance(reg, TVLoss) and all(g.is_cuda and g.dim() == 4 and g.shape[0] == 1 and g.dtype == torch.float32 and g.is_contiguous() for g in grids):
+            from ..autograd import TvLossSumFn
+            return TvLossSumFn.apply(reg.TVLoss_weight, *grids)      # one accumulation on the device over the six grids
         total = 0
         for i in range(self.nplane):
             total = total + reg(self.sdf_plane[i]) + reg(self.sdf_line[i])

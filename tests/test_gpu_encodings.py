@@ -111,3 +111,23 @@ def test_tv_loss_kernels(dev, shape):
     assert float((g.cpu().double() - gr).abs().max()) < 1e-5 * max(1e-6, float(gr.abs().max()))
     again = TVLoss(0.7)(xd)
     assert float(again) == float(got)                       # fixed-order reduction: identical bits run to run
+
+
+def test_tv_loss_of_six_grids_in_one_accumulation(dev):
+    """TensoSDF.TV_loss_sdf (fields.py:133-138) through TvLossSumFn (round 5: tf_tv_fwd + tf_tv_finish per grid into ONE device scalar)
+    against the per-grid TVLoss sum in double precision: value, the gradient of every grid, and identical bits run to run."""
+    from tensoflow_amd.autograd import TvLossSumFn
+    from tensoflow_amd.network.fields import TVLoss
+    gen = torch.Generator().manual_seed(21)
+    shapes = [(1, 36, 48, 48), (1, 36, 48, 1), (1, 36, 40, 48), (1, 36, 40, 1), (1, 36, 48, 40), (1, 36, 48, 1)]
+    xs = [torch.randn(*s, generator=gen) for s in shapes]
+    xd = [x.to(dev).requires_grad_(True) for x in xs]
+    got = TvLossSumFn.apply(0.3, *xd)
+    grads = torch.autograd.grad(got * 2.0, xd)
+    x64 = [x.double().requires_grad_(True) for x in xs]
+    ref = sum(TVLoss(0.3)(x) for x in x64)
+    gref = torch.autograd.grad(ref * 2.0, x64)
+    assert abs(float(got) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    for g, gr in zip(grads, gref):
+        assert float((g.cpu().double() - gr).abs().max()) < 1e-5 * float(gr.abs().max())
+    assert float(TvLossSumFn.apply(0.3, *xd)) == float(got)
