@@ -97,8 +97,9 @@ __global__ void __launch_bounds__(256) cube_filter_kernel(const float* __restric
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int n = 6 * R * R;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= n) return;                            // wave-uniform
+  // a wave owns one output texel at a time and walks the map in strides of the grid: the tables above are built once per workgroup,
+  // not once per four texels (round 5: at 128^2 they were more than half of the kernel)
+  for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += gridDim.x * 4) {
   const int ts = t / (R * R), ty = (t / R) % R, tx = t % R;
   const V3 F = texel_dir(tx, ty, ts, R);
   const float areaF = s_ax[tx] * s_ax[ty];
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(256) cube_filter_kernel(const float* __restric
       out[3 * t] = acc0; out[3 * t + 1] = acc1; out[3 * t + 2] = acc2;
     }
   }
+  }
 }
 
 // table of (texel direction, texel area) of a [6,R,R] map, as cube_filter_kernel derives them
@@ -210,6 +212,22 @@ extern "C" int tf_cubemap_mip_fwd(const float* cube, int32_t res, float* out, tf
   return TF_OK;
 }
 
+// Four output texels per workgroup and turn.  A workgroup takes several turns only where its tables are worth amortising: a narrow lobe
+// (128^2 at roughness 0.08: 1-4 of 1 536 tiles survive, the tables are twice a texel's own work) -- a wide lobe's texels cost tens of
+// times the tables, and one turn per workgroup leaves their uneven windows to the hardware's dispatcher (a fixed stride measured
+// 12-25 % slower there).
+static unsigned filter_blocks(int res, float theta_cut, bool tiles) {
+  const unsigned want = tf_blocks(6LL * res * res, 4);
+  if (!tiles) return want;
+  const int T = res >> 3, ntile = 6 * T * T, nround = (ntile + 63) / 64;
+  const float frac = 0.5f * (1.f - cosf(fminf(theta_cut + 0.1f, 3.14159f)));            // the lobe's share of the sphere (+ a tile's radius)
+  const float per_texel = 15.f * nround + 150.f * fmaxf(1.f, frac * ntile);               // ~instructions of a wave per output texel
+  const float tables = 150.f * ntile / 256.f;                                             // ~instructions per thread, once per workgroup
+  int turns = (int)ceilf(8.f * tables / per_texel);    // (measured at 128^2 / 0.08: 4 turns 0.276 ms, 9 turns 0.235 ms, one turn 0.530 ms)
+  turns = turns < 1 ? 1 : (turns > 16 ? 16 : turns);
+  return (want + turns - 1) / turns;
+}
+
 template <int MODE, int ADJ>
 static int launch_filter(const char* name, const float* src, const float* wsum_in, int res, float roughness, float cos_cutoff,
                          float* out, float* wsum_out, tf_stream_t stream, const float* table = nullptr) {
@@ -222,13 +240,13 @@ static int launch_filter(const char* name, const float* src, const float* wsum_i
   const size_t tile_bytes = (size_t)6 * T * T * sizeof(float4);
   TF_REQUIRE(!table || (reinterpret_cast<uintptr_t>(table) & 15) == 0, TF_EINVAL, "%s: unaligned texel table", name);
   if (MODE == 1 && (res & 7) == 0 && tile_bytes <= 48 * 1024 && table)
-    cube_filter_kernel<MODE, ADJ, true, true><<<tf_blocks(6LL * res * res, 4), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
+    cube_filter_kernel<MODE, ADJ, true, true><<<filter_blocks(res, acosf(cc), true), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
         src, wsum_in, res, a2, cos_cutoff, acosf(cc), out, wsum_out, reinterpret_cast<const float4*>(table));
   else if (MODE == 1 && (res & 7) == 0 && tile_bytes <= 48 * 1024)
-    cube_filter_kernel<MODE, ADJ, true><<<tf_blocks(6LL * res * res, 4), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
+    cube_filter_kernel<MODE, ADJ, true><<<filter_blocks(res, acosf(cc), true), 256, ((res + 3) & ~3) * sizeof(float) + tile_bytes, (hipStream_t)stream>>>(
         src, wsum_in, res, a2, cos_cutoff, acosf(cc), out, wsum_out);
   else
-    cube_filter_kernel<MODE, ADJ, false><<<tf_blocks(6LL * res * res, 4), 256, ((res + 3) & ~3) * sizeof(float) + 16, (hipStream_t)stream>>>(
+    cube_filter_kernel<MODE, ADJ, false><<<filter_blocks(res, acosf(cc), false), 256, ((res + 3) & ~3) * sizeof(float) + 16, (hipStream_t)stream>>>(
         src, wsum_in, res, a2, cos_cutoff, acosf(cc), out, wsum_out);
   TF_LAUNCH_CHECK(name);
   return TF_OK;
