@@ -765,3 +765,41 @@ def test_linear_bwd_chain_equals_layer_by_layer(dev, n, cnt):
         for a, b, name in ((got[l][0], ref[l][0], "weight"), (got[l][1], ref[l][1], "bias")):
             err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
             assert err < 2e-5, (l, name, err)          # the same products; sums accumulate in another order (atomics)
+
+
+def test_flow_logq_bwd_any_row_order_and_saved_z(dev):
+    """tf_flow_logq_bwd's per-point sums are run-length sums over a tile's rows (round 5): rows of a point are contiguous in every
+    caller's order, but any order must give the same gradients -- a random permutation of the (rays_id, x, g) rows against the sorted
+    order -- and the forward's own z handed in (`z=`) must give what the kernel's re-evaluation gives."""
+    from tensoflow_amd import ops
+    from tensoflow_amd.shading import FlowParams
+    from tensoflow_amd.synth import random_mc_state
+    sd = random_mc_state(seed=4, R=32, flow_R=32, env_res=8)
+    fp = FlowParams(sd, "flow_diffuse_copy.", dev)
+    gen = torch.Generator().manual_seed(11)
+    pn, sn = 300, 37                                              # tiles straddle points; the last tile is ragged
+    cond = torch.rand(pn, 37, generator=gen).to(dev)
+    keep = torch.rand(pn, sn, generator=gen) < 0.6
+    rid = torch.arange(pn)[:, None].expand(pn, sn)[keep]
+    m = rid.numel()
+    x = torch.rand(m, 2, generator=gen).clamp(0.05, 0.95)
+    g = torch.randn(m, 1, generator=gen) / m
+    perm = torch.randperm(m, generator=gen)
+
+    def run(order, with_z):
+        xx, rr, gg = x[order].contiguous().to(dev), rid[order].contiguous().to(dev), g[order].contiguous().to(dev)
+        z = ops.flow_logq(fp.nets, cond, xx, rays_id=rr, precision=ops.PREC_F16X3)[0] if with_z else None
+        grads, g_cond, g_x = ops.flow_logq_bwd(fp.nets, cond, xx, gg, rays_id=rr, want_gx=True, z=z)
+        flat = [t.clone() for k in range(2) for pair in grads[k] for t in pair] + [g_cond.clone()]
+        return flat, g_x.clone()
+
+    ident = torch.arange(m)
+    ref, gx_ref = run(ident, False)
+    for order, with_z, what in ((perm, False, "permuted rows"), (ident, True, "forward's z handed in"), (perm, True, "both")):
+        got, gx = run(order, with_z)
+        for a, b in zip(got, ref):
+            scale = float(b.abs().max())
+            assert scale > 0 and float((a - b).abs().max()) < 2e-5 * scale, what
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(m)
+        assert float((gx[inv.to(dev)] - gx_ref).abs().max()) < 2e-5 * float(gx_ref.abs().max()), what
