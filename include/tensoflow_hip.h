@@ -308,6 +308,18 @@ int tf_sample_ray_upsample(const float* rays_o, const float* rays_d, const float
                            float base_radii, float* new_t, float* new_pts, float* new_level, tf_stream_t stream);
 int tf_sample_ray_merge(const float* z, const float* sdf, const float* new_t, const float* new_sdf, int64_t rn, int32_t n_cur,
                         int32_t n_imp, float* z_out, float* sdf_out, tf_stream_t stream);
+/* The element-wise algebra between the sampler and compute_sdf_alpha, one launch each (round 5: ~30 element-wise launches per shape
+ * training step).  tf_sample_ray_intervals: sample_ray's tail (shapeRenderer.py:921-932) on the merged grid t [rn, n_samples] --
+ * t0 = t, t1 = t + dist (dist to the next sample; the last one repeats its predecessor's), inner [rn n_samples] bytes = the interval's
+ * midpoint o + d (t + dist / 2) lies inside aabb_host[6]; the caller compacts the rows with inner != 0.
+ * tf_sample_points: render_core's prelude (:1118-1131) on the packed samples -- mid = (t0 + t1) / 2, dists = t1 - t0,
+ * viewdir [n,3] = dirs[ray_indices], points [n,3] = rays_o[ray_indices] + viewdir mid, level [n] = log2(ball radius / base_radii)
+ * (compute_ball_radii, :1038-1044). */
+int tf_sample_ray_intervals(const float* rays_o, const float* dirs, const float* t, int64_t rn, int32_t n_samples,
+                            const float* aabb_host, float* t0, float* t1, uint8_t* inner, tf_stream_t stream);
+int tf_sample_points(const float* rays_o, const float* dirs, const float* radiis, const float* rays_cos, const int64_t* ray_indices,
+                     const float* t0, const float* t1, int64_t n, float base_radii, float* mid, float* dists, float* viewdir,
+                     float* points, float* level, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Env-light prefilter: EnvLight.build_mips (network/light.py:52-64), rebuilt every shape-stage training step

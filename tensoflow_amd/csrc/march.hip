@@ -390,3 +390,82 @@ extern "C" int tf_sample_ray_merge(const float* z, const float* sdf, const float
   TF_LAUNCH_CHECK("tf_sample_ray_merge");
   return TF_OK;
 }
+
+// ---- the element-wise algebra between sample_ray and compute_sdf_alpha (round 5: ~30 launches per shape training step)
+// sample_ray's tail (shapeRenderer.py:921-932): per sample of the merged grid t [rn,S] the interval [t, t + dist] (dist to the next
+// sample, the last one repeats) and whether the interval's midpoint lies inside the aabb -> t0, t1 [rn*S], inner [rn*S] (bytes)
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) sample_ray_intervals_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ t,
+                                                                   long long rn, int S, MarchBox A, float* __restrict__ t0, float* __restrict__ t1,
+                                                                   unsigned char* __restrict__ inner) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= rn * S) return;
+  const long long r = e / S;
+  const int j = (int)(e - r * S);
+  const float tj = t[e];
+  const float dist = j + 1 < S ? t[e + 1] - tj : (S > 1 ? tj - t[e - 1] : 0.f);
+  const float mid = tj + dist * 0.5f;
+  bool in = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float p = o[3 * r + k] + d[3 * r + k] * mid;
+    in = in && !(A.lo[k] > p) && !(p > A.hi[k]);
+  }
+  t0[e] = tj;
+  t1[e] = tj + dist;
+  inner[e] = in ? 1 : 0;
+}
+
+// render_core's prelude (shapeRenderer.py:1118-1131): per packed sample i of ray ridx[i] with interval [t0, t1]:
+// mid = (t0 + t1) / 2, dists = t1 - t0, viewdir = dirs[ridx], points = o[ridx] + viewdir * mid,
+// level = log2(ball_radii(mid, radiis[ridx], cos[ridx]) / base_radii)   (compute_ball_radii, :1038-1044)
+__global__ void __launch_bounds__(256) sample_points_kernel(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ radiis,
+                                                            const float* __restrict__ rcos, const long long* __restrict__ ridx,
+                                                            const float* __restrict__ t0, const float* __restrict__ t1, long long n,
+                                                            float base_radii, float* __restrict__ mid, float* __restrict__ dists,
+                                                            float* __restrict__ viewdir, float* __restrict__ points, float* __restrict__ level) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long r = ridx[i];
+  const float a = t0[i], b = t1[i];
+  const float m = (a + b) * 0.5f;
+  mid[i] = m;
+  dists[i] = b - a;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float dk = d[3 * r + k];
+    viewdir[3 * i + k] = dk;
+    points[3 * i + k] = o[3 * r + k] + dk * m;
+  }
+  const float rad = radiis[r], c = rcos[r];
+  const float inv = 1.0f / c;
+  const float tmp = sqrtf(inv * inv - 1.f) - rad;
+  const float ball = m * rad * c / sqrtf(tmp * tmp + 1.0f);
+  level[i] = log2f(ball / base_radii);
+}
+#pragma clang fp contract(fast)
+
+extern "C" int tf_sample_ray_intervals(const float* rays_o, const float* dirs, const float* t, int64_t rn, int32_t n_samples,
+                                       const float* aabb_host, float* t0, float* t1, uint8_t* inner, tf_stream_t stream) {
+  TF_REQUIRE(rn >= 0 && n_samples >= 1, TF_ESHAPE, "tf_sample_ray_intervals: bad sizes");
+  if (rn == 0) return TF_OK;
+  TF_REQUIRE(rays_o && dirs && t && aabb_host && t0 && t1 && inner, TF_EINVAL, "tf_sample_ray_intervals: null pointer");
+  MarchBox A;
+  for (int k = 0; k < 3; ++k) { A.lo[k] = aabb_host[k]; A.hi[k] = aabb_host[3 + k]; }
+  sample_ray_intervals_kernel<<<tf_blocks(rn * (int64_t)n_samples, 256), 256, 0, (hipStream_t)stream>>>(rays_o, dirs, t, rn, n_samples, A, t0, t1, inner);
+  TF_LAUNCH_CHECK("tf_sample_ray_intervals");
+  return TF_OK;
+}
+
+extern "C" int tf_sample_points(const float* rays_o, const float* dirs, const float* radiis, const float* rays_cos, const int64_t* ray_indices,
+                                const float* t0, const float* t1, int64_t n, float base_radii, float* mid, float* dists, float* viewdir,
+                                float* points, float* level, tf_stream_t stream) {
+  TF_REQUIRE(n >= 0 && base_radii > 0.f, TF_ESHAPE, "tf_sample_points: n < 0 or base_radii <= 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(rays_o && dirs && radiis && rays_cos && ray_indices && t0 && t1 && mid && dists && viewdir && points && level, TF_EINVAL,
+             "tf_sample_points: null pointer");
+  sample_points_kernel<<<tf_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(rays_o, dirs, radiis, rays_cos, (const long long*)ray_indices, t0, t1, n,
+                                                                           base_radii, mid, dists, viewdir, points, level);
+  TF_LAUNCH_CHECK("tf_sample_points");
+  return TF_OK;
+}

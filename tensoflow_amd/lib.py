@@ -92,6 +92,8 @@ SIGNATURES = {
     "tf_sample_ray_init": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, P(f32 * 6), c_f, c_f, i64, i32, f32, c_f, c_f, c_f, c_f]),
     "tf_sample_ray_upsample": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, i64, i32, i32, f32, c_f, f32, c_f, c_f, c_f, c_f]),
     "tf_sample_ray_merge": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, c_f, c_f, c_f]),
+    "tf_sample_ray_intervals": (C.c_int, [c_f, c_f, c_f, i64, i32, P(f32 * 6), c_f, c_f, c_f, c_f]),
+    "tf_sample_points": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i64, f32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_alpha_mask_sample": (C.c_int, [c_f, i32, i32, i32, C.c_void_p, c_f, i64, c_f, c_f]),
     "tf_march_uniform": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, f32, C.c_void_p, c_f, i32, i32, i32, C.c_void_p, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_cubemap_mip_fwd": (C.c_int, [c_f, i32, c_f, c_f]),

@@ -110,17 +110,11 @@ def sample_ray(field: SdfField, o, d, near, far, radiis, rays_cos, base_radii, n
         nsdf = None if last else field.sdf(npts, nlv).reshape(rn, n_imp)
         t, sdf2 = ops.sample_ray_merge(t, sdf, new_t, nsdf)
         sdf = sdf2 if sdf2 is not None else sdf
-    aabb = field.aabb_dev
-    dists = t[:, 1:] - t[:, :-1]
-    dists = torch.cat([dists, dists[:, -1:]], -1)
-    mid = t + dists * 0.5
-    p = o[:, None] + d[:, None] * mid[..., None]
-    inner = ~((aabb[0] > p) | (p > aabb[1])).any(-1)
-    # ONE compaction (one host sync for the data-dependent size) instead of three boolean-mask indexings; row-major order = the
-    # reference's t[inner] order, ray index = flat index // samples per ray
-    keep = torch.nonzero(inner.reshape(-1))[:, 0]
-    t0 = t.reshape(-1).index_select(0, keep)
-    return t0, t0 + dists.reshape(-1).index_select(0, keep), torch.div(keep, t.shape[1], rounding_mode="floor")
+    # intervals and the inside-the-box test in one launch (round 5; was twelve), then ONE compaction (one host sync for the
+    # data-dependent size); row-major order = the reference's t[inner] order, ray index = flat index // samples per ray
+    t0_all, t1_all, inner = ops.sample_ray_intervals(o, d, t, field.aabb)
+    keep = torch.nonzero(inner)[:, 0]
+    return t0_all.index_select(0, keep), t1_all.index_select(0, keep), torch.div(keep, t.shape[1], rounding_mode="floor")
 
 
 @torch.no_grad()

@@ -305,6 +305,30 @@ def sample_ray_init(o, d, near, far, radiis, rays_cos, aabb, n_samples, base_rad
     return z, pts, lv
 
 
+def sample_ray_intervals(o, d, t, aabb):
+    """tf_sample_ray_intervals: t [rn,S] -> t0, t1 [rn*S], inner [rn*S] uint8 (the interval's midpoint lies inside the aabb)."""
+    o, d, t = _f(o), _f(d), _f(t)
+    rn, S = t.shape
+    t0 = torch.empty(rn * S, dtype=torch.float32, device=t.device)
+    t1 = torch.empty_like(t0)
+    inner = torch.empty(rn * S, dtype=torch.uint8, device=t.device)
+    L.check(L.load().tf_sample_ray_intervals(_p(o), _p(d), _p(t), rn, S, C.byref(_aabb6(aabb)), _p(t0), _p(t1), _p(inner, torch.uint8),
+                                             _stream()), "tf_sample_ray_intervals")
+    return t0, t1, inner
+
+
+def sample_points(o, d, radiis, rays_cos, ray_indices, t0, t1, base_radii):
+    """tf_sample_points -> mid [n], dists [n], viewdir [n,3], points [n,3], level [n,1] of the packed samples."""
+    o, d, t0, t1 = _f(o), _f(d), _f(t0), _f(t1)
+    n, dev = t0.shape[0], t0.device
+    mid, dists, level = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(3))
+    viewdir, points = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 3, dtype=torch.float32, device=dev)
+    L.check(L.load().tf_sample_points(_p(o), _p(d), _p(_f(radiis.reshape(-1))), _p(_f(rays_cos.reshape(-1))),
+                                      _p(ray_indices.contiguous(), torch.int64), _p(t0), _p(t1), n, float(base_radii), _p(mid), _p(dists),
+                                      _p(viewdir), _p(points), _p(level), _stream()), "tf_sample_points")
+    return mid, dists, viewdir, points, level.view(n, 1)
+
+
 def sample_ray_upsample(o, d, radiis, rays_cos, z, sdf, n_imp, inv_s, base_radii, want_pts=True):
     """tf_sample_ray_upsample -> new_t [rn,n_imp] (, pts [rn*n_imp,3], level [rn*n_imp])."""
     lib = L.load()

@@ -780,3 +780,34 @@ def test_march_uniform_matches_oracle(dev, mode):
     assert ridx.dtype == torch.int64 and torch.equal(ridx.cpu(), rr)
     assert torch.equal(t0.cpu(), rt0) and torch.equal(t1.cpu(), rt1)
     assert rr.numel() > 10000
+
+
+def test_sampling_algebra_kernels_equal_the_composition(dev):
+    """tf_sample_ray_intervals / tf_sample_points (round 5: sample_ray's tail and render_core's prelude, one launch each) against the
+    element-wise composition they replace (shapeRenderer.py:921-932, :1118-1131): intervals and the inside-the-box mask bit for bit,
+    points / levels to fp32 rounding."""
+    from tensoflow_amd import march, ops
+    gen = torch.Generator().manual_seed(31)
+    rn, S = 777, 41
+    o = (torch.randn(rn, 3, generator=gen) * 0.4).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(rn, 3, generator=gen), dim=-1).to(dev)
+    t = torch.sort(torch.rand(rn, S, generator=gen) * 3.0, dim=-1).values.to(dev)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    t0, t1, inner = ops.sample_ray_intervals(o, d, t, aabb)
+    dist = t[:, 1:] - t[:, :-1]
+    dist = torch.cat([dist, dist[:, -1:]], -1)
+    p = o[:, None] + d[:, None] * (t + dist * 0.5)[..., None]
+    ref_in = ~((aabb[0].to(dev) > p) | (p > aabb[1].to(dev))).any(-1)
+    assert torch.equal(t0, t.reshape(-1)) and torch.equal(t1, (t + dist).reshape(-1)) and torch.equal(inner.bool(), ref_in.reshape(-1))
+    assert 0.1 < float(inner.float().mean()) < 0.9
+    keep = torch.nonzero(inner)[:, 0]
+    ridx = torch.div(keep, S, rounding_mode="floor")
+    radii = (torch.rand(rn, 1, generator=gen) * 2e-3 + 1e-4).to(dev)
+    cos = (torch.rand(rn, 1, generator=gen) * 0.3 + 0.7).to(dev)
+    a, b = t0[keep], t1[keep]
+    mid, dists, vd, pts, lv = ops.sample_points(o, d, radii, cos, ridx, a, b, 2.0 / 300 / 2)
+    m_ref = (a + b) * 0.5
+    assert torch.equal(mid, m_ref) and torch.equal(dists, b - a) and torch.equal(vd, d[ridx])
+    assert torch.equal(pts, o[ridx] + d[ridx] * m_ref[:, None])
+    lv_ref = torch.log2(march.ball_radii(m_ref[:, None], radii[ridx], cos[ridx]) / (2.0 / 300 / 2))
+    assert float((lv - lv_ref).abs().max()) < 2e-6 * float(lv_ref.abs().max())
