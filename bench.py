@@ -462,7 +462,7 @@ def train_probe(device, verts, faces, aabb, unit, S, steps, pn=2048):
     from tensoflow_amd.network.fields import MCShadingNetwork
     from tensoflow_amd.synth import sphere_surface_points
     torch.manual_seed(6033)
-    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, unit)
+    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S, "outer_light_version": "envlight"}, (verts, faces), aabb, unit)
     for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
         for p in fl.parameters():
             p.requires_grad = False
@@ -723,7 +723,7 @@ def train_dp_leg(device, verts, faces, aabb, unit, world, rank, steps, pn, S=256
     from tensoflow_amd.synth import sphere_surface_points
     from tensoflow_amd.trainer import MaterialTrainer
     torch.manual_seed(6033)                                                  # identical replicas
-    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, unit)
+    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S, "outer_light_version": "envlight"}, (verts, faces), aabb, unit)
     tr = MaterialTrainer(m, {"total_step": 100000}, world=world)
     tr.step_count = 1200                                                     # past nis_start_iter: flow copies sample, NIS losses on
     m.use_flow_diffuse_copy = m.use_flow_specular_copy = True

@@ -9,6 +9,12 @@ struct Frame {
 
 __device__ __forceinline__ void normalize3(float* v) {  // F.normalize(dim=-1), eps 1e-12
   float inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+  // Round 5 traced a wrong tangent-frame choice (make_frame's l0 > l1) under a second stream's load to hipcc's packed form of the three
+  // multiplies below reading the reciprocal in the instruction right behind the v_div_fixup_f32 that writes it (view_angles.hip).  The
+  // root cause is unproven, so EVERY user of this function keeps an instruction of distance between the two: the reciprocal is made
+  // opaque behind two wait states -- whatever the translation unit's vectoriser flags are (shade.hip's direction kernels build the
+  // same frame and must agree with view_angles_kernel about it).
+  asm volatile("s_nop 1" : "+v"(inv));
   v[0] *= inv; v[1] *= inv; v[2] *= inv;
 }
 

@@ -126,14 +126,19 @@ class GradientExchange:
                                   # is a broken contract: the hook raises)
     A parameter that receives no gradient on THIS rank but does on another still takes part as zeros, as in allreduce_gradients."""
 
-    def __init__(self, params, world=None, bucket_bytes=64 << 20, mode="auto", stats=None):
+    def __init__(self, params, world=None, bucket_bytes=64 << 20, mode="auto", stats=None, force_collectives=False):
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.world = int(world)
         self.stats = stats
+        # force_collectives: queue the collectives at world == 1 as well (a one-rank process group must be initialised).  The product
+        # never asks for it -- one rank has nothing to exchange -- but it lets ONE GPU run the whole exchange (flat bucket views, hooks
+        # firing inside a real backward, reduce-scatter + all-gather on the backend's stream, finish) before an 8-GPU node ever does:
+        # tests/test_gpu_dist.py.  At one rank every collective is the identity, so the step must equal the un-exchanged one.
+        self.force = bool(force_collectives)
         self.params = [p for p in params if p.requires_grad]
         if mode == "auto":
-            mode = "rs_ag" if (self.world > 1 and dist.get_backend() == "nccl") else "allreduce"
+            mode = "rs_ag" if ((self.world > 1 or self.force) and dist.get_backend() == "nccl") else "allreduce"
         self.mode = mode
         self.buckets = []          # dicts: params, flat, views, shard, pending (hooks still to fire), work
         cur, size = [], 0
@@ -196,7 +201,7 @@ class GradientExchange:
         self._in_backward = True
 
     def _send(self, b):
-        if b["sent"] or self.world == 1:
+        if b["sent"] or (self.world == 1 and not self.force):
             b["sent"] = True
             return
         flat = b["flat"]

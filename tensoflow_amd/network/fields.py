@@ -199,15 +199,31 @@ class TensoSDF(nn.Module):
 class MCShadingNetwork(nn.Module):
     """Eval-mode material-stage shader with the reference's parameter names (fields.py:668-760).
     `ray_tracer` is the (vertices, triangles) pair the reference hands to raytracing.RayTracer (materialRenderer.py:147-149)."""
-    default_cfg = {"diffuse_sample_num": 512, "specular_sample_num": 256, "outer_light_version": "envlight", "light_exp_max": 5.0,
+    # the reference class's defaults (fields.py:617-667), 'outer_light_version': 'direction' included (every shipped yaml sets the key)
+    default_cfg = {"diffuse_sample_num": 512, "specular_sample_num": 256, "outer_light_version": "direction", "light_exp_max": 5.0,
                    "inner_light_exp_max": 5.0, "human_lights": False, "gridSize": [512, 512, 512], "nis_diffuse_sample_num": 64,
                    "nis_specular_sample_num": 32, "light_reso": 128, "mat_grid": 512, "reg_min_max": True,
                    "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000, "nis_update_interval_diffuse": 1000,
-                   "nis_update_interval_specular": 1000, "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500}
+                   "nis_update_interval_specular": 1000, "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500,
+                   "geometry_type": "schlick", "random_azimuth": True, "shade_fn": "shade_mixed", "use_nis_all": False,
+                   "use_nis_diffuse": True, "use_nis_specular": True, "flow": "pwquad", "flow_diffuse": "pwquad", "flow_specular": "pwquad",
+                   "use_half_all": True, "use_half_diffuse": True, "use_half_specular": True, "disable_tensorial": False,
+                   "disable_reflected": False}
+    # Switches of the reference's cfg whose OTHER value selects code this build does not hold (fields.py: shade_mixed_all / use_nis_all
+    # :1337-1451 with switches :752,1458-1461,1589; fixed samplers beside a flow :1082,1160; whole-direction instead of half-vector flows
+    # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547; the ablations flow.py:726-744).  No
+    # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
+    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True,
+                   "flow_diffuse": "pwquad", "flow_specular": "pwquad", "use_half_diffuse": True, "use_half_specular": True,
+                   "geometry_type": "schlick", "disable_tensorial": False, "disable_reflected": False}
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
+        for key, only in self._only_value.items():
+            if self.cfg[key] != only:
+                raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: this build holds {key}={only!r} only (the "
+                                          f"reference default; /root/reference/network/fields.py:617-667) and does not ignore the key")
         if self.cfg["outer_light_version"] not in ("envlight", "direction", "sphere_direction"):
             raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
         if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":
@@ -396,7 +412,8 @@ class MCShadingNetwork(nn.Module):
     def forward_train(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None):
         """Differentiable forward of shade_mixed with the flow samplers (fields.py:1075-1335): every per-sample stage runs in
         the HIP kernels through autograd Functions whose backward is HIP as well (VM gather, BRDF weights, cube map, flow
-        log-density) or a library GEMM (inner-light weight gradients); the per-point material MLPs are torch modules."""
+        log-density, the inner-light / outer-light nets: LightsFn) or the dense-layer kernels tf_linear_fwd / tf_linear_bwd (the
+        per-point material MLPs through autograd.mlp_apply) -- no library GEMM in a training step."""
         dev = pts.device
         pn = pts.shape[0]
         sd, ss = self.cfg["nis_diffuse_sample_num"], self.cfg["nis_specular_sample_num"]
@@ -412,7 +429,7 @@ class MCShadingNetwork(nn.Module):
             jit = (lambda n: torch.rand(pn, n, device=dev)) if (is_train and self.training) else (lambda n: None)
             ang_d, lq_d = self.flow_diffuse_copy._sample_nograd(pts, va, sd, jit(sd))
             ang_s, lq_s = self.flow_specular_copy._sample_nograd(pts, va, ss, jit(ss))
-            az_jit = torch.rand(pn, device=dev) if (is_train and self.training) else None
+            az_jit = torch.rand(pn, device=dev) if (is_train and self.training and self.cfg["random_azimuth"]) else None      # fields.py:837
         wgt, dirs, smask, live, logjac = ShadeWeightsFn.apply(metallic, roughness, albedo, normals.contiguous(), view_dirs.contiguous(),
                                                               ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit)
         T = dirs.shape[1]
@@ -710,8 +727,8 @@ class ShapeShadingNetwork(nn.Module):
     """Split-sum shading of the shape stage (reference: network/fields.py:319-575) with the reference's parameter names.
 
     Without autograd the whole forward is ONE launch of tf_shape_shade_fwd (three 128-wide MLPs, encodings, cube taps, FG
-    LUT, sRGB).  With autograd the same arithmetic is composed from device-resident torch ops (MLP products = library GEMMs)
-    and the HIP cube-map autograd ops of EnvLight, so that gradients reach the MLPs, the environment map and -- through the
+    LUT, sRGB).  With autograd the same arithmetic is composed from differentiable device ops: the MLP products on tf_linear_fwd /
+    tf_linear_bwd (autograd.mlp_apply: no library GEMM), the cube lookups on the HIP autograd ops of EnvLight, so that gradients reach the MLPs, the environment map and -- through the
     normals / reflective directions / roughness -- the SDF.  `rad_mlp` (has_radiance_field: 161-128-128-3 on [feat, xyz,
     embed4(view), normal], fields.py:407-417,476-483) is a torch module in both modes; human lights are not built."""
     default_cfg = {"human_light": False, "sphere_direction": False, "light_pos_freq": 8, "inner_init": -0.95, "light_exp_max": 0.0,

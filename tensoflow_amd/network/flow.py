@@ -38,8 +38,10 @@ class Block(nn.Module):
 
 def _check_no_grad(module, what):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise RuntimeError(f"{what}: the fused HIP forward has no backward yet (round 1) -- call it under torch.no_grad() "
-                           "or freeze the module (the reference's `*_copy` flows are frozen the same way, fields.py:1054-1065)")
+        raise RuntimeError(f"{what}: this method's fused HIP forward has no backward (the differentiable routes are autograd.SdfAlphaFn "
+                           "for the SDF field inside the renderers and TensoFlow.forward / autograd.FlowLogqFn for the flows' log-density) "
+                           "-- call it under torch.no_grad() or freeze the module (the reference samples from frozen `*_copy` flows only, "
+                           "fields.py:1054-1065)")
 
 
 class TensoFlow(nn.Module):

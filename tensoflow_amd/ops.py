@@ -841,7 +841,12 @@ def cubemap_texel_table(res, device):
     key = (int(res), str(device))
     if key not in _TEXEL_TABLES:
         tab = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("cubemap_texel_table: build the table (one call of EnvLight.build_mips) before capturing a graph")
         L.check(L.load().tf_cubemap_texel_table(int(res), _p(tab), _stream()), "tf_cubemap_texel_table")
+        # the table is cached and later handed to kernels on ANY stream (side streams, shade_many's call streams, the autograd backward
+        # stream): complete it here, once per (resolution, device), instead of ordering every consumer behind the builder's stream
+        torch.cuda.current_stream(tab.device).synchronize()
         _TEXEL_TABLES[key] = tab
     return _TEXEL_TABLES[key]
 

@@ -126,14 +126,15 @@ class MaterialTrainer:
     def _exchange(self):
         """world > 1: the hooked gradient exchange over every parameter the optimizer holds (dist.GradientExchange: persistent flat
         buckets, collectives launched during backward); rebuilt when the optimizer's parameter set changes."""
-        if self.world <= 1:
+        force = getattr(self, "force_exchange", False)        # tests: run the exchange at one rank (dist.GradientExchange force_collectives)
+        if self.world <= 1 and not force:
             return None
         ps = self.trainable()
         ex = getattr(self, "_ex", None)
         if ex is None or not ex.same_params(ps):
             if ex is not None:
                 ex.remove()
-            ex = self._ex = tdist.GradientExchange(ps, self.world)
+            ex = self._ex = tdist.GradientExchange(ps, self.world, force_collectives=force)
         return ex
 
     def refresh_flow_copies(self, step):

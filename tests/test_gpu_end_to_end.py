@@ -44,7 +44,7 @@ def test_shape_stage_to_material_stage(tmp_path):
     assert f.shape[0] > 500
     # ---- material stage on the files
     shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=64, nis_diffuse_sample_num=32,
-                      nis_specular_sample_num=32)
+                      nis_specular_sample_num=32, outer_light_version="envlight")
     mat = MaterialRenderer({"mesh": ply, "geo_model_path": ckpt, "shader_cfg": shader_cfg}, training=False, nvs=True)
     assert mat.gridSize.tolist() == st.net.gridSize.tolist()
     o2, d2, _, _ = [torch.from_numpy(a).to(dev) for a in pinhole_rays(2048, seed=3, h=64, w=64, focal=90.0)]

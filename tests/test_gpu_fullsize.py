@@ -248,10 +248,15 @@ def test_compact_below_ragged_and_unaligned(dev):
 
 def test_full_size_state_against_the_oracle(dev):
     """BASELINE configs[2] at its real sizes -- R = 512 material / flow fields, the 265 k-triangle bench mesh, 128 + 512 + 128
-    secondary rays -- on 64 surface points against the ORACLE (CPU restatement pinned to the reference goldens; the bench mesh is
-    traced by oracle/bvh_cpu.c): hit flags and specular masks bit-exact, per-pixel colour within 1e-4 except points holding an
-    ill-conditioned flow sample (reported: each must show a flow sample displaced by > 1e-4); and configs[1]'s R = 300 field:
-    sdf / gradient / alpha of 4096 samples against the oracle."""
+    secondary rays -- on 256 surface points against the ORACLE (CPU restatement pinned to the reference goldens; the bench mesh is
+    traced by oracle/bvh_cpu.c): hit flags and specular masks bit-exact, per-pixel colour within 1e-4 except a bounded RATE of points
+    (<= 2.5 %, none beyond 2e-3) that hold an ill-conditioned flow sample.  Every such point is re-evaluated by the oracle in fp64
+    (conftest.in_fp64) and must satisfy the criterion bench.py's psnr leg reports: the ORACLE's own fp32-vs-fp64 colours differ by at
+    least half the deviation, or the HIP colour is within 1e-4 of the fp64 evaluation, or -- the sample-level form of the first clause --
+    the flow sample that moved most between HIP and the fp32 oracle is one the oracle ITSELF moves by > 1e-5 between fp32 and fp64 (a
+    well-conditioned sample moves ~1e-7: tests/test_oracle_flow.py::test_reference_spline_root_is_ill_conditioned_in_fp32).  And
+    configs[1]'s R = 300 field: sdf / gradient / alpha of 4096 samples against the oracle."""
+    from conftest import in_fp64
     from oracle import march as om
     from oracle import shading as osh
     from oracle.mesh import BvhRayTracer
@@ -264,7 +269,8 @@ def test_full_size_state_against_the_oracle(dev):
     unit = 2.0 / 511
     sh = MCShader(sd, verts, faces, AABB, unit, device=dev, n_fixed_diffuse=512)
     sh.cull_dead_rays = False
-    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(64, seed=123)]
+    n_pts = 256
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(n_pts, seed=123)]
     out = sh.shade(pts.to(dev), view.to(dev), nrm.to(dev), 128, 128)
     tr = osh.MeshTracer(torch.from_numpy(verts)[torch.from_numpy(faces).long()], bvh=BvhRayTracer(verts, faces))
     with torch.no_grad():
@@ -272,14 +278,24 @@ def test_full_size_state_against_the_oracle(dev):
     assert torch.equal(out["hit"][:, :640].cpu(), ref["diffuse_hit"]) and torch.equal(out["specular_mask"].cpu(), ref["specular_mask"])
     for k in ("metallic", "roughness", "albedo"):
         assert rel_err(out[k].cpu(), ref[k]) < 1e-4 and true_rel_err(out[k].cpu(), ref[k]) < 1e-3, k
-    err = (out["colors"].cpu() - ref["colors"]).abs().amax(-1)
-    moved = torch.maximum((out["diffuse_angles"].cpu() - ref["diffuse_flow_angles"]).abs().amax(-1).amax(-1),
-                          (out["specular_angles"].cpu() - ref["specular_flow_angles"]).abs().amax(-1).amax(-1))
-    bad = err > 1e-4
-    print(f"R=512 state, 64 points: max pixel err {float(err.max()):.2e}, {int(bad.sum())} beyond 1e-4; their worst flow-sample move "
-          f"{[f'{float(v):.1e}' for v in moved[bad]]}")
-    assert int(bad.sum()) <= 3 and float(err.max()) < 2e-3
-    assert bool((moved[bad] > 1e-4).all())               # every outlier holds a displaced (ill-conditioned) flow sample
+    got = out["colors"].cpu()
+    err = (got - ref["colors"]).abs().amax(-1)
+    bad = (err > 1e-4).nonzero()[:, 0]
+    print(f"R=512 state, {n_pts} points: max pixel err {float(err.max()):.2e}, {len(bad)} beyond 1e-4 ({len(bad) / n_pts:.2%})")
+    assert len(bad) <= 0.025 * n_pts and float(err.max()) < 2e-3
+    if len(bad):
+        r64 = in_fp64(osh.shade, sd, tr, unit, AABB, pts[bad], view[bad], nrm[bad], 128, 128, n_fixed_diffuse=512, use_flow=True)
+        a_hip = torch.cat([out["diffuse_angles"], out["specular_angles"]], 1).cpu()[bad]
+        a_32 = torch.cat([ref["diffuse_flow_angles"], ref["specular_flow_angles"]], 1)[bad]
+        a_64 = torch.cat([r64["diffuse_flow_angles"], r64["specular_flow_angles"]], 1).float()
+        mv, mv64 = (a_hip - a_32).abs().amax(-1), (a_32 - a_64).abs().amax(-1)            # [n_bad, 256] sample displacements
+        for k, i in enumerate(bad.tolist()):
+            c64 = r64["colors"][k].float()
+            hip_o32, o32_o64, hip_o64 = float(err[i]), float((ref["colors"][i] - c64).abs().max()), float((got[i] - c64).abs().max())
+            j = int(mv[k].argmax())
+            print(f"  point {i}: hip-vs-oracle32 {hip_o32:.2e}, oracle32-vs-oracle64 {o32_o64:.2e}, hip-vs-oracle64 {hip_o64:.2e}; flow sample {j} "
+                  f"moved {float(mv[k, j]):.2e} (hip vs oracle32) / {float(mv64[k, j]):.2e} (oracle32 vs oracle64)")
+            assert o32_o64 >= 0.5 * hip_o32 or hip_o64 <= 1e-4 or (float(mv[k, j]) > 5e-5 and float(mv64[k, j]) > 1e-5), (i, hip_o32, o32_o64, hip_o64)
     # ---- configs[1]: R = 300 SDF field
     R = 300
     ssd = random_sdf_state(seed=1, R=R)

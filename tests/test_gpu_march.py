@@ -267,7 +267,7 @@ def test_module_mcshading(golden, dev):
     g = golden("shading_small")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-               nis_specular_sample_num=sn_s)
+               nis_specular_sample_num=sn_s, outer_light_version="envlight")
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     missing, unexpected = m.load_state_dict(g.sd, strict=False)
     assert not missing, missing                                  # every parameter of the mirror exists in the reference checkpoint
@@ -311,7 +311,7 @@ def test_mcshading_eval_follows_parameter_updates(golden, dev):
     g = golden("shading_small")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-               nis_specular_sample_num=sn_s)
+               nis_specular_sample_num=sn_s, outer_light_version="envlight")
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     m.load_state_dict(g.sd, strict=False)
     args = (g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev))
@@ -429,7 +429,7 @@ def test_mcshading_training_step_golden(golden, dev):
     g = golden("shading_grad")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-               nis_specular_sample_num=sn_s)
+               nis_specular_sample_num=sn_s, outer_light_version="envlight")
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     missing, _ = m.load_state_dict(g.sd, strict=False)
     assert not missing
@@ -475,7 +475,7 @@ def test_mcshading_training_step_before_flow_copies_golden(golden, dev, step):
     g, base = golden("shading_grad_fixed"), golden("shading_grad")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-               nis_specular_sample_num=sn_s)
+               nis_specular_sample_num=sn_s, outer_light_version="envlight")
     m = MCShadingNetwork(cfg, (base["verts"].numpy(), base["faces"].numpy()), AABB, float(g["unit_size"]))
     m.load_state_dict(base.sd, strict=False)
     for fl in (m.flow_diffuse_copy, m.flow_specular_copy):

@@ -319,7 +319,7 @@ def test_material_renderer(golden, dev, tmp_path):
     gs, gr = golden("shading_small"), golden("refine_r32")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in gs["sn"]]
     shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-                      nis_specular_sample_num=sn_s)
+                      nis_specular_sample_num=sn_s, outer_light_version="envlight")
     geo_ckpt = {"step": 0, "kwargs": {"aabb": AABB, "gridSize": [32, 32, 32], "max_levels": 3, "sdf_n_comp": 36, "sdf_dim": 256, "app_dim": 128},
                 "network_state_dict": {**gr.sd, "deviation_network.variance": torch.log(gr["inv_s"]) / 10.0}}
     m = MaterialRenderer({"mesh": (gr["verts"].numpy(), gr["faces"].numpy()), "shader_cfg": shader_cfg, "geo_model_path": geo_ckpt},
@@ -381,7 +381,7 @@ def test_material_renderer_nvs_frame_golden(golden, dev):
     g, gr, gs = golden("material_nvs_r32"), golden("refine_r32"), golden("shading_small")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in gs["sn"]]
     shader_cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-                      nis_specular_sample_num=sn_s)
+                      nis_specular_sample_num=sn_s, outer_light_version="envlight")
     geo_ckpt = {"step": 0, "kwargs": {"aabb": AABB, "gridSize": [32, 32, 32], "max_levels": 3, "sdf_n_comp": 36, "sdf_dim": 256, "app_dim": 128},
                 "network_state_dict": {**gr.sd, "deviation_network.variance": torch.log(gr["inv_s"]) / 10.0}}
     m = MaterialRenderer({"mesh": (g["verts"].numpy(), g["faces"].numpy()), "shader_cfg": shader_cfg, "geo_model_path": geo_ckpt, "nerfDataType": True},

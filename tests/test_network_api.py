@@ -1,5 +1,6 @@
 """The drop-in modules keep the reference's state_dict keys and shapes (checked against the goldens, which hold the
 reference modules' own state_dicts) -- CPU-only construction, no kernel is launched."""
+import pytest
 import torch
 
 from conftest import AABB
@@ -33,8 +34,46 @@ def test_fused_forward_refuses_autograd():
     import pytest
     from tensoflow_amd.network.flow import TensoFlow
     m = TensoFlow(2, AABB, device="cpu", gridSize=[8, 8, 8])
-    with pytest.raises(RuntimeError, match="no backward yet"):
+    with pytest.raises(RuntimeError, match="has no backward"):
         m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)   # sampling is a frozen-copy op
+
+
+REFUSED_CFG = [("shade_fn", "shade_mixed_all"), ("use_nis_all", True), ("use_nis_diffuse", False), ("use_nis_specular", False),
+               ("flow_diffuse", "pwlinear"), ("flow_specular", "affine"), ("use_half_diffuse", False), ("use_half_specular", False),
+               ("geometry_type", "ggx_smith"), ("disable_tensorial", True), ("disable_reflected", True), ("outer_light_version", "latlong")]
+
+
+@pytest.mark.parametrize("key,value", REFUSED_CFG)
+def test_mcshading_refuses_cfg_switches_it_does_not_build(key, value):
+    """Verdict r5 item 7: a cfg key whose non-default value selects reference code this build lacks (shade_mixed_all / use_nis_all
+    fields.py:1337-1451; one fixed and one flow sampler :1082,1160; whole-direction flows :1084-1208; ggx_smith :1029; the other
+    transforms flow.py:170-312; the ablations flow.py:726-744) raises at construction -- before any device work -- instead of
+    rendering the default path under a non-default cfg."""
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    with pytest.raises(NotImplementedError, match=key):
+        MCShadingNetwork({key: value}, (None, None), AABB, 2.0 / 511)
+
+
+def test_mcshading_default_cfg_is_the_reference_class_default():
+    """fields.py:617-667: the values of the reference's default_cfg for every key this build reads (a bare MCShadingNetwork({}) is the
+    reference's bare MCShadingNetwork({}): 'direction' outer light, 512 / 256 fixed directions, 64 / 32 flow samples)."""
+    from tensoflow_amd.network.fields import MCShadingNetwork
+    ref = {"diffuse_sample_num": 512, "specular_sample_num": 256, "human_lights": False, "light_exp_max": 5.0, "inner_light_exp_max": 5.0,
+           "outer_light_version": "direction", "geometry_type": "schlick", "reg_min_max": True, "random_azimuth": True,
+           "shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True, "gridSize": [512, 512, 512],
+           "nis_diffuse_sample_num": 64, "nis_specular_sample_num": 32, "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000,
+           "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500, "nis_update_interval_diffuse": 1000,
+           "nis_update_interval_specular": 1000, "flow": "pwquad", "flow_diffuse": "pwquad", "flow_specular": "pwquad", "use_half_all": True,
+           "use_half_diffuse": True, "use_half_specular": True, "light_reso": 128, "disable_tensorial": False, "disable_reflected": False}
+    for k, v in ref.items():
+        assert MCShadingNetwork.default_cfg[k] == v, k
+
+
+def test_tensoflow_refuses_other_transforms():
+    from tensoflow_amd.network.flow import TensoFlow
+    for kw in (dict(flow="pwlinear"), dict(flow="affine"), dict(n_bins=8), dict(d=3)):
+        with pytest.raises(NotImplementedError):
+            TensoFlow(**{"d": 2, "aabb": AABB, "device": "cpu", "gridSize": [8, 8, 8], **kw})
 
 
 def test_lazy_output_group_is_built_once_on_first_access():

@@ -40,7 +40,7 @@ def test_material_trainer_fits_and_checkpoints(tmp_path):
     verts, faces = sphere_torus_mesh(24, 48, 32, 16)
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=64, nis_diffuse_sample_num=32,
-               nis_specular_sample_num=32)
+               nis_specular_sample_num=32, outer_light_version="envlight")
     net = MCShadingNetwork(cfg, (verts, faces), aabb, 2.0 / 31)
     tr = MaterialTrainer(net, dict(total_step=200, nis_loss_iter=5, nis_start_iter_diffuse=10, nis_update_interval_diffuse=10,
                                    nis_start_iter_specular=10, nis_update_interval_specular=10))

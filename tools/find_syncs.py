@@ -28,7 +28,7 @@ def main():
         verts, faces = sphere_torus_mesh(224, 448, 256, 128)
         aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
         torch.manual_seed(6033)
-        m = MCShadingNetwork({"nis_diffuse_sample_num": 128, "nis_specular_sample_num": 128}, (verts, faces), aabb, 2.0 / 511)
+        m = MCShadingNetwork({"nis_diffuse_sample_num": 128, "nis_specular_sample_num": 128, "outer_light_version": "envlight"}, (verts, faces), aabb, 2.0 / 511)
         for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
             for p in fl.parameters():
                 p.requires_grad = False

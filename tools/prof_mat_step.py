@@ -17,7 +17,7 @@ def main():
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     S, pn = 128, 2048
     torch.manual_seed(6033)
-    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S}, (verts, faces), aabb, 2.0 / 511)
+    m = MCShadingNetwork({"nis_diffuse_sample_num": S, "nis_specular_sample_num": S, "outer_light_version": "envlight"}, (verts, faces), aabb, 2.0 / 511)
     for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
         for p in fl.parameters():
             p.requires_grad = False
