@@ -74,15 +74,16 @@ def compact_line(line):
     under COMPACT_LIMIT bytes.  Everything else (per-stage times, probes, the per-outlier re-evaluation) goes to the detail
     object (stderr + gpurun_out/bench_detail.json), never to this line: round 3's 21 KB line did not reach the driver's record."""
     out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                       "vs_baseline", "dtype", "data", "value_fp32_grade", "value_with_aux"))
+                       "vs_baseline", "dtype", "data", "value_fp32_grade", "value_f16x2", "value_with_aux"))
     cfg = line.get("config", {})
-    out["config"] = _pick(cfg, ("workload", "points_per_gpu_per_step", "points_per_shade_call", "mesh_triangles", "hit_fraction",
+    out["config"] = _pick(cfg, ("workload", "scene", "points_per_gpu_per_step", "points_per_shade_call", "mesh_triangles", "hit_fraction",
                                 "live_ray_fraction", "inner_light_operands", "aux_outputs", "parallelism"))
-    if isinstance(out["config"].get("workload"), str):
-        out["config"]["workload"] = out["config"]["workload"][:200]
+    for k in ("workload", "scene", "aux_outputs"):
+        if isinstance(out["config"].get(k), str):
+            out["config"][k] = out["config"][k][:200]
     if isinstance(line.get("roofline"), dict):
         out["roofline"] = _pick(line["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
-                                                   "executed_tflops", "frac_executed"))
+                                                   "executed_tflops", "frac_executed", "sustained_mfma_tflops", "frac_executed_of_sustained"))
     # the inner-light and traversal kernels take the same time within a few per cent from round 4 on: whichever is NOT the dominant
     # one of this run is carried beside it, so that the line always holds the matrix-core kernel's figures
     ro = line.get("roofline_other")
@@ -91,9 +92,10 @@ def compact_line(line):
                 for k in ("inner_light3_kernel", "bvh_trace_kernel") if isinstance(ro.get(k), dict)}
         if keep:
             out["roofline_other"] = keep
-    il3 = line.get("inner_light_f16x3")
-    if isinstance(il3, dict) and isinstance(il3.get("roofline"), dict):      # the fp32-grade form of the dominant kernel, beside the headline's
-        out["roofline_f16x3"] = _pick(il3["roofline"], ("achieved", "frac", "avg_launch_ms", "frac_executed"))
+    for other in ("inner_light_f16x2", "inner_light_f16x3"):      # the dominant kernel under the operand mode the headline does NOT run
+        il3 = line.get(other)
+        if isinstance(il3, dict) and isinstance(il3.get("roofline"), dict):
+            out["roofline_" + other[len("inner_light_"):]] = _pick(il3["roofline"], ("achieved", "frac", "avg_launch_ms", "frac_executed"))
     hfp = line.get("hit_fraction_probes")
     if isinstance(hfp, dict):
         out["hit_fraction_probes"] = {k: v for k, v in hfp.items() if k != "note"}
@@ -112,9 +114,9 @@ def compact_line(line):
             out["psnr"]["inner_light_modes"] = {k: v for k, v in out["psnr"]["inner_light_modes"].items() if k != "note"}
     sec = {}
     for key, fields in (("flow_only", ("points_per_s",)), ("train", ("ms_per_step",)), ("train_dp", ("ms_per_step", "ranks")),
-                        ("shape_train", ("ms_per_step",)), ("march", ("rays_per_s", "sdf_alpha_samples_per_s", "algorithmic_frac_of_hbm_peak")),
+                        ("shape_train", ("ms_per_step",)), ("march", ("rays_per_s", "sdf_alpha_samples_per_s", "algorithmic_frac_of_hbm_peak", "measured_fabric_frac_of_hbm_peak")),
                         ("config3_flow256", ("points_per_s",)), ("config4_frame512", ("ms_per_frame",)),
-                        ("eval_with_aux_maps", ("points_per_s",)), ("inner_light_f16x3", ("points_per_s",))):
+                        ("eval_with_aux_maps", ("points_per_s",)), ("inner_light_f16x3", ("points_per_s",)), ("inner_light_f16x2", ("points_per_s",))):
         v = line.get(key)
         if isinstance(v, dict):
             got = _pick(v, fields + ("error",))
@@ -173,18 +175,22 @@ def pmc_traffic(kernel):
         return None
 
 
-def build_scene(device, seed, mesh_res, torus_r=0.12):
+HEADLINE_TORUS = (0.65, 0.14)     # (major radius, tube radius) of the headline scene's torus: see main() / config.scene
+R5_TORUS = (0.75, 0.12)           # rounds 1-5: sphere points only, hit fraction 0.148 (kept as the `r5_scene` probe)
+
+
+def build_scene(device, seed, mesh_res, torus_r=0.12, torus_R=0.75):
     from tensoflow_amd.shading import MCShader
     from tensoflow_amd.synth import random_mc_state, sphere_torus_mesh
     sd = random_mc_state(seed=4, R=512, flow_R=512, env_res=128)
-    verts, faces = sphere_torus_mesh(*mesh_res, torus_r=torus_r)
+    verts, faces = sphere_torus_mesh(*mesh_res, torus_r=torus_r, torus_R=torus_R)
     aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
     unit = 2.0 / 511
     sh = MCShader(sd, verts, faces, aabb, unit, device=device, n_fixed_diffuse=512)
     return sh, sd, verts, faces, aabb, unit
 
 
-def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=None):
+def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=None, points_fn=None):
     """Oracle (CPU PyTorch restatement of the reference path, pinned to the reference's goldens) on a bounded sample of the SAME
     workload: the bench scene itself (all of its triangles, through the oracle's CPU BVH, oracle/bvh_cpu.c), the bench's
     network state, 128 + 512 + 128 secondary rays per point.  With `sh` (the bench's MCShader) the same points are shaded by
@@ -200,7 +206,7 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
     os.environ.setdefault("OMP_NUM_THREADS", str(n_thr))
     tri = torch.from_numpy(verts)[torch.from_numpy(faces).long()]
     tr = osh.MeshTracer(tri, bvh=BvhRayTracer(verts, faces))
-    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(n_points, seed=77)]
+    pts, nrm, view = [torch.from_numpy(a) for a in (points_fn(n_points, 77) if points_fn else sphere_surface_points(n_points, seed=77))]
     t0 = time.time()
     done = 0
     chunk = 128            # the reference shades 2048 points per step; per-call mip builds amortise over the chunk
@@ -266,7 +272,12 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
             a_64 = torch.cat([r64["diffuse_flow_angles"], r64["specular_flow_angles"]], 1).float()
             mv = (a_hip - a_32).abs().amax(-1)                          # [n_out, 2 sn]
             mv64 = (a_32 - a_64).abs().amax(-1)
-            hits_equal = bool(torch.equal(hp["hit"][:, :sn + 512].cpu(), r32["diffuse_hit"]))
+            # hit flags: bit-exact wherever HIP and the oracle traced the SAME direction -- the 512 fixed directions always, a flow sample
+            # where it did not move; a displaced sample (these points hold one) is a different ray and may meet different geometry
+            hd, rd = hp["hit"][:, :sn + 512].cpu(), r32["diffuse_hit"]
+            same_dir = torch.cat([mv[:, :sn] <= 1e-6, torch.ones(len(out_idx), 512, dtype=torch.bool)], 1)
+            hits_equal = bool((hd == rd)[same_dir].all())
+            hit_flips = int((hd != rd).sum())
             mat_err = max(float((hp[k].cpu() - r32[k]).abs().max()) for k in ("metallic", "roughness", "albedo"))
             for k, i in enumerate(out_idx.tolist()):
                 j = int(mv[k].argmax())
@@ -284,7 +295,7 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
                 o["sample_move_hip_vs_oracle32"] > 5e-5 or o["oracle32_vs_oracle64"] >= 0.5 * o["hip_vs_oracle32"]
                 or o["hip_vs_oracle64"] <= 1e-4 for o in outliers)
         else:
-            explained, hits_equal, mat_err = True, True, 0.0
+            explained, hits_equal, mat_err, hit_flips = True, True, 0.0, 0
         psnr = dict(value_db=20 * math.log10(1.0 / math.sqrt(max(mse, 1e-30))), max_rel_err=float(err.max()),
                     max_true_rel_err=float(true_rel.max()), tolerance=1e-4,
                     points=done, frac_points_within_tolerance=float((err <= 1e-4).float().mean()),
@@ -292,7 +303,8 @@ def cpu_baseline(sd, verts, faces, aabb, unit, n_points, sn, budget_s=25.0, sh=N
                     against="oracle/shading.py (CPU restatement pinned to the reference goldens) on the same points, same scene",
                     outliers=outliers, outliers_explained=explained,
                     outliers_where_hip_is_closer_to_oracle64_than_oracle32_is=sum(o["hip_vs_oracle64"] < o["oracle32_vs_oracle64"] for o in outliers),
-                    outlier_points_hit_flags_equal=hits_equal, outlier_points_material_max_err=mat_err,
+                    outlier_points_hit_flags_equal=hits_equal, outlier_points_hit_flips_on_displaced_samples=hit_flips,
+                    outlier_points_material_max_err=mat_err,
                     note="sRGB colours in [0,1]; max_rel_err = max |a-b| / max(|b|, 1), max_true_rel_err = max |a-b| / max(|b|, "
                          "1e-3 max|b|).  `outliers` (first 32): every point beyond the tolerance re-evaluated by HIP, the fp32 oracle and "
                          "the fp64 oracle; `outliers_explained` = at each of them the hit flags and materials agree and one of its flow "
@@ -840,11 +852,17 @@ def main():
     ap.add_argument("--mesh", type=str, default="224,448,256,128", help="n_lat,n_lon,n_major,n_minor (default ~266k triangles)")
     ap.add_argument("--precision", choices=["f16x3", "f32"], default="f16x3",
                     help="matrix-core arithmetic of the 256-wide decoder: f16x3 split (fp32-accurate) or exact fp32 MFMA")
-    ap.add_argument("--inner-precision", choices=["f16x2", "f16x3"], default="f16x2",
-                    help="operands of the inner-light decoder in the TIMED pass (the library default, MCShader.inner_precision, is f16x3: "
-                         "fp32-grade).  f16x2 = weights split hi + lo, activations rounded to f16 once per layer: meets the 1e-4 per-pixel "
-                         "tolerance on every reference golden, narrower than the reference's fp32 per ray -- the line's `dtype` says so and "
-                         "`value_fp32_grade` carries the same pass with f16x3 beside it")
+    ap.add_argument("--inner-precision", choices=["f16x2", "f16x3"], default="f16x3",
+                    help="operands of the inner-light decoder in the TIMED pass.  Default f16x3 = the library default "
+                         "(MCShader.inner_precision): every operand split hi + lo, fp32-grade.  f16x2 (weights split, activations rounded to "
+                         "f16 once per layer: narrower than the reference's fp32 per ray) is an opt-in; the default run reports it as the "
+                         "probe `value_f16x2`, never as `value`")
+    ap.add_argument("--torus", type=str, default=f"{HEADLINE_TORUS[0]},{HEADLINE_TORUS[1]}",
+                    help="major,tube radius of the scene's torus (the sphere has r = 0.5).  SURVEY.md 8(d) config 3 asks for points over "
+                         "sphere AND torus with ~0.20 of the secondary rays hitting: 0.65,0.14 is the geometry of this family whose MEASURED "
+                         "hit fraction comes closest (tools/calib_hit_fraction.py); rounds 1-5 used 0.75,0.12 with points on the sphere only "
+                         "(0.148): kept as the `r5_scene` probe")
+    ap.add_argument("--points-on", choices=["scene", "sphere"], default="scene", help="surface points area-uniform over sphere and torus, or on the sphere only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-march", action="store_true")
     ap.add_argument("--no-train", action="store_true")
@@ -879,16 +897,20 @@ def main():
             dist.init_process_group(backend)
 
     from tensoflow_amd.shading import StageTimer
-    from tensoflow_amd.synth import sphere_surface_points
+    from tensoflow_amd.synth import scene_surface_points, sphere_surface_points
     mesh_res = tuple(int(v) for v in args.mesh.split(","))
-    sh, sd, verts, faces, aabb, unit = build_scene(device, 4, mesh_res)
+    torus_R, torus_r = (float(v) for v in args.torus.split(","))
+    sh, sd, verts, faces, aabb, unit = build_scene(device, 4, mesh_res, torus_r=torus_r, torus_R=torus_R)
+
+    def points_fn(n, seed):
+        return scene_surface_points(n, seed=seed, torus_r=torus_r, torus_R=torus_R) if args.points_on == "scene" else sphere_surface_points(n, seed=seed)
     from tensoflow_amd import ops as _ops
     sh.precision = _ops.PREC_F16X3 if args.precision == "f16x3" else _ops.PREC_F32
     sh.inner_precision = _ops.PREC_F16X2 if (args.inner_precision == "f16x2" and args.precision == "f16x3") else _ops.PREC_F16X3      # explicit opt-in
     S = args.flow_samples
     pn = args.points
     # every rank shades its own shard of the point stream (weak scaling), inputs resident in HBM
-    pts, nrm, view = [torch.from_numpy(a).to(device) for a in sphere_surface_points(pn, seed=6 + 1000 * rank)]
+    pts, nrm, view = [torch.from_numpy(a).to(device) for a in points_fn(pn, 6 + 1000 * rank)]
 
     if os.environ.get("TF_BENCH_PRESORT"):          # dev experiment: spatially coherent point order
         q = ((pts * 0.5 + 0.5).clamp(0, 1) * 1023).long()
@@ -991,6 +1013,12 @@ def main():
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
         traced_per_step = int(live_rays.item())
         live_frac = traced_per_step / max(1, pn * (2 * S + 512))
+        sustained = None
+        if args.precision == "f16x3":
+            try:
+                sustained = _ops.probe_mfma_f16_tflops(200000, device)
+            except Exception as e:
+                print(f"tf_probe_mfma_f16 failed: {e}", file=sys.stderr)
         if dom == "inner_light":
             n_launch = summ[dom][1]
             ach = hits * FLOP_PER_HIT_RAY / (summ[dom][0] * 1e-3) / 1e12
@@ -1001,6 +1029,10 @@ def main():
             roof = dict(kernel="inner_light3_kernel" if (args.precision == "f16x3" and sh.inner_precision in (_ops.PREC_F16X3, _ops.PREC_F16X2)) else "inner_light_kernel", bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s",
                         frac=ach / peak, traffic=pmc_traffic("inner_light3_kernel") or pmc_traffic("inner_light2_kernel") or pmc_traffic("inner_light_kernel"), avg_launch_ms=summ[dom][0] / n_launch,
                         executed_tflops=executed, frac_executed=executed / peak,
+                        # what the matrix cores of THIS box hold on the same instruction under a dense stream of random operands
+                        # (tf_probe_mfma_f16, measured in this run, after the timed region): the part lowers its clock under that load, so
+                        # the spec peak is not a rate any kernel reaches; `frac_executed_of_sustained` is the kernel against that ceiling
+                        sustained_mfma_tflops=sustained, frac_executed_of_sustained=(executed / sustained) if sustained else None,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
                                    f"({'f16 MFMA operands, fp32 accumulate, ' + str(terms) + ' MFMA per product term; peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
         elif dom == "flow_sample":
@@ -1037,8 +1069,12 @@ def main():
                        "aux_outputs": "not in the timed region: a step returns `colors` (and the per-ray arrays); the rest of shade_mixed's dict "
                                       "(light / colour maps, visibility, variances: fields.py:1232-1256) needs EVERY ray traced -- the zero-weight "
                                       "culling off -- and tf_shade_reduce_aux: measured as `eval_with_aux_maps`",
-                       "deviations_from_SURVEY_8d_config3": "surface points on the sphere only: hit fraction 0.148 where the survey sketched ~0.20; the "
-                                                             "`scene_points` probe shades points over sphere AND torus (measured hit fraction there)"},
+                       "scene": f"sphere r = 0.5 inside a torus R = {torus_R}, r = {torus_r} ({len(faces)} triangles); surface points "
+                                + ("area-uniform over sphere AND torus" if args.points_on == "scene" else "on the sphere only")
+                                + " (SURVEY.md 8(d) config 3; the hit fraction is MEASURED: `hit_fraction`)",
+                       "deviations_from_SURVEY_8d_config3": "hit fraction: the survey sketches ~0.20; within aabb = +-1 a sphere-and-torus scene with "
+                                                             "area-uniform points tops out at 0.19 (tools/calib_hit_fraction.py: torus points see "
+                                                             "little geometry); the headline geometry is the one that comes closest"},
             "roofline": roof,
             "roofline_other": dict(other_rooflines(summ, timer, hits, args, sh, dom),
                                    **({"bvh_trace_kernel": bvh_roofline(summ, "bvh_trace", traced_per_step * args.steps, pn * (2 * S + 512) * args.steps)}
@@ -1090,25 +1126,31 @@ def main():
             except Exception as e:
                 line["config4_fp16"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":
-            # the headline pass with EVERY operand of the inner-light decoder split hi + lo (three MFMAs per product term: rounds 1-3's
-            # arithmetic of that net; round 4's default rounds its activations to f16 once per layer -- MCShader.inner_precision)
+            # the same pass under the OTHER operand mode of the inner-light decoder: the headline runs the library default f16x3 (every
+            # operand split, three MFMAs per product term: fp32-grade), the probe `inner_light_f16x2` the opt-in mode (weights split, activations
+            # rounded to f16 once per layer: two MFMAs per term, 128-ray passes -- narrower than the reference's fp32 per ray, reported,
+            # never `value`); with --inner-precision f16x2 the roles swap
+            other, other_name, other_terms = ((_ops.PREC_F16X2, "inner_light_f16x2", 2) if sh.inner_precision == _ops.PREC_F16X3
+                                              else (_ops.PREC_F16X3, "inner_light_f16x3", 3))
             try:
                 keep_ip = sh.inner_precision
-                sh.inner_precision = _ops.PREC_F16X3
+                sh.inner_precision = other
                 t3 = StageTimer()
-                line["inner_light_f16x3"] = flow_count_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps), timer=t3)
-                line["inner_light_f16x3"]["workload"] += ", inner-light decoder with activations AND weights split hi + lo (3 MFMAs per product term)"
+                line[other_name] = flow_count_probe(sh, pts_p, view_p, nrm_p, S, max(2, args.steps), timer=t3)
+                line[other_name]["workload"] += (", inner-light decoder with weights split hi + lo and activations rounded to f16 once per layer (2 MFMAs per product term)"
+                                                 if other_terms == 2 else ", inner-light decoder with activations AND weights split hi + lo (3 MFMAs per product term)")
                 s3 = t3.summary().get("inner_light")
                 if s3 and hits:
                     hits_call = hits / max(1, args.steps) * chunk / pn          # hit rays of one call (the probe shades the step's first chunk)
                     ms3 = s3[0] / max(1, s3[1])
                     ach3 = hits_call * FLOP_PER_HIT_RAY / (ms3 * 1e-3) / 1e12
-                    ex3 = hits_call / 32.0 * 336 * 3 * 2 * 32 * 32 * 16 / (ms3 * 1e-3) / 1e12
-                    line["inner_light_f16x3"]["roofline"] = dict(kernel="inner_light3_kernel<.,3> (64-ray form)", bound="mfma", achieved=ach3, peak=PEAK_F16_MFMA_TFLOPS,
-                                                                 unit="TFLOP/s", frac=ach3 / PEAK_F16_MFMA_TFLOPS, avg_launch_ms=ms3, executed_tflops=ex3,
-                                                                 frac_executed=ex3 / PEAK_F16_MFMA_TFLOPS)
+                    ex3 = hits_call / 32.0 * 336 * other_terms * 2 * 32 * 32 * 16 / (ms3 * 1e-3) / 1e12
+                    line[other_name]["roofline"] = dict(kernel=f"inner_light3_kernel<., {other_terms}>", bound="mfma", achieved=ach3, peak=PEAK_F16_MFMA_TFLOPS,
+                                                        unit="TFLOP/s", frac=ach3 / PEAK_F16_MFMA_TFLOPS, avg_launch_ms=ms3, executed_tflops=ex3,
+                                                        frac_executed=ex3 / PEAK_F16_MFMA_TFLOPS,
+                                                        frac_executed_of_sustained=(ex3 / sustained) if sustained else None)
             except Exception as e:
-                line["inner_light_f16x3"] = {"error": f"{type(e).__name__}: {e}"}
+                line[other_name] = {"error": f"{type(e).__name__}: {e}"}
             finally:
                 sh.inner_precision = keep_ip
         if world == 1 and not args.no_train and args.precision == "f16x3":
@@ -1124,33 +1166,23 @@ def main():
                 line["inner_light_f16_operands"] = {"error": f"{type(e).__name__}: {e}"}
             finally:
                 sh.inner_precision = keep_ip
-        if world == 1 and not args.no_train:
-            # SURVEY.md 8(d) config 3 sketches points over sphere AND torus with ~20 % of the secondary rays hitting: measured, not extrapolated
-            try:
-                from tensoflow_amd.synth import scene_surface_points
-                p2, n2, v2 = [torch.from_numpy(a).to(device) for a in scene_surface_points(chunk, seed=16)]
-                sh.hit_total = None
-                line["scene_points"] = flow_count_probe(sh, p2, v2, n2, S, max(2, args.steps))
-                n_calls = 2 + max(2, args.steps)
-                line["scene_points"]["hit_fraction"] = int(sh.hit_total.item()) / (n_calls * chunk * (2 * S + 512))
-                line["scene_points"]["workload"] += ", surface points area-uniform over sphere and torus"
-            except Exception as e:
-                line["scene_points"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_train:
-            # ... and a scene whose secondary rays hit about as often as SURVEY.md 8(d) sketched (~0.20): the same sphere inside a FAT torus
-            # (tube radius 0.2 instead of 0.12), same triangle count, same network state -- measured, not extrapolated
+        if world == 1 and not args.no_train and (torus_R, torus_r) != R5_TORUS:
+            # rounds 1-5's headline scene (thin torus R = 0.75, r = 0.12, points on the sphere only: hit fraction 0.148), same triangle
+            # counts, same network state: the continuity probe
             try:
                 from tensoflow_amd.shading import MCShader as _MC2
                 from tensoflow_amd.synth import sphere_torus_mesh as _stm
-                v2, f2 = _stm(*mesh_res, torus_r=0.2)
+                v2, f2 = _stm(*mesh_res, torus_r=R5_TORUS[1], torus_R=R5_TORUS[0])
                 sh2 = _MC2(sd, v2, f2, aabb, unit, device=device, n_fixed_diffuse=512)
+                sh2.inner_precision, sh2.precision = sh.inner_precision, sh.precision
+                p2, n2, v2_ = [torch.from_numpy(a).to(device) for a in sphere_surface_points(chunk, seed=6)]
                 sh2.hit_total = None
-                line["fat_torus_scene"] = flow_count_probe(sh2, pts_p, view_p, nrm_p, S, max(2, args.steps))
-                line["fat_torus_scene"]["hit_fraction"] = int(sh2.hit_total.item()) / ((2 + max(2, args.steps)) * chunk * (2 * S + 512))
-                line["fat_torus_scene"]["workload"] += ", sphere r = 0.5 inside a torus R = 0.75, r = 0.2 (headline scene: r = 0.12)"
+                line["r5_scene"] = flow_count_probe(sh2, p2, v2_, n2, S, max(2, args.steps))
+                line["r5_scene"]["hit_fraction"] = int(sh2.hit_total.item()) / ((2 + max(2, args.steps)) * chunk * (2 * S + 512))
+                line["r5_scene"]["workload"] += f", sphere r = 0.5 inside a torus R = {R5_TORUS[0]}, r = {R5_TORUS[1]}, points on the sphere only (the headline scene of rounds 1-5)"
                 del sh2
             except Exception as e:
-                line["fat_torus_scene"] = {"error": f"{type(e).__name__}: {e}"}
+                line["r5_scene"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_train and args.precision == "f16x3":
             # outer_light_version='direction' (configs/mat/syn/{lego,armadillo,horse}.yaml; no BASELINE config uses it): the rays that
             # MISS -- 85 % of them -- are answered by a 72-256-256-256-3 net on the IDE of the direction instead of the cube map
@@ -1201,19 +1233,23 @@ def main():
             except Exception as e:
                 line["march"]["f16_field"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["psnr"] = cpu_baseline(sd, verts, faces, aabb, unit, 16384, S, sh=sh)
+            line["cpu_baseline"], line["psnr"] = cpu_baseline(sd, verts, faces, aabb, unit, 16384, S, sh=sh, points_fn=points_fn)
             if "march" in line:
                 line["march"]["cpu_baseline"] = march_cpu_baseline()
-        # what the headline is worth under the stricter readings, next to it (verdict r4, item 2): the same pass with every operand of
-        # the inner-light net split (fp32-grade arithmetic in every decoder), and the pass that also returns the reference's 15 maps
+        # the headline next to its other readings: `value_fp32_grade` = every decoder on fp32-grade operands (= `value` by default),
+        # `value_f16x2` = the opt-in narrower inner-light operands, `value_with_aux` = the pass that also returns the reference's 15 maps
         if sh.inner_precision == _ops.PREC_F16X3 or args.precision == "f32":
             line["value_fp32_grade"] = value
-        elif isinstance(line.get("inner_light_f16x3"), dict) and "points_per_s" in line["inner_light_f16x3"]:
-            line["value_fp32_grade"] = line["inner_light_f16x3"]["points_per_s"] * world
+            if isinstance(line.get("inner_light_f16x2"), dict) and "points_per_s" in line["inner_light_f16x2"]:
+                line["value_f16x2"] = line["inner_light_f16x2"]["points_per_s"] * world
+        else:
+            line["value_f16x2"] = value
+            if isinstance(line.get("inner_light_f16x3"), dict) and "points_per_s" in line["inner_light_f16x3"]:
+                line["value_fp32_grade"] = line["inner_light_f16x3"]["points_per_s"] * world
         if isinstance(line.get("eval_with_aux_maps"), dict) and "points_per_s" in line["eval_with_aux_maps"]:
             line["value_with_aux"] = line["eval_with_aux_maps"]["points_per_s"] * world
         hf = {"headline": [hit_frac, value]}
-        for k in ("scene_points", "fat_torus_scene"):
+        for k in ("r5_scene",):
             if isinstance(line.get(k), dict) and "hit_fraction" in line[k]:
                 hf[k] = [line[k]["hit_fraction"], line[k]["points_per_s"]]
         line["hit_fraction_probes"] = dict(hf, note="[hit fraction of the secondary rays, points/s]")

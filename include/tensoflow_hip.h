@@ -71,6 +71,14 @@ const char* tf_last_error(void);
  * Results do not depend on the budget (bit-identical). */
 int tf_set_launch_budget(int32_t bvh_blocks_per_cu, int32_t flow_waves_per_block, int32_t inner_teams);
 
+/* Measurement aid (no reference counterpart: the reference never prices its kernels; SURVEY.md 8(d) asks for achieved / peak of the
+ * dominant kernel).  Runs a dense v_mfma_f32_32x32x16_f16 stream shaped like the inner-light decoder's k-step (64 units x 64 rays,
+ * three product terms, operands re-read from LDS, pseudo-random f16 data, one wave per SIMD on every CU) for `iters` iterations per
+ * wave, SYNCHRONOUSLY (it times itself with HIP events on `stream`), and returns the executed TFLOP/s in *tflops_host: the rate the
+ * matrix cores of THIS device hold under that load (the part lowers its clock: ~1.5-1.6 PFLOP/s against the 2.5 PFLOP/s quoted).
+ * scratch: device buffer of >= 256 floats per CU (written). */
+int tf_probe_mfma_f16(int32_t iters, float* scratch, int64_t scratch_floats, double* tflops_host, tf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * VM-decomposed tensorial field (3 planes + 3 lines, C components each).
  * Replaces the 6 x dr.texture(...) + permute/contiguous + per-call mip rebuild of

@@ -414,6 +414,12 @@ struct TraceArgs {
 
 #define BVH_NONE (-1)
 
+#ifdef BVH_DEV_TMAX   // dev-only (tools/exp_bvh_tmax.py): a per-ray upper bound of the hit distance handed in from outside -- what a conservative
+// occupancy pre-test would know before the first node fetch.  Results must not change; the time shows what such a test can be worth.
+__device__ const float* g_bvh_tmax;
+extern "C" void tf_bvh_dev_tmax(const float* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_tmax), &p, sizeof(p)); }
+#endif
+
 #ifdef BVH_CLOCK   // dev-only: where a wave's life goes.  [0] refill (ray fetch, spine, stores) [1] inner steps [2] leaf steps [3] wave lifetime,
 // all in s_memrealtime ticks (100 MHz) summed over waves; [4] waves; [5] earliest wave end, [6] latest wave end, [7] earliest wave start
 // [8] of the refill: result stores of finished rays (+ normal rows) [9] unit claim + spine build [10] ray fetch + spine walk
@@ -524,6 +530,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
     Ax = A.scl[0] * ix; Ay = A.scl[1] * iy; Az = A.scl[2] * iz;
     Bx = (A.org[0] - ox) * ix; By = (A.org[1] - oy) * iy; Bz = (A.org[2] - oz) * iz;
     best = BVH_MAX_DIST; best_tri = -1; sp = 0;
+#ifdef BVH_DEV_TMAX
+    if (g_bvh_tmax) best = g_bvh_tmax[id];
+#endif
     cur = 0;
     if (A.live && !A.live[id]) cur = BVH_NONE;   // zero weight in the integral: reported as a miss, never traversed
 #ifdef BVH_ABLATE_TRAVERSE   // dev-only timing ablation: ray fetch + scheduling + result stores only
@@ -578,6 +587,9 @@ __global__ void __launch_bounds__(256, BVH_WAVES) bvh_trace_kernel(TraceArgs A) 
 #ifdef BVH_STATS
     st_max = max(st_max, st_ray); st_ray = 0;
 #endif
+    // a ray hit iff a triangle was accepted: `best` may start below BVH_MAX_DIST (an upper bound of the hit distance known before the
+    // traversal), so the distance alone no longer tells
+    if (best_tri < 0) best = BVH_MAX_DIST;
 #ifdef BVH_ABLATE_STORE   // dev-only timing ablation: results are not written
     if (best == -123.f) A.depth[rid] = best;
     rid = -1;

@@ -56,10 +56,11 @@ def torus(R=0.75, r=0.12, n_major=48, n_minor=16, center=(0.0, 0.0, 0.0)):
     return v, np.asarray(faces, np.int32)
 
 
-def sphere_torus_mesh(n_lat=16, n_lon=32, n_major=48, n_minor=16, torus_r=0.12):
-    """-> vertices [V,3] f32, triangles [T,3] i32 (outward-facing winding)."""
+def sphere_torus_mesh(n_lat=16, n_lon=32, n_major=48, n_minor=16, torus_r=0.12, torus_R=0.75):
+    """Sphere r = 0.5 inside a torus of major radius `torus_R`, tube radius `torus_r` -> vertices [V,3] f32, triangles [T,3] i32
+    (outward-facing winding)."""
     v0, f0 = uv_sphere(0.5, n_lat, n_lon)
-    v1, f1 = torus(0.75, torus_r, n_major, n_minor)
+    v1, f1 = torus(torus_R, torus_r, n_major, n_minor)
     return np.concatenate([v0, v1], 0), np.concatenate([f0, f1 + len(v0)], 0)
 
 
@@ -100,11 +101,12 @@ def torus_surface_points(n, seed=6, R=0.75, r=0.12, cam_dist=2.0, n_cams=8):
     return pts.astype(np.float32), nrm.astype(np.float32), view.astype(np.float32)
 
 
-def scene_surface_points(n, seed=6):
-    """Points over the WHOLE bench scene (sphere and torus, split by surface area: 47 % / 53 %), shuffled."""
-    a_s, a_t = 4 * math.pi * 0.25, 4 * math.pi ** 2 * 0.75 * 0.12
+def scene_surface_points(n, seed=6, torus_r=0.12, torus_R=0.75):
+    """Points over the WHOLE scene of sphere_torus_mesh (sphere and torus, split by surface area: 47 % / 53 % at R = 0.75, r = 0.12),
+    shuffled."""
+    a_s, a_t = 4 * math.pi * 0.25, 4 * math.pi ** 2 * torus_R * torus_r
     n_s = int(round(n * a_s / (a_s + a_t)))
-    parts = [sphere_surface_points(n_s, seed=seed), torus_surface_points(n - n_s, seed=seed + 1)]
+    parts = [sphere_surface_points(n_s, seed=seed), torus_surface_points(n - n_s, seed=seed + 1, R=torus_R, r=torus_r)]
     perm = np.random.default_rng(seed + 2).permutation(n)
     return tuple(np.concatenate([a[i] for a in parts], 0)[perm] for i in range(3))
 
