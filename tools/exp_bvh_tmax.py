@@ -89,7 +89,10 @@ def run(name, tmax, extra=None):
     results[name] = r
 
 
+ONLY = os.environ.get("BVH_TMAX_ONLY")        # e.g. "grid_256": that variant alone (rocprofv3 --pmc passes: launches 2..7 = no bound, 9..14 = the variant)
 for X in (10.0, 0.3, 0.1, 0.03, 0.01):
+    if ONLY and ONLY != f"oracle_miss_{X}":
+        continue
     run(f"oracle_miss_{X}", torch.where(hit0, depth0 * 1.0001 + 1e-5, torch.full_like(depth0, X)))
 
 # ---- a real conservative bound from an N^3 occupancy grid
@@ -98,6 +101,8 @@ lo_s, hi_s = V.reshape(-1, 3).amin(0) - 1e-3, V.reshape(-1, 3).amax(0) + 1e-3
 o_row = pts[:, None, :].expand(pn, T, 3).reshape(-1, 3)
 org = o_row + dirs * 1e-5 + dirs * (2 * unit)
 for N in (32, 64, 128, 256):
+    if ONLY and ONLY != f"grid_{N}":
+        continue
     cell = (hi_s - lo_s) / N
     tlo = ((V.amin(1) - lo_s) / cell).floor().long().clamp(0, N - 1)
     thi = ((V.amax(1) - lo_s) / cell).floor().long().clamp(0, N - 1)
@@ -137,6 +142,8 @@ for N in (32, 64, 128, 256):
     tlim = torch.where(last >= 0, (last.float() + 1.5) * h, torch.zeros(m, device=dev))
     never = float((last < 0).float().mean())
     miss = ~hit0 & live.reshape(-1).bool()
+    if os.environ.get("BVH_TMAX_SAVE"):          # for tools/exp_bvh_tmax_prof.py (the PMC passes run a script without torch indexing kernels)
+        torch.save(dict(pts=pts.cpu(), dirs=dirs.cpu(), live=live.cpu(), tmax=tlim.cpu(), unit=unit, n_live=n_live, name=f"grid_{N}"), os.environ["BVH_TMAX_SAVE"])
     run(f"grid_{N}", tlim, dict(cell=h, occupied_fraction_raw=raw_frac, occupied_fraction_dilated=float(occ.float().mean()),
                                 rays_without_any_occupied_cell=never, median_tlimit_of_misses=float(tlim[miss].median()),
                                 mean_tlimit_of_misses=float(tlim[miss].mean()), march_steps_max=K))
