@@ -42,7 +42,7 @@ typedef enum TfStatus {
  * Accepted by tf_flow_sample_fwd / tf_flow_logq_fwd and tf_inner_light_fwd / tf_inner_light_indexed_fwd; others reject it.
  * TF_PREC_F16X2 (inner-light net only): weights split hi + lo, activations rounded to f16 once per layer (w_hi x + w_lo x): per ray
  * inside the error of fp32 PyTorch against fp64; runs on the 128-ray form of the staggered kernel. */
-typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1, TF_PREC_F16 = 2, TF_PREC_F16X2 = 3 } TfPrecision;
+typedef enum TfPrecision { TF_PREC_F32 = 0, TF_PREC_F16X3 = 1, TF_PREC_F16 = 2, TF_PREC_F16X2 = 3, TF_PREC_BF16X3 = 4 } TfPrecision;
 /* OR-ed into a `precision` argument: `workspace` still holds this network's packed weights from an earlier call with
  * the same weights and precision (the caller tracks weight updates), so the fragment re-pack launches are skipped. */
 #define TF_WEIGHTS_PACKED 0x100
@@ -601,13 +601,44 @@ int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n
                     float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream);
 
 /* -----------------------------------------------------------------------------------
+ * The element-wise algebra of ShapeShadingNetwork.forward in the TRAINING direction (network/fields.py:448-567) as two differentiable
+ * stages around the nets / cube lookups / encodings (which are entry points of their own), forward and adjoint: 4 launches instead of
+ * the ~150 element-wise launches of the torch composition and its autograd mirror image.
+ *   pre  (:455-463): normals [n,3], view [n,3] (any length), mat [n,5] (mat_mlp's sigmoid outputs) -> normals_u (F.normalize + the
+ *        reference's patch of rows with n.x + n.y == 0), view_u, nov [n] = n . v, reflective [n,3] = 2 nov n - v, roughness [n] = 0.9 m3 + 0.09
+ *        and, with mip non-NULL, mip [n] = clamp(EnvLight.get_mip(roughness), 0, n_levels - 1) (network/light.py:72-80, :101: the
+ *        coordinate in the n_levels-deep specular stack, two linear pieces meeting at max_roughness).
+ *   post (:460-561): mat, nov, diffuse_light / direct_light / indirect_light [n,3], occ_raw [n] (inner_weight's output), FG LUT
+ *        [fg_h,fg_w,2] -> color [n,3] = clamp(sRGB((1 - m) a L_d + ((0.04 (1 - m) + m a) FG.x + FG.y) (L_i occ + L_s (1 - occ))), 0, 1) with
+ *        a = 0.77 m012 + 0.03, occ = clamp(occ_prob, 0, 1), occ_prob [n] = 0.5 occ_raw + 0.5, FG = F.grid_sample(bilinear, border,
+ *        align_corners=False) at (clamp(nov, 0, 1), clamp(roughness, 0, 1)).
+ * The adjoints follow torch autograd's conventions for that composition (clamp masks inclusive, zero LUT gradient on clipped
+ * coordinates, the sRGB branch taken).  pre_bwd: g_normals_u / g_nov / g_reflective / g_roughness / g_mip may be NULL (no gradient arrived; g_mip needs mat);
+ * writes g_normals [n,3] and g_mat [n,5] (column 3, the others zero).  post_bwd: g_occ_prob may be NULL; writes every g_* given. */
+int tf_shape_glue_pre_fwd(const float* normals, const float* view, const float* mat, int64_t n, float* normals_u, float* view_u,
+                          float* nov, float* reflective, float* roughness, float* mip, float min_roughness, float max_roughness,
+                          int32_t n_levels, tf_stream_t stream);
+int tf_shape_glue_pre_bwd(const float* normals, const float* view, const float* g_normals_u, const float* g_nov, const float* g_reflective,
+                          const float* g_roughness, const float* g_mip, const float* mat, float min_roughness, float max_roughness,
+                          int32_t n_levels, int64_t n, float* g_normals, float* g_mat, tf_stream_t stream);
+int tf_shape_glue_post_fwd(const float* mat, const float* nov, const float* diffuse_light, const float* direct_light,
+                           const float* indirect_light, const float* occ_raw, const float* fg_lut, int32_t fg_h, int32_t fg_w, int64_t n,
+                           float* color, float* occ_prob, tf_stream_t stream);
+int tf_shape_glue_post_bwd(const float* mat, const float* nov, const float* diffuse_light, const float* direct_light,
+                           const float* indirect_light, const float* occ_raw, const float* fg_lut, int32_t fg_h, int32_t fg_w,
+                           const float* g_color, const float* g_occ_prob, int64_t n, float* g_mat, float* g_nov, float* g_diffuse_light,
+                           float* g_direct_light, float* g_indirect_light, float* g_occ_raw, tf_stream_t stream);
+
+/* -----------------------------------------------------------------------------------
  * Dense layers of the training direction.  Replace torch.nn.Linear + activation -- the library GEMMs under the reference's
  * TensoSDF decoder (network/fields.py:78-81), make_predictor_3layer / _4layer (network/other_field.py:50-119: material
  * predictors fields.py:1010-1017, inner-light net :905-911, ShapeShadingNetwork's nets :448-567) -- in forward AND backward.
- * precision: TF_PREC_F32 = fp32-grade products with fp32's operand range (what the training ops use): on the 16-byte-aligned shapes a
+ * precision: TF_PREC_F32 = the exact-fp32 instruction v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain (the yardstick of the parity
+ * tests); TF_PREC_BF16X3 (what the training ops pass) = fp32-grade products with fp32's operand range: on the 16-byte-aligned shapes a
  * bf16 TRIPLE split -- x = hi + mid + lo, six v_mfma_f32_32x32x16_bf16 per 16-deep product, every term down to 2^-24 |a||b|, fp32
- * accumulate (round 5; 3-7e-7 of the largest element against fp64, as the exact instruction) -- on the other shapes and with
- * TF_GEMM_SPLIT=0 in the environment the exact-fp32 instruction v_mfma_f32_32x32x2_f32; TF_PREC_F16X3 = f16 operand
+ * accumulate (3-7e-7 of the largest element against fp64, as the exact instruction; operands must be FINITE and below 3.3895e38 in magnitude, the largest
+ * bf16: the outputs an Inf / NaN / larger operand reaches come out NaN, not Inf -- IEEE Inf propagation is TF_PREC_F32's) -- and the exact
+ * instruction on the other shapes; TF_PREC_F16X3 = f16 operand
  * split (three v_mfma_f32_32x32x16_f16 per product term, fp32 accumulate) for operands inside the f16 range only -- unscaled
  * gradients of a mean-reduced loss are not.
  * X [n,K], W [N,K] (torch layout), b [N] or NULL, Y [n,N] row-major.

@@ -154,6 +154,52 @@ def linear_to_srgb(lin, clamp01=False):
     return y.clamp(0, 1) if clamp01 else y
 
 
+class ShapeGluePreFn(torch.autograd.Function):
+    """ShapeShadingNetwork.forward's prelude (fields.py:455-463) as one launch each way: unit normals (degenerate rows patched), unit
+    view, NoV, reflective, roughness and -- with mip_levels = (min_roughness, max_roughness, n_levels) -- the specular-stack coordinate
+    EnvLight.get_mip(roughness).clamp(0, n - 1) (13 element-wise launches of their own before).  Differentiable wrt the normals and mat
+    (the view directions of a training step carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, normals, view, mat, mip_levels=None):
+        ctx.set_materialize_grads(False)
+        nu, vu, nov, refl, rough, mip = ops.shape_glue_pre(normals, view, mat, mip_levels=mip_levels)
+        ctx.save_for_backward(normals, view, mat)
+        ctx.mip_levels = mip_levels
+        ctx.mark_non_differentiable(vu)
+        if mip is None:
+            mip = torch.empty(0, device=normals.device)
+            ctx.mark_non_differentiable(mip)
+        return nu, vu, nov, refl, rough, mip
+
+    @staticmethod
+    def backward(ctx, g_nu, g_vu, g_nov, g_refl, g_rough, g_mip):
+        normals, view, mat = ctx.saved_tensors
+        if ctx.mip_levels is None:
+            g_mip = None
+        gn, gm = ops.shape_glue_pre(normals, view, mat, grads=(g_nu, g_nov, g_refl, g_rough, g_mip), mip_levels=ctx.mip_levels)
+        return gn, None, gm, None
+
+
+class ShapeGluePostFn(torch.autograd.Function):
+    """ShapeShadingNetwork.forward's split-sum combination (fields.py:460-561) as one launch each way -> (color, occ_prob)."""
+
+    @staticmethod
+    def forward(ctx, mat, nov, diffuse_light, direct_light, indirect_light, occ_raw, fg_lut):
+        ctx.set_materialize_grads(False)
+        color, occ_prob = ops.shape_glue_post(mat, nov, diffuse_light, direct_light, indirect_light, occ_raw, fg_lut)
+        ctx.save_for_backward(mat, nov, diffuse_light, direct_light, indirect_light, occ_raw, fg_lut)
+        return color, occ_prob
+
+    @staticmethod
+    def backward(ctx, g_color, g_occ_prob):
+        saved = ctx.saved_tensors
+        if g_color is None:
+            g_color = torch.zeros(saved[0].shape[0], 3, device=saved[0].device)
+        gm, gnov, gdl, gdr, gil, gocc = ops.shape_glue_post(*saved, grads=(g_color, g_occ_prob))
+        return gm, gnov, gdl, gdr, gil, gocc, None
+
+
 class FlowLogqFn(torch.autograd.Function):
     """(z, logq) = TensoFlow.forward given cond; backward = tf_flow_logq_bwd (fused HIP reverse pass)."""
 

@@ -266,6 +266,10 @@ __device__ __forceinline__ void g2_split8(const float (&x)[8], tf_b8& hi, tf_b8&
     const float s0 = r0 - __uint_as_float(mm << 16), s1 = r1 - __uint_as_float(mm & 0xffff0000u);
     h[p] = hh; m[p] = mm; l[p] = g2_cvt2(s0, s1);
   }
+  // (Non-finite operands: an Inf -- or a value that rounds up to the bf16 Inf, |x| > 3.3895e38 -- has hi = Inf and NaN residuals, and even
+  // with those zeroed its products with the OTHER operand's signed residual planes are +Inf and -Inf: the split cannot propagate an Inf
+  // as the fp32 instruction does.  The row such an operand reaches comes out non-finite (NaN), every other row is untouched; a caller
+  // that needs IEEE Inf semantics asks for TF_PREC_F32.  tests/test_gpu_linear.py pins this.)
   hi = __builtin_bit_cast(tf_b8, h); mid = __builtin_bit_cast(tf_b8, m); lo = __builtin_bit_cast(tf_b8, l);
 }
 __device__ __forceinline__ f32x16 g2_mfma_b(tf_b8 a, tf_b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -544,12 +548,11 @@ __global__ void __launch_bounds__(256) thin_weight_kernel(const float* __restric
 inline bool thin_ok(int K, int N) { return TF_GEMM2 && N >= 1 && N <= 4 && K % 4 == 0 && K >= 4 && K <= 1024; }
 
 template <bool A_RF, bool B_RF>
-int launch2(const Gemm2Args& G, int splits, hipStream_t stream, const char* who) {
+int launch2(const Gemm2Args& G, int splits, bool split, hipStream_t stream, const char* who) {
   dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)splits);
-  // the bf16 triple split is the product form (round 5: 76.9 -> 89.3 TF/s effective on 236 k x 256 x 256, errors against fp64 the same
-  // 3-7e-7 of the largest element as the exact-fp32 instruction's, on activations and on 1e-9-scale gradients alike); TF_GEMM_SPLIT=0
-  // selects the v_mfma_f32_32x32x2_f32 form (tools/exp_gemm_split.py)
-  static const bool split = !(getenv("TF_GEMM_SPLIT") && atoi(getenv("TF_GEMM_SPLIT")) == 0);
+  // split = TF_PREC_BF16X3: the bf16 triple split (round 5: 76.9 -> 89.3 TF/s effective on 236 k x 256 x 256, errors against fp64 the same
+  // 3-7e-7 of the largest element as the exact-fp32 instruction's, on activations and on 1e-9-scale gradients alike); TF_PREC_F32 is
+  // the v_mfma_f32_32x32x2_f32 form, always (round 6: the caller names the arithmetic; no environment switch)
   if (split) gemm2_kernel<A_RF, B_RF, true><<<grid, 256, 0, stream>>>(G);
   else gemm2_kernel<A_RF, B_RF, false><<<grid, 256, 0, stream>>>(G);
   TF_LAUNCH_CHECK(who);
@@ -657,7 +660,7 @@ int tf_linear_products(const float* X, const float* W, const float* gZ, long lon
 }
 static int linear_products_x(const float* X, const float* W, const float* gZ, long long n, int K, int N, int precision, float* gX, float* gW,
                              const long long* n_dev, hipStream_t stream, int xact, float xact_param, float* gbx) {
-  const bool h3 = precision == TF_PREC_F16X3;
+  const bool h3 = precision == TF_PREC_F16X3, b3 = precision == TF_PREC_BF16X3;
   const bool fuse = (xact != TF_ACT_NONE || gbx) && gX;      // (a layer below without an activation still gets its bias gradient here)
   if (n == 0) return TF_OK;
   if (!h3 && thin_ok(K, N) && aligned16(X) && aligned16(W) && (!gX || aligned16(gX)) && (!gW || aligned16(gW))) {
@@ -681,7 +684,7 @@ static int linear_products_x(const float* X, const float* W, const float* gZ, lo
     if (g2) {
       Gemm2Args G2{gZ, N, W, K, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
       if (fuse) { G2.mulY = X; G2.mul_act = xact; G2.mul_param = xact_param; G2.colsum = gbx; fused_here = true; }
-      rc = launch2<true, false>(G2, 1, stream, "tf_linear_bwd(data)");
+      rc = launch2<true, false>(G2, 1, b3, stream, "tf_linear_bwd(data)");
     } else {
       GemmArgs G{gZ, N, 1, W, K, 1, gX, K, nullptr, n, K, N, N, TF_ACT_NONE, 0.f, 0, n_dev, 1};
       rc = launch<true, true>(G, 1, h3, stream, "tf_linear_bwd(data)");
@@ -708,7 +711,7 @@ static int linear_products_x(const float* X, const float* W, const float* gZ, lo
     int rc;
     if (g2) {
       Gemm2Args G2{gZ, N, X, K, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, n_dev, 0};
-      rc = launch2<false, false>(G2, splits, stream, "tf_linear_bwd(weight)");
+      rc = launch2<false, false>(G2, splits, b3, stream, "tf_linear_bwd(weight)");
     } else {
       GemmArgs G{gZ, 1, N, X, K, 1, gW, K, nullptr, N, K, n, split, TF_ACT_NONE, 0.f, 1, n_dev, 0};
       rc = launch<false, true>(G, splits, h3, stream, "tf_linear_bwd(weight)");
@@ -722,7 +725,7 @@ extern "C" int tf_linear_fwd(const float* X, const float* W, const float* b, int
                              int32_t precision, float* Y, const int64_t* n_dev, tf_stream_t stream) {
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_fwd: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP, TF_EINVAL, "tf_linear_fwd: unknown activation %d", act);
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_fwd: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_BF16X3, TF_EINVAL, "tf_linear_fwd: precision %d (TF_PREC_F32, TF_PREC_BF16X3 or TF_PREC_F16X3)", precision);
   const bool h3 = precision == TF_PREC_F16X3;
   if (n == 0) return TF_OK;
   TF_REQUIRE(X && W && Y, TF_EINVAL, "tf_linear_fwd: null pointer");
@@ -739,7 +742,7 @@ extern "C" int tf_linear_fwd(const float* X, const float* W, const float* b, int
   }
   if (!h3 && TF_GEMM2 && K % 4 == 0 && N >= 32 && wide_cols_pay(N) && aligned16(X) && aligned16(W)) {
     Gemm2Args G2{X, K, W, K, Y, N, b, n, N, K, K, act, act_param, 0, (const long long*)n_dev, 1};
-    return launch2<true, true>(G2, 1, (hipStream_t)stream, "tf_linear_fwd");
+    return launch2<true, true>(G2, 1, precision == TF_PREC_BF16X3, (hipStream_t)stream, "tf_linear_fwd");
   }
   GemmArgs G{X, K, 1, W, 1, K, Y, N, b, n, N, K, K, act, act_param, 0, (const long long*)n_dev, 1};
   return launch<true, false>(G, 1, h3, (hipStream_t)stream, "tf_linear_fwd");
@@ -749,7 +752,7 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
                              float act_param, int32_t precision, float* gZ, float* gX, float* gW, float* gb, const int64_t* n_dev,
                              tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_bwd: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_BF16X3, TF_EINVAL, "tf_linear_bwd: precision %d (TF_PREC_F32, TF_PREC_BF16X3 or TF_PREC_F16X3)", precision);
   const bool h3 = precision == TF_PREC_F16X3;
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_bwd: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP, TF_EINVAL, "tf_linear_bwd: unknown activation %d", act);
@@ -764,7 +767,7 @@ extern "C" int tf_linear_bwd(const float* X, const float* W, const float* Y, con
   }
   else act_bwd_small_kernel<<<tf_blocks(n * N, 4096), 256, 0, stream>>>(gY, Y, n * N, N, act, act_param, gZ, gb, (const long long*)n_dev);
   TF_LAUNCH_CHECK("tf_linear_bwd(act)");
-  return tf_linear_products(X, W, gZ, n, K, N, h3 ? TF_PREC_F16X3 : TF_PREC_F32, gX, gW, (const long long*)n_dev, stream);
+  return tf_linear_products(X, W, gZ, n, K, N, precision, gX, gW, (const long long*)n_dev, stream);
 }
 
 // One layer of a backward CHAIN through stacked dense layers (LightsFn.backward: the inner-light net's four layers): as tf_linear_bwd,
@@ -774,7 +777,7 @@ extern "C" int tf_linear_bwd_fused(const float* X, const float* W, const float* 
                                    float act_param, int32_t gy_is_gz, int32_t x_act, float x_act_param, int32_t precision, float* gZ,
                                    float* gX, float* gW, float* gb, float* gbx, const int64_t* n_dev, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3, TF_EINVAL, "tf_linear_bwd_fused: precision %d (TF_PREC_F32 or TF_PREC_F16X3)", precision);
+  TF_REQUIRE(precision == TF_PREC_F32 || precision == TF_PREC_F16X3 || precision == TF_PREC_BF16X3, TF_EINVAL, "tf_linear_bwd_fused: precision %d (TF_PREC_F32, TF_PREC_BF16X3 or TF_PREC_F16X3)", precision);
   TF_REQUIRE(n >= 0 && K > 0 && N > 0, TF_ESHAPE, "tf_linear_bwd_fused: bad sizes n=%lld K=%d N=%d", (long long)n, K, N);
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP && x_act >= TF_ACT_NONE && x_act <= TF_ACT_EXP_CLAMP, TF_EINVAL,
              "tf_linear_bwd_fused: unknown activation %d / %d", act, x_act);

@@ -679,7 +679,7 @@ extern "C" int tf_sdf_alpha_bwd(const TfVmDesc* d, const float* packed, const Tf
     const long long c = (n - c0) < kBwdChunk ? (n - c0) : kBwdChunk;
     const float* gf = g_feat ? g_feat + c0 * SDF_APP : nullptr;
     if (gf) {     // dh_app = g_feat . W2[1:]   (gZ [c,128], W [128,256])
-      if (int rc = tf_linear_products(nullptr, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_F32, dh_app, nullptr, nullptr, stream)) return rc;
+      if (int rc = tf_linear_products(nullptr, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_BF16X3, dh_app, nullptr, nullptr, stream)) return rc;
     }
     A.pts = pts + 3 * c0; A.level = level ? level + c0 : nullptr; A.n = c; A.dists = dists + c0; A.dirs = dirs + 3 * c0;
     SdfBwdArgs B = {sdf + c0, taps + 6 * c0, g_alpha ? g_alpha + c0 : nullptr, g_grad ? g_grad + 3 * c0 : nullptr,
@@ -690,11 +690,11 @@ extern "C" int tf_sdf_alpha_bwd(const TfVmDesc* d, const float* packed, const Tf
     else sdf_bwd_kernel<false><<<(unsigned)blocks, 256, lds, stream>>>(A, B);
     TF_LAUNCH_CHECK("tf_sdf_alpha_bwd(recompute)");
     // first layer: din = dz . W1p, [dW1 | db1] += dz^T . [X | 1]
-    if (int rc = tf_linear_products(X, w1p, dz, 7 * c, kXld, SDF_HID, TF_PREC_F32, din, gw1p, nullptr, stream)) return rc;
+    if (int rc = tf_linear_products(X, w1p, dz, 7 * c, kXld, SDF_HID, TF_PREC_BF16X3, din, gw1p, nullptr, stream)) return rc;
     // second layer: row 0 (the sdf) over all taps, rows 1.. (appearance features) on the centre tap (rows [0, c) of h)
-    if (int rc = tf_linear_products(hh, mlp->w2, dsb, 7 * c, SDF_HID, 1, TF_PREC_F32, nullptr, g_w2, nullptr, stream)) return rc;
+    if (int rc = tf_linear_products(hh, mlp->w2, dsb, 7 * c, SDF_HID, 1, TF_PREC_BF16X3, nullptr, g_w2, nullptr, stream)) return rc;
     if (gf) {
-      if (int rc = tf_linear_products(hh, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_F32, nullptr, g_w2 + SDF_HID, nullptr, stream)) return rc;
+      if (int rc = tf_linear_products(hh, mlp->w2 + SDF_HID, gf, c, SDF_HID, SDF_APP, TF_PREC_BF16X3, nullptr, g_w2 + SDF_HID, nullptr, stream)) return rc;
       sdf_colsum_kernel<<<tf_blocks(c, 512), 256, 0, stream>>>(gf, c, SDF_APP, g_b2 + 1);
     }
     if (int rc = tf_vm_scatter_taps(A.g, packed, A.pts, A.level, c, A.units, din, kXld, gpacked, stream)) return rc;

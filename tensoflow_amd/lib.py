@@ -78,6 +78,10 @@ SIGNATURES = {
     "tf_flow_workspace_floats": (sz, [i64]),
     "tf_flow_sample_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, c_f, c_f, c_f, i32, c_f, sz, c_f]),
     "tf_flow_logq_fwd": (C.c_int, [P(TfCouplingNet * 2), c_f, c_f, c_f, i64, i32, i64, c_f, c_f, c_f, i32, c_f, sz, c_f]),
+    "tf_shape_glue_pre_fwd": (C.c_int, [c_f, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, i32, c_f]),
+    "tf_shape_glue_pre_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, i32, i64, c_f, c_f, c_f]),
+    "tf_shape_glue_post_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i64, c_f, c_f, c_f]),
+    "tf_shape_glue_post_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_linear_fwd": (C.c_int, [c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, c_f, c_f, c_f]),
     "tf_linear_bwd": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_linear_bwd_fused": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -841,6 +841,20 @@ class ShapeShadingNetwork(nn.Module):
         env = self.envlight
         if not hasattr(env, "specular"):
             env.build_mips()
+        if (points.is_cuda and not inter_results and not self.cfg["human_light"] and not view_dirs.requires_grad and not points.requires_grad
+                and self.FG_LUT.is_cuda and self.FG_LUT.is_contiguous()):
+            # the default training form: the element-wise algebra as two differentiable launches (tf_shape_glue_*: round 6; ~150
+            # element-wise launches of this composition and autograd's mirror image before), nets / lookups / encodings in between
+            from ..autograd import ShapeGluePostFn, ShapeGluePreFn
+            mat = _mlp(self.mat_mlp, self._mat_input(points, feat))
+            normals, view_dirs, NoV, reflective, roughness, mip = ShapeGluePreFn.apply(
+                normals.contiguous(), view_dirs.contiguous(), mat, (env.min_roughness, env.max_roughness, len(env.specular)))
+            pts = posenc(points, self.cfg["light_pos_freq"])
+            indirect_light = _mlp(self.inner_light, torch.cat([pts, ide5(reflective, roughness)], -1))
+            occ_raw = _mlp(self.inner_weight, torch.cat([pts.detach(), posenc(reflective.detach(), 6)], -1))
+            color, occ_prob = ShapeGluePostFn.apply(mat, NoV, env(normals), env(reflective, roughness, mip=mip), indirect_light, occ_raw, self.FG_LUT)
+            occ_info = {"reflective": reflective, "occ_prob": occ_prob, "roughness": roughness}
+            return color, (self._radiance(points, normals, view_dirs, feat) if want_rad else None), occ_info
         normals, view_dirs = self._unit_inputs(normals, view_dirs)
         NoV = (normals * view_dirs).sum(-1, keepdim=True)
         reflective = NoV * normals * 2 - view_dirs

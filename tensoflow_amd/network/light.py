@@ -197,14 +197,15 @@ class EnvLight(torch.nn.Module):
                            / (self.max_roughness - self.min_roughness) * (n - 2),
                            (roughness.clamp(self.max_roughness, 1.0) - self.max_roughness) / (1.0 - self.max_roughness) + n - 2)
 
-    def forward(self, l, roughness=None):
-        """light.py:95-122: exp of the cube fetch of the diffuse map, or of the trilinear fetch over the specular stack."""
+    def forward(self, l, roughness=None, mip=None):
+        """light.py:95-122: exp of the cube fetch of the diffuse map, or of the trilinear fetch over the specular stack.
+        mip: get_mip(roughness).clamp(0, n - 1) computed by the caller (autograd.ShapeGluePreFn emits it with the roughness)."""
         prefix = l.shape[:-1]
         d = l.reshape(-1, 3).contiguous()
         if roughness is None:
             return torch.exp(_CubeLookupLinear.apply(self.diffuse, d)).view(*prefix, -1)
         n = len(self.specular)
-        mip = self.get_mip(roughness.reshape(-1)).clamp(0, n - 1)
+        mip = self.get_mip(roughness.reshape(-1)).clamp(0, n - 1) if mip is None else mip.reshape(-1)
         if d.is_cuda and not self.composed_lookup:
             return _CubeLookupMips.apply(d, mip, *self.specular).view(*prefix, -1)
         # the per-level composition of rounds 1-4 (every level fetched for every sample): the checker of the fused lookup, and the CPU form

@@ -12,7 +12,7 @@ import torch
 from . import lib as L
 
 
-PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2 = 0, 1, 2, 3      # TfPrecision (PREC_F16: flow + inner-light decoders only, outside the 1e-4 bar)
+PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2, PREC_BF16X3 = 0, 1, 2, 3, 4      # TfPrecision (PREC_F16: flow + inner-light decoders only, outside the 1e-4 bar; PREC_BF16X3: dense layers only)
 
 
 def _stream():
@@ -411,6 +411,58 @@ def linear_to_srgb(lin, clamp01=False, g_out=None):
     return out
 
 
+# ------------------------------------------------------------------------------ split-sum shading algebra (training direction)
+def shape_glue_pre(normals, view, mat, grads=None, mip_levels=None):
+    """tf_shape_glue_pre_fwd: -> (normals_u [n,3], view_u [n,3], nov [n,1], reflective [n,3], roughness [n,1], mip [n] or None); with
+    grads = (g_normals_u, g_nov, g_reflective, g_roughness, g_mip) (entries may be None) tf_shape_glue_pre_bwd: -> (g_normals [n,3],
+    g_mat [n,5]).  mip_levels = (min_roughness, max_roughness, n_levels): also the specular-stack coordinate of EnvLight.get_mip."""
+    normals, view = _f(normals), _f(view)
+    mat = _f(mat) if mat is not None else None          # (the adjoint reads it for the mip coordinate only)
+    n = normals.shape[0]
+    if normals.shape != (n, 3) or view.shape != (n, 3) or (mat is not None and mat.shape != (n, 5)) or (mat is None and grads is None):
+        raise RuntimeError(f"shape_glue_pre: normals {tuple(normals.shape)}, view {tuple(view.shape)}, mat {None if mat is None else tuple(mat.shape)}")
+    dev = normals.device
+    mn, mx, nl = (float(mip_levels[0]), float(mip_levels[1]), int(mip_levels[2])) if mip_levels is not None else (0.0, 0.5, 0)
+    if grads is None:
+        nu, vu, refl = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+        nov, rough = (torch.empty(n, 1, dtype=torch.float32, device=dev) for _ in range(2))
+        mip = torch.empty(n, dtype=torch.float32, device=dev) if mip_levels is not None else None
+        L.check(L.load().tf_shape_glue_pre_fwd(_p(normals), _p(view), _p(mat), n, _p(nu), _p(vu), _p(nov), _p(refl), _p(rough), _p(mip), mn, mx, nl,
+                                               _stream()), "tf_shape_glue_pre_fwd")
+        return nu, vu, nov, refl, rough, mip
+    g = [None if t is None else _f(t) for t in grads]
+    if g[4] is not None and (mat is None or mip_levels is None):
+        raise RuntimeError("shape_glue_pre: the mip coordinate's gradient needs mat and mip_levels")
+    gn, gm = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 5, dtype=torch.float32, device=dev)
+    L.check(L.load().tf_shape_glue_pre_bwd(_p(normals), _p(view), _p(g[0]), _p(g[1]), _p(g[2]), _p(g[3]), _p(g[4]), _p(mat), mn, mx, nl, n, _p(gn),
+                                           _p(gm), _stream()), "tf_shape_glue_pre_bwd")
+    return gn, gm
+
+
+def shape_glue_post(mat, nov, diffuse_light, direct_light, indirect_light, occ_raw, fg_lut, grads=None):
+    """tf_shape_glue_post_fwd: -> (color [n,3], occ_prob [n,1]); with grads = (g_color, g_occ_prob or None) tf_shape_glue_post_bwd:
+    -> (g_mat [n,5], g_nov [n,1], g_diffuse_light, g_direct_light, g_indirect_light [n,3], g_occ_raw [n,1]).  fg_lut [.., H, W, 2]."""
+    mat, nov, dl, dr, il, oc, lut = _f(mat), _f(nov), _f(diffuse_light), _f(direct_light), _f(indirect_light), _f(occ_raw), _f(fg_lut)
+    n = mat.shape[0]
+    H, W = int(lut.shape[-3]), int(lut.shape[-2])
+    if mat.shape != (n, 5) or nov.numel() != n or oc.numel() != n or any(t.shape != (n, 3) for t in (dl, dr, il)) or lut.shape[-1] != 2:
+        raise RuntimeError("shape_glue_post: operand shapes")
+    dev = mat.device
+    if grads is None:
+        color, occ_prob = torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 1, dtype=torch.float32, device=dev)
+        L.check(L.load().tf_shape_glue_post_fwd(_p(mat), _p(nov), _p(dl), _p(dr), _p(il), _p(oc), _p(lut), H, W, n, _p(color), _p(occ_prob),
+                                                _stream()), "tf_shape_glue_post_fwd")
+        return color, occ_prob
+    g_color = _f(grads[0])
+    g_occ = None if grads[1] is None else _f(grads[1])
+    gm = torch.empty(n, 5, dtype=torch.float32, device=dev)
+    gnov, gocc = (torch.empty(n, 1, dtype=torch.float32, device=dev) for _ in range(2))
+    gdl, gdr, gil = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    L.check(L.load().tf_shape_glue_post_bwd(_p(mat), _p(nov), _p(dl), _p(dr), _p(il), _p(oc), _p(lut), H, W, _p(g_color), _p(g_occ), n, _p(gm),
+                                            _p(gnov), _p(gdl), _p(gdr), _p(gil), _p(gocc), _stream()), "tf_shape_glue_post_bwd")
+    return gm, gnov, gdl, gdr, gil, gocc
+
+
 # ------------------------------------------------------------------------------ compositing
 def composite(alpha, ray_indices, values, n_rays):
     lib = L.load()
@@ -484,7 +536,7 @@ def flow_sample(weights, cond, latent, jitter=None, want_bins=False, precision=1
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS, ACT_SIGMOID, ACT_EXP_CLAMP = 0, 1, 2, 3, 4      # TfActivation
 
 
-LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction's dense layers: fp32-grade (round 5: a bf16 triple split on the aligned shapes -- six bf16 matrix steps per 16-deep product, fp32's range -- the exact-fp32 matrix instruction elsewhere; TF_GEMM_SPLIT=0 forces the latter).  PREC_F16X3 exists in the
+LINEAR_PRECISION = PREC_BF16X3   # operand arithmetic of the training direction's dense layers: fp32-grade with fp32's range (a bf16 triple split on the aligned shapes -- six bf16 matrix steps per 16-deep product -- the exact-fp32 matrix instruction elsewhere).  PREC_F32 = the exact instruction everywhere (round 6: named by the caller, no environment switch).  PREC_F16X3 exists in the
                                  # kernel and is NOT the default for two measured reasons: gradients of mean-reduced losses (1e-7 .. 1e-5 per
                                  # element) fall below the f16 range and flush to zero unscaled (test_mcshading_eval_follows_parameter_updates
                                  # caught it), and the tall-skinny products are held by their tile traffic, not by the matrix rate (material
@@ -493,7 +545,7 @@ LINEAR_PRECISION = PREC_F32      # operand arithmetic of the training direction'
 
 def linear_fwd(x, w, b, act=ACT_NONE, act_param=0.0, n_dev=None, precision=None):
     """Y = act(x w^T + b) on the matrix cores (tf_linear_fwd): x [n,K], w [N,K], b [N] or None -> [n,N].
-    precision: PREC_F32 (fp32-grade, see LINEAR_PRECISION; the module default) or PREC_F16X3 (operands within the f16 range only).
+    precision: PREC_BF16X3 (fp32-grade, see LINEAR_PRECISION; the module default), PREC_F32 (the exact-fp32 instruction) or PREC_F16X3 (operands within the f16 range only).
     n_dev: device int64 scalar -- only the first min(n, n_dev) rows are computed (the rest of Y stays uninitialised)."""
     lib = L.load()
     x, w = _f(x), _f(w)

@@ -12,12 +12,13 @@ def _ref_act(z, act, p):
             ops.ACT_SIGMOID: lambda: torch.sigmoid(z), ops.ACT_EXP_CLAMP: lambda: torch.exp(z.clamp(max=p))}[act]()
 
 
-@pytest.fixture(params=["f16x3", "f32"])
+@pytest.fixture(params=["f16x3", "f32", "bf16x3"])
 def linear_precision(request):
-    """Both operand arithmetics of tf_linear_*: the f16x3 split (default) and exact fp32 MFMA -- the same 2e-5 bar for both."""
+    """The three operand arithmetics of tf_linear_*: the bf16 triple split (the training default: fp32-grade, fp32's range), the exact
+    fp32 MFMA and the f16x3 split -- the same 2e-5 bar for all."""
     from tensoflow_amd import ops
     keep = ops.LINEAR_PRECISION
-    ops.LINEAR_PRECISION = ops.PREC_F16X3 if request.param == "f16x3" else ops.PREC_F32
+    ops.LINEAR_PRECISION = {"f16x3": ops.PREC_F16X3, "f32": ops.PREC_F32, "bf16x3": ops.PREC_BF16X3}[request.param]
     yield request.param
     ops.LINEAR_PRECISION = keep
 
@@ -110,3 +111,31 @@ def test_mlp_apply_walks_weight_normed_sequentials():
     g2 = torch.autograd.grad(yr, [x] + list(seq.parameters()), gy)
     for a, r in zip(g1, g2):
         assert float((a - r).abs().max()) <= 2e-5 * (float(r.abs().max()) + 1e-9) + 1e-7
+
+
+def test_bf16_split_keeps_non_finite_operands_in_their_rows():
+    """the bf16 triple split (TF_PREC_BF16X3) is named by the caller now, and what it does with non-finite operands is pinned:
+    x = hi + mid + lo cannot propagate an Inf as the fp32 instruction does (Inf times the other operand's signed residual planes is +Inf
+    and -Inf), so every output such an operand reaches is non-finite (NaN or Inf) -- in ITS row only, every other row is untouched and
+    agrees with the exact instruction -- while TF_PREC_F32, the exact instruction, returns the IEEE +Inf."""
+    from tensoflow_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n, K, N = 512, 256, 256
+    x = torch.randn(n, K, device=dev)
+    w = torch.randn(N, K, device=dev).abs() / 16          # positive weights: an Inf input gives +Inf in every exact-fp32 output of its row
+    x[7, 3] = float("inf")
+    x[9, 100] = 3.4e38                                       # finite in fp32, rounds up to the bf16 Inf
+    x[11, 5] = float("nan")
+    yb = ops.linear_fwd(x, w, None, precision=ops.PREC_BF16X3)
+    ye = ops.linear_fwd(x, w, None, precision=ops.PREC_F32)
+    # (row 9: 3.4e38 is finite in fp32 and so is its exact product row; it rounds up to the bf16 Inf, so the split loses that row too --
+    # operands of the split must stay below 3.3895e38 in magnitude, as the header says)
+    assert torch.isinf(ye[7]).all() and (ye[7] > 0).all() and torch.isnan(ye[11]).all() and torch.isfinite(ye[9]).all()
+    for r in (7, 9, 11):
+        assert not torch.isfinite(yb[r]).any(), r
+    clean = torch.ones(n, dtype=torch.bool, device=dev)
+    clean[[7, 9, 11]] = False
+    clean_e = clean.clone()
+    assert torch.isfinite(yb[clean]).all() and torch.isfinite(ye[clean_e]).all()
+    assert float((yb[clean] - ye[clean]).abs().max()) < 2e-5 * float(ye[clean].abs().max())

@@ -1,7 +1,7 @@
 """Dev tool: the aligned dense-layer products (gemm2_kernel) with exact-fp32 matrix instructions or with the bf16 triple split
-(the default; TF_GEMM_SPLIT=0, read once per process, selects the exact-fp32 instruction): ms per product at the inner-light net's backward size, and the error of both against fp64
-on operands with a gradient-like scale.
-    [TF_GEMM_SPLIT=0] python tools/exp_gemm_split.py"""
+(ops.PREC_BF16X3, the training default; `exact` on the command line selects ops.PREC_F32, the exact-fp32 instruction): ms per product at
+the inner-light net's backward size, and the error of both against fp64 on operands with a gradient-like scale.
+    python tools/exp_gemm_split.py [exact]"""
 import os
 import sys
 
@@ -27,7 +27,9 @@ def timed(fn, n=20):
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    tag = "exact fp32" if os.environ.get("TF_GEMM_SPLIT") == "0" else "bf16x3 split"
+    exact = len(sys.argv) > 1 and sys.argv[1] == "exact"
+    tag = "exact fp32" if exact else "bf16x3 split"
+    ops.LINEAR_PRECISION = ops.PREC_F32 if exact else ops.PREC_BF16X3
     # accuracy: 8 192 rows, activations O(1), gradients at 1e-9 (a 1e-4 loss weight over 1e5 samples) with a heavy tail
     n, K, N = 8192, 256, 256
     x = torch.randn(n, K, generator=g)
