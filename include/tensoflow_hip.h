@@ -629,6 +629,15 @@ int tf_shape_glue_post_bwd(const float* mat, const float* nov, const float* diff
                            const float* g_color, const float* g_occ_prob, int64_t n, float* g_mat, float* g_nov, float* g_diffuse_light,
                            float* g_direct_light, float* g_indirect_light, float* g_occ_raw, tf_stream_t stream);
 
+/* F.normalize(x, dim=-1) of [n,3] rows in the training direction of render_core (network/shapeRenderer.py:1137 normals of the samples,
+ * :1145 the eikonal residual err [n] = (|x| - 1)^2 of the same rows, :1207-1208 the composited ray normal F.normalize(v acc + (1 - acc) c)):
+ * one launch each way.  acc [n] non-NULL (with blend_c, 3 HOST floats): the rows are x acc + (1 - acc) c.  err may be NULL.  The adjoint takes
+ * g_y [n,3] and / or g_err [n] (either may be NULL) and writes g_x [n,3] (and g_acc [n] with acc); conventions as torch autograd
+ * (x / eps below eps = 1e-12, zero gradient of the norm at x = 0). */
+int tf_normalize3_fwd(const float* x, const float* acc, const float* blend_c, int64_t n, float* y, float* err, tf_stream_t stream);
+int tf_normalize3_bwd(const float* x, const float* acc, const float* blend_c, const float* g_y, const float* g_err, int64_t n, float* g_x,
+                      float* g_acc, tf_stream_t stream);
+
 /* -----------------------------------------------------------------------------------
  * Dense layers of the training direction.  Replace torch.nn.Linear + activation -- the library GEMMs under the reference's
  * TensoSDF decoder (network/fields.py:78-81), make_predictor_3layer / _4layer (network/other_field.py:50-119: material
@@ -655,8 +664,10 @@ int tf_linear_bwd(const float* X, const float* W, const float* Y, const float* g
  * Linear + activation node after the other): tf_linear_bwd plus, in the same launches, the activation backward of the layer BELOW.
  * x_act / x_act_param: the activation that produced X (TF_ACT_NONE: X is no layer's output -- plain gX).  Then gX [n,K] receives
  * (gZ . W) * x_act'(X), the gradient wrt the PRE-activation of the layer below, and gbx [K] (or NULL) its column sums = that layer's
- * bias gradient.  gy_is_gz != 0: gY already is this layer's pre-activation gradient (the previous call's gX): no activation pass, Y and
- * gZ are not read, gb must be NULL (it was the previous call's gbx). */
+ * bias gradient.  gy_is_gz bit 0: gY already is this layer's pre-activation gradient (the previous call's gX): no activation pass, Y and
+ * gZ are not read, gb must be NULL (it was the previous call's gbx).  gy_is_gz bit 1 (TF_BWD_GRADS_ZEROED = 2): the caller has zeroed gW /
+ * gb / gbx (they are accumulated into with atomics) -- a chain zeroes ONE flat buffer for all its layers instead of three fills per layer. */
+#define TF_BWD_GRADS_ZEROED 2
 int tf_linear_bwd_fused(const float* X, const float* W, const float* Y, const float* gY, int64_t n, int32_t K, int32_t N, int32_t act,
                         float act_param, int32_t gy_is_gz, int32_t x_act, float x_act_param, int32_t precision, float* gZ, float* gX,
                         float* gW, float* gb, float* gbx, const int64_t* n_dev, tf_stream_t stream);

@@ -54,6 +54,18 @@ class MlpChainFn(torch.autograd.Function):
         hs, ws = saved[:L_ + 1], saved[L_ + 1:]
         grads = [None] * (2 * L_)
         g, is_gz = gy.contiguous(), False
+        # the weight / bias gradients of the whole stack are accumulated (atomics) into ONE buffer zeroed with one launch
+        # (every piece starts on a 256-byte boundary: the aligned dense-product kernels ask for 16-byte aligned operands)
+        up = lambda k: (k + 63) // 64 * 64
+        total = sum(up(w.numel()) + 2 * up(max(w.shape)) for w in ws)
+        pool = torch.zeros(total, dtype=torch.float32, device=gy.device)
+        used = [0]
+
+        def take(k):
+            out = pool[used[0]:used[0] + k]
+            used[0] += up(k)
+            assert used[0] <= total
+            return out
         for l in range(L_ - 1, -1, -1):
             below = l > 0
             need_gx = below or ctx.needs_input_grad[0]
@@ -61,7 +73,8 @@ class MlpChainFn(torch.autograd.Function):
                                                    x_act=acts[l - 1][0] if below else ops.ACT_NONE,
                                                    x_act_param=acts[l - 1][1] if below else 0.0, need_gx=need_gx,
                                                    need_gw=ctx.needs_input_grad[3 + 2 * l], need_gb=has_b[l] and ctx.needs_input_grad[4 + 2 * l],
-                                                   need_gbx=below and has_b[l - 1] and ctx.needs_input_grad[4 + 2 * (l - 1)], n_dev=n_dev)
+                                                   need_gbx=below and has_b[l - 1] and ctx.needs_input_grad[4 + 2 * (l - 1)], n_dev=n_dev,
+                                                   zeroed=take)
             grads[2 * l] = gw
             if not is_gz:
                 grads[2 * l + 1] = gb
@@ -152,6 +165,30 @@ def linear_to_srgb(lin, clamp01=False):
     from .encodings import linear_to_srgb as composed
     y = composed(lin)
     return y.clamp(0, 1) if clamp01 else y
+
+
+class Normalize3Fn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) of [n,3] rows -- optionally of the blend x acc + (1 - acc) c, optionally with the eikonal residual
+    (|x| - 1)^2 -- as one launch each way (render_core: the samples' normals + gradient_error, the composited ray normal)."""
+
+    @staticmethod
+    def forward(ctx, x, acc, blend_c, want_err):
+        ctx.set_materialize_grads(False)
+        y, err = ops.normalize3(x, acc, blend_c, want_err)
+        ctx.save_for_backward(x, acc)
+        ctx.blend_c = blend_c
+        if err is None:
+            err = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(err)
+        return y, err
+
+    @staticmethod
+    def backward(ctx, g_y, g_err):
+        x, acc = ctx.saved_tensors
+        if g_y is None and g_err is None:
+            return None, None, None, None
+        gx, ga = ops.normalize3(x, acc, ctx.blend_c, grads=(g_y, g_err))
+        return gx, (ga.reshape(acc.shape) if acc is not None else None), None, None
 
 
 class ShapeGluePreFn(torch.autograd.Function):

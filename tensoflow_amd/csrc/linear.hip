@@ -782,11 +782,13 @@ extern "C" int tf_linear_bwd_fused(const float* X, const float* W, const float* 
   TF_REQUIRE(act >= TF_ACT_NONE && act <= TF_ACT_EXP_CLAMP && x_act >= TF_ACT_NONE && x_act <= TF_ACT_EXP_CLAMP, TF_EINVAL,
              "tf_linear_bwd_fused: unknown activation %d / %d", act, x_act);
   TF_REQUIRE(W && (n == 0 || (X && gY && (gy_is_gz || (Y && gZ)))), TF_EINVAL, "tf_linear_bwd_fused: null pointer");
+  const bool zeroed = (gy_is_gz & TF_BWD_GRADS_ZEROED) != 0;      // the caller filled gW / gb / gbx with zeros (one fill for a whole chain)
+  gy_is_gz &= 1;
   TF_REQUIRE(!gy_is_gz || !gb, TF_EINVAL, "tf_linear_bwd_fused: with gy_is_gz the bias gradient came out of the previous call (gbx)");
   TF_REQUIRE(!gbx || gX, TF_EINVAL, "tf_linear_bwd_fused: gbx needs gX");
-  if (gW) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
-  if (gb) { hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
-  if (gbx) { hipError_t e = hipMemsetAsync(gbx, 0, sizeof(float) * (size_t)K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (gW && !zeroed) { hipError_t e = hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (gb && !zeroed) { hipError_t e = hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
+  if (gbx && !zeroed) { hipError_t e = hipMemsetAsync(gbx, 0, sizeof(float) * (size_t)K, stream); TF_REQUIRE(e == hipSuccess, TF_EHIP, "tf_linear_bwd_fused: memset failed"); }
   if (n == 0) return TF_OK;
   const float* gz = gY;
   if (!gy_is_gz) {

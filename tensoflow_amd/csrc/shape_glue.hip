@@ -251,3 +251,69 @@ extern "C" int tf_shape_glue_post_bwd(const float* mat, const float* nov, const 
   TF_LAUNCH_CHECK("tf_shape_glue_post_bwd");
   return TF_OK;
 }
+
+// ---- F.normalize(x, dim=-1) on [n,3] rows, optionally with the eikonal residual (|x| - 1)^2 (shapeRenderer.py:1137, :1145) and optionally
+// on the blend x = v a + (1 - a) c with a constant c (the composited ray normal, :1207-1208): one launch each way instead of the 3 + 15
+// (normalize), 3 + 8 (residual) and 7 + 15 (blend + normalize) element-wise launches of torch and its autograd.
+struct Norm3 {
+  const float* x; const float* acc; float c[3];      // acc non-NULL: rows are x acc + (1 - acc) c
+  long long n;
+  float* y; float* err;                              // forward (err may be NULL)
+  const float* g_y; const float* g_err;              // backward inputs (either may be NULL)
+  float* g_x; float* g_acc;                          // backward outputs (g_acc with acc only)
+};
+
+template <bool BWD>
+__global__ void __launch_bounds__(256) normalize3_kernel(Norm3 A) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.n) return;
+  float x0 = A.x[3 * i], x1 = A.x[3 * i + 1], x2 = A.x[3 * i + 2];
+  const float v0 = x0, v1 = x1, v2 = x2;
+  float a = 1.f;
+  if (A.acc) { a = A.acc[i]; x0 = x0 * a + (1.f - a) * A.c[0]; x1 = x1 * a + (1.f - a) * A.c[1]; x2 = x2 * a + (1.f - a) * A.c[2]; }
+  const float len = sqrtf(x0 * x0 + x1 * x1 + x2 * x2), den = fmaxf(len, 1e-12f);
+  const float y0 = x0 / den, y1 = x1 / den, y2 = x2 / den;
+  if (!BWD) {
+    A.y[3 * i] = y0; A.y[3 * i + 1] = y1; A.y[3 * i + 2] = y2;
+    if (A.err) A.err[i] = (len - 1.f) * (len - 1.f);
+    return;
+  }
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (A.g_y) {
+    const float a0 = A.g_y[3 * i], a1 = A.g_y[3 * i + 1], a2 = A.g_y[3 * i + 2];
+    if (len < 1e-12f) { g0 = a0 / den; g1 = a1 / den; g2 = a2 / den; }      // x / eps
+    else { const float d = a0 * y0 + a1 * y1 + a2 * y2; g0 = (a0 - y0 * d) / den; g1 = (a1 - y1 * d) / den; g2 = (a2 - y2 * d) / den; }
+  }
+  if (A.g_err && len > 0.f) {      // d (|x| - 1)^2 = 2 (|x| - 1) x / |x|   (torch's norm backward: 0 at x = 0)
+    const float k = A.g_err[i] * 2.f * (len - 1.f) / len;
+    g0 += k * x0; g1 += k * x1; g2 += k * x2;
+  }
+  if (A.acc) {
+    A.g_acc[i] = g0 * (v0 - A.c[0]) + g1 * (v1 - A.c[1]) + g2 * (v2 - A.c[2]);
+    g0 *= a; g1 *= a; g2 *= a;
+  }
+  A.g_x[3 * i] = g0; A.g_x[3 * i + 1] = g1; A.g_x[3 * i + 2] = g2;
+}
+
+extern "C" int tf_normalize3_fwd(const float* x, const float* acc, const float* blend_c, int64_t n, float* y, float* err, tf_stream_t stream) {
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_normalize3_fwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(x && y && (!acc || blend_c), TF_EINVAL, "tf_normalize3_fwd: null pointer (acc needs blend_c)");
+  Norm3 A{x, acc, {0.f, 0.f, 0.f}, n, y, err, nullptr, nullptr, nullptr, nullptr};
+  if (acc) for (int k = 0; k < 3; ++k) A.c[k] = blend_c[k];
+  normalize3_kernel<false><<<tf_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(A);
+  TF_LAUNCH_CHECK("tf_normalize3_fwd");
+  return TF_OK;
+}
+
+extern "C" int tf_normalize3_bwd(const float* x, const float* acc, const float* blend_c, const float* g_y, const float* g_err, int64_t n,
+                                 float* g_x, float* g_acc, tf_stream_t stream) {
+  TF_REQUIRE(n >= 0, TF_ESHAPE, "tf_normalize3_bwd: n < 0");
+  if (n == 0) return TF_OK;
+  TF_REQUIRE(x && g_x && (!acc || (blend_c && g_acc)), TF_EINVAL, "tf_normalize3_bwd: null pointer (acc needs blend_c and g_acc)");
+  Norm3 A{x, acc, {0.f, 0.f, 0.f}, n, nullptr, nullptr, g_y, g_err, g_x, g_acc};
+  if (acc) for (int k = 0; k < 3; ++k) A.c[k] = blend_c[k];
+  normalize3_kernel<true><<<tf_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(A);
+  TF_LAUNCH_CHECK("tf_normalize3_bwd");
+  return TF_OK;
+}

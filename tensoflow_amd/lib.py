@@ -82,6 +82,8 @@ SIGNATURES = {
     "tf_shape_glue_pre_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, f32, f32, i32, i64, c_f, c_f, c_f]),
     "tf_shape_glue_post_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i64, c_f, c_f, c_f]),
     "tf_shape_glue_post_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, c_f, c_f, i64, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "tf_normalize3_fwd": (C.c_int, [c_f, c_f, P(f32 * 3), i64, c_f, c_f, c_f]),
+    "tf_normalize3_bwd": (C.c_int, [c_f, c_f, P(f32 * 3), c_f, c_f, i64, c_f, c_f, c_f]),
     "tf_linear_fwd": (C.c_int, [c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, c_f, c_f, c_f]),
     "tf_linear_bwd": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_linear_bwd_fused": (C.c_int, [c_f, c_f, c_f, c_f, i64, i32, i32, i32, f32, i32, i32, f32, i32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -264,9 +264,9 @@ class ShapeRenderer(nn.Module):
         """shapeRenderer.py:1105-1277 (white background).  Output keys as the reference's: ray_rgb, gradient_error, acc, sample_num,
         normal, std, loss_sparse, loss_hessian (+ the validation keys when is_train is False)."""
         rn = rays_o.shape[0]
-        mid = (t_starts + t_ends) * 0.5
-        dists = t_ends - t_starts
         if self.alphaMask is not None:
+            mid = (t_starts + t_ends) * 0.5
+            dists = t_ends - t_starts
             pts = rays_o[ray_indices] + viewdirs[ray_indices] * mid[:, None]
             keep = self.alphaMask.sample_alpha(pts) > 0
             ray_indices, mid, dists = ray_indices[keep], mid[keep], dists[keep]
@@ -276,15 +276,22 @@ class ShapeRenderer(nn.Module):
             mid, dists, viewdir, points, levels = ops.sample_points(rays_o, viewdirs, radiis, rays_cos, ray_indices, t_starts, t_ends,
                                                                     self._base_radii_f)
         else:
+            if self.alphaMask is None:
+                mid, dists = (t_starts + t_ends) * 0.5, t_ends - t_starts
             viewdir = viewdirs[ray_indices]
             points = rays_o[ray_indices] + viewdir * mid[:, None]
             levels = torch.log2(self.compute_ball_radii(mid[:, None], radiis[ray_indices], rays_cos[ray_indices]) / self.base_radii)
         alpha, gradients, feat, inv_s, sdf, hessian = self.compute_sdf_alpha(points, levels, dists, viewdir, cos_anneal_ratio, step, is_train)
-        normals = F.normalize(gradients, dim=-1)
+        fused_norm = gradients.is_cuda and gradients.dtype == torch.float32
+        if fused_norm:      # F.normalize + the eikonal residual (:1137, :1145) in one launch each way (round 6: 6 + 26 element-wise launches before)
+            from ..autograd import Normalize3Fn
+            normals, gradient_error = Normalize3Fn.apply(gradients.contiguous(), None, None, True)
+        else:
+            normals = F.normalize(gradients, dim=-1)
+            gradient_error = (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2
         # (per-sample capturer poses, shapeRenderer.py:1139: read by the human_light variant of the shading only)
         poses_pt = human_poses[ray_indices] if (human_poses is not None and self.color_network.cfg["human_light"]) else None
         color, radiance, occ_info = self.color_network(points, normals, -viewdir, feat, poses_pt, step=step)
-        gradient_error = (torch.linalg.norm(gradients, ord=2, dim=-1) - 1.0) ** 2
         zero = torch.zeros(1, device=rays_o.device)
         vals = [color, gradients] + ([radiance, occ_info["roughness"]] if radiance is not None else [])
         vals = torch.cat(vals, -1).contiguous()
@@ -300,7 +307,10 @@ class ShapeRenderer(nn.Module):
         rgb = out[:, :3]
         if self.cfg["isBGWhite"]:
             rgb = rgb + (1 - acc)
-        normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * _const3(0.0, 0.0, 1.0, rays_o.device), dim=-1)
+        if fused_norm:      # the composited ray normal (:1207-1208): blend with (0, 0, 1) by the opacity + F.normalize, one launch each way
+            normal = Normalize3Fn.apply(out[:, 3:6].contiguous(), acc, (0.0, 0.0, 1.0), False)[0]
+        else:
+            normal = F.normalize(out[:, 3:6] * acc + (1.0 - acc) * _const3(0.0, 0.0, 1.0, rays_o.device), dim=-1)
         outputs = {"ray_rgb": rgb, "gradient_error": gradient_error, "acc": acc, "sample_num": N / max(rn, 1), "normal": normal,
                    "std": torch.mean(1 / inv_s) if N > 0 else zero}
         if radiance is not None:                                   # has_radiance_field and step > radiance_field_step (:1195-1206)

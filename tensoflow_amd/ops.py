@@ -439,6 +439,28 @@ def shape_glue_pre(normals, view, mat, grads=None, mip_levels=None):
     return gn, gm
 
 
+def normalize3(x, acc=None, blend_c=None, want_err=False, grads=None):
+    """tf_normalize3_fwd: F.normalize of [n,3] rows (of x acc + (1 - acc) blend_c with acc [n]) -> (y [n,3], err [n] = (|x| - 1)^2 or None);
+    with grads = (g_y or None, g_err or None) tf_normalize3_bwd: -> (g_x [n,3], g_acc [n] or None)."""
+    x = _f(x)
+    n = x.shape[0]
+    if x.shape != (n, 3) or (acc is not None and (acc.numel() != n or blend_c is None)):
+        raise RuntimeError(f"normalize3: x {tuple(x.shape)}, acc {None if acc is None else tuple(acc.shape)}")
+    acc = _f(acc) if acc is not None else None
+    c = (C.c_float * 3)(*[float(v) for v in blend_c]) if blend_c is not None else None
+    dev = x.device
+    if grads is None:
+        y = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        err = torch.empty(n, dtype=torch.float32, device=dev) if want_err else None
+        L.check(L.load().tf_normalize3_fwd(_p(x), _p(acc), c, n, _p(y), _p(err), _stream()), "tf_normalize3_fwd")
+        return y, err
+    gy, ge = (None if t is None else _f(t) for t in grads)
+    gx = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ga = torch.empty(n, dtype=torch.float32, device=dev) if acc is not None else None
+    L.check(L.load().tf_normalize3_bwd(_p(x), _p(acc), c, _p(gy), _p(ge), n, _p(gx), _p(ga), _stream()), "tf_normalize3_bwd")
+    return gx, ga
+
+
 def shape_glue_post(mat, nov, diffuse_light, direct_light, indirect_light, occ_raw, fg_lut, grads=None):
     """tf_shape_glue_post_fwd: -> (color [n,3], occ_prob [n,1]); with grads = (g_color, g_occ_prob or None) tf_shape_glue_post_bwd:
     -> (g_mat [n,5], g_nov [n,1], g_diffuse_light, g_direct_light, g_indirect_light [n,3], g_occ_raw [n,1]).  fg_lut [.., H, W, 2]."""
@@ -577,9 +599,11 @@ def linear_bwd(x, w, y, gy, act=ACT_NONE, act_param=0.0, need_gx=True, need_gw=T
 
 
 def linear_bwd_fused(x, w, y, gy, act=ACT_NONE, act_param=0.0, gy_is_gz=False, x_act=ACT_NONE, x_act_param=0.0, need_gx=True,
-                     need_gw=True, need_gb=True, need_gbx=False, n_dev=None, precision=None):
+                     need_gw=True, need_gb=True, need_gbx=False, n_dev=None, precision=None, zeroed=None):
     """One layer of a backward chain (tf_linear_bwd_fused) -> (gx, gw, gb, gbx).  With x_act the returned gx is the gradient wrt the
-    PRE-activation of the layer below (whose output x is) and gbx that layer's bias gradient; pass it on with gy_is_gz=True."""
+    PRE-activation of the layer below (whose output x is) and gbx that layer's bias gradient; pass it on with gy_is_gz=True.
+    zeroed: a callable n_floats -> zero-filled float tensor carved out of ONE buffer the caller filled once for the whole chain
+    (TF_BWD_GRADS_ZEROED: no fill launches in here)."""
     lib = L.load()
     x, w, gy = _f(x), _f(w), _f(gy)
     n, K = x.shape
@@ -587,11 +611,12 @@ def linear_bwd_fused(x, w, y, gy, act=ACT_NONE, act_param=0.0, gy_is_gz=False, x
     y = None if gy_is_gz else _f(y)
     gz = None if gy_is_gz else torch.empty(n, N, device=x.device)
     gx = torch.empty(n, K, device=x.device) if need_gx else None
-    gw = torch.empty(N, K, device=x.device) if need_gw else None
-    gb = torch.empty(N, device=x.device) if (need_gb and not gy_is_gz) else None
-    gbx = torch.empty(K, device=x.device) if (need_gbx and need_gx) else None
+    new = (lambda k: zeroed(k)) if zeroed is not None else (lambda k: torch.empty(k, device=x.device))
+    gw = new(N * K).view(N, K) if need_gw else None
+    gb = new(N) if (need_gb and not gy_is_gz) else None
+    gbx = new(K) if (need_gbx and need_gx) else None
     L.check(lib.tf_linear_bwd_fused(_p(x), _p(w), _p(y) if y is not None else None, _p(gy), n, K, N, int(act), float(act_param),
-                                    1 if gy_is_gz else 0, int(x_act), float(x_act_param),
+                                    (1 if gy_is_gz else 0) | (2 if zeroed is not None else 0), int(x_act), float(x_act_param),
                                     int(LINEAR_PRECISION if precision is None else precision), _p(gz) if gz is not None else None,
                                     _p(gx) if gx is not None else None, _p(gw) if gw is not None else None,
                                     _p(gb) if gb is not None else None, _p(gbx) if gbx is not None else None,
@@ -807,10 +832,14 @@ def cube_lookup_mips_bwd(texs, dirs, mip, g_out, apply_exp=True, want_texs=True,
     m = dirs.shape[0]
     if dirs.shape != (m, 3) or mip.numel() != m or g_out.shape != (m, 3):
         raise RuntimeError(f"cube_lookup_mips_bwd: dirs / g_out [m,3] and mip [m], got {tuple(dirs.shape)}, {tuple(g_out.shape)}, {mip.numel()}")
-    g_texs = [torch.zeros_like(t) for t in texs] if want_texs else None
+    # ONE zero-filled buffer carved into the gradient arrays (the kernel accumulates with atomics): one fill launch instead of n + 2
+    sizes = ([t.numel() for t in texs] if want_texs else []) + ([3 * m] if want_dirs else []) + ([m] if want_mip else [])
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dirs.device)
+    parts = list(torch.split(flat, sizes)) if sizes else []
+    g_texs = [parts.pop(0).view_as(t) for t in texs] if want_texs else None
     gptrs = (C.c_void_p * n)(*[t.data_ptr() for t in g_texs]) if want_texs else None
-    g_dirs = torch.zeros(m, 3, dtype=torch.float32, device=dirs.device) if want_dirs else None
-    g_mip = torch.zeros(m, dtype=torch.float32, device=dirs.device) if want_mip else None
+    g_dirs = parts.pop(0).view(m, 3) if want_dirs else None
+    g_mip = parts.pop(0) if want_mip else None
     L.check(L.load().tf_cube_lookup_mips_bwd(ptrs, res, n, _p(dirs), _p(mip), m, int(apply_exp), _p(g_out), gptrs, _p(g_dirs), _p(g_mip),
                                              _stream()), "tf_cube_lookup_mips_bwd")
     return g_texs, g_dirs, g_mip

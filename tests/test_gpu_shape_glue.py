@@ -130,3 +130,38 @@ def test_shape_glue_mip_coordinate_equals_envlight_get_mip():
     assert float((mip - ref).abs().max()) < 1e-5
     same = (m1.grad[:, 3] - m2.grad[:, 3]).abs() <= 1e-4 * m2.grad[:, 3].abs().max()
     assert float(same.float().mean()) > 0.998 and float(m1.grad[:, [0, 1, 2, 4]].abs().max()) == 0.0      # (rows within rounding of a branch point may differ)
+
+
+def test_normalize3_values_and_gradients_against_torch():
+    """tf_normalize3_*: F.normalize of [n,3] rows with the eikonal residual, and of the opacity blend with a constant, against torch in fp64
+    (rows of length 0, below the eps, ~1 and large)."""
+    from tensoflow_amd.autograd import Normalize3Fn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    n = 10000
+    x = (torch.randn(n, 3, generator=g) * torch.exp(2 * torch.randn(n, 1, generator=g))).to(dev)
+    x[:10] = 0.0
+    x[10:20] *= 1e-14
+    acc = torch.rand(n, 1, generator=g).to(dev)
+    acc[20:30] = 0.0
+    wy, we = torch.randn(n, 3, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    c = (0.0, 0.0, 1.0)
+    for blend in (False, True):
+        xs = x.clone().requires_grad_(True)
+        a_ = acc.clone().requires_grad_(True) if blend else None
+        y, err = Normalize3Fn.apply(xs, a_, c if blend else None, not blend)
+        ((y * wy).sum() + ((err * we).sum() if not blend else 0.0)).backward()
+        xt = x.double().clone().requires_grad_(True)
+        at = acc.double().clone().requires_grad_(True)
+        xb = xt * at + (1 - at) * torch.tensor(c, device=dev, dtype=torch.float64) if blend else xt
+        yt = F.normalize(xb, dim=-1)
+        et = (torch.linalg.norm(xb, ord=2, dim=-1) - 1.0) ** 2
+        ((yt * wy.double()).sum() + ((et * we.double()).sum() if not blend else 0.0)).backward()
+        assert float((y - yt).abs().max()) < 1e-6, blend
+        if not blend:
+            assert float(((err - et).abs() / et.abs().clamp_min(1.0)).max()) < 1e-5
+        big = xt.grad.abs().amax(-1) < 1e9              # (rows below the eps have gradients of 1e12: compared relatively)
+        rel = (xs.grad - xt.grad).abs().amax(-1) / xt.grad.abs().amax(-1).clamp_min(1e-6)
+        assert float(rel[big].max()) < 1e-4 and float(rel.max()) < 1e-3, (blend, float(rel[big].max()), float(rel.max()))
+        if blend:
+            assert float(((a_.grad - at.grad).abs() / at.grad.abs().clamp_min(1.0)).max()) < 1e-4
