@@ -98,8 +98,14 @@ __device__ __forceinline__ void load_chunk(const int* __restrict__ geo, const fl
   r.t10 = vm_texel4<TEX16>(packed, pb + (unsigned)((y0 * W + x1) * SDF_C));
   r.t01 = vm_texel4<TEX16>(packed, pb + (unsigned)((y1 * W + x0) * SDF_C));
   r.t11 = vm_texel4<TEX16>(packed, pb + (unsigned)((y1 * W + x1) * SDF_C));
+#ifdef SDF_ABLATE_LINES   // dev-only timing ablation (tools/exp_march_lines.py; results are garbage): the two line taps of a chunk are NOT fetched --
+  // the upper bound of what staging the line factors in LDS (north_star) could return, since an LDS read is not free either
+  r.s0 = make_float4(1.f, 1.f, 1.f, 1.f); r.s1 = r.s0;
+  (void)lb; (void)z0; (void)z1;
+#else
   r.s0 = vm_texel4<TEX16>(packed, lb + (unsigned)(z0 * SDF_C));
   r.s1 = vm_texel4<TEX16>(packed, lb + (unsigned)(z1 * SDF_C));
+#endif
 }
 
 // The blend of a chunk, written on PAIRS of channels (xy | zw of the 16-byte texel segments) so that every multiply-add is one packed
