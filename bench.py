@@ -83,7 +83,8 @@ def compact_line(line):
             out["config"][k] = out["config"][k][:200]
     if isinstance(line.get("roofline"), dict):
         out["roofline"] = _pick(line["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
-                                                   "executed_tflops", "frac_executed", "sustained_mfma_tflops", "frac_executed_of_sustained"))
+                                                   "executed_tflops", "frac_executed", "sustained_mfma_tflops", "frac_executed_of_sustained",
+                                                   "sustained_mfma_tflops_relu_operands", "frac_executed_of_sustained_relu_operands"))
     # the inner-light and traversal kernels take the same time within a few per cent from round 4 on: whichever is NOT the dominant
     # one of this run is carried beside it, so that the line always holds the matrix-core kernel's figures
     ro = line.get("roofline_other")
@@ -1013,10 +1014,11 @@ def main():
         hit_frac = hits / max(1, pn * (2 * S + 512) * args.steps)
         traced_per_step = int(live_rays.item())
         live_frac = traced_per_step / max(1, pn * (2 * S + 512))
-        sustained = None
+        sustained = sustained_relu = None
         if args.precision == "f16x3":
             try:
                 sustained = _ops.probe_mfma_f16_tflops(200000, device)
+                sustained_relu = _ops.probe_mfma_f16_tflops(200000, device, relu_like=True)
             except Exception as e:
                 print(f"tf_probe_mfma_f16 failed: {e}", file=sys.stderr)
         if dom == "inner_light":
@@ -1033,6 +1035,10 @@ def main():
                         # (tf_probe_mfma_f16, measured in this run, after the timed region): the part lowers its clock under that load, so
                         # the spec peak is not a rate any kernel reaches; `frac_executed_of_sustained` is the kernel against that ceiling
                         sustained_mfma_tflops=sustained, frac_executed_of_sustained=(executed / sustained) if sustained else None,
+                        # ... and with the kernel's own operand statistics (activations behind a ReLU: half zero -- the part holds a higher
+                        # clock when the multipliers toggle less): the ceiling the kernel's remaining non-matrix cycles are measured against
+                        sustained_mfma_tflops_relu_operands=sustained_relu,
+                        frac_executed_of_sustained_relu_operands=(executed / sustained_relu) if sustained_relu else None,
                         per_launch=f"{hits // max(1, n_launch)} hit rays x {FLOP_PER_HIT_RAY} algorithmic flop "
                                    f"({'f16 MFMA operands, fp32 accumulate, ' + str(terms) + ' MFMA per product term; peak = dense f16; executed = MFMA instructions issued' if args.precision == 'f16x3' else 'exact fp32 MFMA'})")
         elif dom == "flow_sample":

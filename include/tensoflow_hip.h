@@ -76,8 +76,10 @@ int tf_set_launch_budget(int32_t bvh_blocks_per_cu, int32_t flow_waves_per_block
  * three product terms, operands re-read from LDS, pseudo-random f16 data, one wave per SIMD on every CU) for `iters` iterations per
  * wave, SYNCHRONOUSLY (it times itself with HIP events on `stream`), and returns the executed TFLOP/s in *tflops_host: the rate the
  * matrix cores of THIS device hold under that load (the part lowers its clock: ~1.5-1.6 PFLOP/s against the 2.5 PFLOP/s quoted).
+ * relu_like != 0: the B operands (the "activations") are ReLU outputs -- about half of them zero, as in the decoder's hidden layers; the
+ * clock the part holds depends on what the multipliers toggle, so this is the ceiling for the decoder's own operand statistics.
  * scratch: device buffer of >= 256 floats per CU (written). */
-int tf_probe_mfma_f16(int32_t iters, float* scratch, int64_t scratch_floats, double* tflops_host, tf_stream_t stream);
+int tf_probe_mfma_f16(int32_t iters, int32_t relu_like, float* scratch, int64_t scratch_floats, double* tflops_host, tf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * VM-decomposed tensorial field (3 planes + 3 lines, C components each).

@@ -10,7 +10,7 @@
 typedef _Float16 pr_h8 __attribute__((ext_vector_type(8)));
 typedef float pr_f16v __attribute__((ext_vector_type(16)));
 
-static __global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, float* __restrict__ out) {
+static __global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, int relu_like, float* __restrict__ out) {
   __shared__ pr_h8 frag[4096];      // 64 KB
   for (int i = threadIdx.x; i < 4096; i += 256) {
     pr_h8 v;
@@ -18,7 +18,11 @@ static __global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, float
     for (int e = 0; e < 8; ++e) {
       unsigned s = (unsigned)(i * 8 + e) * 2654435761u + 12345u;       // integer hash -> values in (-1, 1)
       s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
-      v[e] = (_Float16)(((float)(s & 0xffffu) - 32768.f) * (1.f / 32768.f));
+      float x = ((float)(s & 0xffffu) - 32768.f) * (1.f / 32768.f);
+      // relu_like: the B operands (fragments 256.. of every 512-fragment slab: the "activations") are ReLU outputs -- the negative half
+      // is zero, as in the decoder's hidden layers (the part's clock under an MFMA stream depends on what the multipliers toggle)
+      if (relu_like && ((i & 511) >= 256) && x < 0.f) x = 0.f;
+      v[e] = (_Float16)x;
     }
     frag[i] = v;
   }
@@ -56,7 +60,7 @@ static __global__ void __launch_bounds__(256) probe_mfma_kernel(int iters, float
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-extern "C" int tf_probe_mfma_f16(int32_t iters, float* scratch, int64_t scratch_floats, double* tflops_host, tf_stream_t stream_) {
+extern "C" int tf_probe_mfma_f16(int32_t iters, int32_t relu_like, float* scratch, int64_t scratch_floats, double* tflops_host, tf_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TF_REQUIRE(iters > 0 && scratch && tflops_host, TF_EINVAL, "tf_probe_mfma_f16: iters <= 0 or null pointer");
   int dev = 0;
@@ -66,9 +70,9 @@ extern "C" int tf_probe_mfma_f16(int32_t iters, float* scratch, int64_t scratch_
   TF_REQUIRE(scratch_floats >= 256LL * cus, TF_ESHAPE, "tf_probe_mfma_f16: scratch needs 256 floats per CU (%d CUs)", cus);
   hipEvent_t e0, e1;
   TF_REQUIRE(hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess, TF_EHIP, "tf_probe_mfma_f16: hipEventCreate failed");
-  probe_mfma_kernel<<<cus, 256, 0, stream>>>(iters / 8 + 1, scratch);        // settle the clock under this load
+  probe_mfma_kernel<<<cus, 256, 0, stream>>>(iters / 8 + 1, relu_like, scratch);        // settle the clock under this load
   hipEventRecord(e0, stream);
-  probe_mfma_kernel<<<cus, 256, 0, stream>>>(iters, scratch);
+  probe_mfma_kernel<<<cus, 256, 0, stream>>>(iters, relu_like, scratch);
   hipEventRecord(e1, stream);
   hipError_t e = hipEventSynchronize(e1);
   float ms = 0.f;

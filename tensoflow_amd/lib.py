@@ -59,7 +59,7 @@ SIGNATURES = {
     "tf_version": (C.c_int, []),
     "tf_last_error": (C.c_char_p, []),
     "tf_set_launch_budget": (C.c_int, [i32, i32, i32]),
-    "tf_probe_mfma_f16": (C.c_int, [i32, c_f, i64, P(C.c_double), c_f]),
+    "tf_probe_mfma_f16": (C.c_int, [i32, i32, c_f, i64, P(C.c_double), c_f]),
     "tf_vm_packed_floats": (sz, [P(TfVmDesc)]),
     "tf_vm_pack_fwd": (C.c_int, [P(TfVmDesc), P(F3), P(F3), c_f, c_f]),
     "tf_vm_pack_to_f16": (C.c_int, [P(TfVmDesc), c_f, c_f, c_f]),

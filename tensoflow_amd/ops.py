@@ -147,14 +147,15 @@ def set_launch_budget(bvh_blocks_per_cu=0, flow_waves_per_block=0, inner_teams=0
     L.check(L.load().tf_set_launch_budget(int(bvh_blocks_per_cu), int(flow_waves_per_block), int(inner_teams)), "tf_set_launch_budget")
 
 
-def probe_mfma_f16_tflops(iters=200000, device=None):
+def probe_mfma_f16_tflops(iters=200000, device=None, relu_like=False):
     """tf_probe_mfma_f16: executed TFLOP/s the matrix cores of this device sustain on a dense v_mfma_f32_32x32x16_f16 stream with random
-    operands (synchronous; ~0.2 s at the default).  A measurement aid of bench.py's roofline figures, never on a product path."""
+    operands (relu_like: the activation operands half zero, as behind a ReLU) (synchronous; ~0.2 s at the default).  A measurement aid
+    of bench.py's roofline figures, never on a product path."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     n = 256 * torch.cuda.get_device_properties(dev).multi_processor_count
     scratch = torch.empty(n, dtype=torch.float32, device=dev)
     out = C.c_double(0.0)
-    L.check(L.load().tf_probe_mfma_f16(int(iters), _p(scratch), n, C.byref(out), _stream()), "tf_probe_mfma_f16")
+    L.check(L.load().tf_probe_mfma_f16(int(iters), int(bool(relu_like)), _p(scratch), n, C.byref(out), _stream()), "tf_probe_mfma_f16")
     return float(out.value)
 
 
