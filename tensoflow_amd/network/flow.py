@@ -49,9 +49,17 @@ class TensoFlow(nn.Module):
                  nis_multires=3, refl_multires=3, roughness_multires=3, angle_multires=3, flow="pwquad", n_bins=10,
                  disable_tensorial=False, disable_reflected=False):
         super().__init__()
-        if flow != "pwquad" or d != 2 or n_bins != 10 or nis_dim != 64 or nis_feature_dim != 16 or \
+        from .flow_transforms import TRANSFORMS
+        if flow not in TRANSFORMS or d != 2 or int(n_bins) < 2 or nis_dim != 64 or nis_feature_dim != 16 or \
                 (nis_multires, refl_multires, roughness_multires, angle_multires) != (3, 3, 3, 3):
-            raise NotImplementedError("the HIP kernels instantiate the reference default: d=2, 'pwquad', 10 bins, 64/16 dims")
+            # 'realnvp' (flow.py:645: Gaussian prior, affine couplings, an analytic-sigmoid output cell) is not built
+            raise NotImplementedError("TensoFlow: d=2, flow in ('pwquad', 'pwlinear'), n_bins >= 2, 64/16 dims, 3 octaves per embedding")
+        # The fused HIP kernels instantiate the reference default ('pwquad', 10 bins: what every shipped config runs).  Any other
+        # (flow, n_bins) is evaluated by a differentiable COMPOSITION (flow_transforms.py: torch ops on the device around the HIP VM gather
+        # and dense layers) -- correct, not fast; round 6.
+        self.flow_kind, self.n_bins = flow, int(n_bins)
+        self._fused = flow == "pwquad" and int(n_bins) == 10
+        self._sample_fn, self._density_fn, bin_fn = TRANSFORMS[flow]
         self.nis_n_comp, self.nis_dim, self.nis_feature_dim = nis_n_comp, nis_dim, nis_feature_dim
         self.device = device
         self.matMode, self.vecMode = [[0, 1], [0, 2], [1, 2]], [2, 1, 0]
@@ -70,7 +78,7 @@ class TensoFlow(nn.Module):
                                      nn.Linear(nis_dim, nis_feature_dim)).to(device)
         self.refl_input_ch, self.roughness_input_ch = 14, 7
         feature_dim = nis_feature_dim + self.refl_input_ch + self.roughness_input_ch
-        self.flows = nn.ModuleList([Block(d, [(i + off) % 2 == 0 for i in range(d)], feature_dim, n_bins=2 * n_bins + 1)
+        self.flows = nn.ModuleList([Block(d, [(i + off) % 2 == 0 for i in range(d)], feature_dim, n_bins=bin_fn(int(n_bins)))
                                     for off in range(2)]).to(device)
         self.disable_tensorial, self.disable_reflected = disable_tensorial, disable_reflected
         self._packed = None
@@ -112,17 +120,75 @@ class TensoFlow(nn.Module):
             refl = torch.zeros_like(refl)
         return torch.cat([feature, refl, torch.zeros(pts.shape[0], 7, device=pts.device)], -1).contiguous()
 
+    # ---- the composition that serves every (flow, n_bins) the fused kernels do not instantiate
+    def _coupling_net(self, blk, keep, cond):
+        """Block.nn on [embed3(kept coordinate), condition row] (flow.py:600-609): Reshift, then Linear + LeakyReLU x 3, Linear."""
+        from ..autograd import LinearActFn
+        h = blk.nn[0](torch.cat([posenc(keep, 3), cond], -1)).contiguous()
+        for l in (1, 3, 5):
+            h = torch.nn.functional.leaky_relu(LinearActFn.apply(h, blk.nn[l].weight, blk.nn[l].bias, ops.ACT_NONE, 0.0, None), 0.01)
+        return LinearActFn.apply(h.contiguous(), blk.nn[7].weight, blk.nn[7].bias, ops.ACT_NONE, 0.0, None)
+
+    def _composed_blocks(self, y, logj, cond, sampling):
+        """TensoFlow.flow / flow_inv (flow.py:766-799) over rows y [M,2], cond [M,37]: the blocks in order with the sampling transform, in
+        reverse order with the density transform.  -> (y, logj, bins [M,2] int64: column b = the bin block b picked)."""
+        bins = torch.zeros(y.shape[0], 2, dtype=torch.long, device=y.device)
+        order = list(enumerate(self.flows)) if sampling else list(enumerate(self.flows))[::-1]
+        for bi, blk in order:
+            mask = torch.tensor(blk.mask, device=y.device)
+            keep, move = y[:, mask], y[:, ~mask]
+            st = self._coupling_net(blk, keep, cond).view(y.shape[0], move.shape[1], -1)
+            new, lj, idx = (self._sample_fn if sampling else self._density_fn)(move, st)
+            out = torch.zeros_like(y)
+            out[:, mask] = keep
+            out[:, ~mask] = new
+            y, logj = out, logj + lj
+            bins[:, bi] = idx[:, 0]
+        return y, logj, bins
+
+    def _composed_sample(self, pts, view_angles, n_samples, jitter=None):
+        """sample() as a composition: SphereSampler (flow.py:52-90) -> the blocks with the sampling transform."""
+        pn = pts.shape[0]
+        x = sphere_latent_on(n_samples, pts.device)[None].expand(pn, n_samples, 2)
+        if jitter is not None:
+            x = torch.cat([(x[..., :1] + jitter[..., None]) % 1, x[..., 1:]], -1)
+        x = x.clamp(1e-6, 1 - 1e-6)
+        logj = -torch.cos(x[..., 1:] * (0.5 * np.pi)).log()
+        cond = self._condition(pts, view_angles)[:, None].expand(pn, n_samples, 37).reshape(-1, 37)
+        y, lj, bins = self._composed_blocks(x.reshape(-1, 2), logj.reshape(-1, 1), cond, sampling=True)
+        self.last_bins = bins.view(pn, n_samples, 2)
+        return y.view(pn, n_samples, 2), lj.view(pn, n_samples, 1)
+
+    def _composed_forward(self, pts, reflections, x, rays_id):
+        """forward() as a composition (flow.py:801-831): the blocks in reverse with the density transform, + log prior of z."""
+        cond = self._condition(pts, reflections)
+        shape = x.shape[:-1]
+        if rays_id is not None:
+            cond_rows = cond[rays_id]
+        else:
+            cond_rows = cond[:, None].expand(*shape, 37).reshape(-1, 37) if x.dim() == 3 else cond
+        xr = x.clamp(1e-6, 1 - 1e-6).reshape(-1, 2)
+        z, lj, bins = self._composed_blocks(xr, torch.zeros(xr.shape[0], 1, device=xr.device), cond_rows, sampling=False)
+        self.last_bins = bins.view(*shape, 2)
+        logq = lj + torch.cos(z[:, 1:] * (0.5 * np.pi)).log()
+        return z.view(*shape, 2), logq.view(*shape, 1)
+
     @torch.no_grad()
     def _sample_nograd(self, pts, view_angles, n_samples, jitter=None):
         """sample() for a frozen copy (fields.py:1054-1065): angles [pn,sn,2], logq [pn,sn,1]."""
+        if not self._fused:
+            return self._composed_sample(pts, view_angles, n_samples, jitter)
         cond = self._condition(pts, view_angles)
         return ops.flow_sample(self._nets(), cond, sphere_latent_on(n_samples, pts.device), jitter, precision=ops.PREC_F16X3)
 
     # ---- reference API
     def sample(self, pts, reflections, roughness, n_samples, return_jacobian=False):
         """flow.py:833-855 -> angles [pn,sn,2] (, logj [pn,sn,1])."""
-        _check_no_grad(self, "TensoFlow.sample")
         jitter = torch.rand(pts.shape[0], n_samples, device=pts.device) if self.training else None   # flow.py:86-87
+        if not self._fused:
+            ang, logj = self._composed_sample(pts, reflections, n_samples, jitter)
+            return (ang, logj) if return_jacobian else ang
+        _check_no_grad(self, "TensoFlow.sample")
         ang, logj = ops.flow_sample(self._nets(), self._condition(pts, reflections), sphere_latent_on(n_samples, pts.device), jitter)
         return (ang, logj) if return_jacobian else ang
 
@@ -130,6 +196,9 @@ class TensoFlow(nn.Module):
         """flow.py:801-831 -> z (, logqx).  Differentiable wrt every parameter of the flow (the NIS loss path):
         forward and backward are fused HIP kernels (autograd.FlowLogqFn / VmGatherFn); the 57-64-16 feature net runs on the
         HIP dense-layer kernels (autograd.mlp_apply)."""
+        if not self._fused:
+            z, logq = self._composed_forward(pts, reflections, x, rays_id)
+            return (z, logq) if return_jacobian else z
         cond = self._condition(pts, reflections)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             wb = []

@@ -169,6 +169,57 @@ def gen_flow():
     save("tensoflow_r32", sd=net.state_dict(), bwd_w=w, **arrays, **grads)
 
 
+def gen_flow_variants():
+    """TensoFlow outside the reference default (flow.py:644-648: flow='pwlinear'; n_bins != 10), the configurations the build evaluates
+    by composition: the element-wise transforms on random net outputs (with edge rows) and the whole module -- sample, density of the
+    samples and of arbitrary points (with and without rays_id), parameter gradients of an NIS-style loss."""
+    from network.flow import ElementWisePWLinearTransform, ElementWisePWQuadraticTransform, TensoFlow
+    g = torch.Generator().manual_seed(77)
+    arrays = {}
+    M = 1024
+    for name, T, width in (("pwlinear_b10", ElementWisePWLinearTransform(), 10), ("pwlinear_b7", ElementWisePWLinearTransform(), 7),
+                           ("pwquad_b6", ElementWisePWQuadraticTransform(), 13), ("pwquad_b16", ElementWisePWQuadraticTransform(), 33)):
+        st = torch.randn(M, 1, width, generator=g) * 1.5
+        y = torch.rand(M, 1, generator=g)
+        y[:8, 0] = torch.tensor([1e-6, 1 - 1e-6, 0.5, 1e-3, 0.999, 0.25, 0.75, 0.1])
+        st[8:16] = 0.0
+        st[16:24, 0, -1] = 8.0
+        st[24:32, 0, 0] = -12.0
+        x, lj = T.flow(y, st, True)
+        o, lji = T.flow_inv(y, st, True)
+        arrays.update({f"t/{name}/st": st[:, 0], f"t/{name}/y": y[:, 0], f"t/{name}/sample_x": x[:, 0], f"t/{name}/sample_logj": lj[:, 0],
+                       f"t/{name}/density_out": o[:, 0], f"t/{name}/density_logj": lji[:, 0]})
+    pn = 40
+    pts = torch.rand(pn, 3, generator=g) * 1.6 - 0.8
+    va = torch.rand(pn, 2, generator=g)
+    rough = torch.rand(pn, 1, generator=g)
+    arrays.update(pts=pts, view_angles=va, roughness=rough)
+    for tag, kw in (("pwlinear", dict(flow="pwlinear", n_bins=10)), ("pwquad6", dict(flow="pwquad", n_bins=6))):
+        torch.manual_seed(11)
+        net = TensoFlow(2, AABB, device="cpu", gridSize=[32, 32, 32], **kw)
+        perturb_(list(net.nis_plane) + list(net.nis_line), 0.1, 3)
+        perturb_([p for n, p in net.flows.named_parameters() if "weight" in n], 0.05, 5)
+        net.eval()
+        with torch.no_grad():
+            ang, logj = net.sample(pts, va, rough, 32, return_jacobian=True)
+            z, logq = net(pts, va, rough, ang, return_jacobian=True)
+            x = torch.rand(pn, 16, 2, generator=g)
+            zx, lqx = net(pts, va, rough, x, return_jacobian=True)
+            rid = torch.sort(torch.randint(0, pn, (200,), generator=g)).values
+            xr = torch.rand(200, 2, generator=g)
+            zr, lqr = net(pts, va, rough, xr, return_jacobian=True, rays_id=rid)
+        w = torch.rand(pn, 16, 1, generator=g)
+        net.zero_grad()
+        _, lq = net(pts, va, rough, x, return_jacobian=True)
+        (-(w * lq).mean()).backward()
+        arrays.update({f"{tag}/angles": ang, f"{tag}/logj": logj, f"{tag}/z": z, f"{tag}/logq": logq, f"{tag}/x_rand": x, f"{tag}/z_rand": zx,
+                       f"{tag}/logq_rand": lqx, f"{tag}/rays_id": rid, f"{tag}/x_rid": xr, f"{tag}/z_rid": zr, f"{tag}/logq_rid": lqr,
+                       f"{tag}/bwd_w": w})
+        arrays.update({f"{tag}/sd/" + k: v for k, v in net.state_dict().items()})
+        arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    save("tensoflow_variants", **arrays)
+
+
 def gen_encodings():
     from utils.network_utils import get_embedder
     from utils.ref_utils import generate_ide_fn
@@ -1142,7 +1193,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
