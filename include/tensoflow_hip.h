@@ -558,6 +558,15 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
                                                           as ITS samples exist, while the next set is still being sampled; the
                                                           sample arrays of sets outside the range are not read */,
                   tf_stream_t stream);
+/* tf_shade_dirs with the flows sampling the OUTGOING direction instead of the half vector (cfg use_half_diffuse / use_half_specular = False,
+ * network/fields.py:1117-1134, :1190-1203): whole_mask bit 0 = the diffuse lobe's flow samples, bit 1 = the specular lobe's are directions
+ * (phi, theta) in the normal's frame; their density is exp(-clamp(logq)) / max(pi^2 sin(theta), 1e-6) and flow_logjac the log of that
+ * denominator (:1279, :1317).  whole_mask = 0 is tf_shade_dirs. */
+int tf_shade_dirs_whole(const float* normals, const float* view, const float* metallic, const float* roughness, const float* albedo,
+                        const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d, const float* az_jitter, int32_t nf,
+                        const float* ang_s, const float* logq_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
+                        uint8_t* live, float* flow_logjac, const int32_t* slot_of_pos, int32_t row_begin, int32_t row_count,
+                        int32_t whole_mask, tf_stream_t stream);
 /* The sampler of the NON-NIS pass of shade_mixed (nis_sample False / flows not yet active; the pass whose colours
  * MCShadingNetwork.forward returns in eval, fields.py:1467-1473): nf fixed cosine directions (sample_diffuse_directions,
  * fields.py:824-856) followed by ss fixed specular directions -- the GGX half-vector warp of the Fibonacci samples fixed_s [ss,2]

@@ -201,6 +201,15 @@ def half_to_dirs(angles01, n, x, y, view):
     return H, dirs, HoV, phi, theta
 
 
+def whole_to_dirs(angles01, n, x, y):
+    """use_half_* False (fields.py:1117-1134, :1190-1203): the flow sample IS the outgoing direction's (phi, theta) in the shading
+    frame -> dirs, theta; pdf Jacobian pi^2 sin(theta)."""
+    phi = angles01[..., :1] * (2 * np.pi)
+    theta = angles01[..., 1:2] * (0.5 * np.pi)
+    dirs = (torch.sin(theta) * torch.cos(phi)) * x[:, None] + (torch.sin(theta) * torch.sin(phi)) * y[:, None] + torch.cos(theta) * n[:, None]
+    return dirs, theta
+
+
 def fixed_diffuse_dirs(n, x, y, view, samples, az_jitter=None):
     """sample_diffuse_directions (fields.py:824-856), eval mode -> dirs, pdf."""
     az, el = samples[None, :, 0:1] * np.pi * 2, samples[None, :, 1:2]
@@ -231,8 +240,9 @@ def fixed_specular_dirs(n, x, y, view, rough, samples):
 
 
 def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, n_fixed_diffuse=512,
-          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None):
+          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None, use_half=(True, True)):
     """MCShadingNetwork.forward -> shade_mixed, eval; outer-light variant and human lights follow the state dict (get_lights).
+    use_half = cfg (use_half_diffuse, use_half_specular): False -> that lobe's flow samples the outgoing direction itself.
     Returns dict(colors, diffuse_colors(lin), specular_colors(lin), metallic, roughness, albedo,
                  specular_rays_id, specular_mask, visibility, ...)."""
     view = F.normalize(view, dim=-1)
@@ -247,8 +257,12 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     ddirs_fix, dpdf_fix = fixed_diffuse_dirs(nrm, x, y, view, fixed_direction_samples(n_fixed_diffuse))
     if use_flow:
         ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_diffuse, aabb, pfx=f"flow_diffuse{flow_sfx}.")
-        H, ddirs, HoV, phi, theta = half_to_dirs(ang, nrm, x, y, view)
-        dpdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoV * torch.sin(theta)).clamp_min(EPS)
+        if use_half[0]:
+            H, ddirs, HoV, phi, theta = half_to_dirs(ang, nrm, x, y, view)
+            dpdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoV * torch.sin(theta)).clamp_min(EPS)
+        else:
+            ddirs, theta = whole_to_dirs(ang, nrm, x, y)
+            dpdf = torch.exp(-logq.clamp(-8, 8)) / (np.pi ** 2 * torch.sin(theta)).clamp_min(EPS)
         ddirs = torch.cat([ddirs, ddirs_fix], 1)
         dpdf = torch.cat([dpdf, dpdf_fix], 1)
         out["diffuse_flow_angles"] = ang
@@ -267,8 +281,12 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     # ---- specular lobe
     if use_flow:
         ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_specular, aabb, pfx=f"flow_specular{flow_sfx}.")
-        H, sdirs, HoVs, phi, theta = half_to_dirs(ang, nrm, x, y, view)
-        spdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoVs * torch.sin(theta)).clamp_min(EPS)
+        if use_half[1]:
+            H, sdirs, HoVs, phi, theta = half_to_dirs(ang, nrm, x, y, view)
+            spdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoVs * torch.sin(theta)).clamp_min(EPS)
+        else:
+            sdirs, theta = whole_to_dirs(ang, nrm, x, y)
+            spdf = torch.exp(-logq.clamp(-8, 8)) / (np.pi ** 2 * torch.sin(theta)).clamp_min(EPS)
         out["specular_flow_angles"] = ang
         out["specular_flow_logq"] = logq
     else:

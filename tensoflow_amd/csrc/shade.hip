@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float* __restrict__ ang_s, const float* __restrict__ logq_s, const float* __restrict__ fixed_s,
     const float* __restrict__ az_jitter_s, int ss, long long pn, float* __restrict__ dirs,
     float* __restrict__ wgt, unsigned char* __restrict__ spec_mask, unsigned char* __restrict__ live,
-    float* __restrict__ flow_logjac, const int* __restrict__ slot_of_pos, int pos0, int npos) {
+    float* __restrict__ flow_logjac, const int* __restrict__ slot_of_pos, int pos0, int npos, int whole_mask) {
   const int T = sd + nf + ss;
   // rows [pos0, pos0 + npos) of every point (the whole point by default): a caller whose direction sets become ready one after the
   // other builds the rows of the sets it has while the next set is still being sampled
@@ -99,12 +99,21 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     float H[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) H[k] = cxh * F.x[k] + cyh * F.y[k] + ct * F.n[k];
-    const float HoV = sat(dot3(v, H));
+    float jac;      // d (angles in [0,1]^2) -> d (outgoing direction): the density's denominator and the NIS loss' log-Jacobian
+    if (whole_mask & (is_spec ? 2 : 1)) {
+      // use_half_diffuse / use_half_specular = False (fields.py:1117-1134, :1190-1203): the flow samples the OUTGOING direction itself
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dir[k] = HoV * H[k] * 2.f - v[k];
-    pdf = fast_exp(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(4.f * kPi * kPi * HoV * st, kEPS);
-    // log of the (angles -> outgoing direction) Jacobian used by the NIS loss (fields.py:1275, :1312)
-    if (flow_logjac) flow_logjac[pt * (sd + ss) + (is_spec ? sd + (slot - sd - nf) : slot)] = logf(fmaxf(4.f * kPi * kPi * HoV * st, kEPS));
+      for (int k = 0; k < 3; ++k) dir[k] = H[k];
+      jac = kPi * kPi * st;
+    } else {
+      const float HoV = sat(dot3(v, H));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dir[k] = HoV * H[k] * 2.f - v[k];
+      jac = 4.f * kPi * kPi * HoV * st;
+    }
+    pdf = fast_exp(-fminf(fmaxf(lq, -8.f), 8.f)) / fmaxf(jac, kEPS);
+    // log of the (angles -> outgoing direction) Jacobian used by the NIS loss (fields.py:1275-1280, :1312-1318)
+    if (flow_logjac) flow_logjac[pt * (sd + ss) + (is_spec ? sd + (slot - sd - nf) : slot)] = logf(fmaxf(jac, kEPS));
   } else {
     // fixed cosine set (fields.py:824-847)
     const int s = slot - sd;
@@ -449,7 +458,7 @@ static int shade_dirs_launch(const float* normals, const float* view, const floa
                              const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, const float* fixed_s,
                              const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
                              uint8_t* live, float* flow_logjac, const int32_t* slot_of_pos, int32_t pos0, int32_t npos, tf_stream_t stream,
-                             const char* who) {
+                             const char* who, int32_t whole_mask = 0) {
   TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "%s: negative size", who);
   if (npos < 0) { pos0 = 0; npos = sd + nf + ss; }
   TF_REQUIRE(pos0 >= 0 && pos0 + npos <= sd + nf + ss, TF_ESHAPE, "%s: row range [%d, %d) outside [0, %d)", who, pos0, pos0 + npos, sd + nf + ss);
@@ -462,7 +471,7 @@ static int shade_dirs_launch(const float* normals, const float* view, const floa
   shade_dirs_kernel<<<tf_blocks(work, 256), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, ang_d,
                                                                           logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s, fixed_s,
                                                                           az_jitter_s, ss, pn, dirs, wgt, spec_mask, live,
-                                                                          fixed_s ? nullptr : flow_logjac, slot_of_pos, pos0, npos);
+                                                                          fixed_s ? nullptr : flow_logjac, slot_of_pos, pos0, npos, whole_mask);
   TF_LAUNCH_CHECK(who);
   return TF_OK;
 }
@@ -475,6 +484,17 @@ extern "C" int tf_shade_dirs(const float* normals, const float* view, const floa
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
                            nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, row_begin, row_count, stream,
                            "tf_shade_dirs");
+}
+
+extern "C" int tf_shade_dirs_whole(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                   const float* albedo, const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d,
+                                   const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
+                                   int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
+                                   const int32_t* slot_of_pos, int32_t row_begin, int32_t row_count, int32_t whole_mask, tf_stream_t stream) {
+  TF_REQUIRE(whole_mask >= 0 && whole_mask <= 3, TF_EINVAL, "tf_shade_dirs_whole: whole_mask must be 0..3");
+  return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
+                           nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, row_begin, row_count, stream,
+                           "tf_shade_dirs_whole", whole_mask);
 }
 
 extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, const float* metallic, const float* roughness,

@@ -129,6 +129,7 @@ SIGNATURES = {
                                c_f, c_f, c_f, c_f, c_f, c_f]),
     "tf_view_angles": (C.c_int, [c_f, c_f, i64, c_f, c_f]),
     "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, c_f]),
+    "tf_shade_dirs_whole": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tf_shade_dirs_fixed": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
     "tf_shade_dirs_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, c_f]),
     "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, i32, c_f, sz, c_f]),

@@ -214,8 +214,10 @@ class MCShadingNetwork(nn.Module):
     # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547; the ablations flow.py:726-744).  No
     # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
     _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True,
-                   "flow_diffuse": "pwquad", "flow_specular": "pwquad", "use_half_diffuse": True, "use_half_specular": True,
+                   "flow_diffuse": "pwquad", "flow_specular": "pwquad",
                    "geometry_type": "schlick", "disable_tensorial": False, "disable_reflected": False}
+    # (use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the half vector, :1117-1134,
+    # :1190-1203 -- ARE built since round 6: tf_shade_dirs_whole; golden `shading_whole`)
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -277,7 +279,8 @@ class MCShadingNetwork(nn.Module):
                                 exp_max=self.cfg["inner_light_exp_max"], n_fixed_specular=self.cfg["specular_sample_num"],
                                 bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"],
                                 # not a reference key: "f16x2" opts in to the narrower inner-light operands (MCShader.__init__); default f16x3
-                                inner_precision={"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[self.cfg.get("inner_light_operands", "f16x3")])
+                                inner_precision={"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[self.cfg.get("inner_light_operands", "f16x3")],
+                                use_half=(bool(self.cfg["use_half_diffuse"]), bool(self.cfg["use_half_specular"])))
         if self._composed_lights:
             self._shader.overlap_dirs = False      # (the composed miss branch allocates between the streams' kernels: keep one stream)
         self._shader_version = ver
@@ -431,7 +434,8 @@ class MCShadingNetwork(nn.Module):
             ang_s, lq_s = self.flow_specular_copy._sample_nograd(pts, va, ss, jit(ss))
             az_jit = torch.rand(pn, device=dev) if (is_train and self.training and self.cfg["random_azimuth"]) else None      # fields.py:837
         wgt, dirs, smask, live, logjac = ShadeWeightsFn.apply(metallic, roughness, albedo, normals.contiguous(), view_dirs.contiguous(),
-                                                              ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit)
+                                                              ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit,
+                                                              (not self.cfg["use_half_diffuse"], not self.cfg["use_half_specular"]))
         T = dirs.shape[1]
         nd = sd + self._fixed.shape[0]
         pts_rep = pts.contiguous()                       # T rays per origin row (tf_bvh_trace rays_per_origin)
@@ -619,18 +623,31 @@ class MCShadingNetwork(nn.Module):
         va = ops.view_angles(normals, view_dirs)
         if step is not None and step >= cfg.get("nis_loss_iter_diffuse", 500):
             sdn = cfg["nis_diffuse_sample_num"]
-            Hd = F.normalize(V + d_dirs[:, :sdn], dim=-1)
-            HoV_d = torch.clamp((Hd * V).sum(-1, keepdim=True), 0.0, 1.0)
-            ph, th = half_angles(Hd)
+            if cfg["use_half_diffuse"]:
+                Hd = F.normalize(V + d_dirs[:, :sdn], dim=-1)
+                HoV_d = torch.clamp((Hd * V).sum(-1, keepdim=True), 0.0, 1.0)
+                ph, th = half_angles(Hd)
+                jac = 4 * PI ** 2 * HoV_d * torch.sin(th)
+            else:      # :1276-1279: the flow is fitted on the directions' own angles (az, arcsin(sqrt(el))) of sample_diffuse_directions
+                ph, th = az.expand(pn, nd, 1)[:, :sdn], torch.arcsin(el_sqrt).expand(pn, nd, 1)[:, :sdn]
+                jac = PI ** 2 * torch.sin(th)
             xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
             _, logq = self.flow_diffuse(pts, va, roughness.detach(), xq.detach().contiguous(), return_jacobian=True)
-            logqx = logq - (4 * PI ** 2 * HoV_d * torch.sin(th)).clamp_min(EPS).log()
+            logqx = logq - jac.clamp_min(EPS).log()
             outputs["loss_nis_diffuse"] = -((d_w * d_lights)[:, :sdn] * logqx / d_pdf.expand(pn, nd, 1)[:, :sdn].clamp_min(EPS)).mean()
         if step is not None and step >= cfg.get("nis_loss_iter_specular", 500):
-            ph, th = sah[:, :1], sah[:, 1:2]
+            if cfg["use_half_specular"]:
+                ph, th = sah[:, :1], sah[:, 1:2]
+                jac = 4 * PI ** 2 * HoV_s * torch.sin(th)
+            else:      # :1314-1317: ... on the angles of the reflected directions themselves (sample_specular_directions' `angles`)
+                cz = (Z.expand(pn, ns, 3)[smask] * sd_).sum(-1, keepdim=True).clamp(-1 + EPS, 1 - EPS)
+                ph = (torch.atan2((Y.expand(pn, ns, 3)[smask] * sd_).sum(-1, keepdim=True), (X.expand(pn, ns, 3)[smask] * sd_).sum(-1, keepdim=True))
+                      + 2 * PI) % (2 * PI)
+                th = torch.acos(cz)
+                jac = PI ** 2 * torch.sin(th)
             xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
             _, logq = self.flow_specular(pts, va, roughness.detach(), xq.contiguous(), return_jacobian=True, rays_id=rid)
-            logqx = logq - (4 * PI ** 2 * HoV_s * torch.sin(th)).clamp_min(EPS).log()
+            logqx = logq - jac.clamp_min(EPS).log()
             outputs["loss_nis_specular"] = -(s_w * s_lights * logqx / sp_.clamp_min(EPS)).mean()
         outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
         return colors, outputs

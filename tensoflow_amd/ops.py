@@ -1200,8 +1200,9 @@ def view_angles(normals, view):
 
 
 def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False,
-               slot_of_pos=None, rows=None, out=None):
-    """slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order).
+               slot_of_pos=None, rows=None, out=None, whole=(False, False)):
+    """whole = (diffuse, specular): that lobe's flow samples are OUTGOING directions, not half vectors (cfg use_half_* = False).
+    slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order).
     rows = (begin, count): build only these rows of every point, into the arrays `out` = (dirs, wgt, mask, live) of an earlier call
     (None: allocate); the sample arrays of direction sets outside the range are not read, so a set's rows can be built while the
     next set is still being sampled (ang_s / logq_s may then be given as shapes: (ss,))."""
@@ -1228,11 +1229,12 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     else:
         a_s, l_s = g(ang_s), g(None if logq_s is None else logq_s.reshape(pn, ss))
     r0, rc = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
-    L.check(lib.tf_shade_dirs(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
-                              _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
-                              _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(a_s), _p(l_s), ss, pn, _p(dirs), _p(wgt),
-                              _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _p(slot_of_pos, torch.int32), r0, rc, _stream()),
-            "tf_shade_dirs")
+    wm = (1 if whole[0] else 0) | (2 if whole[1] else 0)
+    L.check(lib.tf_shade_dirs_whole(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                                    _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
+                                    _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(a_s), _p(l_s), ss, pn, _p(dirs), _p(wgt),
+                                    _p(mask, torch.uint8), _p(live, torch.uint8), _p(logjac), _p(slot_of_pos, torch.int32), r0, rc, wm,
+                                    _stream()), "tf_shade_dirs")
     if want_logjac:
         return dirs, wgt, mask.bool(), live, logjac
     return dirs, wgt, mask.bool() if out is None else mask, live

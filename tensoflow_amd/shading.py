@@ -296,8 +296,10 @@ class MCShader:
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False,
-                 light_exp_max=5.0, inner_precision=None):
+                 light_exp_max=5.0, inner_precision=None, use_half=(True, True)):
         self.device = device
+        # cfg use_half_diffuse / use_half_specular (fields.py:661-662, :1084, :1163): True (the default) = the flows sample the HALF vector
+        self.whole = (not use_half[0], not use_half[1])
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
         # Inner-light decoder (123-256-256-256-3).  Library default: ops.PREC_F16X3 -- every operand split hi + lo, the arithmetic of the
         # flow nets and the per-point nets (fp32-grade: 22 significant bits per operand).  ops.PREC_F16X2 is an explicit opt-in
@@ -611,21 +613,21 @@ class MCShader:
             with torch.cuda.stream(side):
                 with tm.stage("shade_dirs (diffuse + fixed rows)", overlapped=True):
                     ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
-                                   slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs)
+                                   slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs, whole=self.whole)
             with tm.stage("flow_sample"):
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
             with tm.stage("shade_dirs"):
                 cur.wait_stream(side)
                 dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
-                                                        slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs)
+                                                        slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs, whole=self.whole)
         else:
             with tm.stage("flow_sample"):
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
             with tm.stage("shade_dirs"):
                 dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
-                                                        slot_of_pos=order)
+                                                        slot_of_pos=order, whole=self.whole)
         tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built

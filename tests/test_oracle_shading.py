@@ -117,6 +117,25 @@ def test_sphere_direction_outer_light_and_human_lights(golden):
         assert rel_err(o["variance"], g.out["variance" + sfx]) < 5e-4 and rel_err(o["approximate_light"], g.out["approximate_light" + sfx]) < 1e-4
 
 
+def test_whole_direction_flow_lobes(golden):
+    """cfg use_half_diffuse = use_half_specular = False (fields.py:1117-1134, :1190-1203): the oracle's whole-direction branch against
+    the reference's eval forward (golden shading_whole; state and mesh of shading_grad)."""
+    g, base = golden("shading_whole"), golden("shading_grad")
+    tr = _tracer(base)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    kw = dict(n_fixed_diffuse=n_fd, n_fixed_specular=n_fs)
+    fixed = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=False, **kw)
+    assert rel_err(fixed["colors"], g["eval/colors"]) < 2e-5
+    flow = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=True,
+                     use_half=(False, False), **kw)
+    assert rel_err(flow["colors"], g["eval/rgb_pr_nis"]) < 5e-5
+    assert rel_err(flow["visibility"], g["eval/visibility_nis"]) < 1e-6
+    assert rel_err(torch.clamp(osh.linear_to_srgb(flow["diffuse_lin"]), 0, 1), g["eval/diffuse_color_nis"]) < 5e-5
+    assert rel_err(torch.clamp(osh.linear_to_srgb(flow["specular_lin"]), 0, 1), g["eval/specular_color_nis"]) < 5e-5
+    half = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=True, **kw)
+    assert rel_err(half["colors"], g["eval/rgb_pr_nis"]) > 1e-2          # the flag changes the picture: the golden pins the branch
+
+
 def test_cpu_bvh_equals_brute_force():
     """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
     unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along

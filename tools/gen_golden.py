@@ -712,6 +712,59 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
+def gen_shading_whole():
+    """cfg use_half_diffuse = use_half_specular = False (fields.py:661-662): the flows sample the OUTGOING direction instead of the half
+    vector (:1117-1134, :1190-1203; NIS losses :1276-1279, :1314-1317).  The network, mesh and points of `shading_grad` (same seeds: only
+    outputs are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
+    600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
+    from network.fields import MCShadingNetwork
+    from network.materialRenderer import MaterialRenderer
+    from oracle.mesh import BruteForceRayTracer
+    from tensoflow_amd.synth import sphere_surface_points
+    verts, faces = small_mesh()
+    host = types.SimpleNamespace(ray_tracer=BruteForceRayTracer(verts, faces), warned_normal=True)
+    R = 32
+    unit = float((2.0 / (R - 1)))
+    trace = lambda o, d: MaterialRenderer.trace(host, (o + 2 * unit * d).detach(), d.detach())
+    base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
+    cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+               nis_specular_sample_num=8, use_half_diffuse=False, use_half_specular=False)
+    pn = 40
+    pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
+    g = torch.Generator().manual_seed(9)
+    w = torch.rand(pn, 3, generator=g)
+    arrays = dict(pts=pts, view_in=view, normals_in=nrm, bwd_w=w)
+
+    def make():
+        torch.manual_seed(4)
+        net = MCShadingNetwork(cfg, trace, AABB)
+        net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, R)) for _ in range(3)])
+        net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, 1)) for _ in range(3)])
+        missing, unexpected = net.load_state_dict(base, strict=False)
+        assert not missing, missing
+        for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
+            for p in fl.parameters():
+                p.requires_grad = False
+        net.eval()
+        return net
+    net = make()
+    with torch.no_grad():
+        colors, outputs = net(pts, view, nrm, None, None, False)
+    arrays.update({"eval/colors": colors, "eval/rgb_pr_nis": outputs["rgb_pr_nis"], "eval/diffuse_color_nis": outputs["diffuse_color_nis"],
+                   "eval/specular_color_nis": outputs["specular_color_nis"], "eval/visibility_nis": outputs["visibility_nis"]})
+    for tag, copies in (("flow600", True), ("fixed600", False)):
+        net = make()
+        net.use_flow_diffuse_copy = net.use_flow_specular_copy = copies
+        net.zero_grad()
+        colors, outputs = net(pts, view, nrm, None, 600, False)
+        ((colors * w).sum() + outputs["loss_nis"]).backward()
+        arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
+                       f"{tag}/loss_nis_specular": outputs["loss_nis_specular"]})
+        arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    save("shading_whole", verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **arrays)
+
+
 def gen_shading_grad_fixed():
     """Training direction BEFORE the flow copies take over (use_flow_*_copy False: the first nis_start_iter = 1000 steps of the
     material stage, fields.py:1050-1065): MCShadingNetwork.forward at step 100 (fixed samplers only) and step 600 (NIS losses
@@ -1193,7 +1246,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
