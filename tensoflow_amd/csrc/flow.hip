@@ -222,7 +222,7 @@ __device__ __forceinline__ void pw_forward(float xin, const float (&wv)[32], flo
 // accumulator value (v_max x, x: the matrix-core result is not a known-canonical float to it) -- three instructions per
 // activation, 1 150 per 64 rows.  (A packed v_pk_mul_f32 for the products was tried and is NOT safe here: results changed
 // from run to run on 9 % of the samples -- a packed-FP32 read of a matrix-core result that hipcc's hazard recogniser does not
-// cover; tools/exp_flow_determinism.py is the check.)
+// cover; the check was tools/exp_flow_determinism.py of the round-5 tree, git e89d4f5: the same launch twice, bit-compared.)
 __device__ __forceinline__ float leaky(float x) {
 #ifdef TF_FLOW_FMAX_LEAKY   // dev-only switch: the previous form
   return fmaxf(x, 0.01f * x);
