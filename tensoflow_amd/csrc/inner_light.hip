@@ -102,6 +102,12 @@ extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out
 #ifndef IL3_PF
 #define IL3_PF 2
 #endif
+#ifndef IL3_INTERLEAVE
+#define IL3_INTERLEAVE 1
+#endif
+#ifndef IL3_OUT_LATE
+#define IL3_OUT_LATE 1
+#endif
 // Two operand forms of the staggered kernel:
 //   TERMS = 3 (TF_PREC_F16X3): activations AND weights split hi + lo, a_hi w_hi + a_lo w_hi + a_hi w_lo; a team pass is 64 rays
 //     (2 ray tiles x 2 planes = 64 KB of B-fragments per team);
@@ -205,6 +211,16 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
 #pragma unroll
         for (int p = 0; p < XP; ++p) bq[(s + 1) & 1][r][p] = actl[(((s + 1) * RT + r) * XP + p) * 64];
     }
+#if IL3_INTERLEAVE
+    // term-major: consecutive MFMAs go to DIFFERENT accumulators (the order of the three terms per accumulator is the same)
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[t][r] = tf_mfma_h(ring.a[s % (PF + 1)][t][term == 2 ? 1 : 0], bq[s & 1][r][term == 1 ? XP - 1 : 0], acc[t][r]);
+#else
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       const tf_h8 b_hi = bq[s & 1][r][0], b_lo = bq[s & 1][r][XP - 1];
@@ -216,12 +232,28 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
         acc[t][r] = tf_mfma_h(ring.a[s % (PF + 1)][t][1], b_hi, acc[t][r]);
       }
     }
+#endif
     // order inside a k-step: the activation fragments of k-step s + 1 and the weight fragments of k-step s + PF are REQUESTED before
     // the 12 MFMAs of k-step s (left to itself the scheduler sinks the LDS reads behind the last MFMA -- they reuse the registers of
     // the fragments in use -- and every k-step then waits out an LDS round trip with the matrix pipe idle)
+#if IL3_INTERLEAVE
+    // ... and ONE memory instruction behind each of the first MFMAs rather than all eight in front of the first: an instruction of
+    // this wave issued between two MFMAs costs nothing (the matrix pipe is 32 cycles into the previous one), eight of them in a row
+    // with the scalar address arithmetic leave it idle for ~50 cycles per k-step (cycle stamps of a team alone on its CU: 439 cycles
+    // per k-step of 12 MFMAs = 384)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (s + 1 < K16 && i < RT * XP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (s + PF < K16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT * TERMS - 8, 0);
+#else
     __builtin_amdgcn_sched_group_barrier(0x100, RT * XP, 0);         // DS reads
     __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);               // VMEM reads
     __builtin_amdgcn_sched_group_barrier(0x008, 2 * RT * TERMS, 0);  // MFMA
+#endif
     __builtin_amdgcn_sched_barrier(0);      // bounds how far the loads of later k-steps are hoisted (registers)
   }
   }
@@ -739,6 +771,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
     }
     // wave w stores ray tile w of the pass (128-ray form: all four waves; 64-ray form: waves 0, 1): the lanes of half w & 1 hold
     // that tile's source indices (ray 64 (w >> 1) + lane)
+    auto emit_out = [&]() {
     if (it >= 1 && w < RT && hh_o == (w & 1)) {
       const int e = NR == 1 ? 0 : (w >> 1);
       const long long orow = pass_of(it - 1) * RAYS + 64 * e + lane_o;
@@ -754,6 +787,13 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         }
       }
     }
+    };
+    // 64-ray form (IL3_OUT_LATE): not here but in step P1, behind the publish, where this team waits ~5 k cycles for its partner's
+    // M3 anyway: waves 0 and 1 spent ~650 cycles on it at the end of M1, the step in which M1 is what the partner's barrier waits for
+    // (cycle stamps, round 6).  The partial sums stay valid until step FE of the next pass; the stores sit ~5 k cycles ahead of M2's
+    // counted waits
+    constexpr bool OUT_LATE = IL3_OUT_LATE && TERMS == 3;
+    if (!OUT_LATE || !live) emit_out();
     if (!live) break;
     IL3_STAMP(3);
     il3_barrier();
@@ -764,6 +804,9 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
       // the next layer's first weight fragments: they land while this wave publishes and waits for its partner
       if constexpr (TERMS == 2) il4_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
       else il3_prefetch((gw_t)(W + (layer == 1 ? kH2 : kH3) / 4), T0, lane, ring);
+      // (ahead of the gather: its LDS-DMA is an asm statement with a memory clobber, an LDS read behind it waits for vmcnt(0) --
+      // measured: this block took 5 k cycles there, a random-row HBM round trip)
+      if (OUT_LATE && layer == 1) emit_out();
       if (layer == 1 && it + 1 < n_iter) {
         // the gather step: BEHIND layer 2's weight prefetch and a publish + barrier wait ahead of the first wait that has to see it
         // retired (vmcnt retires in order: a random-row gather -- an HBM round trip -- in front of a matrix phase's weight loads stalls

@@ -36,6 +36,8 @@ if os.environ.get("IL_SPARSE"):
 else:
     n_rows = n
 count = torch.tensor([n], dtype=torch.int64, device=dev)
+if os.environ.get("IL_TEAMS"):      # 1: one team per workgroup (tf_set_launch_budget): a team's phases WITHOUT a partner on its SIMDs
+    ops.set_launch_budget(inner_teams=int(os.environ["IL_TEAMS"]))
 res = {}
 for p in precs:
     cache = ops.PackCache()
