@@ -575,21 +575,32 @@ __global__ void __launch_bounds__(MODE == 0 ? 512 : 64 * FLOW_WPB_H3) flow_kerne
 }
 
 // per-point hoisted layer-1 part: P[b][pt][u] = b1[u] + sum_k W1[u][7+k] * (2*cond[pt][k] - 1)
+// A lane owns unit u of one coupling net and keeps its 37 weights in registers; its wave walks FLOW_PP_PTS points, whose condition rows
+// are wave-uniform (scalar loads), one coalesced 256-byte store per point.  (Rounds 1-5: one thread per output re-read its weight row --
+// 64 different rows per wave-wide load, 37 of them per output: 0.54 ms per 262 144 points, 8 launches per bench step; same sum order.)
+#define FLOW_PP_PTS 32
 __global__ void __launch_bounds__(256) flow_point_part_kernel(const float* __restrict__ w1a, const float* __restrict__ b1a,
                                                               const float* __restrict__ w1b, const float* __restrict__ b1b,
                                                               const float* __restrict__ cond, long long pn,
                                                               float* __restrict__ P) {
-  long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= 2 * pn * 64) return;
-  int u = (int)(e & 63);
-  long long pt = (e >> 6) % pn;
-  int blk = (int)((e >> 6) / pn);
+  const int u = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int blk = blockIdx.y;
   const float* w = (blk ? w1b : w1a) + u * 44 + 7;
-  float acc = (blk ? b1b : b1a)[u];
-  const float* c = cond + pt * 37;
+  float wr[37];
 #pragma unroll
-  for (int k = 0; k < 37; ++k) acc += w[k] * (c[k] * 2.f - 1.f);
-  P[e] = acc;
+  for (int k = 0; k < 37; ++k) wr[k] = w[k];
+  const float b = (blk ? b1b : b1a)[u];
+  const long long p0 = ((long long)blockIdx.x * 4 + wave) * FLOW_PP_PTS;
+  for (int i = 0; i < FLOW_PP_PTS; ++i) {
+    const long long pt = p0 + i;
+    if (pt >= pn) break;                                     // wave-uniform
+    const float* c = cond + pt * 37;
+    float acc = b;
+#pragma unroll
+    for (int k = 0; k < 37; ++k) acc += wr[k] * (c[k] * 2.f - 1.f);
+    P[((long long)blk * pn + pt) * 64 + u] = acc;
+  }
 }
 
 static int pack_nets_h3(const TfCouplingNet nets[2], float* netfrag, hipStream_t stream) {
@@ -659,8 +670,8 @@ static int flow_launch(const TfCouplingNet nets[2], const float* cond, const flo
   const bool h3 = precision != TF_PREC_F32;      // TF_PREC_F16 runs on the f16x3 fragment image (hi halves only)
   if (!packed)
     if (int rc = h3 ? pack_nets_h3(nets, netfrag, stream) : pack_nets(nets, netfrag, stream)) return rc;
-  flow_point_part_kernel<<<tf_blocks(2 * pn * 64, 256), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
-                                                                         nets[1].b[0], cond, pn, P);
+  flow_point_part_kernel<<<dim3((unsigned)tf_blocks(pn, 4 * FLOW_PP_PTS), 2), 256, 0, stream>>>(nets[0].w[0], nets[0].b[0], nets[1].w[0],
+                                                                                                nets[1].b[0], cond, pn, P);
   const size_t lds = (size_t)kWsNet * sizeof(float);
   static std::atomic<unsigned long long> attr_set{0};
   int attr_dev;

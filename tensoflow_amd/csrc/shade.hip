@@ -287,8 +287,10 @@ __global__ void __launch_bounds__(256) shade_reduce_env_kernel(const float* __re
   for (int t = lane; t < T; t += 64) {
     const long long r = pt * T + t, e = r * 3;
     // all four rows are requested together (85 % of the rays miss and need every one of them).  Measured neutral against fetching
-    // them behind the branches (2.65 ms either way): the kernel is held by the four texel gathers + ~130 vector instructions of the
-    // environment lookup per missing ray, not by the streams
+    // them behind the branches (2.65 ms either way).  Round 6, measured and not adopted: the rows of 2 / 4 / 6 slots per lane requested
+    // together (2.61 / 2.87 / 2.78 ms against 2.47), RGBA-padded texels (one aligned dwordx4 per tap: 2.455 against 2.450), the cube
+    // edge taps in integer arithmetic (cube.h; kept: same texels, 2.51 -> 2.50).  Counters: 230 vector instructions per
+    // ray, vector unit ~50 % busy at 6.6 waves per SIMD, 44 % of wave time waiting: row round trip + dependent texel round trip per trip
     const F3 w = ld3(wgt + e);
     const F3 dd = ld3(dirs + e);
     const float dr = depth[r];
