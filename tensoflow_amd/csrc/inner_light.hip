@@ -590,6 +590,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           for (int c = 0; c < 3; ++c) sum[r][c] = fsum[r][c][0] + fsum[r][c][1];
       } else {
       if constexpr (SAVE) il3_save_acts(acts + 2 * m_arg * 256, pass_of(it - 1) * RAYS, m, T0, lane_o, acc);
+      // (the packed form of the 128-ray path -- pairs of sums, v_pk_fma_f32: il4_out3 -- was measured here in round 6: step F 2.85 k -> 8.3 k
+      // cycles, 22.3 -> 24.8 ms; the pairs are assembled with register moves beside 64 live accumulators.  Scalar FMAs stay.)
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
