@@ -108,6 +108,9 @@ extern "C" void tf_il3_stamps(unsigned long long* out) { hipMemcpyFromSymbol(out
 #ifndef IL3_OUT_LATE
 #define IL3_OUT_LATE 1
 #endif
+#ifndef IL3_POS_EARLY
+#define IL3_POS_EARLY 1
+#endif
 // Two operand forms of the staggered kernel:
 //   TERMS = 3 (TF_PREC_F16X3): activations AND weights split hi + lo, a_hi w_hi + a_lo w_hi + a_hi w_lo; a team pass is 64 rays
 //     (2 ray tiles x 2 planes = 64 KB of B-fragments per team);
@@ -136,6 +139,17 @@ __device__ __forceinline__ constexpr int il3_col_slot8(int k, int plane) {
 }
 template <int TERMS>
 __device__ __forceinline__ int il3_ray_slot8(int r, int j) { return (r * IL3<TERMS>::XP * 64 + j) * 2; }
+// hi = f16(x), lo = f16(x - hi) of four values, as packed halves (the split of il3_store4 without the store)
+__device__ __forceinline__ void il3_split4(float a, float b, float c, float d, uint2& hv, uint2& lv) {
+  asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+      "v_cvt_pk_f16_f32 %1, %6, %7\n\t"
+      "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(hv.x), "=&v"(hv.y), "=&v"(lv.x), "=&v"(lv.y)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+}
 template <int TERMS>
 __device__ __forceinline__ void il3_store4(uint2* a8 /* team image + the ray's slot */, int k, float a, float b, float c, float d) {
   if (TERMS == 3) {
@@ -466,7 +480,8 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   if (m <= 0) return;
   __shared__ __attribute__((aligned(16))) tf_h8 act[TEAMS * C::TEAM16];     // 128 KB: [team][k-step][ray tile][hi|lo][lane]
   __shared__ __attribute__((aligned(16))) float lbias[3 * 256];             // [layer][lane half][tile * 16 + reg] (128 per half)
-  __shared__ __attribute__((aligned(16))) float w4a[3 * 256];               // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer
+  __shared__ __attribute__((aligned(16))) float w4a[3 * 256 + 4];           // [output][lane half][tile * 16 + reg]: rows of the 256 -> 3 layer; + its 3 biases
+                                                                            // (as three registers held across the whole kernel they were the first to spill)
   // partial sums of the 256 -> 3 layer, [team][wave][ray tile * 3 + output][ray].  They live from step FE to the tail of step M1,
   // while k-steps 8..15 of the team's image are unused (the input row is 128 columns: k-steps 0..7; layer 3 has been read, layer 1 is
   // published one barrier later): the 128-ray form keeps them THERE (its stage is twice the size and the 160 KB are spent).
@@ -542,7 +557,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
   std::conditional_t<TERMS == 3, Il3Ring, Il4Ring> ring;
   f32x16 acc[TERMS == 3 ? 2 : 1][RT];      // (128-ray form: one unit tile at a time)
   il4_f2 fsum[TERMS == 3 ? 1 : RT][3];     // 128-ray form: the wave's share of the 256 -> 3 layer (pairs: even | odd units), from step M3 to step FE
-  const float b4[3] = {ws_arg[kIB4 + 0], ws_arg[kIB4 + 2], ws_arg[kIB4 + 4]};     // packed order: [n * 2 + half], unit n = reg for n < 4
+  if (tid < 3) w4a[3 * 256 + tid] = ws_arg[kIB4 + 2 * tid];                        // packed order: [n * 2 + half], unit n = reg for n < 4
   __syncthreads();
   // Both teams run the SAME straight-line program; team B passes three barriers before it starts and team A three after it has
   // finished, so that A is three steps ahead at every moment (s_barrier only counts arrivals).  Straight-line code instead of a
@@ -556,6 +571,27 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #else
 #define IL3_STAMP(i) do {} while (0)
 #endif
+  // IL3_POS_EARLY (64-ray form): the positional block of the NEXT pass's encodings (6 sincos pairs per lane and their hi / lo split:
+  // ~1.2 k of step FE's cycles) is evaluated in step P2 of the current pass, where this team waits for its partner's M1 anyway -- the
+  // rows of the next pass are in the stage since step P1 -- and held as 12 registers of packed halves across M3; step FE, which bounds
+  // the steps (FE | M2) by ~1.1 k cycles, only stores them.  Same values, same slots.
+  constexpr bool POS_EARLY = IL3_POS_EARLY && TERMS == 3 && !SAVE;        // (the training forward holds the accumulators for il3_save_acts: 12 spills with it)
+  uint2 pos_h[3], pos_l[3];
+  auto pos_block = [&](int ln) {
+    const float4 rp = *reinterpret_cast<const float4*>(staget + 4 * ln);
+    const float p[3] = {rp.x, rp.y, rp.z};
+    float e12[12];
+    const bool small = __all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const float arg = p[i % 3] * (float)(1 << (i / 3)) * (w == 0 ? 1.f : w == 1 ? 4.f : w == 2 ? 16.f : 64.f);   // exact: powers of two
+      if (small) tf_sincos_small(arg, e12[2 * i], e12[2 * i + 1]);
+      else tf_sincos(arg, e12[2 * i], e12[2 * i + 1]);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 3; ++gq) il3_split4(e12[4 * gq], e12[4 * gq + 1], e12[4 * gq + 2], e12[4 * gq + 3], pos_h[gq], pos_l[gq]);
+  };
+  if constexpr (POS_EARLY) pos_block(lane);        // pass 0: its rows are in the stage (gathered and waited for above)
   if (TEAMS == 2 && team == 1) { il3_barrier(); il3_barrier(); il3_barrier(); }
   typedef const __attribute__((address_space(1))) tf_h8* gw_t;      // weights are read as GLOBAL loads (a generic pointer makes them flat loads,
                                                                      // which count against lgkmcnt as well and serialise with the LDS reads)
@@ -663,6 +699,15 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
         // matrix phases (93 registers sat unused through a matrix phase; 28-44 spills, whose reloads wait out the gathers)
         int ray_slot = il3_ray_slot8<TERMS>(q_o >> 5, q_o & 31);
         uint2* a8 = act8 + ray_slot;
+        if constexpr (POS_EARLY) {
+          // the positional block was evaluated and split one step earlier (step P2 of the previous pass / the prologue): only its stores
+          // are left -- first, so that the 12 registers are free for the polynomial work below
+#pragma unroll
+          for (int gq = 0; gq < 3; ++gq) {
+            a8[il3_col_slot8<TERMS>(72 + 12 * w + 4 * gq, 0)] = pos_h[gq];
+            a8[il3_col_slot8<TERMS>(72 + 12 * w + 4 * gq, 1)] = pos_l[gq];
+          }
+        }
         float inv = 1.f / fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-12f);
         n[0] *= inv; n[1] *= inv; n[2] *= inv;
         inv = 1.f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
@@ -722,7 +767,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
           il3_store4<TERMS>(a8, 120, p[0], p[1], p[2], 0.f);
         }
         // positional block of wave w: sincos of octaves 2w, 2w + 1, interleaved [sin, cos] per (octave, coordinate) pair
-        {
+        if constexpr (!POS_EARLY) {
           float e12[12];
           const bool small = __all(fabsf(p[0]) < 3.f && fabsf(p[1]) < 3.f && fabsf(p[2]) < 3.f);
 #pragma unroll
@@ -784,7 +829,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int o = (w * 3 + c) * 32 + (lane_o & 31);
-          const float x = ((partt[o] + partt[3 * RT * 32 + o]) + (partt[2 * 3 * RT * 32 + o] + partt[3 * 3 * RT * 32 + o])) + b4[c];
+          const float x = ((partt[o] + partt[3 * RT * 32 + o]) + (partt[2 * 3 * RT * 32 + o] + partt[3 * 3 * RT * 32 + o])) + w4a[3 * 256 + c];
           out[3 * so + c] = expf(fminf(x, exp_max)) * near;
         }
       }
@@ -826,6 +871,7 @@ inner_light3_kernel(const float* __restrict__ ws_arg, const float* __restrict__ 
       } else {
         il3_publish<TERMS>(actt + lane, T0, acc);
         if constexpr (SAVE) il3_save_acts(acts + (layer - 1) * m_arg * 256, pass_of(it) * RAYS, m, T0, lane, acc);
+        if constexpr (POS_EARLY) { if (layer == 2 && it + 1 < n_iter) pos_block(lane_o); }
       }
       IL3_STAMP(4 * layer + 1);
       il3_barrier();
