@@ -139,7 +139,7 @@ def block_apply(sd, pfx, keep, y, logj, cond, inverse):
 
 
 # ---------------------------------------------------------------------------- TensoFlow
-def flow_condition(sd, pts, view_angles, roughness, aabb, pfx="", n_levels=3):
+def flow_condition(sd, pts, view_angles, roughness, aabb, pfx="", n_levels=3, ablate=(False, False)):
     """[pn,37] = [nis feature 16 | embed3(view_angles) 14 | 0*embed3(roughness) 7]."""
     planes = [sd[f"{pfx}nis_plane.{i}"] for i in range(3)]
     lines = [sd[f"{pfx}nis_line.{i}"] for i in range(3)]
@@ -147,14 +147,19 @@ def flow_condition(sd, pts, view_angles, roughness, aabb, pfx="", n_levels=3):
     h = torch.cat([feat, posenc(pts, 3)], -1)
     h = F.softplus(F.linear(h, sd[f"{pfx}nis_mat.0.weight"], sd[f"{pfx}nis_mat.0.bias"]), beta=100)
     h = F.linear(h, sd[f"{pfx}nis_mat.2.weight"], sd[f"{pfx}nis_mat.2.bias"])
-    return torch.cat([h, posenc(view_angles, 3), torch.zeros_like(posenc(roughness, 3))], -1)
+    refl = posenc(view_angles, 3)
+    if ablate[0]:                      # disable_tensorial (flow.py:807-808, :838-839)
+        h = torch.zeros_like(h)
+    if ablate[1]:                      # disable_reflected (flow.py:811-812, :842-843)
+        refl = torch.zeros_like(refl)
+    return torch.cat([h, refl, torch.zeros_like(posenc(roughness, 3))], -1)
 
 
-def flow_sample(sd, pts, view_angles, roughness, sn, aabb, pfx="", jitter=None, return_bins=False):
+def flow_sample(sd, pts, view_angles, roughness, sn, aabb, pfx="", jitter=None, return_bins=False, ablate=(False, False)):
     """TensoFlow.sample(..., return_jacobian=True) -> angles [pn,sn,2], logj [pn,sn,1]."""
     pn = pts.shape[0]
     x, logj = sphere_prior(pn, sn, jitter)
-    cond = flow_condition(sd, pts, view_angles, roughness, aabb, pfx)
+    cond = flow_condition(sd, pts, view_angles, roughness, aabb, pfx, ablate=ablate)
     cond = cond[:, None, :].expand(pn, sn, cond.shape[-1]).reshape(pn * sn, -1)
     y, lj = x.reshape(-1, 2), logj.reshape(-1, 1)
     y, lj, b0 = block_apply(sd, f"{pfx}flows.0", 0, y, lj, cond, inverse=False)

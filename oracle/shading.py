@@ -240,9 +240,10 @@ def fixed_specular_dirs(n, x, y, view, rough, samples):
 
 
 def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, n_fixed_diffuse=512,
-          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None, use_half=(True, True)):
+          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None, use_half=(True, True), flow_ablate=(False, False)):
     """MCShadingNetwork.forward -> shade_mixed, eval; outer-light variant and human lights follow the state dict (get_lights).
-    use_half = cfg (use_half_diffuse, use_half_specular): False -> that lobe's flow samples the outgoing direction itself.
+    use_half = cfg (use_half_diffuse, use_half_specular): False -> that lobe's flow samples the outgoing direction itself;
+    flow_ablate = cfg (disable_tensorial, disable_reflected).
     Returns dict(colors, diffuse_colors(lin), specular_colors(lin), metallic, roughness, albedo,
                  specular_rays_id, specular_mask, visibility, ...)."""
     view = F.normalize(view, dim=-1)
@@ -256,7 +257,7 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     # ---- diffuse lobe
     ddirs_fix, dpdf_fix = fixed_diffuse_dirs(nrm, x, y, view, fixed_direction_samples(n_fixed_diffuse))
     if use_flow:
-        ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_diffuse, aabb, pfx=f"flow_diffuse{flow_sfx}.")
+        ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_diffuse, aabb, pfx=f"flow_diffuse{flow_sfx}.", ablate=flow_ablate)
         if use_half[0]:
             H, ddirs, HoV, phi, theta = half_to_dirs(ang, nrm, x, y, view)
             dpdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoV * torch.sin(theta)).clamp_min(EPS)
@@ -280,7 +281,7 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
 
     # ---- specular lobe
     if use_flow:
-        ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_specular, aabb, pfx=f"flow_specular{flow_sfx}.")
+        ang, logq = oflow.flow_sample(sd, pts, va, rough, sn_specular, aabb, pfx=f"flow_specular{flow_sfx}.", ablate=flow_ablate)
         if use_half[1]:
             H, sdirs, HoVs, phi, theta = half_to_dirs(ang, nrm, x, y, view)
             spdf = torch.exp(-logq.clamp(-8, 8)) / (4 * np.pi ** 2 * HoVs * torch.sin(theta)).clamp_min(EPS)

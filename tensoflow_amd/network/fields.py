@@ -211,13 +211,14 @@ class MCShadingNetwork(nn.Module):
                    "disable_reflected": False}
     # Switches of the reference's cfg whose OTHER value selects code this build does not hold (fields.py: shade_mixed_all / use_nis_all
     # :1337-1451 with switches :752,1458-1461,1589; fixed samplers beside a flow :1082,1160; whole-direction instead of half-vector flows
-    # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547; the ablations flow.py:726-744).  No
+    # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547).  No
     # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
     _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True,
-                   "flow_diffuse": "pwquad", "flow_specular": "pwquad",
-                   "geometry_type": "schlick", "disable_tensorial": False, "disable_reflected": False}
-    # (use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the half vector, :1117-1134,
-    # :1190-1203 -- ARE built since round 6: tf_shade_dirs_whole; golden `shading_whole`)
+                   "flow_diffuse": "pwquad", "flow_specular": "pwquad", "geometry_type": "schlick"}
+    # (ARE built since round 6: use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the
+    # half vector, :1117-1134, :1190-1203: tf_shade_dirs_whole, golden `shading_whole`; disable_tensorial / disable_reflected -- the
+    # flows' tensorial feature / view-angle embedding zeroed, flow.py:807-812: TensoFlow._condition and MCShader.shade, golden
+    # `shading_ablate`)
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -255,7 +256,8 @@ class MCShadingNetwork(nn.Module):
                                              nn.ReLU(), wn(nn.Linear(256, 4)), nn.Identity()).cuda()
             nn.init.constant_(self.human_light[-2].bias, np.log(0.02))
         self._composed_lights = self.cfg["outer_light_version"] == "sphere_direction" or self.cfg["human_lights"]
-        mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda")
+        mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda", disable_tensorial=bool(self.cfg["disable_tensorial"]),
+                                   disable_reflected=bool(self.cfg["disable_reflected"]))
         self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
         self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
         self._shader, self._shader_version = None, None
@@ -280,7 +282,8 @@ class MCShadingNetwork(nn.Module):
                                 bvh=old.bvh if old is not None else None, light_exp_max=self.cfg["light_exp_max"],
                                 # not a reference key: "f16x2" opts in to the narrower inner-light operands (MCShader.__init__); default f16x3
                                 inner_precision={"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[self.cfg.get("inner_light_operands", "f16x3")],
-                                use_half=(bool(self.cfg["use_half_diffuse"]), bool(self.cfg["use_half_specular"])))
+                                use_half=(bool(self.cfg["use_half_diffuse"]), bool(self.cfg["use_half_specular"])),
+                                flow_ablate=(bool(self.cfg["disable_tensorial"]), bool(self.cfg["disable_reflected"])))
         if self._composed_lights:
             self._shader.overlap_dirs = False      # (the composed miss branch allocates between the streams' kernels: keep one stream)
         self._shader_version = ver

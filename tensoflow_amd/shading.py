@@ -296,8 +296,11 @@ class MCShader:
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False,
-                 light_exp_max=5.0, inner_precision=None, use_half=(True, True)):
+                 light_exp_max=5.0, inner_precision=None, use_half=(True, True), flow_ablate=(False, False)):
         self.device = device
+        # cfg disable_tensorial / disable_reflected (fields.py:665-666 -> flow.py:807-812): the flows' condition rows with the tensorial
+        # feature (columns 0..15) / the view-angle embedding (16..29) zeroed
+        self.flow_ablate = tuple(bool(v) for v in flow_ablate)
         # cfg use_half_diffuse / use_half_specular (fields.py:661-662, :1084, :1163): True (the default) = the flows sample the HALF vector
         self.whole = (not use_half[0], not use_half[1])
         self.precision = precision      # matrix-core arithmetic of the decoders (ops.PREC_F32 = exact fp32 MFMA)
@@ -592,6 +595,12 @@ class MCShader:
             # materials + both flow condition rows: one fused launch (tf_point_fwd) after the view-angle kernel
             va = ops.view_angles(normals, view_dirs)
             metallic, rough, albedo, cond_d, cond_s = self.point_prep(pts, va)
+            if any(self.flow_ablate):
+                for cnd in (cond_d, cond_s):
+                    if self.flow_ablate[0]:
+                        cnd[:, :16] = 0
+                    if self.flow_ablate[1]:
+                        cnd[:, 16:30] = 0
         # a point's rays are STORED in traversal order (row j holds slot order[j]): the traversal then reads and writes consecutive
         # rows from consecutive lanes instead of going through the permutation for every ray; only the kernels that need to know
         # WHICH sample a row is (direction construction, the lobe split of the reduction) take the permutation

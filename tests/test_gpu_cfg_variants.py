@@ -1,7 +1,11 @@
-"""cfg `use_half_diffuse = use_half_specular = False` (reference network/fields.py:661-662): the flows sample the OUTGOING direction in
-the shading frame instead of the half vector (:1117-1134, :1190-1203), the pdf Jacobian is pi^2 sin(theta) with no 4 HoV term, and the
-NIS losses are fitted on the direction's own angles (:1276-1279, :1314-1317).  Against a run of the imported reference
-(tests/golden/shading_whole.npz, tools/gen_golden.py:gen_shading_whole; network state, mesh and points of shading_grad.npz)."""
+"""Non-default cfg switches of MCShadingNetwork that this build holds, each against a run of the imported reference
+(tools/gen_golden.py:_gen_shading_variant; network state, mesh and points of shading_grad.npz):
+
+* `shading_whole`: `use_half_diffuse = use_half_specular = False` (reference network/fields.py:661-662): the flows sample the OUTGOING
+  direction in the shading frame instead of the half vector (:1117-1134, :1190-1203), the pdf Jacobian is pi^2 sin(theta) with no 4 HoV
+  term, and the NIS losses are fitted on the direction's own angles (:1276-1279, :1314-1317);
+* `shading_ablate`: `disable_tensorial = disable_reflected = True` (:665-666 -> network/flow.py:807-812, :838-843): the flows' tensorial
+  feature and view-angle embedding zeroed."""
 import pytest
 import torch
 
@@ -17,12 +21,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _net(golden, dev):
+VARIANTS = {"shading_whole": dict(use_half_diffuse=False, use_half_specular=False),
+            "shading_ablate": dict(disable_tensorial=True, disable_reflected=True)}
+
+
+def _net(golden, dev, variant):
     from tensoflow_amd.network.fields import MCShadingNetwork
-    g, base = golden("shading_whole"), golden("shading_grad")
+    g, base = golden(variant), golden("shading_grad")
     n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
-               nis_specular_sample_num=sn_s, outer_light_version="envlight", use_half_diffuse=False, use_half_specular=False)
+               nis_specular_sample_num=sn_s, outer_light_version="envlight", **VARIANTS[variant])
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     missing, _ = m.load_state_dict(base.sd, strict=False)
     assert not missing
@@ -33,26 +41,27 @@ def _net(golden, dev):
     return m, g
 
 
-def test_whole_direction_eval_golden(golden, dev):
-    """Fused inference path (MCShader.shade through tf_shade_dirs_whole): the flow pass' colours and light maps; the fixed pass does not
-    depend on the flags and must reproduce shading_grad's fixed colours too."""
-    m, g = _net(golden, dev)
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_cfg_variant_eval_golden(golden, dev, variant):
+    """Fused inference path (MCShader.shade): the flow pass' colours and light maps; the fixed pass does not depend on the flags."""
+    m, g = _net(golden, dev, variant)
     with torch.no_grad():
         colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
-    parity(colors.cpu(), g["eval/colors"], label="whole-direction eval: fixed-pass colours")
-    parity(out["rgb_pr_nis"].cpu(), g["eval/rgb_pr_nis"], label="whole-direction eval: rgb_pr_nis")
+    parity(colors.cpu(), g["eval/colors"], label=f"{variant} eval: fixed-pass colours")
+    parity(out["rgb_pr_nis"].cpu(), g["eval/rgb_pr_nis"], label=f"{variant} eval: rgb_pr_nis")
     for k in ("diffuse_color_nis", "specular_color_nis", "visibility_nis"):
-        parity(out[k].cpu(), g["eval/" + k], label=f"whole-direction eval: {k}")
+        parity(out[k].cpu(), g["eval/" + k], label=f"{variant} eval: {k}")
 
 
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
 @pytest.mark.parametrize("tag", ["flow600", "fixed600"])
-def test_whole_direction_training_step_golden(golden, dev, tag):
+def test_cfg_variant_training_step_golden(golden, dev, tag, variant):
     """loss = sum(colors * w) + loss_nis at step 600, the flow copies sampling (`flow600`) or not yet made (`fixed600`): colours, both
     NIS losses and the gradient of every trainable tensor against the reference's autograd."""
-    m, g = _net(golden, dev)
+    m, g = _net(golden, dev, variant)
     m.use_flow_diffuse_copy = m.use_flow_specular_copy = tag == "flow600"
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, 600, False)
-    parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"whole-direction training step {tag}: colours")
+    parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"{variant} training step {tag}: colours")
     for k in ("loss_nis_diffuse", "loss_nis_specular"):
         ref = float(g[f"{tag}/{k}"])
         assert abs(float(out[k].detach()) - ref) < 1e-4 * max(1, abs(ref)), (k, float(out[k].detach()), ref)
@@ -76,6 +85,6 @@ def test_whole_direction_training_step_golden(golden, dev, tag):
                 bad.append((name, round(err, 5), round(l2, 5)))
             checked += 1
     assert not bad, bad
-    assert checked >= 80, checked
+    assert checked >= (80 if variant == "shading_whole" else 60), checked       # (ablated: the flows' tensorial planes / lines get no gradient)
     with_grad = {n for n, p in m.named_parameters() if p.grad is not None}
     assert with_grad >= set(grads), sorted(set(grads) - with_grad)[:5]

@@ -136,6 +136,21 @@ def test_whole_direction_flow_lobes(golden):
     assert rel_err(half["colors"], g["eval/rgb_pr_nis"]) > 1e-2          # the flag changes the picture: the golden pins the branch
 
 
+def test_flow_ablation_switches(golden):
+    """cfg disable_tensorial = disable_reflected = True (fields.py:665-666 -> flow.py:807-812, :838-843): the oracle's zeroed condition
+    columns against the reference's eval forward (golden shading_ablate; state and mesh of shading_grad)."""
+    g, base = golden("shading_ablate"), golden("shading_grad")
+    tr = _tracer(base)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    kw = dict(n_fixed_diffuse=n_fd, n_fixed_specular=n_fs)
+    flow = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=True,
+                     flow_ablate=(True, True), **kw)
+    assert rel_err(flow["colors"], g["eval/rgb_pr_nis"]) < 5e-5
+    assert rel_err(flow["visibility"], g["eval/visibility_nis"]) < 1e-6
+    plain = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=True, **kw)
+    assert rel_err(plain["colors"], g["eval/rgb_pr_nis"]) > 1e-3          # the switches change the picture: the golden pins the branch
+
+
 def test_cpu_bvh_equals_brute_force():
     """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
     unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along

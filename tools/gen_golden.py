@@ -712,9 +712,8 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
-def gen_shading_whole():
-    """cfg use_half_diffuse = use_half_specular = False (fields.py:661-662): the flows sample the OUTGOING direction instead of the half
-    vector (:1117-1134, :1190-1203; NIS losses :1276-1279, :1314-1317).  The network, mesh and points of `shading_grad` (same seeds: only
+def _gen_shading_variant(name, over):
+    """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad`.  The network, mesh and points of `shading_grad` (same seeds: only
     outputs are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
     600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
     from network.fields import MCShadingNetwork
@@ -729,7 +728,7 @@ def gen_shading_whole():
     base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
     cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
                gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
-               nis_specular_sample_num=8, use_half_diffuse=False, use_half_specular=False)
+               nis_specular_sample_num=8, **over)
     pn = 40
     pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
     g = torch.Generator().manual_seed(9)
@@ -762,7 +761,19 @@ def gen_shading_whole():
         arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
                        f"{tag}/loss_nis_specular": outputs["loss_nis_specular"]})
         arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
-    save("shading_whole", verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **arrays)
+    save(name, verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **arrays)
+
+
+def gen_shading_whole():
+    """cfg use_half_diffuse = use_half_specular = False (fields.py:661-662): the flows sample the OUTGOING direction instead of the half
+    vector (:1117-1134, :1190-1203; NIS losses :1276-1279, :1314-1317)."""
+    _gen_shading_variant("shading_whole", dict(use_half_diffuse=False, use_half_specular=False))
+
+
+def gen_shading_ablate():
+    """cfg disable_tensorial = disable_reflected = True (fields.py:665-666 -> TensoFlow, flow.py:807-812, :838-843: the flows' tensorial
+    feature and view-angle embedding zeroed -- the paper's ablation switches)."""
+    _gen_shading_variant("shading_ablate", dict(disable_tensorial=True, disable_reflected=True))
 
 
 def gen_shading_grad_fixed():
@@ -1246,7 +1257,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
