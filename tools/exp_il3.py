@@ -1,5 +1,7 @@
 """Dev: the inner-light kernels alone on synthetic hit rays (bench network state).  python tools/exp_il3.py [n_rays] [precision codes...]
-codes: 1 = f16x3 (staggered two-team kernel), 0x201 = f16x3 on the slab-ring kernel, 2 = f16, 3 = f16x2, 0 = exact fp32"""
+codes (TfPrecision): 1 = f16x3 (staggered two-team kernel, the library default), 3 = f16x2, 2 = f16, 0 = exact fp32.
+IL_SPARSE=<density>: a sorted hit list over a larger ray array (the bench's access pattern); IL_TEAMS=1: one team per workgroup;
+TF_LIB=<variant .so> (tools/build_variant.sh, e.g. "-DTF_DEV" for the cycle stamps of profiles/r6_il3_cycle_stamps.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tensoflow_amd.lib as L
@@ -11,7 +13,7 @@ from tensoflow_amd.shading import wn_weight
 from tensoflow_amd.synth import random_mc_state
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7_424_837
-precs = [int(a, 0) for a in sys.argv[2:]] or [1, 0x201, 2]
+precs = [int(a, 0) for a in sys.argv[2:]] or [1, 3, 2]
 sd = random_mc_state(seed=4, R=32, flow_R=32, env_res=16)
 sdd = {k: v.to(dev).float() for k, v in sd.items() if v.is_floating_point() and "inner_light" in k}
 W = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
@@ -77,12 +79,12 @@ if os.environ.get("TF_LIB") or os.environ.get("TF_TIMING_ONLY"):
             print(f"wave {wv} (team {wv >> 2}) start +{s_[0] - t0:6d}: " + " ".join(f"{nm} {s_[q + 1] - s_[q]:5d}" for q, nm in enumerate(names)) + f" | total {s_[12] - s_[0]}"
                   f" | F {st[wv * 16 + 13] - s_[0]} E {st[wv * 16 + 14] - st[wv * 16 + 13]}")
     sys.exit(0)
-# small-count edge cases against the ring kernel: 1, 63, 64, 65, 129 rays
+# small-count edge cases against the exact-fp32 kernel: 1, 63, 64, 65, 129 rays
 for m in (1, 63, 64, 65, 129, 1000):
     c = torch.tensor([m], dtype=torch.int64, device=dev)
-    a, b = torch.zeros(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+    a, b = torch.zeros(n_rows, 3, device=dev), torch.zeros(n_rows, 3, device=dev)
     ops.inner_light_indexed(W, pos, dirs, nrm, idx, c, depth, a, precision=1)
-    ops.inner_light_indexed(W, pos, dirs, nrm, idx, c, depth, b, precision=0x201)
+    ops.inner_light_indexed(W, pos, dirs, nrm, idx, c, depth, b, precision=0)
     sel = idx[:m]
     ok = bool(((a[sel] - b[sel]).abs() / b[sel].abs().clamp_min(1e-3)).max() < 1e-4) and int((a != 0).any(-1).sum()) == int((b != 0).any(-1).sum())
-    print(f"count {m}: rows written {int((a != 0).any(-1).sum())}, agrees with the ring kernel: {ok}")
+    print(f"count {m}: rows written {int((a != 0).any(-1).sum())}, agrees with the exact-fp32 kernel: {ok}")
