@@ -561,7 +561,9 @@ int tf_shade_dirs(const float* normals, const float* view, const float* metallic
 /* tf_shade_dirs with the flows sampling the OUTGOING direction instead of the half vector (cfg use_half_diffuse / use_half_specular = False,
  * network/fields.py:1117-1134, :1190-1203): whole_mask bit 0 = the diffuse lobe's flow samples, bit 1 = the specular lobe's are directions
  * (phi, theta) in the normal's frame; their density is exp(-clamp(logq)) / max(pi^2 sin(theta), 1e-6) and flow_logjac the log of that
- * denominator (:1279, :1317).  whole_mask = 0 is tf_shade_dirs. */
+ * denominator (:1279, :1317).  Bit 2 (4, also accepted by the two *_mode entry points below): cfg geometry_type = 'ggx_smith' -- the
+ * specular weight's geometry term is geometry_ggx_smith_correlated, 1 / (1 + L(NoV) + L(NoL)) with L(c) = (sqrt(1 + a^2 tan^2) - 1) / 2
+ * (fields.py:1000-1008, :1029), instead of the Schlick-GGX product (:987-998).  whole_mask = 0 is tf_shade_dirs. */
 int tf_shade_dirs_whole(const float* normals, const float* view, const float* metallic, const float* roughness, const float* albedo,
                         const float* ang_d, const float* logq_d, int32_t sd, const float* fixed_d, const float* az_jitter, int32_t nf,
                         const float* ang_s, const float* logq_s, int32_t ss, int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask,
@@ -577,12 +579,22 @@ int tf_shade_dirs_fixed(const float* normals, const float* view, const float* me
                         const float* albedo, const float* fixed_d, const float* az_jitter, int32_t nf,
                         const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
                         uint8_t* spec_mask, uint8_t* live, tf_stream_t stream);
+/* tf_shade_dirs_fixed under cfg geometry_type: mode 0 = 'schlick' (tf_shade_dirs_fixed), 4 = 'ggx_smith' (see tf_shade_dirs_whole). */
+int tf_shade_dirs_fixed_mode(const float* normals, const float* view, const float* metallic, const float* roughness,
+                             const float* albedo, const float* fixed_d, const float* az_jitter, int32_t nf,
+                             const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
+                             uint8_t* spec_mask, uint8_t* live, int32_t mode, tf_stream_t stream);
 /* Backward of the BRDF weights wrt the per-point materials (training): g_wgt [pn,T,3] ->
  * g_albedo [pn,3], g_metallic [pn], g_roughness [pn] (overwritten).  dirs / wgt are tf_shade_dirs' outputs. */
 int tf_shade_dirs_bwd(const float* normals, const float* view, const float* metallic, const float* roughness,
                       const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd,
                       int32_t nf, int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness,
                       tf_stream_t stream);
+/* ... under cfg geometry_type: mode 0 = 'schlick' (tf_shade_dirs_bwd), 4 = 'ggx_smith' (d log G / d roughness of the Smith term). */
+int tf_shade_dirs_bwd_mode(const float* normals, const float* view, const float* metallic, const float* roughness,
+                           const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd,
+                           int32_t nf, int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness,
+                           int32_t mode, tf_stream_t stream);
 /* Same reduction with get_lights' miss branch folded in (fields.py:951-975): a slot whose ray hit the mesh (hit[r] != 0)
  * takes hit_lights[r] (tf_inner_light_indexed_fwd's scatter target; other rows are never read), a slot whose ray missed
  * takes exp(cube(env_base, dirs[r])) * (depth[r] > near_eps) evaluated on the fly -- the [pn,T,3] light array of the

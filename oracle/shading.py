@@ -240,10 +240,10 @@ def fixed_specular_dirs(n, x, y, view, rough, samples):
 
 
 def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, n_fixed_diffuse=512,
-          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None, use_half=(True, True), flow_ablate=(False, False)):
+          n_fixed_specular=256, use_flow=True, exp_max=5.0, flow_sfx="_copy", human_poses=None, use_half=(True, True), flow_ablate=(False, False), geometry_type="schlick"):
     """MCShadingNetwork.forward -> shade_mixed, eval; outer-light variant and human lights follow the state dict (get_lights).
     use_half = cfg (use_half_diffuse, use_half_specular): False -> that lobe's flow samples the outgoing direction itself;
-    flow_ablate = cfg (disable_tensorial, disable_reflected).
+    flow_ablate = cfg (disable_tensorial, disable_reflected); geometry_type = cfg geometry_type ('schlick' | 'ggx_smith', fields.py:1026-1033).
     Returns dict(colors, diffuse_colors(lin), specular_colors(lin), metallic, roughness, albedo,
                  specular_rays_id, specular_mask, visibility, ...)."""
     view = F.normalize(view, dim=-1)
@@ -302,7 +302,11 @@ def shade(sd, tracer, unit_size, aabb, pts, view, nrm, sn_diffuse, sn_specular, 
     fres = F0[rid] + (1.0 - F0[rid]) * (1.0 - HoV).clamp(0.0, 1.0) ** 5.0
     NoV = sat_dot(nrm, view)[rid]
     NoL = sat_dot(nrm[rid], sd_)
-    geo = schlick_g1(NoV, rough[rid]) * schlick_g1(NoL, rough[rid])
+    if geometry_type == "ggx_smith":            # geometry_ggx_smith_correlated (fields.py:1000-1008)
+        lam = lambda a2, c: 0.5 * torch.sqrt(1 + a2 * (1 - c ** 2) / (c ** 2 + 1e-7)) - 0.5
+        geo = 1.0 / (1.0 + lam(rough[rid] ** 2, NoV) + lam(rough[rid] ** 2, NoL))
+    else:
+        geo = schlick_g1(NoV, rough[rid]) * schlick_g1(NoL, rough[rid])
     NoH = sat_dot(nrm[rid], Hs)
     dist = ggx_d(NoH, rough[rid])
     sl, shit, sinter, shlw = get_lights(sd, tracer, unit_size, pts[rid], sd_, exp_max, poses=human_poses[rid] if human_poses is not None else None,

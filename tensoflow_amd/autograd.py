@@ -274,9 +274,10 @@ class ShadeWeightsFn(torch.autograd.Function):
     (tf_shade_dirs_bwd).  Directions, masks, the live flags and the NIS log-Jacobian ride along as non-differentiable outputs."""
 
     @staticmethod
-    def forward(ctx, metallic, roughness, albedo, normals, view, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter, whole=(False, False)):
+    def forward(ctx, metallic, roughness, albedo, normals, view, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter, whole=(False, False), smith=False):
         dirs, wgt, smask, live, logjac = ops.shade_dirs(normals, view, metallic.detach(), roughness.detach(), albedo.detach(), ang_d,
-                                                        logq_d, fixed_d, ang_s, logq_s, az_jitter=az_jitter, want_logjac=True, whole=whole)
+                                                        logq_d, fixed_d, ang_s, logq_s, az_jitter=az_jitter, want_logjac=True, whole=whole, smith=smith)
+        ctx.smith = bool(smith)
         ctx.save_for_backward(metallic, roughness, albedo, normals, view, dirs, wgt)
         ctx.sizes = (ang_d.shape[1], fixed_d.shape[0], ang_s.shape[1])
         ctx.mark_non_differentiable(dirs, smask, live, logjac)
@@ -286,8 +287,8 @@ class ShadeWeightsFn(torch.autograd.Function):
     def backward(ctx, g_wgt, *unused):
         metallic, roughness, albedo, normals, view, dirs, wgt = ctx.saved_tensors
         sd, nf, ss = ctx.sizes
-        g_alb, g_met, g_rough = ops.shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt.contiguous(), sd, nf, ss)
-        return (g_met.view_as(metallic), g_rough.view_as(roughness), g_alb, None, None, None, None, None, None, None, None, None)
+        g_alb, g_met, g_rough = ops.shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt.contiguous(), sd, nf, ss, smith=ctx.smith)
+        return (g_met.view_as(metallic), g_rough.view_as(roughness), g_alb, None, None, None, None, None, None, None, None, None, None)
 
 
 class LightsFn(torch.autograd.Function):

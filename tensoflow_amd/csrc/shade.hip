@@ -26,6 +26,17 @@ __device__ __forceinline__ float schlick_g1(float c, float a) {
   return c / (c * (1.f - k) + k + 1e-5f);
 }
 
+// geometry_ggx_smith_correlated (fields.py:1000-1008): 1 / (1 + L(NoV) + L(NoL)), L(c) = (sqrt(1 + a^2 tan^2) - 1) / 2 with a^2 = roughness^2
+// and tan^2 = (1 - c^2) / (c^2 + 1e-7)
+__device__ __forceinline__ float smith_lambda(float c, float a2) {
+  const float c2 = c * c;
+  const float t2 = (1.f - c2) / (c2 + 1e-7f);
+  return 0.5f * sqrtf(1.f + a2 * t2) - 0.5f;
+}
+#define TF_SHADE_WHOLE_DIFFUSE 1   // mode bits of the direction kernels (tf_shade_dirs_ex): the flow of that lobe samples the outgoing direction
+#define TF_SHADE_WHOLE_SPECULAR 2
+#define TF_SHADE_GGX_SMITH 4       // cfg geometry_type = 'ggx_smith' instead of 'schlick'
+
 // 12-byte rows as ONE memory instruction (global_load_dwordx3 / global_store_dwordx3) instead of three strided dword accesses
 struct __attribute__((packed, aligned(4))) F3 { float x, y, z; };
 __device__ __forceinline__ F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
@@ -145,7 +156,8 @@ __global__ void __launch_bounds__(256) shade_dirs_kernel(
     const float HoV = sat(dot3(Hs, v));
     const float f5 = pow5(sat(1.f - HoV));
     const float NoV = sat(dot3(F.n, v)), NoL = sat(dot3(F.n, dir)), NoH = sat(dot3(F.n, Hs));
-    const float geo = schlick_g1(NoV, rough) * schlick_g1(NoL, rough);
+    const float geo = (whole_mask & TF_SHADE_GGX_SMITH) ? 1.f / (1.f + smith_lambda(NoV, rough * rough) + smith_lambda(NoL, rough * rough))
+                                                        : schlick_g1(NoV, rough) * schlick_g1(NoL, rough);
     const float D = ggx_d(NoH, rough);
     const float inv = 1.f / fmaxf(4.f * NoV, kEPS) / fmaxf(pdf, kEPS) / (float)ss;
 #pragma unroll
@@ -167,7 +179,7 @@ __global__ void __launch_bounds__(256) shade_dirs_bwd_kernel(
     const float* __restrict__ normals, const float* __restrict__ view, const float* __restrict__ metallic,
     const float* __restrict__ roughness, const float* __restrict__ albedo, const float* __restrict__ dirs,
     const float* __restrict__ wgt, const float* __restrict__ g_wgt, int sd, int nf, int ss, long long pn,
-    float* __restrict__ g_albedo, float* __restrict__ g_metallic, float* __restrict__ g_roughness) {
+    float* __restrict__ g_albedo, float* __restrict__ g_metallic, float* __restrict__ g_roughness, int mode) {
   const int lane = threadIdx.x & 63;
   const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pt >= pn) return;
@@ -205,7 +217,13 @@ __global__ void __launch_bounds__(256) shade_dirs_bwd_kernel(
       const float dlogD = (kPi * q * q > kEPS) ? (2.f / a) * (1.f - 2.f * a2 * NoH * NoH / q) : 2.f / a;
       const float k_ = a / 2.f;
       const float denV = NoV * (1.f - k_) + k_ + 1e-5f, denL = NoL * (1.f - k_) + k_ + 1e-5f;
-      const float dlogG = -(1.f - NoV) / (2.f * denV) - (1.f - NoL) / (2.f * denL);
+      float dlogG = -(1.f - NoV) / (2.f * denV) - (1.f - NoL) / (2.f * denL);
+      if (mode & TF_SHADE_GGX_SMITH) {
+        // G = 1 / (1 + L_v + L_l), L = (sqrt(1 + a^2 t) - 1) / 2  ->  dL / da = a t / (2 sqrt(1 + a^2 t))
+        const float tv = (1.f - NoV * NoV) / (NoV * NoV + 1e-7f), tl = (1.f - NoL * NoL) / (NoL * NoL + 1e-7f);
+        const float rv = sqrtf(1.f + a2 * tv), rl = sqrtf(1.f + a2 * tl);
+        dlogG = -(a * tv / (2.f * rv) + a * tl / (2.f * rl)) / (1.f + (0.5f * rv - 0.5f) + (0.5f * rl - 0.5f));
+      }
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float F0 = 0.04f * (1.f - met) + met * alb[k];
@@ -493,7 +511,7 @@ extern "C" int tf_shade_dirs_whole(const float* normals, const float* view, cons
                                    const float* az_jitter, int32_t nf, const float* ang_s, const float* logq_s, int32_t ss,
                                    int64_t pn, float* dirs, float* wgt, uint8_t* spec_mask, uint8_t* live, float* flow_logjac,
                                    const int32_t* slot_of_pos, int32_t row_begin, int32_t row_count, int32_t whole_mask, tf_stream_t stream) {
-  TF_REQUIRE(whole_mask >= 0 && whole_mask <= 3, TF_EINVAL, "tf_shade_dirs_whole: whole_mask must be 0..3");
+  TF_REQUIRE(whole_mask >= 0 && whole_mask <= 7, TF_EINVAL, "tf_shade_dirs_whole: whole_mask must be 0..7");
   return shade_dirs_launch(normals, view, metallic, roughness, albedo, ang_d, logq_d, sd, fixed_d, az_jitter, nf, ang_s, logq_s,
                            nullptr, nullptr, ss, pn, dirs, wgt, spec_mask, live, flow_logjac, slot_of_pos, row_begin, row_count, stream,
                            "tf_shade_dirs_whole", whole_mask);
@@ -507,6 +525,15 @@ extern "C" int tf_shade_dirs_fixed(const float* normals, const float* view, cons
                            fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, nullptr, 0, -1, stream, "tf_shade_dirs_fixed");
 }
 
+extern "C" int tf_shade_dirs_fixed_mode(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                        const float* albedo, const float* fixed_d, const float* az_jitter, int32_t nf,
+                                        const float* fixed_s, const float* az_jitter_s, int32_t ss, int64_t pn, float* dirs, float* wgt,
+                                        uint8_t* spec_mask, uint8_t* live, int32_t mode, tf_stream_t stream) {
+  TF_REQUIRE(mode == 0 || mode == TF_SHADE_GGX_SMITH, TF_EINVAL, "tf_shade_dirs_fixed_mode: mode must be 0 or 4 (ggx_smith geometry)");
+  return shade_dirs_launch(normals, view, metallic, roughness, albedo, nullptr, nullptr, 0, fixed_d, az_jitter, nf, nullptr, nullptr,
+                           fixed_s, az_jitter_s, ss, pn, dirs, wgt, spec_mask, live, nullptr, nullptr, 0, -1, stream, "tf_shade_dirs_fixed_mode", mode);
+}
+
 extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn, int32_t n_diffuse, int32_t ss,
                                float* colors, float* diffuse_lin, float* specular_lin, tf_stream_t stream) {
   TF_REQUIRE(pn >= 0 && n_diffuse >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_reduce: negative size");
@@ -518,15 +545,32 @@ extern "C" int tf_shade_reduce(const float* wgt, const float* lights, int64_t pn
   return TF_OK;
 }
 
+static int shade_dirs_bwd_launch(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                 const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd, int32_t nf,
+                                 int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness, int32_t mode,
+                                 tf_stream_t stream, const char* who) {
+  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "%s: negative size", who);
+  TF_REQUIRE(mode == 0 || mode == TF_SHADE_GGX_SMITH, TF_EINVAL, "%s: mode must be 0 or 4 (ggx_smith geometry)", who);
+  if (pn == 0) return TF_OK;
+  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt && g_wgt && g_albedo && g_metallic && g_roughness,
+             TF_EINVAL, "%s: null pointer", who);
+  shade_dirs_bwd_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, dirs, wgt,
+                                                                          g_wgt, sd, nf, ss, pn, g_albedo, g_metallic, g_roughness, mode);
+  TF_LAUNCH_CHECK(who);
+  return TF_OK;
+}
+
 extern "C" int tf_shade_dirs_bwd(const float* normals, const float* view, const float* metallic, const float* roughness,
                                  const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd, int32_t nf,
                                  int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness, tf_stream_t stream) {
-  TF_REQUIRE(pn >= 0 && sd >= 0 && nf >= 0 && ss >= 0, TF_ESHAPE, "tf_shade_dirs_bwd: negative size");
-  if (pn == 0) return TF_OK;
-  TF_REQUIRE(normals && view && metallic && roughness && albedo && dirs && wgt && g_wgt && g_albedo && g_metallic && g_roughness,
-             TF_EINVAL, "tf_shade_dirs_bwd: null pointer");
-  shade_dirs_bwd_kernel<<<tf_blocks(pn, 4), 256, 0, (hipStream_t)stream>>>(normals, view, metallic, roughness, albedo, dirs, wgt,
-                                                                          g_wgt, sd, nf, ss, pn, g_albedo, g_metallic, g_roughness);
-  TF_LAUNCH_CHECK("tf_shade_dirs_bwd");
-  return TF_OK;
+  return shade_dirs_bwd_launch(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss, pn, g_albedo, g_metallic,
+                               g_roughness, 0, stream, "tf_shade_dirs_bwd");
+}
+
+extern "C" int tf_shade_dirs_bwd_mode(const float* normals, const float* view, const float* metallic, const float* roughness,
+                                      const float* albedo, const float* dirs, const float* wgt, const float* g_wgt, int32_t sd, int32_t nf,
+                                      int32_t ss, int64_t pn, float* g_albedo, float* g_metallic, float* g_roughness, int32_t mode,
+                                      tf_stream_t stream) {
+  return shade_dirs_bwd_launch(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss, pn, g_albedo, g_metallic,
+                               g_roughness, mode, stream, "tf_shade_dirs_bwd_mode");
 }

@@ -131,7 +131,9 @@ SIGNATURES = {
     "tf_shade_dirs": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, c_f]),
     "tf_shade_dirs_whole": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, c_f]),
     "tf_shade_dirs_fixed": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, c_f]),
+    "tf_shade_dirs_fixed_mode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, c_f, c_f, i32, i64, c_f, c_f, c_f, c_f, i32, c_f]),
     "tf_shade_dirs_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, c_f]),
+    "tf_shade_dirs_bwd_mode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, i32, i32, i32, i64, c_f, c_f, c_f, i32, c_f]),
     "tf_inner_light_encode": (C.c_int, [c_f, c_f, c_f, c_f, c_f, i64, c_f, i32, c_f, sz, c_f]),
     "tf_tv_partials": (C.c_int32, []),
     "tf_tv_fwd": (C.c_int, [c_f, i32, i32, i32, c_f, c_f]),

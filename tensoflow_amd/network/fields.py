@@ -214,11 +214,12 @@ class MCShadingNetwork(nn.Module):
     # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547).  No
     # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
     _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True,
-                   "flow_diffuse": "pwquad", "flow_specular": "pwquad", "geometry_type": "schlick"}
+                   "flow_diffuse": "pwquad", "flow_specular": "pwquad"}
     # (ARE built since round 6: use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the
     # half vector, :1117-1134, :1190-1203: tf_shade_dirs_whole, golden `shading_whole`; disable_tensorial / disable_reflected -- the
     # flows' tensorial feature / view-angle embedding zeroed, flow.py:807-812: TensoFlow._condition and MCShader.shade, golden
-    # `shading_ablate`)
+    # `shading_ablate`; geometry_type = 'ggx_smith', :1000-1008: a mode bit of the direction kernels and of their backward, golden
+    # `shading_smith`)
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -229,6 +230,8 @@ class MCShadingNetwork(nn.Module):
                                           f"reference default; /root/reference/network/fields.py:617-667) and does not ignore the key")
         if self.cfg["outer_light_version"] not in ("envlight", "direction", "sphere_direction"):
             raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
+        if self.cfg["geometry_type"] not in ("schlick", "ggx_smith"):      # fields.py:1026-1033: anything else raises there too
+            raise NotImplementedError(f"geometry_type {self.cfg['geometry_type']!r}: 'schlick' or 'ggx_smith'")
         if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":
             raise NotImplementedError("human_lights with the cube-map outer light (no shipped config combines them)")
         self.aabb, self.unit_size, self.ray_tracer = aabb, float(unit_size), ray_tracer
@@ -283,7 +286,8 @@ class MCShadingNetwork(nn.Module):
                                 # not a reference key: "f16x2" opts in to the narrower inner-light operands (MCShader.__init__); default f16x3
                                 inner_precision={"f16x3": ops.PREC_F16X3, "f16x2": ops.PREC_F16X2}[self.cfg.get("inner_light_operands", "f16x3")],
                                 use_half=(bool(self.cfg["use_half_diffuse"]), bool(self.cfg["use_half_specular"])),
-                                flow_ablate=(bool(self.cfg["disable_tensorial"]), bool(self.cfg["disable_reflected"])))
+                                flow_ablate=(bool(self.cfg["disable_tensorial"]), bool(self.cfg["disable_reflected"])),
+                                geometry_type=self.cfg["geometry_type"])
         if self._composed_lights:
             self._shader.overlap_dirs = False      # (the composed miss branch allocates between the streams' kernels: keep one stream)
         self._shader_version = ver
@@ -438,7 +442,8 @@ class MCShadingNetwork(nn.Module):
             az_jit = torch.rand(pn, device=dev) if (is_train and self.training and self.cfg["random_azimuth"]) else None      # fields.py:837
         wgt, dirs, smask, live, logjac = ShadeWeightsFn.apply(metallic, roughness, albedo, normals.contiguous(), view_dirs.contiguous(),
                                                               ang_d, lq_d, self._fixed, ang_s, lq_s, az_jit,
-                                                              (not self.cfg["use_half_diffuse"], not self.cfg["use_half_specular"]))
+                                                              (not self.cfg["use_half_diffuse"], not self.cfg["use_half_specular"]),
+                                                              self.cfg["geometry_type"] == "ggx_smith")
         T = dirs.shape[1]
         nd = sd + self._fixed.shape[0]
         pts_rep = pts.contiguous()                       # T rays per origin row (tf_bvh_trace rays_per_origin)
@@ -594,9 +599,11 @@ class MCShadingNetwork(nn.Module):
         NoV = sat(normals, view_dirs)[rid]
         NoL = sat(normals[rid], sd_)
         g1 = lambda c, r: c / (c * (1 - r / 2) + r / 2 + 1e-5)
-        if cfg.get("geometry_type", "schlick") != "schlick":
-            raise NotImplementedError("geometry_type='schlick' (every shipped config)")
-        geo = g1(NoV, roughness[rid]) * g1(NoL, roughness[rid])
+        if cfg["geometry_type"] == "ggx_smith":              # geometry_ggx_smith_correlated (fields.py:1000-1008)
+            lam = lambda a2, c: 0.5 * torch.sqrt(1 + a2 * (1 - c ** 2) / (c ** 2 + 1e-7)) - 0.5
+            geo = 1.0 / (1.0 + lam(roughness[rid] ** 2, NoV) + lam(roughness[rid] ** 2, NoL))
+        else:
+            geo = g1(NoV, roughness[rid]) * g1(NoL, roughness[rid])
         dist = ggx(sat(normals[rid], Hh), roughness[rid])
         s_lights, s_hit, s_hl = self._lights_of(pts[rid], sd_, human_poses[rid] if human_poses is not None else None)
         s_w = dist * fres * geo / (4 * NoV).clamp_min(EPS)

@@ -1200,8 +1200,9 @@ def view_angles(normals, view):
 
 
 def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_d, ang_s, logq_s, az_jitter=None, want_logjac=False,
-               slot_of_pos=None, rows=None, out=None, whole=(False, False)):
-    """whole = (diffuse, specular): that lobe's flow samples are OUTGOING directions, not half vectors (cfg use_half_* = False).
+               slot_of_pos=None, rows=None, out=None, whole=(False, False), smith=False):
+    """whole = (diffuse, specular): that lobe's flow samples are OUTGOING directions, not half vectors (cfg use_half_* = False);
+    smith: cfg geometry_type = 'ggx_smith' (the Smith geometry term instead of the Schlick-GGX product).
     slot_of_pos [T] int32 permutation: row j of dirs / wgt / live holds slot slot_of_pos[j] (a point's rays stored in traversal order).
     rows = (begin, count): build only these rows of every point, into the arrays `out` = (dirs, wgt, mask, live) of an earlier call
     (None: allocate); the sample arrays of direction sets outside the range are not read, so a set's rows can be built while the
@@ -1229,7 +1230,7 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     else:
         a_s, l_s = g(ang_s), g(None if logq_s is None else logq_s.reshape(pn, ss))
     r0, rc = (0, -1) if rows is None else (int(rows[0]), int(rows[1]))
-    wm = (1 if whole[0] else 0) | (2 if whole[1] else 0)
+    wm = (1 if whole[0] else 0) | (2 if whole[1] else 0) | (4 if smith else 0)
     L.check(lib.tf_shade_dirs_whole(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
                                     _p(_f(albedo)), _p(g(ang_d)), _p(g(None if logq_d is None else logq_d.reshape(pn, sd))), sd,
                                     _p(g(fixed_d)), _p(g(az_jitter)), nf, _p(a_s), _p(l_s), ss, pn, _p(dirs), _p(wgt),
@@ -1240,7 +1241,7 @@ def shade_dirs(normals, view, metallic, roughness, albedo, ang_d, logq_d, fixed_
     return dirs, wgt, mask.bool() if out is None else mask, live
 
 
-def shade_dirs_fixed(normals, view, metallic, roughness, albedo, fixed_d, fixed_s, az_jitter=None, az_jitter_s=None):
+def shade_dirs_fixed(normals, view, metallic, roughness, albedo, fixed_d, fixed_s, az_jitter=None, az_jitter_s=None, smith=False):
     """Direction sets of the non-NIS pass of shade_mixed: nf fixed cosine + ss fixed GGX-warped directions per point.
     -> dirs [pn,nf+ss,3], wgt [pn,nf+ss,3], spec_mask [pn,ss] bool, live [pn,nf+ss] u8."""
     lib = L.load()
@@ -1251,22 +1252,23 @@ def shade_dirs_fixed(normals, view, metallic, roughness, albedo, fixed_d, fixed_
     mask = torch.empty(pn, ss, dtype=torch.uint8, device=dev)
     live = torch.empty(pn, nf + ss, dtype=torch.uint8, device=dev)
     g = lambda t: None if t is None else _f(t)
-    L.check(lib.tf_shade_dirs_fixed(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
-                                    _p(_f(albedo)), _p(_f(fixed_d)), _p(g(az_jitter)), nf, _p(_f(fixed_s)), _p(g(az_jitter_s)), ss, pn,
-                                    _p(dirs), _p(wgt), _p(mask, torch.uint8), _p(live, torch.uint8), _stream()), "tf_shade_dirs_fixed")
+    L.check(lib.tf_shade_dirs_fixed_mode(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                                         _p(_f(albedo)), _p(_f(fixed_d)), _p(g(az_jitter)), nf, _p(_f(fixed_s)), _p(g(az_jitter_s)), ss, pn,
+                                         _p(dirs), _p(wgt), _p(mask, torch.uint8), _p(live, torch.uint8), 4 if smith else 0, _stream()),
+            "tf_shade_dirs_fixed_mode")
     return dirs, wgt, mask.bool(), live
 
 
-def shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss):
+def shade_dirs_bwd(normals, view, metallic, roughness, albedo, dirs, wgt, g_wgt, sd, nf, ss, smith=False):
     lib = L.load()
     pn = normals.shape[0]
     dev = normals.device
     g_alb = torch.empty(pn, 3, dtype=torch.float32, device=dev)
     g_met = torch.empty(pn, dtype=torch.float32, device=dev)
     g_rough = torch.empty(pn, dtype=torch.float32, device=dev)
-    L.check(lib.tf_shade_dirs_bwd(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
-                                  _p(_f(albedo)), _p(_f(dirs)), _p(_f(wgt)), _p(_f(g_wgt)), sd, nf, ss, pn, _p(g_alb), _p(g_met),
-                                  _p(g_rough), _stream()), "tf_shade_dirs_bwd")
+    L.check(lib.tf_shade_dirs_bwd_mode(_p(_f(normals)), _p(_f(view)), _p(_f(metallic.reshape(-1))), _p(_f(roughness.reshape(-1))),
+                                       _p(_f(albedo)), _p(_f(dirs)), _p(_f(wgt)), _p(_f(g_wgt)), sd, nf, ss, pn, _p(g_alb), _p(g_met),
+                                       _p(g_rough), 4 if smith else 0, _stream()), "tf_shade_dirs_bwd_mode")
     return g_alb, g_met, g_rough
 
 

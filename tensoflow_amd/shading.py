@@ -296,8 +296,11 @@ class MCShader:
 
     def __init__(self, sd, vertices, triangles, aabb, unit_size, device="cuda", n_fixed_diffuse=512,
                  exp_max=5.0, flow_suffix="_copy", precision=ops.PREC_F16X3, n_fixed_specular=256, bvh=None, field_f16=False,
-                 light_exp_max=5.0, inner_precision=None, use_half=(True, True), flow_ablate=(False, False)):
+                 light_exp_max=5.0, inner_precision=None, use_half=(True, True), flow_ablate=(False, False), geometry_type="schlick"):
         self.device = device
+        if geometry_type not in ("schlick", "ggx_smith"):           # fields.py:1026-1033
+            raise NotImplementedError(f"geometry_type {geometry_type!r}: 'schlick' or 'ggx_smith'")
+        self.smith = geometry_type == "ggx_smith"
         # cfg disable_tensorial / disable_reflected (fields.py:665-666 -> flow.py:807-812): the flows' condition rows with the tensorial
         # feature (columns 0..15) / the view-angle embedding (16..29) zeroed
         self.flow_ablate = tuple(bool(v) for v in flow_ablate)
@@ -564,7 +567,7 @@ class MCShader:
         pn = pts.shape[0]
         va = ops.view_angles(normals, view_dirs)
         metallic, rough, albedo, _, _ = self.point_prep(pts, va)
-        dirs, wgt, smask, live = ops.shade_dirs_fixed(normals, view_dirs, metallic, rough, albedo, self.fixed_d, self.fixed_s)
+        dirs, wgt, smask, live = ops.shade_dirs_fixed(normals, view_dirs, metallic, rough, albedo, self.fixed_d, self.fixed_s, smith=self.smith)
         T, nd, ns = dirs.shape[1], self.fixed_d.shape[0], self.fixed_s.shape[0]
         # aux: the unweighted maps average over EVERY ray (zero weight or not), so nothing is culled for such a call
         hit_lights, hit, depth, inters = self.trace_and_inner(pts, dirs.reshape(-1, 3), live=live if (self.cull_dead_rays and not aux) else None,
@@ -622,21 +625,21 @@ class MCShader:
             with torch.cuda.stream(side):
                 with tm.stage("shade_dirs (diffuse + fixed rows)", overlapped=True):
                     ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, (sn_specular,), None,
-                                   slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs, whole=self.whole)
+                                   slot_of_pos=order, rows=(0, sn_diffuse + nf), out=bufs, whole=self.whole, smith=self.smith)
             with tm.stage("flow_sample"):
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
             with tm.stage("shade_dirs"):
                 cur.wait_stream(side)
                 dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
-                                                        slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs, whole=self.whole)
+                                                        slot_of_pos=order, rows=(sn_diffuse + nf, sn_specular), out=bufs, whole=self.whole, smith=self.smith)
         else:
             with tm.stage("flow_sample"):
                 ang_s, lq_s = ops.flow_sample(self.flow_s.nets, cond_s, self.latent(sn_specular), jitter_s, precision=self.precision,
                                               cache=self.flow_s.cache)
             with tm.stage("shade_dirs"):
                 dirs, wgt, smask, live = ops.shade_dirs(normals, view_dirs, metallic, rough, albedo, ang_d, lq_d, self.fixed_d, ang_s, lq_s,
-                                                        slot_of_pos=order, whole=self.whole)
+                                                        slot_of_pos=order, whole=self.whole, smith=self.smith)
         tm.add_units("flow_sample", pn * (sn_diffuse + sn_specular))
         T = dirs.shape[1]
         # the T secondary rays of a point share its origin row (tf_bvh_trace rays_per_origin = T): pts[:,None].expand is never built

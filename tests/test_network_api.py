@@ -40,7 +40,7 @@ def test_fused_forward_refuses_autograd():
 
 REFUSED_CFG = [("shade_fn", "shade_mixed_all"), ("use_nis_all", True), ("use_nis_diffuse", False), ("use_nis_specular", False),
                ("flow_diffuse", "pwlinear"), ("flow_specular", "affine"),
-               ("geometry_type", "ggx_smith"), ("outer_light_version", "latlong")]
+               ("geometry_type", "beckmann"), ("outer_light_version", "latlong")]
 
 
 @pytest.mark.parametrize("key,value", REFUSED_CFG)

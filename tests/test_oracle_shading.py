@@ -151,6 +151,21 @@ def test_flow_ablation_switches(golden):
     assert rel_err(plain["colors"], g["eval/rgb_pr_nis"]) > 1e-3          # the switches change the picture: the golden pins the branch
 
 
+def test_ggx_smith_geometry(golden):
+    """cfg geometry_type = 'ggx_smith' (fields.py:1000-1008, :1029): the oracle's branch against the reference's eval forward, both passes
+    (golden shading_smith; state and mesh of shading_grad)."""
+    g, base = golden("shading_smith"), golden("shading_grad")
+    tr = _tracer(base)
+    n_fd, n_fs, sn_d, sn_s = [int(v) for v in g["sn"]]
+    kw = dict(n_fixed_diffuse=n_fd, n_fixed_specular=n_fs)
+    for use_flow, key, tol in ((False, "eval/colors", 2e-5), (True, "eval/rgb_pr_nis", 5e-5)):
+        got = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=use_flow,
+                        geometry_type="ggx_smith", **kw)
+        assert rel_err(got["colors"], g[key]) < tol
+        plain = osh.shade(base.sd, tr, float(g["unit_size"]), AABB, g["pts"], g["view_in"], g["normals_in"], sn_d, sn_s, use_flow=use_flow, **kw)
+        assert rel_err(plain["colors"], g[key]) > 1e-3       # the switch changes the picture: the golden pins the branch
+
+
 def test_cpu_bvh_equals_brute_force():
     """oracle/bvh_cpu.c against oracle/mesh.py:ray_triangles: hit sets identical, the same face wherever the nearest hit is
     unique, t within an ulp or two (torch's 3-term reductions round differently from the C expression on ~1 % of rays); rays along

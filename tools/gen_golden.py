@@ -770,6 +770,11 @@ def gen_shading_whole():
     _gen_shading_variant("shading_whole", dict(use_half_diffuse=False, use_half_specular=False))
 
 
+def gen_shading_smith():
+    """cfg geometry_type = 'ggx_smith' (fields.py:626, :1026-1033): geometry_ggx_smith_correlated (:1000-1008) in the specular weights."""
+    _gen_shading_variant("shading_smith", dict(geometry_type="ggx_smith"))
+
+
 def gen_shading_ablate():
     """cfg disable_tensorial = disable_reflected = True (fields.py:665-666 -> TensoFlow, flow.py:807-812, :838-843: the flows' tensorial
     feature and view-angle embedding zeroed -- the paper's ablation switches)."""
@@ -1257,7 +1262,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
