@@ -213,13 +213,13 @@ class MCShadingNetwork(nn.Module):
     # :1337-1451 with switches :752,1458-1461,1589; fixed samplers beside a flow :1082,1160; whole-direction instead of half-vector flows
     # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547).  No
     # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
-    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True,
-                   "flow_diffuse": "pwquad", "flow_specular": "pwquad"}
+    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True}
     # (ARE built since round 6: use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the
     # half vector, :1117-1134, :1190-1203: tf_shade_dirs_whole, golden `shading_whole`; disable_tensorial / disable_reflected -- the
     # flows' tensorial feature / view-angle embedding zeroed, flow.py:807-812: TensoFlow._condition and MCShader.shade, golden
     # `shading_ablate`; geometry_type = 'ggx_smith', :1000-1008: a mode bit of the direction kernels and of their backward, golden
-    # `shading_smith`)
+    # `shading_smith`; flow_diffuse / flow_specular = 'pwlinear', flow.py:174-312: TensoFlow's composed transforms in every pass, the
+    # inference pass as the two training compositions without autograd -- correct, not fast; golden `shading_pwlinear`)
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -230,6 +230,9 @@ class MCShadingNetwork(nn.Module):
                                           f"reference default; /root/reference/network/fields.py:617-667) and does not ignore the key")
         if self.cfg["outer_light_version"] not in ("envlight", "direction", "sphere_direction"):
             raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
+        for key in ("flow_diffuse", "flow_specular"):                      # 'realnvp' (fields.py:755-760 -> flow.py:645): not built
+            if self.cfg[key] not in ("pwquad", "pwlinear"):
+                raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: 'pwquad' or 'pwlinear'")
         if self.cfg["geometry_type"] not in ("schlick", "ggx_smith"):      # fields.py:1026-1033: anything else raises there too
             raise NotImplementedError(f"geometry_type {self.cfg['geometry_type']!r}: 'schlick' or 'ggx_smith'")
         if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":
@@ -259,10 +262,13 @@ class MCShadingNetwork(nn.Module):
                                              nn.ReLU(), wn(nn.Linear(256, 4)), nn.Identity()).cuda()
             nn.init.constant_(self.human_light[-2].bias, np.log(0.02))
         self._composed_lights = self.cfg["outer_light_version"] == "sphere_direction" or self.cfg["human_lights"]
-        mkflow = lambda: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda", disable_tensorial=bool(self.cfg["disable_tensorial"]),
-                                   disable_reflected=bool(self.cfg["disable_reflected"]))
-        self.flow_diffuse, self.flow_diffuse_copy = mkflow(), mkflow()
-        self.flow_specular, self.flow_specular_copy = mkflow(), mkflow()
+        # fields.py:755-760: one transform per lobe (cfg flow_diffuse / flow_specular; TensoFlow refuses 'realnvp')
+        mkflow = lambda kind: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda", flow=kind,
+                                        disable_tensorial=bool(self.cfg["disable_tensorial"]), disable_reflected=bool(self.cfg["disable_reflected"]))
+        self.flow_diffuse, self.flow_diffuse_copy = mkflow(self.cfg["flow_diffuse"]), mkflow(self.cfg["flow_diffuse"])
+        self.flow_specular, self.flow_specular_copy = mkflow(self.cfg["flow_specular"]), mkflow(self.cfg["flow_specular"])
+        # the fused inference pass (MCShader) instantiates the default transform; any other runs the compositions (see _forward_eval)
+        self._fused_flows = all(fl._fused for fl in (self.flow_diffuse_copy, self.flow_specular_copy))
         self._shader, self._shader_version = None, None
         self.use_flow_diffuse_copy = self.use_flow_specular_copy = False      # fields.py:752-760: set by update_step at nis_start_iter
 
@@ -683,6 +689,8 @@ class MCShadingNetwork(nn.Module):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
         from ..shading import LazyOutputs, aux_outputs
+        if not self._fused_flows:
+            return self._forward_eval_composed(pts, view_dirs, normals, human_poses)
         sh = self.shader()
         nrm = (F.normalize(normals, dim=-1) + 1) / 2
         # the unweighted light maps (diffuse_light, visibility ...) average over EVERY ray, incl. those whose BRDF weight is zero:
@@ -704,6 +712,32 @@ class MCShadingNetwork(nn.Module):
             outputs.set_lazy("human_lights" + sfx, lambda o=o: o["human_lights"])
         outputs.set_lazy("specular_rays_id_nis", lambda: nis["specular_rays_id"])
         return fx["colors"], outputs
+
+    @torch.no_grad()
+    def _forward_eval_composed(self, pts, view_dirs, normals, human_poses=None):
+        """_forward_eval for flows the fused kernels do not instantiate (cfg flow_diffuse / flow_specular != 'pwquad'): the fixed-sampler pass
+        and the flow pass are the two training compositions (forward_train_fixed / forward_train: every stage a HIP kernel or a
+        device-resident torch op) evaluated without autograd, no jitter -- correct, not fast.  Same dict as the fused pass."""
+        from ..shading import LazyOutputs
+        hp = human_poses.float().contiguous() if (human_poses is not None and self.cfg["human_lights"]) else None
+        c_fix, o_fix = self.forward_train_fixed(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp)
+        c_nis, o_nis = self.forward_train(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp)
+        outputs = LazyOutputs()
+        for src, sfx in ((o_fix, ""), (o_nis, "_nis")):
+            keys = set(dict.keys(src)) | set(getattr(src, "_lazy", {}))
+            for k in keys:
+                if k.startswith("loss_nis") or k == "specular_mask":
+                    continue
+                if dict.__contains__(src, k):
+                    outputs[k + sfx] = src[k]
+                else:
+                    outputs.set_lazy(k + sfx, lambda src=src, k=k: src[k])
+        outputs["rgb_pr_nis"] = c_nis
+        outputs.set_lazy("specular_rays_id_nis", lambda: torch.nonzero(o_nis["specular_mask"])[:, 0])
+        zero = torch.zeros((), device=pts.device)
+        for sfx in ("", "_nis"):
+            outputs["loss_nis_diffuse" + sfx] = outputs["loss_nis_specular" + sfx] = outputs["loss_nis" + sfx] = zero
+        return c_fix, outputs
 
 
 def _mlp(seq, x):

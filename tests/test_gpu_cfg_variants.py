@@ -7,7 +7,10 @@
 * `shading_ablate`: `disable_tensorial = disable_reflected = True` (:665-666 -> network/flow.py:807-812, :838-843): the flows' tensorial
   feature and view-angle embedding zeroed;
 * `shading_smith`: `geometry_type = 'ggx_smith'` (:626, :1026-1033): the Smith-correlated geometry term (:1000-1008) in the specular
-  weights of every pass, and its roughness derivative in the backward."""
+  weights of every pass, and its roughness derivative in the backward;
+* `shading_pwlinear`: `flow_diffuse = flow_specular = 'pwlinear'` (:653-654, :755-760 -> network/flow.py:174-312): piecewise-linear
+  coupling transforms in both lobes' flows (TensoFlow's composed transforms in every pass; the inference pass runs the two training
+  compositions without autograd).  The coupling nets' last layers have another shape: stored with the golden as `sdx/*`."""
 import pytest
 import torch
 
@@ -25,7 +28,8 @@ def dev():
 
 VARIANTS = {"shading_whole": dict(use_half_diffuse=False, use_half_specular=False),
             "shading_ablate": dict(disable_tensorial=True, disable_reflected=True),
-            "shading_smith": dict(geometry_type="ggx_smith")}
+            "shading_smith": dict(geometry_type="ggx_smith"),
+            "shading_pwlinear": dict(flow_diffuse="pwlinear", flow_specular="pwlinear")}
 
 
 def _net(golden, dev, variant):
@@ -35,7 +39,9 @@ def _net(golden, dev, variant):
     cfg = dict(gridSize=[32, 32, 32], light_reso=16, mat_grid=32, diffuse_sample_num=n_fd, specular_sample_num=n_fs, nis_diffuse_sample_num=sn_d,
                nis_specular_sample_num=sn_s, outer_light_version="envlight", **VARIANTS[variant])
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
-    missing, _ = m.load_state_dict(base.sd, strict=False)
+    sd = dict(base.sd)
+    sd.update({k[4:]: v for k, v in g.a.items() if k.startswith("sdx/")})          # tensors whose shape the variant changes
+    missing, _ = m.load_state_dict(sd, strict=False)
     assert not missing
     for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
         for p in fl.parameters():

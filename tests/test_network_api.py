@@ -39,7 +39,7 @@ def test_fused_forward_refuses_autograd():
 
 
 REFUSED_CFG = [("shade_fn", "shade_mixed_all"), ("use_nis_all", True), ("use_nis_diffuse", False), ("use_nis_specular", False),
-               ("flow_diffuse", "pwlinear"), ("flow_specular", "affine"),
+               ("flow_diffuse", "realnvp"), ("flow_specular", "affine"),
                ("geometry_type", "beckmann"), ("outer_light_version", "latlong")]
 
 

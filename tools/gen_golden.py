@@ -713,8 +713,8 @@ def gen_shading_grad():
 
 
 def _gen_shading_variant(name, over):
-    """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad`.  The network, mesh and points of `shading_grad` (same seeds: only
-    outputs are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
+    """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad` (same seeds: only outputs -- and the
+    tensors whose shape the variant changes, sdx/* -- are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
     600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
     from network.fields import MCShadingNetwork
     from network.materialRenderer import MaterialRenderer
@@ -735,13 +735,19 @@ def _gen_shading_variant(name, over):
     w = torch.rand(pn, 3, generator=g)
     arrays = dict(pts=pts, view_in=view, normals_in=nrm, bwd_w=w)
 
+    extra = {}
+
     def make():
         torch.manual_seed(4)
         net = MCShadingNetwork(cfg, trace, AABB)
         net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, R)) for _ in range(3)])
         net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, 1)) for _ in range(3)])
-        missing, unexpected = net.load_state_dict(base, strict=False)
-        assert not missing, missing
+        own = net.state_dict()
+        fit = {k: v for k, v in base.items() if k not in own or own[k].shape == v.shape}
+        missing, unexpected = net.load_state_dict(fit, strict=False)
+        # tensors whose SHAPE the variant changes (another transform's coupling nets) keep the seeded initialisation: stored with the golden
+        assert set(missing) == {k for k in base if k in own and own[k].shape != base[k].shape}, missing
+        extra.update({k: own[k].detach().clone() for k in missing})
         for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
             for p in fl.parameters():
                 p.requires_grad = False
@@ -761,6 +767,7 @@ def _gen_shading_variant(name, over):
         arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
                        f"{tag}/loss_nis_specular": outputs["loss_nis_specular"]})
         arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    arrays.update({"sdx/" + k: v for k, v in extra.items()})
     save(name, verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **arrays)
 
 
@@ -773,6 +780,12 @@ def gen_shading_whole():
 def gen_shading_smith():
     """cfg geometry_type = 'ggx_smith' (fields.py:626, :1026-1033): geometry_ggx_smith_correlated (:1000-1008) in the specular weights."""
     _gen_shading_variant("shading_smith", dict(geometry_type="ggx_smith"))
+
+
+def gen_shading_pwlinear():
+    """cfg flow_diffuse = flow_specular = 'pwlinear' (fields.py:653-654, :755-760 -> flow.py:174-312, :646): piecewise-linear coupling
+    transforms in both lobes' flows (their coupling nets end in 10 outputs instead of 21: stored as sdx/*)."""
+    _gen_shading_variant("shading_pwlinear", dict(flow_diffuse="pwlinear", flow_specular="pwlinear"))
 
 
 def gen_shading_ablate():
@@ -1262,7 +1275,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
