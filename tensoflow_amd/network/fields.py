@@ -213,13 +213,15 @@ class MCShadingNetwork(nn.Module):
     # :1337-1451 with switches :752,1458-1461,1589; fixed samplers beside a flow :1082,1160; whole-direction instead of half-vector flows
     # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547).  No
     # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
-    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False, "use_nis_diffuse": True, "use_nis_specular": True}
+    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False}
     # (ARE built since round 6: use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the
     # half vector, :1117-1134, :1190-1203: tf_shade_dirs_whole, golden `shading_whole`; disable_tensorial / disable_reflected -- the
     # flows' tensorial feature / view-angle embedding zeroed, flow.py:807-812: TensoFlow._condition and MCShader.shade, golden
     # `shading_ablate`; geometry_type = 'ggx_smith', :1000-1008: a mode bit of the direction kernels and of their backward, golden
     # `shading_smith`; flow_diffuse / flow_specular = 'pwlinear', flow.py:174-312: TensoFlow's composed transforms in every pass, the
-    # inference pass as the two training compositions without autograd -- correct, not fast; golden `shading_pwlinear`)
+    # inference pass as the two training compositions without autograd -- correct, not fast; golden `shading_pwlinear`;
+    # use_nis_diffuse / use_nis_specular = False and the states with ONE flow copy active, :1081, :1160: forward_train_fixed's flow_lobes,
+    # goldens `shading_nonis_d`, `shading_nonis_s`)
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -265,10 +267,12 @@ class MCShadingNetwork(nn.Module):
         # fields.py:755-760: one transform per lobe (cfg flow_diffuse / flow_specular; TensoFlow refuses 'realnvp')
         mkflow = lambda kind: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda", flow=kind,
                                         disable_tensorial=bool(self.cfg["disable_tensorial"]), disable_reflected=bool(self.cfg["disable_reflected"]))
-        self.flow_diffuse, self.flow_diffuse_copy = mkflow(self.cfg["flow_diffuse"]), mkflow(self.cfg["flow_diffuse"])
-        self.flow_specular, self.flow_specular_copy = mkflow(self.cfg["flow_specular"]), mkflow(self.cfg["flow_specular"])
+        if self.cfg["use_nis_diffuse"]:             # (a lobe without its flow holds no flow modules: the reference's state_dict keys)
+            self.flow_diffuse, self.flow_diffuse_copy = mkflow(self.cfg["flow_diffuse"]), mkflow(self.cfg["flow_diffuse"])
+        if self.cfg["use_nis_specular"]:
+            self.flow_specular, self.flow_specular_copy = mkflow(self.cfg["flow_specular"]), mkflow(self.cfg["flow_specular"])
         # the fused inference pass (MCShader) instantiates the default transform; any other runs the compositions (see _forward_eval)
-        self._fused_flows = all(fl._fused for fl in (self.flow_diffuse_copy, self.flow_specular_copy))
+        self._fused_flows = all(fl._fused for fl in self.flow_copies())
         self._shader, self._shader_version = None, None
         self.use_flow_diffuse_copy = self.use_flow_specular_copy = False      # fields.py:752-760: set by update_step at nis_start_iter
 
@@ -304,13 +308,17 @@ class MCShadingNetwork(nn.Module):
         from ..trainer import material_param_groups
         return material_param_groups(self, lr_init_spatialxyz, lr_init_network, lr_init_envlight)
 
+    def flow_copies(self):
+        """The frozen sampling copies this cfg holds (fields.py:755-760)."""
+        return [getattr(self, n) for n in ("flow_diffuse_copy", "flow_specular_copy") if hasattr(self, n)]
+
     def update_step(self, step):
         """fields.py:1050-1065: every nis_update_interval steps from nis_start_iter on, the frozen sampling copies take the weights of
         the trained flows."""
         done = []
         for name in ("diffuse", "specular"):
             start, every = self.cfg[f"nis_start_iter_{name}"], self.cfg[f"nis_update_interval_{name}"]
-            if (step + 1) >= start and (step + 1 - start) % every == 0:
+            if self.cfg[f"use_nis_{name}"] and (step + 1) >= start and (step + 1 - start) % every == 0:
                 src, dst = getattr(self, f"flow_{name}"), getattr(self, f"flow_{name}_copy")
                 dst.load_state_dict(src.state_dict())
                 for p in dst.parameters():
@@ -524,8 +532,12 @@ class MCShadingNetwork(nn.Module):
         return colors, outputs
 
     # ---------------------------------------------------------------- training before the flow copies take over the sampling
-    def forward_train_fixed(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None):
-        """shade_mixed with BOTH fixed samplers (fields.py:1075-1335 with the `else` branches: the material stage's first
+    def forward_train_fixed(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None, flow_lobes=(False, False)):
+        """flow_lobes = (diffuse, specular): that lobe draws from its frozen flow copy instead (the mixed states of shade_mixed: one
+        copy active and the other not yet, or cfg use_nis_diffuse / use_nis_specular = False; both True is forward_train's fused form).
+        A flow-sampled lobe's directions carry no gradient (fields.py:1084-1134, :1163-1203); its NIS loss is fitted on the sampled
+        angles (:1257-1284, :1294-1330).  Default:
+        shade_mixed with BOTH fixed samplers (fields.py:1075-1335 with the `else` branches: the material stage's first
         nis_start_iter = 1000 steps, update_step :1050-1065): 512 cosine directions for the diffuse lobe and the roughness-warped
         GGX set for the specular lobe (sample_diffuse_directions / sample_specular_directions, :824-903).  Unlike the flow pass, the
         specular DIRECTIONS depend on the predicted roughness, so the colour gradient reaches the material grids through the
@@ -572,6 +584,27 @@ class MCShadingNetwork(nn.Module):
         el_sqrt = torch.sqrt(el + 1e-7)
         d_dirs = (el_sqrt * torch.cos(az)) * X + (el_sqrt * torch.sin(az)) * Y + torch.sqrt(1 - el + 1e-7) * Z
         d_pdf = sat(d_dirs, Z) / PI * (torch.cos((1 - el) * PI / 2) * PI / 2)
+        fd, fs = bool(flow_lobes[0]), bool(flow_lobes[1])
+        va = ops.view_angles(normals, view_dirs)
+        flow_jit = (lambda n: torch.rand(pn, n, device=dev)) if (is_train and self.training) else (lambda n: None)      # flow.py:86-87
+
+        def flow_dirs(flow_copy, n, half):
+            """A frozen copy's samples as directions (:1084-1134 / :1163-1203): -> dirs [pn,n,3], pdf [pn,n,1], x [pn,n,2], jac [pn,n,1]."""
+            with torch.no_grad():
+                ang, lq = flow_copy._sample_nograd(pts, va, n, flow_jit(n))
+                ph_, th_ = ang[..., :1] * (2 * PI), ang[..., 1:2] * (0.5 * PI)
+                Hf = (torch.sin(th_) * torch.cos(ph_)) * X + (torch.sin(th_) * torch.sin(ph_)) * Y + torch.cos(th_) * Z
+                if half:
+                    HoV_f = sat(V, Hf)
+                    dirs_f, jac_f = HoV_f * Hf * 2 - V, 4 * PI ** 2 * HoV_f * torch.sin(th_)
+                else:
+                    dirs_f, jac_f = Hf, PI ** 2 * torch.sin(th_)
+                pdf_f = torch.exp(-lq.clamp(-8, 8)) / jac_f.clamp_min(EPS)
+            return dirs_f, pdf_f, ang, jac_f
+
+        if fd:          # the flow's samples first, then the fixed set (:1136-1139)
+            fdirs, fpdf, d_x, d_jac = flow_dirs(self.flow_diffuse_copy, cfg["nis_diffuse_sample_num"], cfg["use_half_diffuse"])
+            d_dirs, d_pdf = torch.cat([fdirs, d_dirs.expand(pn, -1, 3)], 1), torch.cat([fpdf, d_pdf.expand(pn, -1, 1)], 1)
         nd = d_dirs.shape[1]
         d_lights, _ = lights_of(pts[:, None].expand(pn, nd, 3).reshape(-1, 3), d_dirs.reshape(-1, 3),
                                 human_poses[:, None].expand(pn, nd, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None)
@@ -594,10 +627,13 @@ class MCShadingNetwork(nn.Module):
         ggx = lambda noh, r: r ** 2 / (PI * (noh ** 2 * (r ** 2 - 1.0) + 1.0) ** 2).clamp_min(EPS)
         s_pdf = ggx(NoH_s, a) * NoH_s / (4 * VoH).clamp_min(EPS) * (torch.cos((1 - els) * PI / 2) * PI / 2)
         angles_H = torch.cat([phi.expand(pn, -1, -1), torch.arcsin(sin_t).expand(pn, -1, -1)], -1)
+        if fs:          # the specular set IS the flow's samples (:1163-1203)
+            s_dirs, s_pdf, s_x, s_jac = flow_dirs(self.flow_specular_copy, cfg["nis_specular_sample_num"], cfg["use_half_specular"])
         ns = s_dirs.shape[1]
         smask = (s_dirs * Z).sum(-1) > 0
         rid = torch.arange(pn, device=dev)[:, None].expand(pn, ns)[smask]
-        sd_, sp_, sah = s_dirs[smask], s_pdf[smask], angles_H[smask]
+        sd_, sp_ = s_dirs[smask], s_pdf[smask]
+        sah = None if fs else angles_H[smask]
         F0 = 0.04 * (1 - metallic) + metallic * albedo
         Hh = F.normalize(view_dirs[rid] + sd_, dim=-1)
         HoV_s = torch.clamp((Hh * view_dirs[rid]).sum(-1, keepdim=True), 0.0, 1.0)
@@ -636,10 +672,11 @@ class MCShadingNetwork(nn.Module):
         outputs.set_lazy("inter", lambda: self._bvh.trace(pts[rid].contiguous(), sd_.detach().contiguous(), 1e-5, 2 * self.unit_size)[0])
         zero = torch.zeros((), device=dev)
         outputs["loss_nis_diffuse"] = outputs["loss_nis_specular"] = zero
-        va = ops.view_angles(normals, view_dirs)
-        if step is not None and step >= cfg.get("nis_loss_iter_diffuse", 500):
+        if cfg["use_nis_diffuse"] and step is not None and step >= cfg.get("nis_loss_iter_diffuse", 500):
             sdn = cfg["nis_diffuse_sample_num"]
-            if cfg["use_half_diffuse"]:
+            if fd:      # fitted on the copy's own samples (:1271-1279): x = the sampled angles, Jacobian of their direction map
+                ph, th, jac = None, None, d_jac
+            elif cfg["use_half_diffuse"]:
                 Hd = F.normalize(V + d_dirs[:, :sdn], dim=-1)
                 HoV_d = torch.clamp((Hd * V).sum(-1, keepdim=True), 0.0, 1.0)
                 ph, th = half_angles(Hd)
@@ -647,12 +684,14 @@ class MCShadingNetwork(nn.Module):
             else:      # :1276-1279: the flow is fitted on the directions' own angles (az, arcsin(sqrt(el))) of sample_diffuse_directions
                 ph, th = az.expand(pn, nd, 1)[:, :sdn], torch.arcsin(el_sqrt).expand(pn, nd, 1)[:, :sdn]
                 jac = PI ** 2 * torch.sin(th)
-            xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
+            xq = d_x.clamp(EPS, 1 - EPS) if fd else torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
             _, logq = self.flow_diffuse(pts, va, roughness.detach(), xq.detach().contiguous(), return_jacobian=True)
             logqx = logq - jac.clamp_min(EPS).log()
             outputs["loss_nis_diffuse"] = -((d_w * d_lights)[:, :sdn] * logqx / d_pdf.expand(pn, nd, 1)[:, :sdn].clamp_min(EPS)).mean()
-        if step is not None and step >= cfg.get("nis_loss_iter_specular", 500):
-            if cfg["use_half_specular"]:
+        if cfg["use_nis_specular"] and step is not None and step >= cfg.get("nis_loss_iter_specular", 500):
+            if fs:      # (:1294-1317)
+                ph, th, jac = None, None, s_jac[smask]
+            elif cfg["use_half_specular"]:
                 ph, th = sah[:, :1], sah[:, 1:2]
                 jac = 4 * PI ** 2 * HoV_s * torch.sin(th)
             else:      # :1314-1317: ... on the angles of the reflected directions themselves (sample_specular_directions' `angles`)
@@ -661,7 +700,7 @@ class MCShadingNetwork(nn.Module):
                       + 2 * PI) % (2 * PI)
                 th = torch.acos(cz)
                 jac = PI ** 2 * torch.sin(th)
-            xq = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
+            xq = s_x[smask].clamp(EPS, 1 - EPS) if fs else torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS)
             _, logq = self.flow_specular(pts, va, roughness.detach(), xq.contiguous(), return_jacobian=True, rays_id=rid)
             logqx = logq - jac.clamp_min(EPS).log()
             outputs["loss_nis_specular"] = -(s_w * s_lights * logqx / sp_.clamp_min(EPS)).mean()
@@ -674,14 +713,16 @@ class MCShadingNetwork(nn.Module):
         if self.cfg["human_lights"] and human_poses is None:
             raise ValueError("human_lights=True: forward() needs the per-point human_poses [pn,3,4]")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            fd, fs = getattr(self, "use_flow_diffuse_copy", False), getattr(self, "use_flow_specular_copy", False)
-            if step is not None and not fd and not fs:
-                # fields.py:1082,1160: until the first copy refresh (nis_start_iter) both lobes draw from the fixed samplers
-                return self.forward_train_fixed(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
-            if step is not None and fd != fs:
-                raise NotImplementedError("one lobe on its flow copy and the other on the fixed sampler: set nis_start_iter_diffuse == "
-                                          "nis_start_iter_specular (every shipped config does)")
-            return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
+            # fields.py:1081,1160: a lobe draws from its flow copy once the copy exists (update_step at nis_start_iter) -- and never with
+            # cfg use_nis_diffuse / use_nis_specular = False; until then from its fixed sampler
+            fd = bool(self.cfg["use_nis_diffuse"]) and getattr(self, "use_flow_diffuse_copy", False)
+            fs = bool(self.cfg["use_nis_specular"]) and getattr(self, "use_flow_specular_copy", False)
+            if step is None:                     # (nis_sample True, :1467-1473: every lobe that has a flow samples it)
+                fd, fs = bool(self.cfg["use_nis_diffuse"]), bool(self.cfg["use_nis_specular"])
+            if fd and fs:
+                return self.forward_train(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
+            # both fixed samplers, or the mixed states (one copy active, or a lobe without its flow): the composed pass
+            return self.forward_train_fixed(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses, flow_lobes=(fd, fs))
         return self._forward_eval(pts, view_dirs, normals, human_poses)
 
     @torch.no_grad()
@@ -689,7 +730,7 @@ class MCShadingNetwork(nn.Module):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
         from ..shading import LazyOutputs, aux_outputs
-        if not self._fused_flows:
+        if not (self._fused_flows and self.cfg["use_nis_diffuse"] and self.cfg["use_nis_specular"]):
             return self._forward_eval_composed(pts, view_dirs, normals, human_poses)
         sh = self.shader()
         nrm = (F.normalize(normals, dim=-1) + 1) / 2
@@ -715,13 +756,18 @@ class MCShadingNetwork(nn.Module):
 
     @torch.no_grad()
     def _forward_eval_composed(self, pts, view_dirs, normals, human_poses=None):
-        """_forward_eval for flows the fused kernels do not instantiate (cfg flow_diffuse / flow_specular != 'pwquad'): the fixed-sampler pass
+        """_forward_eval for what the fused pass does not instantiate (cfg flow_diffuse / flow_specular != 'pwquad', a lobe without its
+        flow: use_nis_diffuse / use_nis_specular = False): the fixed-sampler pass
         and the flow pass are the two training compositions (forward_train_fixed / forward_train: every stage a HIP kernel or a
         device-resident torch op) evaluated without autograd, no jitter -- correct, not fast.  Same dict as the fused pass."""
         from ..shading import LazyOutputs
         hp = human_poses.float().contiguous() if (human_poses is not None and self.cfg["human_lights"]) else None
         c_fix, o_fix = self.forward_train_fixed(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp)
-        c_nis, o_nis = self.forward_train(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp)
+        fd, fs = bool(self.cfg["use_nis_diffuse"]), bool(self.cfg["use_nis_specular"])
+        if fd and fs:
+            c_nis, o_nis = self.forward_train(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp)
+        else:            # a lobe without its flow keeps its fixed sampler in the flow pass too (fields.py:1081, :1160)
+            c_nis, o_nis = self.forward_train_fixed(pts, view_dirs, normals, step=None, is_train=False, human_poses=hp, flow_lobes=(fd, fs))
         outputs = LazyOutputs()
         for src, sfx in ((o_fix, ""), (o_nis, "_nis")):
             keys = set(dict.keys(src)) | set(getattr(src, "_lazy", {}))

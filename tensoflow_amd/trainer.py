@@ -61,8 +61,9 @@ def material_param_groups(net, lr_xyz, lr_net, lr_env):
                    + list(net.roughness_predictor.parameters()) + list(net.inner_light.parameters()), "lr": lr_net},
         # (the reference's groups do not list `human_light`: with human_lights=True that net keeps its initial weights, fields.py:1580-1586)
     ]
-    groups += net.flow_diffuse.get_optparam_groups(lr_xyz, lr_net)
-    groups += net.flow_specular.get_optparam_groups(lr_xyz, lr_net)
+    for name in ("flow_diffuse", "flow_specular"):                  # fields.py:1591-1594: the flows this cfg holds (use_nis_diffuse / _specular)
+        if hasattr(net, name):
+            groups += getattr(net, name).get_optparam_groups(lr_xyz, lr_net)
     return groups
 
 
@@ -99,7 +100,7 @@ class MaterialTrainer:
                 net.cfg[k] = cfg[k]
         if cfg and "nis_loss_iter" in cfg:
             net.cfg["nis_loss_iter_diffuse"] = net.cfg["nis_loss_iter_specular"] = cfg["nis_loss_iter"]
-        for fl in (net.flow_diffuse_copy, net.flow_specular_copy):       # the samplers' copies are never trained (fields.py:1054-1065)
+        for fl in net.flow_copies():                                     # the samplers' copies are never trained (fields.py:1054-1065)
             for p in fl.parameters():
                 p.requires_grad = False
         self.optimizer = torch.optim.Adam(material_param_groups(net, self.cfg["lr_xyz_init"], self.cfg["lr_net_init"],

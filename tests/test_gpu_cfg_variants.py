@@ -10,7 +10,11 @@
   weights of every pass, and its roughness derivative in the backward;
 * `shading_pwlinear`: `flow_diffuse = flow_specular = 'pwlinear'` (:653-654, :755-760 -> network/flow.py:174-312): piecewise-linear
   coupling transforms in both lobes' flows (TensoFlow's composed transforms in every pass; the inference pass runs the two training
-  compositions without autograd).  The coupling nets' last layers have another shape: stored with the golden as `sdx/*`."""
+  compositions without autograd).  The coupling nets' last layers have another shape: stored with the golden as `sdx/*`;
+* `shading_nonis_d` / `shading_nonis_s`: `use_nis_diffuse = False` / `use_nis_specular = False` (:649-650, :1081, :1160): that lobe holds
+  no flow, keeps its fixed sampler in every pass and has no NIS loss;
+* `shading_mixed`: the default cfg in the states where ONE flow copy is active (`nis_start_iter_diffuse != nis_start_iter_specular`:
+  update_step :1050-1065) -- the composed pass with one flow-sampled and one fixed lobe, both NIS losses."""
 import pytest
 import torch
 
@@ -29,7 +33,12 @@ def dev():
 VARIANTS = {"shading_whole": dict(use_half_diffuse=False, use_half_specular=False),
             "shading_ablate": dict(disable_tensorial=True, disable_reflected=True),
             "shading_smith": dict(geometry_type="ggx_smith"),
-            "shading_pwlinear": dict(flow_diffuse="pwlinear", flow_specular="pwlinear")}
+            "shading_pwlinear": dict(flow_diffuse="pwlinear", flow_specular="pwlinear"),
+            "shading_nonis_d": dict(use_nis_diffuse=False), "shading_nonis_s": dict(use_nis_specular=False), "shading_mixed": dict()}
+# (tag, use_flow_diffuse_copy, use_flow_specular_copy) of the training-step runs a golden holds (update_step's state, fields.py:1050-1065)
+RUNS = {"shading_mixed": (("copy_d600", True, False), ("copy_s600", False, True))}
+DEFAULT_RUNS = (("flow600", True, True), ("fixed600", False, False))
+STEP_CASES = [(v, *r) for v in sorted(VARIANTS) for r in RUNS.get(v, DEFAULT_RUNS)]
 
 
 def _net(golden, dev, variant):
@@ -43,7 +52,7 @@ def _net(golden, dev, variant):
     sd.update({k[4:]: v for k, v in g.a.items() if k.startswith("sdx/")})          # tensors whose shape the variant changes
     missing, _ = m.load_state_dict(sd, strict=False)
     assert not missing
-    for fl in (m.flow_diffuse_copy, m.flow_specular_copy):
+    for fl in m.flow_copies():
         for p in fl.parameters():
             p.requires_grad = False
     m.eval()
@@ -62,13 +71,12 @@ def test_cfg_variant_eval_golden(golden, dev, variant):
         parity(out[k].cpu(), g["eval/" + k], label=f"{variant} eval: {k}")
 
 
-@pytest.mark.parametrize("variant", sorted(VARIANTS))
-@pytest.mark.parametrize("tag", ["flow600", "fixed600"])
-def test_cfg_variant_training_step_golden(golden, dev, tag, variant):
+@pytest.mark.parametrize("variant,tag,copy_d,copy_s", STEP_CASES)
+def test_cfg_variant_training_step_golden(golden, dev, variant, tag, copy_d, copy_s):
     """loss = sum(colors * w) + loss_nis at step 600, the flow copies sampling (`flow600`) or not yet made (`fixed600`): colours, both
     NIS losses and the gradient of every trainable tensor against the reference's autograd."""
     m, g = _net(golden, dev, variant)
-    m.use_flow_diffuse_copy = m.use_flow_specular_copy = tag == "flow600"
+    m.use_flow_diffuse_copy, m.use_flow_specular_copy = copy_d, copy_s
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, 600, False)
     parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"{variant} training step {tag}: colours")
     for k in ("loss_nis_diffuse", "loss_nis_specular"):
@@ -86,7 +94,7 @@ def test_cfg_variant_training_step_golden(golden, dev, tag, variant):
             l2 = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-20))
             if "inner_light" in name:
                 ok = l2 < 2e-2 and err < 3e-2       # ReLU flips on a few hundred hit rays (see test_gpu_march's training-step tests)
-            elif name.startswith("flow_") and tag == "fixed600":
+            elif name.startswith("flow_") and not (copy_d and copy_s):
                 ok = l2 < 1e-2 and err < 3e-2       # fixed samples on spline knots (same note as the half-vector fixed-pass test)
             else:
                 ok = err < 1e-3 and l2 < 1e-3
@@ -94,6 +102,7 @@ def test_cfg_variant_training_step_golden(golden, dev, tag, variant):
                 bad.append((name, round(err, 5), round(l2, 5)))
             checked += 1
     assert not bad, bad
-    assert checked >= (60 if variant == "shading_ablate" else 80), checked       # (ablated: the flows' tensorial planes / lines get no gradient)
+    # (ablated: the flows' tensorial planes / lines get no gradient; a lobe without its flow has no flow parameters)
+    assert checked >= {"shading_ablate": 60, "shading_nonis_d": 55, "shading_nonis_s": 55}.get(variant, 80), checked
     with_grad = {n for n, p in m.named_parameters() if p.grad is not None}
     assert with_grad >= set(grads), sorted(set(grads) - with_grad)[:5]

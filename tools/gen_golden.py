@@ -712,7 +712,7 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
-def _gen_shading_variant(name, over):
+def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600", False, False))):
     """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad` (same seeds: only outputs -- and the
     tensors whose shape the variant changes, sdx/* -- are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
     600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
@@ -743,12 +743,12 @@ def _gen_shading_variant(name, over):
         net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, R)) for _ in range(3)])
         net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, 1)) for _ in range(3)])
         own = net.state_dict()
-        fit = {k: v for k, v in base.items() if k not in own or own[k].shape == v.shape}
+        fit = {k: v for k, v in base.items() if k in own and own[k].shape == v.shape}        # (a lobe without its flow holds no flow tensors)
         missing, unexpected = net.load_state_dict(fit, strict=False)
         # tensors whose SHAPE the variant changes (another transform's coupling nets) keep the seeded initialisation: stored with the golden
         assert set(missing) == {k for k in base if k in own and own[k].shape != base[k].shape}, missing
         extra.update({k: own[k].detach().clone() for k in missing})
-        for fl in (net.flow_diffuse_copy, net.flow_specular_copy):
+        for fl in [getattr(net, n) for n in ("flow_diffuse_copy", "flow_specular_copy") if hasattr(net, n)]:
             for p in fl.parameters():
                 p.requires_grad = False
         net.eval()
@@ -758,9 +758,9 @@ def _gen_shading_variant(name, over):
         colors, outputs = net(pts, view, nrm, None, None, False)
     arrays.update({"eval/colors": colors, "eval/rgb_pr_nis": outputs["rgb_pr_nis"], "eval/diffuse_color_nis": outputs["diffuse_color_nis"],
                    "eval/specular_color_nis": outputs["specular_color_nis"], "eval/visibility_nis": outputs["visibility_nis"]})
-    for tag, copies in (("flow600", True), ("fixed600", False)):
+    for tag, copy_d, copy_s in runs:                 # (tag, use_flow_diffuse_copy, use_flow_specular_copy: update_step's state, :1050-1065)
         net = make()
-        net.use_flow_diffuse_copy = net.use_flow_specular_copy = copies
+        net.use_flow_diffuse_copy, net.use_flow_specular_copy = copy_d, copy_s
         net.zero_grad()
         colors, outputs = net(pts, view, nrm, None, 600, False)
         ((colors * w).sum() + outputs["loss_nis"]).backward()
@@ -775,6 +775,15 @@ def gen_shading_whole():
     """cfg use_half_diffuse = use_half_specular = False (fields.py:661-662): the flows sample the OUTGOING direction instead of the half
     vector (:1117-1134, :1190-1203; NIS losses :1276-1279, :1314-1317)."""
     _gen_shading_variant("shading_whole", dict(use_half_diffuse=False, use_half_specular=False))
+
+
+def gen_shading_nonis():
+    """A lobe without its flow (cfg use_nis_diffuse = False | use_nis_specular = False, fields.py:649-650, :1081, :1160): that lobe keeps
+    its fixed sampler in every pass and has no NIS loss (:1257, :1294); and the default cfg in the states where ONE copy is active
+    (nis_start_iter_diffuse != nis_start_iter_specular: update_step :1050-1065)."""
+    _gen_shading_variant("shading_nonis_d", dict(use_nis_diffuse=False))
+    _gen_shading_variant("shading_nonis_s", dict(use_nis_specular=False))
+    _gen_shading_variant("shading_mixed", dict(), runs=(("copy_d600", True, False), ("copy_s600", False, True)))
 
 
 def gen_shading_smith():
@@ -1275,7 +1284,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
