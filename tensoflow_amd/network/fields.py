@@ -205,34 +205,29 @@ class MCShadingNetwork(nn.Module):
                    "nis_specular_sample_num": 32, "light_reso": 128, "mat_grid": 512, "reg_min_max": True,
                    "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000, "nis_update_interval_diffuse": 1000,
                    "nis_update_interval_specular": 1000, "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500,
+                   "nis_sample_num": 64, "nis_start_iter": 1000, "nis_loss_iter": 500, "nis_update_interval": 1000,
                    "geometry_type": "schlick", "random_azimuth": True, "shade_fn": "shade_mixed", "use_nis_all": False,
                    "use_nis_diffuse": True, "use_nis_specular": True, "flow": "pwquad", "flow_diffuse": "pwquad", "flow_specular": "pwquad",
                    "use_half_all": True, "use_half_diffuse": True, "use_half_specular": True, "disable_tensorial": False,
                    "disable_reflected": False}
-    # Switches of the reference's cfg whose OTHER value selects code this build does not hold (fields.py: shade_mixed_all / use_nis_all
-    # :1337-1451 with switches :752,1458-1461,1589; fixed samplers beside a flow :1082,1160; whole-direction instead of half-vector flows
-    # :1084-1150,1163-1208; ggx_smith :1029; the non-'pwquad' transforms flow.py:170-312,527-547).  No
-    # shipped config sets any of them; a cfg that does is REFUSED here -- a drop-in never renders a non-default cfg as if it were the default.
-    _only_value = {"shade_fn": "shade_mixed", "use_nis_all": False}
-    # (ARE built since round 6: use_half_diffuse / use_half_specular = False -- the flows sample the outgoing direction instead of the
-    # half vector, :1117-1134, :1190-1203: tf_shade_dirs_whole, golden `shading_whole`; disable_tensorial / disable_reflected -- the
-    # flows' tensorial feature / view-angle embedding zeroed, flow.py:807-812: TensoFlow._condition and MCShader.shade, golden
-    # `shading_ablate`; geometry_type = 'ggx_smith', :1000-1008: a mode bit of the direction kernels and of their backward, golden
-    # `shading_smith`; flow_diffuse / flow_specular = 'pwlinear', flow.py:174-312: TensoFlow's composed transforms in every pass, the
-    # inference pass as the two training compositions without autograd -- correct, not fast; golden `shading_pwlinear`;
-    # use_nis_diffuse / use_nis_specular = False and the states with ONE flow copy active, :1081, :1160: forward_train_fixed's flow_lobes,
-    # goldens `shading_nonis_d`, `shading_nonis_s`)
+    # Every switch of the reference's cfg (fields.py:617-667) selects code this build holds -- the default branches fused, the others (built
+    # in round 6, each against a reference-run golden) as mode bits of the kernels or as device-resident compositions:
+    #   use_half_diffuse / use_half_specular = False (:1117-1134, :1190-1203)   tf_shade_dirs_whole                     shading_whole
+    #   disable_tensorial / disable_reflected (flow.py:807-812)                 TensoFlow._condition, MCShader.shade    shading_ablate
+    #   geometry_type = 'ggx_smith' (:1000-1008)                                mode bit 4 of the direction kernels     shading_smith
+    #   flow_diffuse / flow_specular = 'pwlinear' (flow.py:174-312)             TensoFlow's composed transforms         shading_pwlinear
+    #   use_nis_diffuse / use_nis_specular = False, one copy active (:1081)     forward_train_fixed(flow_lobes=)        shading_nonis_*, shading_mixed
+    #   shade_fn = 'shade_mixed_all' (+ use_nis_all, :1337-1451)                forward_all                             shading_all*
+    # What is NOT built raises at construction: the 'realnvp' transform, an unknown shade_fn / geometry_type / outer_light_version.
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
         self.cfg = {**self.default_cfg, **cfg}
-        for key, only in self._only_value.items():
-            if self.cfg[key] != only:
-                raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: this build holds {key}={only!r} only (the "
-                                          f"reference default; /root/reference/network/fields.py:617-667) and does not ignore the key")
         if self.cfg["outer_light_version"] not in ("envlight", "direction", "sphere_direction"):
             raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
-        for key in ("flow_diffuse", "flow_specular"):                      # 'realnvp' (fields.py:755-760 -> flow.py:645): not built
+        if self.cfg["shade_fn"] not in ("shade_mixed", "shade_mixed_all"):     # fields.py:1458-1463
+            raise NotImplementedError(f"shade_fn {self.cfg['shade_fn']!r}: 'shade_mixed' or 'shade_mixed_all'")
+        for key in ("flow", "flow_diffuse", "flow_specular"):              # 'realnvp' (fields.py:752-760 -> flow.py:645): not built
             if self.cfg[key] not in ("pwquad", "pwlinear"):
                 raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: 'pwquad' or 'pwlinear'")
         if self.cfg["geometry_type"] not in ("schlick", "ggx_smith"):      # fields.py:1026-1033: anything else raises there too
@@ -267,12 +262,15 @@ class MCShadingNetwork(nn.Module):
         # fields.py:755-760: one transform per lobe (cfg flow_diffuse / flow_specular; TensoFlow refuses 'realnvp')
         mkflow = lambda kind: TensoFlow(d=2, aabb=aabb, gridSize=self.cfg["gridSize"], device="cuda", flow=kind,
                                         disable_tensorial=bool(self.cfg["disable_tensorial"]), disable_reflected=bool(self.cfg["disable_reflected"]))
+        self.use_flow_copy = False
+        if self.cfg["use_nis_all"]:                 # fields.py:751-753: shade_mixed_all's single flow over both lobes
+            self.flow, self.flow_copy = mkflow(self.cfg["flow"]), mkflow(self.cfg["flow"])
         if self.cfg["use_nis_diffuse"]:             # (a lobe without its flow holds no flow modules: the reference's state_dict keys)
             self.flow_diffuse, self.flow_diffuse_copy = mkflow(self.cfg["flow_diffuse"]), mkflow(self.cfg["flow_diffuse"])
         if self.cfg["use_nis_specular"]:
             self.flow_specular, self.flow_specular_copy = mkflow(self.cfg["flow_specular"]), mkflow(self.cfg["flow_specular"])
         # the fused inference pass (MCShader) instantiates the default transform; any other runs the compositions (see _forward_eval)
-        self._fused_flows = all(fl._fused for fl in self.flow_copies())
+        self._fused_flows = all(getattr(self, n)._fused for n in ("flow_diffuse_copy", "flow_specular_copy") if hasattr(self, n))
         self._shader, self._shader_version = None, None
         self.use_flow_diffuse_copy = self.use_flow_specular_copy = False      # fields.py:752-760: set by update_step at nis_start_iter
 
@@ -310,20 +308,20 @@ class MCShadingNetwork(nn.Module):
 
     def flow_copies(self):
         """The frozen sampling copies this cfg holds (fields.py:755-760)."""
-        return [getattr(self, n) for n in ("flow_diffuse_copy", "flow_specular_copy") if hasattr(self, n)]
+        return [getattr(self, n) for n in ("flow_copy", "flow_diffuse_copy", "flow_specular_copy") if hasattr(self, n)]
 
     def update_step(self, step):
         """fields.py:1050-1065: every nis_update_interval steps from nis_start_iter on, the frozen sampling copies take the weights of
         the trained flows."""
         done = []
-        for name in ("diffuse", "specular"):
-            start, every = self.cfg[f"nis_start_iter_{name}"], self.cfg[f"nis_update_interval_{name}"]
+        for name, sfx in (("all", ""), ("diffuse", "_diffuse"), ("specular", "_specular")):
+            start, every = self.cfg[f"nis_start_iter{sfx}"], self.cfg[f"nis_update_interval{sfx}"]
             if self.cfg[f"use_nis_{name}"] and (step + 1) >= start and (step + 1 - start) % every == 0:
-                src, dst = getattr(self, f"flow_{name}"), getattr(self, f"flow_{name}_copy")
+                src, dst = getattr(self, f"flow{sfx}"), getattr(self, f"flow{sfx}_copy")
                 dst.load_state_dict(src.state_dict())
                 for p in dst.parameters():
                     p.requires_grad = False
-                setattr(self, f"use_flow_{name}_copy", True)      # load_state_dict bumped the copies' parameter versions: shader() re-packs
+                setattr(self, f"use_flow{sfx}_copy", True)        # load_state_dict bumped the copies' parameter versions: shader() re-packs
                 done.append(name)
         return done
 
@@ -707,11 +705,116 @@ class MCShadingNetwork(nn.Module):
         outputs["loss_nis"] = outputs["loss_nis_diffuse"] + outputs["loss_nis_specular"]
         return colors, outputs
 
+    def forward_all(self, pts, view_dirs, normals, step=None, is_train=True, human_poses=None, use_flow=None):
+        """shade_mixed_all (fields.py:1337-1451; cfg shade_fn = 'shade_mixed_all'): ONE direction set per point -- the samples of the single
+        flow's frozen copy (cfg use_nis_all, once update_step has made the copy; nis_sample_num of them) or the fixed cosine set -- on which
+        the diffuse AND the specular weight are evaluated, nothing masked; from nis_loss_iter on the flow is fitted on the set in use.
+        A composed pass like forward_train_fixed: per-direction algebra in device-resident differentiable ops, visibility, cube map, VM
+        gather, flows and every MLP product on the HIP kernels.  use_flow: None = the training rule (copy active), True / False = the
+        two passes of an inference call (nis_sample, :1467-1468)."""
+        EPS, PI = 1e-6, math.pi
+        dev, pn, cfg = pts.device, pts.shape[0], self.cfg
+        view_dirs, normals = F.normalize(view_dirs, dim=-1), F.normalize(normals, dim=-1)
+        metallic, roughness, albedo = self.predict_materials(pts)
+        sat = lambda a, b: torch.clamp((a * b).sum(-1, keepdim=True), 0.0, 1.0)
+        if not hasattr(self, "_bvh"):
+            self._bvh = ops.Bvh(self.ray_tracer[0], self.ray_tracer[1], dev)
+            self._fixed = fibonacci_samples(cfg["diffuse_sample_num"]).to(dev)
+        z = normals
+        x0 = torch.stack([z[:, 1], -z[:, 0], torch.zeros_like(z[:, 0])], -1)
+        x1 = torch.stack([-z[:, 2], torch.zeros_like(z[:, 0]), z[:, 0]], -1)
+        x = F.normalize(torch.where((x0.norm(dim=-1) > x1.norm(dim=-1))[:, None], x0, x1), dim=-1)
+        y = torch.cross(z, x, dim=-1)
+        X, Y, Z, V = x[:, None], y[:, None], z[:, None], view_dirs[:, None]
+        va = ops.view_angles(normals, view_dirs)
+        if use_flow is None:
+            use_flow = self.use_flow_copy
+        use_flow = bool(use_flow) and bool(cfg["use_nis_all"])
+        training = is_train and self.training
+        if use_flow:
+            with torch.no_grad():
+                sn = cfg["nis_sample_num"]
+                ang, lq = self.flow_copy._sample_nograd(pts, va, sn, torch.rand(pn, sn, device=dev) if training else None)
+                ph_s, th_s = ang[..., :1] * (2 * PI), ang[..., 1:2] * (0.5 * PI)
+                Hf = (torch.sin(th_s) * torch.cos(ph_s)) * X + (torch.sin(th_s) * torch.sin(ph_s)) * Y + torch.cos(th_s) * Z
+                if cfg["use_half_all"]:
+                    HoV_f = sat(V, Hf)
+                    dirs, jac_s = HoV_f * Hf * 2 - V, 4 * PI ** 2 * HoV_f * torch.sin(th_s)
+                else:
+                    dirs, jac_s = Hf, PI ** 2 * torch.sin(th_s)
+                pdf = torch.exp(-lq.clamp(-8, 8)) / jac_s.clamp_min(EPS)
+        else:           # sample_diffuse_directions (:824-856)
+            az, el = self._fixed[:, 0][None, :, None] * (2 * PI), self._fixed[:, 1][None, :, None]
+            if training and cfg["random_azimuth"]:
+                az = (az + torch.rand(pn, 1, 1, device=dev) * (2 * PI)) % (2 * PI)
+            el_sqrt = torch.sqrt(el + 1e-7)
+            dirs = (el_sqrt * torch.cos(az)) * X + (el_sqrt * torch.sin(az)) * Y + torch.sqrt(1 - el + 1e-7) * Z
+            pdf = sat(dirs, Z) / PI * (torch.cos((1 - el) * PI / 2) * PI / 2)
+        sn = dirs.shape[1]
+        poses = human_poses[:, None].expand(pn, sn, 3, 4).reshape(-1, 3, 4) if human_poses is not None else None
+        lights, hit, hl = self._lights_of(pts[:, None].expand(pn, sn, 3).reshape(-1, 3), dirs.reshape(-1, 3), poses)
+        lights, hit = lights.view(pn, sn, 3), hit.view(pn, sn)
+        kd = 1 - metallic[:, None]
+        d_w = albedo[:, None] * kd * (sat(dirs, Z) / PI)
+        diffuse = torch.mean(d_w * lights / pdf.clamp_min(EPS), 1)
+        F0 = (0.04 * (1 - metallic) + metallic * albedo)[:, None]
+        Hh = F.normalize(V + dirs, dim=-1)
+        HoV = torch.clamp((Hh * V).sum(-1, keepdim=True), 0.0, 1.0)
+        fres = F0 + (1.0 - F0) * torch.clamp(1.0 - HoV, 0.0, 1.0) ** 5.0
+        NoV, NoL, a = sat(normals, view_dirs)[:, None], sat(Z, dirs), roughness[:, None]
+        if cfg["geometry_type"] == "ggx_smith":
+            lam = lambda a2, c: 0.5 * torch.sqrt(1 + a2 * (1 - c ** 2) / (c ** 2 + 1e-7)) - 0.5
+            geo = 1.0 / (1.0 + lam(a ** 2, NoV) + lam(a ** 2, NoL))
+        else:
+            g1 = lambda c, r: c / (c * (1 - r / 2) + r / 2 + 1e-5)
+            geo = g1(NoV, a) * g1(NoL, a)
+        dist = a ** 2 / (PI * (sat(Z, Hh) ** 2 * (a ** 2 - 1.0) + 1.0) ** 2).clamp_min(EPS)
+        s_w = dist * fres * geo / (4 * NoV).clamp_min(EPS)
+        specular = torch.mean(s_w * lights / pdf.clamp_min(EPS), 1)
+        colors = self._linear_to_srgb(diffuse + specular)
+        c01 = lambda t: self._linear_to_srgb(t, clamp01=True)
+        hit_f = hit.float()
+        fx = (d_w + s_w) * lights
+        outputs = {"albedo": albedo, "normal": (normals + 1) / 2, "roughness": roughness, "metallic": metallic,
+                   "human_lights": hl if hl is not None else torch.zeros(int((~hit).sum()), 3, device=dev),
+                   "diffuse_light": c01(lights.mean(1)), "specular_light": c01(lights.mean(1)), "diffuse_color": c01(diffuse),
+                   "specular_color": c01(specular), "approximate_light": c01(torch.mean(kd * lights, 1) + c01(specular)),
+                   "visibility": 1 - hit_f.mean(1, keepdim=True), "indirect_light": torch.mean(lights * hit_f[..., None], 1),
+                   "variance": torch.var(fx.mean(-1, keepdim=True) / pdf.clamp_min(EPS))}
+        outputs["loss_nis"] = torch.zeros((), device=dev)
+        if cfg["use_nis_all"] and step is not None and step >= cfg["nis_loss_iter"]:
+            if use_flow:
+                xq, jac = ang.clamp(EPS, 1 - EPS), jac_s
+            elif cfg["use_half_all"]:          # the sampler's half angles (:850-856) with the BRDF's HoV (:1435)
+                cz = (Z * Hh).sum(-1, keepdim=True).clamp(-1 + EPS, 1 - EPS)
+                ph = (torch.atan2((Y * Hh).sum(-1, keepdim=True), (X * Hh).sum(-1, keepdim=True)) + 2 * PI) % (2 * PI)
+                th = torch.acos(cz)
+                xq, jac = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS), 4 * PI ** 2 * HoV * torch.sin(th)
+            else:                              # the directions' own angles (:843)
+                ph, th = az.expand(pn, sn, 1), torch.arcsin(el_sqrt).expand(pn, sn, 1)
+                xq, jac = torch.cat([ph / (2 * PI), th / (0.5 * PI)], -1).clamp(EPS, 1 - EPS), PI ** 2 * torch.sin(th)
+            _, logq = self.flow(pts, va, roughness.detach(), xq.detach().contiguous(), return_jacobian=True)
+            logqx = logq - jac.clamp_min(EPS).log()
+            outputs["loss_nis"] = -(fx * logqx / pdf.clamp_min(EPS)).mean()
+        return colors, outputs
+
     def forward(self, pts, view_dirs, normals, human_poses=None, step=None, is_train=False):
         """fields.py:1453-1473 with the flow samplers active: -> (colors [pn,3], outputs dict).
         With autograd enabled (training) the differentiable composition is used; otherwise the fused inference path."""
         if self.cfg["human_lights"] and human_poses is None:
             raise ValueError("human_lights=True: forward() needs the per-point human_poses [pn,3,4]")
+        if self.cfg["shade_fn"] == "shade_mixed_all":
+            grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            any_nis = self.cfg["use_nis_all"] or self.cfg["use_nis_diffuse"] or self.cfg["use_nis_specular"]          # self.use_nis, :670
+            if step is not None or grad or not any_nis:
+                with torch.set_grad_enabled(grad):
+                    return self.forward_all(pts, view_dirs, normals, step=step, is_train=is_train, human_poses=human_poses)
+            with torch.no_grad():             # :1467-1471: nis_sample False, then nis_sample True with the `_nis` suffix
+                colors, outputs = self.forward_all(pts, view_dirs, normals, None, is_train, human_poses, use_flow=False)
+                c_nis, o_nis = self.forward_all(pts, view_dirs, normals, None, is_train, human_poses, use_flow=True)
+            o_nis["rgb_pr"] = c_nis
+            outputs.update({k + "_nis": v for k, v in o_nis.items()})
+            return colors, outputs
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # fields.py:1081,1160: a lobe draws from its flow copy once the copy exists (update_step at nis_start_iter) -- and never with
             # cfg use_nis_diffuse / use_nis_specular = False; until then from its fixed sampler

@@ -61,7 +61,7 @@ def material_param_groups(net, lr_xyz, lr_net, lr_env):
                    + list(net.roughness_predictor.parameters()) + list(net.inner_light.parameters()), "lr": lr_net},
         # (the reference's groups do not list `human_light`: with human_lights=True that net keeps its initial weights, fields.py:1580-1586)
     ]
-    for name in ("flow_diffuse", "flow_specular"):                  # fields.py:1591-1594: the flows this cfg holds (use_nis_diffuse / _specular)
+    for name in ("flow", "flow_diffuse", "flow_specular"):          # fields.py:1589-1594: the flows this cfg holds (use_nis_all / _diffuse / _specular)
         if hasattr(net, name):
             groups += getattr(net, name).get_optparam_groups(lr_xyz, lr_net)
     return groups

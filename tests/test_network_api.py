@@ -38,7 +38,7 @@ def test_fused_forward_refuses_autograd():
         m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)   # sampling is a frozen-copy op
 
 
-REFUSED_CFG = [("shade_fn", "shade_mixed_all"), ("use_nis_all", True),
+REFUSED_CFG = [("shade_fn", "shade_direct"), ("flow", "realnvp"),
                ("flow_diffuse", "realnvp"), ("flow_specular", "affine"),
                ("geometry_type", "beckmann"), ("outer_light_version", "latlong")]
 

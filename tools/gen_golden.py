@@ -745,10 +745,11 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
         own = net.state_dict()
         fit = {k: v for k, v in base.items() if k in own and own[k].shape == v.shape}        # (a lobe without its flow holds no flow tensors)
         missing, unexpected = net.load_state_dict(fit, strict=False)
-        # tensors whose SHAPE the variant changes (another transform's coupling nets) keep the seeded initialisation: stored with the golden
-        assert set(missing) == {k for k in base if k in own and own[k].shape != base[k].shape}, missing
+        # tensors whose SHAPE the variant changes (another transform's coupling nets) or that it adds (shade_mixed_all's single flow) keep
+        # the seeded initialisation: stored with the golden
+        assert set(missing) >= {k for k in base if k in own and own[k].shape != base[k].shape}, missing
         extra.update({k: own[k].detach().clone() for k in missing})
-        for fl in [getattr(net, n) for n in ("flow_diffuse_copy", "flow_specular_copy") if hasattr(net, n)]:
+        for fl in [getattr(net, n) for n in ("flow_copy", "flow_diffuse_copy", "flow_specular_copy") if hasattr(net, n)]:
             for p in fl.parameters():
                 p.requires_grad = False
         net.eval()
@@ -761,10 +762,12 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
     for tag, copy_d, copy_s in runs:                 # (tag, use_flow_diffuse_copy, use_flow_specular_copy: update_step's state, :1050-1065)
         net = make()
         net.use_flow_diffuse_copy, net.use_flow_specular_copy = copy_d, copy_s
+        net.use_flow_copy = copy_d                    # (shade_mixed_all's single copy)
         net.zero_grad()
         colors, outputs = net(pts, view, nrm, None, 600, False)
         ((colors * w).sum() + outputs["loss_nis"]).backward()
-        arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
+        arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis": outputs["loss_nis"]} if "loss_nis_diffuse" not in outputs else
+                      {f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
                        f"{tag}/loss_nis_specular": outputs["loss_nis_specular"]})
         arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
     arrays.update({"sdx/" + k: v for k, v in extra.items()})
@@ -784,6 +787,13 @@ def gen_shading_nonis():
     _gen_shading_variant("shading_nonis_d", dict(use_nis_diffuse=False))
     _gen_shading_variant("shading_nonis_s", dict(use_nis_specular=False))
     _gen_shading_variant("shading_mixed", dict(), runs=(("copy_d600", True, False), ("copy_s600", False, True)))
+
+
+def gen_shading_all():
+    """cfg shade_fn = 'shade_mixed_all' with use_nis_all (fields.py:640-641, :1337-1451): one flow over both lobes, one direction set per
+    point (its copy's nis_sample_num samples, or the fixed cosine set before the copy exists); half-vector and whole-direction flows."""
+    _gen_shading_variant("shading_all", dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16))
+    _gen_shading_variant("shading_all_whole", dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16, use_half_all=False))
 
 
 def gen_shading_smith():
@@ -1284,7 +1294,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_all', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
