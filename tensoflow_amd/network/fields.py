@@ -218,7 +218,8 @@ class MCShadingNetwork(nn.Module):
     #   flow_diffuse / flow_specular = 'pwlinear' (flow.py:174-312)             TensoFlow's composed transforms         shading_pwlinear
     #   use_nis_diffuse / use_nis_specular = False, one copy active (:1081)     forward_train_fixed(flow_lobes=)        shading_nonis_*, shading_mixed
     #   shade_fn = 'shade_mixed_all' (+ use_nis_all, :1337-1451)                forward_all                             shading_all*
-    # What is NOT built raises at construction: the 'realnvp' transform, an unknown shade_fn / geometry_type / outer_light_version.
+    #   flow* = 'realnvp' (flow.py:645)                                         TensoFlow's composed transforms         tensoflow_realnvp, shading_realnvp
+    # An unknown flow / shade_fn / geometry_type / outer_light_version raises at construction (as the reference does when it gets there).
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
         super().__init__()
@@ -227,9 +228,9 @@ class MCShadingNetwork(nn.Module):
             raise NotImplementedError(f"outer_light_version {self.cfg['outer_light_version']!r}")
         if self.cfg["shade_fn"] not in ("shade_mixed", "shade_mixed_all"):     # fields.py:1458-1463
             raise NotImplementedError(f"shade_fn {self.cfg['shade_fn']!r}: 'shade_mixed' or 'shade_mixed_all'")
-        for key in ("flow", "flow_diffuse", "flow_specular"):              # 'realnvp' (fields.py:752-760 -> flow.py:645): not built
-            if self.cfg[key] not in ("pwquad", "pwlinear"):
-                raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: 'pwquad' or 'pwlinear'")
+        for key in ("flow", "flow_diffuse", "flow_specular"):              # TensoFlow.flow_kwargs (flow.py:644-648)
+            if self.cfg[key] not in ("pwquad", "pwlinear", "realnvp"):
+                raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: 'pwquad', 'pwlinear' or 'realnvp'")
         if self.cfg["geometry_type"] not in ("schlick", "ggx_smith"):      # fields.py:1026-1033: anything else raises there too
             raise NotImplementedError(f"geometry_type {self.cfg['geometry_type']!r}: 'schlick' or 'ggx_smith'")
         if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":

@@ -21,13 +21,14 @@ class Reshift(nn.Module):
 
 
 class Block(nn.Module):
-    """Coupling block container (network/flow.py:549-598): nn = [Reshift, Linear, LeakyReLU, ... , Linear]."""
+    """Coupling block container (network/flow.py:549-598): nn = [Reshift (not for 'realnvp'), Linear, LeakyReLU, ... , Linear]."""
 
-    def __init__(self, d, mask, feature_dim, multires=3, d_hidden=64, n_hidden=3, n_bins=21):
+    def __init__(self, d, mask, feature_dim, multires=3, d_hidden=64, n_hidden=3, n_bins=21, reshift=True):
         super().__init__()
         self.d, self.mask = d, mask
         d_in = sum(mask) * (1 + 2 * multires)
-        layers = [Reshift()]
+        layers = [Reshift()] if reshift else []          # (flow.py:646: 'realnvp' has no input activation -- its Linear layers sit at 0, 2, 4, 6)
+        self.first = len(layers)
         last = d_in + feature_dim
         for _ in range(n_hidden):
             layers += [nn.Linear(last, d_hidden), nn.LeakyReLU()]
@@ -52,11 +53,11 @@ class TensoFlow(nn.Module):
         from .flow_transforms import TRANSFORMS
         if flow not in TRANSFORMS or d != 2 or int(n_bins) < 2 or nis_dim != 64 or nis_feature_dim != 16 or \
                 (nis_multires, refl_multires, roughness_multires, angle_multires) != (3, 3, 3, 3):
-            # 'realnvp' (flow.py:645: Gaussian prior, affine couplings, an analytic-sigmoid output cell) is not built
-            raise NotImplementedError("TensoFlow: d=2, flow in ('pwquad', 'pwlinear'), n_bins >= 2, 64/16 dims, 3 octaves per embedding")
+            raise NotImplementedError("TensoFlow: d=2, flow in ('pwquad', 'pwlinear', 'realnvp'), n_bins >= 2, 64/16 dims, 3 octaves per embedding")
         # The fused HIP kernels instantiate the reference default ('pwquad', 10 bins: what every shipped config runs).  Any other
         # (flow, n_bins) is evaluated by a differentiable COMPOSITION (flow_transforms.py: torch ops on the device around the HIP VM gather
-        # and dense layers) -- correct, not fast; round 6.
+        # and dense layers) -- correct, not fast; round 6.  'realnvp' (flow.py:645): Gaussian latent prior, affine couplings without the
+        # Reshift input activation, and the analytic-sigmoid output cell behind the two blocks.
         self.flow_kind, self.n_bins = flow, int(n_bins)
         self._fused = flow == "pwquad" and int(n_bins) == 10
         self._sample_fn, self._density_fn, bin_fn = TRANSFORMS[flow]
@@ -78,8 +79,9 @@ class TensoFlow(nn.Module):
                                      nn.Linear(nis_dim, nis_feature_dim)).to(device)
         self.refl_input_ch, self.roughness_input_ch = 14, 7
         feature_dim = nis_feature_dim + self.refl_input_ch + self.roughness_input_ch
-        self.flows = nn.ModuleList([Block(d, [(i + off) % 2 == 0 for i in range(d)], feature_dim, n_bins=bin_fn(int(n_bins)))
-                                    for off in range(2)]).to(device)
+        self.gaussian = flow == "realnvp"
+        self.flows = nn.ModuleList([Block(d, [(i + off) % 2 == 0 for i in range(d)], feature_dim, n_bins=bin_fn(int(n_bins)),
+                                          reshift=not self.gaussian) for off in range(2)]).to(device)
         self.disable_tensorial, self.disable_reflected = disable_tensorial, disable_reflected
         self._packed = None
         self._packed_version = None
@@ -124,16 +126,22 @@ class TensoFlow(nn.Module):
     def _coupling_net(self, blk, keep, cond):
         """Block.nn on [embed3(kept coordinate), condition row] (flow.py:600-609): Reshift, then Linear + LeakyReLU x 3, Linear."""
         from ..autograd import LinearActFn
-        h = blk.nn[0](torch.cat([posenc(keep, 3), cond], -1)).contiguous()
-        for l in (1, 3, 5):
+        h = torch.cat([posenc(keep, 3), cond], -1)
+        f0 = blk.first
+        h = (blk.nn[0](h) if f0 else h).contiguous()
+        for l in (f0, f0 + 2, f0 + 4):
             h = torch.nn.functional.leaky_relu(LinearActFn.apply(h, blk.nn[l].weight, blk.nn[l].bias, ops.ACT_NONE, 0.0, None), 0.01)
-        return LinearActFn.apply(h.contiguous(), blk.nn[7].weight, blk.nn[7].bias, ops.ACT_NONE, 0.0, None)
+        return LinearActFn.apply(h.contiguous(), blk.nn[f0 + 6].weight, blk.nn[f0 + 6].bias, ops.ACT_NONE, 0.0, None)
 
     def _composed_blocks(self, y, logj, cond, sampling):
         """TensoFlow.flow / flow_inv (flow.py:766-799) over rows y [M,2], cond [M,37]: the blocks in order with the sampling transform, in
         reverse order with the density transform.  -> (y, logj, bins [M,2] int64: column b = the bin block b picked)."""
+        from .flow_transforms import sigmoid_cell_density, sigmoid_cell_sample
         bins = torch.zeros(y.shape[0], 2, dtype=torch.long, device=y.device)
         order = list(enumerate(self.flows)) if sampling else list(enumerate(self.flows))[::-1]
+        if self.gaussian and not sampling:          # the output cell is the LAST flow (flow.py:676-677): first on the way back
+            y, lj = sigmoid_cell_density(y)
+            logj = logj + lj
         for bi, blk in order:
             mask = torch.tensor(blk.mask, device=y.device)
             keep, move = y[:, mask], y[:, ~mask]
@@ -144,20 +152,32 @@ class TensoFlow(nn.Module):
             out[:, ~mask] = new
             y, logj = out, logj + lj
             bins[:, bi] = idx[:, 0]
+        if self.gaussian and sampling:
+            y, lj = sigmoid_cell_sample(y)
+            logj = logj + lj
         return y, logj, bins
 
     def _composed_sample(self, pts, view_angles, n_samples, jitter=None):
         """sample() as a composition: SphereSampler (flow.py:52-90) -> the blocks with the sampling transform."""
         pn = pts.shape[0]
-        x = sphere_latent_on(n_samples, pts.device)[None].expand(pn, n_samples, 2)
-        if jitter is not None:
-            x = torch.cat([(x[..., :1] + jitter[..., None]) % 1, x[..., 1:]], -1)
-        x = x.clamp(1e-6, 1 - 1e-6)
-        logj = -torch.cos(x[..., 1:] * (0.5 * np.pi)).log()
+        if self.gaussian:            # FactorizedGaussianSampler.forward (flow.py:21-24): fresh normal draws, logj = -log_prob
+            from .flow_transforms import gaussian_log_prob
+            x = self._gaussian_latent(pn, n_samples, pts.device)
+            logj = -gaussian_log_prob(x)
+        else:
+            x = sphere_latent_on(n_samples, pts.device)[None].expand(pn, n_samples, 2)
+            if jitter is not None:
+                x = torch.cat([(x[..., :1] + jitter[..., None]) % 1, x[..., 1:]], -1)
+            x = x.clamp(1e-6, 1 - 1e-6)
+            logj = -torch.cos(x[..., 1:] * (0.5 * np.pi)).log()
         cond = self._condition(pts, view_angles)[:, None].expand(pn, n_samples, 37).reshape(-1, 37)
         y, lj, bins = self._composed_blocks(x.reshape(-1, 2), logj.reshape(-1, 1), cond, sampling=True)
         self.last_bins = bins.view(pn, n_samples, 2)
         return y.view(pn, n_samples, 2), lj.view(pn, n_samples, 1)
+
+    def _gaussian_latent(self, pn, n_samples, device):
+        """The latent draws of the 'realnvp' prior [pn, n_samples, 2] (one place, so that a test can substitute recorded draws)."""
+        return torch.randn(pn, n_samples, 2, device=device)
 
     def _composed_forward(self, pts, reflections, x, rays_id):
         """forward() as a composition (flow.py:801-831): the blocks in reverse with the density transform, + log prior of z."""
@@ -170,7 +190,11 @@ class TensoFlow(nn.Module):
         xr = x.clamp(1e-6, 1 - 1e-6).reshape(-1, 2)
         z, lj, bins = self._composed_blocks(xr, torch.zeros(xr.shape[0], 1, device=xr.device), cond_rows, sampling=False)
         self.last_bins = bins.view(*shape, 2)
-        logq = lj + torch.cos(z[:, 1:] * (0.5 * np.pi)).log()
+        if self.gaussian:
+            from .flow_transforms import gaussian_log_prob
+            logq = lj + gaussian_log_prob(z)
+        else:
+            logq = lj + torch.cos(z[:, 1:] * (0.5 * np.pi)).log()
         return z.view(*shape, 2), logq.view(*shape, 1)
 
     @torch.no_grad()

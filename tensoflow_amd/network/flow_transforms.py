@@ -1,9 +1,10 @@
-"""The coupling transforms of TensoFlow for the configurations the fused HIP kernels do not instantiate (`flow='pwlinear'`, any
-`n_bins != 10`): a differentiable composition of device-resident torch ops around the HIP dense-layer kernels -- correct, not fast; no
+"""The coupling transforms of TensoFlow for the configurations the fused HIP kernels do not instantiate (`flow='pwlinear'`, `'realnvp'`,
+any `n_bins != 10`): a differentiable composition of device-resident torch ops around the HIP dense-layer kernels -- correct, not fast; no
 shipped config selects them (the fused kernels serve the reference default `flow='pwquad', n_bins=10`).
 
 Reference: network/flow.py:166-168 (modified_softmax), :174-312 (ElementWisePWLinearTransform), :314-525
-(ElementWisePWQuadraticTransform).  Every function takes the coordinates being moved, x or y [M, k], and the net's outputs [M, k, B] and
+(ElementWisePWQuadraticTransform), :527-547 (ElementWiseAffineTransform), :123-144 (the sigmoid output cell), :9-24 (Gaussian prior).
+Every coupling function takes the coordinates being moved, x or y [M, k], and the net's outputs [M, k, B] and
 returns (moved coordinates [M, k], log-Jacobian [M, 1], bin index [M, k] int64).  Directions: `*_density` is the reference's `flow_inv`
 (data -> latent, used by TensoFlow.forward), `*_sample` its `flow` (latent -> data, used by TensoFlow.sample)."""
 import torch
@@ -114,4 +115,33 @@ def pwlinear_sample(y, q_t):
     return x, -torch.log(slope).sum(-1, keepdim=True), e
 
 
-TRANSFORMS = {"pwquad": (pwquad_sample, pwquad_density, lambda n: 2 * n + 1), "pwlinear": (pwlinear_sample, pwlinear_density, lambda n: n)}
+def affine_sample(y, st):
+    """ElementWiseAffineTransform.flow (flow.py:528-537), latent -> data: x = exp(s) y + t; st [M,k,2] = (s, t)."""
+    es = torch.exp(st[..., 0])
+    return es * y + st[..., 1], torch.log(es.clamp_min(1e-6)).sum(-1, keepdim=True), torch.zeros_like(y, dtype=torch.long)
+
+
+def affine_density(x, st):
+    """ElementWiseAffineTransform.flow_inv (flow.py:539-547), data -> latent: exp(-s) (x - t)."""
+    es = torch.exp(-st[..., 0])
+    return es * (x - st[..., 1]), torch.log(es.clamp_min(1e-6)).sum(-1, keepdim=True), torch.zeros_like(x, dtype=torch.long)
+
+
+def sigmoid_cell_sample(x):
+    """InvertibleAnalyticSigmoid.flow (flow.py:130-136): the output cell of 'realnvp', R^d -> (0,1)^d.  -> (y, log-Jacobian [M,1])."""
+    y = torch.sigmoid(x).clamp(1e-6, 1 - 1e-6)
+    return y, torch.log((y * (1 - y)).clamp_min(1e-6)).sum(-1, keepdim=True)
+
+
+def sigmoid_cell_density(x):
+    """InvertibleAnalyticSigmoid.flow_inv (flow.py:138-144; inverse_sigmoid :123-124)."""
+    return torch.log((x / (1 - x)).clamp_min(1e-6)), -torch.log((x * (1 - x)).clamp_min(1e-6)).sum(-1, keepdim=True)
+
+
+def gaussian_log_prob(x):
+    """FactorizedGaussianSampler.log_prob (flow.py:18-19): sum over the coordinates of Normal(0, 1).log_prob."""
+    return (-0.5 * x * x - 0.9189385332046727).sum(-1, keepdim=True)          # log sqrt(2 pi)
+
+
+TRANSFORMS = {"pwquad": (pwquad_sample, pwquad_density, lambda n: 2 * n + 1), "pwlinear": (pwlinear_sample, pwlinear_density, lambda n: n),
+              "realnvp": (affine_sample, affine_density, lambda n: 2)}

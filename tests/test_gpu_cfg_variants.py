@@ -16,7 +16,10 @@
 * `shading_mixed`: the default cfg in the states where ONE flow copy is active (`nis_start_iter_diffuse != nis_start_iter_specular`:
   update_step :1050-1065) -- the composed pass with one flow-sampled and one fixed lobe, both NIS losses;
 * `shading_all` / `shading_all_whole`: `shade_fn = 'shade_mixed_all'` with `use_nis_all` (:640-641, :1337-1451): one flow over both lobes,
-  one direction set per point (the copy's samples, or the fixed cosine set before the copy exists), half-vector / whole-direction flow."""
+  one direction set per point (the copy's samples, or the fixed cosine set before the copy exists), half-vector / whole-direction flow;
+* `shading_realnvp`: `flow_diffuse = flow_specular = 'realnvp'` (flow.py:645): Gaussian-prior affine flows with the sigmoid output cell.
+  The prior draws fresh normals per call: both sides take them from `tools/gen_golden.py:shading_realnvp_latent` (a function of the
+  request's shape, restated below)."""
 import pytest
 import torch
 
@@ -38,7 +41,8 @@ VARIANTS = {"shading_whole": dict(use_half_diffuse=False, use_half_specular=Fals
             "shading_pwlinear": dict(flow_diffuse="pwlinear", flow_specular="pwlinear"),
             "shading_nonis_d": dict(use_nis_diffuse=False), "shading_nonis_s": dict(use_nis_specular=False), "shading_mixed": dict(),
             "shading_all": dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16),
-            "shading_all_whole": dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16, use_half_all=False)}
+            "shading_all_whole": dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16, use_half_all=False),
+            "shading_realnvp": dict(flow_diffuse="realnvp", flow_specular="realnvp")}
 # (tag, use_flow_diffuse_copy, use_flow_specular_copy) of the training-step runs a golden holds (update_step's state, fields.py:1050-1065)
 RUNS = {"shading_mixed": (("copy_d600", True, False), ("copy_s600", False, True))}
 DEFAULT_RUNS = (("flow600", True, True), ("fixed600", False, False))
@@ -59,6 +63,9 @@ def _net(golden, dev, variant):
     for fl in m.flow_copies():
         for p in fl.parameters():
             p.requires_grad = False
+    if variant == "shading_realnvp":             # the recorded rule of the reference run's latent draws (shading_realnvp_latent)
+        for fl in m.flow_copies():
+            fl._gaussian_latent = lambda pn, n, device: torch.randn(pn, n, 2, generator=torch.Generator().manual_seed(1000 + int(n))).to(device)
     m.eval()
     return m, g
 

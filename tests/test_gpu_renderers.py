@@ -51,7 +51,7 @@ def test_cube_lookup_direction_gradient(dev):
     tref = tex.clone().requires_grad_(True)
     (ot.cube_bilinear(tref, dref) * gout).sum().backward()
     g_base, g_dirs = ops.cube_lookup_bwd_dirs(tex.to(dev), d.to(dev), gout.to(dev), apply_exp=False)
-    parity(g_base.cpu(), tref.grad, label="cube_lookup_direction_gradient:54")
+    parity(g_base.cpu(), tref.grad, label="cube_lookup_direction_gradient:54", floor=1e-2)   # (float atomics in arrival order over ~60 contributions of both signs per texel: an entry that cancels to 1e-3 of the scale moves by 1e-4 of itself from run to run)
     # a direction within float rounding of a texel boundary picks the other cell on one side: compare away from them
     err = ((g_dirs.cpu() - dref.grad).abs() / dref.grad.abs().clamp_min(1.0)).amax(-1)
     assert float(torch.quantile(err, 0.995)) < TOL and float((err > 1e-3).float().mean()) < 0.005

@@ -38,17 +38,16 @@ def test_fused_forward_refuses_autograd():
         m.sample(torch.zeros(2, 3), torch.zeros(2, 2), torch.zeros(2, 1), 8, return_jacobian=True)   # sampling is a frozen-copy op
 
 
-REFUSED_CFG = [("shade_fn", "shade_direct"), ("flow", "realnvp"),
-               ("flow_diffuse", "realnvp"), ("flow_specular", "affine"),
+REFUSED_CFG = [("shade_fn", "shade_direct"), ("flow", "glow"),
+               ("flow_diffuse", "glow"), ("flow_specular", "affine"),
                ("geometry_type", "beckmann"), ("outer_light_version", "latlong")]
 
 
 @pytest.mark.parametrize("key,value", REFUSED_CFG)
 def test_mcshading_refuses_cfg_switches_it_does_not_build(key, value):
-    """Verdict r5 item 7: a cfg key whose non-default value selects reference code this build lacks (shade_mixed_all / use_nis_all
-    fields.py:1337-1451; one fixed and one flow sampler :1082,1160; whole-direction flows :1084-1208; ggx_smith :1029; the other
-    transforms flow.py:170-312; the ablations flow.py:726-744) raises at construction -- before any device work -- instead of
-    rendering the default path under a non-default cfg."""
+    """Verdict r5 item 7, after round 6: every switch of the reference cfg selects built code (tests/test_gpu_cfg_variants.py), so what is
+    left to refuse is a VALUE the reference itself has no branch for (fields.py:1458-1463, :1026-1033, flow.py:644-648) -- at
+    construction, before any device work, instead of rendering the default path under it."""
     from tensoflow_amd.network.fields import MCShadingNetwork
     with pytest.raises(NotImplementedError, match=key):
         MCShadingNetwork({key: value}, (None, None), AABB, 2.0 / 511)
@@ -71,8 +70,9 @@ def test_mcshading_default_cfg_is_the_reference_class_default():
 
 def test_tensoflow_refuses_other_transforms():
     from tensoflow_amd.network.flow import TensoFlow
-    # ('pwlinear' and n_bins != 10 are served by the composition since round 6: tests/test_flow_variants.py)
-    for kw in (dict(flow="realnvp"), dict(flow="affine"), dict(n_bins=1), dict(d=3)):
+    # ('pwlinear', 'realnvp' and n_bins != 10 are served by the composition since round 6: tests/test_flow_variants.py; the reference's
+    # flow_kwargs (flow.py:644-648) holds nothing else)
+    for kw in (dict(flow="glow"), dict(flow="affine"), dict(n_bins=1), dict(d=3)):
         with pytest.raises(NotImplementedError):
             TensoFlow(**{"d": 2, "aabb": AABB, "device": "cpu", "gridSize": [8, 8, 8], **kw})
 

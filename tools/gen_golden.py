@@ -220,6 +220,66 @@ def gen_flow_variants():
     save("tensoflow_variants", **arrays)
 
 
+def gen_flow_realnvp():
+    """TensoFlow(flow='realnvp') (flow.py:645: Gaussian latent prior :9-24, affine couplings :527-547 without the Reshift input
+    activation, the analytic-sigmoid output cell :123-144): the element-wise transform and the cell on random inputs with edge rows; the
+    whole module -- sample on RECORDED latent draws (the prior draws fresh normals: `realnvp/latent`), density of the samples and of
+    arbitrary points (with and without rays_id), parameter gradients of an NIS-style loss."""
+    from network.flow import ElementWiseAffineTransform, InvertibleAnalyticSigmoid, TensoFlow
+    g = torch.Generator().manual_seed(78)
+    arrays = {}
+    M = 512
+    T = ElementWiseAffineTransform()
+    st = torch.randn(M, 1, 2, generator=g) * 1.5
+    y = torch.randn(M, 1, generator=g)
+    st[:4, 0, 0] = torch.tensor([-20.0, 20.0, 0.0, -14.0])          # exp(+-s) at the 1e-6 clamp of the log-Jacobian
+    x, lj = T.flow(y, st, True)
+    o, lji = T.flow_inv(y, st, True)
+    arrays.update({"t/affine/st": st[:, 0], "t/affine/y": y[:, 0], "t/affine/sample_x": x[:, 0], "t/affine/sample_logj": lj[:, 0],
+                   "t/affine/density_out": o[:, 0], "t/affine/density_logj": lji[:, 0]})
+    C = InvertibleAnalyticSigmoid()
+    v = torch.randn(M, 2, generator=g) * 4
+    v[:4] = torch.tensor([[-30.0, 30.0], [0.0, 0.0], [-14.0, 14.0], [20.0, -20.0]])
+    u = torch.rand(M, 2, generator=g)
+    u[:4] = torch.tensor([[1e-6, 1 - 1e-6], [0.5, 0.5], [1e-3, 0.999], [1e-7, 0.25]])
+    zero = torch.zeros(M, 1)
+    cy, clj = C.flow(v, zero, None, True)
+    cz, clji = C.flow_inv(u, zero, None, True)
+    arrays.update({"t/cell/v": v, "t/cell/sample_y": cy, "t/cell/sample_logj": clj, "t/cell/u": u, "t/cell/density_z": cz, "t/cell/density_logj": clji})
+    pn = 40
+    pts = torch.rand(pn, 3, generator=g) * 1.6 - 0.8
+    va = torch.rand(pn, 2, generator=g)
+    rough = torch.rand(pn, 1, generator=g)
+    arrays.update(pts=pts, view_angles=va, roughness=rough)
+    torch.manual_seed(11)
+    net = TensoFlow(2, AABB, device="cpu", gridSize=[32, 32, 32], flow="realnvp")
+    perturb_(list(net.nis_plane) + list(net.nis_line), 0.1, 3)
+    perturb_([p for n, p in net.flows.named_parameters() if "weight" in n], 0.05, 5)
+    net.eval()
+    latent = torch.randn(pn, 32, 2, generator=g)
+    prior = net.latent_prior
+    prior.forward = lambda shape: (latent, -prior.log_prob(latent))       # the recorded draws instead of fresh ones (shape == (pn, 32))
+    with torch.no_grad():
+        ang, logj = net.sample(pts, va, rough, 32, return_jacobian=True)
+        z, logq = net(pts, va, rough, ang, return_jacobian=True)
+        x = torch.rand(pn, 16, 2, generator=g)
+        zx, lqx = net(pts, va, rough, x, return_jacobian=True)
+        rid = torch.sort(torch.randint(0, pn, (200,), generator=g)).values
+        xr = torch.rand(200, 2, generator=g)
+        zr, lqr = net(pts, va, rough, xr, return_jacobian=True, rays_id=rid)
+    w = torch.rand(pn, 16, 1, generator=g)
+    net.zero_grad()
+    _, lq = net(pts, va, rough, x, return_jacobian=True)
+    (-(w * lq).mean()).backward()
+    tag = "realnvp"
+    arrays.update({f"{tag}/latent": latent, f"{tag}/angles": ang, f"{tag}/logj": logj, f"{tag}/z": z, f"{tag}/logq": logq, f"{tag}/x_rand": x,
+                   f"{tag}/z_rand": zx, f"{tag}/logq_rand": lqx, f"{tag}/rays_id": rid, f"{tag}/x_rid": xr, f"{tag}/z_rid": zr, f"{tag}/logq_rid": lqr,
+                   f"{tag}/bwd_w": w})
+    arrays.update({f"{tag}/sd/" + k: v for k, v in net.state_dict().items()})
+    arrays.update({f"{tag}/grad/" + k: p.grad for k, p in net.named_parameters() if p.grad is not None})
+    save("tensoflow_realnvp", **arrays)
+
+
 def gen_encodings():
     from utils.network_utils import get_embedder
     from utils.ref_utils import generate_ide_fn
@@ -712,7 +772,7 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
-def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600", False, False))):
+def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600", False, False)), patch=None):
     """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad` (same seeds: only outputs -- and the
     tensors whose shape the variant changes, sdx/* -- are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
     600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
@@ -753,6 +813,8 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
             for p in fl.parameters():
                 p.requires_grad = False
         net.eval()
+        if patch is not None:
+            patch(net)
         return net
     net = make()
     with torch.no_grad():
@@ -794,6 +856,21 @@ def gen_shading_all():
     point (its copy's nis_sample_num samples, or the fixed cosine set before the copy exists); half-vector and whole-direction flows."""
     _gen_shading_variant("shading_all", dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16))
     _gen_shading_variant("shading_all_whole", dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16, use_half_all=False))
+
+
+def shading_realnvp_latent(shape):
+    """The Gaussian prior's draws of the `shading_realnvp` runs: a function of the request's shape, so that the test side can repeat them."""
+    return torch.randn(*shape, 2, generator=torch.Generator().manual_seed(1000 + int(shape[1])))
+
+
+def gen_shading_realnvp():
+    """cfg flow_diffuse = flow_specular = 'realnvp' (fields.py:653-654, :755-760 -> flow.py:645): Gaussian-prior affine flows in both lobes.
+    The prior draws fresh normals on every call: every flow's prior returns `shading_realnvp_latent(shape)` here."""
+    def patch(net):
+        for n in ("flow_diffuse", "flow_diffuse_copy", "flow_specular", "flow_specular_copy"):
+            prior = getattr(net, n).latent_prior
+            prior.forward = (lambda shape, prior=prior: (lambda x: (x, -prior.log_prob(x)))(shading_realnvp_latent(shape)))
+    _gen_shading_variant("shading_realnvp", dict(flow_diffuse="realnvp", flow_specular="realnvp"), patch=patch)
 
 
 def gen_shading_smith():
@@ -1294,7 +1371,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_all', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'flow_realnvp', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_all', 'shading_realnvp', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
