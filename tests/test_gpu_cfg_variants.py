@@ -76,10 +76,11 @@ def test_cfg_variant_eval_golden(golden, dev, variant):
     m, g = _net(golden, dev, variant)
     with torch.no_grad():
         colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
-    parity(colors.cpu(), g["eval/colors"], label=f"{variant} eval: fixed-pass colours")
-    parity(out["rgb_pr_nis"].cpu(), g["eval/rgb_pr_nis"], label=f"{variant} eval: rgb_pr_nis")
+    # sRGB colours in [0,1]: north_star's per-pixel bar is the absolute one (conftest.parity, absolute=True)
+    parity(colors.cpu(), g["eval/colors"], label=f"{variant} eval: fixed-pass colours", absolute=True)
+    parity(out["rgb_pr_nis"].cpu(), g["eval/rgb_pr_nis"], label=f"{variant} eval: rgb_pr_nis", absolute=True)
     for k in ("diffuse_color_nis", "specular_color_nis", "visibility_nis"):
-        parity(out[k].cpu(), g["eval/" + k], label=f"{variant} eval: {k}")
+        parity(out[k].cpu(), g["eval/" + k], label=f"{variant} eval: {k}", absolute=True)
 
 
 @pytest.mark.parametrize("variant,tag,copy_d,copy_s", STEP_CASES)
@@ -90,7 +91,7 @@ def test_cfg_variant_training_step_golden(golden, dev, variant, tag, copy_d, cop
     m.use_flow_diffuse_copy, m.use_flow_specular_copy = copy_d, copy_s
     m.use_flow_copy = copy_d                         # (shade_mixed_all's single copy)
     colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, 600, False)
-    parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"{variant} training step {tag}: colours")
+    parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"{variant} training step {tag}: colours", absolute=True)
     for k in (("loss_nis",) if f"{tag}/loss_nis" in g.a else ("loss_nis_diffuse", "loss_nis_specular")):
         ref = float(g[f"{tag}/{k}"])
         assert abs(float(out[k].detach()) - ref) < 1e-4 * max(1, abs(ref)), (k, float(out[k].detach()), ref)
