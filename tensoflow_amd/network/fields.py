@@ -219,6 +219,7 @@ class MCShadingNetwork(nn.Module):
     #   use_nis_diffuse / use_nis_specular = False, one copy active (:1081)     forward_train_fixed(flow_lobes=)        shading_nonis_*, shading_mixed
     #   shade_fn = 'shade_mixed_all' (+ use_nis_all, :1337-1451)                forward_all                             shading_all*
     #   flow* = 'realnvp' (flow.py:645)                                         TensoFlow's composed transforms         tensoflow_realnvp, shading_realnvp
+    #   human_lights with outer_light_version = 'envlight' (:929-930, :962-968) the composed passes                     shading_envhuman
     # An unknown flow / shade_fn / geometry_type / outer_light_version raises at construction (as the reference does when it gets there).
 
     def __init__(self, cfg, ray_tracer, aabb, unit_size):
@@ -233,8 +234,6 @@ class MCShadingNetwork(nn.Module):
                 raise NotImplementedError(f"MCShadingNetwork cfg {key}={self.cfg[key]!r}: 'pwquad', 'pwlinear' or 'realnvp'")
         if self.cfg["geometry_type"] not in ("schlick", "ggx_smith"):      # fields.py:1026-1033: anything else raises there too
             raise NotImplementedError(f"geometry_type {self.cfg['geometry_type']!r}: 'schlick' or 'ggx_smith'")
-        if self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight":
-            raise NotImplementedError("human_lights with the cube-map outer light (no shipped config combines them)")
         self.aabb, self.unit_size, self.ray_tracer = aabb, float(unit_size), ray_tracer
         R, C = self.cfg["mat_grid"], 36
         self.mat_plane = nn.ParameterList([nn.Parameter(1e-4 * (2 * torch.rand(1, C, R, R) - 1)) for _ in range(3)]).cuda()
@@ -361,7 +360,8 @@ class MCShadingNetwork(nn.Module):
     def _miss_lights(self, origins, dirs, poses):
         """Outer light of the rays that missed, blended with the capturer's reflection when human_lights is on (fields.py:962-968)
         -> (lights [n,3], human_lights * human_weights [n,3] or None)."""
-        outer = self._outer_mlp(dirs, origins)
+        # (the cube map with human lights, fields.py:929-930 + :962-968 -- no shipped config combines them: composed passes only)
+        outer = self.outer_light.direct_light(dirs) if self.cfg["outer_light_version"] == "envlight" else self._outer_mlp(dirs, origins)
         if not self.cfg["human_lights"]:
             return outer, None
         R, t = poses[:, :, :3], poses[:, :, 3]
@@ -419,7 +419,7 @@ class MCShadingNetwork(nn.Module):
         miss = ~hit
         hl = None
         if bool(miss.any()):
-            if self.cfg["outer_light_version"] == "envlight":
+            if self.cfg["outer_light_version"] == "envlight" and not self.cfg["human_lights"]:
                 outer = self.outer_light.direct_light(dirs[miss])
             else:
                 outer, hl = self._miss_lights(origins[miss], dirs[miss], poses[miss] if poses is not None else None)
@@ -834,7 +834,8 @@ class MCShadingNetwork(nn.Module):
         """fields.py:1467-1473 with step=None: the fixed-sampler pass gives `colors` and the un-suffixed outputs, the flow-sampler
         pass the `*_nis` outputs (`rgb_pr_nis` = its colours)."""
         from ..shading import LazyOutputs, aux_outputs
-        if not (self._fused_flows and self.cfg["use_nis_diffuse"] and self.cfg["use_nis_specular"]):
+        env_human = self.cfg["human_lights"] and self.cfg["outer_light_version"] == "envlight"       # (MCShader holds the net outer lights with humans)
+        if env_human or not (self._fused_flows and self.cfg["use_nis_diffuse"] and self.cfg["use_nis_specular"]):
             return self._forward_eval_composed(pts, view_dirs, normals, human_poses)
         sh = self.shader()
         nrm = (F.normalize(normals, dim=-1) + 1) / 2

@@ -19,7 +19,9 @@
   one direction set per point (the copy's samples, or the fixed cosine set before the copy exists), half-vector / whole-direction flow;
 * `shading_realnvp`: `flow_diffuse = flow_specular = 'realnvp'` (flow.py:645): Gaussian-prior affine flows with the sigmoid output cell.
   The prior draws fresh normals per call: both sides take them from `tools/gen_golden.py:shading_realnvp_latent` (a function of the
-  request's shape, restated below)."""
+  request's shape, restated below);
+* `shading_envhuman`: `human_lights = True` with the cube-map outer light (:727-729, :929-930, :962-968; no shipped config combines
+  them): the capturer's net and the per-point poses of `shading_custom.npz`; composed passes only."""
 import pytest
 import torch
 
@@ -42,7 +44,8 @@ VARIANTS = {"shading_whole": dict(use_half_diffuse=False, use_half_specular=Fals
             "shading_nonis_d": dict(use_nis_diffuse=False), "shading_nonis_s": dict(use_nis_specular=False), "shading_mixed": dict(),
             "shading_all": dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16),
             "shading_all_whole": dict(shade_fn="shade_mixed_all", use_nis_all=True, nis_sample_num=16, use_half_all=False),
-            "shading_realnvp": dict(flow_diffuse="realnvp", flow_specular="realnvp")}
+            "shading_realnvp": dict(flow_diffuse="realnvp", flow_specular="realnvp"),
+            "shading_envhuman": dict(human_lights=True)}
 # (tag, use_flow_diffuse_copy, use_flow_specular_copy) of the training-step runs a golden holds (update_step's state, fields.py:1050-1065)
 RUNS = {"shading_mixed": (("copy_d600", True, False), ("copy_s600", False, True))}
 DEFAULT_RUNS = (("flow600", True, True), ("fixed600", False, False))
@@ -58,6 +61,8 @@ def _net(golden, dev, variant):
     m = MCShadingNetwork(cfg, (g["verts"].numpy(), g["faces"].numpy()), AABB, float(g["unit_size"]))
     sd = dict(base.sd)
     sd.update({k[4:]: v for k, v in g.a.items() if k.startswith("sdx/")})          # tensors whose shape the variant changes
+    if variant == "shading_envhuman":
+        sd.update({k: v for k, v in golden("shading_custom").sd.items() if k.startswith("human_light.")})
     missing, _ = m.load_state_dict(sd, strict=False)
     assert not missing
     for fl in m.flow_copies():
@@ -70,12 +75,16 @@ def _net(golden, dev, variant):
     return m, g
 
 
+def _poses(golden, dev, variant):
+    return golden("shading_custom")["human_poses"].to(dev) if variant == "shading_envhuman" else None
+
+
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_cfg_variant_eval_golden(golden, dev, variant):
     """Fused inference path (MCShader.shade): the flow pass' colours and light maps; the fixed pass does not depend on the flags."""
     m, g = _net(golden, dev, variant)
     with torch.no_grad():
-        colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, None, False)
+        colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), _poses(golden, dev, variant), None, False)
     # sRGB colours in [0,1]: north_star's per-pixel bar is the absolute one (conftest.parity, absolute=True)
     parity(colors.cpu(), g["eval/colors"], label=f"{variant} eval: fixed-pass colours", absolute=True)
     parity(out["rgb_pr_nis"].cpu(), g["eval/rgb_pr_nis"], label=f"{variant} eval: rgb_pr_nis", absolute=True)
@@ -90,7 +99,7 @@ def test_cfg_variant_training_step_golden(golden, dev, variant, tag, copy_d, cop
     m, g = _net(golden, dev, variant)
     m.use_flow_diffuse_copy, m.use_flow_specular_copy = copy_d, copy_s
     m.use_flow_copy = copy_d                         # (shade_mixed_all's single copy)
-    colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), None, 600, False)
+    colors, out = m(g["pts"].to(dev), g["view_in"].to(dev), g["normals_in"].to(dev), _poses(golden, dev, variant), 600, False)
     parity(colors.detach().cpu(), g[f"{tag}/colors"], label=f"{variant} training step {tag}: colours", absolute=True)
     for k in (("loss_nis",) if f"{tag}/loss_nis" in g.a else ("loss_nis_diffuse", "loss_nis_specular")):
         ref = float(g[f"{tag}/{k}"])
@@ -111,6 +120,11 @@ def test_cfg_variant_training_step_golden(golden, dev, variant, tag, copy_d, cop
                 # fixed samples on spline knots (same note as the half-vector fixed-pass test); shade_mixed_all's single flow (`flow.`) is
                 # fitted on 16 flow samples / 32 fixed samples per point: measured l2 3e-4 (flow samples) ... 9e-3 (fixed lattice)
                 ok = l2 < 1.5e-2 and err < 3e-2
+            elif variant == "shading_envhuman" and ("human_light" in name or "roughness_predictor" in name):
+                # the capturer's disc is a step in the direction (hits = |mean| < 1.5 and dist > 0, fields.py:938-940): the fixed specular
+                # directions move with the roughness, one of 640 rays on the other side of the step is 1e-2 of the roughness head's
+                # gradient (measured 8.3e-3 on its scalar weight-norm magnitude); the human-lights test of test_gpu_march makes the same allowance
+                ok = l2 < 2e-2 and err < 6e-2
             else:
                 ok = err < 1e-3 and l2 < 1e-3
             if not ok:

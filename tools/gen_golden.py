@@ -772,7 +772,7 @@ def gen_shading_grad():
          verts=verts, faces=faces, unit_size=np.float32(unit), sn=np.array([32, 16, 16, 8], np.int32), **grads)
 
 
-def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600", False, False)), patch=None):
+def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600", False, False)), patch=None, poses=None, more_sd=None):
     """A non-default cfg of MCShadingNetwork (`over`) on the network, mesh and points of `shading_grad` (same seeds: only outputs -- and the
     tensors whose shape the variant changes, sdx/* -- are stored): the eval forward (step None: fixed pass + flow pass), the training step with the flow copies sampling (step
     600) and the training step before the copies exist (step 600, NIS losses fitted on the fixed samples' own direction angles)."""
@@ -786,9 +786,9 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
     unit = float((2.0 / (R - 1)))
     trace = lambda o, d: MaterialRenderer.trace(host, (o + 2 * unit * d).detach(), d.detach())
     base = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "shading_grad.npz")).items() if k.startswith("sd/")}
-    cfg = dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
-               gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
-               nis_specular_sample_num=8, **over)
+    cfg = {**dict(outer_light_version="envlight", light_exp_max=5.0, inner_light_exp_max=5.0, human_lights=False,
+                  gridSize=[R, R, R], light_reso=16, diffuse_sample_num=32, specular_sample_num=16, nis_diffuse_sample_num=16,
+                  nis_specular_sample_num=8), **over}
     pn = 40
     pts, nrm, view = [torch.from_numpy(a) for a in sphere_surface_points(pn, seed=8)]
     g = torch.Generator().manual_seed(9)
@@ -803,11 +803,12 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
         net.mat_plane = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, R)) for _ in range(3)])
         net.mat_line = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1, 36, R, 1)) for _ in range(3)])
         own = net.state_dict()
-        fit = {k: v for k, v in base.items() if k in own and own[k].shape == v.shape}        # (a lobe without its flow holds no flow tensors)
+        fit = {k: v for k, v in {**base, **(more_sd or {})}.items() if k in own and own[k].shape == v.shape}     # (a lobe without its flow holds no flow tensors)
         missing, unexpected = net.load_state_dict(fit, strict=False)
         # tensors whose SHAPE the variant changes (another transform's coupling nets) or that it adds (shade_mixed_all's single flow) keep
         # the seeded initialisation: stored with the golden
         assert set(missing) >= {k for k in base if k in own and own[k].shape != base[k].shape}, missing
+        missing = [k for k in missing if k not in (more_sd or {})]
         extra.update({k: own[k].detach().clone() for k in missing})
         for fl in [getattr(net, n) for n in ("flow_copy", "flow_diffuse_copy", "flow_specular_copy") if hasattr(net, n)]:
             for p in fl.parameters():
@@ -818,7 +819,7 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
         return net
     net = make()
     with torch.no_grad():
-        colors, outputs = net(pts, view, nrm, None, None, False)
+        colors, outputs = net(pts, view, nrm, poses, None, False)
     arrays.update({"eval/colors": colors, "eval/rgb_pr_nis": outputs["rgb_pr_nis"], "eval/diffuse_color_nis": outputs["diffuse_color_nis"],
                    "eval/specular_color_nis": outputs["specular_color_nis"], "eval/visibility_nis": outputs["visibility_nis"]})
     for tag, copy_d, copy_s in runs:                 # (tag, use_flow_diffuse_copy, use_flow_specular_copy: update_step's state, :1050-1065)
@@ -826,7 +827,7 @@ def _gen_shading_variant(name, over, runs=(("flow600", True, True), ("fixed600",
         net.use_flow_diffuse_copy, net.use_flow_specular_copy = copy_d, copy_s
         net.use_flow_copy = copy_d                    # (shade_mixed_all's single copy)
         net.zero_grad()
-        colors, outputs = net(pts, view, nrm, None, 600, False)
+        colors, outputs = net(pts, view, nrm, poses, 600, False)
         ((colors * w).sum() + outputs["loss_nis"]).backward()
         arrays.update({f"{tag}/colors": colors, f"{tag}/loss_nis": outputs["loss_nis"]} if "loss_nis_diffuse" not in outputs else
                       {f"{tag}/colors": colors, f"{tag}/loss_nis_diffuse": outputs["loss_nis_diffuse"],
@@ -871,6 +872,15 @@ def gen_shading_realnvp():
             prior = getattr(net, n).latent_prior
             prior.forward = (lambda shape, prior=prior: (lambda x: (x, -prior.log_prob(x)))(shading_realnvp_latent(shape)))
     _gen_shading_variant("shading_realnvp", dict(flow_diffuse="realnvp", flow_specular="realnvp"), patch=patch)
+
+
+def gen_shading_envhuman():
+    """cfg human_lights = True with the cube-map outer light (fields.py:727-729 + 'envlight' :929-930; blended at :962-968) -- a combination
+    no shipped config uses: the capturer's net and the per-point poses of `shading_custom` on the network of `shading_grad`."""
+    c = np.load(os.path.join(OUT, "shading_custom.npz"))
+    human = {k[3:]: torch.from_numpy(c[k]) for k in c.files if k.startswith("sd/human_light.")}
+    assert human, "shading_custom.npz holds the trained human_light net"
+    _gen_shading_variant("shading_envhuman", dict(human_lights=True), poses=torch.from_numpy(c["human_poses"]), more_sd=human)
 
 
 def gen_shading_smith():
@@ -1371,7 +1381,7 @@ def gen_alpha_mask():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'flow_realnvp', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_all', 'shading_realnvp', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
+    which = sys.argv[1:] or ['tensosdf', 'tensosdf_multires', 'pwquad', 'flow', 'flow_variants', 'flow_realnvp', 'encodings', 'shading', 'shading_wide', 'march', 'march_eval', 'march_late', 'refine', 'material_nvs', 'shading_grad', 'shading_whole', 'shading_ablate', 'shading_smith', 'shading_pwlinear', 'shading_nonis', 'shading_all', 'shading_realnvp', 'shading_envhuman', 'shading_grad_fixed', 'shading_direction', 'shading_custom', 'march_grad', 'trainer', 'alpha_mask', 'shape_variants']      # every generator, in dependency order
     with ref_shim.reference():
         for w in which:
             globals()["gen_" + w]()
