@@ -920,16 +920,20 @@ class _Exp(nn.Module):
 
 
 class SingleVarianceNetwork(nn.Module):
-    """other_field.py:193-207 with activation='exp': inv_s = exp(10 * variance), one scalar parameter."""
+    """other_field.py:193-207: one scalar parameter; inv_s = exp(10 v) (cfg std_act = 'exp', every shipped config), 10 v ('linear') or
+    (10 v)^2 ('square')."""
 
     def __init__(self, init_val, activation="exp"):
         super().__init__()
-        if activation != "exp":
-            raise NotImplementedError("std_act='exp' (configs/shape/*: default)")
+        if activation not in ("exp", "linear", "square"):
+            raise NotImplementedError(f"std_act {activation!r}: 'exp', 'linear' or 'square' (other_field.py:200-207)")
+        self.act = activation
         self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
 
     def inv_s(self):
-        return torch.exp(self.variance * 10.0)
+        if self.act == "exp":
+            return torch.exp(self.variance * 10.0)
+        return self.variance * 10.0 if self.act == "linear" else (self.variance * 10.0) ** 2
 
     def forward(self, x):
         return torch.ones([*x.shape[:-1], 1], device=x.device) * self.inv_s()

@@ -118,3 +118,18 @@ def test_linear_to_srgb_host_form_and_inv_s_cache():
     with torch.no_grad():
         r.deviation_network.variance.add_(0.1)           # an optimizer step bumps the version counter
     assert abs(r._inv_s_host() - float(torch.exp(torch.tensor(4.0)))) < 1e-3
+
+
+def test_single_variance_network_activations():
+    """other_field.py:193-207: cfg std_act = 'exp' | 'linear' | 'square' (ShapeRenderer / MaterialRenderer cfg, shapeRenderer.py:104,220);
+    anything else raises there as here."""
+    from tensoflow_amd.network.fields import SingleVarianceNetwork
+    x = torch.zeros(5, 3)
+    for act, want in (("exp", float(torch.exp(torch.tensor(3.0)))), ("linear", 3.0), ("square", 9.0)):
+        m = SingleVarianceNetwork(0.3, act)
+        out = m(x)
+        assert out.shape == (5, 1) and abs(float(out[0, 0]) - want) < 1e-5 * want, act
+        out.sum().backward()                        # the scalar is an ordinary autograd node for every activation
+        assert m.variance.grad is not None and float(m.variance.grad) != 0.0
+    with pytest.raises(NotImplementedError):
+        SingleVarianceNetwork(0.3, "softplus")
