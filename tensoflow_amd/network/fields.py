@@ -206,6 +206,7 @@ class MCShadingNetwork(nn.Module):
                    "nis_start_iter_diffuse": 1000, "nis_start_iter_specular": 1000, "nis_update_interval_diffuse": 1000,
                    "nis_update_interval_specular": 1000, "nis_loss_iter_diffuse": 500, "nis_loss_iter_specular": 500,
                    "nis_sample_num": 64, "nis_start_iter": 1000, "nis_loss_iter": 500, "nis_update_interval": 1000,
+                   "light_upsample_interval": 1000,
                    "geometry_type": "schlick", "random_azimuth": True, "shade_fn": "shade_mixed", "use_nis_all": False,
                    "use_nis_diffuse": True, "use_nis_specular": True, "flow": "pwquad", "flow_diffuse": "pwquad", "flow_specular": "pwquad",
                    "use_half_all": True, "use_half_diffuse": True, "use_half_specular": True, "disable_tensorial": False,
@@ -323,6 +324,11 @@ class MCShadingNetwork(nn.Module):
                     p.requires_grad = False
                 setattr(self, f"use_flow{sfx}_copy", True)        # load_state_dict bumped the copies' parameter versions: shader() re-packs
                 done.append(name)
+        # fields.py:1067-1068: the cube map's `level` bookkeeping (EnvLight.upsample; no lookup reads it -- kept for state fidelity.  The
+        # reference calls it on the net of 'direction' / 'sphere_direction' too, where it does not exist)
+        every = self.cfg.get("light_upsample_interval", 1000)
+        if self.cfg["outer_light_version"] == "envlight" and every and (step + 1) % every == 0:
+            self.outer_light.upsample()
         return done
 
     def TV_loss(self):
