@@ -42,7 +42,7 @@ class AlphaGridMask(nn.Module):
 
 class ShapeRenderer(nn.Module):
     default_cfg = {
-        "std_act": "exp", "inv_s_init": 0.3, "freeze_inv_s_step": None, "shader_config": {},
+        "std_act": "exp", "inv_s_init": 0.3, "freeze_inv_s_step": None, "val_geometry": False, "shader_config": {},
         "n_samples": 64, "n_importance": 64, "up_sample_steps": 4, "perturb": 1.0, "anneal_end": 50000,
         "train_ray_num": 1024, "test_ray_num": 2048, "clip_sample_variance": True,
         "apply_occ_loss": True, "apply_tv_loss": True, "apply_sparse_loss": True, "apply_hessian_loss": True,
@@ -531,8 +531,8 @@ class ShapeRenderer(nn.Module):
 
     def forward(self, data):
         """shapeRenderer.py:1279-1310: a training iteration (`data['step']`) or one validation image (`data['eval']`, `data['index']`).
-        Needs the dataset side (training=True).  The validation-time marching-cubes dump (`val_geometry`) is
-        tensoflow_amd.mesh.extract_mesh, called by whoever wants the file."""
+        Needs the dataset side (training=True).  cfg val_geometry (:1298-1302): the first validation image also carries the 512^3
+        marching-cubes surface of the SDF (`vertices`, `triangles`: tensoflow_amd.mesh.extract_mesh)."""
         if not hasattr(self, "train_table"):
             raise NotImplementedError("ShapeRenderer.forward drives the dataset tables: construct with training=True on a TensoSDF "
                                       "synthetic scene, or call render() with a ray batch / nvs(pose, K, h, w)")
@@ -541,4 +541,8 @@ class ShapeRenderer(nn.Module):
             self.update_occ_grid(step)
             self.color_network.envlight.build_mips()
             return self.train_step(step)
-        return self.test_step(data["index"], step=step)
+        outputs = self.test_step(data["index"], step=step)
+        if data["index"] == 0 and self.cfg.get("val_geometry", False):
+            from ..mesh import extract_mesh
+            outputs["vertices"], outputs["triangles"] = extract_mesh(self, 512)
+        return outputs
