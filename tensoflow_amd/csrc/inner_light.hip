@@ -212,7 +212,12 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
     for (int p = 0; p < XP; ++p) bq[0][r][p] = actl[((0 * RT + r) * XP + p) * 64];
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
+#ifdef IL3_ABLATE_WSTREAM   // dev-only timing ablation (results are garbage): the weight fragments of a layer are NOT streamed from L2 -- the ring keeps
+    // what the prefetch of its first k-steps brought.  What the L2 -> CU weight stream costs the kernel in time (latency AND power).
+    if (false) {
+#else
     if (s + PF < K16) {
+#endif
       il3_gw_t b = il3_kstep_base(Wl, T0, s + PF);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
