@@ -17,6 +17,10 @@ precs = [int(a, 0) for a in sys.argv[2:]] or [1, 3, 2]
 sd = random_mc_state(seed=4, R=32, flow_R=32, env_res=16)
 sdd = {k: v.to(dev).float() for k, v in sd.items() if v.is_floating_point() and "inner_light" in k}
 W = [(wn_weight(sdd, f"inner_light.{i}").contiguous(), sdd[f"inner_light.{i}.bias"].contiguous()) for i in (0, 2, 4, 6)]
+if os.environ.get("IL_PERIODIC_W"):       # dev: weights periodic in the input index (period 48 = three k-steps): the operand stream the
+    # -DIL3_ABLATE_WSTREAM=1 build feeds its MFMAs, but fetched in full from L2 -- separates the weight stream's cost from the lower
+    # toggle rate of repeated operands
+    W = [(w[:, torch.arange(w.shape[1], device=dev) % 48].contiguous(), b) for w, b in W]
 g = torch.Generator(device=dev).manual_seed(1)
 pos = (torch.rand(n, 3, device=dev, generator=g) * 2 - 1) * 0.8
 dirs = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1)
