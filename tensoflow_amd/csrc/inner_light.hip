@@ -213,17 +213,8 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
 #ifdef IL3_ABLATE_WSTREAM   // dev-only timing ablation (results are garbage): the weight fragments of a layer are NOT streamed from L2 -- the ring keeps
-    // what the prefetch of its first k-steps brought.  What the L2 -> CU weight stream costs the kernel in time (latency AND power).
-#if IL3_ABLATE_WSTREAM == 2    // ... 2: the stream IS fetched (same fabric traffic) but not used -- separates the stream's cost from the lower toggle
-    // rate of the repeated operands
-    if (s + PF < K16) {
-      il3_gw_t bq_ = il3_kstep_base(Wl, T0, s + PF);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) { tf_h8 sink = bq_[lane + t * 128 + p * 64]; asm volatile("" :: "v"(sink)); }
-    }
-#endif
+    // what the prefetch of its first k-steps brought.  Measured (round 6): 15.6 ms against 21.5 at the SAME cycles per pass -- 2.13 GHz
+    // instead of 1.57: the stream costs power, not latency (control: tools/exp_il3.py IL_PERIODIC_W=1).
     if (false) {
 #else
     if (s + PF < K16) {
