@@ -182,6 +182,9 @@ typedef const __attribute__((address_space(1))) tf_h8* il3_gw_t;
 // the (unit tile, plane) sub-block in the instruction's immediate offset (0 / 1 / 2 / 3 KB).  Written as one index expression
 // wp[(s * 8 + t) * 128 + p * 64 + lane] every load of every k-step got its own loop-invariant offset register (96 of the 256).
 __device__ __forceinline__ il3_gw_t il3_kstep_base(il3_gw_t Wl, int T0, int s) {
+#if defined(IL3_ABLATE_WSTREAM) && IL3_ABLATE_WSTREAM == 3   // dev-only (garbage results): every load of every wave reads the SAME 4 KB -- the loads,
+  T0 = 0; s = 0;                                              // the L1 look-ups and the register writes stay, the L2 / fabric traffic goes
+#endif
   il3_gw_t b = Wl + T0 * 128 + s * 1024;           // k-step stride: 8 unit tiles x (hi | lo) x 64 lanes = 1024 fragments of 16 bytes
   asm volatile("" : "+s"(b));
   return b;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void il3_layer(il3_gw_t Wl /* wave-uniform */, int T0
     for (int p = 0; p < XP; ++p) bq[0][r][p] = actl[((0 * RT + r) * XP + p) * 64];
 #pragma unroll
   for (int s = 0; s < K16; ++s) {
-#ifdef IL3_ABLATE_WSTREAM   // dev-only timing ablation (results are garbage): the weight fragments of a layer are NOT streamed from L2 -- the ring keeps
+#if defined(IL3_ABLATE_WSTREAM) && IL3_ABLATE_WSTREAM != 3   // dev-only timing ablation (results are garbage): the weight fragments of a layer are NOT streamed from L2 -- the ring keeps
     // what the prefetch of its first k-steps brought.  Measured (round 6): 15.6 ms against 21.5 at the SAME cycles per pass -- 2.13 GHz
     // instead of 1.57: the stream costs power, not latency (control: tools/exp_il3.py IL_PERIODIC_W=1).
     if (false) {
